@@ -1,0 +1,165 @@
+/*
+ * raft_hip.h -- C ABI of the MI355X (gfx950) engine for RAFT's hot path:
+ *
+ *   PAF overlap records -> per-read interval buckets -> binned coverage pileup
+ *   -> high-coverage repeat runs -> cut points -> fragment table
+ *
+ * The reference (at-cg/RAFT @ 2024_10_08) has no FFI; the in-process seam this
+ * library replaces is the three calls in break_long_reads():
+ *
+ *   create_pileup(paf, reads, idx_pileup, umap, param)   chop.hpp:366  (-> :133-191)
+ *   repeat_annotate(reads, idx_pileup, param)            chop.hpp:370  (-> repeat.hpp:81-204,
+ *                                                                         profileCoverage :28-79)
+ *   break_reads(param, n_read, reads, reads_final)       chop.hpp:372  (-> :193-324, integer half)
+ *
+ * i.e. everything between "a PAF record has been tokenised into 2 resolved read
+ * ids + 4 coordinates" (chop.hpp:157-163) and "a read's final_stars / fragment
+ * bounds exist" (chop.hpp:242-321).  Text parsing and text/FASTA emission stay on
+ * the host (raft_amd/host/, the `raft` CLI).
+ *
+ * Conventions: plain pointers and sizes only; every entry point returns an
+ * RAFT_HIP_* code and never throws or exits; one context per host thread, one
+ * HIP stream per context.  The caller owns all inputs; the context owns all
+ * outputs until the next run or raft_hip_destroy().  Inputs on which the
+ * reference has undefined behaviour are rejected with a defined error instead
+ * (SURVEY.md §5.3): unknown read id, interval reaching past the last bin,
+ * read_length < interval_length, fragment start before 0.
+ */
+#ifndef RAFT_HIP_H
+#define RAFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAFT_HIP_ABI_VERSION 1
+
+/* error codes (0..5 are shared with oracle/raft_oracle.h) */
+enum {
+    RAFT_HIP_OK = 0,
+    RAFT_HIP_ERR_PARAM = 1,    /* reso/interval_length/repeat_length/est_cov <= 0, read_length/interval_length == 0, negative read length */
+    RAFT_HIP_ERR_READ_ID = 2,  /* a record names a read id outside [0, n_reads)            (chop.hpp:165 OOB)       */
+    RAFT_HIP_ERR_COORD = 3,    /* negative coordinate or interval reaching a bin >= ceil(len/reso) (repeat.hpp:69-72 OOB) */
+    RAFT_HIP_ERR_FRAGMENT = 4, /* a fragment would start before base 0 (F[pos] - overlap_length < 0, chop.hpp:318 throws) */
+    RAFT_HIP_ERR_NOMEM = 5,    /* host or device allocation failed */
+    RAFT_HIP_ERR_DEVICE = 6,   /* no usable gfx950 device / HIP runtime error (see raft_hip_last_error) */
+    RAFT_HIP_ERR_STATE = 7,    /* call order violated (e.g. fetch before run) */
+    RAFT_HIP_ERR_TOO_LARGE = 8 /* more than 2^31-1 reads, or a per-read quantity overflowing int32 */
+};
+
+/* algoParams (param.hpp:4-31): the scalars the path reads.  symmetric_mode:
+ * -1 = detect as the reference does (first later record that mirrors record 0,
+ * chop.hpp:175-184); 0 / 1 = caller asserts the final value of
+ * algoParams::symmetric_overlaps and the detection pass is skipped. */
+typedef struct raft_hip_params {
+    int32_t reso;            /* -r  (param.hpp:20, default 50)    */
+    int32_t est_cov;         /* -e  (mandatory > 0, main.cpp:65)  */
+    double  cov_mul;         /* -m  (default 1.5); high_cov = (int)(est_cov*cov_mul), repeat.hpp:89-90 */
+    int32_t repeat_length;   /* -p  (default 10000)               */
+    int32_t interval_length; /* -p  (default 10000)               */
+    int32_t read_length;     /* -l  (default 20000)               */
+    int32_t overlap_length;  /* -v  (default 500)                 */
+    int32_t flanking_length; /* -f  (default 1000)                */
+    int32_t symmetric_mode;  /* -1 auto | 0 | 1                   */
+} raft_hip_params;
+
+/* Scalars of one finished run (host values). */
+typedef struct raft_hip_summary {
+    int32_t n_reads;
+    int32_t symmetric;          /* resolved algoParams::symmetric_overlaps (chop.hpp:189) */
+    int32_t high_cov;           /* repeat.hpp:90-91 */
+    int32_t interval_path;      /* 0 = sorted-segment fast path (records already grouped by ascending query id in
+                                   <= 8 runs, query side only); 1 = counting-sort bucketing path */
+    int32_t n_segments;         /* sorted runs found in the record stream (fast path) */
+    int64_t n_records;          /* PAF records consumed ("length of alignments", chop.hpp:190) */
+    int64_t n_intervals;        /* intervals piled up (query sides + target sides when not symmetric) */
+    int64_t n_bins;             /* sum of ceil(len/reso) */
+    int64_t n_repeats, n_cuts, n_fragments;
+    int64_t total_coverage;     /* repeat.hpp:93,116 */
+    int64_t total_windows;      /* repeat.hpp:95,117 (int in the reference; int64 here) */
+    int64_t total_repeat_length;/* repeat.hpp:96,127,152 */
+    int64_t total_read_length;  /* repeat.hpp:97,101 */
+    int64_t error_index;        /* record or read index that raised the returned error, -1 if none */
+} raft_hip_summary;
+
+/* Device-resident outputs of the last run (valid until the next run/destroy).
+ * Layout is CSR per read, FASTA-index order (= reference output order):
+ *   cov[cov_offset[i] + j]  = coverage of window j of read i   (repeat.hpp:105-108: "pos,cov" with pos = j*reso)
+ *   rep_s/rep_e[rep_offset[i] ..]  = Read::long_repeats of read i (repeat.hpp:142,167)
+ *   cuts[cut_offset[i] ..]         = final_stars of read i        (chop.hpp:225-246)
+ *   frag_*[frag_offset[i] ..]      = fragments of read i; read_num = row index + 1 (chop.hpp:195,266,319);
+ *                                    sequence = bases[frag_begin, frag_end)          (chop.hpp:265,318) */
+typedef struct raft_hip_outputs {
+    const int64_t *cov_offset;  /* [n_reads+1] */
+    const int32_t *cov;         /* [n_bins]    */
+    const int64_t *rep_offset;  /* [n_reads+1] */
+    const int32_t *rep_s, *rep_e;
+    const int64_t *cut_offset;  /* [n_reads+1] */
+    const int32_t *cuts;
+    const int64_t *frag_offset; /* [n_reads+1] */
+    const int32_t *frag_read, *frag_begin, *frag_end;
+} raft_hip_outputs;
+
+typedef struct raft_hip_ctx raft_hip_ctx;
+
+int         raft_hip_abi_version(void);
+const char *raft_hip_strerror(int code);
+/* Text of the last HIP runtime failure seen by this context ("" if none). */
+const char *raft_hip_last_error(const raft_hip_ctx *ctx);
+
+/* Binds a context to HIP device `device_id` (must be gfx950) and validates params. */
+int  raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx **out);
+void raft_hip_destroy(raft_hip_ctx *ctx);
+int  raft_hip_set_params(raft_hip_ctx *ctx, const raft_hip_params *params);
+
+/* Use `stream` (a hipStream_t) for all work of this context instead of the
+ * context's own stream; NULL restores the own stream. */
+int  raft_hip_set_stream(raft_hip_ctx *ctx, void *stream);
+void *raft_hip_get_stream(raft_hip_ctx *ctx);
+
+/* One pass of the hot path over inputs that already live in device memory
+ * (int32 SoA columns, 4-byte aligned; read ids are FASTA indices).  Enqueues
+ * every kernel; returns after the last launch, not after completion.  It waits
+ * for the device twice on the way (sizes of the coverage array, choice of
+ * interval path), which is part of the cost of a pass. */
+int  raft_hip_run_device(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *d_read_len,
+                         int64_t n_rec, const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
+                         const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te);
+
+/* Same pass from host memory: stages the seven columns to the device first. */
+int  raft_hip_run_host(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_len,
+                       int64_t n_rec, const int32_t *qid, const int32_t *qs, const int32_t *qe,
+                       const int32_t *tid, const int32_t *ts, const int32_t *te);
+
+/* Waits for the pass, reads back its scalars and reports data errors found on
+ * the device (RAFT_HIP_ERR_READ_ID / _COORD / _FRAGMENT). */
+int  raft_hip_finish(raft_hip_ctx *ctx, raft_hip_summary *summary);
+
+/* Device pointers of the finished pass. */
+int  raft_hip_outputs_device(raft_hip_ctx *ctx, raft_hip_outputs *out);
+
+/* Copies outputs of the finished pass to caller-provided host arrays sized from
+ * the summary (any pointer may be NULL to skip that array). */
+int  raft_hip_fetch(raft_hip_ctx *ctx, int64_t *cov_offset, int32_t *cov,
+                    int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
+                    int64_t *cut_offset, int32_t *cuts,
+                    int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end);
+
+/* Device seconds spent in the dominant kernel (coverage pileup + run scan) and
+ * in all kernels of the last finished pass, from HIP events recorded on the
+ * context's stream around them. */
+int  raft_hip_last_timing(raft_hip_ctx *ctx, double *pileup_seconds, double *pass_seconds);
+
+/* Tuning knobs (optional): tile quantum in bins for the pileup kernel's
+ * read->workgroup map; 0 keeps the default. */
+int  raft_hip_set_tuning(raft_hip_ctx *ctx, int32_t tile_bins, int32_t force_bucket_path);
+
+/* On-device self test of the wavefront primitives (scan, ballots); 0 = pass. */
+int  raft_hip_selftest(int device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,179 @@
+// bucket.hpp -- everything that turns the PAF record stream into per-read
+// interval ranges for the pileup kernel.
+//
+// Reference: create_pileup (chop.hpp:133-191) heap-allocates one Overlap per
+// record and pushes its pointer into the query's bucket and, while the symmetric
+// flag is 0 and query != target, into the target's bucket; profileCoverage
+// (repeat.hpp:48-58) then keeps the query side of every record of a read, and the
+// target side only when the FINAL flag is 0.  Equivalent multiset of intervals:
+//     symmetric == 1 : { (qid, qs, qe) }                         I = n_rec
+//     symmetric == 0 : { (qid, qs, qe) } + { (tid, ts, te) : qid != tid }
+//
+// Two ways to hand those to the pileup kernel:
+//   * sorted-segment fast path: hifiasm writes its PAF grouped by ascending query
+//     index and the workflow concatenates two such files (README.md:36-38), so the
+//     record stream is a handful of sorted runs.  In symmetric mode the original
+//     columns (qid,qs,qe) ARE the bucketed intervals: only the per-tile start
+//     positions are needed (one binary search per tile and run).  No copy.
+//   * bucketing path: counting sort by read id -- histogram, exclusive scan,
+//     scatter -- with per-wave run aggregation so that grouped input costs one
+//     atomic per run, not per record.
+#pragma once
+#include "pileup.hpp"
+
+namespace raft {
+
+struct InspectOut {            // device words written by inspect_kernel
+    int32_t sym_found;         // a record i >= 1 mirrors record 0 (chop.hpp:175-184)
+    int32_t n_desc;            // positions i with qid[i] < qid[i-1]
+    int32_t err_flags;
+    int32_t pad;
+    long long err_index;
+    long long desc_pos[kMaxSeg]; // first kMaxSeg descent positions (unordered)
+};
+
+// One pass over qid (and over the other columns only where qid matches tid[0]).
+__global__ __launch_bounds__(256) void inspect_kernel(long long n_rec, int32_t n_reads, int detect_sym,
+                                                      const int32_t *qid, const int32_t *qs, const int32_t *qe,
+                                                      const int32_t *tid, const int32_t *ts, const int32_t *te,
+                                                      InspectOut *out)
+{
+    const int32_t q0 = qid[0], t0 = tid[0], qs0 = qs[0], qe0 = qe[0], ts0 = ts[0], te0 = te[0];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += stride) {
+        const int32_t q = qid[i];
+        if (q < 0 || q >= n_reads) {
+            atomicOr(&out->err_flags, kErrReadId);
+            atomicMin((unsigned long long *)&out->err_index, (unsigned long long)i);
+        }
+        if (i > 0) {
+            if (q < qid[i - 1]) {
+                const int slot = atomicAdd(&out->n_desc, 1);
+                if (slot < kMaxSeg) out->desc_pos[slot] = i;
+            }
+            if (detect_sym && q == t0) {
+                if (tid[i] == q0 && ts[i] == qs0 && te[i] == qe0 && qs[i] == ts0 && qe[i] == te0)
+                    out->sym_found = 1;
+            }
+        }
+    }
+}
+
+// tile_first[k] = first read whose first window lies in tile k or later (tiles of Q windows).
+__global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const long long *cov_off, int Q,
+                                                         long long n_tiles, int32_t *tile_first)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_reads) return;
+    const long long t_r = (r < n_reads) ? cov_off[r] / Q : n_tiles;
+    const long long t_p = (r > 0) ? cov_off[r - 1] / Q : -1;
+    for (long long k = t_p + 1; k <= t_r; ++k) tile_first[k] = (int32_t)r;
+}
+
+struct SegBounds { long long start[kMaxSeg + 1]; int32_t n_seg; };
+
+// tile_iv[s][k] = first interval of segment s whose read id >= tile_first[k].
+// seg_end_dev (optional) overrides the end of segment 0 with a device-resident count (bucketing path).
+__global__ __launch_bounds__(256) void tile_iv_kernel(SegBounds sb, const long long *seg_end_dev,
+                                                      const int32_t *iv_rid, const int32_t *tile_first,
+                                                      long long n_tiles_p1, long long *tile_iv)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    if (k >= n_tiles_p1) return;
+    long long lo = sb.start[s], hi = sb.start[s + 1];
+    if (seg_end_dev) hi = *seg_end_dev;
+    tile_iv[(long long)s * n_tiles_p1 + k] = lower_bound_rid(iv_rid, lo, hi, tile_first[k]);
+}
+
+// ---- counting sort by read id ------------------------------------------------
+
+// Lanes that hold the same key as the previous lane are folded into the run's
+// head lane: one atomic per run.  Returns, for every lane, the head lane of its
+// run and (in *run_len) the length of the run when called on the head.
+__device__ __forceinline__ int run_head(bool valid, int key, int lane, int *run_len, bool *is_head)
+{
+    const int prev_key = __shfl_up(key, 1, kWave);
+    const bool prev_valid = __shfl_up((int)valid, 1, kWave) != 0;
+    const bool head = valid && (lane == 0 || !prev_valid || prev_key != key);
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long vm = __ballot(valid);
+    // head lane of my run: highest head bit at or below my lane
+    const unsigned long long below = hm & ((2ull << lane) - 1ull);
+    const int h = below ? top_bit(below) : lane;
+    // run length for a head: distance to the next head above it, or to the end of the valid lanes
+    const unsigned long long above = (lane < 63) ? (hm >> (lane + 1)) : 0ull;
+    const int nvalid = __popcll(vm);              // valid lanes are a prefix of the wave by construction
+    const int next = above ? lane + 1 + (int)__builtin_ctzll(above) : nvalid;
+    *run_len = next - lane;
+    *is_head = head;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void bucket_hist_kernel(long long n_rec, int32_t n_reads, int symmetric,
+                                                          const int32_t *qid, const int32_t *tid,
+                                                          int32_t *cnt, int32_t *err_flags, long long *err_index)
+{
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n_round = (n_rec + 63) & ~63LL;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        const bool valid = i < n_rec;
+        int q = valid ? qid[i] : -1;
+        bool okq = valid && q >= 0 && q < n_reads;   // out-of-range ids were already flagged by inspect_kernel
+        int len; bool head;
+        run_head(okq, q, lane, &len, &head);
+        // the fold assumes valid lanes form a prefix; a bad id in the middle breaks that, so fall back per lane
+        const unsigned long long vm = __ballot(okq);
+        const bool prefix = (vm & (vm + 1ull)) == 0ull;
+        if (prefix) { if (head) atomicAdd(&cnt[q], len); }
+        else if (okq) atomicAdd(&cnt[q], 1);
+        if (!symmetric && valid) {
+            const int t = tid[i];
+            if (t < 0 || t >= n_reads) {
+                atomicOr(err_flags, kErrReadId);
+                atomicMin((unsigned long long *)err_index, (unsigned long long)i);
+            } else if (t != q) atomicAdd(&cnt[t], 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(long long n_rec, int32_t n_reads, int symmetric,
+                                                             const int32_t *qid, const int32_t *qs, const int32_t *qe,
+                                                             const int32_t *tid, const int32_t *ts, const int32_t *te,
+                                                             const long long *iv_off, int32_t *cursor,
+                                                             int32_t *b_rid, int32_t *b_s, int32_t *b_e)
+{
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n_round = (n_rec + 63) & ~63LL;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        const bool valid = i < n_rec;
+        int q = valid ? qid[i] : -1;
+        const bool okq = valid && q >= 0 && q < n_reads;
+        int len; bool head;
+        const int h = run_head(okq, q, lane, &len, &head);
+        const unsigned long long vm = __ballot(okq);
+        const bool prefix = (vm & (vm + 1ull)) == 0ull;
+        int slot = 0;
+        if (prefix) {
+            int base = 0;
+            if (head) base = atomicAdd(&cursor[q], len);
+            base = __shfl(base, h, kWave);
+            slot = base + (lane - h);
+        } else if (okq) slot = atomicAdd(&cursor[q], 1);
+        if (okq) {
+            const long long d = iv_off[q] + slot;
+            b_rid[d] = q; b_s[d] = qs[i]; b_e[d] = qe[i];
+        }
+        if (!symmetric && valid) {
+            const int t = tid[i];
+            if (t >= 0 && t < n_reads && t != q) {
+                const long long d = iv_off[t] + atomicAdd(&cursor[t], 1);
+                b_rid[d] = t; b_s[d] = ts[i]; b_e[d] = te[i];
+            }
+        }
+    }
+}
+
+} // namespace raft

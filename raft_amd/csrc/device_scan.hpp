@@ -1,0 +1,142 @@
+// device_scan.hpp -- device-wide exclusive prefix sums over per-read quantities.
+//
+// These run over N (reads), not over bins or records, so they are a few MB of
+// traffic against the GBs of the pileup kernel; a plain three-launch
+// reduce / scan-partials / apply scheme is enough.  K independent int64 sums are
+// carried at once so that one pass produces several CSR offset arrays.
+#pragma once
+#include "wave.hpp"
+
+namespace raft {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+template <int K> struct ScanOut { long long *p[K]; };
+
+inline int scan_blocks(long long n) { return (int)((n + kScanTile - 1) / kScanTile); }
+
+// block-wide exclusive scan of one int64 per thread; returns exclusive prefix, total in *total
+template <int THREADS>
+__device__ __forceinline__ long long block_excl_scan64(long long v, long long *total, long long *lds /*[THREADS/64 + 1]*/)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    long long incl = wave_incl_scan_add64(v);
+    if (lane == 63) lds[wid] = incl;
+    __syncthreads();
+    long long base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) {
+        long long s = lds[w];
+        if (w < wid) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+template <class Loader, int K>
+__global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(Loader ld, long long n, long long *partials)
+{
+    __shared__ long long lds[kScanThreads / 64 + 1];
+    long long acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0;
+    long long i0 = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+    for (int j = 0; j < kScanItems; ++j) {
+        long long i = i0 + j;
+        if (i < n) {
+            long long v[K];
+            ld(i, v);
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += v[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        long long tot;
+        (void)block_excl_scan64<kScanThreads>(acc[k], &tot, lds);
+        if (threadIdx.x == 0) partials[(long long)blockIdx.x * K + k] = tot;
+    }
+}
+
+// one workgroup: exclusive scan of the per-block partials in place; grand totals go to totals[K]
+template <int K>
+__global__ __launch_bounds__(1024) void scan_partials_scan_kernel(long long *partials, int nblocks, long long *totals)
+{
+    __shared__ long long lds[1024 / 64 + 1];
+    long long carry[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) carry[k] = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
+        int b = b0 + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            long long v = (b < nblocks) ? partials[(long long)b * K + k] : 0;
+            long long tot;
+            long long ex = block_excl_scan64<1024>(v, &tot, lds);
+            if (b < nblocks) partials[(long long)b * K + k] = carry[k] + ex;
+            carry[k] += tot;
+        }
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) totals[k] = carry[k];
+    }
+}
+
+template <class Loader, int K>
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, long long n, const long long *partials,
+                                                                  const long long *totals, ScanOut<K> out)
+{
+    __shared__ long long lds[kScanThreads / 64 + 1];
+    long long v[kScanItems][K];
+    long long acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0;
+    long long i0 = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        long long i = i0 + j;
+        if (i < n) ld(i, v[j]);
+        else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[j][k] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += v[j][k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        long long tot;
+        long long run = partials[(long long)blockIdx.x * K + k] + block_excl_scan64<kScanThreads>(acc[k], &tot, lds);
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) {
+            long long i = i0 + j;
+            if (i < n) out.p[k][i] = run;
+            run += v[j][k];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) out.p[k][n] = totals[k];
+    }
+}
+
+// Host driver.  partials must hold (scan_blocks(n) * K) + K int64; totals = partials + nblocks*K.
+template <class Loader, int K>
+inline void exclusive_scan(hipStream_t st, Loader ld, long long n, long long *partials, ScanOut<K> out,
+                           long long **totals_dev = nullptr)
+{
+    int nb = scan_blocks(n);
+    if (nb < 1) nb = 1;
+    long long *totals = partials + (long long)nb * K;
+    hipLaunchKernelGGL((scan_partials_kernel<Loader, K>), dim3(nb), dim3(kScanThreads), 0, st, ld, n, partials);
+    hipLaunchKernelGGL((scan_partials_scan_kernel<K>), dim3(1), dim3(1024), 0, st, partials, nb, totals);
+    hipLaunchKernelGGL((scan_apply_kernel<Loader, K>), dim3(nb), dim3(kScanThreads), 0, st, ld, n, partials, totals, out);
+    if (totals_dev) *totals_dev = totals;
+}
+
+} // namespace raft

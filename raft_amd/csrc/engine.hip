@@ -1,0 +1,596 @@
+// engine.hip -- context, launch sequence and C ABI (include/raft_hip.h) of the
+// MI355X engine.  One context = one device + one stream + grow-only device
+// buffers; one pass = the kernels listed in DESIGN.md §Kernels, in order.
+#include "../../include/raft_hip.h"
+
+#include "bucket.hpp"
+#include "device_scan.hpp"
+#include "finalize.hpp"
+#include "pileup.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace raft;
+
+namespace {
+
+constexpr int kPileThreads = 256;
+constexpr int kPileCap = 7424;        // windows staged in LDS per workgroup (31.9 KB -> 5 workgroups per CU)
+constexpr int kShortMax = 2048;       // reads with more windows than this may be split off into chunk mode
+constexpr int kDefaultTile = kPileCap - kShortMax; // tile quantum Q
+
+struct Ctrl {                         // device control block, cleared every pass
+    int32_t err_flags;
+    int32_t pad;
+    long long err_index;
+    unsigned long long totals[4];     // coverage, repeat bp, read length
+    InspectOut insp;
+    long long out_totals[4];          // rep / cut / frag totals land here via the scan
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = (bytes + 255) & ~size_t(255);
+        if (want == 0) want = 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct ReadPrepLoader {               // per read: windows, reserved repeat slots, marker capacity
+    const int32_t *len;
+    int32_t reso, minbins, L;
+    int32_t *err_flags;
+    long long *err_index;
+    __device__ void operator()(long long i, long long (&v)[3]) const
+    {
+        int l = len[i];
+        if (l < 0) {
+            atomicOr(err_flags, kErrLen);
+            atomicMin((unsigned long long *)err_index, (unsigned long long)i);
+            l = 0;
+        }
+        const long long nb = l / reso + ((l % reso) ? 1 : 0);   // repeat.hpp:32-37
+        v[0] = nb;
+        v[1] = (nb + 1) / ((long long)minbins + 1);              // most runs of >= minbins windows a read can hold
+        v[2] = l / L + 2;                                        // chop.hpp:209-223
+    }
+};
+
+template <int K> struct CountLoader {
+    const int32_t *c[K];
+    __device__ void operator()(long long i, long long (&v)[K]) const
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = c[k][i];
+    }
+};
+
+__global__ void selftest_kernel(const int *in, int *out_dpp, int *out_shfl, unsigned long long *ballots)
+{
+    const int v = in[threadIdx.x];
+    out_dpp[threadIdx.x] = wave_incl_scan_add(v);
+    out_shfl[threadIdx.x] = wave_incl_scan_add_shfl(v);
+    const unsigned long long b = __ballot(v & 1);
+    if ((threadIdx.x & 63) == 0) ballots[threadIdx.x >> 6] = b;
+}
+
+} // namespace
+
+struct raft_hip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    raft_hip_params prm{};
+    int32_t high_cov = 0, div = 0, minbins = 1;
+    int32_t tile_q = kDefaultTile;
+    int32_t force_bucket = 0;
+    std::string last_error;
+
+    // device buffers
+    DevBuf ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_iv, tile_sums;
+    DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
+    DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
+    DevBuf b_cnt, b_off, b_rid, b_s, b_e;
+    DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
+    void *pinned = nullptr;           // small pinned scratch for readbacks
+    hipEvent_t ev_pass0 = nullptr, ev_pass1 = nullptr, ev_pile0 = nullptr, ev_pile1 = nullptr;
+
+    // state of the last pass
+    bool ran = false, finished = false;
+    int pending_err = RAFT_HIP_OK;
+    long long pending_err_index = -1;
+    raft_hip_summary sum{};
+    long long cap_rep = 0, cap_cut = 0;
+};
+
+namespace {
+
+int fail_hip(raft_hip_ctx *c, hipError_t e, const char *what)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    c->last_error = buf;
+    return e == hipErrorOutOfMemory ? RAFT_HIP_ERR_NOMEM : RAFT_HIP_ERR_DEVICE;
+}
+
+#define HIP_TRY(c, expr)                                         \
+    do {                                                         \
+        hipError_t e_ = (expr);                                  \
+        if (e_ != hipSuccess) return fail_hip((c), e_, #expr);   \
+    } while (0)
+
+int check_params(const raft_hip_params *p)
+{
+    if (!p) return RAFT_HIP_ERR_PARAM;
+    if (p->reso <= 0 || p->est_cov <= 0 || p->repeat_length <= 0 || p->interval_length <= 0) return RAFT_HIP_ERR_PARAM;
+    if (p->read_length / p->interval_length <= 0) return RAFT_HIP_ERR_PARAM; // div == 0: SIGFPE at chop.hpp:270
+    if (p->symmetric_mode < -1 || p->symmetric_mode > 1) return RAFT_HIP_ERR_PARAM;
+    return RAFT_HIP_OK;
+}
+
+void apply_params(raft_hip_ctx *c, const raft_hip_params *p)
+{
+    c->prm = *p;
+    c->high_cov = (int32_t)(p->est_cov * p->cov_mul);            // repeat.hpp:89-90 (int * double, truncated)
+    c->div = p->read_length / p->interval_length;                // chop.hpp:248
+    c->minbins = (p->repeat_length + p->reso - 1) / p->reso;     // windows a run needs to reach repeat_length
+    if (c->minbins < 1) c->minbins = 1;
+}
+
+int code_from_flags(int flags)
+{
+    if (flags & kErrLen) return RAFT_HIP_ERR_PARAM;
+    if (flags & kErrReadId) return RAFT_HIP_ERR_READ_ID;
+    if (flags & kErrCoord) return RAFT_HIP_ERR_COORD;
+    if (flags & kErrFragment) return RAFT_HIP_ERR_FRAGMENT;
+    if (flags & kErrInternal) return RAFT_HIP_ERR_DEVICE;
+    return RAFT_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int raft_hip_abi_version(void) { return RAFT_HIP_ABI_VERSION; }
+
+const char *raft_hip_strerror(int code)
+{
+    switch (code) {
+    case RAFT_HIP_OK: return "ok";
+    case RAFT_HIP_ERR_PARAM: return "invalid parameter (reso/est_cov/repeat_length/interval_length <= 0, read_length < interval_length, or negative read length)";
+    case RAFT_HIP_ERR_READ_ID: return "PAF record names a read id outside [0, n_reads)";
+    case RAFT_HIP_ERR_COORD: return "PAF coordinate negative or beyond the last coverage window of its read";
+    case RAFT_HIP_ERR_FRAGMENT: return "fragment would start before base 0 (overlap_length larger than its first cut point)";
+    case RAFT_HIP_ERR_NOMEM: return "out of memory";
+    case RAFT_HIP_ERR_DEVICE: return "HIP device/runtime error";
+    case RAFT_HIP_ERR_STATE: return "call order violated";
+    case RAFT_HIP_ERR_TOO_LARGE: return "input too large for 32-bit per-read quantities";
+    default: return "unknown error";
+    }
+}
+
+const char *raft_hip_last_error(const raft_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx **out)
+{
+    if (!out) return RAFT_HIP_ERR_PARAM;
+    *out = nullptr;
+    int rc = check_params(params);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return RAFT_HIP_ERR_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return RAFT_HIP_ERR_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RAFT_HIP_ERR_DEVICE; // kernels are built for gfx950 only
+    raft_hip_ctx *c = new (std::nothrow) raft_hip_ctx();
+    if (!c) return RAFT_HIP_ERR_NOMEM;
+    c->device = device_id;
+    apply_params(c, params);
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreate(&c->ev_pass0) != hipSuccess || hipEventCreate(&c->ev_pass1) != hipSuccess ||
+        hipEventCreate(&c->ev_pile0) != hipSuccess || hipEventCreate(&c->ev_pile1) != hipSuccess) {
+        raft_hip_destroy(c);
+        return RAFT_HIP_ERR_DEVICE;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return RAFT_HIP_OK;
+}
+
+void raft_hip_destroy(raft_hip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_iv,
+                     &c->tile_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
+                     &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
+                     &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
+                     &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+    for (DevBuf *b : all) b->release();
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
+    if (c->ev_pass1) (void)hipEventDestroy(c->ev_pass1);
+    if (c->ev_pile0) (void)hipEventDestroy(c->ev_pile0);
+    if (c->ev_pile1) (void)hipEventDestroy(c->ev_pile1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int raft_hip_set_params(raft_hip_ctx *c, const raft_hip_params *params)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    int rc = check_params(params);
+    if (rc) return rc;
+    apply_params(c, params);
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_set_stream(raft_hip_ctx *c, void *stream)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    c->stream = stream ? (hipStream_t)stream : c->own_stream;
+    return RAFT_HIP_OK;
+}
+
+void *raft_hip_get_stream(raft_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket_path)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    if (tile_bins < 0 || tile_bins > kPileCap) return RAFT_HIP_ERR_PARAM;
+    c->tile_q = tile_bins ? tile_bins : kDefaultTile;
+    c->force_bucket = force_bucket_path ? 1 : 0;
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int64_t n_rec,
+                        const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
+                        const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    if (n_reads < 0 || n_rec < 0) return RAFT_HIP_ERR_PARAM;
+    if (n_reads > 0 && !d_len) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && (!d_qid || !d_qs || !d_qe || !d_tid || !d_ts || !d_te)) return RAFT_HIP_ERR_PARAM;
+    if (n_reads == INT32_MAX) return RAFT_HIP_ERR_TOO_LARGE;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1;
+    memset(&c->sum, 0, sizeof c->sum);
+    c->sum.n_reads = n_reads; c->sum.n_records = n_rec; c->sum.high_cov = c->high_cov; c->sum.error_index = -1;
+    const long long N = n_reads;
+
+    HIP_TRY(c, hipEventRecord(c->ev_pass0, st));
+    HIP_TRY(c, c->ctrl.ensure(sizeof(Ctrl)));
+    Ctrl *ctrl = c->ctrl.as<Ctrl>();
+    HIP_TRY(c, hipMemsetAsync(ctrl, 0, sizeof(Ctrl), st));
+    HIP_TRY(c, hipMemsetAsync(&ctrl->err_index, 0xFF, sizeof(long long), st));
+    HIP_TRY(c, hipMemsetAsync(&ctrl->insp.err_index, 0xFF, sizeof(long long), st));
+
+    // ---- per-read geometry: windows, reserved repeat slots, marker capacity (one scan, three sums)
+    const int nb_scan = std::max(scan_blocks(N), 1);
+    HIP_TRY(c, c->scan_tmp.ensure(((size_t)nb_scan * 3 + 8) * sizeof(long long)));
+    HIP_TRY(c, c->cov_off.ensure((size_t)(N + 1) * 8));
+    HIP_TRY(c, c->rep_res_off.ensure((size_t)(N + 1) * 8));
+    HIP_TRY(c, c->cutcap_off.ensure((size_t)(N + 1) * 8));
+    long long *scan_totals = nullptr;
+    {
+        ReadPrepLoader ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, &ctrl->err_flags, &ctrl->err_index};
+        ScanOut<3> so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), c->cutcap_off.as<long long>()}};
+        exclusive_scan<ReadPrepLoader, 3>(st, ld, N, c->scan_tmp.as<long long>(), so, &scan_totals);
+    }
+    long long *h = reinterpret_cast<long long *>(c->pinned);
+    HIP_TRY(c, hipMemcpyAsync(h, scan_totals, 3 * sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(h + 4, ctrl, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));                                   // wait #1: sizes
+    const long long B = h[0], RU = h[1], CU = h[2];
+    {
+        const int32_t flags = reinterpret_cast<int32_t *>(h + 4)[0];
+        if (flags) {
+            c->pending_err = code_from_flags(flags);
+            c->pending_err_index = h[5];
+            c->ran = true;
+            HIP_TRY(c, hipEventRecord(c->ev_pile0, st)); HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
+            HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
+            return RAFT_HIP_OK;
+        }
+    }
+    c->sum.n_bins = B; c->sum.total_windows = B;
+    c->cap_rep = RU; c->cap_cut = CU;
+    const int Q = c->tile_q;
+    const long long n_tiles = B / Q + 1;
+    if (n_tiles + 1 >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;
+
+    HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
+    HIP_TRY(c, c->tile_first.ensure((size_t)(n_tiles + 1) * 4));
+    HIP_TRY(c, c->tile_iv.ensure((size_t)(n_tiles + 1) * 8 * kMaxSeg));
+    HIP_TRY(c, c->tile_sums.ensure((size_t)n_tiles * 16));
+    HIP_TRY(c, c->rep_cnt.ensure((size_t)std::max(N, 1LL) * 4));
+    HIP_TRY(c, c->cut_cnt.ensure((size_t)std::max(N, 1LL) * 4));
+    HIP_TRY(c, c->frag_cnt.ensure((size_t)std::max(N, 1LL) * 4));
+    HIP_TRY(c, c->raw_key.ensure((size_t)std::max(RU, 1LL) * 4));
+    HIP_TRY(c, c->raw_s.ensure((size_t)std::max(RU, 1LL) * 4));
+    HIP_TRY(c, c->raw_e.ensure((size_t)std::max(RU, 1LL) * 4));
+    HIP_TRY(c, c->rep_s.ensure((size_t)std::max(RU, 1LL) * 4));
+    HIP_TRY(c, c->rep_e.ensure((size_t)std::max(RU, 1LL) * 4));
+    HIP_TRY(c, c->cuts.ensure((size_t)std::max(CU, 1LL) * 4));
+    HIP_TRY(c, c->frag_read.ensure((size_t)std::max(CU, 1LL) * 4));
+    HIP_TRY(c, c->frag_begin.ensure((size_t)std::max(CU, 1LL) * 4));
+    HIP_TRY(c, c->frag_end.ensure((size_t)std::max(CU, 1LL) * 4));
+    HIP_TRY(c, c->rep_off.ensure((size_t)(N + 1) * 8));
+    HIP_TRY(c, c->cut_off.ensure((size_t)(N + 1) * 8));
+    HIP_TRY(c, c->frag_off.ensure((size_t)(N + 1) * 8));
+    HIP_TRY(c, hipMemsetAsync(c->rep_cnt.p, 0, (size_t)std::max(N, 1LL) * 4, st));
+
+    hipLaunchKernelGGL(tile_first_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, st, n_reads,
+                       c->cov_off.as<long long>(), Q, n_tiles, c->tile_first.as<int32_t>());
+
+    // ---- look at the record stream: symmetric PAF? sorted runs? ids in range?
+    int symmetric = c->prm.symmetric_mode == 1 ? 1 : 0;
+    int n_desc = 0;
+    long long desc[kMaxSeg];
+    if (n_rec > 0) {
+        const unsigned grid = (unsigned)std::min<long long>((n_rec + 255) / 256, 4096);
+        hipLaunchKernelGGL(inspect_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads,
+                           c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
+        InspectOut *hi = reinterpret_cast<InspectOut *>(h + 8);
+        HIP_TRY(c, hipMemcpyAsync(hi, &ctrl->insp, sizeof(InspectOut), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));                               // wait #2: path choice
+        if (hi->err_flags) {
+            c->pending_err = code_from_flags(hi->err_flags);
+            c->pending_err_index = hi->err_index;
+            c->ran = true;
+            HIP_TRY(c, hipEventRecord(c->ev_pile0, st)); HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
+            HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
+            return RAFT_HIP_OK;
+        }
+        if (c->prm.symmetric_mode < 0) symmetric = hi->sym_found ? 1 : 0;
+        n_desc = hi->n_desc;
+        for (int i = 0; i < std::min(n_desc, kMaxSeg); ++i) desc[i] = hi->desc_pos[i];
+    }
+    c->sum.symmetric = symmetric;
+
+    PileupArgs pa{};
+    pa.read_len = d_len; pa.cov_off = c->cov_off.as<long long>(); pa.tile_first = c->tile_first.as<int32_t>();
+    pa.n_tiles_p1 = n_tiles + 1; pa.n_reads = n_reads;
+    pa.reso = c->prm.reso; pa.high_cov = c->high_cov; pa.repeat_length = c->prm.repeat_length; pa.flank = c->prm.flanking_length;
+    pa.cov = c->cov.as<int32_t>(); pa.rep_res_off = c->rep_res_off.as<long long>(); pa.rep_cnt = c->rep_cnt.as<int32_t>();
+    pa.raw_key = c->raw_key.as<int32_t>(); pa.raw_s = c->raw_s.as<int32_t>(); pa.raw_e = c->raw_e.as<int32_t>();
+    pa.tile_sums = c->tile_sums.as<long long>(); pa.err_flags = &ctrl->err_flags; pa.err_index = &ctrl->err_index;
+    pa.tile_iv = c->tile_iv.as<long long>();
+
+    const bool fast = n_rec > 0 && symmetric && !c->force_bucket && n_desc + 1 <= kMaxSeg;
+    const unsigned tgrid = (unsigned)((n_tiles + 1 + 255) / 256);
+    if (n_rec == 0) {
+        pa.n_seg = 0;
+        c->sum.interval_path = 0; c->sum.n_segments = 0; c->sum.n_intervals = 0;
+    } else if (fast) {
+        SegBounds sb{};
+        std::sort(desc, desc + n_desc);
+        sb.n_seg = n_desc + 1;
+        sb.start[0] = 0;
+        for (int i = 0; i < n_desc; ++i) sb.start[i + 1] = desc[i];
+        sb.start[n_desc + 1] = n_rec;
+        pa.iv_rid = d_qid; pa.iv_s = d_qs; pa.iv_e = d_qe; pa.n_seg = sb.n_seg;
+        hipLaunchKernelGGL(tile_iv_kernel, dim3(tgrid, sb.n_seg), dim3(256), 0, st, sb, (const long long *)nullptr,
+                           d_qid, c->tile_first.as<int32_t>(), n_tiles + 1, c->tile_iv.as<long long>());
+        c->sum.interval_path = 0; c->sum.n_segments = sb.n_seg; c->sum.n_intervals = n_rec;
+    } else {
+        const long long cap_iv = symmetric ? (long long)n_rec : 2 * (long long)n_rec;
+        HIP_TRY(c, c->b_cnt.ensure((size_t)std::max(N, 1LL) * 4));
+        HIP_TRY(c, c->b_off.ensure((size_t)(N + 1) * 8));
+        HIP_TRY(c, c->b_rid.ensure((size_t)cap_iv * 4));
+        HIP_TRY(c, c->b_s.ensure((size_t)cap_iv * 4));
+        HIP_TRY(c, c->b_e.ensure((size_t)cap_iv * 4));
+        HIP_TRY(c, hipMemsetAsync(c->b_cnt.p, 0, (size_t)std::max(N, 1LL) * 4, st));
+        const unsigned grid = (unsigned)std::min<long long>((n_rec + 255) / 256, 8192);
+        hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads, symmetric, d_qid,
+                           d_tid, c->b_cnt.as<int32_t>(), &ctrl->err_flags, &ctrl->err_index);
+        long long *iv_total = nullptr;
+        {
+            CountLoader<1> ld{{c->b_cnt.as<int32_t>()}};
+            ScanOut<1> so{{c->b_off.as<long long>()}};
+            exclusive_scan<CountLoader<1>, 1>(st, ld, N, c->scan_tmp.as<long long>(), so, &iv_total);
+        }
+        HIP_TRY(c, hipMemsetAsync(c->b_cnt.p, 0, (size_t)std::max(N, 1LL) * 4, st)); // reused as the scatter cursor
+        hipLaunchKernelGGL(bucket_scatter_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads, symmetric, d_qid,
+                           d_qs, d_qe, d_tid, d_ts, d_te, c->b_off.as<long long>(), c->b_cnt.as<int32_t>(),
+                           c->b_rid.as<int32_t>(), c->b_s.as<int32_t>(), c->b_e.as<int32_t>());
+        SegBounds sb{};
+        sb.n_seg = 1; sb.start[0] = 0; sb.start[1] = cap_iv;
+        pa.iv_rid = c->b_rid.as<int32_t>(); pa.iv_s = c->b_s.as<int32_t>(); pa.iv_e = c->b_e.as<int32_t>(); pa.n_seg = 1;
+        // the true interval count lives at b_off[N]; tile_iv_kernel reads it from there
+        hipLaunchKernelGGL(tile_iv_kernel, dim3(tgrid, 1), dim3(256), 0, st, sb, c->b_off.as<long long>() + N,
+                           c->b_rid.as<int32_t>(), c->tile_first.as<int32_t>(), n_tiles + 1, c->tile_iv.as<long long>());
+        c->sum.interval_path = 1; c->sum.n_segments = n_desc + 1; c->sum.n_intervals = -1; // read back in finish
+        (void)iv_total;
+    }
+
+    // ---- the dominant kernel
+    HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
+    hipLaunchKernelGGL((pileup_kernel<kPileThreads, kPileCap>), dim3((unsigned)n_tiles), dim3(kPileThreads), 0, st, pa);
+    HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
+
+    // ---- per-read tail: order repeats, mask markers, fragments
+    FinalizeArgs fa{};
+    fa.n_reads = n_reads; fa.read_len = d_len; fa.rep_res_off = c->rep_res_off.as<long long>();
+    fa.rep_cnt = c->rep_cnt.as<int32_t>(); fa.raw_key = c->raw_key.as<int32_t>(); fa.raw_s = c->raw_s.as<int32_t>();
+    fa.raw_e = c->raw_e.as<int32_t>(); fa.interval_length = c->prm.interval_length; fa.div = c->div;
+    fa.overlap_length = c->prm.overlap_length; fa.cut_cnt = c->cut_cnt.as<int32_t>(); fa.frag_cnt = c->frag_cnt.as<int32_t>();
+    fa.rep_off = c->rep_off.as<long long>(); fa.cut_off = c->cut_off.as<long long>(); fa.frag_off = c->frag_off.as<long long>();
+    fa.rep_s = c->rep_s.as<int32_t>(); fa.rep_e = c->rep_e.as<int32_t>(); fa.cuts = c->cuts.as<int32_t>();
+    fa.frag_read = c->frag_read.as<int32_t>(); fa.frag_begin = c->frag_begin.as<int32_t>(); fa.frag_end = c->frag_end.as<int32_t>();
+    fa.err_flags = &ctrl->err_flags; fa.err_index = &ctrl->err_index;
+    if (N > 0) {
+        const unsigned rgrid = (unsigned)((N + 255) / 256);
+        hipLaunchKernelGGL(finalize_count_kernel, dim3(rgrid), dim3(256), 0, st, fa);
+        CountLoader<3> ld{{c->rep_cnt.as<int32_t>(), c->cut_cnt.as<int32_t>(), c->frag_cnt.as<int32_t>()}};
+        ScanOut<3> so{{c->rep_off.as<long long>(), c->cut_off.as<long long>(), c->frag_off.as<long long>()}};
+        exclusive_scan<CountLoader<3>, 3>(st, ld, N, c->scan_tmp.as<long long>(), so);
+        hipLaunchKernelGGL(finalize_fill_kernel, dim3(rgrid), dim3(256), 0, st, fa);
+    } else {
+        HIP_TRY(c, hipMemsetAsync(c->rep_off.p, 0, 8, st));
+        HIP_TRY(c, hipMemsetAsync(c->cut_off.p, 0, 8, st));
+        HIP_TRY(c, hipMemsetAsync(c->frag_off.p, 0, 8, st));
+    }
+    {
+        const unsigned g = (unsigned)std::min<long long>((std::max(n_tiles, N) + 255) / 256, 1024);
+        hipLaunchKernelGGL(totals_kernel, dim3(std::max(g, 1u)), dim3(256), 0, st, n_tiles, c->tile_sums.as<long long>(),
+                           n_reads, d_len, ctrl->totals);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
+    HIP_TRY(c, hipGetLastError());
+    c->ran = true;
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_run_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                      const int32_t *qid, const int32_t *qs, const int32_t *qe,
+                      const int32_t *tid, const int32_t *ts, const int32_t *te)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    if (n_reads < 0 || n_rec < 0) return RAFT_HIP_ERR_PARAM;
+    if (n_reads > 0 && !read_len) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && (!qid || !qs || !qe || !tid || !ts || !te)) return RAFT_HIP_ERR_PARAM;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->in_len.ensure((size_t)std::max<long long>(n_reads, 1) * 4));
+    if (n_reads) HIP_TRY(c, hipMemcpyAsync(c->in_len.p, read_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
+    const int32_t *src[6] = {qid, qs, qe, tid, ts, te};
+    for (int k = 0; k < 6; ++k) {
+        HIP_TRY(c, c->in_col[k].ensure((size_t)std::max<long long>(n_rec, 1) * 4));
+        if (n_rec) HIP_TRY(c, hipMemcpyAsync(c->in_col[k].p, src[k], (size_t)n_rec * 4, hipMemcpyHostToDevice, st));
+    }
+    return raft_hip_run_device(c, n_reads, c->in_len.as<int32_t>(), n_rec, c->in_col[0].as<int32_t>(),
+                               c->in_col[1].as<int32_t>(), c->in_col[2].as<int32_t>(), c->in_col[3].as<int32_t>(),
+                               c->in_col[4].as<int32_t>(), c->in_col[5].as<int32_t>());
+}
+
+int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    if (!c->ran) return RAFT_HIP_ERR_STATE;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->finished) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->pending_err == RAFT_HIP_OK) {
+            Ctrl hc;
+            HIP_TRY(c, hipMemcpy(&hc, c->ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost));
+            const long long N = c->sum.n_reads;
+            long long tails[4] = {0, 0, 0, 0};
+            HIP_TRY(c, hipMemcpy(&tails[0], c->rep_off.as<long long>() + N, 8, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(&tails[1], c->cut_off.as<long long>() + N, 8, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(&tails[2], c->frag_off.as<long long>() + N, 8, hipMemcpyDeviceToHost));
+            if (c->sum.interval_path == 1)
+                HIP_TRY(c, hipMemcpy(&tails[3], c->b_off.as<long long>() + N, 8, hipMemcpyDeviceToHost));
+            c->sum.n_repeats = tails[0]; c->sum.n_cuts = tails[1]; c->sum.n_fragments = tails[2];
+            if (c->sum.interval_path == 1) c->sum.n_intervals = tails[3];
+            c->sum.total_coverage = (long long)hc.totals[0];
+            c->sum.total_repeat_length = (long long)hc.totals[1];
+            c->sum.total_read_length = (long long)hc.totals[2];
+            if (hc.err_flags) {
+                c->pending_err = code_from_flags(hc.err_flags);
+                c->pending_err_index = hc.err_index;
+            }
+        }
+        c->sum.error_index = c->pending_err ? c->pending_err_index : -1;
+        c->finished = true;
+    }
+    if (summary) *summary = c->sum;
+    return c->pending_err;
+}
+
+int raft_hip_outputs_device(raft_hip_ctx *c, raft_hip_outputs *o)
+{
+    if (!c || !o) return RAFT_HIP_ERR_PARAM;
+    if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
+    o->cov_offset = c->cov_off.as<int64_t>(); o->cov = c->cov.as<int32_t>();
+    o->rep_offset = c->rep_off.as<int64_t>(); o->rep_s = c->rep_s.as<int32_t>(); o->rep_e = c->rep_e.as<int32_t>();
+    o->cut_offset = c->cut_off.as<int64_t>(); o->cuts = c->cuts.as<int32_t>();
+    o->frag_offset = c->frag_off.as<int64_t>(); o->frag_read = c->frag_read.as<int32_t>();
+    o->frag_begin = c->frag_begin.as<int32_t>(); o->frag_end = c->frag_end.as<int32_t>();
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_fetch(raft_hip_ctx *c, int64_t *cov_offset, int32_t *cov, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
+                   int64_t *cut_offset, int32_t *cuts, int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin,
+                   int32_t *frag_end)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t N1 = (size_t)c->sum.n_reads + 1;
+    struct { void *dst; const void *src; size_t bytes; } job[] = {
+        {cov_offset, c->cov_off.p, N1 * 8}, {cov, c->cov.p, (size_t)c->sum.n_bins * 4},
+        {rep_offset, c->rep_off.p, N1 * 8}, {rep_s, c->rep_s.p, (size_t)c->sum.n_repeats * 4},
+        {rep_e, c->rep_e.p, (size_t)c->sum.n_repeats * 4}, {cut_offset, c->cut_off.p, N1 * 8},
+        {cuts, c->cuts.p, (size_t)c->sum.n_cuts * 4}, {frag_offset, c->frag_off.p, N1 * 8},
+        {frag_read, c->frag_read.p, (size_t)c->sum.n_fragments * 4}, {frag_begin, c->frag_begin.p, (size_t)c->sum.n_fragments * 4},
+        {frag_end, c->frag_end.p, (size_t)c->sum.n_fragments * 4}};
+    for (auto &j : job)
+        if (j.dst && j.bytes) HIP_TRY(c, hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost));
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_last_timing(raft_hip_ctx *c, double *pileup_seconds, double *pass_seconds)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    if (!c->finished) return RAFT_HIP_ERR_STATE;
+    float ms = 0.f;
+    if (pileup_seconds) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pile0, c->ev_pile1)); *pileup_seconds = ms * 1e-3; }
+    if (pass_seconds) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pass0, c->ev_pass1)); *pass_seconds = ms * 1e-3; }
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_selftest(int device_id)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return RAFT_HIP_ERR_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return RAFT_HIP_ERR_DEVICE;
+    const int n = 256;
+    int h_in[n], h_a[n], h_b[n];
+    unsigned long long h_bal[n / 64];
+    unsigned s = 12345u;
+    for (int i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h_in[i] = (int)(s >> 20) - 2048; }
+    int *d_in = nullptr, *d_a = nullptr, *d_b = nullptr;
+    unsigned long long *d_bal = nullptr;
+    int rc = RAFT_HIP_ERR_DEVICE;
+    if (hipMalloc(&d_in, sizeof h_in) == hipSuccess && hipMalloc(&d_a, sizeof h_a) == hipSuccess &&
+        hipMalloc(&d_b, sizeof h_b) == hipSuccess && hipMalloc(&d_bal, sizeof h_bal) == hipSuccess &&
+        hipMemcpy(d_in, h_in, sizeof h_in, hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(n), 0, 0, d_in, d_a, d_b, d_bal);
+        if (hipMemcpy(h_a, d_a, sizeof h_a, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(h_b, d_b, sizeof h_b, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(h_bal, d_bal, sizeof h_bal, hipMemcpyDeviceToHost) == hipSuccess) {
+            rc = RAFT_HIP_OK;
+            for (int w = 0; w < n / 64; ++w) {
+                int run = 0;
+                unsigned long long bal = 0;
+                for (int l = 0; l < 64; ++l) {
+                    run += h_in[w * 64 + l];
+                    if (h_in[w * 64 + l] & 1) bal |= 1ull << l;
+                    if (h_a[w * 64 + l] != run || h_b[w * 64 + l] != run) rc = 100 + w;
+                }
+                if (bal != h_bal[w]) rc = 200 + w;
+            }
+        }
+    }
+    (void)hipFree(d_in); (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_bal);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,158 @@
+// finalize.hpp -- per-read tail of the path: order the read's repeats, mask the
+// cut-point markers, count and emit fragments, reduce the stdout statistics.
+//
+// Reference: chop.hpp:209-321 (break_reads, integer half) and repeat.hpp:170.
+// Work here is O(markers + repeats) per read -- a few integers against the
+// hundreds of windows the pileup kernel wrote for the same read -- so one lane per
+// read is enough; it is not on the roofline-relevant part of the pass.
+#pragma once
+#include "pileup.hpp"
+
+namespace raft {
+
+struct FinalizeArgs {
+    int32_t n_reads;
+    const int32_t *read_len;
+    const long long *rep_res_off;
+    const int32_t *rep_cnt;
+    int32_t *raw_key, *raw_s, *raw_e;     // sorted in place by finalize_count_kernel
+    int32_t interval_length, div, overlap_length;
+    int32_t *cut_cnt, *frag_cnt;          // [n_reads]
+    const long long *rep_off, *cut_off, *frag_off; // [n_reads+1] (fill kernel)
+    int32_t *rep_s, *rep_e, *cuts, *frag_read, *frag_begin, *frag_end;
+    int32_t *err_flags;
+    long long *err_index;
+};
+
+__device__ __forceinline__ void swap3(int32_t *k, int32_t *s, int32_t *e, long long i, long long j)
+{
+    int32_t t;
+    t = k[i]; k[i] = k[j]; k[j] = t;
+    t = s[i]; s[i] = s[j]; s[j] = t;
+    t = e[i]; e[i] = e[j]; e[j] = t;
+}
+
+// in-place sort of a read's raw repeats by run start (keys are distinct: runs are disjoint)
+__device__ void sort_repeats(int32_t *k, int32_t *s, int32_t *e, int n)
+{
+    if (n <= 24) {
+        for (int i = 1; i < n; ++i) {
+            const int32_t kk = k[i], ss = s[i], ee = e[i];
+            int j = i - 1;
+            while (j >= 0 && k[j] > kk) { k[j + 1] = k[j]; s[j + 1] = s[j]; e[j + 1] = e[j]; --j; }
+            k[j + 1] = kk; s[j + 1] = ss; e[j + 1] = ee;
+        }
+        return;
+    }
+    // heap sort
+    for (int root0 = n / 2 - 1; root0 >= 0; --root0) {
+        int root = root0;
+        for (;;) {
+            int c = 2 * root + 1;
+            if (c >= n) break;
+            if (c + 1 < n && k[c + 1] > k[c]) ++c;
+            if (k[root] >= k[c]) break;
+            swap3(k, s, e, root, c);
+            root = c;
+        }
+    }
+    for (int end = n - 1; end > 0; --end) {
+        swap3(k, s, e, 0, end);
+        int root = 0;
+        for (;;) {
+            int c = 2 * root + 1;
+            if (c >= end) break;
+            if (c + 1 < end && k[c + 1] > k[c]) ++c;
+            if (k[root] >= k[c]) break;
+            swap3(k, s, e, root, c);
+            root = c;
+        }
+    }
+}
+
+// Walks the candidate markers 0, L, 2L, ..., (+len) of one read (chop.hpp:209-223) and keeps
+// the first, the last, and every marker not inside a flanked repeat [s,e] (chop.hpp:225-246).
+// Calls keep(m) for each kept marker in ascending order; returns their number.
+template <class Keep>
+__device__ __forceinline__ int walk_cuts(int len, int L, const int32_t *s, const int32_t *e, int n, Keep keep)
+{
+    const int parts = len / L;
+    const int nm = parts + 1 + ((len % L) ? 1 : 0);
+    int kept = 0, k = 0;
+    for (int j = 0; j < nm; ++j) {
+        const int m = (j <= parts) ? j * L : len;
+        bool covered = false;
+        if (j > 0 && j < nm - 1) {
+            while (k < n && e[k] < m) ++k;     // repeats are ordered by start and by end
+            covered = (k < n) && (s[k] <= m);
+        }
+        if (!covered) { keep(m); ++kept; }
+    }
+    return kept;
+}
+
+__global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    const int n = a.rep_cnt[r];
+    const long long base = a.rep_res_off[r];
+    if (n > 1) sort_repeats(a.raw_key + base, a.raw_s + base, a.raw_e + base, n);
+    const int nF = walk_cuts(a.read_len[r], a.interval_length, a.raw_s + base, a.raw_e + base, n, [](int) {});
+    int nf = 1;                                   // chop.hpp:250-276
+    if (nF > a.div + 1) nf = (nF - 1 + a.div - 1) / a.div;
+    a.cut_cnt[r] = nF;
+    a.frag_cnt[r] = nf;
+}
+
+__global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    const int n = a.rep_cnt[r];
+    const long long base = a.rep_res_off[r];
+    const long long ro = a.rep_off[r];
+    for (int i = 0; i < n; ++i) { a.rep_s[ro + i] = a.raw_s[base + i]; a.rep_e[ro + i] = a.raw_e[base + i]; }
+    const long long co = a.cut_off[r];
+    const int len = a.read_len[r];
+    int32_t *F = a.cuts + co;
+    int w = 0;
+    const int nF = walk_cuts(len, a.interval_length, a.raw_s + base, a.raw_e + base, n, [&](int m) { F[w++] = m; });
+    const long long fo = a.frag_off[r];
+    if (nF <= a.div + 1) {                        // chop.hpp:250-267: the read is kept whole
+        a.frag_read[fo] = r; a.frag_begin[fo] = 0; a.frag_end[fo] = len;
+        return;
+    }
+    const int nf = (nF - 1 + a.div - 1) / a.div;
+    int pos = 0;
+    for (int j = 1; j <= nf; ++j) {               // chop.hpp:280-321
+        const int ovl = (j == 1) ? 0 : a.overlap_length;
+        const int last = (j == nf) ? F[nF - 1] : F[pos + a.div];
+        const int begin = F[pos] - ovl;
+        if (begin < 0 || begin > len) {
+            atomicOr(a.err_flags, kErrFragment);
+            atomicMin((unsigned long long *)a.err_index, (unsigned long long)r);
+        }
+        a.frag_read[fo + j - 1] = r; a.frag_begin[fo + j - 1] = begin; a.frag_end[fo + j - 1] = last;
+        pos += a.div;
+    }
+}
+
+// totals[0] = sum coverage, [1] = sum unclamped repeat bp, [2] = sum read length
+__global__ __launch_bounds__(256) void totals_kernel(long long n_tiles, const long long *tile_sums, int32_t n_reads,
+                                                     const int32_t *read_len, unsigned long long *totals)
+{
+    long long c = 0, rp = 0, l = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = i0; i < n_tiles; i += stride) { c += tile_sums[2 * i]; rp += tile_sums[2 * i + 1]; }
+    for (long long i = i0; i < n_reads; i += stride) l += read_len[i];
+    c = wave_reduce_add64(c); rp = wave_reduce_add64(rp); l = wave_reduce_add64(l);
+    if ((threadIdx.x & 63) == 0) {
+        if (c) atomicAdd(&totals[0], (unsigned long long)c);
+        if (rp) atomicAdd(&totals[1], (unsigned long long)rp);
+        if (l) atomicAdd(&totals[2], (unsigned long long)l);
+    }
+}
+
+} // namespace raft

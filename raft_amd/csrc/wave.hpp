@@ -1,0 +1,70 @@
+// wave.hpp -- wavefront (64-lane) primitives for gfx950.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace raft {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id()
+{
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Inclusive +-scan across the 64 lanes with DPP row shifts and row broadcasts
+// (the sequence LLVM's AMDGPU atomic optimizer emits for GFX9-family waves).
+// Requires EXEC = all ones.
+__device__ __forceinline__ int wave_incl_scan_add(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2,3
+    return v;
+}
+
+// Same scan through ds_bpermute shuffles; used by the self test as the cross-check
+// and by kernels that are not on the hot path.
+__device__ __forceinline__ int wave_incl_scan_add_shfl(int v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        int o = __shfl_up(v, d, kWave);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ long long wave_incl_scan_add64(long long v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        long long o = __shfl_up(v, d, kWave);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ long long wave_reduce_add64(long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+
+__device__ __forceinline__ int wave_reduce_add(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+
+// Position (0..63) of the highest set bit; m != 0.
+__device__ __forceinline__ int top_bit(unsigned long long m) { return 63 - __clzll((long long)m); }
+
+} // namespace raft

@@ -1,0 +1,251 @@
+"""ctypes binding of the C ABI in ``include/raft_hip.h`` (libraft_hip.so).
+
+This is the host-side mirror of the seam the engine replaces in the reference --
+``create_pileup`` / ``repeat_annotate`` / ``break_reads`` (chop.hpp:366-372) -- for Python
+callers (tests, bench.py, the multi-GPU driver).  There is no CPU fallback: if the HIP
+library is missing or no gfx950 device is present, construction fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from .params import RaftParams
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libraft_hip.so")
+
+OK, ERR_PARAM, ERR_READ_ID, ERR_COORD, ERR_FRAGMENT, ERR_NOMEM, ERR_DEVICE, ERR_STATE, ERR_TOO_LARGE = range(9)
+
+EXPORTS = (
+    "raft_hip_abi_version", "raft_hip_strerror", "raft_hip_last_error", "raft_hip_create", "raft_hip_destroy",
+    "raft_hip_set_params", "raft_hip_set_stream", "raft_hip_get_stream", "raft_hip_run_device", "raft_hip_run_host",
+    "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
+    "raft_hip_selftest",
+)
+
+
+class _Params(C.Structure):
+    _fields_ = [("reso", C.c_int32), ("est_cov", C.c_int32), ("cov_mul", C.c_double),
+                ("repeat_length", C.c_int32), ("interval_length", C.c_int32), ("read_length", C.c_int32),
+                ("overlap_length", C.c_int32), ("flanking_length", C.c_int32), ("symmetric_mode", C.c_int32)]
+
+
+class _Summary(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("symmetric", C.c_int32), ("high_cov", C.c_int32),
+                ("interval_path", C.c_int32), ("n_segments", C.c_int32),
+                ("n_records", C.c_int64), ("n_intervals", C.c_int64), ("n_bins", C.c_int64),
+                ("n_repeats", C.c_int64), ("n_cuts", C.c_int64), ("n_fragments", C.c_int64),
+                ("total_coverage", C.c_int64), ("total_windows", C.c_int64),
+                ("total_repeat_length", C.c_int64), ("total_read_length", C.c_int64),
+                ("error_index", C.c_int64)]
+
+
+class _Outputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("cov_offset", "cov", "rep_offset", "rep_s", "rep_e", "cut_offset", "cuts",
+                                          "frag_offset", "frag_read", "frag_begin", "frag_end")]
+
+
+@dataclass
+class Summary:
+    n_reads: int
+    symmetric: int
+    high_cov: int
+    interval_path: int
+    n_segments: int
+    n_records: int
+    n_intervals: int
+    n_bins: int
+    n_repeats: int
+    n_cuts: int
+    n_fragments: int
+    total_coverage: int
+    total_windows: int
+    total_repeat_length: int
+    total_read_length: int
+    error_index: int
+
+
+class RaftError(RuntimeError):
+    def __init__(self, code: int, message: str, index: int = -1):
+        super().__init__(f"raft_hip error {code}: {message}" + (f" (index {index})" if index >= 0 else ""))
+        self.code = code
+        self.index = index
+
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """Loads libraft_hip.so and declares every entry point of include/raft_hip.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the RAFT hot path)")
+    lib = C.CDLL(p)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.raft_hip_abi_version.restype = C.c_int
+    lib.raft_hip_strerror.restype = C.c_char_p
+    lib.raft_hip_strerror.argtypes = [C.c_int]
+    lib.raft_hip_last_error.restype = C.c_char_p
+    lib.raft_hip_last_error.argtypes = [vp]
+    lib.raft_hip_create.argtypes = [C.c_int, C.POINTER(_Params), C.POINTER(vp)]
+    lib.raft_hip_destroy.argtypes = [vp]
+    lib.raft_hip_destroy.restype = None
+    lib.raft_hip_set_params.argtypes = [vp, C.POINTER(_Params)]
+    lib.raft_hip_set_stream.argtypes = [vp, vp]
+    lib.raft_hip_get_stream.argtypes = [vp]
+    lib.raft_hip_get_stream.restype = vp
+    lib.raft_hip_run_device.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.raft_hip_run_host.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.raft_hip_finish.argtypes = [vp, C.POINTER(_Summary)]
+    lib.raft_hip_outputs_device.argtypes = [vp, C.POINTER(_Outputs)]
+    lib.raft_hip_fetch.argtypes = [vp] + [vp] * 11
+    lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.raft_hip_set_tuning.argtypes = [vp, i32, i32]
+    lib.raft_hip_selftest.argtypes = [C.c_int]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _cparams(p: RaftParams) -> _Params:
+    return _Params(p.reso, p.est_cov, p.cov_mul, p.repeat_length, p.interval_length, p.read_length,
+                   p.overlap_length, p.flanking_length, p.symmetric_mode)
+
+
+class _DevArray:
+    """Zero-copy view of a device buffer for ``torch.as_tensor`` (CUDA array interface v2)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str, owner):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr or 0, False), "version": 2}
+        self._owner = owner
+
+
+class Engine:
+    """One context on one MI355X: ``run*`` -> ``finish`` -> ``fetch`` / ``outputs_device``."""
+
+    def __init__(self, params: RaftParams, device: int = 0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        self.params = params
+        cp = _cparams(params)
+        rc = self._lib.raft_hip_create(device, C.byref(cp), C.byref(self._ctx))
+        if rc != OK:
+            self._ctx = C.c_void_p()
+            raise RaftError(rc, self._lib.raft_hip_strerror(rc).decode())
+        self.device = device
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.raft_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, index: int = -1):
+        if rc != OK:
+            msg = self._lib.raft_hip_strerror(rc).decode()
+            detail = self._lib.raft_hip_last_error(self._ctx).decode()
+            raise RaftError(rc, msg + (f" [{detail}]" if detail else ""), index)
+
+    def set_params(self, params: RaftParams):
+        cp = _cparams(params)
+        self._check(self._lib.raft_hip_set_params(self._ctx, C.byref(cp)))
+        self.params = params
+
+    def set_tuning(self, tile_bins: int = 0, force_bucket_path: bool = False):
+        self._check(self._lib.raft_hip_set_tuning(self._ctx, tile_bins, int(force_bucket_path)))
+
+    def use_torch_stream(self):
+        import torch
+        self._check(self._lib.raft_hip_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    # -- passes -----------------------------------------------------------------
+    def run_device(self, read_len, qid, qs, qe, tid, ts, te):
+        """Inputs: int32 torch tensors on this engine's device (kept alive until the next pass)."""
+        import torch
+        cols = (read_len, qid, qs, qe, tid, ts, te)
+        for t in cols:
+            if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+                raise TypeError("run_device needs contiguous int32 CUDA tensors")
+        n_rec = int(qid.numel())
+        for t in cols[2:]:
+            if int(t.numel()) != n_rec:
+                raise ValueError("PAF columns differ in length")
+        self._keep = cols
+        ptr = [C.c_void_p(t.data_ptr() if t.numel() else 0) for t in cols]
+        self._check(self._lib.raft_hip_run_device(self._ctx, int(read_len.numel()), ptr[0], n_rec, *ptr[1:]))
+
+    def run_host(self, read_len, qid, qs, qe, tid, ts, te):
+        cols = [np.ascontiguousarray(np.asarray(a), dtype=np.int32) for a in (read_len, qid, qs, qe, tid, ts, te)]
+        n_rec = cols[1].size
+        for a in cols[2:]:
+            if a.size != n_rec:
+                raise ValueError("PAF columns differ in length")
+        self._keep = cols
+        ptr = [C.c_void_p(a.ctypes.data if a.size else 0) for a in cols]
+        self._check(self._lib.raft_hip_run_host(self._ctx, cols[0].size, ptr[0], n_rec, *ptr[1:]))
+
+    def finish(self) -> Summary:
+        s = _Summary()
+        rc = self._lib.raft_hip_finish(self._ctx, C.byref(s))
+        summ = Summary(**{f: int(getattr(s, f)) for f, _ in _Summary._fields_})
+        self.summary = summ
+        self._check(rc, summ.error_index)
+        return summ
+
+    def timing(self) -> tuple[float, float]:
+        a, b = C.c_double(), C.c_double()
+        self._check(self._lib.raft_hip_last_timing(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def fetch(self, coverage: bool = True) -> dict:
+        """Host copies (numpy) of the finished pass, CSR per read."""
+        s = self.summary
+        n1 = s.n_reads + 1
+        out = {
+            "cov_offset": np.empty(n1, np.int64), "cov": np.empty(s.n_bins if coverage else 0, np.int32),
+            "rep_offset": np.empty(n1, np.int64), "rep_s": np.empty(s.n_repeats, np.int32), "rep_e": np.empty(s.n_repeats, np.int32),
+            "cut_offset": np.empty(n1, np.int64), "cuts": np.empty(s.n_cuts, np.int32),
+            "frag_offset": np.empty(n1, np.int64), "frag_read": np.empty(s.n_fragments, np.int32),
+            "frag_begin": np.empty(s.n_fragments, np.int32), "frag_end": np.empty(s.n_fragments, np.int32),
+        }
+        order = ("cov_offset", "cov", "rep_offset", "rep_s", "rep_e", "cut_offset", "cuts", "frag_offset",
+                 "frag_read", "frag_begin", "frag_end")
+        ptr = [C.c_void_p(out[k].ctypes.data if out[k].size else 0) for k in order]
+        self._check(self._lib.raft_hip_fetch(self._ctx, *ptr))
+        return out
+
+    def outputs_device(self) -> dict:
+        """Zero-copy torch views of the device-resident outputs (valid until the next pass)."""
+        import torch
+        o = _Outputs()
+        self._check(self._lib.raft_hip_outputs_device(self._ctx, C.byref(o)))
+        s = self.summary
+        n1 = s.n_reads + 1
+        spec = {"cov_offset": (n1, "<i8"), "cov": (s.n_bins, "<i4"), "rep_offset": (n1, "<i8"),
+                "rep_s": (s.n_repeats, "<i4"), "rep_e": (s.n_repeats, "<i4"), "cut_offset": (n1, "<i8"),
+                "cuts": (s.n_cuts, "<i4"), "frag_offset": (n1, "<i8"), "frag_read": (s.n_fragments, "<i4"),
+                "frag_begin": (s.n_fragments, "<i4"), "frag_end": (s.n_fragments, "<i4")}
+        res = {}
+        for k, (n, ts) in spec.items():
+            if n == 0:
+                res[k] = torch.empty(0, dtype=torch.int64 if ts == "<i8" else torch.int32, device=f"cuda:{self.device}")
+            else:
+                res[k] = torch.as_tensor(_DevArray(getattr(o, k), n, ts, self), device=f"cuda:{self.device}")
+        return res
+
+
+def selftest(device: int = 0) -> int:
+    return int(load_library().raft_hip_selftest(device))

@@ -1,0 +1,46 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/raft_hip.h declares."""
+import os
+import re
+
+import pytest
+from raft_testlib import ROOT
+
+from raft_amd import engine
+from raft_amd.params import RaftParams
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "raft_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(raft_hip_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(engine.EXPORTS)
+
+
+def test_library_exports_every_symbol():
+    lib = engine.load_library()
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.raft_hip_abi_version() == 1
+    assert lib.raft_hip_strerror(2).decode().startswith("PAF record names a read id")
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(engine.RaftError) as e:
+        engine.Engine(RaftParams(est_cov=30))
+    assert e.value.code == engine.ERR_DEVICE
+
+
+def test_invalid_params_rejected_before_any_device_work():
+    lib = engine.load_library()
+    import ctypes as C
+    ctx = C.c_void_p()
+    bad = engine._cparams(RaftParams(est_cov=0))
+    assert lib.raft_hip_create(0, C.byref(bad), C.byref(ctx)) == engine.ERR_PARAM
+    bad = engine._cparams(RaftParams(est_cov=3, read_length=100, interval_length=200, repeat_length=200))
+    assert lib.raft_hip_create(0, C.byref(bad), C.byref(ctx)) == engine.ERR_PARAM
