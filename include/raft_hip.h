@@ -114,9 +114,11 @@ int  raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx 
 void raft_hip_destroy(raft_hip_ctx *ctx);
 int  raft_hip_set_params(raft_hip_ctx *ctx, const raft_hip_params *params);
 
-/* Use `stream` (a hipStream_t) for all work of this context instead of the
- * context's own stream; NULL restores the own stream. */
+/* Use `stream` (a hipStream_t; NULL = the device's default stream, which is what
+ * torch.cuda.current_stream() is unless the caller changed it) for all work of this
+ * context; raft_hip_use_own_stream() switches back to the context's private stream. */
 int  raft_hip_set_stream(raft_hip_ctx *ctx, void *stream);
+int  raft_hip_use_own_stream(raft_hip_ctx *ctx);
 void *raft_hip_get_stream(raft_hip_ctx *ctx);
 
 /* One pass of the hot path over inputs that already live in device memory

@@ -215,7 +215,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_iv,
                      &c->tile_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
@@ -243,7 +243,14 @@ int raft_hip_set_params(raft_hip_ctx *c, const raft_hip_params *params)
 int raft_hip_set_stream(raft_hip_ctx *c, void *stream)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
-    c->stream = stream ? (hipStream_t)stream : c->own_stream;
+    c->stream = (hipStream_t)stream;
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_use_own_stream(raft_hip_ctx *c)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    c->stream = c->own_stream;
     return RAFT_HIP_OK;
 }
 

@@ -260,7 +260,11 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
         const unsigned long long SB0 = __ballot(nib & 1u), SB1 = __ballot(nib & 2u),
                                  SB2 = __ballot(nib & 4u), SB3 = __ballot(nib & 8u);
         // P_k: the slot before (lane,k) is a high window
-        const unsigned long long P0 = (M3 << 1) | (hp ? 1ull : 0ull), P1 = M0, P2 = M1, P3 = M2;
+        // the carried-in bit belongs to the first valid slot: slot off0 of row 0, else slot 0 of the row
+        const unsigned long long hb = hp ? 1ull : 0ull;
+        const int hk = (row == 0) ? off0 : 0;
+        const unsigned long long P0 = (M3 << 1) | (hk == 0 ? hb : 0ull), P1 = M0 | (hk == 1 ? hb : 0ull),
+                                 P2 = M1 | (hk == 2 ? hb : 0ull), P3 = M2 | (hk == 3 ? hb : 0ull);
         const unsigned long long CL0 = P0 & (~M0 | SB0) & VE0, CL1 = P1 & (~M1 | SB1) & VE1,
                                  CL2 = P2 & (~M2 | SB2) & VE2, CL3 = P3 & (~M3 | SB3) & VE3; // run ends before this slot
         const unsigned long long CA0 = M0 & (~P0 | SB0), CA1 = M1 & (~P1 | SB1),

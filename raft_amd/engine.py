@@ -21,7 +21,7 @@ OK, ERR_PARAM, ERR_READ_ID, ERR_COORD, ERR_FRAGMENT, ERR_NOMEM, ERR_DEVICE, ERR_
 
 EXPORTS = (
     "raft_hip_abi_version", "raft_hip_strerror", "raft_hip_last_error", "raft_hip_create", "raft_hip_destroy",
-    "raft_hip_set_params", "raft_hip_set_stream", "raft_hip_get_stream", "raft_hip_run_device", "raft_hip_run_host",
+    "raft_hip_set_params", "raft_hip_set_stream", "raft_hip_use_own_stream", "raft_hip_get_stream", "raft_hip_run_device", "raft_hip_run_host",
     "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
     "raft_hip_selftest",
 )
@@ -87,6 +87,12 @@ def load_library(path: str | None = None) -> C.CDLL:
     if not os.path.exists(p):
         raise RuntimeError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the RAFT hot path)")
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64.so.7.  It must be the first HIP runtime in the process:
+        # loading the system one (our DT_NEEDED) first leaves torch with a second, device-less runtime.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.raft_hip_abi_version.restype = C.c_int
@@ -99,6 +105,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_destroy.restype = None
     lib.raft_hip_set_params.argtypes = [vp, C.POINTER(_Params)]
     lib.raft_hip_set_stream.argtypes = [vp, vp]
+    lib.raft_hip_use_own_stream.argtypes = [vp]
     lib.raft_hip_get_stream.argtypes = [vp]
     lib.raft_hip_get_stream.restype = vp
     lib.raft_hip_run_device.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp]
@@ -184,6 +191,7 @@ class Engine:
             if int(t.numel()) != n_rec:
                 raise ValueError("PAF columns differ in length")
         self._keep = cols
+        self.use_torch_stream()     # the tensors were produced on torch's current stream: order after it
         ptr = [C.c_void_p(t.data_ptr() if t.numel() else 0) for t in cols]
         self._check(self._lib.raft_hip_run_device(self._ctx, int(read_len.numel()), ptr[0], n_rec, *ptr[1:]))
 
