@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-bins", type=int, default=0)
     ap.add_argument("--force-bucket", action="store_true")
+    ap.add_argument("--variant", type=int, default=-1, help="pileup kernel variant (engine.hip kVariants), -1 = default")
     args = ap.parse_args()
 
     import torch
@@ -104,7 +105,7 @@ def main():
     torch.cuda.synchronize()
 
     eng = engine.Engine(p, device=local)
-    eng.set_tuning(args.tile_bins, args.force_bucket)
+    eng.set_tuning(args.tile_bins, args.force_bucket, args.variant)
     eng.use_torch_stream()
     frag_totals = torch.zeros(n_gpus, dtype=torch.int64, device=dev)
 
@@ -165,7 +166,7 @@ def main():
                        "interval_path": "sorted-segments" if s.interval_path == 0 else "counting-sort",
                        "segments": s.n_segments, "sharding": f"reads x{n_gpus}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "pileup_kernel<256,7424>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "pileup_kernel" + ("" if args.variant < 0 else f" variant {args.variant}"),
                          "kernel_ms": pile * 1e3, "bytes_algorithmic": bytes_alg,
                          "pass_device_ms": sum(pass_t) / len(pass_t) * 1e3},
         }

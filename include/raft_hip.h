@@ -154,9 +154,14 @@ int  raft_hip_fetch(raft_hip_ctx *ctx, int64_t *cov_offset, int32_t *cov,
  * context's stream around them. */
 int  raft_hip_last_timing(raft_hip_ctx *ctx, double *pileup_seconds, double *pass_seconds);
 
-/* Tuning knobs (optional): tile quantum in bins for the pileup kernel's
- * read->workgroup map; 0 keeps the default. */
-int  raft_hip_set_tuning(raft_hip_ctx *ctx, int32_t tile_bins, int32_t force_bucket_path);
+/* Tuning knobs (optional): tile quantum in windows for the pileup kernel's read->workgroup map
+ * (0 = the variant's default), force the counting-sort interval path, and the pileup kernel
+ * variant (-1 = default; see kVariants in raft_amd/csrc/engine.hip). */
+int  raft_hip_set_tuning(raft_hip_ctx *ctx, int32_t tile_bins, int32_t force_bucket_path, int32_t variant);
+
+/* Diagnostic variant (5) only: copies the per-workgroup s_memtime stamps of the last pass
+ * (16 uint64 per tile) to `host`; *n_tiles receives the number of tiles of that pass. */
+int  raft_hip_debug_stamps(raft_hip_ctx *ctx, unsigned long long *host, int64_t max_tiles, int64_t *n_tiles);
 
 /* On-device self test of the wavefront primitives (scan, ballots); 0 = pass. */
 int  raft_hip_selftest(int device_id);

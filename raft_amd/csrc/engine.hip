@@ -7,6 +7,7 @@
 #include "device_scan.hpp"
 #include "finalize.hpp"
 #include "pileup.hpp"
+#include "pileup_wave.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -18,10 +19,40 @@ using namespace raft;
 
 namespace {
 
-constexpr int kPileThreads = 256;
-constexpr int kPileCap = 7424;        // windows staged in LDS per workgroup (31.9 KB -> 5 workgroups per CU)
-constexpr int kShortMax = 2048;       // reads with more windows than this may be split off into chunk mode
-constexpr int kDefaultTile = kPileCap - kShortMax; // tile quantum Q
+// Pileup kernel variants (THREADS, CAP = windows staged in LDS per workgroup, MINW = waves per SIMD asked of the
+// register allocator).  The tile quantum Q defaults to CAP - short_max: a tile whose reads all have at most
+// short_max windows then always fits one LDS window.
+struct PileVariant { int threads, cap, minw, short_max; };
+constexpr PileVariant kVariants[] = {
+    {256, 7424, 4, 2048},   // 0: 34 KB LDS, 4 workgroups/CU
+    {256, 6912, 5, 2048},   // 1: 32 KB LDS, 5 workgroups/CU
+    {256, 3584, 8, 1024},   // 2: 19 KB LDS, 8 workgroups/CU
+    {512, 15104, 4, 4096},  // 3: 64 KB LDS, 2 workgroups/CU of 8 waves
+    {256, 5376, 6, 1536},   // 4: 26 KB LDS, 6 workgroups/CU
+    {256, 6912, 5, 2048},   // 5: variant 1 with s_memtime stamps (diagnostic build; raft_hip_debug_stamps)
+    {256, 1536, 5, 512},    // 6: wave-per-tile kernel, 4 waves x 7.9 KB LDS, 5 workgroups/CU
+    {256, 1792, 4, 768},    // 7: wave-per-tile kernel, 4 waves x 8.9 KB LDS, 4 workgroups/CU
+    {256, 1024, 6, 384},    // 8: wave-per-tile kernel, 4 waves x 5.8 KB LDS, 6 workgroups/CU
+};
+constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+constexpr int kDefaultVariant = 1;
+
+template <int WPB, int CAPW, int MINW>
+void launch_pileup_wave(hipStream_t st, int blocks_per_cu, const PileupArgs &pa, const TileDesc *td, long long n_tiles,
+                        long long *wave_sums, long long *n_waves)
+{
+    long long grid = std::min<long long>((n_tiles + WPB - 1) / WPB, 256LL * blocks_per_cu);
+    if (grid < 1) grid = 1;
+    *n_waves = grid * WPB;
+    hipLaunchKernelGGL((pileup_wave_kernel<WPB, CAPW, MINW>), dim3((unsigned)grid), dim3(WPB * 64), 0, st, pa, td, n_tiles,
+                       wave_sums);
+}
+
+template <int T, int CAP, int MINW, bool DIAG = false>
+void launch_pileup(hipStream_t st, unsigned grid, const PileupArgs &pa)
+{
+    hipLaunchKernelGGL((pileup_kernel<T, CAP, MINW, DIAG>), dim3(grid), dim3(T), 0, st, pa);
+}
 
 struct Ctrl {                         // device control block, cleared every pass
     int32_t err_flags;
@@ -95,16 +126,20 @@ struct raft_hip_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     raft_hip_params prm{};
     int32_t high_cov = 0, div = 0, minbins = 1;
-    int32_t tile_q = kDefaultTile;
+    int32_t tile_q = 0;               // 0 = variant default
+    int32_t variant = kDefaultVariant;
     int32_t force_bucket = 0;
     std::string last_error;
 
     // device buffers
-    DevBuf ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_iv, tile_sums;
+    DevBuf ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_iv, tile_glo, tile_sums;
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
+    DevBuf dbg;                       // diagnostic variant only
+    DevBuf tile_desc;                 // wave-per-tile variants
+    long long dbg_tiles = 0;
     void *pinned = nullptr;           // small pinned scratch for readbacks
     hipEvent_t ev_pass0 = nullptr, ev_pass1 = nullptr, ev_pile0 = nullptr, ev_pile1 = nullptr;
 
@@ -216,11 +251,11 @@ void raft_hip_destroy(raft_hip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_iv,
+    DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_iv, &c->tile_glo,
                      &c->tile_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->tile_desc, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -256,11 +291,14 @@ int raft_hip_use_own_stream(raft_hip_ctx *c)
 
 void *raft_hip_get_stream(raft_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
-int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket_path)
+int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket_path, int32_t variant)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
-    if (tile_bins < 0 || tile_bins > kPileCap) return RAFT_HIP_ERR_PARAM;
-    c->tile_q = tile_bins ? tile_bins : kDefaultTile;
+    if (variant < -1 || variant >= kNumVariants) return RAFT_HIP_ERR_PARAM;
+    const int v = variant < 0 ? kDefaultVariant : variant;
+    if (tile_bins < 0 || tile_bins > kVariants[v].cap) return RAFT_HIP_ERR_PARAM;
+    c->variant = v;
+    c->tile_q = tile_bins;
     c->force_bucket = force_bucket_path ? 1 : 0;
     return RAFT_HIP_OK;
 }
@@ -318,13 +356,15 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     }
     c->sum.n_bins = B; c->sum.total_windows = B;
     c->cap_rep = RU; c->cap_cut = CU;
-    const int Q = c->tile_q;
+    const PileVariant &pv = kVariants[c->variant];
+    const int Q = c->tile_q ? std::min(c->tile_q, pv.cap) : pv.cap - pv.short_max;
     const long long n_tiles = B / Q + 1;
     if (n_tiles + 1 >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;
 
     HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
     HIP_TRY(c, c->tile_first.ensure((size_t)(n_tiles + 1) * 4));
     HIP_TRY(c, c->tile_iv.ensure((size_t)(n_tiles + 1) * 8 * kMaxSeg));
+    HIP_TRY(c, c->tile_glo.ensure((size_t)(n_tiles + 1) * 8));
     HIP_TRY(c, c->tile_sums.ensure((size_t)n_tiles * 16));
     HIP_TRY(c, c->rep_cnt.ensure((size_t)std::max(N, 1LL) * 4));
     HIP_TRY(c, c->cut_cnt.ensure((size_t)std::max(N, 1LL) * 4));
@@ -378,23 +418,42 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     pa.cov = c->cov.as<int32_t>(); pa.rep_res_off = c->rep_res_off.as<long long>(); pa.rep_cnt = c->rep_cnt.as<int32_t>();
     pa.raw_key = c->raw_key.as<int32_t>(); pa.raw_s = c->raw_s.as<int32_t>(); pa.raw_e = c->raw_e.as<int32_t>();
     pa.tile_sums = c->tile_sums.as<long long>(); pa.err_flags = &ctrl->err_flags; pa.err_index = &ctrl->err_index;
-    pa.tile_iv = c->tile_iv.as<long long>();
+    pa.tile_iv = c->tile_iv.as<long long>(); pa.tile_glo = c->tile_glo.as<long long>();
+    {   // n / reso as mulhi + shift, exact for 0 <= n < 2^31: with L = ceil(log2 reso) and
+        // m = floor(2^(31+L) / reso) + 1 (< 2^32), n / reso == (n * m) >> (31 + L) == mulhi(n, m) >> (L - 1)
+        const unsigned d = (unsigned)c->prm.reso;
+        if (d == 1) { pa.div_magic = 0; pa.div_shift = -1; }
+        else {
+            int L = 0;
+            while ((1ull << L) < d) ++L;
+            pa.div_magic = (uint32_t)((1ull << (31 + L)) / d + 1ull);
+            pa.div_shift = L - 1;
+        }
+    }
 
     const bool fast = n_rec > 0 && symmetric && !c->force_bucket && n_desc + 1 <= kMaxSeg;
+    const bool wave_kernel = c->variant >= 6;
     const unsigned tgrid = (unsigned)((n_tiles + 1 + 255) / 256);
+    SegBounds sb{};
+    const long long *seg_end_dev = nullptr;
     if (n_rec == 0) {
         pa.n_seg = 0;
+        if (!wave_kernel)
+        hipLaunchKernelGGL(tile_iv_kernel, dim3(tgrid, 1), dim3(256), 0, st, sb, (const long long *)nullptr,
+                           (const int32_t *)nullptr, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), n_tiles + 1,
+                           c->tile_iv.as<long long>(), c->tile_glo.as<long long>());
         c->sum.interval_path = 0; c->sum.n_segments = 0; c->sum.n_intervals = 0;
     } else if (fast) {
-        SegBounds sb{};
         std::sort(desc, desc + n_desc);
         sb.n_seg = n_desc + 1;
         sb.start[0] = 0;
         for (int i = 0; i < n_desc; ++i) sb.start[i + 1] = desc[i];
         sb.start[n_desc + 1] = n_rec;
         pa.iv_rid = d_qid; pa.iv_s = d_qs; pa.iv_e = d_qe; pa.n_seg = sb.n_seg;
+        if (!wave_kernel)
         hipLaunchKernelGGL(tile_iv_kernel, dim3(tgrid, sb.n_seg), dim3(256), 0, st, sb, (const long long *)nullptr,
-                           d_qid, c->tile_first.as<int32_t>(), n_tiles + 1, c->tile_iv.as<long long>());
+                           d_qid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), n_tiles + 1,
+                           c->tile_iv.as<long long>(), c->tile_glo.as<long long>());
         c->sum.interval_path = 0; c->sum.n_segments = sb.n_seg; c->sum.n_intervals = n_rec;
     } else {
         const long long cap_iv = symmetric ? (long long)n_rec : 2 * (long long)n_rec;
@@ -417,19 +476,49 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads, symmetric, d_qid,
                            d_qs, d_qe, d_tid, d_ts, d_te, c->b_off.as<long long>(), c->b_cnt.as<int32_t>(),
                            c->b_rid.as<int32_t>(), c->b_s.as<int32_t>(), c->b_e.as<int32_t>());
-        SegBounds sb{};
         sb.n_seg = 1; sb.start[0] = 0; sb.start[1] = cap_iv;
+        seg_end_dev = c->b_off.as<long long>() + N;
         pa.iv_rid = c->b_rid.as<int32_t>(); pa.iv_s = c->b_s.as<int32_t>(); pa.iv_e = c->b_e.as<int32_t>(); pa.n_seg = 1;
-        // the true interval count lives at b_off[N]; tile_iv_kernel reads it from there
+        // the true interval count lives at b_off[N]; the tile kernels read it from there
+        if (!wave_kernel)
         hipLaunchKernelGGL(tile_iv_kernel, dim3(tgrid, 1), dim3(256), 0, st, sb, c->b_off.as<long long>() + N,
-                           c->b_rid.as<int32_t>(), c->tile_first.as<int32_t>(), n_tiles + 1, c->tile_iv.as<long long>());
+                           c->b_rid.as<int32_t>(), c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), n_tiles + 1,
+                           c->tile_iv.as<long long>(), c->tile_glo.as<long long>());
         c->sum.interval_path = 1; c->sum.n_segments = n_desc + 1; c->sum.n_intervals = -1; // read back in finish
         (void)iv_total;
     }
 
+    pa.dbg = nullptr;
+    if (c->variant == 5) {
+        HIP_TRY(c, c->dbg.ensure((size_t)n_tiles * 16 * 8));
+        HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, (size_t)n_tiles * 16 * 8, st));
+        pa.dbg = c->dbg.as<unsigned long long>();
+        c->dbg_tiles = n_tiles;
+    }
+    long long n_sum_rows = n_tiles;           // rows of (coverage, repeat bp) partial sums the totals kernel reduces
+    if (wave_kernel) {
+        SegStarts ss{};
+        ss.n_seg = pa.n_seg;
+        for (int i = 0; i <= kMaxSeg; ++i) ss.start[i] = sb.start[i];
+        HIP_TRY(c, c->tile_desc.ensure((size_t)n_tiles * sizeof(TileDesc)));
+        hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, n_tiles, ss,
+                           seg_end_dev, pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(),
+                           c->tile_desc.as<TileDesc>());
+        HIP_TRY(c, c->tile_sums.ensure((size_t)std::max<long long>(n_tiles, 256LL * 8 * 4) * 16));
+    }
     // ---- the dominant kernel
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
-    hipLaunchKernelGGL((pileup_kernel<kPileThreads, kPileCap>), dim3((unsigned)n_tiles), dim3(kPileThreads), 0, st, pa);
+    switch (c->variant) {
+    case 0: launch_pileup<256, 7424, 4>(st, (unsigned)n_tiles, pa); break;
+    case 1: launch_pileup<256, 6912, 5>(st, (unsigned)n_tiles, pa); break;
+    case 2: launch_pileup<256, 3584, 8>(st, (unsigned)n_tiles, pa); break;
+    case 3: launch_pileup<512, 15104, 4>(st, (unsigned)n_tiles, pa); break;
+    case 4: launch_pileup<256, 5376, 6>(st, (unsigned)n_tiles, pa); break;
+    case 5: launch_pileup<256, 6912, 5, true>(st, (unsigned)n_tiles, pa); break;
+    case 6: launch_pileup_wave<4, 1536, 5>(st, 5, pa, c->tile_desc.as<TileDesc>(), n_tiles, c->tile_sums.as<long long>(), &n_sum_rows); break;
+    case 7: launch_pileup_wave<4, 1792, 4>(st, 4, pa, c->tile_desc.as<TileDesc>(), n_tiles, c->tile_sums.as<long long>(), &n_sum_rows); break;
+    default: launch_pileup_wave<4, 1024, 6>(st, 6, pa, c->tile_desc.as<TileDesc>(), n_tiles, c->tile_sums.as<long long>(), &n_sum_rows); break;
+    }
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
 
     // ---- per-read tail: order repeats, mask markers, fragments
@@ -456,7 +545,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     }
     {
         const unsigned g = (unsigned)std::min<long long>((std::max(n_tiles, N) + 255) / 256, 1024);
-        hipLaunchKernelGGL(totals_kernel, dim3(std::max(g, 1u)), dim3(256), 0, st, n_tiles, c->tile_sums.as<long long>(),
+        hipLaunchKernelGGL(totals_kernel, dim3(std::max(g, 1u)), dim3(256), 0, st, n_sum_rows, c->tile_sums.as<long long>(),
                            n_reads, d_len, ctrl->totals);
     }
     HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
@@ -560,6 +649,16 @@ int raft_hip_last_timing(raft_hip_ctx *c, double *pileup_seconds, double *pass_s
     float ms = 0.f;
     if (pileup_seconds) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pile0, c->ev_pile1)); *pileup_seconds = ms * 1e-3; }
     if (pass_seconds) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pass0, c->ev_pass1)); *pass_seconds = ms * 1e-3; }
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_debug_stamps(raft_hip_ctx *c, unsigned long long *host, int64_t max_tiles, int64_t *n_tiles)
+{
+    if (!c || !n_tiles) return RAFT_HIP_ERR_PARAM;
+    if (!c->finished || c->variant != 5) return RAFT_HIP_ERR_STATE;
+    *n_tiles = c->dbg_tiles;
+    const long long n = std::min<long long>(max_tiles, c->dbg_tiles);
+    if (host && n > 0) HIP_TRY(c, hipMemcpy(host, c->dbg.p, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
     return RAFT_HIP_OK;
 }
 

@@ -33,7 +33,7 @@
 
 namespace raft {
 
-constexpr int kMaxSeg = 8;
+constexpr int kMaxSeg = 4;   // sorted runs of the record stream the fast path accepts (hifiasm cis+trans = 2)
 
 enum : int {
     kErrReadId = 1 << 0,
@@ -52,10 +52,13 @@ struct PileupArgs {
     const int32_t *read_len;
     const long long *cov_off;   // [n_reads+1]
     const int32_t *tile_first;  // [n_tiles+1]
+    const long long *tile_glo;  // [n_tiles+1] cov_off[tile_first[k]] (saves one dependent load per workgroup)
     long long n_tiles_p1;       // stride of tile_iv rows
     int32_t n_reads;
     // params
     int32_t reso, high_cov, repeat_length, flank;
+    uint32_t div_magic;           // n / reso == mulhi(n, div_magic) >> div_shift for 0 <= n < 2^31 (reso > 1)
+    int32_t div_shift;            // -1: reso == 1
     // outputs
     int32_t *cov;
     const long long *rep_res_off; // [n_reads+1] reserved slots for raw repeats
@@ -64,6 +67,7 @@ struct PileupArgs {
     long long *tile_sums;         // [2*n_tiles]: sum of coverage, sum of unclamped repeat bp
     int32_t *err_flags;           // device word, OR of kErr*
     long long *err_index;         // first offending interval index (min)
+    unsigned long long *dbg;      // diagnostic build only: [n_tiles][16] s_memtime stamps
 };
 
 constexpr int kOpen = -2; // run began before this wave's first window
@@ -74,15 +78,29 @@ struct PileupSmem {
     static constexpr int NW = THREADS / 64;
     static constexpr int SLOTS = CAP + 256; // window slots: 3 alignment + CAP + 1 sentinel, rounded to rows
     static constexpr int SBW = SLOTS / 32;
+    static constexpr int MAXR = 510;       // reads per window whose offsets are staged in LDS
     int32_t diff[SLOTS];
     uint32_t sbits[SBW];
-    long long iv_lo[kMaxSeg], iv_hi[kMaxSeg];
+    int32_t roff[MAXR + 2];                 // first slot of read r_a+j relative to a0 (j <= nr)
     unsigned long long acc_cov, acc_rep;
     long long carry_open;
     int32_t carry_hp;
     int32_t wsum[NW];
     int32_t w_rows[NW], w_pclose[NW], w_sfinal[NW], w_hpfinal[NW], w_hpin[NW];
 };
+
+// window index of base n (0 <= n < 2^31): n / reso without a hardware divide
+__device__ __forceinline__ unsigned win_of(const PileupArgs &a, unsigned n)
+{
+    return a.div_shift < 0 ? n : (__umulhi(n, a.div_magic) >> a.div_shift);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global
+// stores (s_waitcnt vmcnt(0)), which would park every wave behind its own coverage stores.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ void raise_error(const PileupArgs &a, int flag, long long idx)
 {
@@ -126,6 +144,16 @@ __device__ __forceinline__ void emit_run(const PileupArgs &a, Smem &sm, int r_a,
     atomicAdd(&sm.acc_rep, (unsigned long long)(end - start)); // repeat.hpp:127,152
 }
 
+// same search with wave-uniform arguments: keeps the loop in scalar registers
+__device__ __forceinline__ long long lower_bound_rid_uni(const int32_t *iv_rid, long long lo, long long hi, int r)
+{
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (uni(iv_rid[mid]) < r) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 // lower bound of read id `r` in iv_rid[lo, hi)
 __device__ __forceinline__ long long lower_bound_rid(const int32_t *iv_rid, long long lo, long long hi, int r)
 {
@@ -138,63 +166,117 @@ __device__ __forceinline__ long long lower_bound_rid(const int32_t *iv_rid, long
 
 // One LDS window: global windows [w_lo, w_hi) (at most CAP) belonging to reads [r_a, r_b).
 // single_read: the window is a chunk of one long read r_a (intervals are clipped to the chunk).
-template <int THREADS, int CAP>
+#define RAFT_STAMP(slot)                                                                              \
+    do {                                                                                              \
+        if (DIAG && threadIdx.x == 0 && a.dbg) a.dbg[(long long)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+template <int THREADS, int CAP, bool DIAG>
 __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, int r_a, int r_b,
-                            long long w_lo, long long w_hi, bool single_read, bool first_chunk, bool last_chunk)
+                            long long w_lo, long long w_hi, bool single_read, bool first_chunk, bool last_chunk,
+                            const long long (&seg_lo)[kMaxSeg], const int (&seg_cum)[kMaxSeg + 1])
 {
     using Smem = PileupSmem<THREADS, CAP>;
     constexpr int NW = Smem::NW;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = uni((int)(threadIdx.x >> 6)); // wave-uniform: keeps row counters, carries and ballots in SGPRs
     const long long a0 = w_lo & ~3LL;          // 16-byte aligned base of the staged range
     const int off0 = (int)(w_lo - a0);         // first valid slot
     const int t_end = off0 + (int)(w_hi - w_lo); // one past the last valid slot
     const int rows = (t_end + 1 + 255) >> 8;   // rows of 256 slots, sentinel slot included
 
-    // 1. clear the difference array and the read-start bits
+    // 0. issue the global loads first: the reads' first windows and the first four intervals per lane.
+    //    Intervals of all segments form one virtual range [0, n_iv); v -> (segment, index).
+    const int nr = r_b - r_a;
+    const bool use_tab = nr <= Smem::MAXR;
+    const int n_iv = seg_cum[kMaxSeg];
+    long long cv0 = 0, cv1 = 0;
+    if (use_tab) {
+        if (tid <= nr) cv0 = a.cov_off[r_a + tid];
+        if (tid + THREADS <= nr) cv1 = a.cov_off[r_a + tid + THREADS];
+    }
+    auto iv_index = [&](int v) -> long long {
+        long long idx = seg_lo[0] + v;
+#pragma unroll
+        for (int s = 1; s < kMaxSeg; ++s)
+            if (v >= seg_cum[s]) idx = seg_lo[s] + (v - seg_cum[s]);
+        return idx;
+    };
+    int rid[4], st[4], en[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int v = tid + u * THREADS;
+        const bool ok = v < n_iv;
+        const long long i = ok ? iv_index(v) : 0;
+        rid[u] = ok ? a.iv_rid[i] : -1;
+        st[u] = ok ? a.iv_s[i] : 0;
+        en[u] = ok ? a.iv_e[i] : 0;
+    }
+
+    // 1. clear the difference array and the read-start bits while those loads fly; stage the offsets
     for (int i = tid * 4; i < rows * 256; i += THREADS * 4)
         *reinterpret_cast<int4 *>(&sm.diff[i]) = make_int4(0, 0, 0, 0);
     for (int i = tid; i < rows * 8; i += THREADS) sm.sbits[i] = 0u;
-    __syncthreads();
+    if (use_tab) {
+        if (tid <= nr) sm.roff[tid] = (int)(cv0 - a0);
+        if (tid + THREADS <= nr) sm.roff[tid + THREADS] = (int)(cv1 - a0);
+    }
+    lds_barrier();
+    RAFT_STAMP(2);
 
     // 2. read-start bits (a run never continues across a read boundary, repeat.hpp:111-112)
     if (single_read) {
         if (first_chunk && tid == 0) sm.sbits[0] = 1u << off0;
     } else {
-        for (int rr = r_a + tid; rr < r_b; rr += THREADS) {
-            const int p = (int)(a.cov_off[rr] - a0);
+        for (int j = tid; j < nr; j += THREADS) {
+            const int p = use_tab ? sm.roff[j] : (int)(a.cov_off[r_a + j] - a0);
             atomicOr(&sm.sbits[p >> 5], 1u << (p & 31));
         }
     }
 
-    // 3. intervals -> +1 / -1 (profileCoverage, closed form)
-    for (int s = 0; s < a.n_seg; ++s) {
-        const long long lo = sm.iv_lo[s], hi = sm.iv_hi[s];
-        for (long long i = lo + tid; i < hi; i += THREADS) {
-            const int rid = a.iv_rid[i];
-            const int st = a.iv_s[i];
-            const int en = a.iv_e[i];
-            if ((st | en) < 0) { raise_error(a, kErrCoord, i); continue; }
-            const int first = st / a.reso;
-            int last = (en > 0) ? (en - 1) / a.reso : -1;
+    // 3. intervals -> +1 / -1 (profileCoverage, closed form); four records in flight per lane
+    for (int v0 = tid; v0 < n_iv; v0 += THREADS * 4) {
+        if (v0 != tid) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = v0 + u * THREADS;
+                const bool ok = v < n_iv;
+                const long long i = ok ? iv_index(v) : 0;
+                rid[u] = ok ? a.iv_rid[i] : -1;
+                st[u] = ok ? a.iv_s[i] : 0;
+                en[u] = ok ? a.iv_e[i] : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (rid[u] < 0) continue;
+            if ((st[u] | en[u]) < 0) { raise_error(a, kErrCoord, iv_index(v0 + u * THREADS)); continue; }
+            const int first = (int)win_of(a, (unsigned)st[u]);
+            int last = (en[u] > 0) ? (int)win_of(a, (unsigned)(en[u] - 1)) : -1;
             if (last < first) continue;
-            const long long c0 = a.cov_off[rid];
-            const int nb_r = (int)(a.cov_off[rid + 1] - c0);
-            if (last >= nb_r) {                 // reference writes past its vector here (repeat.hpp:69-72)
-                raise_error(a, kErrCoord, i);
+            int b0, nb_r;
+            if (use_tab) { const int j = rid[u] - r_a; b0 = sm.roff[j]; nb_r = sm.roff[j + 1] - b0; }
+            else {
+                const long long c0 = a.cov_off[rid[u]];
+                b0 = (int)(c0 - a0); nb_r = (int)(a.cov_off[rid[u] + 1] - c0);
+            }
+            if (last >= nb_r) {             // reference writes past its vector here (repeat.hpp:69-72)
+                raise_error(a, kErrCoord, iv_index(v0 + u * THREADS));
                 last = nb_r - 1;
                 if (last < first) continue;
             }
-            long long gf = c0 + first, gl1 = c0 + last + 1;
+            int pf = b0 + first, pl1 = b0 + last + 1; // slots relative to a0
             if (single_read) {
-                if (gf < w_lo) gf = w_lo;
-                if (gl1 > w_hi) gl1 = w_hi;
-                if (gf >= gl1) continue;
+                pf = max(pf, off0);
+                pl1 = min(pl1, t_end);
+                if (pf >= pl1) continue;
             }
-            __hip_atomic_fetch_add(&sm.diff[(int)(gf - a0)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&sm.diff[(int)(gl1 - a0)], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sm.diff[pf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sm.diff[pl1], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
-    __syncthreads();
+    lds_barrier();
+    RAFT_STAMP(3);
 
     // 4. pass A: per-wave sums of the difference array (each wave owns rpw contiguous rows)
     const int rpw = (rows + NW - 1) / NW;
@@ -209,13 +291,14 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
         s = wave_reduce_add(s);
         if (lane == 0) sm.wsum[wid] = s;
     }
-    __syncthreads();
+    lds_barrier();
+    RAFT_STAMP(4);
 
     // 5. pass B: prefix sum, store, run detection
     int carry = 0;
-    for (int w = 0; w < wid; ++w) carry += sm.wsum[w];
+    for (int w = 0; w < wid; ++w) carry += uni(sm.wsum[w]);
     bool hp; // was the window just before this wave's first slot high (and in the same run domain)?
-    if (wid == 0) hp = single_read && !first_chunk && sm.carry_hp != 0;
+    if (wid == 0) hp = single_read && !first_chunk && uni(sm.carry_hp) != 0;
     else hp = (row_b < rows) && (carry >= a.high_cov);
     const bool hp_in = hp;
     int S = hp ? kOpen : kNone;  // start slot of the run currently open
@@ -231,30 +314,27 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
         const int excl = incl - w + carry;
         carry += __builtin_amdgcn_readlane(incl, 63);
         int c0 = excl + x, c1 = excl + y, c2 = excl + z, c3 = excl + w;
+        // validity of the lane's four slots: off0 <= p0+k < t_end, as one unsigned compare each; the ballots land
+        // in SGPR pairs and are combined with scalar ANDs (no control flow between their definition and their use)
         const bool full = (base >= off0) && (base + 256 <= t_end);
-        unsigned long long M0, M1, M2, M3, VE0, VE1, VE2, VE3;
+        const unsigned q0 = (unsigned)(p0 - off0), nbw_u = (unsigned)(t_end - off0);
+        const unsigned long long VA0 = __ballot(q0 + 0u < nbw_u), VA1 = __ballot(q0 + 1u < nbw_u),
+                                 VA2 = __ballot(q0 + 2u < nbw_u), VA3 = __ballot(q0 + 3u < nbw_u);
+        const unsigned long long M0 = __ballot(c0 >= a.high_cov) & VA0, M1 = __ballot(c1 >= a.high_cov) & VA1,
+                                 M2 = __ballot(c2 >= a.high_cov) & VA2, M3 = __ballot(c3 >= a.high_cov) & VA3;
         if (full) {
             *reinterpret_cast<int4 *>(&a.cov[a0 + p0]) = make_int4(c0, c1, c2, c3);
-            covsum += (long long)c0 + c1 + c2 + c3;
-            M0 = __ballot(c0 >= a.high_cov); M1 = __ballot(c1 >= a.high_cov);
-            M2 = __ballot(c2 >= a.high_cov); M3 = __ballot(c3 >= a.high_cov);
-            VE0 = VE1 = VE2 = VE3 = ~0ull;
+            covsum += (long long)(c0 + c1 + c2 + c3);
         } else {
-            const bool v0 = (p0 + 0 >= off0) && (p0 + 0 < t_end);
-            const bool v1 = (p0 + 1 >= off0) && (p0 + 1 < t_end);
-            const bool v2 = (p0 + 2 >= off0) && (p0 + 2 < t_end);
-            const bool v3 = (p0 + 3 >= off0) && (p0 + 3 < t_end);
-            if (v0) { a.cov[a0 + p0 + 0] = c0; covsum += c0; }
-            if (v1) { a.cov[a0 + p0 + 1] = c1; covsum += c1; }
-            if (v2) { a.cov[a0 + p0 + 2] = c2; covsum += c2; }
-            if (v3) { a.cov[a0 + p0 + 3] = c3; covsum += c3; }
-            M0 = __ballot(v0 && c0 >= a.high_cov); M1 = __ballot(v1 && c1 >= a.high_cov);
-            M2 = __ballot(v2 && c2 >= a.high_cov); M3 = __ballot(v3 && c3 >= a.high_cov);
-            VE0 = __ballot(p0 + 0 < t_end); VE1 = __ballot(p0 + 1 < t_end);
-            VE2 = __ballot(p0 + 2 < t_end); VE3 = __ballot(p0 + 3 < t_end);
+            if ((p0 + 0 >= off0) && (p0 + 0 < t_end)) { a.cov[a0 + p0 + 0] = c0; covsum += c0; }
+            if ((p0 + 1 >= off0) && (p0 + 1 < t_end)) { a.cov[a0 + p0 + 1] = c1; covsum += c1; }
+            if ((p0 + 2 >= off0) && (p0 + 2 < t_end)) { a.cov[a0 + p0 + 2] = c2; covsum += c2; }
+            if ((p0 + 3 >= off0) && (p0 + 3 < t_end)) { a.cov[a0 + p0 + 3] = c3; covsum += c3; }
         }
         if ((M0 | M1 | M2 | M3) == 0ull && !hp) continue; // no high window in or just before this row
 
+        const unsigned long long VE0 = __ballot(p0 + 0 < t_end), VE1 = __ballot(p0 + 1 < t_end),
+                                 VE2 = __ballot(p0 + 2 < t_end), VE3 = __ballot(p0 + 3 < t_end);
         const uint32_t word = sm.sbits[p0 >> 5];
         const uint32_t nib = (word >> (p0 & 31)) & 0xFu;
         const unsigned long long SB0 = __ballot(nib & 1u), SB1 = __ballot(nib & 2u),
@@ -270,22 +350,22 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
         const unsigned long long CA0 = M0 & (~P0 | SB0), CA1 = M1 & (~P1 | SB1),
                                  CA2 = M2 & (~P2 | SB2), CA3 = M3 & (~P3 | SB3);             // run starts at this slot
         if ((CL0 | CL1 | CL2 | CL3) != 0ull) {
-            const unsigned long long bit = 1ull << lane, lt = bit - 1ull, le = lt | bit;
-            const unsigned long long CLk[4] = {CL0, CL1, CL2, CL3};
-            const unsigned long long CAk[4] = {CA0, CA1, CA2, CA3};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (CLk[k] & bit) {
-                    int best = S;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const unsigned long long m = CAk[j] & (j < k ? le : lt);
-                        if (m) best = max(best, base + 4 * top_bit(m) + j);
-                    }
-                    const int t = p0 + k;
-                    if (best == kOpen) pclose = t;
-                    else emit_run(a, sm, r_a, r_b, single_read, a0 + best, a0 + t);
-                }
+            const unsigned long long lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+            unsigned cl4 = (unsigned)((CL0 >> lane) & 1ull) | (unsigned)(((CL1 >> lane) & 1ull) << 1) |
+                           (unsigned)(((CL2 >> lane) & 1ull) << 2) | (unsigned)(((CL3 >> lane) & 1ull) << 3);
+#pragma unroll 1
+            while (cl4) {                        // rare: this lane sees the end of a run
+                const int k = __builtin_ctz(cl4);
+                cl4 &= cl4 - 1u;
+                int best = S;                    // latest run start at a slot before (lane, k)
+                unsigned long long m;
+                m = CA0 & (0 < k ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 0);
+                m = CA1 & (1 < k ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 1);
+                m = CA2 & (2 < k ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 2);
+                m = CA3 & lt;                if (m) best = max(best, base + 4 * top_bit(m) + 3);
+                const int t = p0 + k;
+                if (best == kOpen) pclose = t;
+                else emit_run(a, sm, r_a, r_b, single_read, a0 + best, a0 + t);
             }
         }
         if (CA0) S = max(S, base + 4 * top_bit(CA0) + 0);
@@ -315,88 +395,112 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
             if (covsum) atomicAdd(&sm.acc_cov, (unsigned long long)covsum);
         }
     }
-    __syncthreads();
+    RAFT_STAMP(5);
+    lds_barrier();
+    RAFT_STAMP(6);
 
-    // 7. stitch runs across wave seams and the window end
+    // 7. stitch runs across wave seams and the window end (step w == NW is the window end)
     if (tid == 0) {
         long long open = (single_read && !first_chunk) ? sm.carry_open : -1;
-        for (int w = 0; w < NW; ++w) {
-            if (!sm.w_rows[w]) continue;
-            if (sm.w_hpin[w] && sm.w_pclose[w] >= 0 && open >= 0) {
-                emit_run(a, sm, r_a, r_b, single_read, open, a0 + sm.w_pclose[w]);
-                open = -1;
+#pragma unroll 1
+        for (int w = 0; w <= NW; ++w) {
+            bool do_emit = false;
+            long long gT = 0;
+            if (w < NW) {
+                if (!sm.w_rows[w]) continue;
+                if (sm.w_hpin[w] && sm.w_pclose[w] >= 0 && open >= 0) { do_emit = true; gT = a0 + sm.w_pclose[w]; }
+            } else if (last_chunk && open >= 0) { do_emit = true; gT = w_hi; } // end of read closes the run (repeat.hpp:150)
+            if (do_emit) { emit_run(a, sm, r_a, r_b, single_read, open, gT); open = -1; }
+            if (w < NW) {
+                if (sm.w_hpfinal[w]) { if (sm.w_sfinal[w] != kOpen) open = a0 + sm.w_sfinal[w]; }
+                else open = -1;
             }
-            if (sm.w_hpfinal[w]) {
-                if (sm.w_sfinal[w] != kOpen) open = a0 + sm.w_sfinal[w];
-            } else open = -1;
-        }
-        if (last_chunk && open >= 0) { // end of read closes the run (repeat.hpp:150)
-            emit_run(a, sm, r_a, r_b, single_read, open, w_hi);
-            open = -1;
         }
         sm.carry_open = open;
         sm.carry_hp = open >= 0 ? 1 : 0;
     }
-    __syncthreads();
+    lds_barrier();
 }
 
-template <int THREADS, int CAP>
-__global__ __launch_bounds__(THREADS) void pileup_kernel(PileupArgs a)
+template <int THREADS, int CAP, int MINW, bool DIAG>
+__global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
 {
+    RAFT_STAMP(0);
     using Smem = PileupSmem<THREADS, CAP>;
     __shared__ __attribute__((aligned(16))) Smem sm;
     const int k = blockIdx.x;
     const int tid = threadIdx.x;
-    int r = a.tile_first[k];
-    const int r_hi = a.tile_first[k + 1];
+    const int r_lo = uni(a.tile_first[k]), r_hi = uni(a.tile_first[k + 1]);
+    const long long g_lo_tile = uni(a.tile_glo[k]), g_hi_all = uni(a.tile_glo[k + 1]);
+    if (DIAG && tid == 0 && a.dbg) { a.dbg[(long long)k * 16 + 8] = (unsigned long long)(g_hi_all - g_lo_tile); a.dbg[(long long)k * 16 + 9] = __builtin_amdgcn_s_memrealtime(); }
+    RAFT_STAMP(1);
     if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; sm.carry_open = -1; sm.carry_hp = 0; }
-    if (r >= r_hi) {
+    if (r_lo >= r_hi) {
         if (tid == 0) { a.tile_sums[2 * (long long)k] = 0; a.tile_sums[2 * (long long)k + 1] = 0; }
         return;
     }
-    const long long g_hi_all = a.cov_off[r_hi];
-    while (r < r_hi) {
-        const long long g_lo = a.cov_off[r];
-        int r2;
-        if (g_hi_all - g_lo <= CAP) r2 = r_hi;
-        else {
-            int lo = r, hi = r_hi; // cov_off[lo]-g_lo <= CAP < cov_off[hi]-g_lo
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (a.cov_off[mid] - g_lo <= CAP) lo = mid; else hi = mid;
-            }
-            r2 = lo;
-        }
-        const bool single = (r2 == r);
-        const int r_b = single ? r + 1 : r2;
-        // interval ranges of reads [r, r_b) in every segment
-        __syncthreads();
-        if (tid < a.n_seg) {
-            const long long t_lo = a.tile_iv[(long long)tid * a.n_tiles_p1 + k];
-            const long long t_hi = a.tile_iv[(long long)tid * a.n_tiles_p1 + k + 1];
-            if (r == a.tile_first[k] && r_b == r_hi) { sm.iv_lo[tid] = t_lo; sm.iv_hi[tid] = t_hi; }
+    int r = r_lo;
+    long long chunk_pos = -1, g_first = 0, g_end = 0; // chunk state of a read longer than CAP windows
+    for (;;) {
+        int r_a, r_b;
+        long long w_lo, w_hi;
+        bool single, first, last;
+        if (chunk_pos < 0) {
+            if (r >= r_hi) break;
+            const long long g_lo = (r == r_lo) ? g_lo_tile : uni(a.cov_off[r]);
+            int r2;
+            if (g_hi_all - g_lo <= CAP) r2 = r_hi;
             else {
-                sm.iv_lo[tid] = lower_bound_rid(a.iv_rid, t_lo, t_hi, r);
-                sm.iv_hi[tid] = lower_bound_rid(a.iv_rid, t_lo, t_hi, r_b);
+                int lo = r, hi = r_hi; // cov_off[lo]-g_lo <= CAP < cov_off[hi]-g_lo
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (uni(a.cov_off[mid]) - g_lo <= CAP) lo = mid; else hi = mid;
+                }
+                r2 = lo;
+            }
+            if (r2 > r) {
+                r_a = r; r_b = r2; w_lo = g_lo; w_hi = (r2 == r_hi) ? g_hi_all : uni(a.cov_off[r2]);
+                single = false; first = true; last = true;
+                r = r2;
+                if (w_hi == w_lo) continue;      // only reads without windows
+            } else {
+                g_first = g_lo; g_end = uni(a.cov_off[r + 1]); chunk_pos = g_lo;
             }
         }
-        __syncthreads();
-        if (!single) {
-            const long long w_hi = a.cov_off[r_b];
-            if (w_hi > g_lo) pile_window<THREADS, CAP>(a, sm, r, r_b, g_lo, w_hi, false, true, true);
-        } else {
-            const long long g_end = a.cov_off[r + 1];
-            for (long long c = g_lo; c < g_end; c += CAP) {
-                const long long c_hi = (c + CAP < g_end) ? c + CAP : g_end;
-                pile_window<THREADS, CAP>(a, sm, r, r + 1, c, c_hi, true, c == g_lo, c_hi == g_end);
-            }
+        if (chunk_pos >= 0) {
+            r_a = r; r_b = r + 1; w_lo = chunk_pos;
+            w_hi = (chunk_pos + CAP < g_end) ? chunk_pos + CAP : g_end;
+            single = true; first = (chunk_pos == g_first); last = (w_hi == g_end);
+            if (last) { chunk_pos = -1; r = r + 1; } else chunk_pos = w_hi;
         }
-        r = r_b;
+        // interval ranges of reads [r_a, r_b) in every segment (uniform; scalar loads)
+        long long seg_lo[kMaxSeg];
+        int seg_cum[kMaxSeg + 1];
+        seg_cum[0] = 0;
+        const bool whole = (r_a == r_lo && r_b == r_hi);
+#pragma unroll
+        for (int s = 0; s < kMaxSeg; ++s) {
+            long long lo = 0, hi = 0;
+            if (s < a.n_seg) {
+                lo = uni(a.tile_iv[(long long)s * a.n_tiles_p1 + k]);
+                hi = uni(a.tile_iv[(long long)s * a.n_tiles_p1 + k + 1]);
+                if (!whole) {
+                    const long long l2 = lower_bound_rid_uni(a.iv_rid, lo, hi, r_a);
+                    hi = lower_bound_rid_uni(a.iv_rid, lo, hi, r_b);
+                    lo = l2;
+                }
+            }
+            seg_lo[s] = lo;
+            seg_cum[s + 1] = seg_cum[s] + (int)(hi - lo);
+        }
+        pile_window<THREADS, CAP, DIAG>(a, sm, r_a, r_b, w_lo, w_hi, single, first, last, seg_lo, seg_cum);
     }
     if (tid == 0) {
         a.tile_sums[2 * (long long)k] = (long long)sm.acc_cov;
         a.tile_sums[2 * (long long)k + 1] = (long long)sm.acc_rep;
     }
+    RAFT_STAMP(7);
+    if (DIAG && tid == 0 && a.dbg) a.dbg[(long long)k * 16 + 10] = __builtin_amdgcn_s_memrealtime();
 }
 
 } // namespace raft

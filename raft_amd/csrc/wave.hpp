@@ -64,6 +64,17 @@ __device__ __forceinline__ int wave_reduce_add(int v)
     return v;
 }
 
+// Values that are the same in every lane but were fetched with vector loads (the compiler cannot prove the
+// memory is not clobbered by the kernel's own stores, so it will not use scalar loads): move them to SGPRs so
+// that everything computed from them -- loop bounds, branch conditions, addresses -- stays scalar.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni(long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // Position (0..63) of the highest set bit; m != 0.
 __device__ __forceinline__ int top_bit(unsigned long long m) { return 63 - __clzll((long long)m); }
 

@@ -23,7 +23,7 @@ EXPORTS = (
     "raft_hip_abi_version", "raft_hip_strerror", "raft_hip_last_error", "raft_hip_create", "raft_hip_destroy",
     "raft_hip_set_params", "raft_hip_set_stream", "raft_hip_use_own_stream", "raft_hip_get_stream", "raft_hip_run_device", "raft_hip_run_host",
     "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
-    "raft_hip_selftest",
+    "raft_hip_selftest", "raft_hip_debug_stamps",
 )
 
 
@@ -114,8 +114,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_outputs_device.argtypes = [vp, C.POINTER(_Outputs)]
     lib.raft_hip_fetch.argtypes = [vp] + [vp] * 11
     lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    lib.raft_hip_set_tuning.argtypes = [vp, i32, i32]
+    lib.raft_hip_set_tuning.argtypes = [vp, i32, i32, i32]
     lib.raft_hip_selftest.argtypes = [C.c_int]
+    lib.raft_hip_debug_stamps.argtypes = [vp, vp, i64, C.POINTER(i64)]
     if path is None:
         _lib = lib
     return lib
@@ -171,8 +172,8 @@ class Engine:
         self._check(self._lib.raft_hip_set_params(self._ctx, C.byref(cp)))
         self.params = params
 
-    def set_tuning(self, tile_bins: int = 0, force_bucket_path: bool = False):
-        self._check(self._lib.raft_hip_set_tuning(self._ctx, tile_bins, int(force_bucket_path)))
+    def set_tuning(self, tile_bins: int = 0, force_bucket_path: bool = False, variant: int = -1):
+        self._check(self._lib.raft_hip_set_tuning(self._ctx, tile_bins, int(force_bucket_path), variant))
 
     def use_torch_stream(self):
         import torch
@@ -233,6 +234,15 @@ class Engine:
                  "frag_read", "frag_begin", "frag_end")
         ptr = [C.c_void_p(out[k].ctypes.data if out[k].size else 0) for k in order]
         self._check(self._lib.raft_hip_fetch(self._ctx, *ptr))
+        return out
+
+    def debug_stamps(self, max_tiles: int = 1 << 20) -> np.ndarray:
+        """Diagnostic kernel variant 5: per-tile s_memtime stamps [n, 16] of the last pass."""
+        n = C.c_int64()
+        self._check(self._lib.raft_hip_debug_stamps(self._ctx, None, 0, C.byref(n)))
+        m = min(int(n.value), max_tiles)
+        out = np.zeros((m, 16), np.uint64)
+        self._check(self._lib.raft_hip_debug_stamps(self._ctx, C.c_void_p(out.ctypes.data), m, C.byref(n)))
         return out
 
     def outputs_device(self) -> dict:

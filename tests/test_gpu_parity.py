@@ -20,10 +20,10 @@ def eng_mod():
     return engine
 
 
-def run_engine(engine, p, cols, tile_bins=0, force_bucket=False, device_resident=False):
+def run_engine(engine, p, cols, tile_bins=0, force_bucket=False, device_resident=False, variant=-1):
     eng = engine.Engine(p, device=0)
     try:
-        eng.set_tuning(tile_bins, force_bucket)
+        eng.set_tuning(tile_bins, force_bucket, variant)
         if device_resident:
             import torch
             dev = [torch.as_tensor(np.ascontiguousarray(c, dtype=np.int32)).to("cuda:0") for c in cols]
@@ -112,9 +112,19 @@ def random_case(seed, n_lo=1, n_hi=60, len_hi=3000, m_hi=600):
 def test_random_small_vs_oracle(eng_mod, seed):
     p, cols = random_case(seed)
     want = oracle_run(p, *cols)
-    for tile, bucket in ((0, False), (32, False), (0, True)):
-        got, s = run_engine(eng_mod, p, cols, tile_bins=tile, force_bucket=bucket)
-        assert_same_result(got, want, f"seed {seed} tile {tile} bucket {bucket}")
+    for tile, bucket, variant in ((0, False, -1), (32, False, seed % 9), (0, True, (seed + 2) % 9), (200, False, (seed + 3) % 9),
+                                  (0, False, 6 + seed % 3)):
+        got, s = run_engine(eng_mod, p, cols, tile_bins=tile, force_bucket=bucket, variant=variant)
+        assert_same_result(got, want, f"seed {seed} tile {tile} bucket {bucket} variant {variant}")
+
+
+@pytest.mark.parametrize("variant", range(9))
+@pytest.mark.parametrize("name", ["s60_ultralong", "s200_smallparams", "s300_default", "edge_reads"])
+def test_golden_cases_all_kernel_variants(eng_mod, name, variant):
+    p, cols, exp, meta = load_case(name)
+    want = oracle_run(p, *cols)
+    got, s = run_engine(eng_mod, p, cols, variant=variant)
+    assert_same_result(got, want, f"{name}/variant {variant}")
 
 
 @pytest.mark.parametrize("kw", [dict(n_reads=5000, seed=21), dict(n_reads=4000, seed=22, symmetric=False, shuffle=True),
