@@ -70,27 +70,6 @@ __global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const 
     for (long long k = t_p + 1; k <= t_r; ++k) tile_first[k] = (int32_t)r;
 }
 
-struct SegBounds { long long start[kMaxSeg + 1]; int32_t n_seg; };
-
-// tile_iv[s][k] = first interval of segment s whose read id >= tile_first[k];
-// tile_glo[k] = first window of tile k's first read (written by the s == 0 row).
-// seg_end_dev (optional) overrides the end of segment 0 with a device-resident count (bucketing path).
-__global__ __launch_bounds__(256) void tile_iv_kernel(SegBounds sb, const long long *seg_end_dev,
-                                                      const int32_t *iv_rid, const int32_t *tile_first,
-                                                      const long long *cov_off, long long n_tiles_p1,
-                                                      long long *tile_iv, long long *tile_glo)
-{
-    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int s = blockIdx.y;
-    if (k >= n_tiles_p1) return;
-    const int r = tile_first[k];
-    if (s == 0) tile_glo[k] = cov_off[r];
-    if (s >= sb.n_seg) return;
-    long long lo = sb.start[s], hi = sb.start[s + 1];
-    if (seg_end_dev) hi = *seg_end_dev;
-    tile_iv[(long long)s * n_tiles_p1 + k] = lower_bound_rid(iv_rid, lo, hi, r);
-}
-
 // ---- counting sort by read id ------------------------------------------------
 
 // Lanes that hold the same key as the previous lane are folded into the run's

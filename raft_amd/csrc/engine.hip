@@ -7,7 +7,6 @@
 #include "device_scan.hpp"
 #include "finalize.hpp"
 #include "pileup.hpp"
-#include "pileup_wave.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -19,34 +18,20 @@ using namespace raft;
 
 namespace {
 
-// Pileup kernel variants (THREADS, CAP = windows staged in LDS per workgroup, MINW = waves per SIMD asked of the
-// register allocator).  The tile quantum Q defaults to CAP - short_max: a tile whose reads all have at most
-// short_max windows then always fits one LDS window.
-struct PileVariant { int threads, cap, minw, short_max; };
+// Pileup kernel variants: THREADS per workgroup, CAP = windows staged in LDS, MINW = waves per SIMD asked of the
+// register allocator (= resident workgroups per CU for 256 threads), short_max = the tile quantum Q defaults to
+// CAP - short_max, so that a tile whose reads all have at most short_max windows always fits one LDS window.
+struct PileVariant { int threads, cap, minw, short_max, blocks_per_cu; };
 constexpr PileVariant kVariants[] = {
-    {256, 7424, 4, 2048},   // 0: 34 KB LDS, 4 workgroups/CU
-    {256, 6912, 5, 2048},   // 1: 32 KB LDS, 5 workgroups/CU
-    {256, 3584, 8, 1024},   // 2: 19 KB LDS, 8 workgroups/CU
-    {512, 15104, 4, 4096},  // 3: 64 KB LDS, 2 workgroups/CU of 8 waves
-    {256, 5376, 6, 1536},   // 4: 26 KB LDS, 6 workgroups/CU
-    {256, 6912, 5, 2048},   // 5: variant 1 with s_memtime stamps (diagnostic build; raft_hip_debug_stamps)
-    {256, 1536, 5, 512},    // 6: wave-per-tile kernel, 4 waves x 7.9 KB LDS, 5 workgroups/CU
-    {256, 1792, 4, 768},    // 7: wave-per-tile kernel, 4 waves x 8.9 KB LDS, 4 workgroups/CU
-    {256, 1024, 6, 384},    // 8: wave-per-tile kernel, 4 waves x 5.8 KB LDS, 6 workgroups/CU
+    {256, 6912, 5, 2048, 5},   // 0: 31.9 KB LDS, 5 workgroups/CU (default)
+    {256, 5376, 6, 1536, 6},   // 1: 25.5 KB LDS, 6 workgroups/CU
+    {256, 3840, 8, 1024, 8},   // 2: 19.2 KB LDS, 8 workgroups/CU
+    {512, 14848, 4, 4096, 2},  // 3: 66.7 KB LDS, 2 workgroups of 8 waves per CU
+    {256, 6912, 5, 2048, 5},   // 4: variant 0 with s_memtime stamps (diagnostic build; raft_hip_debug_stamps)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
-constexpr int kDefaultVariant = 1;
-
-template <int WPB, int CAPW, int MINW>
-void launch_pileup_wave(hipStream_t st, int blocks_per_cu, const PileupArgs &pa, const TileDesc *td, long long n_tiles,
-                        long long *wave_sums, long long *n_waves)
-{
-    long long grid = std::min<long long>((n_tiles + WPB - 1) / WPB, 256LL * blocks_per_cu);
-    if (grid < 1) grid = 1;
-    *n_waves = grid * WPB;
-    hipLaunchKernelGGL((pileup_wave_kernel<WPB, CAPW, MINW>), dim3((unsigned)grid), dim3(WPB * 64), 0, st, pa, td, n_tiles,
-                       wave_sums);
-}
+constexpr int kDefaultVariant = 0;
+constexpr int kDiagVariant = 4;
 
 template <int T, int CAP, int MINW, bool DIAG = false>
 void launch_pileup(hipStream_t st, unsigned grid, const PileupArgs &pa)
@@ -132,13 +117,12 @@ struct raft_hip_ctx {
     std::string last_error;
 
     // device buffers
-    DevBuf ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_iv, tile_glo, tile_sums;
+    DevBuf ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_desc, block_sums;
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
     DevBuf dbg;                       // diagnostic variant only
-    DevBuf tile_desc;                 // wave-per-tile variants
     long long dbg_tiles = 0;
     void *pinned = nullptr;           // small pinned scratch for readbacks
     hipEvent_t ev_pass0 = nullptr, ev_pass1 = nullptr, ev_pile0 = nullptr, ev_pile1 = nullptr;
@@ -251,11 +235,11 @@ void raft_hip_destroy(raft_hip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_iv, &c->tile_glo,
-                     &c->tile_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
+    DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc,
+                     &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->dbg, &c->tile_desc, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -363,9 +347,8 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
 
     HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
     HIP_TRY(c, c->tile_first.ensure((size_t)(n_tiles + 1) * 4));
-    HIP_TRY(c, c->tile_iv.ensure((size_t)(n_tiles + 1) * 8 * kMaxSeg));
-    HIP_TRY(c, c->tile_glo.ensure((size_t)(n_tiles + 1) * 8));
-    HIP_TRY(c, c->tile_sums.ensure((size_t)n_tiles * 16));
+    HIP_TRY(c, c->tile_desc.ensure((size_t)n_tiles * sizeof(TileDesc)));
+    HIP_TRY(c, c->block_sums.ensure((size_t)256 * 8 * 16));
     HIP_TRY(c, c->rep_cnt.ensure((size_t)std::max(N, 1LL) * 4));
     HIP_TRY(c, c->cut_cnt.ensure((size_t)std::max(N, 1LL) * 4));
     HIP_TRY(c, c->frag_cnt.ensure((size_t)std::max(N, 1LL) * 4));
@@ -412,13 +395,12 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     c->sum.symmetric = symmetric;
 
     PileupArgs pa{};
-    pa.read_len = d_len; pa.cov_off = c->cov_off.as<long long>(); pa.tile_first = c->tile_first.as<int32_t>();
-    pa.n_tiles_p1 = n_tiles + 1; pa.n_reads = n_reads;
+    pa.read_len = d_len; pa.cov_off = c->cov_off.as<long long>();
+    pa.td = c->tile_desc.as<TileDesc>(); pa.n_tiles = n_tiles; pa.n_reads = n_reads;
     pa.reso = c->prm.reso; pa.high_cov = c->high_cov; pa.repeat_length = c->prm.repeat_length; pa.flank = c->prm.flanking_length;
     pa.cov = c->cov.as<int32_t>(); pa.rep_res_off = c->rep_res_off.as<long long>(); pa.rep_cnt = c->rep_cnt.as<int32_t>();
     pa.raw_key = c->raw_key.as<int32_t>(); pa.raw_s = c->raw_s.as<int32_t>(); pa.raw_e = c->raw_e.as<int32_t>();
-    pa.tile_sums = c->tile_sums.as<long long>(); pa.err_flags = &ctrl->err_flags; pa.err_index = &ctrl->err_index;
-    pa.tile_iv = c->tile_iv.as<long long>(); pa.tile_glo = c->tile_glo.as<long long>();
+    pa.block_sums = c->block_sums.as<long long>(); pa.err_flags = &ctrl->err_flags; pa.err_index = &ctrl->err_index;
     {   // n / reso as mulhi + shift, exact for 0 <= n < 2^31: with L = ceil(log2 reso) and
         // m = floor(2^(31+L) / reso) + 1 (< 2^32), n / reso == (n * m) >> (31 + L) == mulhi(n, m) >> (L - 1)
         const unsigned d = (unsigned)c->prm.reso;
@@ -432,16 +414,10 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     }
 
     const bool fast = n_rec > 0 && symmetric && !c->force_bucket && n_desc + 1 <= kMaxSeg;
-    const bool wave_kernel = c->variant >= 6;
-    const unsigned tgrid = (unsigned)((n_tiles + 1 + 255) / 256);
-    SegBounds sb{};
+    SegStarts sb{};
     const long long *seg_end_dev = nullptr;
     if (n_rec == 0) {
         pa.n_seg = 0;
-        if (!wave_kernel)
-        hipLaunchKernelGGL(tile_iv_kernel, dim3(tgrid, 1), dim3(256), 0, st, sb, (const long long *)nullptr,
-                           (const int32_t *)nullptr, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), n_tiles + 1,
-                           c->tile_iv.as<long long>(), c->tile_glo.as<long long>());
         c->sum.interval_path = 0; c->sum.n_segments = 0; c->sum.n_intervals = 0;
     } else if (fast) {
         std::sort(desc, desc + n_desc);
@@ -450,10 +426,6 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
         for (int i = 0; i < n_desc; ++i) sb.start[i + 1] = desc[i];
         sb.start[n_desc + 1] = n_rec;
         pa.iv_rid = d_qid; pa.iv_s = d_qs; pa.iv_e = d_qe; pa.n_seg = sb.n_seg;
-        if (!wave_kernel)
-        hipLaunchKernelGGL(tile_iv_kernel, dim3(tgrid, sb.n_seg), dim3(256), 0, st, sb, (const long long *)nullptr,
-                           d_qid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), n_tiles + 1,
-                           c->tile_iv.as<long long>(), c->tile_glo.as<long long>());
         c->sum.interval_path = 0; c->sum.n_segments = sb.n_seg; c->sum.n_intervals = n_rec;
     } else {
         const long long cap_iv = symmetric ? (long long)n_rec : 2 * (long long)n_rec;
@@ -466,58 +438,39 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
         const unsigned grid = (unsigned)std::min<long long>((n_rec + 255) / 256, 8192);
         hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads, symmetric, d_qid,
                            d_tid, c->b_cnt.as<int32_t>(), &ctrl->err_flags, &ctrl->err_index);
-        long long *iv_total = nullptr;
         {
             CountLoader<1> ld{{c->b_cnt.as<int32_t>()}};
             ScanOut<1> so{{c->b_off.as<long long>()}};
-            exclusive_scan<CountLoader<1>, 1>(st, ld, N, c->scan_tmp.as<long long>(), so, &iv_total);
+            exclusive_scan<CountLoader<1>, 1>(st, ld, N, c->scan_tmp.as<long long>(), so);
         }
         HIP_TRY(c, hipMemsetAsync(c->b_cnt.p, 0, (size_t)std::max(N, 1LL) * 4, st)); // reused as the scatter cursor
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads, symmetric, d_qid,
                            d_qs, d_qe, d_tid, d_ts, d_te, c->b_off.as<long long>(), c->b_cnt.as<int32_t>(),
                            c->b_rid.as<int32_t>(), c->b_s.as<int32_t>(), c->b_e.as<int32_t>());
         sb.n_seg = 1; sb.start[0] = 0; sb.start[1] = cap_iv;
-        seg_end_dev = c->b_off.as<long long>() + N;
+        seg_end_dev = c->b_off.as<long long>() + N;   // the true interval count lives at b_off[N]
         pa.iv_rid = c->b_rid.as<int32_t>(); pa.iv_s = c->b_s.as<int32_t>(); pa.iv_e = c->b_e.as<int32_t>(); pa.n_seg = 1;
-        // the true interval count lives at b_off[N]; the tile kernels read it from there
-        if (!wave_kernel)
-        hipLaunchKernelGGL(tile_iv_kernel, dim3(tgrid, 1), dim3(256), 0, st, sb, c->b_off.as<long long>() + N,
-                           c->b_rid.as<int32_t>(), c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), n_tiles + 1,
-                           c->tile_iv.as<long long>(), c->tile_glo.as<long long>());
         c->sum.interval_path = 1; c->sum.n_segments = n_desc + 1; c->sum.n_intervals = -1; // read back in finish
-        (void)iv_total;
     }
+    hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
+                       pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>());
 
     pa.dbg = nullptr;
-    if (c->variant == 5) {
+    if (c->variant == kDiagVariant) {
         HIP_TRY(c, c->dbg.ensure((size_t)n_tiles * 16 * 8));
         HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, (size_t)n_tiles * 16 * 8, st));
         pa.dbg = c->dbg.as<unsigned long long>();
         c->dbg_tiles = n_tiles;
     }
-    long long n_sum_rows = n_tiles;           // rows of (coverage, repeat bp) partial sums the totals kernel reduces
-    if (wave_kernel) {
-        SegStarts ss{};
-        ss.n_seg = pa.n_seg;
-        for (int i = 0; i <= kMaxSeg; ++i) ss.start[i] = sb.start[i];
-        HIP_TRY(c, c->tile_desc.ensure((size_t)n_tiles * sizeof(TileDesc)));
-        hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, n_tiles, ss,
-                           seg_end_dev, pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(),
-                           c->tile_desc.as<TileDesc>());
-        HIP_TRY(c, c->tile_sums.ensure((size_t)std::max<long long>(n_tiles, 256LL * 8 * 4) * 16));
-    }
-    // ---- the dominant kernel
+    // ---- the dominant kernel: persistent workgroups, blocks_per_cu per CU
+    const unsigned pgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * pv.blocks_per_cu));
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
     switch (c->variant) {
-    case 0: launch_pileup<256, 7424, 4>(st, (unsigned)n_tiles, pa); break;
-    case 1: launch_pileup<256, 6912, 5>(st, (unsigned)n_tiles, pa); break;
-    case 2: launch_pileup<256, 3584, 8>(st, (unsigned)n_tiles, pa); break;
-    case 3: launch_pileup<512, 15104, 4>(st, (unsigned)n_tiles, pa); break;
-    case 4: launch_pileup<256, 5376, 6>(st, (unsigned)n_tiles, pa); break;
-    case 5: launch_pileup<256, 6912, 5, true>(st, (unsigned)n_tiles, pa); break;
-    case 6: launch_pileup_wave<4, 1536, 5>(st, 5, pa, c->tile_desc.as<TileDesc>(), n_tiles, c->tile_sums.as<long long>(), &n_sum_rows); break;
-    case 7: launch_pileup_wave<4, 1792, 4>(st, 4, pa, c->tile_desc.as<TileDesc>(), n_tiles, c->tile_sums.as<long long>(), &n_sum_rows); break;
-    default: launch_pileup_wave<4, 1024, 6>(st, 6, pa, c->tile_desc.as<TileDesc>(), n_tiles, c->tile_sums.as<long long>(), &n_sum_rows); break;
+    case 0: launch_pileup<256, 6912, 5>(st, pgrid, pa); break;
+    case 1: launch_pileup<256, 5376, 6>(st, pgrid, pa); break;
+    case 2: launch_pileup<256, 3840, 8>(st, pgrid, pa); break;
+    case 3: launch_pileup<512, 14848, 4>(st, pgrid, pa); break;
+    default: launch_pileup<256, 6912, 5, true>(st, pgrid, pa); break;
     }
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
 
@@ -545,7 +498,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     }
     {
         const unsigned g = (unsigned)std::min<long long>((std::max(n_tiles, N) + 255) / 256, 1024);
-        hipLaunchKernelGGL(totals_kernel, dim3(std::max(g, 1u)), dim3(256), 0, st, n_sum_rows, c->tile_sums.as<long long>(),
+        hipLaunchKernelGGL(totals_kernel, dim3(std::max(g, 1u)), dim3(256), 0, st, (long long)pgrid, c->block_sums.as<long long>(),
                            n_reads, d_len, ctrl->totals);
     }
     HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
@@ -655,7 +608,7 @@ int raft_hip_last_timing(raft_hip_ctx *c, double *pileup_seconds, double *pass_s
 int raft_hip_debug_stamps(raft_hip_ctx *c, unsigned long long *host, int64_t max_tiles, int64_t *n_tiles)
 {
     if (!c || !n_tiles) return RAFT_HIP_ERR_PARAM;
-    if (!c->finished || c->variant != 5) return RAFT_HIP_ERR_STATE;
+    if (!c->finished || c->variant != kDiagVariant) return RAFT_HIP_ERR_STATE;
     *n_tiles = c->dbg_tiles;
     const long long n = std::min<long long>(max_tiles, c->dbg_tiles);
     if (host && n > 0) HIP_TRY(c, hipMemcpy(host, c->dbg.p, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));

@@ -1,6 +1,5 @@
 // pileup.hpp -- the dominant kernel: binned coverage pileup + prefix scan +
-// coalesced coverage store + high-coverage run detection, one tile of reads per
-// workgroup.
+// coalesced coverage store + high-coverage run detection.
 //
 // Reference semantics reproduced (closed forms of SURVEY.md §3.2, checked
 // against oracle/raft_oracle.c and the compiled reference):
@@ -9,25 +8,28 @@
 //                                       kept when (#windows*reso) >= repeat_length,
 //                                       widened by flanking_length and clamped to [0,len]
 //
-// Work decomposition (MI355X-first, HBM-write bound):
-//   * the output coverage array cov[] (4 B per window, all reads concatenated in
-//     FASTA order) is cut into tiles by a quantum of Q windows; tile k owns the
-//     reads whose first window falls in [kQ,(k+1)Q)  (tile_first[], host-free);
-//   * a workgroup stages the tile's windows in LDS as a difference array:
-//     +1 at the first window of an interval, -1 one past its last (ds_add_u32),
-//     so a plain prefix sum over the concatenated reads yields every read's
-//     coverage (each read's +1/-1 balance out before the next read begins);
-//   * each wave owns a contiguous quarter of the tile: it prefix-sums rows of
-//     256 windows (int4 per lane, DPP wave scan), and streams them to HBM as
-//     1 KiB-per-instruction aligned stores -- coverage is written exactly once
-//     and never read back;
-//   * the >= high_cov predicate of a row is four 64-bit ballots; run starts /
-//     run ends are found with scalar bit logic on those masks, so rows without
-//     any high window (the common case) cost no vector work for the repeat scan;
-//   * runs crossing wave seams (and chunk seams of reads longer than the LDS
-//     capacity) are stitched by one lane from four words per wave.
+// Work decomposition (MI355X-first; the kernel is bound by the HBM write of cov[]):
+//   * cov[] (4 B per window, all reads concatenated in FASTA order) is cut into tiles by a
+//     quantum of Q windows; tile k owns the reads whose first window falls in [kQ,(k+1)Q).
+//     A 72-byte TileDesc per tile (reads, windows, interval ranges) is built on the device.
+//   * PERSISTENT workgroups (CUs x resident workgroups) walk the tiles.  While tile i is being
+//     processed, the descriptor of tile i+2 and the read offsets + first 1024 intervals of
+//     tile i+1 are already in flight into registers: a wave waits for them once, just before
+//     it starts storing tile i (vmcnt is one in-order counter for loads and stores, so a wait
+//     placed after the stores would also wait for the stores -- measured, tools/stamp_probe.py).
+//   * the tile's windows are staged in LDS as a difference array: +1 at the first window of
+//     an interval, -1 one past its last (ds_add_u32); a plain prefix sum over the
+//     concatenated reads yields every read's coverage (each read's +1/-1 balance out before
+//     the next read begins).  Barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier).
+//   * each wave owns a contiguous quarter of the tile: rows of 256 windows (int4 per lane)
+//     are prefix-summed with a DPP wave scan and a scalar carry and stored as aligned
+//     1 KiB-per-instruction wave stores -- coverage is written exactly once, never re-read.
+//   * the >= high_cov predicate of a row is four 64-bit ballots held in SGPRs; run starts /
+//     ends are scalar bit logic on them, so rows without a high window (the common case) cost
+//     no vector work for the repeat scan; runs crossing wave seams (or chunk seams of a read
+//     longer than the LDS window) are stitched by one wave from five words per wave.
 //
-// Algorithmic bytes per launch: 12*I + 4*B (+ 8 per read of offsets).
+// Algorithmic bytes per launch: 12*I + 4*B + 4*N + 8*R.
 #pragma once
 #include "wave.hpp"
 
@@ -43,17 +45,26 @@ enum : int {
     kErrLen = 1 << 4
 };
 
+struct SegStarts { long long start[kMaxSeg + 1]; int32_t n_seg; };
+
+struct TileDesc {              // written by tile_desc_kernel; 18 dwords
+    int32_t r_lo, r_hi;        // reads [r_lo, r_hi) start in this tile
+    int32_t n_iv[kMaxSeg];     // intervals of those reads in segment s
+    long long g_lo, g_hi;      // their windows [g_lo, g_hi) in cov[]
+    long long iv_lo[kMaxSeg];  // first interval in segment s
+};
+constexpr int kDescDwords = (int)(sizeof(TileDesc) / 4);
+static_assert(sizeof(TileDesc) == 72, "descriptor is fetched as 18 dwords, one per lane");
+
 struct PileupArgs {
     // intervals: sorted by read id inside each of n_seg segments
     const int32_t *iv_rid, *iv_s, *iv_e;
     int32_t n_seg;
-    const long long *tile_iv;   // [n_seg][n_tiles+1] first interval of segment s belonging to tile k
-    // reads
+    // tiles and reads
+    const TileDesc *td;
+    long long n_tiles;
     const int32_t *read_len;
     const long long *cov_off;   // [n_reads+1]
-    const int32_t *tile_first;  // [n_tiles+1]
-    const long long *tile_glo;  // [n_tiles+1] cov_off[tile_first[k]] (saves one dependent load per workgroup)
-    long long n_tiles_p1;       // stride of tile_iv rows
     int32_t n_reads;
     // params
     int32_t reso, high_cov, repeat_length, flank;
@@ -64,7 +75,7 @@ struct PileupArgs {
     const long long *rep_res_off; // [n_reads+1] reserved slots for raw repeats
     int32_t *rep_cnt;             // [n_reads], zeroed
     int32_t *raw_key, *raw_s, *raw_e;
-    long long *tile_sums;         // [2*n_tiles]: sum of coverage, sum of unclamped repeat bp
+    long long *block_sums;        // [2*gridDim.x]: sum of coverage, sum of unclamped repeat bp
     int32_t *err_flags;           // device word, OR of kErr*
     long long *err_index;         // first offending interval index (min)
     unsigned long long *dbg;      // diagnostic build only: [n_tiles][16] s_memtime stamps
@@ -78,7 +89,8 @@ struct PileupSmem {
     static constexpr int NW = THREADS / 64;
     static constexpr int SLOTS = CAP + 256; // window slots: 3 alignment + CAP + 1 sentinel, rounded to rows
     static constexpr int SBW = SLOTS / 32;
-    static constexpr int MAXR = 510;       // reads per window whose offsets are staged in LDS
+    static constexpr int MAXR = 2 * THREADS - 2; // reads per window whose offsets are staged in LDS
+    static_assert(NW * 8 <= 64, "wave seam words are read by one wave instruction");
     int32_t diff[SLOTS];
     uint32_t sbits[SBW];
     int32_t roff[MAXR + 2];                 // first slot of read r_a+j relative to a0 (j <= nr)
@@ -86,7 +98,7 @@ struct PileupSmem {
     long long carry_open;
     int32_t carry_hp;
     int32_t wsum[NW];
-    int32_t w_rows[NW], w_pclose[NW], w_sfinal[NW], w_hpfinal[NW], w_hpin[NW];
+    int32_t wst[NW * 8];                    // per wave: rows, pclose, sfinal, hpfinal, hpin, need
 };
 
 // window index of base n (0 <= n < 2^31): n / reso without a hardware divide
@@ -101,6 +113,9 @@ __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+
+// s_waitcnt vmcnt(0) that the compiler's wait-count pass can see (it then knows every earlier load has landed)
+__device__ __forceinline__ void wait_all_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 __device__ __forceinline__ void raise_error(const PileupArgs &a, int flag, long long idx)
 {
@@ -144,7 +159,15 @@ __device__ __forceinline__ void emit_run(const PileupArgs &a, Smem &sm, int r_a,
     atomicAdd(&sm.acc_rep, (unsigned long long)(end - start)); // repeat.hpp:127,152
 }
 
-// same search with wave-uniform arguments: keeps the loop in scalar registers
+// lower bound of read id `r` in iv_rid[lo, hi); per-lane and wave-uniform forms
+__device__ __forceinline__ long long lower_bound_rid(const int32_t *iv_rid, long long lo, long long hi, int r)
+{
+    while (lo < hi) {
+        long long mid = (lo + hi) >> 1;
+        if (iv_rid[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
 __device__ __forceinline__ long long lower_bound_rid_uni(const int32_t *iv_rid, long long lo, long long hi, int r)
 {
     while (lo < hi) {
@@ -154,27 +177,62 @@ __device__ __forceinline__ long long lower_bound_rid_uni(const int32_t *iv_rid, 
     return lo;
 }
 
-// lower bound of read id `r` in iv_rid[lo, hi)
-__device__ __forceinline__ long long lower_bound_rid(const int32_t *iv_rid, long long lo, long long hi, int r)
+// What a lane holds of a window before the window is processed: two read offsets and four intervals.
+struct Prefetch {
+    int rid[4], st[4], en[4];
+    long long cv0, cv1;
+};
+
+struct TileRegs {            // descriptor unpacked into scalars
+    int r_lo, r_hi;
+    long long g_lo, g_hi;
+    long long seg_lo[kMaxSeg];
+    int seg_cum[kMaxSeg + 1];
+};
+
+// v-th interval of a window whose segments are (seg_lo[s], seg_cum[s] .. seg_cum[s+1])
+__device__ __forceinline__ long long iv_index_of(const long long (&seg_lo)[kMaxSeg], const int (&seg_cum)[kMaxSeg + 1], int v)
 {
-    while (lo < hi) {
-        long long mid = (lo + hi) >> 1;
-        if (iv_rid[mid] < r) lo = mid + 1; else hi = mid;
-    }
-    return lo;
+    long long idx = seg_lo[0] + v;
+#pragma unroll
+    for (int s = 1; s < kMaxSeg; ++s)
+        if (v >= seg_cum[s]) idx = seg_lo[s] + (v - seg_cum[s]);
+    return idx;
 }
+
+template <int THREADS>
+__device__ __forceinline__ void issue_prefetch(const PileupArgs &a, int tid, int r_a, int nr,
+                                               const long long (&seg_lo)[kMaxSeg], const int (&seg_cum)[kMaxSeg + 1],
+                                               Prefetch &g)
+{
+    g.cv0 = 0; g.cv1 = 0;                       // nr <= MAXR = 2*THREADS - 2: two offsets per lane cover reads r_a .. r_a+nr
+    if (tid <= nr) g.cv0 = a.cov_off[r_a + tid];
+    if (tid + THREADS <= nr) g.cv1 = a.cov_off[r_a + tid + THREADS];
+    const int n_iv = seg_cum[kMaxSeg];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int v = tid + u * THREADS;
+        const bool ok = v < n_iv;
+        const long long i = ok ? iv_index_of(seg_lo, seg_cum, v) : 0;
+        g.rid[u] = ok ? a.iv_rid[i] : -1;
+        g.st[u] = ok ? a.iv_s[i] : 0;
+        g.en[u] = ok ? a.iv_e[i] : 0;
+    }
+}
+
+#define RAFT_STAMP(slot)                                                                                  \
+    do {                                                                                                  \
+        if (DIAG && threadIdx.x == 0 && a.dbg) a.dbg[stamp_row * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 
 // One LDS window: global windows [w_lo, w_hi) (at most CAP) belonging to reads [r_a, r_b).
 // single_read: the window is a chunk of one long read r_a (intervals are clipped to the chunk).
-#define RAFT_STAMP(slot)                                                                              \
-    do {                                                                                              \
-        if (DIAG && threadIdx.x == 0 && a.dbg) a.dbg[(long long)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-
+// g holds the window's prefetched loads (issue_prefetch with the same arguments).
 template <int THREADS, int CAP, bool DIAG>
 __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, int r_a, int r_b,
                             long long w_lo, long long w_hi, bool single_read, bool first_chunk, bool last_chunk,
-                            const long long (&seg_lo)[kMaxSeg], const int (&seg_cum)[kMaxSeg + 1])
+                            const long long (&seg_lo)[kMaxSeg], const int (&seg_cum)[kMaxSeg + 1], Prefetch &g,
+                            long long stamp_row)
 {
     using Smem = PileupSmem<THREADS, CAP>;
     constexpr int NW = Smem::NW;
@@ -184,43 +242,15 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     const int off0 = (int)(w_lo - a0);         // first valid slot
     const int t_end = off0 + (int)(w_hi - w_lo); // one past the last valid slot
     const int rows = (t_end + 1 + 255) >> 8;   // rows of 256 slots, sentinel slot included
-
-    // 0. issue the global loads first: the reads' first windows and the first four intervals per lane.
-    //    Intervals of all segments form one virtual range [0, n_iv); v -> (segment, index).
     const int nr = r_b - r_a;
-    const bool use_tab = nr <= Smem::MAXR;
     const int n_iv = seg_cum[kMaxSeg];
-    long long cv0 = 0, cv1 = 0;
-    if (use_tab) {
-        if (tid <= nr) cv0 = a.cov_off[r_a + tid];
-        if (tid + THREADS <= nr) cv1 = a.cov_off[r_a + tid + THREADS];
-    }
-    auto iv_index = [&](int v) -> long long {
-        long long idx = seg_lo[0] + v;
-#pragma unroll
-        for (int s = 1; s < kMaxSeg; ++s)
-            if (v >= seg_cum[s]) idx = seg_lo[s] + (v - seg_cum[s]);
-        return idx;
-    };
-    int rid[4], st[4], en[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int v = tid + u * THREADS;
-        const bool ok = v < n_iv;
-        const long long i = ok ? iv_index(v) : 0;
-        rid[u] = ok ? a.iv_rid[i] : -1;
-        st[u] = ok ? a.iv_s[i] : 0;
-        en[u] = ok ? a.iv_e[i] : 0;
-    }
 
-    // 1. clear the difference array and the read-start bits while those loads fly; stage the offsets
+    // 1. clear the difference array and the read-start bits; stage the reads' first slots
     for (int i = tid * 4; i < rows * 256; i += THREADS * 4)
         *reinterpret_cast<int4 *>(&sm.diff[i]) = make_int4(0, 0, 0, 0);
     for (int i = tid; i < rows * 8; i += THREADS) sm.sbits[i] = 0u;
-    if (use_tab) {
-        if (tid <= nr) sm.roff[tid] = (int)(cv0 - a0);
-        if (tid + THREADS <= nr) sm.roff[tid + THREADS] = (int)(cv1 - a0);
-    }
+    if (tid <= nr) sm.roff[tid] = (int)(g.cv0 - a0);
+    if (tid + THREADS <= nr) sm.roff[tid + THREADS] = (int)(g.cv1 - a0);
     lds_barrier();
     RAFT_STAMP(2);
 
@@ -229,7 +259,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
         if (first_chunk && tid == 0) sm.sbits[0] = 1u << off0;
     } else {
         for (int j = tid; j < nr; j += THREADS) {
-            const int p = use_tab ? sm.roff[j] : (int)(a.cov_off[r_a + j] - a0);
+            const int p = sm.roff[j];
             atomicOr(&sm.sbits[p >> 5], 1u << (p & 31));
         }
     }
@@ -241,27 +271,23 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
             for (int u = 0; u < 4; ++u) {
                 const int v = v0 + u * THREADS;
                 const bool ok = v < n_iv;
-                const long long i = ok ? iv_index(v) : 0;
-                rid[u] = ok ? a.iv_rid[i] : -1;
-                st[u] = ok ? a.iv_s[i] : 0;
-                en[u] = ok ? a.iv_e[i] : 0;
+                const long long i = ok ? iv_index_of(seg_lo, seg_cum, v) : 0;
+                g.rid[u] = ok ? a.iv_rid[i] : -1;
+                g.st[u] = ok ? a.iv_s[i] : 0;
+                g.en[u] = ok ? a.iv_e[i] : 0;
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (rid[u] < 0) continue;
-            if ((st[u] | en[u]) < 0) { raise_error(a, kErrCoord, iv_index(v0 + u * THREADS)); continue; }
-            const int first = (int)win_of(a, (unsigned)st[u]);
-            int last = (en[u] > 0) ? (int)win_of(a, (unsigned)(en[u] - 1)) : -1;
+            if (g.rid[u] < 0) continue;
+            if ((g.st[u] | g.en[u]) < 0) { raise_error(a, kErrCoord, iv_index_of(seg_lo, seg_cum, v0 + u * THREADS)); continue; }
+            const int first = (int)win_of(a, (unsigned)g.st[u]);
+            int last = (g.en[u] > 0) ? (int)win_of(a, (unsigned)(g.en[u] - 1)) : -1;
             if (last < first) continue;
-            int b0, nb_r;
-            if (use_tab) { const int j = rid[u] - r_a; b0 = sm.roff[j]; nb_r = sm.roff[j + 1] - b0; }
-            else {
-                const long long c0 = a.cov_off[rid[u]];
-                b0 = (int)(c0 - a0); nb_r = (int)(a.cov_off[rid[u] + 1] - c0);
-            }
+            const int j = g.rid[u] - r_a;
+            const int b0 = sm.roff[j], nb_r = sm.roff[j + 1] - b0;
             if (last >= nb_r) {             // reference writes past its vector here (repeat.hpp:69-72)
-                raise_error(a, kErrCoord, iv_index(v0 + u * THREADS));
+                raise_error(a, kErrCoord, iv_index_of(seg_lo, seg_cum, v0 + u * THREADS));
                 last = nb_r - 1;
                 if (last < first) continue;
             }
@@ -294,6 +320,10 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     lds_barrier();
     RAFT_STAMP(4);
 
+    // Every load issued so far -- including the NEXT tile's prefetch -- must land before this wave's first
+    // coverage store: after the stores, any vmcnt wait would also wait for the stores.
+    wait_all_loads();
+
     // 5. pass B: prefix sum, store, run detection
     int carry = 0;
     for (int w = 0; w < wid; ++w) carry += uni(sm.wsum[w]);
@@ -313,7 +343,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
         const int incl = wave_incl_scan_add(w);
         const int excl = incl - w + carry;
         carry += __builtin_amdgcn_readlane(incl, 63);
-        int c0 = excl + x, c1 = excl + y, c2 = excl + z, c3 = excl + w;
+        const int c0 = excl + x, c1 = excl + y, c2 = excl + z, c3 = excl + w;
         // validity of the lane's four slots: off0 <= p0+k < t_end, as one unsigned compare each; the ballots land
         // in SGPR pairs and are combined with scalar ANDs (no control flow between their definition and their use)
         const bool full = (base >= off0) && (base + 256 <= t_end);
@@ -387,11 +417,10 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
         if (pm) pc = __builtin_amdgcn_readlane(pclose, (int)__builtin_ctzll(pm));
         covsum = wave_reduce_add64(covsum);
         if (lane == 0) {
-            sm.w_rows[wid] = row_e > row_b ? 1 : 0;
-            sm.w_pclose[wid] = pc;
-            sm.w_sfinal[wid] = S;
-            sm.w_hpfinal[wid] = hp ? 1 : 0;
-            sm.w_hpin[wid] = hp_in ? 1 : 0;
+            int4 w0 = make_int4(row_e > row_b ? 1 : 0, pc, S, hp ? 1 : 0);
+            *reinterpret_cast<int4 *>(&sm.wst[wid * 8]) = w0;
+            sm.wst[wid * 8 + 4] = hp_in ? 1 : 0;
+            sm.wst[wid * 8 + 5] = (hp_in || hp || pc >= 0) ? 1 : 0;
             if (covsum) atomicAdd(&sm.acc_cov, (unsigned long long)covsum);
         }
     }
@@ -399,108 +428,192 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     lds_barrier();
     RAFT_STAMP(6);
 
-    // 7. stitch runs across wave seams and the window end (step w == NW is the window end)
-    if (tid == 0) {
-        long long open = (single_read && !first_chunk) ? sm.carry_open : -1;
+    // 7. stitch runs across wave seams and the window end (step w == NW is the window end): wave 0 reads all
+    //    seam words with one LDS instruction and walks them as scalars; skipped when no seam carries a run
+    if (wid == 0) {
+        const int v = (lane < NW * 8) ? sm.wst[lane] : 0;
+        const unsigned long long needm = __ballot((lane & 7) == 5 && v != 0);
+        if (needm != 0ull || single_read) {
+            long long open = (single_read && !first_chunk) ? uni(sm.carry_open) : -1;
 #pragma unroll 1
-        for (int w = 0; w <= NW; ++w) {
-            bool do_emit = false;
-            long long gT = 0;
-            if (w < NW) {
-                if (!sm.w_rows[w]) continue;
-                if (sm.w_hpin[w] && sm.w_pclose[w] >= 0 && open >= 0) { do_emit = true; gT = a0 + sm.w_pclose[w]; }
-            } else if (last_chunk && open >= 0) { do_emit = true; gT = w_hi; } // end of read closes the run (repeat.hpp:150)
-            if (do_emit) { emit_run(a, sm, r_a, r_b, single_read, open, gT); open = -1; }
-            if (w < NW) {
-                if (sm.w_hpfinal[w]) { if (sm.w_sfinal[w] != kOpen) open = a0 + sm.w_sfinal[w]; }
-                else open = -1;
+            for (int w = 0; w <= NW; ++w) {
+                bool do_emit = false;
+                long long gT = 0;
+                int hpfinal = 0, sfinal = kNone;
+                if (w < NW) {
+                    if (!__builtin_amdgcn_readlane(v, w * 8 + 0)) continue;
+                    const int pcl = __builtin_amdgcn_readlane(v, w * 8 + 1);
+                    sfinal = __builtin_amdgcn_readlane(v, w * 8 + 2);
+                    hpfinal = __builtin_amdgcn_readlane(v, w * 8 + 3);
+                    const int hpin = __builtin_amdgcn_readlane(v, w * 8 + 4);
+                    if (hpin && pcl >= 0 && open >= 0) { do_emit = true; gT = a0 + pcl; }
+                } else if (last_chunk && open >= 0) { do_emit = true; gT = w_hi; } // end of read closes the run (repeat.hpp:150)
+                if (do_emit) {
+                    if (lane == 0) emit_run(a, sm, r_a, r_b, single_read, open, gT);
+                    open = -1;
+                }
+                if (w < NW) {
+                    if (hpfinal) { if (sfinal != kOpen) open = a0 + sfinal; }
+                    else open = -1;
+                }
             }
+            if (lane == 0) { sm.carry_open = open; sm.carry_hp = open >= 0 ? 1 : 0; }
         }
-        sm.carry_open = open;
-        sm.carry_hp = open >= 0 ? 1 : 0;
     }
     lds_barrier();
+}
+
+// unpacks a descriptor that lane l holds as dword l (l < 18) into scalars
+__device__ __forceinline__ void unpack_desc(int raw, TileRegs &t)
+{
+    auto d = [&](int i) -> int { return __builtin_amdgcn_readlane(raw, i); };
+    auto q = [&](int i) -> long long { return (long long)(((unsigned long long)(unsigned)d(i + 1) << 32) | (unsigned)d(i)); };
+    t.r_lo = d(0); t.r_hi = d(1);
+    t.seg_cum[0] = 0;
+#pragma unroll
+    for (int s = 0; s < kMaxSeg; ++s) t.seg_cum[s + 1] = t.seg_cum[s] + d(2 + s);
+    t.g_lo = q(2 + kMaxSeg); t.g_hi = q(4 + kMaxSeg);
+#pragma unroll
+    for (int s = 0; s < kMaxSeg; ++s) t.seg_lo[s] = q(6 + kMaxSeg + 2 * s);
 }
 
 template <int THREADS, int CAP, int MINW, bool DIAG>
 __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
 {
-    RAFT_STAMP(0);
     using Smem = PileupSmem<THREADS, CAP>;
     __shared__ __attribute__((aligned(16))) Smem sm;
-    const int k = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int r_lo = uni(a.tile_first[k]), r_hi = uni(a.tile_first[k + 1]);
-    const long long g_lo_tile = uni(a.tile_glo[k]), g_hi_all = uni(a.tile_glo[k + 1]);
-    if (DIAG && tid == 0 && a.dbg) { a.dbg[(long long)k * 16 + 8] = (unsigned long long)(g_hi_all - g_lo_tile); a.dbg[(long long)k * 16 + 9] = __builtin_amdgcn_s_memrealtime(); }
-    RAFT_STAMP(1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long long nb = gridDim.x;
+    const int32_t *td_words = reinterpret_cast<const int32_t *>(a.td);
     if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; sm.carry_open = -1; sm.carry_hp = 0; }
-    if (r_lo >= r_hi) {
-        if (tid == 0) { a.tile_sums[2 * (long long)k] = 0; a.tile_sums[2 * (long long)k + 1] = 0; }
-        return;
+
+    long long k = blockIdx.x;
+    TileRegs cur{}, nxt{};
+    Prefetch g{}, gn{};
+    bool simple = false, nsimple = false;
+    int raw = 0;
+    if (k < a.n_tiles) {
+        raw = (lane < kDescDwords) ? td_words[k * kDescDwords + lane] : 0;
+        unpack_desc(raw, cur);
+        simple = (cur.r_hi > cur.r_lo) && (cur.g_hi > cur.g_lo) && (cur.g_hi - cur.g_lo <= CAP) &&
+                 (cur.r_hi - cur.r_lo <= Smem::MAXR);
+        if (simple) issue_prefetch<THREADS>(a, tid, cur.r_lo, cur.r_hi - cur.r_lo, cur.seg_lo, cur.seg_cum, g);
+        if (k + nb < a.n_tiles) raw = (lane < kDescDwords) ? td_words[(k + nb) * kDescDwords + lane] : 0;
     }
-    int r = r_lo;
-    long long chunk_pos = -1, g_first = 0, g_end = 0; // chunk state of a read longer than CAP windows
-    for (;;) {
-        int r_a, r_b;
-        long long w_lo, w_hi;
-        bool single, first, last;
-        if (chunk_pos < 0) {
-            if (r >= r_hi) break;
-            const long long g_lo = (r == r_lo) ? g_lo_tile : uni(a.cov_off[r]);
-            int r2;
-            if (g_hi_all - g_lo <= CAP) r2 = r_hi;
-            else {
-                int lo = r, hi = r_hi; // cov_off[lo]-g_lo <= CAP < cov_off[hi]-g_lo
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (uni(a.cov_off[mid]) - g_lo <= CAP) lo = mid; else hi = mid;
+    while (k < a.n_tiles) {
+        const long long kn = k + nb;
+        const long long stamp_row = k;
+        if (DIAG && tid == 0 && a.dbg) { a.dbg[k * 16 + 0] = __builtin_amdgcn_s_memtime(); a.dbg[k * 16 + 9] = __builtin_amdgcn_s_memrealtime(); }
+        // next tile: its descriptor was requested one iteration ago; start its loads now
+        nsimple = false;
+        if (kn < a.n_tiles) {
+            unpack_desc(raw, nxt);
+            nsimple = (nxt.r_hi > nxt.r_lo) && (nxt.g_hi > nxt.g_lo) && (nxt.g_hi - nxt.g_lo <= CAP) &&
+                      (nxt.r_hi - nxt.r_lo <= Smem::MAXR);
+            if (nsimple) issue_prefetch<THREADS>(a, tid, nxt.r_lo, nxt.r_hi - nxt.r_lo, nxt.seg_lo, nxt.seg_cum, gn);
+            if (kn + nb < a.n_tiles) raw = (lane < kDescDwords) ? td_words[(kn + nb) * kDescDwords + lane] : 0;
+        }
+        if (DIAG && tid == 0 && a.dbg) a.dbg[k * 16 + 8] = (unsigned long long)(cur.g_hi - cur.g_lo);
+        RAFT_STAMP(1);
+
+        if (simple) {
+            pile_window<THREADS, CAP, DIAG>(a, sm, cur.r_lo, cur.r_hi, cur.g_lo, cur.g_hi, false, true, true, cur.seg_lo,
+                                            cur.seg_cum, g, stamp_row);
+        } else if (cur.r_hi > cur.r_lo) {
+            // A tile holding a read longer than the LDS window (or very many reads) is split on the fly:
+            // sub-batches of whole reads, long reads in chunks of CAP windows; loads are issued synchronously.
+            int r = cur.r_lo;
+            long long chunk_pos = -1, g_first = 0, g_end = 0;
+            for (;;) {
+                int r_a, r_b;
+                long long w_lo, w_hi;
+                bool single, first, last;
+                if (chunk_pos < 0) {
+                    if (r >= cur.r_hi) break;
+                    const long long gl = (r == cur.r_lo) ? cur.g_lo : uni(a.cov_off[r]);
+                    // largest r2 in (r, r + MAXR] with all windows of reads [r, r2) inside one LDS window
+                    const int hi_lim = min(cur.r_hi, r + Smem::MAXR);
+                    const long long g_lim = (hi_lim == cur.r_hi) ? cur.g_hi : uni(a.cov_off[hi_lim]);
+                    int r2;
+                    if (g_lim - gl <= CAP) r2 = hi_lim;
+                    else {
+                        int lo = r, hi = hi_lim; // cov_off[lo]-gl <= CAP < cov_off[hi]-gl
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (uni(a.cov_off[mid]) - gl <= CAP) lo = mid; else hi = mid;
+                        }
+                        r2 = lo;
+                    }
+                    if (r2 > r) {
+                        r_a = r; r_b = r2; w_lo = gl; w_hi = (r2 == cur.r_hi) ? cur.g_hi : uni(a.cov_off[r2]);
+                        single = false; first = true; last = true;
+                        r = r2;
+                        if (w_hi == w_lo) continue;      // only reads without windows
+                    } else {
+                        g_first = gl; g_end = uni(a.cov_off[r + 1]); chunk_pos = gl;
+                    }
                 }
-                r2 = lo;
-            }
-            if (r2 > r) {
-                r_a = r; r_b = r2; w_lo = g_lo; w_hi = (r2 == r_hi) ? g_hi_all : uni(a.cov_off[r2]);
-                single = false; first = true; last = true;
-                r = r2;
-                if (w_hi == w_lo) continue;      // only reads without windows
-            } else {
-                g_first = g_lo; g_end = uni(a.cov_off[r + 1]); chunk_pos = g_lo;
-            }
-        }
-        if (chunk_pos >= 0) {
-            r_a = r; r_b = r + 1; w_lo = chunk_pos;
-            w_hi = (chunk_pos + CAP < g_end) ? chunk_pos + CAP : g_end;
-            single = true; first = (chunk_pos == g_first); last = (w_hi == g_end);
-            if (last) { chunk_pos = -1; r = r + 1; } else chunk_pos = w_hi;
-        }
-        // interval ranges of reads [r_a, r_b) in every segment (uniform; scalar loads)
-        long long seg_lo[kMaxSeg];
-        int seg_cum[kMaxSeg + 1];
-        seg_cum[0] = 0;
-        const bool whole = (r_a == r_lo && r_b == r_hi);
+                if (chunk_pos >= 0) {
+                    r_a = r; r_b = r + 1; w_lo = chunk_pos;
+                    w_hi = (chunk_pos + CAP < g_end) ? chunk_pos + CAP : g_end;
+                    single = true; first = (chunk_pos == g_first); last = (w_hi == g_end);
+                    if (last) { chunk_pos = -1; r = r + 1; } else chunk_pos = w_hi;
+                }
+                long long s_lo[kMaxSeg];
+                int s_cum[kMaxSeg + 1];
+                s_cum[0] = 0;
 #pragma unroll
-        for (int s = 0; s < kMaxSeg; ++s) {
-            long long lo = 0, hi = 0;
-            if (s < a.n_seg) {
-                lo = uni(a.tile_iv[(long long)s * a.n_tiles_p1 + k]);
-                hi = uni(a.tile_iv[(long long)s * a.n_tiles_p1 + k + 1]);
-                if (!whole) {
-                    const long long l2 = lower_bound_rid_uni(a.iv_rid, lo, hi, r_a);
-                    hi = lower_bound_rid_uni(a.iv_rid, lo, hi, r_b);
-                    lo = l2;
+                for (int s = 0; s < kMaxSeg; ++s) {
+                    long long lo = cur.seg_lo[s], hi = cur.seg_lo[s] + (cur.seg_cum[s + 1] - cur.seg_cum[s]);
+                    if (s < a.n_seg && !(r_a == cur.r_lo && r_b == cur.r_hi)) {
+                        const long long l2 = lower_bound_rid_uni(a.iv_rid, lo, hi, r_a);
+                        hi = lower_bound_rid_uni(a.iv_rid, lo, hi, r_b);
+                        lo = l2;
+                    }
+                    s_lo[s] = lo;
+                    s_cum[s + 1] = s_cum[s] + (int)(hi - lo);
                 }
+                Prefetch gs;
+                issue_prefetch<THREADS>(a, tid, r_a, r_b - r_a, s_lo, s_cum, gs);
+                pile_window<THREADS, CAP, DIAG>(a, sm, r_a, r_b, w_lo, w_hi, single, first, last, s_lo, s_cum, gs, stamp_row);
             }
-            seg_lo[s] = lo;
-            seg_cum[s + 1] = seg_cum[s] + (int)(hi - lo);
+            wait_all_loads(); // keep the "no load pending after a tile" invariant on this path too
         }
-        pile_window<THREADS, CAP, DIAG>(a, sm, r_a, r_b, w_lo, w_hi, single, first, last, seg_lo, seg_cum);
+        RAFT_STAMP(7);
+        if (DIAG && tid == 0 && a.dbg) a.dbg[k * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+
+        k = kn; cur = nxt; simple = nsimple; g = gn;
     }
+    lds_barrier();
     if (tid == 0) {
-        a.tile_sums[2 * (long long)k] = (long long)sm.acc_cov;
-        a.tile_sums[2 * (long long)k + 1] = (long long)sm.acc_rep;
+        a.block_sums[2 * (long long)blockIdx.x] = (long long)sm.acc_cov;
+        a.block_sums[2 * (long long)blockIdx.x + 1] = (long long)sm.acc_rep;
     }
-    RAFT_STAMP(7);
-    if (DIAG && tid == 0 && a.dbg) a.dbg[(long long)k * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+}
+
+// One thread per tile: the descriptor the pileup workgroups fetch (reads, windows, interval ranges).
+__global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegStarts sb, const long long *seg_end_dev,
+                                                        const int32_t *iv_rid, const int32_t *tile_first,
+                                                        const long long *cov_off, TileDesc *td)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_tiles) return;
+    TileDesc d;
+    d.r_lo = tile_first[k]; d.r_hi = tile_first[k + 1];
+    d.g_lo = cov_off[d.r_lo]; d.g_hi = cov_off[d.r_hi];
+#pragma unroll
+    for (int s = 0; s < kMaxSeg; ++s) {
+        long long lo = 0, hi = 0;
+        if (s < sb.n_seg) {
+            long long b = sb.start[s], e = sb.start[s + 1];
+            if (seg_end_dev) e = *seg_end_dev;
+            lo = lower_bound_rid(iv_rid, b, e, d.r_lo);
+            hi = lower_bound_rid(iv_rid, b, e, d.r_hi);
+        }
+        d.iv_lo[s] = lo;
+        d.n_iv[s] = (int)(hi - lo);
+    }
+    td[k] = d;
 }
 
 } // namespace raft

@@ -237,7 +237,7 @@ class Engine:
         return out
 
     def debug_stamps(self, max_tiles: int = 1 << 20) -> np.ndarray:
-        """Diagnostic kernel variant 5: per-tile s_memtime stamps [n, 16] of the last pass."""
+        """Diagnostic kernel variant 4: per-tile s_memtime stamps [n, 16] of the last pass."""
         n = C.c_int64()
         self._check(self._lib.raft_hip_debug_stamps(self._ctx, None, 0, C.byref(n)))
         m = min(int(n.value), max_tiles)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase s_memtime shares of the pileup kernel (variant 5 = variant 1 + stamps).
+"""Diagnostic: per-phase s_memtime shares of the pileup kernel (variant 4 = variant 0 + stamps).
 
 Stamps per tile (thread 0): 0 kernel entry, 1 after tile descriptor loads, 2 after LDS clear + offset
 table, 3 after interval phase, 4 after pass A, 5 own wave done with pass B, 6 all waves done, 7 exit.
@@ -17,7 +17,7 @@ from raft_amd.synth import make_overlaps
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 o = make_overlaps(reads, mean_len=30000.0, coverage=32.0, seed=7, device="cuda:0")
 eng = engine.Engine(RaftParams(est_cov=32))
-eng.set_tuning(0, False, 5)
+eng.set_tuning(0, False, 4)
 for _ in range(2):
     eng.run_device(o.read_len, *o.columns()); s = eng.finish()
 st = eng.debug_stamps().astype(np.int64)
@@ -26,7 +26,7 @@ ok = st[:, 7] > 0
 st = st[ok]
 print(f"tiles {len(st)}  kernel {pile*1e3:.3f} ms")
 d = np.diff(st[:, :8], axis=1)
-names = ["descr loads", "clear+offset table", "interval phase", "pass A", "pass B (own wave)", "wait other waves", "stitch+exit"]
+names = ["descr unpack+prefetch issue", "clear+offset table", "interval phase", "pass A", "wait loads + pass B (own wave)", "wait other waves", "stitch"]
 life = st[:, 7] - st[:, 0]
 print(f"lifetime cycles: median {np.median(life):.0f} mean {life.mean():.0f} p90 {np.percentile(life,90):.0f}")
 for i, n in enumerate(names):
