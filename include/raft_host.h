@@ -1,0 +1,65 @@
+/*
+ * raft_host.h -- C ABI of the host-side text layer around the engine (libraft_host.so):
+ * the FASTA/FASTQ and PAF readers that feed include/raft_hip.h, and the writers of the
+ * reference's four output files.  Used by the `raft` CLI (raft_amd/host/raft_main.cpp) and,
+ * without a GPU, by the CPU tests that check tokenisation and byte-exact formatting.
+ *
+ * Reference behaviour reproduced (own code; kseq.h is third-party and is not copied):
+ *   loadFASTA          chop.hpp:88-131   name = first whitespace-delimited token, multi-line
+ *                                        sequences joined, FASTQ qualities dropped, gz via zlib;
+ *                                        first read decides real/simulated mode (regex :101)
+ *   paf_read/paf_parse paf.hpp:50-100    split on TAB only, >= 10 fields else the line is skipped,
+ *                                        columns 3,4,8,9 through strtol -> uint32 -> int
+ *   create_pileup      chop.hpp:157-163  name -> read id (FASTA order)
+ *   writers            repeat.hpp:105-108,180-203 ; chop.hpp:250-322
+ * Inputs on which the reference is undefined are rejected: duplicate FASTA names, PAF names that
+ * are not in the FASTA ("Inputs on which the reference is undefined").
+ */
+#ifndef RAFT_HOST_H
+#define RAFT_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    RAFT_HOST_OK = 0,
+    RAFT_HOST_ERR_OPEN = 1,       /* file missing / unreadable */
+    RAFT_HOST_ERR_DUP_NAME = 2,   /* two reads share a name (ids would be ambiguous, chop.hpp:108) */
+    RAFT_HOST_ERR_UNKNOWN_NAME = 3,/* PAF names a read that is not in the reads file (chop.hpp:162-165 OOB) */
+    RAFT_HOST_ERR_IO = 4,         /* write failed */
+    RAFT_HOST_ERR_ARG = 5
+};
+
+typedef struct raft_host_reads raft_host_reads;
+typedef struct raft_host_paf raft_host_paf;
+
+/* reads */
+int            raft_host_reads_load(const char *path, raft_host_reads **out);
+void           raft_host_reads_free(raft_host_reads *r);
+int32_t        raft_host_reads_count(const raft_host_reads *r);
+const int32_t *raft_host_reads_lengths(const raft_host_reads *r);          /* [count] */
+const char    *raft_host_reads_name(const raft_host_reads *r, int32_t i);
+const char    *raft_host_reads_bases(const raft_host_reads *r, int32_t i); /* not NUL-terminated; lengths[i] bytes */
+int            raft_host_reads_real(const raft_host_reads *r);             /* algoParams::real_reads */
+
+/* overlaps: name -> id resolution against `reads`; err_name (may be NULL) receives the offending name */
+int            raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host_paf **out,
+                                  char *err_name, int err_name_cap);
+void           raft_host_paf_free(raft_host_paf *p);
+int64_t        raft_host_paf_count(const raft_host_paf *p);                /* accepted records */
+const int32_t *raft_host_paf_column(const raft_host_paf *p, int k);        /* k: 0 qid 1 qs 2 qe 3 tid 4 ts 5 te */
+
+/* writers (CSR arrays as returned by raft_hip_fetch) */
+int raft_host_write_coverage(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset, const int32_t *cov);
+int raft_host_write_repeats(const char *txt_path, const char *bed_path, const raft_host_reads *reads,
+                            const int64_t *rep_offset, const int32_t *rep_s, const int32_t *rep_e);
+int raft_host_write_fasta(const char *path, const raft_host_reads *reads, const int64_t *frag_offset,
+                          const int32_t *frag_begin, const int32_t *frag_end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

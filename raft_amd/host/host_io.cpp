@@ -1,0 +1,440 @@
+// host_io.cpp -- text layer of the MI355X RAFT engine: FASTA/FASTQ + PAF readers and the writers of
+// PREFIX.coverage.txt / .long_repeats.txt / .long_repeats.bed / .reads.fasta (include/raft_host.h).
+//
+// Everything here is written from the behaviour of the reference's readers and writers (file:line in
+// raft_host.h); kseq.h / paf.hpp are not copied.  Tokenisation rules kept exactly:
+//   * a sequence record starts at the next '>' or '@'; its name runs to the first isspace() byte, the
+//     rest of the header line is dropped; sequence lines are concatenated until a line that STARTS with
+//     '>', '@' or '+'; empty lines are skipped; one trailing '\r' per line is dropped (only when the
+//     accumulated sequence is longer than one byte -- kseq's `l > 1` test);
+//   * after '+', the rest of that line is skipped and quality lines are consumed until they are at
+//     least as long as the sequence; a length mismatch or EOF ends the file (records so far are kept);
+//   * a PAF line is cut at '\n', loses one trailing '\r' (when longer than one byte), is split on TAB
+//     only and is skipped when it has fewer than 10 fields; numeric fields go through strtol.
+#include "../../include/raft_host.h"
+
+#include <zlib.h>
+
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---- buffered byte stream over gz/plain files --------------------------------------------------
+class Stream {
+public:
+    explicit Stream(const char *path) : f_(gzopen(path, "rb")), buf_(1 << 20) { if (f_) gzbuffer(f_, 1 << 20); }
+    ~Stream() { if (f_) gzclose(f_); }
+    bool ok() const { return f_ != nullptr; }
+    int getc()
+    {
+        if (b_ >= e_ && !fill()) return -1;
+        return buf_[b_++];
+    }
+    // Appends bytes up to (not including) the first byte for which is_delim holds and consumes that byte.
+    // Returns false only when the stream was already exhausted (nothing at all could be looked at).
+    template <class Pred> bool get_until(Pred is_delim, std::string &out, int *delim)
+    {
+        bool gotany = false;
+        if (delim) *delim = 0;
+        for (;;) {
+            if (b_ >= e_ && !fill()) break;
+            gotany = true;
+            size_t i = b_;
+            while (i < e_ && !is_delim(buf_[i])) ++i;
+            out.append(reinterpret_cast<const char *>(&buf_[b_]), i - b_);
+            b_ = i + 1;
+            if (i < e_) { if (delim) *delim = buf_[i]; break; }
+            b_ = e_;
+        }
+        return gotany;
+    }
+    bool get_line(std::string &out) // appends; drops one trailing '\r' when the result is longer than one byte
+    {
+        const bool any = get_until([](unsigned char c) { return c == '\n'; }, out, nullptr);
+        if (any && out.size() > 1 && out.back() == '\r') out.pop_back();
+        return any;
+    }
+
+private:
+    bool fill()
+    {
+        if (eof_ || !f_) return false;
+        const int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
+        if (n <= 0) { eof_ = true; b_ = e_ = 0; return false; }
+        b_ = 0; e_ = (size_t)n;
+        return true;
+    }
+    gzFile f_;
+    std::vector<unsigned char> buf_;
+    size_t b_ = 0, e_ = 0;
+    bool eof_ = false;
+};
+
+// ---- name table: open addressing over (offset, length) into one arena ---------------------------
+class NameTable {
+public:
+    int32_t find(const char *s, size_t n) const
+    {
+        if (slots_.empty()) return -1;
+        size_t h = hash(s, n) & (slots_.size() - 1);
+        for (;;) {
+            const int32_t id = slots_[h];
+            if (id < 0) return -1;
+            if (len_[id] == n && memcmp(arena_.data() + off_[id], s, n) == 0) return id;
+            h = (h + 1) & (slots_.size() - 1);
+        }
+    }
+    // returns the new id, or -1 - existing_id when the name is already present
+    int32_t add(const char *s, size_t n)
+    {
+        if ((off_.size() + 1) * 2 > slots_.size()) grow();
+        const int32_t have = find(s, n);
+        if (have >= 0) return -1 - have;
+        const int32_t id = (int32_t)off_.size();
+        off_.push_back(arena_.size()); len_.push_back(n);
+        arena_.append(s, n); arena_.push_back('\0');
+        place(id);
+        return id;
+    }
+    const char *name(int32_t id) const { return arena_.data() + off_[id]; }
+    size_t name_len(int32_t id) const { return len_[id]; }
+    size_t size() const { return off_.size(); }
+
+private:
+    static size_t hash(const char *s, size_t n)
+    {
+        unsigned long long h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)s[i]; h *= 1099511628211ull; }
+        return (size_t)(h ^ (h >> 29));
+    }
+    void place(int32_t id)
+    {
+        size_t h = hash(arena_.data() + off_[id], len_[id]) & (slots_.size() - 1);
+        while (slots_[h] >= 0) h = (h + 1) & (slots_.size() - 1);
+        slots_[h] = id;
+    }
+    void grow()
+    {
+        const size_t n = slots_.empty() ? 1024 : slots_.size() * 2;
+        slots_.assign(n, -1);
+        for (int32_t id = 0; id < (int32_t)off_.size(); ++id) place(id);
+    }
+    std::string arena_;
+    std::vector<size_t> off_, len_;
+    std::vector<int32_t> slots_;
+};
+
+// chop.hpp:101: ^read=[0-9]+,[a-z]+,position=[0-9]+-[0-9]+,length=[0-9]+,(.*)  (whole-name match)
+bool looks_simulated(const std::string &s)
+{
+    size_t i = 0;
+    auto lit = [&](const char *t) { const size_t n = strlen(t); if (s.compare(i, n, t) != 0) return false; i += n; return true; };
+    auto digits = [&]() { const size_t b = i; while (i < s.size() && isdigit((unsigned char)s[i])) ++i; return i > b; };
+    auto lower = [&]() { const size_t b = i; while (i < s.size() && s[i] >= 'a' && s[i] <= 'z') ++i; return i > b; };
+    return lit("read=") && digits() && lit(",") && lower() && lit(",position=") && digits() && lit("-") && digits() &&
+           lit(",length=") && digits() && lit(",");
+}
+
+// ---- fast integer formatting ---------------------------------------------------------------------
+class Out {
+public:
+    explicit Out(const char *path) : f_(fopen(path, "wb")) { buf_.reserve(kCap + 64); }
+    ~Out() { close(); }
+    bool ok() const { return f_ != nullptr && !err_; }
+    void ch(char c) { buf_.push_back(c); maybe_flush(); }
+    void str(const char *s, size_t n)
+    {
+        if (n > kCap) { flush(); if (f_ && fwrite(s, 1, n, f_) != n) err_ = true; return; }
+        buf_.append(s, n); maybe_flush();
+    }
+    void str(const char *s) { str(s, strlen(s)); }
+    void num(long long v)
+    {
+        char t[24];
+        int n = 0;
+        unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) t[n++] = '-';
+        while (n) buf_.push_back(t[--n]);
+        maybe_flush();
+    }
+    bool close()
+    {
+        flush();
+        if (f_) { if (fclose(f_) != 0) err_ = true; f_ = nullptr; }
+        return !err_;
+    }
+
+private:
+    static constexpr size_t kCap = 4u << 20;
+    void maybe_flush() { if (buf_.size() >= kCap) flush(); }
+    void flush()
+    {
+        if (f_ && !buf_.empty() && fwrite(buf_.data(), 1, buf_.size(), f_) != buf_.size()) err_ = true;
+        buf_.clear();
+    }
+    FILE *f_;
+    std::string buf_;
+    bool err_ = false;
+};
+
+} // namespace
+
+struct raft_host_reads {
+    NameTable names;
+    std::vector<int32_t> lens;
+    std::vector<size_t> base_off;
+    std::string bases;
+    int real_reads = 1;
+    // simulated-read mode (chop.hpp:116-121): parsed from every name
+    std::vector<int32_t> start_pos, end_pos;
+    std::vector<std::string> align, chr;
+};
+
+struct raft_host_paf {
+    std::vector<int32_t> col[6];
+};
+
+extern "C" {
+
+int raft_host_reads_load(const char *path, raft_host_reads **out)
+{
+    if (!path || !out) return RAFT_HOST_ERR_ARG;
+    *out = nullptr;
+    Stream in(path);
+    if (!in.ok()) return RAFT_HOST_ERR_OPEN;
+    raft_host_reads *R = new raft_host_reads();
+    int last = 0; // header byte already consumed by the previous record
+    std::string name, seq, junk;
+    int rc = RAFT_HOST_OK;
+    for (;;) {
+        int c;
+        if (last == 0) {
+            while ((c = in.getc()) >= 0 && c != '>' && c != '@') {}
+            if (c < 0) break;
+        }
+        name.clear();
+        int delim = 0;
+        if (!in.get_until([](unsigned char ch) { return isspace(ch) != 0; }, name, &delim)) break;
+        if (delim != '\n') { junk.clear(); in.get_line(junk); } // comment
+        seq.clear();
+        while ((c = in.getc()) >= 0 && c != '>' && c != '+' && c != '@') {
+            if (c == '\n') continue;
+            seq.push_back((char)c);
+            in.get_line(seq);
+        }
+        last = (c == '>' || c == '@') ? c : 0;
+        bool stop_after = false;
+        if (c == '+') {
+            while ((c = in.getc()) >= 0 && c != '\n') {}
+            if (c < 0) break;                       // no quality string: record and the rest are dropped
+            std::string qual;
+            while (qual.size() < seq.size() && in.get_line(qual)) {}
+            last = 0;
+            if (qual.size() != seq.size()) break;   // kseq_read returns -2: loadFASTA's loop ends
+        }
+        // chop.hpp:99-106: the first read decides the mode
+        if (R->lens.empty() && looks_simulated(name)) R->real_reads = 0;
+        const int32_t id = R->names.add(name.data(), name.size());
+        if (id < 0) { rc = RAFT_HOST_ERR_DUP_NAME; break; }
+        R->lens.push_back((int32_t)seq.size());
+        R->base_off.push_back(R->bases.size());
+        R->bases.append(seq);
+        if (!R->real_reads) {
+            // chop.hpp:25-70: position=<start>-<end>, second field = orientation, last field = contig
+            const size_t c1 = name.find(',');
+            size_t eq = c1 == std::string::npos ? std::string::npos : name.find('=', c1);
+            int32_t sp = 0, ep = 0;
+            if (eq != std::string::npos) sp = atoi(name.c_str() + eq + 1);
+            const size_t dash = name.find('-');
+            if (dash != std::string::npos) ep = atoi(name.c_str() + dash + 1);
+            R->start_pos.push_back(sp); R->end_pos.push_back(ep);
+            std::string al;
+            if (c1 != std::string::npos) { const size_t c2 = name.find(',', c1 + 1); al = name.substr(c1 + 1, c2 == std::string::npos ? std::string::npos : c2 - c1 - 1); }
+            R->align.push_back(al);
+            const size_t lc = name.rfind(',');
+            R->chr.push_back(lc == std::string::npos ? std::string() : name.substr(lc + 1));
+        }
+        if (stop_after) break;
+    }
+    if (rc != RAFT_HOST_OK) { delete R; return rc; }
+    *out = R;
+    return RAFT_HOST_OK;
+}
+
+void raft_host_reads_free(raft_host_reads *r) { delete r; }
+int32_t raft_host_reads_count(const raft_host_reads *r) { return r ? (int32_t)r->lens.size() : 0; }
+const int32_t *raft_host_reads_lengths(const raft_host_reads *r) { return r ? r->lens.data() : nullptr; }
+const char *raft_host_reads_name(const raft_host_reads *r, int32_t i) { return r->names.name(i); }
+const char *raft_host_reads_bases(const raft_host_reads *r, int32_t i) { return r->bases.data() + r->base_off[i]; }
+int raft_host_reads_real(const raft_host_reads *r) { return r ? r->real_reads : 1; }
+
+int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host_paf **out, char *err_name, int err_cap)
+{
+    if (!path || !reads || !out) return RAFT_HOST_ERR_ARG;
+    *out = nullptr;
+    gzFile f = gzopen(path, "rb");
+    if (!f) return RAFT_HOST_ERR_OPEN;
+    gzbuffer(f, 1 << 20);
+    std::vector<char> data;
+    {
+        size_t used = 0;
+        data.resize(8u << 20);
+        for (;;) {
+            if (data.size() - used < (4u << 20)) data.resize(data.size() * 2);
+            const int n = gzread(f, data.data() + used, (unsigned)std::min<size_t>(data.size() - used - 1, 1u << 30));
+            if (n <= 0) break;
+            used += (size_t)n;
+        }
+        gzclose(f);
+        data.resize(used + 1);
+        data[used] = '\n'; // a last line without newline is still a line
+        if (used == 0) data.clear();
+    }
+    raft_host_paf *P = new raft_host_paf();
+    int rc = RAFT_HOST_OK;
+    const char *lastq = nullptr, *lastt = nullptr;
+    size_t lastq_n = 0, lastt_n = 0;
+    int32_t lastq_id = -1, lastt_id = -1;
+    auto resolve = [&](char *s, size_t n, const char *&cs, size_t &cn, int32_t &cid) -> int32_t {
+        if (cs && cn == n && memcmp(cs, s, n) == 0) return cid;
+        const int32_t id = reads->names.find(s, n);
+        if (id >= 0) { cs = s; cn = n; cid = id; }
+        return id;
+    };
+    size_t pos = 0;
+    const size_t total = data.size();
+    while (pos < total) {
+        char *line = data.data() + pos;
+        char *nl = (char *)memchr(line, '\n', total - pos);
+        if (!nl) break;
+        size_t len = (size_t)(nl - line);
+        const bool is_last_sentinel = (size_t)(nl - data.data()) == total - 1;
+        pos += len + 1;
+        if (is_last_sentinel && len == 0) break;     // the newline we appended after a file that ended in '\n'
+        if (len > 1 && line[len - 1] == '\r') --len;
+        // split on TAB only (paf.hpp:56-58)
+        char *fld[11];
+        size_t fl[11];
+        int t = 0;
+        char *q = line;
+        for (size_t i = 0; i <= len; ++i) {
+            if (i < len && line[i] != '\t') continue;
+            if (t < 11) { fld[t] = q; fl[t] = (size_t)(line + i - q); }
+            line[i] = '\0';
+            ++t;
+            q = line + i + 1;
+        }
+        if (t < 10) continue;                         // paf.hpp:84-85: silently skipped
+        const int32_t a = resolve(fld[0], fl[0], lastq, lastq_n, lastq_id);
+        const int32_t b = resolve(fld[5], fl[5], lastt, lastt_n, lastt_id);
+        if (a < 0 || b < 0) {
+            rc = RAFT_HOST_ERR_UNKNOWN_NAME;
+            if (err_name && err_cap > 0) snprintf(err_name, (size_t)err_cap, "%s", a < 0 ? fld[0] : fld[5]);
+            break;
+        }
+        auto num = [](const char *s) -> int32_t { return (int32_t)(uint32_t)strtol(s, nullptr, 10); }; // paf.hpp:64-75 -> chop.hpp:157-160
+        P->col[0].push_back(a); P->col[1].push_back(num(fld[2])); P->col[2].push_back(num(fld[3]));
+        P->col[3].push_back(b); P->col[4].push_back(num(fld[7])); P->col[5].push_back(num(fld[8]));
+    }
+    if (rc != RAFT_HOST_OK) { delete P; return rc; }
+    *out = P;
+    return RAFT_HOST_OK;
+}
+
+void raft_host_paf_free(raft_host_paf *p) { delete p; }
+int64_t raft_host_paf_count(const raft_host_paf *p) { return p ? (int64_t)p->col[0].size() : 0; }
+const int32_t *raft_host_paf_column(const raft_host_paf *p, int k) { return (p && k >= 0 && k < 6) ? p->col[k].data() : nullptr; }
+
+// repeat.hpp:105-108: "read <i> " then "<pos>,<cov> " per window, then newline
+int raft_host_write_coverage(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset, const int32_t *cov)
+{
+    Out o(path);
+    if (!o.ok()) return RAFT_HOST_ERR_IO;
+    for (int32_t i = 0; i < n_reads; ++i) {
+        o.str("read ", 5); o.num(i); o.ch(' ');
+        const int64_t b = cov_offset[i], e = cov_offset[i + 1];
+        for (int64_t j = b; j < e; ++j) { o.num((long long)(j - b) * reso); o.ch(','); o.num(cov[j]); o.ch(' '); }
+        o.ch('\n');
+    }
+    return o.close() ? RAFT_HOST_OK : RAFT_HOST_ERR_IO;
+}
+
+// repeat.hpp:180-203: every read gets a line "read <i>, " + "<s>,<e>    " per repeat; .bed only in simulated mode
+int raft_host_write_repeats(const char *txt_path, const char *bed_path, const raft_host_reads *reads,
+                            const int64_t *rep_offset, const int32_t *rep_s, const int32_t *rep_e)
+{
+    Out t(txt_path), b(bed_path);
+    if (!t.ok() || !b.ok()) return RAFT_HOST_ERR_IO;
+    const int32_t n = (int32_t)reads->lens.size();
+    for (int32_t i = 0; i < n; ++i) {
+        t.str("read ", 5); t.num(i); t.str(", ", 2);
+        for (int64_t j = rep_offset[i]; j < rep_offset[i + 1]; ++j) {
+            t.num(rep_s[j]); t.ch(','); t.num(rep_e[j]); t.str("    ", 4);
+            if (!reads->real_reads) {
+                const std::string &al = reads->align[i];
+                if (al == "forward") {
+                    b.str(reads->chr[i].data(), reads->chr[i].size()); b.ch('\t'); b.num(reads->start_pos[i] + rep_s[j]);
+                    b.ch('\t'); b.num(reads->start_pos[i] + rep_e[j]); b.ch('\n');
+                } else if (al == "reverse") {
+                    b.str(reads->chr[i].data(), reads->chr[i].size()); b.ch('\t'); b.num(reads->end_pos[i] - rep_e[j]);
+                    b.ch('\t'); b.num(reads->end_pos[i] - rep_s[j]); b.ch('\n');
+                }
+            }
+        }
+        t.ch('\n');
+    }
+    const bool ok1 = t.close(), ok2 = b.close();
+    return (ok1 && ok2) ? RAFT_HOST_OK : RAFT_HOST_ERR_IO;
+}
+
+// chop.hpp:250-322: one FASTA record per fragment, read_num counts from 1 over the whole file
+int raft_host_write_fasta(const char *path, const raft_host_reads *reads, const int64_t *frag_offset,
+                          const int32_t *frag_begin, const int32_t *frag_end)
+{
+    Out o(path);
+    if (!o.ok()) return RAFT_HOST_ERR_IO;
+    const int32_t n = (int32_t)reads->lens.size();
+    for (int32_t i = 0; i < n; ++i) {
+        const char *name = reads->names.name(i);
+        const size_t name_n = reads->names.name_len(i);
+        const char *seq = reads->bases.data() + reads->base_off[i];
+        const int64_t f0 = frag_offset[i], f1 = frag_offset[i + 1];
+        const bool whole = (f1 - f0) == 1;             // kept in one piece (chop.hpp:250-267)
+        for (int64_t f = f0; f < f1; ++f) {
+            const long long read_num = f + 1;
+            const int32_t b = frag_begin[f], e = frag_end[f];
+            if (reads->real_reads) {
+                o.str(">read=", 6); o.num(read_num); o.ch(','); o.str(name, name_n);
+                o.str(",pos_on_original_read=", 22); o.num(b); o.ch('-'); o.num(e); o.ch('\n');
+            } else {
+                // tail = name.substr(name.find_last_of(','))  -> ",<contig>"
+                const std::string nm(name, name_n);
+                const size_t lc = nm.find_last_of(',');
+                const std::string tail = lc == std::string::npos ? std::string() : nm.substr(lc);
+                const std::string &al = reads->align[i];
+                const int32_t sp = reads->start_pos[i], ep = reads->end_pos[i];
+                bool header = true;
+                long long p0 = 0, p1 = 0, ln = 0;
+                if (whole) { p0 = sp; p1 = ep; ln = reads->lens[i]; }
+                else if (al == "forward") { p0 = (long long)sp + b; p1 = (long long)sp + e; ln = e - b; }
+                else if (al == "reverse") { p0 = (long long)ep - e; p1 = (long long)ep - b; ln = e - b; }
+                else header = false;                     // chop.hpp:293-311 writes no header for other orientations
+                if (header) {
+                    o.str(">read=", 6); o.num(read_num); o.ch(','); o.str(al.data(), al.size()); o.str(",position=", 10);
+                    o.num(p0); o.ch('-'); o.num(p1); o.str(",length=", 8); o.num(ln); o.str(tail.data(), tail.size()); o.ch('\n');
+                }
+            }
+            o.str(seq + b, (size_t)(e - b));
+            o.ch('\n');
+        }
+    }
+    return o.close() ? RAFT_HOST_OK : RAFT_HOST_ERR_IO;
+}
+
+} // extern "C"

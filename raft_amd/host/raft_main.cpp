@@ -1,0 +1,176 @@
+// raft_main.cpp -- `raft [options] <input-reads.fa> <in.paf>`: the reference's command line (main.cpp:21-87,
+// chop.hpp:331-373) in front of the MI355X engine.  Host code only tokenises text, resolves names and formats the
+// four output files; everything between "records are integers" and "fragment bounds exist" runs on the GPU through
+// the C ABI of include/raft_hip.h.  There is no CPU fallback: without libraft_hip.so / a gfx950 device it fails.
+//
+// Kept on purpose (they change file names or exit codes): -p sets repeat_length AND
+// interval_length (main.cpp:44-47); -v falls through into -o (main.cpp:51-55); -i is accepted by getopt but has
+// no case, so it prints the usage and exits 1 (main.cpp:56-57); PREFIX.reads.fasta is created before the inputs
+// are validated (chop.hpp:333-349); messages go to stdout.
+#include "../../include/raft_hip.h"
+#include "../../include/raft_host.h"
+
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Params {            // param.hpp:18-31
+    int reso = 50, est_cov = 0;
+    double cov_mul = 1.5;
+    int repeat_length = 10000, interval_length = 10000, read_length = 20000, overlap_length = 500, flanking_length = 1000;
+    std::string prefix = "raft";
+};
+
+[[noreturn]] void print_help(const Params &p) // main.cpp:7-19
+{
+    std::cout << "Usage: raft [options] <input-reads.fa> <in.paf>\n";
+    std::cout << "  -r NUM     resolution of coverage " << p.reso << "\n";
+    std::cout << "  -e NUM     estimated coverage " << "\n";
+    std::cout << "  -m NUM     coverage multiplier " << p.cov_mul << "\n";
+    std::cout << "  -l NUM     read_length " << p.read_length << "\n";
+    std::cout << "  -v NUM     overlap_length " << p.overlap_length << "\n";
+    std::cout << "  -p NUM     repeat_length " << p.repeat_length << "\n";
+    std::cout << "  -f NUM     flanking_length " << p.flanking_length << "\n";
+    std::cout << "  -o FILE    prefix of output files " << p.prefix << "\n";
+    std::cout.flush();
+    exit(1);
+}
+
+bool missing_or_empty(const char *fn) // chop.hpp:326-329,336-349
+{
+    std::ifstream f(fn);
+    return !f || f.peek() == std::ifstream::traits_type::eof();
+}
+
+[[noreturn]] void die(const std::string &msg)
+{
+    std::cout << msg << "\n";
+    std::cout.flush();
+    exit(1);
+}
+
+} // namespace
+
+int main(int argc, char *argv[])
+{
+    Params p;
+    int option;
+    while ((option = getopt(argc, argv, "r:e:m:l:i:p:f:v:o:")) != -1) {
+        switch (option) {
+        case 'r': p.reso = atoi(optarg); break;
+        case 'e': p.est_cov = atoi(optarg); break;
+        case 'm': p.cov_mul = std::stod(optarg); break;
+        case 'l': p.read_length = atoi(optarg); break;
+        case 'p': p.repeat_length = atoi(optarg); p.interval_length = atoi(optarg); break;
+        case 'f': p.flanking_length = atoi(optarg); break;
+        case 'v': p.overlap_length = atoi(optarg); // no break in the reference: -v also sets the prefix (main.cpp:51-55)
+                  /* fall through */
+        case 'o': p.prefix = optarg; break;
+        default: print_help(p);
+        }
+    }
+    if (argc < optind + 2) print_help(p);
+    if (p.est_cov <= 0) {
+        std::cout << "ERROR, main(), estimated coverage must be set properly\n";
+        print_help(p);
+    }
+    // param.hpp:33-43
+    std::cout << "INFO, printParams(), reso = " << p.reso << "\n";
+    std::cout << "INFO, printParams(), est_cov = " << p.est_cov << "\n";
+    std::cout << "INFO, printParams(), cov_mul = " << p.cov_mul << "\n";
+    std::cout << "INFO, printParams(), repeat_length = " << p.repeat_length << "\n";
+    std::cout << "INFO, printParams(), interval_length = " << p.interval_length << "\n";
+    std::cout << "INFO, printParams(), read_length = " << p.read_length << "\n";
+    std::cout << "INFO, printParams(), overlap_length = " << p.overlap_length << "\n";
+    std::cout << "INFO, printParams(), flanking_length = " << p.flanking_length << "\n";
+
+    const auto t_start = std::chrono::system_clock::now();
+    std::cout << "INFO, main(), started timer\n";
+
+    const char *reads_fn = argv[optind], *paf_fn = argv[optind + 1];
+    const std::string fasta_out = p.prefix + ".reads.fasta";
+    { std::ofstream touch(fasta_out); }               // chop.hpp:333: created before any validation
+    if (missing_or_empty(reads_fn)) die(std::string("ERROR, break_long_reads(), ") + reads_fn + " input file either does not exist or is empty");
+    if (missing_or_empty(paf_fn)) die(std::string("ERROR, break_long_reads(), ") + paf_fn + " input file either does not exist or is empty");
+
+    raft_hip_params hp{};
+    hp.reso = p.reso; hp.est_cov = p.est_cov; hp.cov_mul = p.cov_mul; hp.repeat_length = p.repeat_length;
+    hp.interval_length = p.interval_length; hp.read_length = p.read_length; hp.overlap_length = p.overlap_length;
+    hp.flanking_length = p.flanking_length; hp.symmetric_mode = -1;
+    raft_hip_ctx *ctx = nullptr;
+    const char *dev_env = getenv("RAFT_DEVICE");
+    int rc = raft_hip_create(dev_env ? atoi(dev_env) : 0, &hp, &ctx);
+    if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_create(), ") + raft_hip_strerror(rc));
+
+    raft_host_reads *reads = nullptr;
+    rc = raft_host_reads_load(reads_fn, &reads);
+    if (rc == RAFT_HOST_ERR_DUP_NAME) die("ERROR, loadFASTA(), two reads share a name");
+    if (rc != RAFT_HOST_OK) die(std::string("ERROR, loadFASTA(), cannot read ") + reads_fn);
+    const int32_t n_reads = raft_host_reads_count(reads);
+    std::cout.flush();
+    if (n_reads > 0) fprintf(stdout, "Real Reads %d \n", raft_host_reads_real(reads)); // chop.hpp:105
+
+    raft_host_paf *paf = nullptr;
+    char bad[256] = {0};
+    rc = raft_host_paf_load(paf_fn, reads, &paf, bad, sizeof bad);
+    if (rc == RAFT_HOST_ERR_UNKNOWN_NAME) die(std::string("ERROR, create_pileup(), read ") + bad + " of the overlaps file is not in the reads file");
+    if (rc != RAFT_HOST_OK) die(std::string("ERROR, create_pileup(), cannot read ") + paf_fn);
+    const int64_t n_rec = raft_host_paf_count(paf);
+
+    rc = raft_hip_run_host(ctx, n_reads, raft_host_reads_lengths(reads), n_rec, raft_host_paf_column(paf, 0),
+                           raft_host_paf_column(paf, 1), raft_host_paf_column(paf, 2), raft_host_paf_column(paf, 3),
+                           raft_host_paf_column(paf, 4), raft_host_paf_column(paf, 5));
+    raft_hip_summary s{};
+    if (rc == RAFT_HIP_OK) rc = raft_hip_finish(ctx, &s);
+    if (rc != RAFT_HIP_OK) {
+        std::string m = std::string("ERROR, raft_hip, ") + raft_hip_strerror(rc);
+        if (s.error_index >= 0) m += " (index " + std::to_string(s.error_index) + ")";
+        const char *d = raft_hip_last_error(ctx);
+        if (d && *d) m += std::string(" [") + d + "]";
+        die(m);
+    }
+    fprintf(stdout, "INFO, Symmetric overlaps %d \n", s.symmetric);            // chop.hpp:189-190
+    fprintf(stdout, "INFO, length of alignments  %d()\n", (int)s.n_records);
+    fprintf(stdout, "high_cov %d\n", s.high_cov);                              // repeat.hpp:91
+
+    std::vector<int64_t> cov_off((size_t)n_reads + 1), rep_off((size_t)n_reads + 1), frag_off((size_t)n_reads + 1);
+    std::vector<int32_t> cov((size_t)s.n_bins), rep_s((size_t)s.n_repeats), rep_e((size_t)s.n_repeats);
+    std::vector<int32_t> fb((size_t)s.n_fragments), fe((size_t)s.n_fragments);
+    rc = raft_hip_fetch(ctx, cov_off.data(), cov.data(), rep_off.data(), rep_s.data(), rep_e.data(), nullptr, nullptr,
+                        frag_off.data(), nullptr, fb.data(), fe.data());
+    if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_fetch(), ") + raft_hip_strerror(rc));
+
+    if (raft_host_write_coverage((p.prefix + ".coverage.txt").c_str(), n_reads, p.reso, cov_off.data(), cov.data()) != RAFT_HOST_OK ||
+        raft_host_write_repeats((p.prefix + ".long_repeats.txt").c_str(), (p.prefix + ".long_repeats.bed").c_str(), reads,
+                                rep_off.data(), rep_s.data(), rep_e.data()) != RAFT_HOST_OK)
+        die("ERROR, repeat_annotate(), cannot write output files");
+    // repeat.hpp:173-178 (total_windows is an int in the reference; identical below 2^31 windows)
+    const double cpw = (double)s.total_coverage / (double)s.total_windows;
+    fprintf(stdout, "coverage per window is %f \n", cpw);
+    fprintf(stdout, "coverage per window/average coverage is %f \n", cpw / p.est_cov);
+    fprintf(stdout, "fraction_of_repeat_length %f \n", (double)s.total_repeat_length / (double)s.total_read_length);
+
+    if (raft_host_write_fasta(fasta_out.c_str(), reads, frag_off.data(), fb.data(), fe.data()) != RAFT_HOST_OK)
+        die("ERROR, break_reads(), cannot write " + fasta_out);
+    fflush(stdout);
+
+    const std::chrono::duration<double> wct = std::chrono::system_clock::now() - t_start;
+    std::cout << "INFO, main(), program completed after " << wct.count() << " seconds\n";
+    std::cout.flush();
+    fprintf(stdout, "INFO, %s(), CMD:", __func__);   // main.cpp:81-84
+    for (int i = 0; i < argc; ++i) fprintf(stdout, " %s", argv[i]);
+    fflush(stdout);
+    std::cout << "\n";
+    raft_host_paf_free(paf);
+    raft_host_reads_free(reads);
+    raft_hip_destroy(ctx);
+    return 0;
+}

@@ -1,0 +1,107 @@
+"""ctypes binding of include/raft_host.h (libraft_host.so): the host text layer of the `raft` CLI."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libraft_host.so")
+OK, ERR_OPEN, ERR_DUP_NAME, ERR_UNKNOWN_NAME, ERR_IO, ERR_ARG = range(6)
+
+EXPORTS = ("raft_host_reads_load", "raft_host_reads_free", "raft_host_reads_count", "raft_host_reads_lengths",
+           "raft_host_reads_name", "raft_host_reads_bases", "raft_host_reads_real", "raft_host_paf_load", "raft_host_paf_free",
+           "raft_host_paf_count", "raft_host_paf_column", "raft_host_write_coverage", "raft_host_write_repeats",
+           "raft_host_write_fasta")
+
+
+class HostError(RuntimeError):
+    def __init__(self, code, what=""):
+        super().__init__(f"raft_host error {code} {what}")
+        self.code = code
+        self.what = what
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(_LIB_PATH)
+        vp = C.c_void_p
+        lib.raft_host_reads_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        lib.raft_host_reads_free.argtypes = [vp]; lib.raft_host_reads_free.restype = None
+        lib.raft_host_reads_count.argtypes = [vp]; lib.raft_host_reads_count.restype = C.c_int32
+        lib.raft_host_reads_lengths.argtypes = [vp]; lib.raft_host_reads_lengths.restype = C.POINTER(C.c_int32)
+        lib.raft_host_reads_name.argtypes = [vp, C.c_int32]; lib.raft_host_reads_name.restype = C.c_char_p
+        lib.raft_host_reads_bases.argtypes = [vp, C.c_int32]; lib.raft_host_reads_bases.restype = C.POINTER(C.c_char)
+        lib.raft_host_reads_real.argtypes = [vp]
+        lib.raft_host_paf_load.argtypes = [C.c_char_p, vp, C.POINTER(vp), C.c_char_p, C.c_int]
+        lib.raft_host_paf_free.argtypes = [vp]; lib.raft_host_paf_free.restype = None
+        lib.raft_host_paf_count.argtypes = [vp]; lib.raft_host_paf_count.restype = C.c_int64
+        lib.raft_host_paf_column.argtypes = [vp, C.c_int]; lib.raft_host_paf_column.restype = C.POINTER(C.c_int32)
+        lib.raft_host_write_coverage.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp, vp]
+        lib.raft_host_write_repeats.argtypes = [C.c_char_p, C.c_char_p, vp, vp, vp, vp]
+        lib.raft_host_write_fasta.argtypes = [C.c_char_p, vp, vp, vp, vp]
+        _lib = lib
+    return _lib
+
+
+class Reads:
+    def __init__(self, path: str):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.raft_host_reads_load(path.encode(), C.byref(self._h))
+        if rc != OK:
+            raise HostError(rc, path)
+        n = self._lib.raft_host_reads_count(self._h)
+        self.n = n
+        self.lengths = np.ctypeslib.as_array(self._lib.raft_host_reads_lengths(self._h), shape=(n,)).copy() if n else np.empty(0, np.int32)
+        self.real = int(self._lib.raft_host_reads_real(self._h))
+
+    def name(self, i: int) -> str:
+        return self._lib.raft_host_reads_name(self._h, i).decode()
+
+    def bases(self, i: int) -> bytes:
+        return C.string_at(self._lib.raft_host_reads_bases(self._h, i), int(self.lengths[i]))
+
+    def close(self):
+        if self._h:
+            self._lib.raft_host_reads_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_paf(path: str, reads: Reads):
+    """-> six int32 numpy columns (qid, qs, qe, tid, ts, te)."""
+    lib = load_library()
+    h = C.c_void_p()
+    err = C.create_string_buffer(256)
+    rc = lib.raft_host_paf_load(path.encode(), reads._h, C.byref(h), err, 256)
+    if rc != OK:
+        raise HostError(rc, err.value.decode())
+    n = lib.raft_host_paf_count(h)
+    cols = [np.ctypeslib.as_array(lib.raft_host_paf_column(h, k), shape=(n,)).copy() if n else np.empty(0, np.int32) for k in range(6)]
+    lib.raft_host_paf_free(h)
+    return cols
+
+
+def write_outputs(prefix: str, reads: Reads, reso: int, res: dict):
+    """Writes PREFIX.coverage.txt / .long_repeats.txt / .long_repeats.bed / .reads.fasta from CSR arrays."""
+    lib = load_library()
+    a = {k: np.ascontiguousarray(res[k]) for k in ("cov_offset", "cov", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end")}
+    p = lambda x: C.c_void_p(x.ctypes.data)
+    for rc in (lib.raft_host_write_coverage((prefix + ".coverage.txt").encode(), reads.n, reso, p(a["cov_offset"]), p(a["cov"])),
+               lib.raft_host_write_repeats((prefix + ".long_repeats.txt").encode(), (prefix + ".long_repeats.bed").encode(), reads._h,
+                                           p(a["rep_offset"]), p(a["rep_s"]), p(a["rep_e"])),
+               lib.raft_host_write_fasta((prefix + ".reads.fasta").encode(), reads._h, p(a["frag_offset"]), p(a["frag_begin"]), p(a["frag_end"]))):
+        if rc != OK:
+            raise HostError(rc, prefix)

@@ -27,6 +27,18 @@ def test_library_exports_every_symbol():
     assert lib.raft_hip_strerror(2).decode().startswith("PAF record names a read id")
 
 
+def test_cli_binary_fails_loudly_without_device(tmp_path):
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    exe = os.path.join(ROOT, "raft_amd", "bin", "raft")
+    (tmp_path / "a.fa").write_text(">x\nACGT\n")
+    (tmp_path / "b.paf").write_text("x\t4\t0\t4\t+\tx\t4\t0\t4\t1\t1\t1\n")
+    r = subprocess.run([exe, "-e", "3", "a.fa", "b.paf"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 1 and b"ERROR, raft_hip_create(), HIP device/runtime error" in r.stdout
+
+
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():

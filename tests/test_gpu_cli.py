@@ -1,0 +1,71 @@
+"""GPU: the `raft` command line (raft_amd/bin/raft -> libraft_hip.so) against the reference's own outputs:
+the four files byte for byte, stdout line for line (minus the timing / CMD lines), exit codes."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+from raft_testlib import GOLDEN, ROOT, md5, write_fasta, write_paf
+from test_oracle_golden import MAN, load_case
+
+pytestmark = pytest.mark.gpu
+RAFT = os.path.join(ROOT, "raft_amd", "bin", "raft")
+
+
+def strip_timing(out: str) -> str:
+    return "\n".join(l for l in out.split("\n")
+                     if not l.startswith("INFO, main(), program completed after") and not l.startswith("INFO, main(), CMD:"))
+
+
+def run(cwd, args):
+    r = subprocess.run([RAFT] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    return r.returncode, r.stdout.decode()
+
+
+@pytest.mark.parametrize("name", sorted(MAN["micro"]))
+def test_cli_micro_cases(tmp_path, name):
+    d = os.path.join(GOLDEN, "micro", name)
+    meta = MAN["micro"][name]
+    shutil.copy(os.path.join(d, "reads.fa"), tmp_path)
+    shutil.copy(os.path.join(d, "overlaps.paf"), tmp_path)
+    rc, out = run(tmp_path, meta["args"] + ["reads.fa", "overlaps.paf"])
+    assert rc == 0, out
+    assert strip_timing(out) == open(os.path.join(d, "expect.stdout")).read()
+    assert "INFO, main(), program completed after" in out and "INFO, main(), CMD: " + RAFT in out
+    produced = sorted(f for f in os.listdir(tmp_path) if f not in ("reads.fa", "overlaps.paf"))
+    assert produced == meta["outputs"]
+    for f in produced:
+        assert open(tmp_path / f, "rb").read() == open(os.path.join(d, "expect." + f), "rb").read(), (name, f)
+
+
+@pytest.mark.parametrize("name", sorted(MAN["synthetic"]))
+def test_cli_synthetic_cases(tmp_path, name):
+    p, cols, exp, meta = load_case(name)
+    names = [f"r{i}" for i in range(len(cols[0]))]
+    write_fasta(tmp_path / "reads.fa", names, cols[0])
+    write_paf(tmp_path / "overlaps.paf", names, *cols)
+    rc, out = run(tmp_path, meta["args"] + ["reads.fa", "overlaps.paf"])
+    assert rc == 0, out
+    assert strip_timing(out) == meta["stdout"]
+    for f, digest in meta["md5"].items():
+        assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, (name, f)
+
+
+def test_cli_usage_and_input_errors(tmp_path):
+    rc, out = run(tmp_path, [])
+    assert rc == 1 and out.startswith("Usage: raft [options] <input-reads.fa> <in.paf>\n")
+    rc, out = run(tmp_path, ["-e", "30", "-i", "5", "a.fa", "b.paf"])       # -i is in the getopt string but has no case
+    assert rc == 1 and "Usage: raft" in out
+    rc, out = run(tmp_path, ["a.fa", "b.paf"])                               # est_cov not set
+    assert rc == 1 and out.startswith("ERROR, main(), estimated coverage must be set properly\nUsage:")
+    rc, out = run(tmp_path, ["-e", "30", "-o", "pre", "a.fa", "b.paf"])
+    assert rc == 1 and "ERROR, break_long_reads(), a.fa input file either does not exist or is empty" in out
+    assert os.path.exists(tmp_path / "pre.reads.fasta") and os.path.getsize(tmp_path / "pre.reads.fasta") == 0
+    (tmp_path / "a.fa").write_text(">x\nACGT\n")
+    (tmp_path / "b.paf").write_text("x\t4\t0\t4\t+\tnope\t4\t0\t4\t1\t1\t1\n")
+    rc, out = run(tmp_path, ["-e", "30", "a.fa", "b.paf"])
+    assert rc == 1 and "read nope of the overlaps file is not in the reads file" in out
+    (tmp_path / "b.paf").write_text("x\t4\t0\t400\t+\tx\t4\t0\t4\t1\t1\t1\n")  # reaches past the last window: defined error
+    rc, out = run(tmp_path, ["-e", "30", "a.fa", "b.paf"])
+    assert rc == 1 and "ERROR, raft_hip, PAF coordinate" in out
