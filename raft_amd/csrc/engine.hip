@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -28,6 +29,7 @@ constexpr PileVariant kVariants[] = {
     {256, 3840, 8, 1024, 8},   // 2: 19.2 KB LDS, 8 workgroups/CU
     {512, 14848, 4, 4096, 2},  // 3: 66.7 KB LDS, 2 workgroups of 8 waves per CU
     {256, 6912, 5, 2048, 5},   // 4: variant 0 with s_memtime stamps (diagnostic build; raft_hip_debug_stamps)
+    {256, 7680, 4, 2048, 4},   // 5: 35.0 KB LDS, 4 workgroups/CU, 128 VGPRs
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kDefaultVariant = 0;
@@ -343,7 +345,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     const PileVariant &pv = kVariants[c->variant];
     const int Q = c->tile_q ? std::min(c->tile_q, pv.cap) : pv.cap - pv.short_max;
     const long long n_tiles = B / Q + 1;
-    if (n_tiles + 1 >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;
+    if (n_tiles * kDescDwords >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE; // descriptors are indexed with 32 bits
 
     HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
     HIP_TRY(c, c->tile_first.ensure((size_t)(n_tiles + 1) * 4));
@@ -463,14 +465,17 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
         c->dbg_tiles = n_tiles;
     }
     // ---- the dominant kernel: persistent workgroups, blocks_per_cu per CU
-    const unsigned pgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * pv.blocks_per_cu));
+    int bpc = pv.blocks_per_cu;
+    if (const char *e = getenv("RAFT_PILEUP_WG_PER_CU")) bpc = std::max(1, std::min(atoi(e), pv.blocks_per_cu)); // occupancy experiments
+    const unsigned pgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * bpc));
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
     switch (c->variant) {
     case 0: launch_pileup<256, 6912, 5>(st, pgrid, pa); break;
     case 1: launch_pileup<256, 5376, 6>(st, pgrid, pa); break;
     case 2: launch_pileup<256, 3840, 8>(st, pgrid, pa); break;
     case 3: launch_pileup<512, 14848, 4>(st, pgrid, pa); break;
-    default: launch_pileup<256, 6912, 5, true>(st, pgrid, pa); break;
+    case 4: launch_pileup<256, 6912, 5, true>(st, pgrid, pa); break;
+    default: launch_pileup<256, 7680, 4>(st, pgrid, pa); break;
     }
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
 

@@ -487,19 +487,30 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
     const int32_t *td_words = reinterpret_cast<const int32_t *>(a.td);
     if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; sm.carry_open = -1; sm.carry_hp = 0; }
 
+    // Descriptors travel as ONE VGPR (lane l holds dword l): raw_n = tile k+nb (landed), raw_nn = tile k+2nb (in
+    // flight).  Only the current tile's descriptor is kept unpacked in scalars across the window code.
+    auto desc_word = [&](long long tile) -> int {
+        // 32-bit dword index (n_tiles * 18 < 2^31 is checked by the host): base in SGPRs + one 32-bit VGPR offset.
+        // A per-lane 64-bit address gets hoisted out of the loop, spilled, and its scratch reload then waits on
+        // vmcnt(0) -- behind every prefetch just issued and every coverage store still draining.
+        const unsigned idx = (unsigned)tile * (unsigned)kDescDwords + (unsigned)lane;
+        return (lane < kDescDwords) ? td_words[idx] : 0;
+    };
+    auto is_simple = [&](const TileRegs &t) -> bool {
+        return (t.r_hi > t.r_lo) && (t.g_hi > t.g_lo) && (t.g_hi - t.g_lo <= CAP) && (t.r_hi - t.r_lo <= Smem::MAXR);
+    };
     long long k = blockIdx.x;
-    TileRegs cur{}, nxt{};
+    TileRegs cur{};
     Prefetch g{}, gn{};
     bool simple = false, nsimple = false;
-    int raw = 0;
+    int raw_n = 0, raw_nn = 0;
     if (k < a.n_tiles) {
-        raw = (lane < kDescDwords) ? td_words[k * kDescDwords + lane] : 0;
-        unpack_desc(raw, cur);
-        simple = (cur.r_hi > cur.r_lo) && (cur.g_hi > cur.g_lo) && (cur.g_hi - cur.g_lo <= CAP) &&
-                 (cur.r_hi - cur.r_lo <= Smem::MAXR);
+        unpack_desc(desc_word(k), cur);
+        simple = is_simple(cur);
         if (simple) issue_prefetch<THREADS>(a, tid, cur.r_lo, cur.r_hi - cur.r_lo, cur.seg_lo, cur.seg_cum, g);
-        if (k + nb < a.n_tiles) raw = (lane < kDescDwords) ? td_words[(k + nb) * kDescDwords + lane] : 0;
+        if (k + nb < a.n_tiles) raw_n = desc_word(k + nb);
     }
+    wait_all_loads(); // loop invariant: nothing is pending at the loop head on any incoming edge
     while (k < a.n_tiles) {
         const long long kn = k + nb;
         const long long stamp_row = k;
@@ -507,11 +518,11 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
         // next tile: its descriptor was requested one iteration ago; start its loads now
         nsimple = false;
         if (kn < a.n_tiles) {
-            unpack_desc(raw, nxt);
-            nsimple = (nxt.r_hi > nxt.r_lo) && (nxt.g_hi > nxt.g_lo) && (nxt.g_hi - nxt.g_lo <= CAP) &&
-                      (nxt.r_hi - nxt.r_lo <= Smem::MAXR);
+            TileRegs nxt;
+            unpack_desc(raw_n, nxt);
+            nsimple = is_simple(nxt);
             if (nsimple) issue_prefetch<THREADS>(a, tid, nxt.r_lo, nxt.r_hi - nxt.r_lo, nxt.seg_lo, nxt.seg_cum, gn);
-            if (kn + nb < a.n_tiles) raw = (lane < kDescDwords) ? td_words[(kn + nb) * kDescDwords + lane] : 0;
+            if (kn + nb < a.n_tiles) raw_nn = desc_word(kn + nb);
         }
         if (DIAG && tid == 0 && a.dbg) a.dbg[k * 16 + 8] = (unsigned long long)(cur.g_hi - cur.g_lo);
         RAFT_STAMP(1);
@@ -578,11 +589,15 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
                 pile_window<THREADS, CAP, DIAG>(a, sm, r_a, r_b, w_lo, w_hi, single, first, last, s_lo, s_cum, gs, stamp_row);
             }
             wait_all_loads(); // keep the "no load pending after a tile" invariant on this path too
+        } else {
+            wait_all_loads(); // tile without reads: same invariant (else the loop head waits behind the last stores)
         }
         RAFT_STAMP(7);
         if (DIAG && tid == 0 && a.dbg) a.dbg[k * 16 + 10] = __builtin_amdgcn_s_memrealtime();
 
-        k = kn; cur = nxt; simple = nsimple; g = gn;
+        k = kn; simple = nsimple; g = gn;
+        if (k < a.n_tiles) unpack_desc(raw_n, cur);
+        raw_n = raw_nn;
     }
     lds_barrier();
     if (tid == 0) {
