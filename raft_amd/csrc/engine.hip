@@ -376,7 +376,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     int n_desc = 0;
     long long desc[kMaxSeg];
     if (n_rec > 0) {
-        const unsigned grid = (unsigned)std::min<long long>((n_rec + 255) / 256, 4096);
+        const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((n_rec / 4 + 255) / 256, 256 * 8));
         hipLaunchKernelGGL(inspect_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads,
                            c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
         InspectOut *hi = reinterpret_cast<InspectOut *>(h + 8);

@@ -606,29 +606,35 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
     }
 }
 
-// One thread per tile: the descriptor the pileup workgroups fetch (reads, windows, interval ranges).
+// One thread per tile: the descriptor the pileup workgroups fetch (reads, windows, interval ranges).  A tile's
+// interval range ends where the next tile's begins, so each lane searches once per segment and takes the end from
+// its neighbour lane (the last lane of a wave searches twice).
 __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegStarts sb, const long long *seg_end_dev,
                                                         const int32_t *iv_rid, const int32_t *tile_first,
                                                         const long long *cov_off, TileDesc *td)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_tiles) return;
-    TileDesc d;
-    d.r_lo = tile_first[k]; d.r_hi = tile_first[k + 1];
-    d.g_lo = cov_off[d.r_lo]; d.g_hi = cov_off[d.r_hi];
+    const int lane = threadIdx.x & 63;
+    const bool live = k < n_tiles;
+    TileDesc d{};
+    if (live) {
+        d.r_lo = tile_first[k]; d.r_hi = tile_first[k + 1];
+        d.g_lo = cov_off[d.r_lo]; d.g_hi = cov_off[d.r_hi];
+    }
 #pragma unroll
     for (int s = 0; s < kMaxSeg; ++s) {
         long long lo = 0, hi = 0;
-        if (s < sb.n_seg) {
+        if (s < sb.n_seg) {                         // uniform
             long long b = sb.start[s], e = sb.start[s + 1];
             if (seg_end_dev) e = *seg_end_dev;
-            lo = lower_bound_rid(iv_rid, b, e, d.r_lo);
-            hi = lower_bound_rid(iv_rid, b, e, d.r_hi);
+            if (live) lo = lower_bound_rid(iv_rid, b, e, d.r_lo);
+            hi = __shfl_down(lo, 1, kWave);
+            if (live && (lane == 63 || k + 1 >= n_tiles)) hi = lower_bound_rid(iv_rid, b, e, d.r_hi);
         }
         d.iv_lo[s] = lo;
         d.n_iv[s] = (int)(hi - lo);
     }
-    td[k] = d;
+    if (live) td[k] = d;
 }
 
 } // namespace raft
