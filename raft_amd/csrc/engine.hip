@@ -24,21 +24,21 @@ namespace {
 // CAP - short_max, so that a tile whose reads all have at most short_max windows always fits one LDS window.
 struct PileVariant { int threads, cap, minw, short_max, blocks_per_cu; };
 constexpr PileVariant kVariants[] = {
-    {256, 6912, 5, 2048, 5},   // 0: 31.9 KB LDS, 5 workgroups/CU (default)
-    {256, 5376, 6, 1536, 6},   // 1: 25.5 KB LDS, 6 workgroups/CU
-    {256, 3840, 8, 1024, 8},   // 2: 19.2 KB LDS, 8 workgroups/CU
-    {512, 14848, 4, 4096, 2},  // 3: 66.7 KB LDS, 2 workgroups of 8 waves per CU
-    {256, 6912, 5, 2048, 5},   // 4: variant 0 with s_memtime stamps (diagnostic build; raft_hip_debug_stamps)
-    {256, 7680, 4, 2048, 4},   // 5: 35.0 KB LDS, 4 workgroups/CU, 128 VGPRs
+    {256, 6144, 5, 2048, 5},   // 0: 31.8 KB LDS, 5 workgroups/CU (default)
+    {256, 4864, 6, 1536, 6},   // 1: 26.6 KB LDS, 6 workgroups/CU
+    {256, 3072, 8, 1024, 8},   // 2: 19.2 KB LDS, 8 workgroups/CU
+    {512, 13312, 4, 4096, 2},  // 3: 66.3 KB LDS, 2 workgroups of 8 waves per CU
+    {256, 6144, 5, 2048, 5},   // 4: variant 0 with s_memtime stamps (diagnostic build; raft_hip_debug_stamps)
+    {256, 7424, 4, 2048, 4},   // 5: 36.9 KB LDS, 4 workgroups/CU, 128 VGPRs
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kDefaultVariant = 0;
 constexpr int kDiagVariant = 4;
 
-template <int T, int CAP, int MINW, bool DIAG = false>
+template <int T, int CAP, int MINW, int U, bool DIAG = false>
 void launch_pileup(hipStream_t st, unsigned grid, const PileupArgs &pa)
 {
-    hipLaunchKernelGGL((pileup_kernel<T, CAP, MINW, DIAG>), dim3(grid), dim3(T), 0, st, pa);
+    hipLaunchKernelGGL((pileup_kernel<T, CAP, MINW, U, DIAG>), dim3(grid), dim3(T), 0, st, pa);
 }
 
 struct Ctrl {                         // device control block, cleared every pass
@@ -342,6 +342,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     }
     c->sum.n_bins = B; c->sum.total_windows = B;
     c->cap_rep = RU; c->cap_cut = CU;
+    if (RU >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;   // reserved raw-repeat slots are indexed with 32 bits in LDS
     const PileVariant &pv = kVariants[c->variant];
     const int Q = c->tile_q ? std::min(c->tile_q, pv.cap) : pv.cap - pv.short_max;
     const long long n_tiles = B / Q + 1;
@@ -470,12 +471,12 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     const unsigned pgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * bpc));
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
     switch (c->variant) {
-    case 0: launch_pileup<256, 6912, 5>(st, pgrid, pa); break;
-    case 1: launch_pileup<256, 5376, 6>(st, pgrid, pa); break;
-    case 2: launch_pileup<256, 3840, 8>(st, pgrid, pa); break;
-    case 3: launch_pileup<512, 14848, 4>(st, pgrid, pa); break;
-    case 4: launch_pileup<256, 6912, 5, true>(st, pgrid, pa); break;
-    default: launch_pileup<256, 7680, 4>(st, pgrid, pa); break;
+    case 0: launch_pileup<256, 6144, 5, 3>(st, pgrid, pa); break;
+    case 1: launch_pileup<256, 4864, 6, 2>(st, pgrid, pa); break;
+    case 2: launch_pileup<256, 3072, 8, 2>(st, pgrid, pa); break;
+    case 3: launch_pileup<512, 13312, 4, 4>(st, pgrid, pa); break;
+    case 4: launch_pileup<256, 6144, 5, 3, true>(st, pgrid, pa); break;
+    default: launch_pileup<256, 7424, 4, 4>(st, pgrid, pa); break;
     }
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
 

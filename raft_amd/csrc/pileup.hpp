@@ -13,7 +13,7 @@
 //     quantum of Q windows; tile k owns the reads whose first window falls in [kQ,(k+1)Q).
 //     A 72-byte TileDesc per tile (reads, windows, interval ranges) is built on the device.
 //   * PERSISTENT workgroups (CUs x resident workgroups) walk the tiles.  While tile i is being
-//     processed, the descriptor of tile i+2 and the read offsets + first 1024 intervals of
+//     processed, the descriptor of tile i+2 and the read offsets + first U x THREADS intervals of
 //     tile i+1 are already in flight into registers: a wave waits for them once, just before
 //     it starts storing tile i (vmcnt is one in-order counter for loads and stores, so a wait
 //     placed after the stores would also wait for the stores -- measured, tools/stamp_probe.py).
@@ -89,16 +89,20 @@ struct PileupSmem {
     static constexpr int NW = THREADS / 64;
     static constexpr int SLOTS = CAP + 256; // window slots: 3 alignment + CAP + 1 sentinel, rounded to rows
     static constexpr int SBW = SLOTS / 32;
-    static constexpr int MAXR = 2 * THREADS - 2; // reads per window whose offsets are staged in LDS
+    static constexpr int MAXR = THREADS - 2; // reads per window: their offsets, lengths, repeat slots live in LDS
     static_assert(NW * 8 <= 64, "wave seam words are read by one wave instruction");
     int32_t diff[SLOTS];
     uint32_t sbits[SBW];
     int32_t roff[MAXR + 2];                 // first slot of read r_a+j relative to a0 (j <= nr)
+    int32_t rlen[MAXR + 2];                 // read length
+    int32_t rcnt[MAXR + 2];                 // raw repeats emitted so far for the read
+    int32_t rres[MAXR + 2];                 // its first reserved raw-repeat slot (rep_res_off, < 2^31 checked by the host)
     unsigned long long acc_cov, acc_rep;
     long long carry_open;
     int32_t carry_hp;
     int32_t wsum[NW];
     int32_t wst[NW * 8];                    // per wave: rows, pclose, sfinal, hpfinal, hpin, need
+    unsigned long long stamps[16];          // diagnostic build
 };
 
 // window index of base n (0 <= n < 2^31): n / reso without a hardware divide
@@ -134,25 +138,32 @@ __device__ __forceinline__ int owner_of_window(const long long *cov_off, int r_a
     return lo;
 }
 
-// A closed run of high windows [gS, gT) (global window indices) -> one raw repeat record.
+// A closed run of high windows [sS, sT) (slots of the current LDS window, i.e. relative to a0) -> one raw repeat
+// record.  Everything it needs about the read sits in LDS tables staged with the window; the only global traffic
+// is three fire-and-forget stores, so nothing here waits behind the wave's coverage stores (vmcnt is in-order).
 template <class Smem>
-__device__ __forceinline__ void emit_run(const PileupArgs &a, Smem &sm, int r_a, int r_b, bool single_read,
-                                         long long gS, long long gT)
+__device__ __forceinline__ void emit_run(const PileupArgs &a, Smem &sm, int nr, int sS, int sT)
 {
-    const long long nwin = gT - gS;
-    if (nwin * (long long)a.reso < (long long)a.repeat_length) return; // repeat.hpp:125,150
-    const int rid = single_read ? r_a : owner_of_window(a.cov_off, r_a, r_b, gS);
-    const long long c0 = a.cov_off[rid];
-    const int len = a.read_len[rid];
-    const int start = (int)(gS - c0) * a.reso;
-    const int end = start + (int)nwin * a.reso;
+    const int nwin = sT - sS;
+    if ((long long)nwin * a.reso < (long long)a.repeat_length) return; // repeat.hpp:125,150
+    int j = 0;                                   // read of the window that owns slot sS (reads without windows skipped)
+    {
+        int lo = 0, hi = nr;                     // invariant: roff[lo] <= sS < roff[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (sm.roff[mid] <= sS) lo = mid; else hi = mid;
+        }
+        j = lo;
+    }
+    const int len = sm.rlen[j];
+    const int start = (sS - sm.roff[j]) * a.reso;
+    const int end = start + nwin * a.reso;
     int s = start - a.flank, e = end + a.flank;   // repeat.hpp:129-140
     if (s <= 0) s = 0;
     if (e >= len) e = len;
-    const int slot = atomicAdd(&a.rep_cnt[rid], 1);
-    const long long cap = a.rep_res_off[rid + 1] - a.rep_res_off[rid];
-    if (slot >= cap) { raise_error(a, kErrInternal, rid); return; }
-    const long long idx = a.rep_res_off[rid] + slot;
+    const int slot = atomicAdd(&sm.rcnt[j], 1);
+    if (slot >= sm.rres[j + 1] - sm.rres[j]) { raise_error(a, kErrInternal, j); return; }
+    const long long idx = (long long)sm.rres[j] + slot;
     a.raw_key[idx] = start;
     a.raw_s[idx] = s;
     a.raw_e[idx] = e;
@@ -178,9 +189,11 @@ __device__ __forceinline__ long long lower_bound_rid_uni(const int32_t *iv_rid, 
 }
 
 // What a lane holds of a window before the window is processed: two read offsets and four intervals.
+template <int U>
 struct Prefetch {
-    int rid[4], st[4], en[4];
-    long long cv0, cv1;
+    int rid[U], st[U], en[U];
+    long long cv;           // cov_off of read r_a + thread-id (thread-id <= nr)
+    int rr, rl;             // its first reserved raw-repeat slot (low 32 bits; the host checks the total) and length
 };
 
 struct TileRegs {            // descriptor unpacked into scalars
@@ -200,17 +213,20 @@ __device__ __forceinline__ long long iv_index_of(const long long (&seg_lo)[kMaxS
     return idx;
 }
 
-template <int THREADS>
+template <int THREADS, int U>
 __device__ __forceinline__ void issue_prefetch(const PileupArgs &a, int tid, int r_a, int nr,
                                                const long long (&seg_lo)[kMaxSeg], const int (&seg_cum)[kMaxSeg + 1],
-                                               Prefetch &g)
+                                               Prefetch<U> &g)
 {
-    g.cv0 = 0; g.cv1 = 0;                       // nr <= MAXR = 2*THREADS - 2: two offsets per lane cover reads r_a .. r_a+nr
-    if (tid <= nr) g.cv0 = a.cov_off[r_a + tid];
-    if (tid + THREADS <= nr) g.cv1 = a.cov_off[r_a + tid + THREADS];
+    g.cv = 0; g.rr = 0; g.rl = 0;               // nr <= MAXR = THREADS - 2: thread j covers read r_a + j (j <= nr)
+    if (tid <= nr) {
+        g.cv = a.cov_off[r_a + tid];
+        g.rr = reinterpret_cast<const int32_t *>(a.rep_res_off)[2 * (long long)(r_a + tid)];
+        g.rl = (tid < nr) ? a.read_len[r_a + tid] : 0;
+    }
     const int n_iv = seg_cum[kMaxSeg];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int v = tid + u * THREADS;
         const bool ok = v < n_iv;
         const long long i = ok ? iv_index_of(seg_lo, seg_cum, v) : 0;
@@ -220,18 +236,20 @@ __device__ __forceinline__ void issue_prefetch(const PileupArgs &a, int tid, int
     }
 }
 
-#define RAFT_STAMP(slot)                                                                                  \
-    do {                                                                                                  \
-        if (DIAG && threadIdx.x == 0 && a.dbg) a.dbg[stamp_row * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+// Diagnostic build only: s_memtime stamps are parked in LDS (a global store would queue behind the coverage stores
+// and measure the store queue instead of the phase) and dumped once per tile.
+#define RAFT_STAMP(slot)                                                                      \
+    do {                                                                                      \
+        if (DIAG && threadIdx.x == 0 && a.dbg) sm.stamps[(slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
 // One LDS window: global windows [w_lo, w_hi) (at most CAP) belonging to reads [r_a, r_b).
 // single_read: the window is a chunk of one long read r_a (intervals are clipped to the chunk).
 // g holds the window's prefetched loads (issue_prefetch with the same arguments).
-template <int THREADS, int CAP, bool DIAG>
+template <int THREADS, int CAP, int U, bool DIAG>
 __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, int r_a, int r_b,
                             long long w_lo, long long w_hi, bool single_read, bool first_chunk, bool last_chunk,
-                            const long long (&seg_lo)[kMaxSeg], const int (&seg_cum)[kMaxSeg + 1], Prefetch &g,
+                            const long long (&seg_lo)[kMaxSeg], const int (&seg_cum)[kMaxSeg + 1], Prefetch<U> &g,
                             long long stamp_row)
 {
     using Smem = PileupSmem<THREADS, CAP>;
@@ -249,8 +267,12 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     for (int i = tid * 4; i < rows * 256; i += THREADS * 4)
         *reinterpret_cast<int4 *>(&sm.diff[i]) = make_int4(0, 0, 0, 0);
     for (int i = tid; i < rows * 8; i += THREADS) sm.sbits[i] = 0u;
-    if (tid <= nr) sm.roff[tid] = (int)(g.cv0 - a0);
-    if (tid + THREADS <= nr) sm.roff[tid + THREADS] = (int)(g.cv1 - a0);
+    if (tid <= nr) {
+        sm.roff[tid] = (int)(g.cv - a0);
+        sm.rlen[tid] = g.rl;
+        sm.rres[tid] = g.rr;
+        if (!(single_read && !first_chunk)) sm.rcnt[tid] = 0;   // a long read keeps counting across its chunks
+    }
     lds_barrier();
     RAFT_STAMP(2);
 
@@ -265,10 +287,10 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     }
 
     // 3. intervals -> +1 / -1 (profileCoverage, closed form); four records in flight per lane
-    for (int v0 = tid; v0 < n_iv; v0 += THREADS * 4) {
+    for (int v0 = tid; v0 < n_iv; v0 += THREADS * U) {
         if (v0 != tid) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int v = v0 + u * THREADS;
                 const bool ok = v < n_iv;
                 const long long i = ok ? iv_index_of(seg_lo, seg_cum, v) : 0;
@@ -278,7 +300,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (g.rid[u] < 0) continue;
             if ((g.st[u] | g.en[u]) < 0) { raise_error(a, kErrCoord, iv_index_of(seg_lo, seg_cum, v0 + u * THREADS)); continue; }
             const int first = (int)win_of(a, (unsigned)g.st[u]);
@@ -395,7 +417,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
                 m = CA3 & lt;                if (m) best = max(best, base + 4 * top_bit(m) + 3);
                 const int t = p0 + k;
                 if (best == kOpen) pclose = t;
-                else emit_run(a, sm, r_a, r_b, single_read, a0 + best, a0 + t);
+                else emit_run(a, sm, nr, best, t);
             }
         }
         if (CA0) S = max(S, base + 4 * top_bit(CA0) + 0);
@@ -449,7 +471,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
                     if (hpin && pcl >= 0 && open >= 0) { do_emit = true; gT = a0 + pcl; }
                 } else if (last_chunk && open >= 0) { do_emit = true; gT = w_hi; } // end of read closes the run (repeat.hpp:150)
                 if (do_emit) {
-                    if (lane == 0) emit_run(a, sm, r_a, r_b, single_read, open, gT);
+                    if (lane == 0) emit_run(a, sm, nr, (int)(open - a0), (int)(gT - a0));
                     open = -1;
                 }
                 if (w < NW) {
@@ -461,6 +483,11 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
         }
     }
     lds_barrier();
+    // publish the repeat counts of the reads that are complete (rep_cnt[] was zeroed by the host)
+    if (tid < nr && (!single_read || last_chunk)) {
+        const int c = sm.rcnt[tid];
+        if (c) a.rep_cnt[r_a + tid] = c;
+    }
 }
 
 // unpacks a descriptor that lane l holds as dword l (l < 18) into scalars
@@ -477,7 +504,7 @@ __device__ __forceinline__ void unpack_desc(int raw, TileRegs &t)
     for (int s = 0; s < kMaxSeg; ++s) t.seg_lo[s] = q(6 + kMaxSeg + 2 * s);
 }
 
-template <int THREADS, int CAP, int MINW, bool DIAG>
+template <int THREADS, int CAP, int MINW, int U, bool DIAG>
 __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
 {
     using Smem = PileupSmem<THREADS, CAP>;
@@ -501,34 +528,34 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
     };
     long long k = blockIdx.x;
     TileRegs cur{};
-    Prefetch g{}, gn{};
+    Prefetch<U> g{}, gn{};
     bool simple = false, nsimple = false;
     int raw_n = 0, raw_nn = 0;
     if (k < a.n_tiles) {
         unpack_desc(desc_word(k), cur);
         simple = is_simple(cur);
-        if (simple) issue_prefetch<THREADS>(a, tid, cur.r_lo, cur.r_hi - cur.r_lo, cur.seg_lo, cur.seg_cum, g);
+        if (simple) issue_prefetch<THREADS, U>(a, tid, cur.r_lo, cur.r_hi - cur.r_lo, cur.seg_lo, cur.seg_cum, g);
         if (k + nb < a.n_tiles) raw_n = desc_word(k + nb);
     }
     wait_all_loads(); // loop invariant: nothing is pending at the loop head on any incoming edge
     while (k < a.n_tiles) {
         const long long kn = k + nb;
         const long long stamp_row = k;
-        if (DIAG && tid == 0 && a.dbg) { a.dbg[k * 16 + 0] = __builtin_amdgcn_s_memtime(); a.dbg[k * 16 + 9] = __builtin_amdgcn_s_memrealtime(); }
+        if (DIAG && tid == 0 && a.dbg) { sm.stamps[0] = __builtin_amdgcn_s_memtime(); sm.stamps[9] = __builtin_amdgcn_s_memrealtime(); }
         // next tile: its descriptor was requested one iteration ago; start its loads now
         nsimple = false;
         if (kn < a.n_tiles) {
             TileRegs nxt;
             unpack_desc(raw_n, nxt);
             nsimple = is_simple(nxt);
-            if (nsimple) issue_prefetch<THREADS>(a, tid, nxt.r_lo, nxt.r_hi - nxt.r_lo, nxt.seg_lo, nxt.seg_cum, gn);
+            if (nsimple) issue_prefetch<THREADS, U>(a, tid, nxt.r_lo, nxt.r_hi - nxt.r_lo, nxt.seg_lo, nxt.seg_cum, gn);
             if (kn + nb < a.n_tiles) raw_nn = desc_word(kn + nb);
         }
-        if (DIAG && tid == 0 && a.dbg) a.dbg[k * 16 + 8] = (unsigned long long)(cur.g_hi - cur.g_lo);
+        if (DIAG && tid == 0 && a.dbg) sm.stamps[8] = (unsigned long long)(cur.g_hi - cur.g_lo);
         RAFT_STAMP(1);
 
         if (simple) {
-            pile_window<THREADS, CAP, DIAG>(a, sm, cur.r_lo, cur.r_hi, cur.g_lo, cur.g_hi, false, true, true, cur.seg_lo,
+            pile_window<THREADS, CAP, U, DIAG>(a, sm, cur.r_lo, cur.r_hi, cur.g_lo, cur.g_hi, false, true, true, cur.seg_lo,
                                             cur.seg_cum, g, stamp_row);
         } else if (cur.r_hi > cur.r_lo) {
             // A tile holding a read longer than the LDS window (or very many reads) is split on the fly:
@@ -584,16 +611,19 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
                     s_lo[s] = lo;
                     s_cum[s + 1] = s_cum[s] + (int)(hi - lo);
                 }
-                Prefetch gs;
-                issue_prefetch<THREADS>(a, tid, r_a, r_b - r_a, s_lo, s_cum, gs);
-                pile_window<THREADS, CAP, DIAG>(a, sm, r_a, r_b, w_lo, w_hi, single, first, last, s_lo, s_cum, gs, stamp_row);
+                Prefetch<U> gs;
+                issue_prefetch<THREADS, U>(a, tid, r_a, r_b - r_a, s_lo, s_cum, gs);
+                pile_window<THREADS, CAP, U, DIAG>(a, sm, r_a, r_b, w_lo, w_hi, single, first, last, s_lo, s_cum, gs, stamp_row);
             }
             wait_all_loads(); // keep the "no load pending after a tile" invariant on this path too
         } else {
             wait_all_loads(); // tile without reads: same invariant (else the loop head waits behind the last stores)
         }
         RAFT_STAMP(7);
-        if (DIAG && tid == 0 && a.dbg) a.dbg[k * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+        if (DIAG && tid == 0 && a.dbg) {
+            sm.stamps[10] = __builtin_amdgcn_s_memrealtime();
+            for (int i = 0; i < 11; ++i) a.dbg[k * 16 + i] = sm.stamps[i];
+        }
 
         k = kn; simple = nsimple; g = gn;
         if (k < a.n_tiles) unpack_desc(raw_n, cur);
