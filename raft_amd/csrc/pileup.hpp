@@ -81,6 +81,7 @@ struct PileupArgs {
     unsigned long long *dbg;      // diagnostic build only: [n_tiles][16] s_memtime stamps
 };
 
+constexpr int kRunQ = 16; // parked runs per wave and window before falling back to immediate emission
 constexpr int kOpen = -2; // run began before this wave's first window
 constexpr int kNone = -1;
 
@@ -103,6 +104,8 @@ struct PileupSmem {
     int32_t wsum[NW];
     int32_t wst[NW * 8];                    // per wave: rows, pclose, sfinal, hpfinal, hpin, need
     unsigned long long stamps[16];          // diagnostic build
+    int32_t runq_n[NW];                     // per wave: closed runs parked for emission (slots relative to a0)
+    int32_t runq[NW * 2 * kRunQ];
 };
 
 // window index of base n (0 <= n < 2^31): n / reso without a hardware divide
@@ -138,36 +141,47 @@ __device__ __forceinline__ int owner_of_window(const long long *cov_off, int r_a
     return lo;
 }
 
-// A closed run of high windows [sS, sT) (slots of the current LDS window, i.e. relative to a0) -> one raw repeat
-// record.  Everything it needs about the read sits in LDS tables staged with the window; the only global traffic
-// is three fire-and-forget stores, so nothing here waits behind the wave's coverage stores (vmcnt is in-order).
+// A closed run of high windows [sS, sT) (slots of the current LDS window, i.e. relative to a0) of the window's
+// j-th read -> one raw repeat record.  Everything it needs about the read sits in LDS tables staged with the
+// window (four independent LDS reads = one round trip); the only global traffic is three fire-and-forget stores,
+// so nothing here waits behind the wave's coverage stores (vmcnt is in-order).
 template <class Smem>
-__device__ __forceinline__ void emit_run(const PileupArgs &a, Smem &sm, int nr, int sS, int sT)
+__device__ __forceinline__ void emit_run_of(const PileupArgs &a, Smem &sm, int j, int sS, int sT)
 {
     const int nwin = sT - sS;
     if ((long long)nwin * a.reso < (long long)a.repeat_length) return; // repeat.hpp:125,150
-    int j = 0;                                   // read of the window that owns slot sS (reads without windows skipped)
-    {
-        int lo = 0, hi = nr;                     // invariant: roff[lo] <= sS < roff[hi]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (sm.roff[mid] <= sS) lo = mid; else hi = mid;
-        }
-        j = lo;
-    }
-    const int len = sm.rlen[j];
-    const int start = (sS - sm.roff[j]) * a.reso;
+    const int len = sm.rlen[j], off = sm.roff[j], r0 = sm.rres[j], r1 = sm.rres[j + 1];
+    const int slot = atomicAdd(&sm.rcnt[j], 1);
+    const int start = (sS - off) * a.reso;
     const int end = start + nwin * a.reso;
     int s = start - a.flank, e = end + a.flank;   // repeat.hpp:129-140
     if (s <= 0) s = 0;
     if (e >= len) e = len;
-    const int slot = atomicAdd(&sm.rcnt[j], 1);
-    if (slot >= sm.rres[j + 1] - sm.rres[j]) { raise_error(a, kErrInternal, j); return; }
-    const long long idx = (long long)sm.rres[j] + slot;
+    if (slot >= r1 - r0) { raise_error(a, kErrInternal, j); return; }
+    const long long idx = (long long)r0 + slot;
     a.raw_key[idx] = start;
     a.raw_s[idx] = s;
     a.raw_e[idx] = e;
     atomicAdd(&sm.acc_rep, (unsigned long long)(end - start)); // repeat.hpp:127,152
+}
+
+// read of the window (0 .. nr-1) that owns slot sS; reads without windows are skipped
+template <class Smem>
+__device__ __forceinline__ int owner_slot(const Smem &sm, int nr, int sS)
+{
+    int lo = 0, hi = nr;                         // invariant: roff[lo] <= sS < roff[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (sm.roff[mid] <= sS) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <class Smem>
+__device__ __forceinline__ void emit_run(const PileupArgs &a, Smem &sm, int nr, int sS, int sT)
+{
+    if ((long long)(sT - sS) * a.reso < (long long)a.repeat_length) return;
+    emit_run_of(a, sm, owner_slot(sm, nr, sS), sS, sT);
 }
 
 // lower bound of read id `r` in iv_rid[lo, hi); per-lane and wave-uniform forms
@@ -286,7 +300,8 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
         }
     }
 
-    // 3. intervals -> +1 / -1 (profileCoverage, closed form); four records in flight per lane
+    // 3. intervals -> +1 / -1 (profileCoverage, closed form); U records in flight per lane
+    int covsum = 0;
     for (int v0 = tid; v0 < n_iv; v0 += THREADS * U) {
         if (v0 != tid) {
 #pragma unroll
@@ -321,7 +336,12 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
             }
             __hip_atomic_fetch_add(&sm.diff[pf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&sm.diff[pl1], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            covsum += pl1 - pf;            // sum of coverage over the window == windows touched by its intervals
         }
+    }
+    {
+        const long long cs = wave_reduce_add64((long long)covsum);
+        if (lane == 0 && cs) atomicAdd(&sm.acc_cov, (unsigned long long)cs);
     }
     lds_barrier();
     RAFT_STAMP(3);
@@ -346,7 +366,8 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     // coverage store: after the stores, any vmcnt wait would also wait for the stores.
     wait_all_loads();
 
-    // 5. pass B: prefix sum, store, run detection
+    // 5. pass B: prefix sum, store, run detection.  Rows that lie entirely inside the window (all but the first
+    //    and last of a window) take the lean path: no per-slot validity masks.
     int carry = 0;
     for (int w = 0; w < wid; ++w) carry += uni(sm.wsum[w]);
     bool hp; // was the window just before this wave's first slot high (and in the same run domain)?
@@ -355,44 +376,18 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     const bool hp_in = hp;
     int S = hp ? kOpen : kNone;  // start slot of the run currently open
     int pclose = -1;             // slot at which the run inherited from before this wave closed
-    long long covsum = 0;
 
-    for (int row = row_b; row < row_e; ++row) {
-        const int base = row * 256;
-        const int p0 = base + lane * 4;
-        const int4 d = *reinterpret_cast<const int4 *>(&sm.diff[p0]);
-        const int x = d.x, y = x + d.y, z = y + d.z, w = z + d.w;
-        const int incl = wave_incl_scan_add(w);
-        const int excl = incl - w + carry;
-        carry += __builtin_amdgcn_readlane(incl, 63);
-        const int c0 = excl + x, c1 = excl + y, c2 = excl + z, c3 = excl + w;
-        // validity of the lane's four slots: off0 <= p0+k < t_end, as one unsigned compare each; the ballots land
-        // in SGPR pairs and are combined with scalar ANDs (no control flow between their definition and their use)
-        const bool full = (base >= off0) && (base + 256 <= t_end);
-        const unsigned q0 = (unsigned)(p0 - off0), nbw_u = (unsigned)(t_end - off0);
-        const unsigned long long VA0 = __ballot(q0 + 0u < nbw_u), VA1 = __ballot(q0 + 1u < nbw_u),
-                                 VA2 = __ballot(q0 + 2u < nbw_u), VA3 = __ballot(q0 + 3u < nbw_u);
-        const unsigned long long M0 = __ballot(c0 >= a.high_cov) & VA0, M1 = __ballot(c1 >= a.high_cov) & VA1,
-                                 M2 = __ballot(c2 >= a.high_cov) & VA2, M3 = __ballot(c3 >= a.high_cov) & VA3;
-        if (full) {
-            *reinterpret_cast<int4 *>(&a.cov[a0 + p0]) = make_int4(c0, c1, c2, c3);
-            covsum += (long long)(c0 + c1 + c2 + c3);
-        } else {
-            if ((p0 + 0 >= off0) && (p0 + 0 < t_end)) { a.cov[a0 + p0 + 0] = c0; covsum += c0; }
-            if ((p0 + 1 >= off0) && (p0 + 1 < t_end)) { a.cov[a0 + p0 + 1] = c1; covsum += c1; }
-            if ((p0 + 2 >= off0) && (p0 + 2 < t_end)) { a.cov[a0 + p0 + 2] = c2; covsum += c2; }
-            if ((p0 + 3 >= off0) && (p0 + 3 < t_end)) { a.cov[a0 + p0 + 3] = c3; covsum += c3; }
-        }
-        if ((M0 | M1 | M2 | M3) == 0ull && !hp) continue; // no high window in or just before this row
-
+    // the repeat scan of one row, given its four >= high_cov ballots (already masked to valid slots)
+    auto scan_row = [&](int row, int base, int p0, unsigned long long M0, unsigned long long M1, unsigned long long M2,
+                        unsigned long long M3) {
         const unsigned long long VE0 = __ballot(p0 + 0 < t_end), VE1 = __ballot(p0 + 1 < t_end),
                                  VE2 = __ballot(p0 + 2 < t_end), VE3 = __ballot(p0 + 3 < t_end);
         const uint32_t word = sm.sbits[p0 >> 5];
         const uint32_t nib = (word >> (p0 & 31)) & 0xFu;
         const unsigned long long SB0 = __ballot(nib & 1u), SB1 = __ballot(nib & 2u),
                                  SB2 = __ballot(nib & 4u), SB3 = __ballot(nib & 8u);
-        // P_k: the slot before (lane,k) is a high window
-        // the carried-in bit belongs to the first valid slot: slot off0 of row 0, else slot 0 of the row
+        // P_k: the slot before (lane,k) is a high window; the carried-in bit belongs to the first valid slot:
+        // slot off0 of row 0, else slot 0 of the row
         const unsigned long long hb = hp ? 1ull : 0ull;
         const int hk = (row == 0) ? off0 : 0;
         const unsigned long long P0 = (M3 << 1) | (hk == 0 ? hb : 0ull), P1 = M0 | (hk == 1 ? hb : 0ull),
@@ -417,7 +412,12 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
                 m = CA3 & lt;                if (m) best = max(best, base + 4 * top_bit(m) + 3);
                 const int t = p0 + k;
                 if (best == kOpen) pclose = t;
-                else emit_run(a, sm, nr, best, t);
+                else if ((long long)(t - best) * a.reso >= (long long)a.repeat_length) { // repeat.hpp:125
+                    // park the run; all parked runs become repeat records at once after the seams are resolved
+                    const int q = atomicAdd(&sm.runq_n[wid], 1);
+                    if (q < kRunQ) { sm.runq[(wid * kRunQ + q) * 2] = best; sm.runq[(wid * kRunQ + q) * 2 + 1] = t; }
+                    else emit_run(a, sm, nr, best, t);
+                }
             }
         }
         if (CA0) S = max(S, base + 4 * top_bit(CA0) + 0);
@@ -430,59 +430,121 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
             const unsigned long long Mk = (tl & 3) == 0 ? M0 : (tl & 3) == 1 ? M1 : (tl & 3) == 2 ? M2 : M3;
             hp = ((Mk >> (tl >> 2)) & 1ull) != 0ull;
         }
+    };
+    // prefix sum of one row of 256 slots
+    auto row_values = [&](int p0, int &c0, int &c1, int &c2, int &c3) {
+        const int4 d = *reinterpret_cast<const int4 *>(&sm.diff[p0]);
+        const int x = d.x, y = x + d.y, z = y + d.z, w = z + d.w;
+        const int incl = wave_incl_scan_add(w);
+        const int excl = incl - w + carry;
+        carry += __builtin_amdgcn_readlane(incl, 63);
+        c0 = excl + x; c1 = excl + y; c2 = excl + z; c3 = excl + w;
+    };
+    auto partial_row = [&](int row) {          // first / last rows of a window: per-slot validity
+        const int base = row * 256, p0 = base + lane * 4;
+        int c0, c1, c2, c3;
+        row_values(p0, c0, c1, c2, c3);
+        const unsigned q0 = (unsigned)(p0 - off0), nbw_u = (unsigned)(t_end - off0);
+        const unsigned long long M0 = __ballot(c0 >= a.high_cov && q0 + 0u < nbw_u), M1 = __ballot(c1 >= a.high_cov && q0 + 1u < nbw_u),
+                                 M2 = __ballot(c2 >= a.high_cov && q0 + 2u < nbw_u), M3 = __ballot(c3 >= a.high_cov && q0 + 3u < nbw_u);
+        if (q0 + 0u < nbw_u) a.cov[a0 + p0 + 0] = c0;
+        if (q0 + 1u < nbw_u) a.cov[a0 + p0 + 1] = c1;
+        if (q0 + 2u < nbw_u) a.cov[a0 + p0 + 2] = c2;
+        if (q0 + 3u < nbw_u) a.cov[a0 + p0 + 3] = c3;
+        if ((M0 | M1 | M2 | M3) != 0ull || hp) scan_row(row, base, p0, M0, M1, M2, M3);
+    };
+    {
+        int row = row_b;
+        // rows [full_b, full_e) are entirely inside [off0, t_end)
+        const int full_b = max(row_b, (off0 + 255) >> 8), full_e = min(row_e, t_end >> 8);
+        for (; row < min(full_b, row_e); ++row) partial_row(row);
+        for (; row < full_e; ++row) {
+            const int base = row * 256, p0 = base + lane * 4;
+            int c0, c1, c2, c3;
+            row_values(p0, c0, c1, c2, c3);
+            *reinterpret_cast<int4 *>(&a.cov[a0 + p0]) = make_int4(c0, c1, c2, c3);
+            const unsigned long long M0 = __ballot(c0 >= a.high_cov), M1 = __ballot(c1 >= a.high_cov),
+                                     M2 = __ballot(c2 >= a.high_cov), M3 = __ballot(c3 >= a.high_cov);
+            if ((M0 | M1 | M2 | M3) != 0ull || hp) scan_row(row, base, p0, M0, M1, M2, M3);
+        }
+        for (; row < row_e; ++row) partial_row(row);
     }
 
-    // 6. hand the wave's seam state to the stitcher
+    // 6. publish the wave's seam state: rows, slot where the inherited run closed, start of the run open at the
+    //    end, high at the end, high at the start
     {
         const unsigned long long pm = __ballot(pclose >= 0);
         int pc = -1;
         if (pm) pc = __builtin_amdgcn_readlane(pclose, (int)__builtin_ctzll(pm));
-        covsum = wave_reduce_add64(covsum);
+        pclose = pc;
         if (lane == 0) {
-            int4 w0 = make_int4(row_e > row_b ? 1 : 0, pc, S, hp ? 1 : 0);
-            *reinterpret_cast<int4 *>(&sm.wst[wid * 8]) = w0;
+            *reinterpret_cast<int4 *>(&sm.wst[wid * 8]) = make_int4(row_e > row_b ? 1 : 0, pc, S, hp ? 1 : 0);
             sm.wst[wid * 8 + 4] = hp_in ? 1 : 0;
-            sm.wst[wid * 8 + 5] = (hp_in || hp || pc >= 0) ? 1 : 0;
-            if (covsum) atomicAdd(&sm.acc_cov, (unsigned long long)covsum);
         }
     }
     RAFT_STAMP(5);
     lds_barrier();
     RAFT_STAMP(6);
 
-    // 7. stitch runs across wave seams and the window end (step w == NW is the window end): wave 0 reads all
-    //    seam words with one LDS instruction and walks them as scalars; skipped when no seam carries a run
-    if (wid == 0) {
+    // 7. seams, resolved by every wave for itself (no serial walk): a run inherited from earlier waves starts at
+    //    the run-start of the nearest earlier wave that saw one (or at the chunk carry); the wave holding the last
+    //    valid slot closes the run that reaches the window end, or carries it into the next chunk.
+    {
         const int v = (lane < NW * 8) ? sm.wst[lane] : 0;
-        const unsigned long long needm = __ballot((lane & 7) == 5 && v != 0);
-        if (needm != 0ull || single_read) {
-            long long open = (single_read && !first_chunk) ? uni(sm.carry_open) : -1;
-#pragma unroll 1
-            for (int w = 0; w <= NW; ++w) {
-                bool do_emit = false;
-                long long gT = 0;
-                int hpfinal = 0, sfinal = kNone;
-                if (w < NW) {
-                    if (!__builtin_amdgcn_readlane(v, w * 8 + 0)) continue;
-                    const int pcl = __builtin_amdgcn_readlane(v, w * 8 + 1);
-                    sfinal = __builtin_amdgcn_readlane(v, w * 8 + 2);
-                    hpfinal = __builtin_amdgcn_readlane(v, w * 8 + 3);
-                    const int hpin = __builtin_amdgcn_readlane(v, w * 8 + 4);
-                    if (hpin && pcl >= 0 && open >= 0) { do_emit = true; gT = a0 + pcl; }
-                } else if (last_chunk && open >= 0) { do_emit = true; gT = w_hi; } // end of read closes the run (repeat.hpp:150)
-                if (do_emit) {
-                    if (lane == 0) emit_run(a, sm, nr, (int)(open - a0), (int)(gT - a0));
-                    open = -1;
-                }
-                if (w < NW) {
-                    if (hpfinal) { if (sfinal != kOpen) open = a0 + sfinal; }
-                    else open = -1;
-                }
+        const long long carry_open = (single_read && !first_chunk) ? uni(sm.carry_open) : -1;
+        auto run_start_before = [&](int w) -> long long { // start (global window) of the run open at the end of wave w
+#pragma unroll
+            for (int y = NW - 1; y >= 0; --y) {
+                if (y > w) continue;
+                if (!__builtin_amdgcn_readlane(v, y * 8 + 0)) continue;
+                const int sf = __builtin_amdgcn_readlane(v, y * 8 + 2);
+                if (sf != kOpen) return a0 + sf;
             }
-            if (lane == 0) { sm.carry_open = open; sm.carry_hp = open >= 0 ? 1 : 0; }
+            return carry_open;
+        };
+        auto park = [&](long long gS, long long gT) {
+            if (gS < 0 || (gT - gS) * (long long)a.reso < (long long)a.repeat_length) return;
+            if (lane == 0) {
+                const int q = atomicAdd(&sm.runq_n[wid], 1);
+                if (q < kRunQ) { sm.runq[(wid * kRunQ + q) * 2] = (int)(gS - a0); sm.runq[(wid * kRunQ + q) * 2 + 1] = (int)(gT - a0); }
+                else emit_run(a, sm, nr, (int)(gS - a0), (int)(gT - a0));
+            }
+        };
+        if (row_e > row_b) {
+            if (hp_in && pclose >= 0) park(wid == 0 ? carry_open : run_start_before(wid - 1), a0 + pclose);
+            const bool last_wave = (row_e == rows);           // this wave holds the last valid slot
+            if (last_wave) {
+                const long long open = hp ? ((S != kOpen) ? a0 + S : (wid == 0 ? carry_open : run_start_before(wid - 1))) : -1;
+                if (last_chunk) { if (open >= 0) park(open, w_hi); }   // end of read closes the run (repeat.hpp:150)
+                if (single_read && lane == 0) { sm.carry_open = last_chunk ? -1 : open; sm.carry_hp = (!last_chunk && open >= 0) ? 1 : 0; }
+            }
         }
     }
+    RAFT_STAMP(11);
+
+    // 8. every run this wave parked becomes a repeat record, one lane per run, so their LDS look-ups overlap
+    {
+        const int nq = uni(sm.runq_n[wid]);
+        if (nq > 0) {
+            const int m = min(nq, kRunQ);
+            int sS = 0, sT = 0, j = 0;
+            if (lane < m) { sS = sm.runq[(wid * kRunQ + lane) * 2]; sT = sm.runq[(wid * kRunQ + lane) * 2 + 1]; }
+            if (nr <= 64) {
+                // owner of each run by one compare + ballot per run against the (register-held) read offsets
+                const int ro = (lane < nr) ? sm.roff[lane] : 0x7fffffff;
+#pragma unroll 1
+                for (int q = 0; q < m; ++q) {
+                    const int jq = __popcll(__ballot(ro <= __builtin_amdgcn_readlane(sS, q))) - 1;
+                    if (lane == q) j = jq;
+                }
+            } else if (lane < m) j = owner_slot(sm, nr, sS);
+            if (lane < m) emit_run_of(a, sm, j, sS, sT);
+            if (lane == 0) sm.runq_n[wid] = 0;
+        }
+    }
+    RAFT_STAMP(13);
     lds_barrier();
+    RAFT_STAMP(14);
     // publish the repeat counts of the reads that are complete (rep_cnt[] was zeroed by the host)
     if (tid < nr && (!single_read || last_chunk)) {
         const int c = sm.rcnt[tid];
@@ -513,6 +575,7 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
     const long long nb = gridDim.x;
     const int32_t *td_words = reinterpret_cast<const int32_t *>(a.td);
     if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; sm.carry_open = -1; sm.carry_hp = 0; }
+    if (tid < Smem::NW) sm.runq_n[tid] = 0;
 
     // Descriptors travel as ONE VGPR (lane l holds dword l): raw_n = tile k+nb (landed), raw_nn = tile k+2nb (in
     // flight).  Only the current tile's descriptor is kept unpacked in scalars across the window code.
@@ -622,7 +685,7 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
         RAFT_STAMP(7);
         if (DIAG && tid == 0 && a.dbg) {
             sm.stamps[10] = __builtin_amdgcn_s_memrealtime();
-            for (int i = 0; i < 11; ++i) a.dbg[k * 16 + i] = sm.stamps[i];
+            for (int i = 0; i < 15; ++i) a.dbg[k * 16 + i] = sm.stamps[i];
         }
 
         k = kn; simple = nsimple; g = gn;
