@@ -298,6 +298,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     if (n_reads > 0 && !d_len) return RAFT_HIP_ERR_PARAM;
     if (n_rec > 0 && (!d_qid || !d_qs || !d_qe || !d_tid || !d_ts || !d_te)) return RAFT_HIP_ERR_PARAM;
     if (n_reads == INT32_MAX) return RAFT_HIP_ERR_TOO_LARGE;
+    if (n_rec >= (1LL << 29)) return RAFT_HIP_ERR_TOO_LARGE;   // interval byte offsets are 32-bit (2 sides per record at most)
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1;

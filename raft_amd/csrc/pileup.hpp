@@ -217,14 +217,35 @@ struct TileRegs {            // descriptor unpacked into scalars
     int seg_cum[kMaxSeg + 1];
 };
 
-// v-th interval of a window whose segments are (seg_lo[s], seg_cum[s] .. seg_cum[s+1])
-__device__ __forceinline__ long long iv_index_of(const long long (&seg_lo)[kMaxSeg], const int (&seg_cum)[kMaxSeg + 1], int v)
+// v-th interval of a window whose segments are (seg_lo[s], seg_cum[s] .. seg_cum[s+1]): its index relative to
+// seg_lo[0], in 32 bits (the host guarantees fewer than 2^30 intervals, so the byte offset fits 32 bits and the
+// loads use scalar base + 32-bit vector offset addressing)
+__device__ __forceinline__ unsigned iv_rel_of(const long long (&seg_lo)[kMaxSeg], const int (&seg_cum)[kMaxSeg + 1], int v)
 {
-    long long idx = seg_lo[0] + v;
+    int d = 0;
 #pragma unroll
     for (int s = 1; s < kMaxSeg; ++s)
-        if (v >= seg_cum[s]) idx = seg_lo[s] + (v - seg_cum[s]);
-    return idx;
+        if (v >= seg_cum[s]) d = (int)(seg_lo[s] - seg_lo[0]) - seg_cum[s];
+    return (unsigned)(v + d);
+}
+
+template <int THREADS, int U>
+__device__ __forceinline__ void load_intervals(const PileupArgs &a, int v0, const long long (&seg_lo)[kMaxSeg],
+                                               const int (&seg_cum)[kMaxSeg + 1], Prefetch<U> &g)
+{
+    const int n_iv = seg_cum[kMaxSeg];
+    const char *b_rid = reinterpret_cast<const char *>(a.iv_rid + seg_lo[0]);
+    const char *b_s = reinterpret_cast<const char *>(a.iv_s + seg_lo[0]);
+    const char *b_e = reinterpret_cast<const char *>(a.iv_e + seg_lo[0]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int v = v0 + u * THREADS;
+        const bool ok = v < n_iv;
+        const unsigned off = iv_rel_of(seg_lo, seg_cum, v) * 4u;
+        g.rid[u] = ok ? *reinterpret_cast<const int32_t *>(b_rid + off) : -1;
+        g.st[u] = ok ? *reinterpret_cast<const int32_t *>(b_s + off) : 0;
+        g.en[u] = ok ? *reinterpret_cast<const int32_t *>(b_e + off) : 0;
+    }
 }
 
 template <int THREADS, int U>
@@ -238,16 +259,7 @@ __device__ __forceinline__ void issue_prefetch(const PileupArgs &a, int tid, int
         g.rr = reinterpret_cast<const int32_t *>(a.rep_res_off)[2 * (long long)(r_a + tid)];
         g.rl = (tid < nr) ? a.read_len[r_a + tid] : 0;
     }
-    const int n_iv = seg_cum[kMaxSeg];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int v = tid + u * THREADS;
-        const bool ok = v < n_iv;
-        const long long i = ok ? iv_index_of(seg_lo, seg_cum, v) : 0;
-        g.rid[u] = ok ? a.iv_rid[i] : -1;
-        g.st[u] = ok ? a.iv_s[i] : 0;
-        g.en[u] = ok ? a.iv_e[i] : 0;
-    }
+    load_intervals<THREADS, U>(a, tid, seg_lo, seg_cum, g);
 }
 
 // Diagnostic build only: s_memtime stamps are parked in LDS (a global store would queue behind the coverage stores
@@ -300,44 +312,35 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
         }
     }
 
-    // 3. intervals -> +1 / -1 (profileCoverage, closed form); U records in flight per lane
+    // 3. intervals -> +1 / -1 (profileCoverage, closed form); U records in flight per lane.  One predicated region
+    //    per record (the two LDS adds); malformed records only set a lane flag that is looked at once per window.
     int covsum = 0;
+    int bad_v = -1;                              // a record of this lane with a coordinate error (virtual index)
     for (int v0 = tid; v0 < n_iv; v0 += THREADS * U) {
-        if (v0 != tid) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int v = v0 + u * THREADS;
-                const bool ok = v < n_iv;
-                const long long i = ok ? iv_index_of(seg_lo, seg_cum, v) : 0;
-                g.rid[u] = ok ? a.iv_rid[i] : -1;
-                g.st[u] = ok ? a.iv_s[i] : 0;
-                g.en[u] = ok ? a.iv_e[i] : 0;
-            }
-        }
+        if (v0 != tid) load_intervals<THREADS, U>(a, v0, seg_lo, seg_cum, g);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (g.rid[u] < 0) continue;
-            if ((g.st[u] | g.en[u]) < 0) { raise_error(a, kErrCoord, iv_index_of(seg_lo, seg_cum, v0 + u * THREADS)); continue; }
-            const int first = (int)win_of(a, (unsigned)g.st[u]);
-            int last = (g.en[u] > 0) ? (int)win_of(a, (unsigned)(g.en[u] - 1)) : -1;
-            if (last < first) continue;
-            const int j = g.rid[u] - r_a;
+            const int st = g.st[u], en = g.en[u];
+            const bool valid = g.rid[u] >= 0;
+            const int j = valid ? g.rid[u] - r_a : 0;
             const int b0 = sm.roff[j], nb_r = sm.roff[j + 1] - b0;
-            if (last >= nb_r) {             // reference writes past its vector here (repeat.hpp:69-72)
-                raise_error(a, kErrCoord, iv_index_of(seg_lo, seg_cum, v0 + u * THREADS));
-                last = nb_r - 1;
-                if (last < first) continue;
+            const int first = (int)win_of(a, (unsigned)st);
+            int last = (en > 0) ? (int)win_of(a, (unsigned)(en - 1)) : -1;
+            const bool neg = (st | en) < 0;
+            const bool over = !neg && last >= first && last >= nb_r; // reference writes past its vector (repeat.hpp:69-72)
+            if (valid && (neg || over)) bad_v = v0 + u * THREADS;
+            last = min(last, nb_r - 1);
+            int pf = b0 + first, pl1 = b0 + last + 1;   // slots relative to a0
+            if (single_read) { pf = max(pf, off0); pl1 = min(pl1, t_end); }
+            if (valid && !neg && pf < pl1) {
+                __hip_atomic_fetch_add(&sm.diff[pf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sm.diff[pl1], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                covsum += pl1 - pf;        // sum of coverage over the window == windows touched by its intervals
             }
-            int pf = b0 + first, pl1 = b0 + last + 1; // slots relative to a0
-            if (single_read) {
-                pf = max(pf, off0);
-                pl1 = min(pl1, t_end);
-                if (pf >= pl1) continue;
-            }
-            __hip_atomic_fetch_add(&sm.diff[pf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&sm.diff[pl1], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            covsum += pl1 - pf;            // sum of coverage over the window == windows touched by its intervals
         }
+    }
+    if (__ballot(bad_v >= 0) != 0ull) {          // rare
+        if (bad_v >= 0) raise_error(a, kErrCoord, seg_lo[0] + (long long)iv_rel_of(seg_lo, seg_cum, bad_v));
     }
     {
         const long long cs = wave_reduce_add64((long long)covsum);
@@ -365,6 +368,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     // Every load issued so far -- including the NEXT tile's prefetch -- must land before this wave's first
     // coverage store: after the stores, any vmcnt wait would also wait for the stores.
     wait_all_loads();
+    RAFT_STAMP(15);
 
     // 5. pass B: prefix sum, store, run detection.  Rows that lie entirely inside the window (all but the first
     //    and last of a window) take the lean path: no per-slot validity masks.
@@ -431,9 +435,8 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
             hp = ((Mk >> (tl >> 2)) & 1ull) != 0ull;
         }
     };
-    // prefix sum of one row of 256 slots
-    auto row_values = [&](int p0, int &c0, int &c1, int &c2, int &c3) {
-        const int4 d = *reinterpret_cast<const int4 *>(&sm.diff[p0]);
+    // prefix sum of one row of 256 slots, given the row's four differences per lane
+    auto row_values = [&](const int4 d, int &c0, int &c1, int &c2, int &c3) {
         const int x = d.x, y = x + d.y, z = y + d.z, w = z + d.w;
         const int incl = wave_incl_scan_add(w);
         const int excl = incl - w + carry;
@@ -443,7 +446,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     auto partial_row = [&](int row) {          // first / last rows of a window: per-slot validity
         const int base = row * 256, p0 = base + lane * 4;
         int c0, c1, c2, c3;
-        row_values(p0, c0, c1, c2, c3);
+        row_values(*reinterpret_cast<const int4 *>(&sm.diff[p0]), c0, c1, c2, c3);
         const unsigned q0 = (unsigned)(p0 - off0), nbw_u = (unsigned)(t_end - off0);
         const unsigned long long M0 = __ballot(c0 >= a.high_cov && q0 + 0u < nbw_u), M1 = __ballot(c1 >= a.high_cov && q0 + 1u < nbw_u),
                                  M2 = __ballot(c2 >= a.high_cov && q0 + 2u < nbw_u), M3 = __ballot(c3 >= a.high_cov && q0 + 3u < nbw_u);
@@ -458,10 +461,15 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
         // rows [full_b, full_e) are entirely inside [off0, t_end)
         const int full_b = max(row_b, (off0 + 255) >> 8), full_e = min(row_e, t_end >> 8);
         for (; row < min(full_b, row_e); ++row) partial_row(row);
+        // the next row's LDS read is issued before the current row's scan: the read latency hides under the DPP chain
+        int4 dn = make_int4(0, 0, 0, 0);
+        if (row < full_e) dn = *reinterpret_cast<const int4 *>(&sm.diff[row * 256 + lane * 4]);
         for (; row < full_e; ++row) {
             const int base = row * 256, p0 = base + lane * 4;
+            const int4 dc = dn;
+            if (row + 1 < full_e) dn = *reinterpret_cast<const int4 *>(&sm.diff[p0 + 256]);
             int c0, c1, c2, c3;
-            row_values(p0, c0, c1, c2, c3);
+            row_values(dc, c0, c1, c2, c3);
             *reinterpret_cast<int4 *>(&a.cov[a0 + p0]) = make_int4(c0, c1, c2, c3);
             const unsigned long long M0 = __ballot(c0 >= a.high_cov), M1 = __ballot(c1 >= a.high_cov),
                                      M2 = __ballot(c2 >= a.high_cov), M3 = __ballot(c3 >= a.high_cov);
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
         RAFT_STAMP(7);
         if (DIAG && tid == 0 && a.dbg) {
             sm.stamps[10] = __builtin_amdgcn_s_memrealtime();
-            for (int i = 0; i < 15; ++i) a.dbg[k * 16 + i] = sm.stamps[i];
+            for (int i = 0; i < 16; ++i) a.dbg[k * 16 + i] = sm.stamps[i];
         }
 
         k = kn; simple = nsimple; g = gn;

@@ -31,6 +31,8 @@ life = st[:, 7] - st[:, 0]
 print(f"lifetime cycles: median {np.median(life):.0f} mean {life.mean():.0f} p90 {np.percentile(life,90):.0f}")
 for i, n in enumerate(names):
     print(f"  {n:22s} median {np.median(d[:, i]):8.0f}  mean {d[:, i].mean():8.0f}  share {d[:, i].sum()/life.sum():.3f}")
+w = st[:, 15] - st[:, 4]
+print(f"  4->15 vmcnt(0) before pass B  median {np.median(w):8.0f} mean {w.mean():8.0f}")
 sub = np.stack([st[:, 11] - st[:, 6], st[:, 13] - st[:, 11], st[:, 14] - st[:, 13], st[:, 7] - st[:, 14]], 1)
 for n, c in zip(["  6->11 resolve seams", "  11->13 emit parked runs", "  13->14 barrier", "  14->7 publish counts"], sub.T):
     print(f"{n:28s} median {np.median(c):8.0f} mean {c.mean():8.0f}")
