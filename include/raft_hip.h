@@ -159,7 +159,7 @@ int  raft_hip_last_timing(raft_hip_ctx *ctx, double *pileup_seconds, double *pas
  * variant (-1 = default; see kVariants in raft_amd/csrc/engine.hip). */
 int  raft_hip_set_tuning(raft_hip_ctx *ctx, int32_t tile_bins, int32_t force_bucket_path, int32_t variant);
 
-/* Diagnostic variant (4) only: copies the per-workgroup s_memtime stamps of the last pass
+/* Diagnostic variant (3) only: copies the per-workgroup s_memtime stamps of the last pass
  * (16 uint64 per tile) to `host`; *n_tiles receives the number of tiles of that pass. */
 int  raft_hip_debug_stamps(raft_hip_ctx *ctx, unsigned long long *host, int64_t max_tiles, int64_t *n_tiles);
 

@@ -24,16 +24,14 @@ namespace {
 // CAP - short_max, so that a tile whose reads all have at most short_max windows always fits one LDS window.
 struct PileVariant { int threads, cap, minw, short_max, blocks_per_cu; };
 constexpr PileVariant kVariants[] = {
-    {256, 6144, 5, 2048, 5},   // 0: 31.8 KB LDS, 5 workgroups/CU (default)
-    {256, 4864, 6, 1536, 6},   // 1: 26.6 KB LDS, 6 workgroups/CU
-    {256, 3072, 8, 1024, 8},   // 2: 19.2 KB LDS, 8 workgroups/CU
-    {512, 13312, 4, 4096, 2},  // 3: 66.3 KB LDS, 2 workgroups of 8 waves per CU
-    {256, 6144, 5, 2048, 5},   // 4: variant 0 with s_memtime stamps (diagnostic build; raft_hip_debug_stamps)
-    {256, 7424, 4, 2048, 4},   // 5: 36.9 KB LDS, 4 workgroups/CU, 128 VGPRs
+    {256, 6144, 5, 2048, 5},   // 0: 30.8 KB LDS, 5 workgroups/CU, 3 intervals per lane in flight (default)
+    {256, 4864, 6, 1536, 6},   // 1: 25.5 KB LDS, 6 workgroups/CU, 2 intervals per lane
+    {256, 7424, 4, 2048, 4},   // 2: 36.0 KB LDS, 4 workgroups/CU, 4 intervals per lane
+    {256, 6144, 5, 2048, 5},   // 3: variant 0 with s_memtime stamps (diagnostic build; raft_hip_debug_stamps)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kDefaultVariant = 0;
-constexpr int kDiagVariant = 4;
+constexpr int kDiagVariant = 3;
 
 template <int T, int CAP, int MINW, int U, bool DIAG = false>
 void launch_pileup(hipStream_t st, unsigned grid, const PileupArgs &pa)
@@ -474,10 +472,8 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     switch (c->variant) {
     case 0: launch_pileup<256, 6144, 5, 3>(st, pgrid, pa); break;
     case 1: launch_pileup<256, 4864, 6, 2>(st, pgrid, pa); break;
-    case 2: launch_pileup<256, 3072, 8, 2>(st, pgrid, pa); break;
-    case 3: launch_pileup<512, 13312, 4, 4>(st, pgrid, pa); break;
-    case 4: launch_pileup<256, 6144, 5, 3, true>(st, pgrid, pa); break;
-    default: launch_pileup<256, 7424, 4, 4>(st, pgrid, pa); break;
+    case 2: launch_pileup<256, 7424, 4, 4>(st, pgrid, pa); break;
+    default: launch_pileup<256, 6144, 5, 3, true>(st, pgrid, pa); break;
     }
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
 

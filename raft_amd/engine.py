@@ -83,7 +83,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or _LIB_PATH
+    p = path or os.environ.get("RAFT_HIP_LIB") or _LIB_PATH   # RAFT_HIP_LIB: A/B runs of two builds in one session
     if not os.path.exists(p):
         raise RuntimeError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the RAFT hot path)")
@@ -237,7 +237,7 @@ class Engine:
         return out
 
     def debug_stamps(self, max_tiles: int = 1 << 20) -> np.ndarray:
-        """Diagnostic kernel variant 4: per-tile s_memtime stamps [n, 16] of the last pass."""
+        """Diagnostic kernel variant 3: per-tile s_memtime stamps [n, 16] of the last pass."""
         n = C.c_int64()
         self._check(self._lib.raft_hip_debug_stamps(self._ctx, None, 0, C.byref(n)))
         m = min(int(n.value), max_tiles)

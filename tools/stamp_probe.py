@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase s_memtime shares of the pileup kernel (variant 4 = variant 0 + stamps).
+"""Diagnostic: per-phase s_memtime shares of the pileup kernel (variant 3 = variant 0 + stamps).
 
 Stamps per tile (thread 0): 0 kernel entry, 1 after tile descriptor loads, 2 after LDS clear + offset
 table, 3 after interval phase, 4 after pass A, 5 own wave done with pass B, 6 all waves done, 7 exit.
@@ -17,7 +17,7 @@ from raft_amd.synth import make_overlaps
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 o = make_overlaps(reads, mean_len=30000.0, coverage=32.0, seed=7, device="cuda:0")
 eng = engine.Engine(RaftParams(est_cov=32))
-eng.set_tuning(0, False, 4)
+eng.set_tuning(0, False, 3)
 for _ in range(2):
     eng.run_device(o.read_len, *o.columns()); s = eng.finish()
 st = eng.debug_stamps().astype(np.int64)
