@@ -89,11 +89,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()
     dist = None
+    coll_dev = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if n_dev >= world:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))     # RCCL over xGMI
+            coll_dev = f"cuda:{local}"
+        else:
+            # fewer GPUs than ranks (a 1-GPU box): ranks share devices and the tiny collectives go through gloo --
+            # only good for checking the multi-rank code path, not a scaling number
+            local = local % max(n_dev, 1)
+            dist.init_process_group("gloo")
+            coll_dev = "cpu"
     n_gpus = max(world, 1)
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
@@ -107,14 +117,14 @@ def main():
     eng = engine.Engine(p, device=local)
     eng.set_tuning(args.tile_bins, args.force_bucket, args.variant)
     eng.use_torch_stream()
-    frag_totals = torch.zeros(n_gpus, dtype=torch.int64, device=dev)
+    from raft_amd import dist as rdist
 
     def step():
         eng.run_device(*cols)
         s = eng.finish()
-        if dist is not None:  # global read_num base of this shard's fragments (chop.hpp:195 is one global counter)
-            mine = torch.tensor([s.n_fragments], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(frag_totals, mine)
+        if dist is not None:  # global read_num base of this shard's fragments + the stdout sums (chop.hpp:195, repeat.hpp:93-97)
+            rdist.combine_totals(s.n_fragments, s.total_coverage, s.total_windows, s.total_repeat_length,
+                                 s.total_read_length, device=coll_dev)
         return s
 
     for _ in range(args.warmup):
@@ -135,10 +145,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([o.n_rec, s.n_fragments, s.n_bins, s.n_intervals], dtype=torch.int64, device=dev)
+        cnt = torch.tensor([o.n_rec, s.n_fragments, s.n_bins, s.n_intervals], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         tot_rec, tot_frag, tot_bins, tot_iv = (int(x) for x in cnt.tolist())
     else:
@@ -164,7 +174,7 @@ def main():
                        "windows_total": tot_bins, "intervals_total": tot_iv, "fragments_total": tot_frag,
                        "repeats_rank0": s.n_repeats, "mean_read_len": args.mean_len, "coverage": args.coverage,
                        "interval_path": "sorted-segments" if s.interval_path == 0 else "counting-sort",
-                       "segments": s.n_segments, "sharding": f"reads x{n_gpus}, no data-path collective"},
+                       "segments": s.n_segments, "sharding": f"reads x{n_gpus}, no data-path collective" + (", ranks share GPUs (gloo check run)" if world > 1 and n_dev < world else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "pileup_kernel" + ("" if args.variant < 0 else f" variant {args.variant}"),
                          "kernel_ms": pile * 1e3, "bytes_algorithmic": bytes_alg,
