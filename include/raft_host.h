@@ -36,6 +36,12 @@ enum {
 typedef struct raft_host_reads raft_host_reads;
 typedef struct raft_host_paf raft_host_paf;
 
+/* Worker threads used by the loaders and writers below (the reference is single-threaded; output bytes do not
+ * depend on the count).  Default: RAFT_HOST_THREADS, else the hardware threads, capped at 32.  n = 0 restores the
+ * default, n = 1 runs everything on the calling thread. */
+int            raft_host_set_threads(int n);
+int            raft_host_get_threads(void);
+
 /* reads */
 int            raft_host_reads_load(const char *path, raft_host_reads **out);
 void           raft_host_reads_free(raft_host_reads *r);

@@ -15,14 +15,47 @@
 
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
+
+// Worker threads of the host layer: RAFT_HOST_THREADS (default: hardware threads, at most 32).  1 = everything
+// inline on the calling thread (the reference's own behaviour; used by tests to cross-check the parallel paths).
+std::atomic<int> g_threads{0};   // 0 = not chosen yet
+
+int host_threads()
+{
+    int n = g_threads.load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    const char *e = getenv("RAFT_HOST_THREADS");
+    int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    n = std::min(std::max(v, 1), 32);
+    g_threads.store(n, std::memory_order_relaxed);
+    return n;
+}
+
+template <class F> void parallel_for(int n_tasks, F fn)   // fn(task) for task in [0, n_tasks), one thread per task
+{
+    if (n_tasks <= 1) { for (int t = 0; t < n_tasks; ++t) fn(t); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)n_tasks - 1);
+    for (int t = 1; t < n_tasks; ++t) th.emplace_back([&fn, t] { fn(t); });
+    fn(0);
+    for (auto &x : th) x.join();
+}
 
 // ---- buffered byte stream over gz/plain files --------------------------------------------------
 class Stream {
@@ -183,6 +216,49 @@ private:
     bool err_ = false;
 };
 
+// Appends v in decimal.
+inline void put_num(std::string &b, long long v)
+{
+    char t[24];
+    int n = 0;
+    unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) t[n++] = '-';
+    while (n) b.push_back(t[--n]);
+}
+
+// Writes items 0..n-1 to `path` in order.  Items are grouped into blocks of about `block` weight units; up to
+// host_threads() blocks are formatted concurrently (fmt(i, buffer) appends item i) and then written in order, so
+// the bytes are exactly those of a sequential writer.
+template <class W, class F>
+int write_ordered(const char *path, long long n, long long block, W weight, F fmt)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return RAFT_HOST_ERR_IO;
+    const int T = host_threads();
+    bool ok = true;
+    long long i = 0;
+    std::vector<std::string> buf((size_t)T);
+    while (i < n && ok) {
+        std::vector<long long> cut{i};
+        for (int t = 0; t < T && cut.back() < n; ++t) {
+            long long j = cut.back(), acc = 0;
+            while (j < n && acc < block) acc += weight(j++);
+            cut.push_back(j);
+        }
+        const int nb = (int)cut.size() - 1;
+        parallel_for(nb, [&](int t) {
+            buf[(size_t)t].clear();
+            for (long long k = cut[(size_t)t]; k < cut[(size_t)t + 1]; ++k) fmt(k, buf[(size_t)t]);
+        });
+        for (int t = 0; t < nb && ok; ++t)
+            if (!buf[(size_t)t].empty() && fwrite(buf[(size_t)t].data(), 1, buf[(size_t)t].size(), f) != buf[(size_t)t].size()) ok = false;
+        i = cut.back();
+    }
+    if (fclose(f) != 0) ok = false;
+    return ok ? RAFT_HOST_OK : RAFT_HOST_ERR_IO;
+}
+
 } // namespace
 
 struct raft_host_reads {
@@ -200,12 +276,170 @@ struct raft_host_paf {
     std::vector<int32_t> col[6];
 };
 
+namespace {
+
+// Name-derived state of one read, in file order: mode decision on the first read (chop.hpp:99-106), id assignment
+// (chop.hpp:108), and the simulated-read fields (chop.hpp:25-70, 116-121).
+int add_read_meta(raft_host_reads *R, const std::string &name)
+{
+    if (R->names.size() == 0 && looks_simulated(name)) R->real_reads = 0;
+    const int32_t id = R->names.add(name.data(), name.size());
+    if (id < 0) return RAFT_HOST_ERR_DUP_NAME;
+    if (!R->real_reads) {
+        // position=<start>-<end>, second field = orientation, last field = contig
+        const size_t c1 = name.find(',');
+        size_t eq = c1 == std::string::npos ? std::string::npos : name.find('=', c1);
+        int32_t sp = 0, ep = 0;
+        if (eq != std::string::npos) sp = atoi(name.c_str() + eq + 1);
+        const size_t dash = name.find('-');
+        if (dash != std::string::npos) ep = atoi(name.c_str() + dash + 1);
+        R->start_pos.push_back(sp); R->end_pos.push_back(ep);
+        std::string al;
+        if (c1 != std::string::npos) { const size_t c2 = name.find(',', c1 + 1); al = name.substr(c1 + 1, c2 == std::string::npos ? std::string::npos : c2 - c1 - 1); }
+        R->align.push_back(al);
+        const size_t lc = name.rfind(',');
+        R->chr.push_back(lc == std::string::npos ? std::string() : name.substr(lc + 1));
+    }
+    return RAFT_HOST_OK;
+}
+
+// Fast path for the common input: an uncompressed FASTA whose first byte is '>' and which holds no '\r' and no line
+// starting with '@' or '+'.  On such a file kseq's state machine (chop.hpp:88-131 via kseq.h) reduces to "a record
+// starts at every line that begins with '>'", so the file is mapped, cut into byte ranges, and scanned by
+// host_threads() workers.  Returns -1 when the file is not of that shape (the streaming reader then handles it),
+// otherwise a RAFT_HOST_* code.  Results are identical to the streaming reader's.
+int load_plain_fasta_parallel(const char *path, raft_host_reads *R)
+{
+    const int T = host_threads();
+    if (T <= 1) return -1;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { close(fd); return -1; }
+    const size_t n = (size_t)st.st_size;
+    void *map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return -1;
+    const char *d = static_cast<const char *>(map);
+    struct Unmap { void *p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, n};
+    if (d[0] != '>') return -1;
+
+    // pass 0: record starts per byte range; eligibility
+    std::vector<std::vector<size_t>> starts((size_t)T);
+    std::vector<char> bad((size_t)T, 0);
+    parallel_for(T, [&](int t) {
+        const size_t lo = n * (size_t)t / (size_t)T, hi = n * ((size_t)t + 1) / (size_t)T;
+        if (lo >= hi) return;
+        if (memchr(d + lo, '\r', hi - lo)) { bad[(size_t)t] = 1; return; }
+        auto &v = starts[(size_t)t];
+        auto line_start = [&](size_t q) {
+            const char c = d[q];
+            if (c == '>') v.push_back(q);
+            else if (c == '@' || c == '+') bad[(size_t)t] = 1;
+        };
+        if (lo == 0) line_start(0);
+        // a line start q belongs to the range holding q; its '\n' is at q-1 >= lo-1
+        size_t p = lo == 0 ? 0 : lo - 1;
+        while (p < hi - 1) {
+            const char *nl = static_cast<const char *>(memchr(d + p, '\n', hi - 1 - p));
+            if (!nl) break;
+            const size_t q = (size_t)(nl - d) + 1;
+            line_start(q);
+            p = q;
+        }
+    });
+    for (char b : bad) if (b) return -1;
+    std::vector<size_t> rec;
+    for (auto &v : starts) rec.insert(rec.end(), v.begin(), v.end());
+    size_t data_end = n;
+    if (!rec.empty() && rec.back() + 1 == n) { data_end = rec.back(); rec.pop_back(); }   // bare '>' as the last byte: kseq finds no name and stops
+    const size_t n_rec = rec.size();
+    if (n_rec > 0x7fffffffull) return RAFT_HOST_ERR_ARG;
+
+    // pass 1: name span, first sequence byte, sequence length of every record
+    std::vector<size_t> name_end(n_rec), seq_begin(n_rec);
+    R->lens.assign(n_rec, 0);
+    auto rec_range = [&](int t, size_t &a, size_t &b) { a = n_rec * (size_t)t / (size_t)T; b = n_rec * ((size_t)t + 1) / (size_t)T; };
+    parallel_for(T, [&](int t) {
+        size_t a, b;
+        rec_range(t, a, b);
+        for (size_t i = a; i < b; ++i) {
+            const size_t end = i + 1 < n_rec ? rec[i + 1] : data_end;
+            size_t q = rec[i] + 1;
+            while (q < end && !isspace((unsigned char)d[q])) ++q;
+            name_end[i] = q;
+            if (q < end && d[q] != '\n') {                          // comment: skipped to the end of the line
+                const char *nl = static_cast<const char *>(memchr(d + q, '\n', end - q));
+                q = nl ? (size_t)(nl - d) : end;
+            }
+            const size_t sb = q < end ? q + 1 : end;
+            seq_begin[i] = sb;
+            size_t newlines = 0;
+            for (size_t p = sb; p < end;) {
+                const char *nl = static_cast<const char *>(memchr(d + p, '\n', end - p));
+                if (!nl) break;
+                ++newlines;
+                p = (size_t)(nl - d) + 1;
+            }
+            R->lens[i] = (int32_t)(end - sb - newlines);
+        }
+    });
+    R->base_off.resize(n_rec);
+    size_t total = 0;
+    for (size_t i = 0; i < n_rec; ++i) { R->base_off[i] = total; total += (size_t)R->lens[i]; }
+    R->bases.resize(total);
+
+    // pass 2: bases, lines joined
+    parallel_for(T, [&](int t) {
+        size_t a, b;
+        rec_range(t, a, b);
+        for (size_t i = a; i < b; ++i) {
+            const size_t end = i + 1 < n_rec ? rec[i + 1] : data_end;
+            char *dst = &R->bases[0] + R->base_off[i];
+            for (size_t p = seq_begin[i]; p < end;) {
+                const char *nl = static_cast<const char *>(memchr(d + p, '\n', end - p));
+                const size_t le = nl ? (size_t)(nl - d) : end;
+                memcpy(dst, d + p, le - p);
+                dst += le - p;
+                p = le + 1;
+            }
+        }
+    });
+
+    // names, in file order (ids are FASTA positions)
+    std::string name;
+    for (size_t i = 0; i < n_rec; ++i) {
+        name.assign(d + rec[i] + 1, name_end[i] - rec[i] - 1);
+        const int rc = add_read_meta(R, name);
+        if (rc != RAFT_HOST_OK) return rc;
+    }
+    return RAFT_HOST_OK;
+}
+
+} // namespace
+
 extern "C" {
+
+int raft_host_set_threads(int n)
+{
+    if (n < 0) return RAFT_HOST_ERR_ARG;
+    g_threads.store(n > 32 ? 32 : n, std::memory_order_relaxed);   // 0: back to RAFT_HOST_THREADS / hardware default
+    return RAFT_HOST_OK;
+}
+
+int raft_host_get_threads(void) { return host_threads(); }
 
 int raft_host_reads_load(const char *path, raft_host_reads **out)
 {
     if (!path || !out) return RAFT_HOST_ERR_ARG;
     *out = nullptr;
+    {
+        raft_host_reads *P = new raft_host_reads();
+        const int prc = load_plain_fasta_parallel(path, P);
+        if (prc == RAFT_HOST_OK) { *out = P; return RAFT_HOST_OK; }
+        delete P;
+        if (prc > 0) return prc;
+    }
     Stream in(path);
     if (!in.ok()) return RAFT_HOST_ERR_OPEN;
     raft_host_reads *R = new raft_host_reads();
@@ -238,28 +472,11 @@ int raft_host_reads_load(const char *path, raft_host_reads **out)
             last = 0;
             if (qual.size() != seq.size()) break;   // kseq_read returns -2: loadFASTA's loop ends
         }
-        // chop.hpp:99-106: the first read decides the mode
-        if (R->lens.empty() && looks_simulated(name)) R->real_reads = 0;
-        const int32_t id = R->names.add(name.data(), name.size());
-        if (id < 0) { rc = RAFT_HOST_ERR_DUP_NAME; break; }
+        rc = add_read_meta(R, name);
+        if (rc != RAFT_HOST_OK) break;
         R->lens.push_back((int32_t)seq.size());
         R->base_off.push_back(R->bases.size());
         R->bases.append(seq);
-        if (!R->real_reads) {
-            // chop.hpp:25-70: position=<start>-<end>, second field = orientation, last field = contig
-            const size_t c1 = name.find(',');
-            size_t eq = c1 == std::string::npos ? std::string::npos : name.find('=', c1);
-            int32_t sp = 0, ep = 0;
-            if (eq != std::string::npos) sp = atoi(name.c_str() + eq + 1);
-            const size_t dash = name.find('-');
-            if (dash != std::string::npos) ep = atoi(name.c_str() + dash + 1);
-            R->start_pos.push_back(sp); R->end_pos.push_back(ep);
-            std::string al;
-            if (c1 != std::string::npos) { const size_t c2 = name.find(',', c1 + 1); al = name.substr(c1 + 1, c2 == std::string::npos ? std::string::npos : c2 - c1 - 1); }
-            R->align.push_back(al);
-            const size_t lc = name.rfind(',');
-            R->chr.push_back(lc == std::string::npos ? std::string() : name.substr(lc + 1));
-        }
         if (stop_after) break;
     }
     if (rc != RAFT_HOST_OK) { delete R; return rc; }
@@ -296,53 +513,82 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
         data[used] = '\n'; // a last line without newline is still a line
         if (used == 0) data.clear();
     }
-    raft_host_paf *P = new raft_host_paf();
-    int rc = RAFT_HOST_OK;
-    const char *lastq = nullptr, *lastt = nullptr;
-    size_t lastq_n = 0, lastt_n = 0;
-    int32_t lastq_id = -1, lastt_id = -1;
-    auto resolve = [&](char *s, size_t n, const char *&cs, size_t &cn, int32_t &cid) -> int32_t {
-        if (cs && cn == n && memcmp(cs, s, n) == 0) return cid;
-        const int32_t id = reads->names.find(s, n);
-        if (id >= 0) { cs = s; cn = n; cid = id; }
-        return id;
-    };
-    size_t pos = 0;
+    // Lines are independent: the buffer is cut at newlines into one chunk per thread, each chunk is tokenised into
+    // its own columns (paf.hpp:50-87 rules), and the chunks are concatenated in file order.
+    struct Chunk { std::vector<int32_t> col[6]; size_t err_pos = (size_t)-1; std::string err_name; };
     const size_t total = data.size();
-    while (pos < total) {
-        char *line = data.data() + pos;
-        char *nl = (char *)memchr(line, '\n', total - pos);
-        if (!nl) break;
-        size_t len = (size_t)(nl - line);
-        const bool is_last_sentinel = (size_t)(nl - data.data()) == total - 1;
-        pos += len + 1;
-        if (is_last_sentinel && len == 0) break;     // the newline we appended after a file that ended in '\n'
-        if (len > 1 && line[len - 1] == '\r') --len;
-        // split on TAB only (paf.hpp:56-58)
-        char *fld[11];
-        size_t fl[11];
-        int t = 0;
-        char *q = line;
-        for (size_t i = 0; i <= len; ++i) {
-            if (i < len && line[i] != '\t') continue;
-            if (t < 11) { fld[t] = q; fl[t] = (size_t)(line + i - q); }
-            line[i] = '\0';
-            ++t;
-            q = line + i + 1;
+    int T = host_threads();
+    if (total < (1u << 20)) T = 1;
+    std::vector<size_t> cut((size_t)T + 1, total);
+    cut[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        size_t p0 = total / (size_t)T * (size_t)t;
+        if (p0 < cut[t - 1]) p0 = cut[t - 1];
+        const char *nl = p0 < total ? (const char *)memchr(data.data() + p0, '\n', total - p0) : nullptr;
+        cut[t] = nl ? (size_t)(nl - data.data()) + 1 : total;
+    }
+    std::vector<Chunk> chunks((size_t)T);
+    parallel_for(T, [&](int t) {
+        Chunk &C = chunks[(size_t)t];
+        const char *lastq = nullptr, *lastt = nullptr;
+        size_t lastq_n = 0, lastt_n = 0;
+        int32_t lastq_id = -1, lastt_id = -1;
+        auto resolve = [&](char *s, size_t n, const char *&cs, size_t &cn, int32_t &cid) -> int32_t {
+            if (cs && cn == n && memcmp(cs, s, n) == 0) return cid;
+            const int32_t id = reads->names.find(s, n);
+            if (id >= 0) { cs = s; cn = n; cid = id; }
+            return id;
+        };
+        size_t pos = cut[t];
+        const size_t end = cut[t + 1];
+        while (pos < end) {
+            char *line = data.data() + pos;
+            char *nl = (char *)memchr(line, '\n', end - pos);
+            if (!nl) break;
+            size_t len = (size_t)(nl - line);
+            const bool is_last_sentinel = (size_t)(nl - data.data()) == total - 1;
+            const size_t line_pos = pos;
+            pos += len + 1;
+            if (is_last_sentinel && len == 0) break;     // the newline we appended after a file that ended in '\n'
+            if (len > 1 && line[len - 1] == '\r') --len;
+            // split on TAB only (paf.hpp:56-58)
+            char *fld[11];
+            size_t fl[11];
+            int nf = 0;
+            char *q = line;
+            for (size_t i = 0; i <= len; ++i) {
+                if (i < len && line[i] != '\t') continue;
+                if (nf < 11) { fld[nf] = q; fl[nf] = (size_t)(line + i - q); }
+                line[i] = '\0';
+                ++nf;
+                q = line + i + 1;
+            }
+            if (nf < 10) continue;                        // paf.hpp:84-85: silently skipped
+            const int32_t a = resolve(fld[0], fl[0], lastq, lastq_n, lastq_id);
+            const int32_t b = resolve(fld[5], fl[5], lastt, lastt_n, lastt_id);
+            if (a < 0 || b < 0) { C.err_pos = line_pos; C.err_name = a < 0 ? fld[0] : fld[5]; break; }
+            auto num = [](const char *s) -> int32_t { return (int32_t)(uint32_t)strtol(s, nullptr, 10); }; // paf.hpp:64-75 -> chop.hpp:157-160
+            C.col[0].push_back(a); C.col[1].push_back(num(fld[2])); C.col[2].push_back(num(fld[3]));
+            C.col[3].push_back(b); C.col[4].push_back(num(fld[7])); C.col[5].push_back(num(fld[8]));
         }
-        if (t < 10) continue;                         // paf.hpp:84-85: silently skipped
-        const int32_t a = resolve(fld[0], fl[0], lastq, lastq_n, lastq_id);
-        const int32_t b = resolve(fld[5], fl[5], lastt, lastt_n, lastt_id);
-        if (a < 0 || b < 0) {
+    });
+    int rc = RAFT_HOST_OK;
+    for (const Chunk &C : chunks)                         // the first offending line in file order wins
+        if (C.err_pos != (size_t)-1) {
             rc = RAFT_HOST_ERR_UNKNOWN_NAME;
-            if (err_name && err_cap > 0) snprintf(err_name, (size_t)err_cap, "%s", a < 0 ? fld[0] : fld[5]);
+            if (err_name && err_cap > 0) snprintf(err_name, (size_t)err_cap, "%s", C.err_name.c_str());
             break;
         }
-        auto num = [](const char *s) -> int32_t { return (int32_t)(uint32_t)strtol(s, nullptr, 10); }; // paf.hpp:64-75 -> chop.hpp:157-160
-        P->col[0].push_back(a); P->col[1].push_back(num(fld[2])); P->col[2].push_back(num(fld[3]));
-        P->col[3].push_back(b); P->col[4].push_back(num(fld[7])); P->col[5].push_back(num(fld[8]));
-    }
-    if (rc != RAFT_HOST_OK) { delete P; return rc; }
+    if (rc != RAFT_HOST_OK) return rc;
+    raft_host_paf *P = new raft_host_paf();
+    std::vector<size_t> off((size_t)T + 1, 0);
+    for (int t = 0; t < T; ++t) off[(size_t)t + 1] = off[(size_t)t] + chunks[(size_t)t].col[0].size();
+    for (int k = 0; k < 6; ++k) P->col[k].resize(off[(size_t)T]);
+    parallel_for(T, [&](int t) {
+        for (int k = 0; k < 6; ++k)
+            if (!chunks[(size_t)t].col[k].empty())
+                memcpy(P->col[k].data() + off[(size_t)t], chunks[(size_t)t].col[k].data(), chunks[(size_t)t].col[k].size() * sizeof(int32_t));
+    });
     *out = P;
     return RAFT_HOST_OK;
 }
@@ -354,15 +600,14 @@ const int32_t *raft_host_paf_column(const raft_host_paf *p, int k) { return (p &
 // repeat.hpp:105-108: "read <i> " then "<pos>,<cov> " per window, then newline
 int raft_host_write_coverage(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset, const int32_t *cov)
 {
-    Out o(path);
-    if (!o.ok()) return RAFT_HOST_ERR_IO;
-    for (int32_t i = 0; i < n_reads; ++i) {
-        o.str("read ", 5); o.num(i); o.ch(' ');
-        const int64_t b = cov_offset[i], e = cov_offset[i + 1];
-        for (int64_t j = b; j < e; ++j) { o.num((long long)(j - b) * reso); o.ch(','); o.num(cov[j]); o.ch(' '); }
-        o.ch('\n');
-    }
-    return o.close() ? RAFT_HOST_OK : RAFT_HOST_ERR_IO;
+    return write_ordered(path, n_reads, 1 << 20,
+                         [&](long long i) { return (long long)(cov_offset[i + 1] - cov_offset[i]) + 4; },
+                         [&](long long i, std::string &o) {
+                             o.append("read ", 5); put_num(o, i); o.push_back(' ');
+                             const int64_t b = cov_offset[i], e = cov_offset[i + 1];
+                             for (int64_t j = b; j < e; ++j) { put_num(o, (long long)(j - b) * reso); o.push_back(','); put_num(o, cov[j]); o.push_back(' '); }
+                             o.push_back('\n');
+                         });
 }
 
 // repeat.hpp:180-203: every read gets a line "read <i>, " + "<s>,<e>    " per repeat; .bed only in simulated mode
@@ -397,44 +642,42 @@ int raft_host_write_repeats(const char *txt_path, const char *bed_path, const ra
 int raft_host_write_fasta(const char *path, const raft_host_reads *reads, const int64_t *frag_offset,
                           const int32_t *frag_begin, const int32_t *frag_end)
 {
-    Out o(path);
-    if (!o.ok()) return RAFT_HOST_ERR_IO;
     const int32_t n = (int32_t)reads->lens.size();
-    for (int32_t i = 0; i < n; ++i) {
-        const char *name = reads->names.name(i);
-        const size_t name_n = reads->names.name_len(i);
-        const char *seq = reads->bases.data() + reads->base_off[i];
+    auto one_read = [&](long long i, std::string &o) {
+        const char *name = reads->names.name((int32_t)i);
+        const size_t name_n = reads->names.name_len((int32_t)i);
+        const char *seq = reads->bases.data() + reads->base_off[(size_t)i];
         const int64_t f0 = frag_offset[i], f1 = frag_offset[i + 1];
         const bool whole = (f1 - f0) == 1;             // kept in one piece (chop.hpp:250-267)
         for (int64_t f = f0; f < f1; ++f) {
             const long long read_num = f + 1;
             const int32_t b = frag_begin[f], e = frag_end[f];
             if (reads->real_reads) {
-                o.str(">read=", 6); o.num(read_num); o.ch(','); o.str(name, name_n);
-                o.str(",pos_on_original_read=", 22); o.num(b); o.ch('-'); o.num(e); o.ch('\n');
+                o.append(">read=", 6); put_num(o, read_num); o.push_back(','); o.append(name, name_n);
+                o.append(",pos_on_original_read=", 22); put_num(o, b); o.push_back('-'); put_num(o, e); o.push_back('\n');
             } else {
                 // tail = name.substr(name.find_last_of(','))  -> ",<contig>"
                 const std::string nm(name, name_n);
                 const size_t lc = nm.find_last_of(',');
                 const std::string tail = lc == std::string::npos ? std::string() : nm.substr(lc);
-                const std::string &al = reads->align[i];
-                const int32_t sp = reads->start_pos[i], ep = reads->end_pos[i];
+                const std::string &al = reads->align[(size_t)i];
+                const int32_t sp = reads->start_pos[(size_t)i], ep = reads->end_pos[(size_t)i];
                 bool header = true;
                 long long p0 = 0, p1 = 0, ln = 0;
-                if (whole) { p0 = sp; p1 = ep; ln = reads->lens[i]; }
+                if (whole) { p0 = sp; p1 = ep; ln = reads->lens[(size_t)i]; }
                 else if (al == "forward") { p0 = (long long)sp + b; p1 = (long long)sp + e; ln = e - b; }
                 else if (al == "reverse") { p0 = (long long)ep - e; p1 = (long long)ep - b; ln = e - b; }
                 else header = false;                     // chop.hpp:293-311 writes no header for other orientations
                 if (header) {
-                    o.str(">read=", 6); o.num(read_num); o.ch(','); o.str(al.data(), al.size()); o.str(",position=", 10);
-                    o.num(p0); o.ch('-'); o.num(p1); o.str(",length=", 8); o.num(ln); o.str(tail.data(), tail.size()); o.ch('\n');
+                    o.append(">read=", 6); put_num(o, read_num); o.push_back(','); o.append(al); o.append(",position=", 10);
+                    put_num(o, p0); o.push_back('-'); put_num(o, p1); o.append(",length=", 8); put_num(o, ln); o.append(tail); o.push_back('\n');
                 }
             }
-            o.str(seq + b, (size_t)(e - b));
-            o.ch('\n');
+            o.append(seq + b, (size_t)(e - b));
+            o.push_back('\n');
         }
-    }
-    return o.close() ? RAFT_HOST_OK : RAFT_HOST_ERR_IO;
+    };
+    return write_ordered(path, n, 8 << 20, [&](long long i) { return (long long)reads->lens[(size_t)i] + 64; }, one_read);
 }
 
 } // extern "C"

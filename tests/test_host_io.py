@@ -122,3 +122,91 @@ def test_paf_number_semantics_and_errors(tmp_path):
     with pytest.raises(hostio.HostError) as e:
         hostio.Reads(str(tmp_path / "missing.fa"))
     assert e.value.code == hostio.ERR_OPEN
+
+
+# ---- worker threads: the parallel loaders/writers give the bytes of the sequential ones -------------------------
+
+def _snapshot_reads(path):
+    r = hostio.Reads(str(path))
+    snap = ([r.name(i) for i in range(r.n)], r.lengths.tolist(), [r.bases(i) for i in range(r.n)], r.real)
+    r.close()
+    return snap
+
+
+FASTA_SHAPES = {
+    "wrapped": ">a c1 c2\nACGT\nAC\n>b\tx\nGG\n\nTT\n>c\n>d\nA\n",
+    "no_final_newline": ">a\nACGT\n>b\nGGTT",
+    "bare_header_at_eof": ">a\nACGT\n>",
+    "name_at_eof": ">a\nACGT\n>zz",
+    "comment_at_eof": ">a\nACGT\n>zz comment",
+    "gt_inside_lines": ">a >x\nAC>GT\nA>\n>b\nCC\n",
+    "blank_lines": ">a\n\n\nAC\n\n>b\n\n",
+    "simulated": ">read=1,forward,position=5-15,length=10,chr1\nACGTACGTAC\n>read=2,reverse,position=7-11,length=4,chr2\nGGGG\n",
+    # not eligible for the mapped path (CR, FASTQ, leading junk): both thread counts take the streaming reader
+    "crlf": ">a\r\nAC\r\nGT\r\n>b\r\nTT\r\n",
+    "fastq_mixed": ">a\nAC\n@q\nGGTT\n+\nIIII\n>b\nTT\n",
+    "junk_before_header": "xx\n>a\nAC\n",
+    "plus_line": ">a\nAC\n+\nGT\n>b\nTT\n",
+}
+
+
+@pytest.mark.parametrize("shape", sorted(FASTA_SHAPES))
+def test_reads_loader_thread_count_does_not_matter(tmp_path, shape):
+    f = tmp_path / "r.fa"
+    f.write_bytes(FASTA_SHAPES[shape].encode())
+    try:
+        hostio.set_threads(1)
+        want = _snapshot_reads(f)
+        for t in (2, 3, 8):
+            hostio.set_threads(t)
+            assert hostio.get_threads() == t
+            assert _snapshot_reads(f) == want, (shape, t)
+    finally:
+        hostio.set_threads(0)
+
+
+def test_loaders_and_writers_thread_count_random(tmp_path):
+    rng = np.random.default_rng(77)
+    n = 700
+    lens = rng.integers(0, 900, n)
+    lens[rng.integers(0, n, 20)] = 0
+    names = [f"read{i}/x" for i in range(n)]
+    with open(tmp_path / "r.fa", "wb") as f:
+        for i in range(n):
+            seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(lens[i])))
+            width = int(rng.choice([0, 60, 7]))
+            f.write(b">" + names[i].encode() + (b" extra words" if i % 3 == 0 else b"") + b"\n")
+            if width == 0:
+                f.write(seq + b"\n")
+            else:
+                for k in range(0, len(seq), width):
+                    f.write(seq[k:k + width] + b"\n")
+    m = 5000
+    q, t = rng.integers(0, n, m), rng.integers(0, n, m)
+    cols = [lens.astype(np.int32), q, np.zeros(m, np.int64), np.zeros(m, np.int64), t, np.zeros(m, np.int64), np.zeros(m, np.int64)]
+    for side, (ids, si, ei) in enumerate(((q, 2, 3), (t, 5, 6))):
+        L = np.maximum(lens[ids], 1)
+        a, b = rng.integers(0, L), rng.integers(0, L)
+        cols[si], cols[ei] = np.minimum(a, b), np.minimum(np.maximum(a, b) + 1, lens[ids])
+    keep = (lens[q] > 0) & (lens[t] > 0)
+    cols = [cols[0]] + [c[keep].astype(np.int32) for c in cols[1:]]
+    write_paf(tmp_path / "o.paf", names, *cols)
+    p = RaftParams(est_cov=3, repeat_length=100, interval_length=100, read_length=300, overlap_length=50, flanking_length=20)
+    outs = {}
+    try:
+        for th in (1, 5):
+            hostio.set_threads(th)
+            reads = hostio.Reads(str(tmp_path / "r.fa"))
+            got = hostio.load_paf(str(tmp_path / "o.paf"), reads)
+            for a, b in zip(got, cols[1:]):
+                assert np.array_equal(a, b)
+            assert reads.lengths.tolist() == lens.tolist()
+            res = oracle_run(p, reads.lengths, *got)
+            hostio.write_outputs(str(tmp_path / f"t{th}"), reads, p.reso, res)
+            outs[th] = {s: open(tmp_path / f"t{th}.{s}", "rb").read()
+                        for s in ("coverage.txt", "long_repeats.txt", "long_repeats.bed", "reads.fasta")}
+            reads.close()
+    finally:
+        hostio.set_threads(0)
+    assert outs[1] == outs[5]
+    assert len(outs[1]["reads.fasta"]) > 0 and len(outs[1]["coverage.txt"]) > 0
