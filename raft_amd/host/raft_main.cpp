@@ -13,6 +13,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -50,8 +51,12 @@ bool missing_or_empty(const char *fn) // chop.hpp:326-329,336-349
     return !f || f.peek() == std::ifstream::traits_type::eof();
 }
 
+std::thread *g_background[2] = {nullptr, nullptr};   // helpers that must be finished before the process exits
+
 [[noreturn]] void die(const std::string &msg)
 {
+    for (std::thread *t : g_background)
+        if (t && t->joinable()) t->join();
     std::cout << msg << "\n";
     std::cout.flush();
     exit(1);
@@ -105,13 +110,25 @@ int main(int argc, char *argv[])
     hp.reso = p.reso; hp.est_cov = p.est_cov; hp.cov_mul = p.cov_mul; hp.repeat_length = p.repeat_length;
     hp.interval_length = p.interval_length; hp.read_length = p.read_length; hp.overlap_length = p.overlap_length;
     hp.flanking_length = p.flanking_length; hp.symmetric_mode = -1;
+    // stage clock on stderr when RAFT_TIMING is set (stdout stays the reference's)
+    const bool timing = getenv("RAFT_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stage = [&](const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (timing) fprintf(stderr, "TIMING %-16s %8.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+        t_prev = now;
+    };
+
+    // the device context comes up (runtime init, first allocations) while the host tokenises the inputs
     raft_hip_ctx *ctx = nullptr;
     const char *dev_env = getenv("RAFT_DEVICE");
-    int rc = raft_hip_create(dev_env ? atoi(dev_env) : 0, &hp, &ctx);
-    if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_create(), ") + raft_hip_strerror(rc));
+    int create_rc = RAFT_HIP_OK;
+    std::thread bring_up([&] { create_rc = raft_hip_create(dev_env ? atoi(dev_env) : 0, &hp, &ctx); });
+    g_background[0] = &bring_up;
 
     raft_host_reads *reads = nullptr;
-    rc = raft_host_reads_load(reads_fn, &reads);
+    int rc = raft_host_reads_load(reads_fn, &reads);
+    stage("reads_load");
     if (rc == RAFT_HOST_ERR_DUP_NAME) die("ERROR, loadFASTA(), two reads share a name");
     if (rc != RAFT_HOST_OK) die(std::string("ERROR, loadFASTA(), cannot read ") + reads_fn);
     const int32_t n_reads = raft_host_reads_count(reads);
@@ -124,6 +141,10 @@ int main(int argc, char *argv[])
     if (rc == RAFT_HOST_ERR_UNKNOWN_NAME) die(std::string("ERROR, create_pileup(), read ") + bad + " of the overlaps file is not in the reads file");
     if (rc != RAFT_HOST_OK) die(std::string("ERROR, create_pileup(), cannot read ") + paf_fn);
     const int64_t n_rec = raft_host_paf_count(paf);
+    stage("paf_load");
+    bring_up.join();
+    if (create_rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_create(), ") + raft_hip_strerror(create_rc));
+    stage("device_wait");
 
     rc = raft_hip_run_host(ctx, n_reads, raft_host_reads_lengths(reads), n_rec, raft_host_paf_column(paf, 0),
                            raft_host_paf_column(paf, 1), raft_host_paf_column(paf, 2), raft_host_paf_column(paf, 3),
@@ -137,6 +158,7 @@ int main(int argc, char *argv[])
         if (d && *d) m += std::string(" [") + d + "]";
         die(m);
     }
+    stage("engine");
     fprintf(stdout, "INFO, Symmetric overlaps %d \n", s.symmetric);            // chop.hpp:189-190
     fprintf(stdout, "INFO, length of alignments  %d()\n", (int)s.n_records);
     fprintf(stdout, "high_cov %d\n", s.high_cov);                              // repeat.hpp:91
@@ -147,19 +169,27 @@ int main(int argc, char *argv[])
     rc = raft_hip_fetch(ctx, cov_off.data(), cov.data(), rep_off.data(), rep_s.data(), rep_e.data(), nullptr, nullptr,
                         frag_off.data(), nullptr, fb.data(), fe.data());
     if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_fetch(), ") + raft_hip_strerror(rc));
+    stage("fetch");
 
+    // the four output files are independent: the FASTA is written beside the coverage/repeat tables
+    int fasta_rc = RAFT_HOST_OK;
+    std::thread fasta_writer([&] { fasta_rc = raft_host_write_fasta(fasta_out.c_str(), reads, frag_off.data(), fb.data(), fe.data()); });
+    g_background[1] = &fasta_writer;
     if (raft_host_write_coverage((p.prefix + ".coverage.txt").c_str(), n_reads, p.reso, cov_off.data(), cov.data()) != RAFT_HOST_OK ||
         raft_host_write_repeats((p.prefix + ".long_repeats.txt").c_str(), (p.prefix + ".long_repeats.bed").c_str(), reads,
-                                rep_off.data(), rep_s.data(), rep_e.data()) != RAFT_HOST_OK)
+                                rep_off.data(), rep_s.data(), rep_e.data()) != RAFT_HOST_OK) {
         die("ERROR, repeat_annotate(), cannot write output files");
+    }
+    stage("write_tables");
     // repeat.hpp:173-178 (total_windows is an int in the reference; identical below 2^31 windows)
     const double cpw = (double)s.total_coverage / (double)s.total_windows;
     fprintf(stdout, "coverage per window is %f \n", cpw);
     fprintf(stdout, "coverage per window/average coverage is %f \n", cpw / p.est_cov);
     fprintf(stdout, "fraction_of_repeat_length %f \n", (double)s.total_repeat_length / (double)s.total_read_length);
 
-    if (raft_host_write_fasta(fasta_out.c_str(), reads, frag_off.data(), fb.data(), fe.data()) != RAFT_HOST_OK)
-        die("ERROR, break_reads(), cannot write " + fasta_out);
+    fasta_writer.join();
+    if (fasta_rc != RAFT_HOST_OK) die("ERROR, break_reads(), cannot write " + fasta_out);
+    stage("write_fasta");
     fflush(stdout);
 
     const std::chrono::duration<double> wct = std::chrono::system_clock::now() - t_start;

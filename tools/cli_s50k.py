@@ -31,8 +31,10 @@ print(f"inputs written in {time.time()-t0:.1f} s: {os.path.getsize(d+'/reads.fa'
 
 def run(exe, prefix):
     t = time.time()
-    r = subprocess.run([exe, "-e", "30", "-o", prefix, "reads.fa", "overlaps.paf"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    r = subprocess.run([exe, "-e", "30", "-o", prefix, "reads.fa", "overlaps.paf"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       env=dict(os.environ, RAFT_TIMING="1"))
     dt = time.time() - t
+    print("".join(l + "\n" for l in r.stdout.decode().splitlines() if l.startswith("TIMING")), end="")
     md = {x: hashlib.md5(open(os.path.join(d, f"{prefix}.{x}"), "rb").read()).hexdigest() for x in ("reads.fasta", "coverage.txt", "long_repeats.txt", "long_repeats.bed")} if r.returncode == 0 else {}
     return r.returncode, dt, md, r.stdout.decode()[-300:]
 
