@@ -7,6 +7,7 @@
 #include "device_scan.hpp"
 #include "finalize.hpp"
 #include "pileup.hpp"
+#include "pileup_fast.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -19,29 +20,43 @@ using namespace raft;
 
 namespace {
 
-// Pileup kernel variants: THREADS per workgroup, CAP = windows staged in LDS, MINW = waves per SIMD asked of the
-// register allocator (= resident workgroups per CU for 256 threads), short_max = the tile quantum Q defaults to
-// CAP - short_max, so that a tile whose reads all have at most short_max windows always fits one LDS window.
-struct PileVariant { int threads, cap, minw, short_max, blocks_per_cu; };
+// Pileup configurations.  `fast`: tiles of whole reads that fit one LDS window go to pileup_fast_kernel and the
+// general pileup_kernel only walks the remaining tiles; otherwise the general kernel handles every tile.
+// cap = windows staged in LDS, wg_per_cu = resident workgroups per CU (= waves per SIMD asked of the register
+// allocator), short_max: the tile quantum Q defaults to cap - short_max, so that a tile whose reads all have at most
+// short_max windows always fits one LDS window.
+struct PileVariant { int fast, cap, wg_per_cu, short_max; };
 constexpr PileVariant kVariants[] = {
-    {256, 6144, 5, 2048, 5},   // 0: 30.8 KB LDS, 5 workgroups/CU, 3 intervals per lane in flight (default)
-    {256, 4864, 6, 1536, 6},   // 1: 25.5 KB LDS, 6 workgroups/CU, 2 intervals per lane
-    {256, 7424, 4, 2048, 4},   // 2: 36.0 KB LDS, 4 workgroups/CU, 4 intervals per lane
-    {256, 6144, 5, 2048, 5},   // 3: variant 0 with s_memtime stamps (diagnostic build; raft_hip_debug_stamps)
+    {1, 6144, 5, 1536},   // 0: default: fast kernel, 30.8 KB LDS, 5 workgroups/CU
+    {0, 6144, 5, 2048},   // 1: general kernel only
+    {1, 4864, 6, 1280},   // 2: fast kernel, 25.5 KB LDS, 6 workgroups/CU
+    {1, 6144, 5, 1536},   // 3: variant 0 with s_memtime stamps in the fast kernel (diagnostic; raft_hip_debug_stamps)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kDefaultVariant = 0;
 constexpr int kDiagVariant = 3;
+constexpr int kFastSlots = 4;     // prefetched intervals per lane and tile in the fast kernel
 
-template <int T, int CAP, int MINW, int U, bool DIAG = false>
-void launch_pileup(hipStream_t st, unsigned grid, const PileupArgs &pa)
+template <int CAP, int MINW>
+void launch_general(hipStream_t st, unsigned grid, const PileupArgs &pa)
 {
-    hipLaunchKernelGGL((pileup_kernel<T, CAP, MINW, U, DIAG>), dim3(grid), dim3(T), 0, st, pa);
+    hipLaunchKernelGGL((pileup_kernel<256, CAP, MINW, 3, false>), dim3(grid), dim3(256), 0, st, pa);
+}
+
+template <int CAP, int MINW, bool DIAG>
+void launch_fast(hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
+{
+    if (n_seg <= 1)
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), 0, st, cuts, pa);
+    else if (n_seg == 2)
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), 0, st, cuts, pa);
+    else
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), 0, st, cuts, pa);
 }
 
 struct Ctrl {                         // device control block, cleared every pass
     int32_t err_flags;
-    int32_t pad;
+    int32_t n_slow;                   // tiles left to the general pileup kernel (fast configurations)
     long long err_index;
     unsigned long long totals[4];     // coverage, repeat bp, read length
     InspectOut insp;
@@ -117,7 +132,7 @@ struct raft_hip_ctx {
     std::string last_error;
 
     // device buffers
-    DevBuf ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_desc, block_sums;
+    DevBuf ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_desc, tile_cuts, slow_list, block_sums;
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
@@ -235,7 +250,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc,
+    DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
@@ -350,7 +365,11 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
     HIP_TRY(c, c->tile_first.ensure((size_t)(n_tiles + 1) * 4));
     HIP_TRY(c, c->tile_desc.ensure((size_t)n_tiles * sizeof(TileDesc)));
-    HIP_TRY(c, c->block_sums.ensure((size_t)256 * 8 * 16));
+    if (pv.fast) {
+        HIP_TRY(c, c->tile_cuts.ensure((size_t)(n_tiles + 1) * sizeof(TileCut)));
+        HIP_TRY(c, c->slow_list.ensure((size_t)n_tiles * 4));
+    }
+    HIP_TRY(c, c->block_sums.ensure((size_t)256 * 8 * 16 * 2));
     HIP_TRY(c, c->rep_cnt.ensure((size_t)std::max(N, 1LL) * 4));
     HIP_TRY(c, c->cut_cnt.ensure((size_t)std::max(N, 1LL) * 4));
     HIP_TRY(c, c->frag_cnt.ensure((size_t)std::max(N, 1LL) * 4));
@@ -454,8 +473,11 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
         pa.iv_rid = c->b_rid.as<int32_t>(); pa.iv_s = c->b_s.as<int32_t>(); pa.iv_e = c->b_e.as<int32_t>(); pa.n_seg = 1;
         c->sum.interval_path = 1; c->sum.n_segments = n_desc + 1; c->sum.n_intervals = -1; // read back in finish
     }
-    hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
-                       pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>());
+    using GenSmem = PileupSmem<256, 6144>;
+    hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
+                       pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>(),
+                       pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, pv.cap, (int)GenSmem::MAXR,
+                       pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow);
 
     pa.dbg = nullptr;
     if (c->variant == kDiagVariant) {
@@ -464,16 +486,29 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
         pa.dbg = c->dbg.as<unsigned long long>();
         c->dbg_tiles = n_tiles;
     }
-    // ---- the dominant kernel: persistent workgroups, blocks_per_cu per CU
-    int bpc = pv.blocks_per_cu;
-    if (const char *e = getenv("RAFT_PILEUP_WG_PER_CU")) bpc = std::max(1, std::min(atoi(e), pv.blocks_per_cu)); // occupancy experiments
+    // ---- the dominant kernel(s): persistent workgroups, wg_per_cu per CU
+    int bpc = pv.wg_per_cu;
+    if (const char *e = getenv("RAFT_PILEUP_WG_PER_CU")) bpc = std::max(1, std::min(atoi(e), pv.wg_per_cu)); // occupancy experiments
     const unsigned pgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * bpc));
+    unsigned n_sum_blocks = pgrid;
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
-    switch (c->variant) {
-    case 0: launch_pileup<256, 6144, 5, 3>(st, pgrid, pa); break;
-    case 1: launch_pileup<256, 4864, 6, 2>(st, pgrid, pa); break;
-    case 2: launch_pileup<256, 7424, 4, 4>(st, pgrid, pa); break;
-    default: launch_pileup<256, 6144, 5, 3, true>(st, pgrid, pa); break;
+    if (pv.fast) {
+        const TileCut *cuts = c->tile_cuts.as<TileCut>();
+        switch (c->variant) {
+        case 0: launch_fast<6144, 5, false>(st, pgrid, pa.n_seg, cuts, pa); break;
+        case 2: launch_fast<4864, 6, false>(st, pgrid, pa.n_seg, cuts, pa); break;
+        default: launch_fast<6144, 5, true>(st, pgrid, pa.n_seg, cuts, pa); break;
+        }
+        // the tiles the fast kernel does not take (reads longer than the LDS window, very many reads)
+        PileupArgs ps = pa;
+        ps.slow_list = c->slow_list.as<int32_t>(); ps.n_slow = &ctrl->n_slow;
+        ps.block_sums = pa.block_sums + 2 * (long long)pgrid;
+        ps.dbg = nullptr;
+        const unsigned sgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * 5));
+        launch_general<6144, 5>(st, sgrid, ps);
+        n_sum_blocks = pgrid + sgrid;
+    } else {
+        launch_general<6144, 5>(st, pgrid, pa);
     }
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
 
@@ -501,7 +536,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     }
     {
         const unsigned g = (unsigned)std::min<long long>((std::max(n_tiles, N) + 255) / 256, 1024);
-        hipLaunchKernelGGL(totals_kernel, dim3(std::max(g, 1u)), dim3(256), 0, st, (long long)pgrid, c->block_sums.as<long long>(),
+        hipLaunchKernelGGL(totals_kernel, dim3(std::max(g, 1u)), dim3(256), 0, st, (long long)n_sum_blocks, c->block_sums.as<long long>(),
                            n_reads, d_len, ctrl->totals);
     }
     HIP_TRY(c, hipEventRecord(c->ev_pass1, st));

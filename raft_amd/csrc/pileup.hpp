@@ -54,6 +54,17 @@ struct TileDesc {              // written by tile_desc_kernel; 18 dwords
     long long iv_lo[kMaxSeg];  // first interval in segment s
 };
 constexpr int kDescDwords = (int)(sizeof(TileDesc) / 4);
+
+// The same tiling as seen by pileup_fast_kernel (pileup_fast.hpp): boundary k says where tile k begins; entry
+// n_tiles closes the last tile.  Two adjacent cuts describe a tile and arrive as one 64-byte scalar load.
+struct TileCut {
+    int32_t r_lo;              // first read of tile k
+    int32_t flags;             // kCutFast: tile k holds whole reads that fit one LDS window
+    int32_t iv_lo[kMaxSeg];    // first interval of tile k in segment s (absolute index, < 2^31 checked by the host)
+    long long g_lo;            // first window of tile k in cov[]
+};
+static_assert(sizeof(TileCut) == 32, "two adjacent cuts are one 64-byte scalar load");
+enum : int { kCutFast = 1 };
 static_assert(sizeof(TileDesc) == 72, "descriptor is fetched as 18 dwords, one per lane");
 
 struct PileupArgs {
@@ -79,6 +90,9 @@ struct PileupArgs {
     int32_t *err_flags;           // device word, OR of kErr*
     long long *err_index;         // first offending interval index (min)
     unsigned long long *dbg;      // diagnostic build only: [n_tiles][16] s_memtime stamps
+    // When pileup_fast_kernel takes the tiles of whole reads, this kernel walks only the others:
+    const int32_t *slow_list;     // tile ids (any order), or nullptr: every tile is handled here
+    const int32_t *n_slow;        // device count of slow_list
 };
 
 constexpr int kRunQ = 16; // parked runs per wave and window before falling back to immediate emission
@@ -597,30 +611,33 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
     auto is_simple = [&](const TileRegs &t) -> bool {
         return (t.r_hi > t.r_lo) && (t.g_hi > t.g_lo) && (t.g_hi - t.g_lo <= CAP) && (t.r_hi - t.r_lo <= Smem::MAXR);
     };
+    // items of this kernel: all tiles, or the tiles listed in slow_list
+    const long long n_items = a.slow_list ? (long long)uni(*a.n_slow) : a.n_tiles;
+    auto tile_at = [&](long long i) -> long long { return a.slow_list ? (long long)uni(a.slow_list[i]) : i; };
     long long k = blockIdx.x;
     TileRegs cur{};
     Prefetch<U> g{}, gn{};
     bool simple = false, nsimple = false;
     int raw_n = 0, raw_nn = 0;
-    if (k < a.n_tiles) {
-        unpack_desc(desc_word(k), cur);
+    if (k < n_items) {
+        unpack_desc(desc_word(tile_at(k)), cur);
         simple = is_simple(cur);
         if (simple) issue_prefetch<THREADS, U>(a, tid, cur.r_lo, cur.r_hi - cur.r_lo, cur.seg_lo, cur.seg_cum, g);
-        if (k + nb < a.n_tiles) raw_n = desc_word(k + nb);
+        if (k + nb < n_items) raw_n = desc_word(tile_at(k + nb));
     }
     wait_all_loads(); // loop invariant: nothing is pending at the loop head on any incoming edge
-    while (k < a.n_tiles) {
+    while (k < n_items) {
         const long long kn = k + nb;
-        const long long stamp_row = k;
+        const long long stamp_row = a.slow_list ? tile_at(k) : k;
         if (DIAG && tid == 0 && a.dbg) { sm.stamps[0] = __builtin_amdgcn_s_memtime(); sm.stamps[9] = __builtin_amdgcn_s_memrealtime(); }
         // next tile: its descriptor was requested one iteration ago; start its loads now
         nsimple = false;
-        if (kn < a.n_tiles) {
+        if (kn < n_items) {
             TileRegs nxt;
             unpack_desc(raw_n, nxt);
             nsimple = is_simple(nxt);
             if (nsimple) issue_prefetch<THREADS, U>(a, tid, nxt.r_lo, nxt.r_hi - nxt.r_lo, nxt.seg_lo, nxt.seg_cum, gn);
-            if (kn + nb < a.n_tiles) raw_nn = desc_word(kn + nb);
+            if (kn + nb < n_items) raw_nn = desc_word(tile_at(kn + nb));
         }
         if (DIAG && tid == 0 && a.dbg) sm.stamps[8] = (unsigned long long)(cur.g_hi - cur.g_lo);
         RAFT_STAMP(1);
@@ -693,11 +710,11 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
         RAFT_STAMP(7);
         if (DIAG && tid == 0 && a.dbg) {
             sm.stamps[10] = __builtin_amdgcn_s_memrealtime();
-            for (int i = 0; i < 16; ++i) a.dbg[k * 16 + i] = sm.stamps[i];
+            for (int i = 0; i < 16; ++i) a.dbg[stamp_row * 16 + i] = sm.stamps[i];
         }
 
         k = kn; simple = nsimple; g = gn;
-        if (k < a.n_tiles) unpack_desc(raw_n, cur);
+        if (k < n_items) unpack_desc(raw_n, cur);
         raw_n = raw_nn;
     }
     lds_barrier();
@@ -707,20 +724,27 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
     }
 }
 
-// One thread per tile: the descriptor the pileup workgroups fetch (reads, windows, interval ranges).  A tile's
-// interval range ends where the next tile's begins, so each lane searches once per segment and takes the end from
-// its neighbour lane (the last lane of a wave searches twice).
+// One thread per tile boundary: the descriptor the general pileup workgroups fetch (reads, windows, interval
+// ranges) and, when `cuts` is given, the compact boundary record of pileup_fast_kernel plus the list of tiles that
+// kernel leaves to the general one.  A tile's interval range ends where the next tile's begins, so each lane
+// searches once per segment and takes the end from its neighbour lane (the last lane of a wave searches twice).
 __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegStarts sb, const long long *seg_end_dev,
                                                         const int32_t *iv_rid, const int32_t *tile_first,
-                                                        const long long *cov_off, TileDesc *td)
+                                                        const long long *cov_off, TileDesc *td, TileCut *cuts,
+                                                        int fast_cap, int fast_max_reads, int32_t *slow_list,
+                                                        int32_t *n_slow)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool live = k < n_tiles;
+    const bool edge = k <= n_tiles;                 // boundary n_tiles closes the last tile
     TileDesc d{};
     if (live) {
         d.r_lo = tile_first[k]; d.r_hi = tile_first[k + 1];
         d.g_lo = cov_off[d.r_lo]; d.g_hi = cov_off[d.r_hi];
+    } else if (edge) {
+        d.r_lo = d.r_hi = tile_first[k];
+        d.g_lo = d.g_hi = cov_off[d.r_lo];
     }
 #pragma unroll
     for (int s = 0; s < kMaxSeg; ++s) {
@@ -728,14 +752,25 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
         if (s < sb.n_seg) {                         // uniform
             long long b = sb.start[s], e = sb.start[s + 1];
             if (seg_end_dev) e = *seg_end_dev;
-            if (live) lo = lower_bound_rid(iv_rid, b, e, d.r_lo);
+            if (edge) lo = lower_bound_rid(iv_rid, b, e, d.r_lo);
             hi = __shfl_down(lo, 1, kWave);
-            if (live && (lane == 63 || k + 1 >= n_tiles)) hi = lower_bound_rid(iv_rid, b, e, d.r_hi);
+            if (live && lane == 63) hi = lower_bound_rid(iv_rid, b, e, d.r_hi);
         }
         d.iv_lo[s] = lo;
         d.n_iv[s] = (int)(hi - lo);
     }
     if (live) td[k] = d;
+    if (cuts && edge) {
+        const int nr = d.r_hi - d.r_lo;
+        const long long nwin = d.g_hi - d.g_lo;
+        const bool fast = live && nr >= 1 && nr <= fast_max_reads && nwin > 0 && nwin <= fast_cap;
+        TileCut c;
+        c.r_lo = d.r_lo; c.flags = fast ? kCutFast : 0; c.g_lo = d.g_lo;
+#pragma unroll
+        for (int s = 0; s < kMaxSeg; ++s) c.iv_lo[s] = (int32_t)d.iv_lo[s];
+        cuts[k] = c;
+        if (live && nr >= 1 && !fast) slow_list[atomicAdd(n_slow, 1)] = (int32_t)k;
+    }
 }
 
 } // namespace raft

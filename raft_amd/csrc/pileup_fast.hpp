@@ -1,0 +1,386 @@
+// pileup_fast.hpp -- the lean pileup kernel for tiles of whole reads that fit one LDS window (all tiles of a
+// HiFi-like read set).  Same algorithm and LDS layout as pileup.hpp (which keeps handling the other tiles: reads
+// longer than the LDS window, tiles with very many reads); what differs is the bookkeeping around the rows, which
+// in the general kernel cost four times the vector instructions of the rows themselves (rocprofv3 SQ_INSTS_VALU):
+//   * a tile is described by two adjacent 32-byte TileCut records (first read, first interval per segment, first
+//     window) that arrive through the scalar data cache (s_load) -- no per-lane descriptor, no readlane unpacking;
+//   * prefetch slot u of a lane is interval (u / NSEG) * 256 + lane-id of segment u % NSEG: the address is a scalar
+//     base plus the constant lane offset, no per-record index arithmetic; intervals beyond the prefetched slots
+//     (tiles inside repeats) are fetched synchronously afterwards;
+//   * coverage totals accumulate per lane in registers and are reduced once per workgroup, not once per tile;
+//   * one row body (first/last rows of a tile only differ in masks), so the run scan is instantiated once.
+// Reference semantics: repeat.hpp:28-79 (profileCoverage), repeat.hpp:111-168 (run scan); see pileup.hpp.
+#pragma once
+#include "pileup.hpp"
+
+namespace raft {
+
+template <int U>
+struct FastRegs {
+    int rid[U], st[U], en[U];
+    int cv, rr, rl;            // low dwords of cov_off / rep_res_off and the length of read r_a + thread-id
+};
+
+struct FastTile {              // scalars of one tile
+    int r_a, nr, nwin, fast, more;   // more: a segment holds intervals beyond the prefetched slots
+    long long g_lo;
+};
+
+template <int NSEG, int ITER>
+__device__ __forceinline__ void cut_unpack(const TileCut &c0, const TileCut &c1, FastTile &t, int (&lo)[NSEG], int (&n)[NSEG])
+{
+    t.r_a = c0.r_lo; t.nr = c1.r_lo - c0.r_lo; t.fast = c0.flags & kCutFast; t.g_lo = c0.g_lo;
+    t.nwin = (int)(c1.g_lo - c0.g_lo);
+    t.more = 0;
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        lo[s] = c0.iv_lo[s]; n[s] = c1.iv_lo[s] - c0.iv_lo[s];
+        if (n[s] > ITER * 256) t.more = 1;
+    }
+}
+
+// Loads of one tile: three per read (threads 0..nr) and three per interval slot.
+template <int NSEG, int U>
+__device__ __forceinline__ void fast_issue(const PileupArgs &a, unsigned tid, const FastTile &t, const int (&lo)[NSEG],
+                                           const int (&n)[NSEG], FastRegs<U> &g)
+{
+    g.cv = 0; g.rr = 0; g.rl = 0;
+    if ((int)tid <= t.nr) {
+        g.cv = (reinterpret_cast<const int32_t *>(a.cov_off) + 2 * (long long)t.r_a)[2u * tid];
+        g.rr = (reinterpret_cast<const int32_t *>(a.rep_res_off) + 2 * (long long)t.r_a)[2u * tid];
+    }
+    if ((int)tid < t.nr) g.rl = (a.read_len + t.r_a)[tid];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int s = u % NSEG, first = (u / NSEG) * 256;
+        g.rid[u] = -1; g.st[u] = 0; g.en[u] = 0;
+        if ((int)tid < n[s] - first) {
+            const long long base = (long long)lo[s] + first;
+            g.rid[u] = (a.iv_rid + base)[tid];
+            g.st[u] = (a.iv_s + base)[tid];
+            g.en[u] = (a.iv_e + base)[tid];
+        }
+    }
+}
+
+template <int CAP, int NSEG, int U, int MINW, bool DIAG>
+__global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *__restrict__ cuts, PileupArgs a)
+{
+    constexpr int THREADS = 256, NW = 4, ITER = U / NSEG;
+    static_assert(U % NSEG == 0 && ITER >= 1, "slots are split evenly over the segments");
+    using Smem = PileupSmem<THREADS, CAP>;
+    __shared__ __attribute__((aligned(16))) Smem sm;
+    const unsigned tid = threadIdx.x;
+    const int lane = (int)(tid & 63u);
+    const int wid = uni((int)(tid >> 6));
+    const long long nb = gridDim.x;
+    if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; }
+    if (tid < (unsigned)NW) sm.runq_n[tid] = 0;
+    long long lane_cov = 0;                      // this lane's share of the coverage total (reduced once, at the end)
+
+    long long k = blockIdx.x;
+    FastTile cur{}, nxt{};
+    FastRegs<U> g{}, gn{};
+    TileCut c0{}, c1{};                          // cuts of the tile after next, requested one tile ahead
+    if (k < a.n_tiles) {
+        int lo[NSEG], n[NSEG];
+        cut_unpack<NSEG, ITER>(cuts[k], cuts[k + 1], cur, lo, n);
+        if (cur.fast) fast_issue<NSEG, U>(a, tid, cur, lo, n, g);
+        if (k + nb < a.n_tiles) { c0 = cuts[k + nb]; c1 = cuts[k + nb + 1]; }
+    }
+    wait_all_loads();
+    while (k < a.n_tiles) {
+        const long long kn = k + nb;
+        if (DIAG && tid == 0 && a.dbg) { sm.stamps[0] = __builtin_amdgcn_s_memtime(); sm.stamps[9] = __builtin_amdgcn_s_memrealtime(); }
+        nxt.fast = 0;
+        if (kn < a.n_tiles) {
+            int lo[NSEG], n[NSEG];
+            cut_unpack<NSEG, ITER>(c0, c1, nxt, lo, n);
+            if (nxt.fast) fast_issue<NSEG, U>(a, tid, nxt, lo, n, gn);
+            if (kn + nb < a.n_tiles) { c0 = cuts[kn + nb]; c1 = cuts[kn + nb + 1]; }
+        }
+        if (DIAG && tid == 0 && a.dbg) sm.stamps[8] = (unsigned long long)cur.nwin;
+        RAFT_STAMP(1);
+        if (cur.fast) {
+            // ---- geometry of the LDS window: slots are windows relative to a0 (16-byte aligned in cov[])
+            const int nr = cur.nr, r_a = cur.r_a;
+            const long long a0 = cur.g_lo & ~3LL;
+            const int off0 = (int)(cur.g_lo - a0);       // first valid slot
+            const int t_end = off0 + cur.nwin;           // one past the last valid slot (the sentinel slot)
+            const int rows = (t_end + 1 + 255) >> 8;
+            const int my_off = g.cv - (int)a0;           // first slot of read r_a + tid (32-bit wrap-around is exact)
+            int32_t *const cov0 = a.cov + a0;
+
+            // 1. clear the difference array and the read-start bits; stage the per-read tables
+            for (int i = (int)tid * 4; i < rows * 256; i += THREADS * 4)
+                *reinterpret_cast<int4 *>(&sm.diff[i]) = make_int4(0, 0, 0, 0);
+            for (int i = (int)tid; i < rows * 8; i += THREADS) sm.sbits[i] = 0u;
+            if ((int)tid <= nr) {
+                sm.roff[tid] = my_off; sm.rlen[tid] = g.rl; sm.rres[tid] = g.rr; sm.rcnt[tid] = 0;
+            }
+            lds_barrier();
+            RAFT_STAMP(2);
+
+            // 2. read-start bits (a run never continues across a read boundary, repeat.hpp:111-112)
+            if ((int)tid < nr) atomicOr(&sm.sbits[my_off >> 5], 1u << (my_off & 31));
+
+            // 3. intervals -> +1 / -1 (profileCoverage, closed form)
+            int covsum = 0;
+            bool bad_any = false;
+            auto one = [&](int rid, int st, int en) {
+                if (rid >= 0) {
+                    const int j = rid - r_a;
+                    const int b0 = sm.roff[j], nb_r = sm.roff[j + 1] - b0;
+                    const int first = (int)win_of(a, (unsigned)st);
+                    const int last1 = (int)win_of(a, (unsigned)(en - 1)) + 1;     // meaningful for en >= 1
+                    const bool sign_ok = (st | en) >= 0, pos = en > 0;
+                    const bool over = last1 > first && last1 > nb_r;               // repeat.hpp:69-72 writes past its vector
+                    const int pf = b0 + first, pl1 = b0 + min(last1, nb_r);
+                    bad_any |= !sign_ok || (pos && over);
+                    if (sign_ok && pos && pf < pl1) {
+                        __hip_atomic_fetch_add(&sm.diff[pf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&sm.diff[pl1], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        covsum += pl1 - pf;      // sum of coverage over the window == windows touched by its intervals
+                    }
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < U; ++u) one(g.rid[u], g.st[u], g.en[u]);
+            if (cur.more) {                      // intervals beyond the prefetched slots (dense tiles): synchronous loads
+                const TileCut d0 = cuts[k], d1 = cuts[k + 1];
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) {
+                    const int n_s = d1.iv_lo[s] - d0.iv_lo[s];
+                    const long long base = (long long)d0.iv_lo[s];
+                    for (int i = ITER * 256 + (int)tid; i < n_s; i += 256)
+                        one((a.iv_rid + base)[i], (a.iv_s + base)[i], (a.iv_e + base)[i]);
+                }
+            }
+            if (__ballot(bad_any) != 0ull) {     // rare: find the offending records again and report the first index
+                const TileCut d0 = cuts[k], d1 = cuts[k + 1];
+                auto is_bad = [&](int rid, int st, int en) -> bool {
+                    if (rid < 0) return false;
+                    const int j = rid - r_a;
+                    const int nb_r = sm.roff[j + 1] - sm.roff[j];
+                    const int first = (int)win_of(a, (unsigned)st), last1 = (int)win_of(a, (unsigned)(en - 1)) + 1;
+                    return (st | en) < 0 || (en > 0 && last1 > first && last1 > nb_r);
+                };
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) {
+                    const int n_s = d1.iv_lo[s] - d0.iv_lo[s];
+                    const long long base = (long long)d0.iv_lo[s];
+                    for (int i = (int)tid; i < n_s; i += 256)
+                        if (is_bad((a.iv_rid + base)[i], (a.iv_s + base)[i], (a.iv_e + base)[i])) raise_error(a, kErrCoord, base + i);
+                }
+            }
+            lane_cov += covsum;
+            lds_barrier();
+            RAFT_STAMP(3);
+
+            // 4. pass A: per-wave sums of the difference array (each wave owns rpw contiguous rows)
+            const int rpw = (rows + NW - 1) / NW;
+            const int row_b = wid * rpw;
+            const int row_e = min(rows, row_b + rpw);
+            {
+                int s = 0;
+                for (int row = row_b; row < row_e; ++row) {
+                    const int4 d = *reinterpret_cast<const int4 *>(&sm.diff[row * 256 + lane * 4]);
+                    s += d.x + d.y + d.z + d.w;
+                }
+                s = wave_reduce_add(s);
+                if (lane == 0) sm.wsum[wid] = s;
+            }
+            lds_barrier();
+            RAFT_STAMP(4);
+
+            // Every load issued so far -- including the NEXT tile's prefetch -- must land before this wave's first
+            // coverage store: after the stores, any vmcnt wait would also wait for the stores.
+            wait_all_loads();
+            RAFT_STAMP(15);
+
+            // 5. pass B: prefix sum, store, run detection
+            int carry = 0;
+            for (int w = 0; w < wid; ++w) carry += uni(sm.wsum[w]);
+            bool hp = (wid > 0) && (row_b < rows) && (carry >= a.high_cov); // window before this wave's first slot is high
+            const bool hp_in = hp;
+            int S = hp ? kOpen : kNone;  // start slot of the run currently open
+            int pclose = -1;             // slot at which the run inherited from before this wave closed
+            const int full_b = (off0 + 255) >> 8, full_e = t_end >> 8;   // rows [full_b, full_e) hold valid slots only
+
+            int4 dn = make_int4(0, 0, 0, 0);
+            if (row_b < row_e) dn = *reinterpret_cast<const int4 *>(&sm.diff[row_b * 256 + lane * 4]);
+            for (int row = row_b; row < row_e; ++row) {
+                const int base = row * 256, p0 = base + lane * 4;
+                const int4 d = dn;
+                if (row + 1 < row_e) dn = *reinterpret_cast<const int4 *>(&sm.diff[p0 + 256]);
+                // prefix sum of the row's 256 slots
+                const int x = d.x, y = x + d.y, z = y + d.z, w = z + d.w;
+                const int incl = wave_incl_scan_add(w);
+                const int excl = incl - w + carry;
+                carry += __builtin_amdgcn_readlane(incl, 63);
+                const int c0 = excl + x, c1 = excl + y, c2 = excl + z, c3 = excl + w;
+                unsigned long long M0, M1, M2, M3;
+                if (row >= full_b && row < full_e) {
+                    *reinterpret_cast<int4 *>(&cov0[p0]) = make_int4(c0, c1, c2, c3);
+                    M0 = __ballot(c0 >= a.high_cov); M1 = __ballot(c1 >= a.high_cov);
+                    M2 = __ballot(c2 >= a.high_cov); M3 = __ballot(c3 >= a.high_cov);
+                } else {                         // first / last row of the tile: some slots lie outside [off0, t_end)
+                    const unsigned q0 = (unsigned)(p0 - off0), nw_u = (unsigned)cur.nwin;
+                    const bool v0 = q0 < nw_u, v1 = q0 + 1u < nw_u, v2 = q0 + 2u < nw_u, v3 = q0 + 3u < nw_u;
+                    if (v0 && v3) *reinterpret_cast<int4 *>(&cov0[p0]) = make_int4(c0, c1, c2, c3);
+                    else {
+                        if (v0) cov0[p0 + 0] = c0;
+                        if (v1) cov0[p0 + 1] = c1;
+                        if (v2) cov0[p0 + 2] = c2;
+                        if (v3) cov0[p0 + 3] = c3;
+                    }
+                    M0 = __ballot(v0 && c0 >= a.high_cov); M1 = __ballot(v1 && c1 >= a.high_cov);
+                    M2 = __ballot(v2 && c2 >= a.high_cov); M3 = __ballot(v3 && c3 >= a.high_cov);
+                }
+                if ((M0 | M1 | M2 | M3) == 0ull && !hp) continue;   // the common case: no high window in the row
+
+                // ---- run scan of the row on its four >= high_cov ballots (scalar bit logic)
+                const unsigned long long VE0 = __ballot(p0 + 0 < t_end), VE1 = __ballot(p0 + 1 < t_end),
+                                         VE2 = __ballot(p0 + 2 < t_end), VE3 = __ballot(p0 + 3 < t_end);
+                const uint32_t word = sm.sbits[p0 >> 5];
+                const uint32_t nib = (word >> (p0 & 31)) & 0xFu;
+                const unsigned long long SB0 = __ballot(nib & 1u), SB1 = __ballot(nib & 2u),
+                                         SB2 = __ballot(nib & 4u), SB3 = __ballot(nib & 8u);
+                // P_k: the slot before (lane,k) is a high window; the carried-in bit belongs to the first valid slot:
+                // slot off0 of row 0, else slot 0 of the row
+                const unsigned long long hb = hp ? 1ull : 0ull;
+                const int hk = (row == 0) ? off0 : 0;
+                const unsigned long long P0 = (M3 << 1) | (hk == 0 ? hb : 0ull), P1 = M0 | (hk == 1 ? hb : 0ull),
+                                         P2 = M1 | (hk == 2 ? hb : 0ull), P3 = M2 | (hk == 3 ? hb : 0ull);
+                const unsigned long long CL0 = P0 & (~M0 | SB0) & VE0, CL1 = P1 & (~M1 | SB1) & VE1,
+                                         CL2 = P2 & (~M2 | SB2) & VE2, CL3 = P3 & (~M3 | SB3) & VE3; // run ends before this slot
+                const unsigned long long CA0 = M0 & (~P0 | SB0), CA1 = M1 & (~P1 | SB1),
+                                         CA2 = M2 & (~P2 | SB2), CA3 = M3 & (~P3 | SB3);             // run starts at this slot
+                if ((CL0 | CL1 | CL2 | CL3) != 0ull) {
+                    const unsigned long long lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+                    unsigned cl4 = (unsigned)((CL0 >> lane) & 1ull) | (unsigned)(((CL1 >> lane) & 1ull) << 1) |
+                                   (unsigned)(((CL2 >> lane) & 1ull) << 2) | (unsigned)(((CL3 >> lane) & 1ull) << 3);
+#pragma unroll 1
+                    while (cl4) {                        // rare: this lane sees the end of a run
+                        const int kk = __builtin_ctz(cl4);
+                        cl4 &= cl4 - 1u;
+                        int best = S;                    // latest run start at a slot before (lane, kk)
+                        unsigned long long m;
+                        m = CA0 & (0 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 0);
+                        m = CA1 & (1 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 1);
+                        m = CA2 & (2 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 2);
+                        m = CA3 & lt;                 if (m) best = max(best, base + 4 * top_bit(m) + 3);
+                        const int t = p0 + kk;
+                        if (best == kOpen) pclose = t;
+                        else if ((long long)(t - best) * a.reso >= (long long)a.repeat_length) { // repeat.hpp:125
+                            const int q = atomicAdd(&sm.runq_n[wid], 1);
+                            if (q < kRunQ) { sm.runq[(wid * kRunQ + q) * 2] = best; sm.runq[(wid * kRunQ + q) * 2 + 1] = t; }
+                            else emit_run(a, sm, nr, best, t);
+                        }
+                    }
+                }
+                if (CA0) S = max(S, base + 4 * top_bit(CA0) + 0);
+                if (CA1) S = max(S, base + 4 * top_bit(CA1) + 1);
+                if (CA2) S = max(S, base + 4 * top_bit(CA2) + 2);
+                if (CA3) S = max(S, base + 4 * top_bit(CA3) + 3);
+                if (base + 256 <= t_end) hp = (M3 >> 63) != 0ull;
+                else if (t_end > base) {
+                    const int tl = t_end - 1 - base; // last valid slot of the row
+                    const unsigned long long Mk = (tl & 3) == 0 ? M0 : (tl & 3) == 1 ? M1 : (tl & 3) == 2 ? M2 : M3;
+                    hp = ((Mk >> (tl >> 2)) & 1ull) != 0ull;
+                }
+            }
+
+            // 6. publish the wave's seam state
+            {
+                const unsigned long long pm = __ballot(pclose >= 0);
+                int pc = -1;
+                if (pm) pc = __builtin_amdgcn_readlane(pclose, (int)__builtin_ctzll(pm));
+                pclose = pc;
+                if (lane == 0) {
+                    *reinterpret_cast<int4 *>(&sm.wst[wid * 8]) = make_int4(row_e > row_b ? 1 : 0, pc, S, hp ? 1 : 0);
+                    sm.wst[wid * 8 + 4] = hp_in ? 1 : 0;
+                }
+            }
+            RAFT_STAMP(5);
+            lds_barrier();
+            RAFT_STAMP(6);
+
+            // 7. seams, resolved by every wave for itself: a run inherited from earlier waves starts at the run start of
+            //    the nearest earlier wave that saw one; the wave holding the last valid slot closes the run that
+            //    reaches the end of the tile (the end of a read closes a run, repeat.hpp:150)
+            {
+                const int v = (lane < NW * 8) ? sm.wst[lane] : 0;
+                auto run_start_before = [&](int w) -> int { // start slot of the run open at the end of wave w
+#pragma unroll
+                    for (int y = NW - 1; y >= 0; --y) {
+                        if (y > w) continue;
+                        if (!__builtin_amdgcn_readlane(v, y * 8 + 0)) continue;
+                        const int sf = __builtin_amdgcn_readlane(v, y * 8 + 2);
+                        if (sf != kOpen) return sf;
+                    }
+                    return -1;
+                };
+                auto park = [&](int sS, int sT) {
+                    if (sS < 0 || (long long)(sT - sS) * a.reso < (long long)a.repeat_length) return;
+                    if (lane == 0) {
+                        const int q = atomicAdd(&sm.runq_n[wid], 1);
+                        if (q < kRunQ) { sm.runq[(wid * kRunQ + q) * 2] = sS; sm.runq[(wid * kRunQ + q) * 2 + 1] = sT; }
+                        else emit_run(a, sm, nr, sS, sT);
+                    }
+                };
+                if (row_e > row_b) {
+                    if (hp_in && pclose >= 0) park(run_start_before(wid - 1), pclose);
+                    if (row_e == rows && hp)             // this wave holds the last valid slot
+                        park((S != kOpen) ? S : (wid == 0 ? -1 : run_start_before(wid - 1)), t_end);
+                }
+            }
+            RAFT_STAMP(11);
+
+            // 8. every run this wave parked becomes a repeat record, one lane per run
+            {
+                const int nq = uni(sm.runq_n[wid]);
+                if (nq > 0) {
+                    const int m = min(nq, kRunQ);
+                    int sS = 0, sT = 0, j = 0;
+                    if (lane < m) { sS = sm.runq[(wid * kRunQ + lane) * 2]; sT = sm.runq[(wid * kRunQ + lane) * 2 + 1]; }
+                    if (nr <= 64) {
+                        const int ro = (lane < nr) ? sm.roff[lane] : 0x7fffffff;
+#pragma unroll 1
+                        for (int q = 0; q < m; ++q) {
+                            const int jq = __popcll(__ballot(ro <= __builtin_amdgcn_readlane(sS, q))) - 1;
+                            if (lane == q) j = jq;
+                        }
+                    } else if (lane < m) j = owner_slot(sm, nr, sS);
+                    if (lane < m) emit_run_of(a, sm, j, sS, sT);
+                    if (lane == 0) sm.runq_n[wid] = 0;
+                }
+            }
+            RAFT_STAMP(13);
+            lds_barrier();
+            RAFT_STAMP(14);
+            // publish the repeat counts (rep_cnt[] was zeroed by the host)
+            if ((int)tid < nr) {
+                const int c = sm.rcnt[tid];
+                if (c) a.rep_cnt[r_a + tid] = c;
+            }
+        }
+        RAFT_STAMP(7);
+        if (DIAG && tid == 0 && a.dbg) {
+            sm.stamps[10] = __builtin_amdgcn_s_memrealtime();
+            for (int i = 0; i < 16; ++i) a.dbg[k * 16 + i] = sm.stamps[i];
+        }
+        k = kn; cur = nxt; g = gn;
+    }
+    {
+        const long long cs = wave_reduce_add64(lane_cov);
+        if (lane == 0 && cs) atomicAdd(&sm.acc_cov, (unsigned long long)cs);
+    }
+    lds_barrier();
+    if (tid == 0) {
+        a.block_sums[2 * (long long)blockIdx.x] = (long long)sm.acc_cov;
+        a.block_sums[2 * (long long)blockIdx.x + 1] = (long long)sm.acc_rep;
+    }
+}
+
+} // namespace raft
