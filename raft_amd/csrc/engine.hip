@@ -46,12 +46,25 @@ void launch_general(hipStream_t st, unsigned grid, const PileupArgs &pa)
 template <int CAP, int MINW, bool DIAG>
 void launch_fast(hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
+    const size_t dyn = 0;
     if (n_seg <= 1)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), 0, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else if (n_seg == 2)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), 0, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), 0, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+}
+
+// RAFT_PRINT_OCCUPANCY=1: what the runtime thinks of the pileup kernels (registers, LDS, resident workgroups per CU)
+template <class K>
+void print_occupancy(const char *name, K kernel)
+{
+    hipFuncAttributes fa{};
+    int nb = -1;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0);
+    fprintf(stderr, "occupancy %-28s regs %d lds %zu scratch %zu maxThreads %d -> blocks/CU (API) %d\n", name, fa.numRegs,
+            fa.sharedSizeBytes, fa.localSizeBytes, fa.maxThreadsPerBlock, nb);
 }
 
 struct Ctrl {                         // device control block, cleared every pass
@@ -473,10 +486,9 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
         pa.iv_rid = c->b_rid.as<int32_t>(); pa.iv_s = c->b_s.as<int32_t>(); pa.iv_e = c->b_e.as<int32_t>(); pa.n_seg = 1;
         c->sum.interval_path = 1; c->sum.n_segments = n_desc + 1; c->sum.n_intervals = -1; // read back in finish
     }
-    using GenSmem = PileupSmem<256, 6144>;
     hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
                        pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>(),
-                       pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, pv.cap, (int)GenSmem::MAXR,
+                       pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, pv.cap, kFastMaxReads,
                        pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow);
 
     pa.dbg = nullptr;
@@ -658,6 +670,12 @@ int raft_hip_selftest(int device_id)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return RAFT_HIP_ERR_DEVICE;
     if (hipSetDevice(device_id) != hipSuccess) return RAFT_HIP_ERR_DEVICE;
+    if (getenv("RAFT_PRINT_OCCUPANCY")) {
+        print_occupancy("fast<6144,2,4,5>", pileup_fast_kernel<6144, 2, kFastSlots, 5, false>);
+        print_occupancy("fast<6144,1,4,5>", pileup_fast_kernel<6144, 1, kFastSlots, 5, false>);
+        print_occupancy("fast<4864,2,4,6>", pileup_fast_kernel<4864, 2, kFastSlots, 6, false>);
+        print_occupancy("general<256,6144,5,3>", pileup_kernel<256, 6144, 5, 3, false>);
+    }
     const int n = 256;
     int h_in[n], h_a[n], h_b[n];
     unsigned long long h_bal[n / 64];

@@ -1,12 +1,17 @@
 // pileup_fast.hpp -- the lean pileup kernel for tiles of whole reads that fit one LDS window (all tiles of a
-// HiFi-like read set).  Same algorithm and LDS layout as pileup.hpp (which keeps handling the other tiles: reads
-// longer than the LDS window, tiles with very many reads); what differs is the bookkeeping around the rows, which
-// in the general kernel cost four times the vector instructions of the rows themselves (rocprofv3 SQ_INSTS_VALU):
+// HiFi-like read set).  Same algorithm as pileup.hpp (which keeps handling the other tiles: reads longer than the
+// LDS window, tiles with very many reads); what differs is the bookkeeping around the rows, which in the general
+// kernel costs four times the vector instructions of the rows themselves (rocprofv3 SQ_INSTS_VALU) and five
+// workgroup barriers per tile:
 //   * a tile is described by two adjacent 32-byte TileCut records (first read, first interval per segment, first
 //     window) that arrive through the scalar data cache (s_load) -- no per-lane descriptor, no readlane unpacking;
 //   * prefetch slot u of a lane is interval (u / NSEG) * 256 + lane-id of segment u % NSEG: the address is a scalar
 //     base plus the constant lane offset, no per-record index arithmetic; intervals beyond the prefetched slots
 //     (tiles inside repeats) are fetched synchronously afterwards;
+//   * three barriers per tile: pass B zeroes each row of the difference array right after reading it, and the
+//     per-read tables and read-start bits are double-buffered -- those of tile i+1 are written from the prefetched
+//     registers just before pass B of tile i, the repeat counts of tile i-1 are published at the same point -- so
+//     no clearing phase, no table phase and no publish phase stand between barriers;
 //   * coverage totals accumulate per lane in registers and are reduced once per workgroup, not once per tile;
 //   * one row body (first/last rows of a tile only differ in masks), so the run scan is instantiated once.
 // Reference semantics: repeat.hpp:28-79 (profileCoverage), repeat.hpp:111-168 (run scan); see pileup.hpp.
@@ -18,47 +23,93 @@ namespace raft {
 template <int U>
 struct FastRegs {
     int rid[U], st[U], en[U];
-    int cv, rr, rl;            // low dwords of cov_off / rep_res_off and the length of read r_a + thread-id
+};
+struct FastReadRegs {           // per read of a tile (thread j <-> read r_a + j, j <= nr)
+    int cv, rr, rl;             // low dwords of cov_off / rep_res_off, read length
 };
 
-struct FastTile {              // scalars of one tile
+struct FastTile {               // scalars of one tile
     int r_a, nr, nwin, fast, more;   // more: a segment holds intervals beyond the prefetched slots
     long long g_lo;
 };
 
+constexpr int kFastMaxReads = 86;    // reads per fast tile (their tables live in LDS, double-buffered)
+
+template <int CAP>
+struct FastSmem {
+    static constexpr int NW = 4;
+    static constexpr int SLOTS = CAP + 256;  // window slots: 3 alignment + CAP + 1 sentinel, rounded to rows
+    static constexpr int SBW = SLOTS / 32;
+    static constexpr int TAB = kFastMaxReads + 2;
+    int32_t diff[SLOTS];                     // zero whenever no tile is between its interval phase and its pass B
+    uint32_t sbits[2][SBW];                  // read-start bits of the tile in flight / the next tile
+    int32_t roff[2][TAB];                    // first slot of read r_a+j relative to a0 (j <= nr)
+    int32_t rlen[2][TAB];
+    int32_t rcnt[2][TAB];                    // raw repeats emitted for the read
+    int32_t rres[2][TAB];                    // its first reserved raw-repeat slot (rep_res_off, < 2^31 checked by the host)
+    unsigned long long acc_cov, acc_rep;
+    int32_t wsum[NW];
+    int32_t wst[NW * 8];                     // per wave: rows, pclose, sfinal, hpfinal, hpin
+    unsigned long long stamps[16];           // diagnostic build
+    int32_t runq_n[NW];
+    int32_t runq[NW * 2 * kRunQ];
+};
+
+struct FastTables {             // the table set of one tile, in the shape emit_run_of()/owner_slot() expect
+    int32_t *roff, *rlen, *rcnt, *rres;
+    unsigned long long &acc_rep;
+};
+
+// Two adjacent cuts (16 dwords) travel as ONE VGPR -- lane l holds dword l -- from the load one tile ahead to the
+// readlanes that unpack them: ten scalar registers held across a whole tile would be spilled to VGPR lanes right
+// after an s_load (measured: three exposed scalar-load waits per tile).
 template <int NSEG, int ITER>
-__device__ __forceinline__ void cut_unpack(const TileCut &c0, const TileCut &c1, FastTile &t, int (&lo)[NSEG], int (&n)[NSEG])
+__device__ __forceinline__ void cut_unpack(int raw, FastTile &t, int (&lo)[NSEG], int (&n)[NSEG])
 {
-    t.r_a = c0.r_lo; t.nr = c1.r_lo - c0.r_lo; t.fast = c0.flags & kCutFast; t.g_lo = c0.g_lo;
-    t.nwin = (int)(c1.g_lo - c0.g_lo);
+    auto d = [&](int i) -> int { return __builtin_amdgcn_readlane(raw, i); };
+    auto q = [&](int i) -> long long { return (long long)(((unsigned long long)(unsigned)d(i + 1) << 32) | (unsigned)d(i)); };
+    const int r0 = d(0);
+    t.r_a = r0; t.nr = d(8) - r0; t.fast = d(1) & kCutFast; t.g_lo = q(6);
+    t.nwin = d(14) - d(6);                        // low dwords suffice: a fast tile has at most CAP windows
     t.more = 0;
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
-        lo[s] = c0.iv_lo[s]; n[s] = c1.iv_lo[s] - c0.iv_lo[s];
+        lo[s] = d(2 + s); n[s] = d(10 + s) - lo[s];
         if (n[s] > ITER * 256) t.more = 1;
     }
 }
 
-// Loads of one tile: three per read (threads 0..nr) and three per interval slot.
+// Loads of one tile: three per read (threads 0..nr) and three per interval slot.  Every address is a per-tile scalar
+// base plus this lane's constant byte offset (global_load saddr form).  The offsets pass through an empty asm so
+// that the compiler cannot fold them into six loop-invariant 64-bit per-lane pointers (12 VGPRs held for the whole
+// kernel); `at` does the typed load.
+template <class T>
+__device__ __forceinline__ T at(const T *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 template <int NSEG, int U>
 __device__ __forceinline__ void fast_issue(const PileupArgs &a, unsigned tid, const FastTile &t, const int (&lo)[NSEG],
-                                           const int (&n)[NSEG], FastRegs<U> &g)
+                                           const int (&n)[NSEG], FastRegs<U> &g, FastReadRegs &rd)
 {
-    g.cv = 0; g.rr = 0; g.rl = 0;
+    unsigned b4 = tid * 4u, b8 = tid * 8u;
+    asm volatile("" : "+v"(b4), "+v"(b8));
+    rd.cv = 0; rd.rr = 0; rd.rl = 0;
     if ((int)tid <= t.nr) {
-        g.cv = (reinterpret_cast<const int32_t *>(a.cov_off) + 2 * (long long)t.r_a)[2u * tid];
-        g.rr = (reinterpret_cast<const int32_t *>(a.rep_res_off) + 2 * (long long)t.r_a)[2u * tid];
+        rd.cv = at(reinterpret_cast<const int32_t *>(a.cov_off + t.r_a), b8);
+        rd.rr = at(reinterpret_cast<const int32_t *>(a.rep_res_off + t.r_a), b8);
     }
-    if ((int)tid < t.nr) g.rl = (a.read_len + t.r_a)[tid];
+    if ((int)tid < t.nr) rd.rl = at(a.read_len + t.r_a, b4);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int s = u % NSEG, first = (u / NSEG) * 256;
         g.rid[u] = -1; g.st[u] = 0; g.en[u] = 0;
         if ((int)tid < n[s] - first) {
             const long long base = (long long)lo[s] + first;
-            g.rid[u] = (a.iv_rid + base)[tid];
-            g.st[u] = (a.iv_s + base)[tid];
-            g.en[u] = (a.iv_e + base)[tid];
+            g.rid[u] = at(a.iv_rid + base, b4);
+            g.st[u] = at(a.iv_s + base, b4);
+            g.en[u] = at(a.iv_e + base, b4);
         }
     }
 }
@@ -68,36 +119,80 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
 {
     constexpr int THREADS = 256, NW = 4, ITER = U / NSEG;
     static_assert(U % NSEG == 0 && ITER >= 1, "slots are split evenly over the segments");
-    using Smem = PileupSmem<THREADS, CAP>;
+    using Smem = FastSmem<CAP>;
+    // Measured on MI355X (tools/occ_probe.hip, tools/stamp_probe.py): five 31,744-byte workgroups share a CU, five
+    // 31,856-byte ones do not -- a fifth of the persistent grid then starts only when the first workgroups retire and
+    // the kernel takes a third longer.  Stay at or below the footprint that is known to fit.
+    static_assert(sizeof(Smem) * MINW <= 31328 * 5, "LDS footprint does not allow MINW workgroups per CU");
     __shared__ __attribute__((aligned(16))) Smem sm;
     const unsigned tid = threadIdx.x;
     const int lane = (int)(tid & 63u);
     const int wid = uni((int)(tid >> 6));
     const long long nb = gridDim.x;
+    const long long last_cut = a.n_tiles - 1;    // cuts[last_cut + 1] is the closing boundary
+
+    // LDS starts clean: difference array and both sets of read-start bits are zero between tiles
+    for (int i = (int)tid * 4; i < Smem::SLOTS; i += THREADS * 4) *reinterpret_cast<int4 *>(&sm.diff[i]) = make_int4(0, 0, 0, 0);
+    for (int i = (int)tid; i < 2 * Smem::SBW; i += THREADS) (&sm.sbits[0][0])[i] = 0u;
     if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; }
     if (tid < (unsigned)NW) sm.runq_n[tid] = 0;
+    lds_barrier();
     long long lane_cov = 0;                      // this lane's share of the coverage total (reduced once, at the end)
 
+    // tables + read-start bits of a tile, from the registers its loads filled; returns this thread's first slot
+    auto stage_reads = [&](int set, const FastTile &t, const FastReadRegs &rd) -> int {
+        const int off = rd.cv - (int)(t.g_lo & ~3LL);       // 32-bit wrap-around is exact
+        if ((int)tid <= t.nr) {
+            sm.roff[set][tid] = off; sm.rlen[set][tid] = rd.rl; sm.rres[set][tid] = rd.rr; sm.rcnt[set][tid] = 0;
+        }
+        // a run never continues across a read boundary (repeat.hpp:111-112)
+        if ((int)tid < t.nr) atomicOr(&sm.sbits[set][off >> 5], 1u << (off & 31));
+        return off;
+    };
+    // repeat counts of a finished tile (rep_cnt[] was zeroed by the host)
+    auto publish_counts = [&](int set, int r_a, int nr) {
+        if ((int)tid < nr) {
+            const int c = sm.rcnt[set][tid];
+            if (c) a.rep_cnt[r_a + tid] = c;
+        }
+    };
+
+    const int32_t *cut_words = reinterpret_cast<const int32_t *>(cuts);
+    auto cut_word = [&](long long kc) -> int {   // dword `lane` of cuts[kc], cuts[kc + 1]; n_tiles * 8 < 2^31 (host check)
+        const unsigned idx = (unsigned)kc * 8u + (unsigned)lane;
+        return lane < 16 ? cut_words[idx] : 0;
+    };
     long long k = blockIdx.x;
     FastTile cur{}, nxt{};
     FastRegs<U> g{}, gn{};
-    TileCut c0{}, c1{};                          // cuts of the tile after next, requested one tile ahead
+    FastReadRegs rdn{};
+    int cur_off = 0, nxt_off = 0;                // first slot of this thread's read in the current / next tile
+    int pub_r_a = 0, pub_nr = 0;                 // tile whose repeat counts are still in LDS (set 1 - p)
+    int p = 0;                                   // table / start-bit set of the current tile
+    int raw_n = 0, raw_nn = 0;                   // cuts of the next tile (landed) / of the tile after next (in flight)
     if (k < a.n_tiles) {
         int lo[NSEG], n[NSEG];
-        cut_unpack<NSEG, ITER>(cuts[k], cuts[k + 1], cur, lo, n);
-        if (cur.fast) fast_issue<NSEG, U>(a, tid, cur, lo, n, g);
-        if (k + nb < a.n_tiles) { c0 = cuts[k + nb]; c1 = cuts[k + nb + 1]; }
+        cut_unpack<NSEG, ITER>(cut_word(k), cur, lo, n);
+        if (cur.fast) {
+            FastReadRegs rd;
+            fast_issue<NSEG, U>(a, tid, cur, lo, n, g, rd);
+            wait_all_loads();
+            cur_off = stage_reads(0, cur, rd);
+        }
+        raw_n = cut_word(min(k + nb, last_cut));
     }
     wait_all_loads();
+    lds_barrier();
     while (k < a.n_tiles) {
         const long long kn = k + nb;
         if (DIAG && tid == 0 && a.dbg) { sm.stamps[0] = __builtin_amdgcn_s_memtime(); sm.stamps[9] = __builtin_amdgcn_s_memrealtime(); }
-        nxt.fast = 0;
-        if (kn < a.n_tiles) {
+        {
+            // raw_n always holds real cuts (the index is clamped), so the unpacking needs no guard
             int lo[NSEG], n[NSEG];
-            cut_unpack<NSEG, ITER>(c0, c1, nxt, lo, n);
-            if (nxt.fast) fast_issue<NSEG, U>(a, tid, nxt, lo, n, gn);
-            if (kn + nb < a.n_tiles) { c0 = cuts[kn + nb]; c1 = cuts[kn + nb + 1]; }
+            cut_unpack<NSEG, ITER>(raw_n, nxt, lo, n);
+            if (kn >= a.n_tiles) nxt.fast = 0;
+            raw_nn = cut_word(min(kn + nb, last_cut));
+            if (nxt.fast) fast_issue<NSEG, U>(a, tid, nxt, lo, n, gn, rdn);
         }
         if (DIAG && tid == 0 && a.dbg) sm.stamps[8] = (unsigned long long)cur.nwin;
         RAFT_STAMP(1);
@@ -108,29 +203,16 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             const int off0 = (int)(cur.g_lo - a0);       // first valid slot
             const int t_end = off0 + cur.nwin;           // one past the last valid slot (the sentinel slot)
             const int rows = (t_end + 1 + 255) >> 8;
-            const int my_off = g.cv - (int)a0;           // first slot of read r_a + tid (32-bit wrap-around is exact)
             int32_t *const cov0 = a.cov + a0;
+            FastTables tb{sm.roff[p], sm.rlen[p], sm.rcnt[p], sm.rres[p], sm.acc_rep};
 
-            // 1. clear the difference array and the read-start bits; stage the per-read tables
-            for (int i = (int)tid * 4; i < rows * 256; i += THREADS * 4)
-                *reinterpret_cast<int4 *>(&sm.diff[i]) = make_int4(0, 0, 0, 0);
-            for (int i = (int)tid; i < rows * 8; i += THREADS) sm.sbits[i] = 0u;
-            if ((int)tid <= nr) {
-                sm.roff[tid] = my_off; sm.rlen[tid] = g.rl; sm.rres[tid] = g.rr; sm.rcnt[tid] = 0;
-            }
-            lds_barrier();
-            RAFT_STAMP(2);
-
-            // 2. read-start bits (a run never continues across a read boundary, repeat.hpp:111-112)
-            if ((int)tid < nr) atomicOr(&sm.sbits[my_off >> 5], 1u << (my_off & 31));
-
-            // 3. intervals -> +1 / -1 (profileCoverage, closed form)
+            // 1. intervals -> +1 / -1 (profileCoverage, closed form)
             int covsum = 0;
             bool bad_any = false;
             auto one = [&](int rid, int st, int en) {
                 if (rid >= 0) {
                     const int j = rid - r_a;
-                    const int b0 = sm.roff[j], nb_r = sm.roff[j + 1] - b0;
+                    const int b0 = tb.roff[j], nb_r = tb.roff[j + 1] - b0;
                     const int first = (int)win_of(a, (unsigned)st);
                     const int last1 = (int)win_of(a, (unsigned)(en - 1)) + 1;     // meaningful for en >= 1
                     const bool sign_ok = (st | en) >= 0, pos = en > 0;
@@ -159,9 +241,8 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             if (__ballot(bad_any) != 0ull) {     // rare: find the offending records again and report the first index
                 const TileCut d0 = cuts[k], d1 = cuts[k + 1];
                 auto is_bad = [&](int rid, int st, int en) -> bool {
-                    if (rid < 0) return false;
                     const int j = rid - r_a;
-                    const int nb_r = sm.roff[j + 1] - sm.roff[j];
+                    const int nb_r = tb.roff[j + 1] - tb.roff[j];
                     const int first = (int)win_of(a, (unsigned)st), last1 = (int)win_of(a, (unsigned)(en - 1)) + 1;
                     return (st | en) < 0 || (en > 0 && last1 > first && last1 > nb_r);
                 };
@@ -174,10 +255,11 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 }
             }
             lane_cov += covsum;
+            RAFT_STAMP(2);
             lds_barrier();
             RAFT_STAMP(3);
 
-            // 4. pass A: per-wave sums of the difference array (each wave owns rpw contiguous rows)
+            // 2. pass A: per-wave sums of the difference array (each wave owns rpw contiguous rows)
             const int rpw = (rows + NW - 1) / NW;
             const int row_b = wid * rpw;
             const int row_e = min(rows, row_b + rpw);
@@ -197,8 +279,12 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             // coverage store: after the stores, any vmcnt wait would also wait for the stores.
             wait_all_loads();
             RAFT_STAMP(15);
+            // The other table set is free now (its tile's runs were emitted before the last barrier pair): publish
+            // that tile's repeat counts, then stage the next tile's reads in it.
+            publish_counts(1 - p, pub_r_a, pub_nr);
+            if (nxt.fast) nxt_off = stage_reads(1 - p, nxt, rdn);
 
-            // 5. pass B: prefix sum, store, run detection
+            // 3. pass B: prefix sum, store, run detection; each row is zeroed for the next tile once it is read
             int carry = 0;
             for (int w = 0; w < wid; ++w) carry += uni(sm.wsum[w]);
             bool hp = (wid > 0) && (row_b < rows) && (carry >= a.high_cov); // window before this wave's first slot is high
@@ -213,6 +299,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 const int base = row * 256, p0 = base + lane * 4;
                 const int4 d = dn;
                 if (row + 1 < row_e) dn = *reinterpret_cast<const int4 *>(&sm.diff[p0 + 256]);
+                *reinterpret_cast<int4 *>(&sm.diff[p0]) = make_int4(0, 0, 0, 0);
                 // prefix sum of the row's 256 slots
                 const int x = d.x, y = x + d.y, z = y + d.z, w = z + d.w;
                 const int incl = wave_incl_scan_add(w);
@@ -242,7 +329,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 // ---- run scan of the row on its four >= high_cov ballots (scalar bit logic)
                 const unsigned long long VE0 = __ballot(p0 + 0 < t_end), VE1 = __ballot(p0 + 1 < t_end),
                                          VE2 = __ballot(p0 + 2 < t_end), VE3 = __ballot(p0 + 3 < t_end);
-                const uint32_t word = sm.sbits[p0 >> 5];
+                const uint32_t word = sm.sbits[p][p0 >> 5];
                 const uint32_t nib = (word >> (p0 & 31)) & 0xFu;
                 const unsigned long long SB0 = __ballot(nib & 1u), SB1 = __ballot(nib & 2u),
                                          SB2 = __ballot(nib & 4u), SB3 = __ballot(nib & 8u);
@@ -275,7 +362,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                         else if ((long long)(t - best) * a.reso >= (long long)a.repeat_length) { // repeat.hpp:125
                             const int q = atomicAdd(&sm.runq_n[wid], 1);
                             if (q < kRunQ) { sm.runq[(wid * kRunQ + q) * 2] = best; sm.runq[(wid * kRunQ + q) * 2 + 1] = t; }
-                            else emit_run(a, sm, nr, best, t);
+                            else emit_run(a, tb, nr, best, t);
                         }
                     }
                 }
@@ -291,7 +378,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 }
             }
 
-            // 6. publish the wave's seam state
+            // 4. publish the wave's seam state
             {
                 const unsigned long long pm = __ballot(pclose >= 0);
                 int pc = -1;
@@ -306,7 +393,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             lds_barrier();
             RAFT_STAMP(6);
 
-            // 7. seams, resolved by every wave for itself: a run inherited from earlier waves starts at the run start of
+            // 5. seams, resolved by every wave for itself: a run inherited from earlier waves starts at the run start of
             //    the nearest earlier wave that saw one; the wave holding the last valid slot closes the run that
             //    reaches the end of the tile (the end of a read closes a run, repeat.hpp:150)
             {
@@ -326,7 +413,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                     if (lane == 0) {
                         const int q = atomicAdd(&sm.runq_n[wid], 1);
                         if (q < kRunQ) { sm.runq[(wid * kRunQ + q) * 2] = sS; sm.runq[(wid * kRunQ + q) * 2 + 1] = sT; }
-                        else emit_run(a, sm, nr, sS, sT);
+                        else emit_run(a, tb, nr, sS, sT);
                     }
                 };
                 if (row_e > row_b) {
@@ -337,7 +424,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             }
             RAFT_STAMP(11);
 
-            // 8. every run this wave parked becomes a repeat record, one lane per run
+            // 6. every run this wave parked becomes a repeat record, one lane per run
             {
                 const int nq = uni(sm.runq_n[wid]);
                 if (nq > 0) {
@@ -345,33 +432,39 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                     int sS = 0, sT = 0, j = 0;
                     if (lane < m) { sS = sm.runq[(wid * kRunQ + lane) * 2]; sT = sm.runq[(wid * kRunQ + lane) * 2 + 1]; }
                     if (nr <= 64) {
-                        const int ro = (lane < nr) ? sm.roff[lane] : 0x7fffffff;
+                        const int ro = (lane < nr) ? tb.roff[lane] : 0x7fffffff;
 #pragma unroll 1
                         for (int q = 0; q < m; ++q) {
                             const int jq = __popcll(__ballot(ro <= __builtin_amdgcn_readlane(sS, q))) - 1;
                             if (lane == q) j = jq;
                         }
-                    } else if (lane < m) j = owner_slot(sm, nr, sS);
-                    if (lane < m) emit_run_of(a, sm, j, sS, sT);
+                    } else if (lane < m) j = owner_slot(tb, nr, sS);
+                    if (lane < m) emit_run_of(a, tb, j, sS, sT);
                     if (lane == 0) sm.runq_n[wid] = 0;
                 }
             }
+            // this tile's read-start bits go away (the set is next used two tiles from now, two barriers later)
+            if ((int)tid < nr) sm.sbits[p][cur_off >> 5] = 0u;
             RAFT_STAMP(13);
+            pub_r_a = r_a; pub_nr = nr;          // counts are final once every wave is past its next barrier
+        } else {
+            // no work in this tile: keep the hand-over of the table sets going
+            lds_barrier();                       // the previous tile's runs are all emitted
+            wait_all_loads();
+            publish_counts(1 - p, pub_r_a, pub_nr);
+            if (nxt.fast) nxt_off = stage_reads(1 - p, nxt, rdn);
             lds_barrier();
-            RAFT_STAMP(14);
-            // publish the repeat counts (rep_cnt[] was zeroed by the host)
-            if ((int)tid < nr) {
-                const int c = sm.rcnt[tid];
-                if (c) a.rep_cnt[r_a + tid] = c;
-            }
+            pub_nr = 0;
         }
         RAFT_STAMP(7);
         if (DIAG && tid == 0 && a.dbg) {
             sm.stamps[10] = __builtin_amdgcn_s_memrealtime();
             for (int i = 0; i < 16; ++i) a.dbg[k * 16 + i] = sm.stamps[i];
         }
-        k = kn; cur = nxt; g = gn;
+        k = kn; cur = nxt; g = gn; cur_off = nxt_off; p = 1 - p; raw_n = raw_nn;
     }
+    lds_barrier();                               // the last tile's runs are all emitted
+    publish_counts(1 - p, pub_r_a, pub_nr);
     {
         const long long cs = wave_reduce_add64(lane_cov);
         if (lane == 0 && cs) atomicAdd(&sm.acc_cov, (unsigned long long)cs);

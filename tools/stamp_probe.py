@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase s_memtime shares of the pileup kernel (variant 3 = variant 0 + stamps).
 
-Stamps per tile (thread 0): 0 kernel entry, 1 after tile descriptor loads, 2 after LDS clear + offset
-table, 3 after interval phase, 4 after pass A, 5 own wave done with pass B, 6 all waves done, 7 exit.
+Stamps per tile (thread 0) of pileup_fast_kernel: 0 tile start, 1 after cut unpack + prefetch issue, 2 own wave
+done with the interval phase, 3 past barrier A, 4 past pass A and barrier B, 15 loads landed, 5 own wave done with
+staging the next tile + pass B, 6 past barrier C, 11 seams resolved, 13 runs emitted, 7 tile end.
 Read SHARES, not lengths (the stamps serialise scalar memory).
 """
 import os, sys
@@ -26,18 +27,51 @@ ok = st[:, 7] > 0
 st = st[ok]
 print(f"tiles {len(st)}  kernel {pile*1e3:.3f} ms")
 d = np.diff(st[:, :8], axis=1)
-names = ["descr unpack+prefetch issue", "clear+offset table", "interval phase", "pass A", "wait loads + pass B (own wave)", "wait other waves", "stitch"]
+names = ["cut unpack+prefetch issue", "interval phase (own)", "barrier A", "pass A + barrier B", "wait loads+stage next+pass B (own)", "barrier C", "seams+emit"]
 life = st[:, 7] - st[:, 0]
 print(f"lifetime cycles: median {np.median(life):.0f} mean {life.mean():.0f} p90 {np.percentile(life,90):.0f}")
 for i, n in enumerate(names):
     print(f"  {n:22s} median {np.median(d[:, i]):8.0f}  mean {d[:, i].mean():8.0f}  share {d[:, i].sum()/life.sum():.3f}")
 w = st[:, 15] - st[:, 4]
 print(f"  4->15 vmcnt(0) before pass B  median {np.median(w):8.0f} mean {w.mean():8.0f}")
-sub = np.stack([st[:, 11] - st[:, 6], st[:, 13] - st[:, 11], st[:, 14] - st[:, 13], st[:, 7] - st[:, 14]], 1)
-for n, c in zip(["  6->11 resolve seams", "  11->13 emit parked runs", "  13->14 barrier", "  14->7 publish counts"], sub.T):
+sub = np.stack([st[:, 11] - st[:, 6], st[:, 13] - st[:, 11]], 1)
+for n, c in zip(["  6->11 resolve seams", "  11->13 emit parked runs"], sub.T):
     print(f"{n:28s} median {np.median(c):8.0f} mean {c.mean():8.0f}")
 rt = (st[:, 10] - st[:, 9])
 print("memtime ticks per 100MHz realtime tick:", np.median(life[rt > 0] / rt[rt > 0]))
 # concurrency: kernel span vs sum of lifetimes
 span = st[:, 7].max() - st[:, 0].min()
 print(f"span {span} ticks; sum lifetimes/span = {life.sum()/span:.1f} tiles in flight on average")
+# per-workgroup view (persistent grid: tile k belongs to workgroup k % grid)
+grid = int(os.environ.get("RAFT_PROBE_GRID", "1280"))
+full = eng.debug_stamps().astype(np.int64)
+kidx = np.nonzero(full[:, 7] > 0)[0]
+good = (full[kidx, 0] > 0) & (full[kidx, 7] > full[kidx, 0]) & (full[kidx, 7] - full[kidx, 0] < 10_000_000)
+kidx = kidx[good]
+wg = kidx % grid
+t0 = full[kidx, 0]; t7 = full[kidx, 7]
+first = np.full(grid, np.iinfo(np.int64).max); last = np.zeros(grid, np.int64); busy = np.zeros(grid, np.int64); cnt = np.zeros(grid, np.int64)
+np.minimum.at(first, wg, t0); np.maximum.at(last, wg, t7); np.add.at(busy, wg, t7 - t0); np.add.at(cnt, wg, 1)
+okw = cnt > 0
+origin = first[okw].min()
+print(f"workgroups with tiles {okw.sum()}  start spread (cycles after the first): median {np.median(first[okw]-origin):.0f} p90 {np.percentile(first[okw]-origin,90):.0f} max {(first[okw]-origin).max():.0f}")
+print(f"workgroup span median {np.median((last-first)[okw]):.0f}  in-tile share of span median {np.median(busy[okw]/(last-first)[okw]):.3f}  kernel span {last[okw].max()-origin}")
+order = np.argsort(kidx)
+ks, ws, a0, a7 = kidx[order], wg[order], t0[order], t7[order]
+nxt = {}
+gaps = []
+for k_, w_, s0, s7 in zip(ks[::-1], ws[::-1], a0[::-1], a7[::-1]):
+    if w_ in nxt: gaps.append(nxt[w_] - s7)
+    nxt[w_] = s0
+gaps = np.array(gaps)
+print(f"gap between tiles of a workgroup (stamp 7 -> next stamp 0): median {np.median(gaps):.0f} mean {gaps.mean():.0f} p90 {np.percentile(gaps,90):.0f}")
+# the same on the 100 MHz s_memrealtime clock (common to all XCDs): when does each workgroup start / stop?
+r0 = full[kidx, 9]; r1 = full[kidx, 10]
+rfirst = np.full(grid, np.iinfo(np.int64).max); rlast = np.zeros(grid, np.int64)
+np.minimum.at(rfirst, wg, r0); np.maximum.at(rlast, wg, r1)
+o = rfirst[okw].min()
+st_us = (rfirst[okw] - o) / 100.0; en_us = (rlast[okw] - o) / 100.0
+print("workgroup start (us after first): p10 %.0f p50 %.0f p75 %.0f p85 %.0f p95 %.0f max %.0f" % tuple(np.percentile(st_us, [10, 50, 75, 85, 95, 100])))
+print("workgroup end   (us after first): p10 %.0f p50 %.0f p75 %.0f p85 %.0f p95 %.0f max %.0f" % tuple(np.percentile(en_us, [10, 50, 75, 85, 95, 100])))
+late = st_us > 0.25 * en_us.max()
+print(f"workgroups starting later than 25% into the kernel: {late.sum()} of {okw.sum()}")
