@@ -39,20 +39,17 @@ template <int CAP>
 struct FastSmem {
     static constexpr int NW = 4;
     static constexpr int SLOTS = CAP + 256;  // window slots: 3 alignment + CAP + 1 sentinel, rounded to rows
-    static constexpr int SBW = SLOTS / 32;
     static constexpr int TAB = kFastMaxReads + 2;
     int32_t diff[SLOTS];                     // zero whenever no tile is between its interval phase and its pass B
-    uint32_t sbits[2][SBW];                  // read-start bits of the tile in flight / the next tile
     int32_t roff[2][TAB];                    // first slot of read r_a+j relative to a0 (j <= nr)
     int32_t rlen[2][TAB];
     int32_t rcnt[2][TAB];                    // raw repeats emitted for the read
     int32_t rres[2][TAB];                    // its first reserved raw-repeat slot (rep_res_off, < 2^31 checked by the host)
     unsigned long long acc_cov, acc_rep;
-    int32_t wsum[NW];
+    __attribute__((aligned(16))) int32_t wsum[NW];
     int32_t wst[NW * 8];                     // per wave: rows, pclose, sfinal, hpfinal, hpin
     unsigned long long stamps[16];           // diagnostic build
-    int32_t runq_n[NW];
-    int32_t runq[NW * 2 * kRunQ];
+    int32_t runq[NW * 2 * kRunQ];            // per wave: closed runs parked for emission (slots relative to a0)
 };
 
 struct FastTables {             // the table set of one tile, in the shape emit_run_of()/owner_slot() expect
@@ -130,24 +127,26 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     const int wid = uni((int)(tid >> 6));
     const long long nb = gridDim.x;
     const long long last_cut = a.n_tiles - 1;    // cuts[last_cut + 1] is the closing boundary
+    // runs are kept from ceil(repeat_length / reso) windows on; from 68 windows on, pass B can tell by whole lanes
+    // of four windows that a row ends no such run (see there)
+    const bool long_runs_only = ((long long)a.repeat_length + a.reso - 1) / a.reso >= 68;
+    // window of base n without a branch: n / reso == ((n & win_m1) | mulhi(n, div_magic)) >> win_sh  (div_magic is 0 and
+    // win_m1 all ones when reso == 1, see win_of)
+    const unsigned win_m1 = a.div_shift < 0 ? ~0u : 0u;
+    const int win_sh = a.div_shift < 0 ? 0 : a.div_shift;
 
-    // LDS starts clean: difference array and both sets of read-start bits are zero between tiles
+    // LDS starts clean: the difference array is zero between tiles
     for (int i = (int)tid * 4; i < Smem::SLOTS; i += THREADS * 4) *reinterpret_cast<int4 *>(&sm.diff[i]) = make_int4(0, 0, 0, 0);
-    for (int i = (int)tid; i < 2 * Smem::SBW; i += THREADS) (&sm.sbits[0][0])[i] = 0u;
     if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; }
-    if (tid < (unsigned)NW) sm.runq_n[tid] = 0;
     lds_barrier();
     long long lane_cov = 0;                      // this lane's share of the coverage total (reduced once, at the end)
 
-    // tables + read-start bits of a tile, from the registers its loads filled; returns this thread's first slot
-    auto stage_reads = [&](int set, const FastTile &t, const FastReadRegs &rd) -> int {
-        const int off = rd.cv - (int)(t.g_lo & ~3LL);       // 32-bit wrap-around is exact
+    // per-read tables of a tile, from the registers its loads filled
+    auto stage_reads = [&](int set, const FastTile &t, const FastReadRegs &rd) {
         if ((int)tid <= t.nr) {
-            sm.roff[set][tid] = off; sm.rlen[set][tid] = rd.rl; sm.rres[set][tid] = rd.rr; sm.rcnt[set][tid] = 0;
+            sm.roff[set][tid] = rd.cv - (int)(t.g_lo & ~3LL);       // 32-bit wrap-around is exact
+            sm.rlen[set][tid] = rd.rl; sm.rres[set][tid] = rd.rr; sm.rcnt[set][tid] = 0;
         }
-        // a run never continues across a read boundary (repeat.hpp:111-112)
-        if ((int)tid < t.nr) atomicOr(&sm.sbits[set][off >> 5], 1u << (off & 31));
-        return off;
     };
     // repeat counts of a finished tile (rep_cnt[] was zeroed by the host)
     auto publish_counts = [&](int set, int r_a, int nr) {
@@ -166,7 +165,6 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     FastTile cur{}, nxt{};
     FastRegs<U> g{}, gn{};
     FastReadRegs rdn{};
-    int cur_off = 0, nxt_off = 0;                // first slot of this thread's read in the current / next tile
     int pub_r_a = 0, pub_nr = 0;                 // tile whose repeat counts are still in LDS (set 1 - p)
     int p = 0;                                   // table / start-bit set of the current tile
     int raw_n = 0, raw_nn = 0;                   // cuts of the next tile (landed) / of the tile after next (in flight)
@@ -177,7 +175,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             FastReadRegs rd;
             fast_issue<NSEG, U>(a, tid, cur, lo, n, g, rd);
             wait_all_loads();
-            cur_off = stage_reads(0, cur, rd);
+            stage_reads(0, cur, rd);
         }
         raw_n = cut_word(min(k + nb, last_cut));
     }
@@ -194,7 +192,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             raw_nn = cut_word(min(kn + nb, last_cut));
             if (nxt.fast) fast_issue<NSEG, U>(a, tid, nxt, lo, n, gn, rdn);
         }
-        if (DIAG && tid == 0 && a.dbg) sm.stamps[8] = (unsigned long long)cur.nwin;
+        if (DIAG && tid == 0 && a.dbg) { sm.stamps[8] = (unsigned long long)cur.nwin; sm.stamps[12] = (unsigned long long)cur.more; }
         RAFT_STAMP(1);
         if (cur.fast) {
             // ---- geometry of the LDS window: slots are windows relative to a0 (16-byte aligned in cov[])
@@ -206,28 +204,28 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             int32_t *const cov0 = a.cov + a0;
             FastTables tb{sm.roff[p], sm.rlen[p], sm.rcnt[p], sm.rres[p], sm.acc_rep};
 
-            // 1. intervals -> +1 / -1 (profileCoverage, closed form)
+            // 1. intervals -> +1 / -1 (profileCoverage, closed form).  (Tried and measured slower: issuing the table
+            //    look-ups of all slots first and predicating only the two LDS adds -- more live state, more spills.)
             int covsum = 0;
             bool bad_any = false;
+            auto win = [&](unsigned n) -> int { return (int)(((n & win_m1) | __umulhi(n, a.div_magic)) >> win_sh); };
             auto one = [&](int rid, int st, int en) {
-                if (rid >= 0) {
-                    const int j = rid - r_a;
-                    const int b0 = tb.roff[j], nb_r = tb.roff[j + 1] - b0;
-                    const int first = (int)win_of(a, (unsigned)st);
-                    const int last1 = (int)win_of(a, (unsigned)(en - 1)) + 1;     // meaningful for en >= 1
-                    const bool sign_ok = (st | en) >= 0, pos = en > 0;
-                    const bool over = last1 > first && last1 > nb_r;               // repeat.hpp:69-72 writes past its vector
-                    const int pf = b0 + first, pl1 = b0 + min(last1, nb_r);
-                    bad_any |= !sign_ok || (pos && over);
-                    if (sign_ok && pos && pf < pl1) {
-                        __hip_atomic_fetch_add(&sm.diff[pf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&sm.diff[pl1], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        covsum += pl1 - pf;      // sum of coverage over the window == windows touched by its intervals
-                    }
+                const unsigned j = min((unsigned)(rid - r_a), (unsigned)nr);      // (an empty slot would read entry nr)
+                const int b0 = tb.roff[j], nb_r = tb.roff[j + 1] - b0;
+                const int first = win((unsigned)st);
+                const int last1 = win((unsigned)(en - 1)) + 1;                    // meaningful for en >= 1
+                const bool valid = rid >= 0, sign_ok = (st | en) >= 0, pos = en > 0;
+                const bool over = last1 > first && last1 > nb_r;                   // repeat.hpp:69-72 writes past its vector
+                const int pf = b0 + first, pl1 = b0 + min(last1, nb_r);
+                bad_any |= valid && (!sign_ok || (pos && over));
+                if (valid && sign_ok && pos && pf < pl1) {
+                    __hip_atomic_fetch_add(&sm.diff[pf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&sm.diff[pl1], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    covsum += pl1 - pf;          // sum of coverage over the window == windows touched by its intervals
                 }
             };
 #pragma unroll
-            for (int u = 0; u < U; ++u) one(g.rid[u], g.st[u], g.en[u]);
+            for (int u = 0; u < U; ++u) if (g.rid[u] >= 0) one(g.rid[u], g.st[u], g.en[u]);
             if (cur.more) {                      // intervals beyond the prefetched slots (dense tiles): synchronous loads
                 const TileCut d0 = cuts[k], d1 = cuts[k + 1];
 #pragma unroll
@@ -282,16 +280,32 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             // The other table set is free now (its tile's runs were emitted before the last barrier pair): publish
             // that tile's repeat counts, then stage the next tile's reads in it.
             publish_counts(1 - p, pub_r_a, pub_nr);
-            if (nxt.fast) nxt_off = stage_reads(1 - p, nxt, rdn);
+            if (nxt.fast) stage_reads(1 - p, nxt, rdn);
 
             // 3. pass B: prefix sum, store, run detection; each row is zeroed for the next tile once it is read
-            int carry = 0;
-            for (int w = 0; w < wid; ++w) carry += uni(sm.wsum[w]);
+            int carry;
+            {
+                const int4 ws = *reinterpret_cast<const int4 *>(&sm.wsum[0]);   // one LDS read, the same in every lane
+                const int w0 = uni(ws.x), w1 = uni(ws.y), w2 = uni(ws.z);
+                carry = (wid > 0 ? w0 : 0) + (wid > 1 ? w1 : 0) + (wid > 2 ? w2 : 0);
+            }
             bool hp = (wid > 0) && (row_b < rows) && (carry >= a.high_cov); // window before this wave's first slot is high
             const bool hp_in = hp;
             int S = hp ? kOpen : kNone;  // start slot of the run currently open
             int pclose = -1;             // slot at which the run inherited from before this wave closed
+            int nq = 0;                  // runs this wave has parked for emission
             const int full_b = (off0 + 255) >> 8, full_e = t_end >> 8;   // rows [full_b, full_e) hold valid slots only
+            // first slots of the tile's reads, two per lane (a run never continues across a read boundary,
+            // repeat.hpp:111-112); also used to find the owner of a parked run
+            const int ro0 = (lane < nr) ? tb.roff[lane] : 0x7fffffff;
+            const int ro1 = (lane + 64 < nr) ? tb.roff[lane + 64] : 0x7fffffff;
+            auto park = [&](int sS, int sT) {    // wave-uniform arguments
+                if ((long long)(sT - sS) * a.reso < (long long)a.repeat_length) return;   // repeat.hpp:125,150
+                if (nq < kRunQ) {
+                    if (lane == 0) { sm.runq[(wid * kRunQ + nq) * 2] = sS; sm.runq[(wid * kRunQ + nq) * 2 + 1] = sT; }
+                    ++nq;
+                } else if (lane == 0) emit_run(a, tb, nr, sS, sT);
+            };
 
             int4 dn = make_int4(0, 0, 0, 0);
             if (row_b < row_e) dn = *reinterpret_cast<const int4 *>(&sm.diff[row_b * 256 + lane * 4]);
@@ -325,52 +339,96 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                     M2 = __ballot(v2 && c2 >= a.high_cov); M3 = __ballot(v3 && c3 >= a.high_cov);
                 }
                 if ((M0 | M1 | M2 | M3) == 0ull && !hp) continue;   // the common case: no high window in the row
+                const unsigned long long RS0 = __ballot((ro0 >> 8) == row), RS1 = __ballot((ro1 >> 8) == row); // reads starting here
+                const bool tail = base + 256 > t_end;               // the row holds slots past the end of the tile
+                const unsigned long long A = M0 & M1 & M2 & M3;     // lanes whose four slots are all high
+                // a run passes through the whole row (all high, no read begins, no tile end)
+                if (hp && !tail && (RS0 | RS1) == 0ull && A == ~0ull) continue;
 
-                // ---- run scan of the row on its four >= high_cov ballots (scalar bit logic)
-                const unsigned long long VE0 = __ballot(p0 + 0 < t_end), VE1 = __ballot(p0 + 1 < t_end),
-                                         VE2 = __ballot(p0 + 2 < t_end), VE3 = __ballot(p0 + 3 < t_end);
-                const uint32_t word = sm.sbits[p][p0 >> 5];
-                const uint32_t nib = (word >> (p0 & 31)) & 0xFu;
-                const unsigned long long SB0 = __ballot(nib & 1u), SB1 = __ballot(nib & 2u),
-                                         SB2 = __ballot(nib & 4u), SB3 = __ballot(nib & 8u);
+                // ---- reads that begin in the row: their slots (SB_k), their lanes, the last of them
+                unsigned long long SB0 = 0ull, SB1 = 0ull, SB2 = 0ull, SB3 = 0ull, start_lanes = 0ull;
+                int last_start = -3;
+                auto mark_starts = [&](unsigned long long rs, int ro) {
+                    while (rs) {
+                        const int pos = __builtin_amdgcn_readlane(ro, (int)__builtin_ctzll(rs)) & 255;
+                        rs &= rs - 1ull;
+                        const unsigned long long bit = 1ull << (pos >> 2);
+                        const int sk = pos & 3;              // selects, not a 4-entry array (that would live in scratch)
+                        SB0 |= sk == 0 ? bit : 0ull; SB1 |= sk == 1 ? bit : 0ull; SB2 |= sk == 2 ? bit : 0ull; SB3 |= sk == 3 ? bit : 0ull;
+                        start_lanes |= bit;
+                        last_start = max(last_start, base + pos);
+                    }
+                };
+                mark_starts(RS0, ro0);
+                mark_starts(RS1, ro1);
+
+                // ---- most rows with high windows neither end nor could end a run long enough to be kept (coverage noise,
+                // the inside of a long run, the first part of one).  A kept run has Lmin = ceil(repeat_length / reso) >= 68
+                // windows, so the 16 lanes (of four slots) below the lane in which it ends are completely high and hold no
+                // read start; if it ends in the first 16 lanes of the row it came in from the previous row.  Rows without
+                // such an end only update the two facts later rows need: is the last slot high, and where did the run that
+                // is open there begin.
+                if (long_runs_only && !tail) {
+                    const unsigned long long Af = A & ~start_lanes;
+                    unsigned long long E = Af;               // E bit i: lanes i-15 .. i are full
+                    E &= E << 1; E &= E << 2; E &= E << 4; E &= E << 8;
+                    const unsigned long long ends = E & ~(Af >> 1) & 0x7fffffffffffffffull;   // full lanes, then one that is not
+                    const bool inherited_ends = hp && (Af & 0xffffull) != 0xffffull;
+                    if (ends == 0ull && !inherited_ends) {
+                        const bool open = (M3 >> 63) != 0ull;
+                        if (open) {                          // start of the run open at the end of the row
+                            int ns = hp ? -3 : base + ((row == 0) ? off0 : 0);
+                            unsigned long long z;
+                            z = ~M0; if (z) ns = max(ns, base + 4 * top_bit(z) + 1);
+                            z = ~M1; if (z) ns = max(ns, base + 4 * top_bit(z) + 2);
+                            z = ~M2; if (z) ns = max(ns, base + 4 * top_bit(z) + 3);
+                            z = ~M3; if (z) ns = max(ns, base + 4 * top_bit(z) + 4);
+                            S = max(S, max(ns, last_start));
+                        }
+                        hp = open;
+                        continue;
+                    }
+                }
+
+                // ---- exact run scan of the row: scalar bit logic on the four >= high_cov ballots
+                unsigned long long VE0 = ~0ull, VE1 = ~0ull, VE2 = ~0ull, VE3 = ~0ull;   // slot is inside the tile
+                if (tail) {
+                    VE0 = __ballot(p0 + 0 < t_end); VE1 = __ballot(p0 + 1 < t_end);
+                    VE2 = __ballot(p0 + 2 < t_end); VE3 = __ballot(p0 + 3 < t_end);
+                }
                 // P_k: the slot before (lane,k) is a high window; the carried-in bit belongs to the first valid slot:
                 // slot off0 of row 0, else slot 0 of the row
                 const unsigned long long hb = hp ? 1ull : 0ull;
                 const int hk = (row == 0) ? off0 : 0;
                 const unsigned long long P0 = (M3 << 1) | (hk == 0 ? hb : 0ull), P1 = M0 | (hk == 1 ? hb : 0ull),
                                          P2 = M1 | (hk == 2 ? hb : 0ull), P3 = M2 | (hk == 3 ? hb : 0ull);
-                const unsigned long long CL0 = P0 & (~M0 | SB0) & VE0, CL1 = P1 & (~M1 | SB1) & VE1,
-                                         CL2 = P2 & (~M2 | SB2) & VE2, CL3 = P3 & (~M3 | SB3) & VE3; // run ends before this slot
+                unsigned long long CL0 = P0 & (~M0 | SB0) & VE0, CL1 = P1 & (~M1 | SB1) & VE1,
+                                   CL2 = P2 & (~M2 | SB2) & VE2, CL3 = P3 & (~M3 | SB3) & VE3; // run ends before this slot
                 const unsigned long long CA0 = M0 & (~P0 | SB0), CA1 = M1 & (~P1 | SB1),
-                                         CA2 = M2 & (~P2 | SB2), CA3 = M3 & (~P3 | SB3);             // run starts at this slot
-                if ((CL0 | CL1 | CL2 | CL3) != 0ull) {
-                    const unsigned long long lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
-                    unsigned cl4 = (unsigned)((CL0 >> lane) & 1ull) | (unsigned)(((CL1 >> lane) & 1ull) << 1) |
-                                   (unsigned)(((CL2 >> lane) & 1ull) << 2) | (unsigned)(((CL3 >> lane) & 1ull) << 3);
-#pragma unroll 1
-                    while (cl4) {                        // rare: this lane sees the end of a run
-                        const int kk = __builtin_ctz(cl4);
-                        cl4 &= cl4 - 1u;
-                        int best = S;                    // latest run start at a slot before (lane, kk)
-                        unsigned long long m;
-                        m = CA0 & (0 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 0);
-                        m = CA1 & (1 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 1);
-                        m = CA2 & (2 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 2);
-                        m = CA3 & lt;                 if (m) best = max(best, base + 4 * top_bit(m) + 3);
-                        const int t = p0 + kk;
-                        if (best == kOpen) pclose = t;
-                        else if ((long long)(t - best) * a.reso >= (long long)a.repeat_length) { // repeat.hpp:125
-                            const int q = atomicAdd(&sm.runq_n[wid], 1);
-                            if (q < kRunQ) { sm.runq[(wid * kRunQ + q) * 2] = best; sm.runq[(wid * kRunQ + q) * 2 + 1] = t; }
-                            else emit_run(a, tb, nr, best, t);
-                        }
-                    }
+                                         CA2 = M2 & (~P2 | SB2), CA3 = M3 & (~P3 | SB3);       // run starts at this slot
+                unsigned long long any_cl = CL0 | CL1 | CL2 | CL3;
+                while (any_cl) {                         // ends of runs, in slot order (rarely more than one per row)
+                    const int l = (int)__builtin_ctzll(any_cl);
+                    const unsigned long long bl = 1ull << l, lt = bl - 1ull, le = lt | bl;
+                    int kk;
+                    if (CL0 & bl) { kk = 0; CL0 &= ~bl; } else if (CL1 & bl) { kk = 1; CL1 &= ~bl; }
+                    else if (CL2 & bl) { kk = 2; CL2 &= ~bl; } else { kk = 3; CL3 &= ~bl; }
+                    any_cl = CL0 | CL1 | CL2 | CL3;
+                    int best = S;                        // latest run start at a slot before (l, kk)
+                    unsigned long long m;
+                    m = CA0 & (0 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 0);
+                    m = CA1 & (1 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 1);
+                    m = CA2 & (2 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 2);
+                    m = CA3 & lt;                 if (m) best = max(best, base + 4 * top_bit(m) + 3);
+                    const int t = base + 4 * l + kk;
+                    if (best == kOpen) pclose = t;       // the inherited run: its start is known after the barrier
+                    else park(best, t);
                 }
                 if (CA0) S = max(S, base + 4 * top_bit(CA0) + 0);
                 if (CA1) S = max(S, base + 4 * top_bit(CA1) + 1);
                 if (CA2) S = max(S, base + 4 * top_bit(CA2) + 2);
                 if (CA3) S = max(S, base + 4 * top_bit(CA3) + 3);
-                if (base + 256 <= t_end) hp = (M3 >> 63) != 0ull;
+                if (!tail) hp = (M3 >> 63) != 0ull;
                 else if (t_end > base) {
                     const int tl = t_end - 1 - base; // last valid slot of the row
                     const unsigned long long Mk = (tl & 3) == 0 ? M0 : (tl & 3) == 1 ? M1 : (tl & 3) == 2 ? M2 : M3;
@@ -379,15 +437,9 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             }
 
             // 4. publish the wave's seam state
-            {
-                const unsigned long long pm = __ballot(pclose >= 0);
-                int pc = -1;
-                if (pm) pc = __builtin_amdgcn_readlane(pclose, (int)__builtin_ctzll(pm));
-                pclose = pc;
-                if (lane == 0) {
-                    *reinterpret_cast<int4 *>(&sm.wst[wid * 8]) = make_int4(row_e > row_b ? 1 : 0, pc, S, hp ? 1 : 0);
-                    sm.wst[wid * 8 + 4] = hp_in ? 1 : 0;
-                }
+            if (lane == 0) {
+                *reinterpret_cast<int4 *>(&sm.wst[wid * 8]) = make_int4(row_e > row_b ? 1 : 0, pclose, S, hp ? 1 : 0);
+                sm.wst[wid * 8 + 4] = hp_in ? 1 : 0;
             }
             RAFT_STAMP(5);
             lds_barrier();
@@ -408,43 +460,29 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                     }
                     return -1;
                 };
-                auto park = [&](int sS, int sT) {
-                    if (sS < 0 || (long long)(sT - sS) * a.reso < (long long)a.repeat_length) return;
-                    if (lane == 0) {
-                        const int q = atomicAdd(&sm.runq_n[wid], 1);
-                        if (q < kRunQ) { sm.runq[(wid * kRunQ + q) * 2] = sS; sm.runq[(wid * kRunQ + q) * 2 + 1] = sT; }
-                        else emit_run(a, tb, nr, sS, sT);
-                    }
-                };
                 if (row_e > row_b) {
-                    if (hp_in && pclose >= 0) park(run_start_before(wid - 1), pclose);
-                    if (row_e == rows && hp)             // this wave holds the last valid slot
-                        park((S != kOpen) ? S : (wid == 0 ? -1 : run_start_before(wid - 1)), t_end);
+                    if (hp_in && pclose >= 0) { const int b = run_start_before(wid - 1); if (b >= 0) park(b, pclose); }
+                    if (row_e == rows && hp) {           // this wave holds the last valid slot
+                        const int b = (S != kOpen) ? S : (wid == 0 ? -1 : run_start_before(wid - 1));
+                        if (b >= 0) park(b, t_end);
+                    }
                 }
             }
             RAFT_STAMP(11);
 
             // 6. every run this wave parked becomes a repeat record, one lane per run
-            {
-                const int nq = uni(sm.runq_n[wid]);
-                if (nq > 0) {
-                    const int m = min(nq, kRunQ);
-                    int sS = 0, sT = 0, j = 0;
-                    if (lane < m) { sS = sm.runq[(wid * kRunQ + lane) * 2]; sT = sm.runq[(wid * kRunQ + lane) * 2 + 1]; }
-                    if (nr <= 64) {
-                        const int ro = (lane < nr) ? tb.roff[lane] : 0x7fffffff;
+            if (nq > 0) {
+                int sS = 0, sT = 0, j = 0;
+                if (lane < nq) { sS = sm.runq[(wid * kRunQ + lane) * 2]; sT = sm.runq[(wid * kRunQ + lane) * 2 + 1]; }
+                // owner of each run: the number of reads that begin at or before its first slot (one compare + ballot)
 #pragma unroll 1
-                        for (int q = 0; q < m; ++q) {
-                            const int jq = __popcll(__ballot(ro <= __builtin_amdgcn_readlane(sS, q))) - 1;
-                            if (lane == q) j = jq;
-                        }
-                    } else if (lane < m) j = owner_slot(tb, nr, sS);
-                    if (lane < m) emit_run_of(a, tb, j, sS, sT);
-                    if (lane == 0) sm.runq_n[wid] = 0;
+                for (int q = 0; q < nq; ++q) {
+                    const int s0 = __builtin_amdgcn_readlane(sS, q);
+                    const int jq = __popcll(__ballot(ro0 <= s0)) + __popcll(__ballot(ro1 <= s0)) - 1;
+                    if (lane == q) j = jq;
                 }
+                if (lane < nq) emit_run_of(a, tb, j, sS, sT);
             }
-            // this tile's read-start bits go away (the set is next used two tiles from now, two barriers later)
-            if ((int)tid < nr) sm.sbits[p][cur_off >> 5] = 0u;
             RAFT_STAMP(13);
             pub_r_a = r_a; pub_nr = nr;          // counts are final once every wave is past its next barrier
         } else {
@@ -452,7 +490,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             lds_barrier();                       // the previous tile's runs are all emitted
             wait_all_loads();
             publish_counts(1 - p, pub_r_a, pub_nr);
-            if (nxt.fast) nxt_off = stage_reads(1 - p, nxt, rdn);
+            if (nxt.fast) stage_reads(1 - p, nxt, rdn);
             lds_barrier();
             pub_nr = 0;
         }
@@ -461,7 +499,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             sm.stamps[10] = __builtin_amdgcn_s_memrealtime();
             for (int i = 0; i < 16; ++i) a.dbg[k * 16 + i] = sm.stamps[i];
         }
-        k = kn; cur = nxt; g = gn; cur_off = nxt_off; p = 1 - p; raw_n = raw_nn;
+        k = kn; cur = nxt; g = gn; p = 1 - p; raw_n = raw_nn;
     }
     lds_barrier();                               // the last tile's runs are all emitted
     publish_counts(1 - p, pub_r_a, pub_nr);

@@ -57,11 +57,11 @@ __device__ __forceinline__ long long wave_reduce_add64(long long v)
     return v;
 }
 
+// Sum over the wave, returned in a scalar register: the DPP scan's last lane.  (An xor-shuffle tree costs six
+// dependent ds_bpermute round trips, ~600 cycles per call in the pileup kernels.)
 __device__ __forceinline__ int wave_reduce_add(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
-    return v;
+    return __builtin_amdgcn_readlane(wave_incl_scan_add(v), kWave - 1);
 }
 
 // Values that are the same in every lane but were fetched with vector loads (the compiler cannot prove the

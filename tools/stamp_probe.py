@@ -37,6 +37,7 @@ print(f"  4->15 vmcnt(0) before pass B  median {np.median(w):8.0f} mean {w.mean(
 sub = np.stack([st[:, 11] - st[:, 6], st[:, 13] - st[:, 11]], 1)
 for n, c in zip(["  6->11 resolve seams", "  11->13 emit parked runs"], sub.T):
     print(f"{n:28s} median {np.median(c):8.0f} mean {c.mean():8.0f}")
+print(f"tiles with intervals beyond the prefetched slots: {(st[:, 12] != 0).mean():.3f}")
 rt = (st[:, 10] - st[:, 9])
 print("memtime ticks per 100MHz realtime tick:", np.median(life[rt > 0] / rt[rt > 0]))
 # concurrency: kernel span vs sum of lifetimes
