@@ -176,7 +176,8 @@ def main():
                        "interval_path": "sorted-segments" if s.interval_path == 0 else "counting-sort",
                        "segments": s.n_segments, "sharding": f"reads x{n_gpus}, no data-path collective" + (", ranks share GPUs (gloo check run)" if world > 1 and n_dev < world else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "pileup_kernel" + ("" if args.variant < 0 else f" variant {args.variant}"),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": ("pileup_fast_kernel (+ pileup_kernel for the tiles it leaves)" if args.variant != 1 else "pileup_kernel")
+                                   + ("" if args.variant < 0 else f" variant {args.variant}"),
                          "kernel_ms": pile * 1e3, "bytes_algorithmic": bytes_alg,
                          "pass_device_ms": sum(pass_t) / len(pass_t) * 1e3},
         }

@@ -209,3 +209,80 @@ def test_full_size_properties(eng_mod):
              total_repeat_length=s.total_repeat_length, total_read_length=s.total_read_length)
     assert_same_result(a, want, "S50k")
     eng.close()
+
+
+# ---- the paths of pileup_fast_kernel (variant 0/2/3) next to the general kernel (variant 1) ---------------------
+
+def _sym_case(rl, qid, s, e, rng):
+    """Symmetric record set from query-side intervals: record 1 mirrors record 0, targets are arbitrary other reads."""
+    n = len(rl)
+    tid = ((qid.astype(np.int64) + 1 + rng.integers(0, max(n - 1, 1), len(qid))) % n).astype(np.int32)
+    ts, te = np.zeros_like(s), np.minimum(rl[tid], 1).astype(np.int32)
+    cols = [np.asarray(a, np.int32) for a in (qid, s, e, tid, ts, te)]
+    # mirror of record 0 placed at position 1 (chop.hpp:175-184), kept consistent with the sorted order by choosing
+    # the mirror's query (= record 0's target) freely: it only has to exist
+    q0, s0, e0, t0, ts0, te0 = (int(c[0]) for c in cols)
+    mir = [t0, ts0, te0, q0, s0, e0]
+    return [np.insert(c, 1, v).astype(np.int32) for c, v in zip(cols, mir)]
+
+
+def _intervals(rl, ids, rng, frac=1.0):
+    ln = rl[ids].astype(np.int64)
+    a = (rng.random(len(ids)) * ln).astype(np.int64)
+    b = np.minimum(ln, a + 1 + (rng.random(len(ids)) * ln * frac).astype(np.int64))
+    return a.astype(np.int32), b.astype(np.int32)
+
+
+def _fast_kernel_cases():
+    rng = np.random.default_rng(77)
+    cases = {}
+    # (a) very many tiny reads per tile (more than the fast kernel's table holds) between ordinary reads
+    rl = np.concatenate([rng.integers(2000, 30000, 40), rng.integers(60, 400, 1500), rng.integers(2000, 30000, 40)]).astype(np.int32)
+    qid = np.sort(rng.integers(0, len(rl), 30000)).astype(np.int32)
+    s, e = _intervals(rl, qid, rng)
+    cases["tiny_reads"] = (RaftParams(est_cov=8), [rl] + _sym_case(rl, qid, s, e, rng))
+    # (b) dense tiles: far more intervals per tile and sorted run than the prefetch slots hold
+    rl = rng.integers(20000, 40000, 60).astype(np.int32)
+    parts = [np.sort(rng.integers(0, len(rl), 40000)) for _ in range(2)]
+    qid = np.concatenate(parts).astype(np.int32)
+    s, e = _intervals(rl, qid, rng, 0.3)
+    cases["dense_two_runs"] = (RaftParams(est_cov=100), [rl] + _sym_case(rl, qid, s, e, rng))
+    # (c) one sorted run / four sorted runs (other instantiations of the kernel)
+    rl = rng.integers(5000, 60000, 300).astype(np.int32)
+    for name, k in (("one_run", 1), ("several_runs", 3)):   # the inserted mirror may add a run: still at most four
+        qid = np.concatenate([np.sort(rng.integers(0, len(rl), 6000)) for _ in range(k)]).astype(np.int32)
+        s, e = _intervals(rl, qid, rng, 0.6)
+        cols = _sym_case(rl, qid, s, e, rng)
+        if k == 1:                                   # keep the stream one ascending run: the mirror goes where it sorts
+            o = np.argsort(cols[0][1:], kind="stable") + 1
+            cols = [np.concatenate([c[:1], c[o]]) for c in cols]
+            if cols[0][1] < cols[0][0]: cols = None
+        if cols is not None: cases[name] = (RaftParams(est_cov=20), [rl] + cols)
+    # (d) reads longer than the LDS window in the middle of ordinary ones (default reso: > 307 kb)
+    rl = rng.integers(8000, 30000, 120).astype(np.int32)
+    rl[[17, 60, 61]] = [450000, 330000, 900000]
+    qid = np.concatenate([np.sort(rng.integers(0, len(rl), 9000)) for _ in range(2)]).astype(np.int32)
+    s, e = _intervals(rl, qid, rng, 0.5)
+    cases["long_reads_between"] = (RaftParams(est_cov=25), [rl] + _sym_case(rl, qid, s, e, rng))
+    # (e) long runs across rows, waves and tiles with read starts inside them: every window high
+    rl = rng.integers(9000, 45000, 200).astype(np.int32)
+    qid = np.sort(np.repeat(np.arange(len(rl)), 12)).astype(np.int32)
+    s = np.zeros(len(qid), np.int32); e = rl[qid].astype(np.int32)
+    drop = rng.random(len(qid)) < 0.15                        # thin the coverage in places: runs end and begin
+    s[drop] = (rl[qid[drop]] * 0.4).astype(np.int32); e[drop] = (rl[qid[drop]] * 0.6).astype(np.int32)
+    cases["all_high"] = (RaftParams(est_cov=6), [rl] + _sym_case(rl, qid, s, e, rng))
+    return cases
+
+
+FAST_CASES = _fast_kernel_cases()
+
+
+@pytest.mark.parametrize("variant", range(4))
+@pytest.mark.parametrize("name", sorted(FAST_CASES))
+def test_fast_kernel_paths(eng_mod, name, variant):
+    p, cols = FAST_CASES[name]
+    want = oracle_run(p, *cols)
+    got, s = run_engine(eng_mod, p, cols, variant=variant)
+    assert_same_result(got, want, f"{name}/variant {variant}")
+    assert s.symmetric == 1 and s.interval_path == 0          # the sorted-segment path, i.e. the kernels under test
+    if name == "all_high": assert want["rep_s"].size > 50     # the case does produce long repeats

@@ -13,11 +13,13 @@ python3 - <<PY
 import csv, glob, json, collections
 tag = "$TAG"
 def pileup_mean(d, counter):
-    v = []
+    # per pass: pileup_fast_kernel + the general pileup_kernel that walks the remaining tiles (means per launch, summed)
+    v = collections.defaultdict(list)
     for f in glob.glob(f"gpurun_out/{tag}/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "pileup_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter: v.append(float(r["Counter_Value"]))
-    return sum(v) / len(v) if v else None
+            if "pileup" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                v["fast" if "pileup_fast" in r["Kernel_Name"] else "general"].append(float(r["Counter_Value"]))
+    return sum(sum(x) / len(x) for x in v.values()) if v else None
 fetch, write = pileup_mean("pmc_fetch", "FETCH_SIZE"), pileup_mean("pmc_write", "WRITE_SIZE")
 print("FETCH_SIZE", fetch, "WRITE_SIZE", write)
 b = json.load(open(f"gpurun_out/{tag}/bench.json"))
@@ -26,7 +28,7 @@ if fetch is not None and write is not None:
     traffic = (2 * fetch + write) * 1024
     json.dump({"hbm_bytes_per_launch": traffic, "fetch_size_kib": fetch, "write_size_kib": write,
                "records_per_gpu": b["config"]["records_per_gpu"],
-               "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), pileup_kernel mean per launch; "
+               "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), pileup_fast_kernel + pileup_kernel, means per launch summed; "
                          f"bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section; profiles/{tag}_pmc_traffic.json"},
               open(f"gpurun_out/{tag}/pmc_traffic.json", "w"), indent=1)
     print("traffic bytes", traffic, "algorithmic", b["roofline"]["bytes_algorithmic"])
