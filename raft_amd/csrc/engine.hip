@@ -354,7 +354,15 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     long long *h = reinterpret_cast<long long *>(c->pinned);
     HIP_TRY(c, hipMemcpyAsync(h, scan_totals, 3 * sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(h + 4, ctrl, 16, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));                                   // wait #1: sizes
+    // ---- look at the record stream in the same trip: symmetric PAF? sorted runs? ids in range?
+    InspectOut *hi = reinterpret_cast<InspectOut *>(h + 8);
+    if (n_rec > 0) {
+        const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((n_rec / 4 + 255) / 256, 256 * 8));
+        hipLaunchKernelGGL(inspect_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads,
+                           c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
+        HIP_TRY(c, hipMemcpyAsync(hi, &ctrl->insp, sizeof(InspectOut), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));                                   // the pass's only host wait: sizes + path choice
     const long long B = h[0], RU = h[1], CU = h[2];
     {
         const int32_t flags = reinterpret_cast<int32_t *>(h + 4)[0];
@@ -403,17 +411,10 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     hipLaunchKernelGGL(tile_first_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, st, n_reads,
                        c->cov_off.as<long long>(), Q, n_tiles, c->tile_first.as<int32_t>());
 
-    // ---- look at the record stream: symmetric PAF? sorted runs? ids in range?
     int symmetric = c->prm.symmetric_mode == 1 ? 1 : 0;
     int n_desc = 0;
     long long desc[kMaxSeg];
     if (n_rec > 0) {
-        const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((n_rec / 4 + 255) / 256, 256 * 8));
-        hipLaunchKernelGGL(inspect_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads,
-                           c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
-        InspectOut *hi = reinterpret_cast<InspectOut *>(h + 8);
-        HIP_TRY(c, hipMemcpyAsync(hi, &ctrl->insp, sizeof(InspectOut), hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));                               // wait #2: path choice
         if (hi->err_flags) {
             c->pending_err = code_from_flags(hi->err_flags);
             c->pending_err_index = hi->err_index;
@@ -547,7 +548,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
         HIP_TRY(c, hipMemsetAsync(c->frag_off.p, 0, 8, st));
     }
     {
-        const unsigned g = (unsigned)std::min<long long>((std::max(n_tiles, N) + 255) / 256, 1024);
+        const unsigned g = (unsigned)std::min<long long>((std::max(n_tiles, N) + 255) / 256, 512);
         hipLaunchKernelGGL(totals_kernel, dim3(std::max(g, 1u)), dim3(256), 0, st, (long long)n_sum_blocks, c->block_sums.as<long long>(),
                            n_reads, d_len, ctrl->totals);
     }

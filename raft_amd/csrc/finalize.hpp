@@ -138,20 +138,25 @@ __global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
     }
 }
 
-// totals[0] = sum coverage, [1] = sum unclamped repeat bp, [2] = sum read length
+// totals[0] = sum coverage, [1] = sum unclamped repeat bp, [2] = sum read length.  One atomic per workgroup and
+// total (a few hundred per launch): with one per wave the three counters saw 12 k serialised atomics and the kernel
+// took 56 us for 13 MB of input.
 __global__ __launch_bounds__(256) void totals_kernel(long long n_tiles, const long long *tile_sums, int32_t n_reads,
                                                      const int32_t *read_len, unsigned long long *totals)
 {
+    __shared__ long long part[3][4];
     long long c = 0, rp = 0, l = 0;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (long long i = i0; i < n_tiles; i += stride) { c += tile_sums[2 * i]; rp += tile_sums[2 * i + 1]; }
     for (long long i = i0; i < n_reads; i += stride) l += read_len[i];
     c = wave_reduce_add64(c); rp = wave_reduce_add64(rp); l = wave_reduce_add64(l);
-    if ((threadIdx.x & 63) == 0) {
-        if (c) atomicAdd(&totals[0], (unsigned long long)c);
-        if (rp) atomicAdd(&totals[1], (unsigned long long)rp);
-        if (l) atomicAdd(&totals[2], (unsigned long long)l);
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[0][wid] = c; part[1][wid] = rp; part[2][wid] = l; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const long long v = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+        if (v) atomicAdd(&totals[threadIdx.x], (unsigned long long)v);
     }
 }
 

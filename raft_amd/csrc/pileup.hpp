@@ -746,30 +746,66 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
         d.r_lo = d.r_hi = tile_first[k];
         d.g_lo = d.g_hi = cov_off[d.r_lo];
     }
+    // A tile's interval range ends where the next tile's begins: every lane takes that from its neighbour (the last
+    // lane of a wave searches for its own end as well).  The kernel's time is the chain of dependent probes (~1.3 us
+    // each into a GB-sized array), so all bisections of a thread advance together: each round issues the probes of
+    // every segment -- and of the own-end searches -- back to back and only then looks at them.
+    const bool own_end = live && lane == 63;
+    long long blo[2 * kMaxSeg], bhi[2 * kMaxSeg];
 #pragma unroll
     for (int s = 0; s < kMaxSeg; ++s) {
-        long long lo = 0, hi = 0;
+        blo[s] = bhi[s] = blo[kMaxSeg + s] = bhi[kMaxSeg + s] = 0;
         if (s < sb.n_seg) {                         // uniform
-            long long b = sb.start[s], e = sb.start[s + 1];
-            if (seg_end_dev) e = *seg_end_dev;
-            if (edge) lo = lower_bound_rid(iv_rid, b, e, d.r_lo);
-            hi = __shfl_down(lo, 1, kWave);
-            if (live && lane == 63) hi = lower_bound_rid(iv_rid, b, e, d.r_hi);
+            const long long seg_e = seg_end_dev ? *seg_end_dev : sb.start[s + 1];
+            if (edge) { blo[s] = sb.start[s]; bhi[s] = seg_e; }
+            if (own_end) { blo[kMaxSeg + s] = sb.start[s]; bhi[kMaxSeg + s] = seg_e; }
         }
+    }
+    for (;;) {
+        int v[2 * kMaxSeg];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 2 * kMaxSeg; ++q) {
+            v[q] = 0;
+            if (blo[q] < bhi[q]) { v[q] = iv_rid[(blo[q] + bhi[q]) >> 1]; any = true; }
+        }
+        if (!any) break;
+#pragma unroll
+        for (int q = 0; q < 2 * kMaxSeg; ++q) {
+            if (blo[q] < bhi[q]) {
+                const long long mid = (blo[q] + bhi[q]) >> 1;
+                if (v[q] < (q < kMaxSeg ? d.r_lo : d.r_hi)) blo[q] = mid + 1; else bhi[q] = mid;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < kMaxSeg; ++s) {
+        const long long lo = blo[s];
+        long long hi = __shfl_down(lo, 1, kWave);
+        if (own_end) hi = blo[kMaxSeg + s];
         d.iv_lo[s] = lo;
         d.n_iv[s] = (int)(hi - lo);
     }
-    if (live) td[k] = d;
+    const int nr = d.r_hi - d.r_lo;
+    const long long nwin = d.g_hi - d.g_lo;
+    const bool fast = cuts && live && nr >= 1 && nr <= fast_max_reads && nwin > 0 && nwin <= fast_cap;
+    if (live && !fast) td[k] = d;                   // the general kernel only looks at the tiles the fast one leaves
     if (cuts && edge) {
-        const int nr = d.r_hi - d.r_lo;
-        const long long nwin = d.g_hi - d.g_lo;
-        const bool fast = live && nr >= 1 && nr <= fast_max_reads && nwin > 0 && nwin <= fast_cap;
         TileCut c;
         c.r_lo = d.r_lo; c.flags = fast ? kCutFast : 0; c.g_lo = d.g_lo;
 #pragma unroll
         for (int s = 0; s < kMaxSeg; ++s) c.iv_lo[s] = (int32_t)d.iv_lo[s];
         cuts[k] = c;
-        if (live && nr >= 1 && !fast) slow_list[atomicAdd(n_slow, 1)] = (int32_t)k;
+    }
+    // tiles left to the general kernel: one append per wave (one atomic per tile on the same word serialises)
+    const bool slow = cuts && live && nr >= 1 && !fast;
+    const unsigned long long sm = __ballot(slow);
+    if (sm) {
+        const int leader = (int)__builtin_ctzll(sm);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(n_slow, (int)__popcll(sm));
+        base = __shfl(base, leader, kWave);
+        if (slow) slow_list[base + (int)__popcll(sm & ((1ull << lane) - 1ull))] = (int32_t)k;
     }
 }
 
