@@ -44,9 +44,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(Loader ld, 
     long long acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0;
-    long long i0 = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+    // only the block total matters here, so the elements are taken striped: coalesced loads
+    const long long block0 = (long long)blockIdx.x * kScanTile;
+#pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
-        long long i = i0 + j;
+        const long long i = block0 + j * kScanThreads + threadIdx.x;
         if (i < n) {
             long long v[K];
             ld(i, v);
@@ -92,11 +94,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, lon
                                                                   const long long *totals, ScanOut<K> out)
 {
     __shared__ long long lds[kScanThreads / 64 + 1];
+    __shared__ long long stage[kScanTile];      // blocked -> striped, so that the stores are coalesced
     long long v[kScanItems][K];
     long long acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0;
-    long long i0 = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+    const long long block0 = (long long)blockIdx.x * kScanTile;
+    long long i0 = block0 + (long long)threadIdx.x * kScanItems;
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
         long long i = i0 + j;
@@ -114,10 +118,16 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, lon
         long long run = partials[(long long)blockIdx.x * K + k] + block_excl_scan64<kScanThreads>(acc[k], &tot, lds);
 #pragma unroll
         for (int j = 0; j < kScanItems; ++j) {
-            long long i = i0 + j;
-            if (i < n) out.p[k][i] = run;
+            stage[threadIdx.x * kScanItems + j] = run;
             run += v[j][k];
         }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) {
+            const long long i = block0 + j * kScanThreads + threadIdx.x;
+            if (i < n) out.p[k][i] = stage[j * kScanThreads + threadIdx.x];
+        }
+        __syncthreads();
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
 #pragma unroll

@@ -98,7 +98,22 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
     const int n = a.rep_cnt[r];
     const long long base = a.rep_res_off[r];
     if (n > 1) sort_repeats(a.raw_key + base, a.raw_s + base, a.raw_e + base, n);
-    const int nF = walk_cuts(a.read_len[r], a.interval_length, a.raw_s + base, a.raw_e + base, n, [](int) {});
+    // Number of markers walk_cuts() keeps, without walking them: the interior markers are L, 2L, .., J*L; a flanked
+    // repeat [s,e] covers the multiples of L inside it; repeats are ordered by start and by end, so the union is
+    // counted in one sweep over the read's (few) repeats.
+    const int len = a.read_len[r], L = a.interval_length;
+    const int parts = len / L;
+    const int tail = (len % L) ? 1 : 0;
+    const int J = tail ? parts : parts - 1;       // last interior marker is J * L
+    int covered = 0, done = 0;                    // multiples 1 .. done are accounted for
+    for (int k = 0; k < n && done < J; ++k) {
+        const int s = a.raw_s[base + k], e = a.raw_e[base + k];
+        int lo = s <= 0 ? 0 : (s + L - 1) / L;
+        lo = max(lo, done + 1);
+        const int hi = e < 0 ? -1 : min(e / L, J);
+        if (hi >= lo) { covered += hi - lo + 1; done = hi; }
+    }
+    const int nF = parts + 1 + tail - covered;
     int nf = 1;                                   // chop.hpp:250-276
     if (nF > a.div + 1) nf = (nF - 1 + a.div - 1) / a.div;
     a.cut_cnt[r] = nF;

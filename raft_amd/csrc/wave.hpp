@@ -39,22 +39,33 @@ __device__ __forceinline__ int wave_incl_scan_add_shfl(int v)
     return v;
 }
 
+// 64-bit inclusive scan: the same six DPP steps on (low, high) dword pairs (a shuffle version costs twelve
+// ds_bpermute round trips per call)
 __device__ __forceinline__ long long wave_incl_scan_add64(long long v)
 {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        long long o = __shfl_up(v, d, kWave);
-        if (lane >= d) v += o;
+    unsigned long long x = (unsigned long long)v;
+#define RAFT_DPP64_STEP(ctrl, rows)                                                                          \
+    {                                                                                                        \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)x, ctrl, rows, 0xf, false);          \
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), ctrl, rows, 0xf, false);  \
+        x += ((unsigned long long)hi << 32) | lo;                                                            \
     }
-    return v;
+    RAFT_DPP64_STEP(0x111, 0xf) // row_shr:1
+    RAFT_DPP64_STEP(0x112, 0xf) // row_shr:2
+    RAFT_DPP64_STEP(0x114, 0xf) // row_shr:4
+    RAFT_DPP64_STEP(0x118, 0xf) // row_shr:8
+    RAFT_DPP64_STEP(0x142, 0xa) // row_bcast:15 into rows 1,3
+    RAFT_DPP64_STEP(0x143, 0xc) // row_bcast:31 into rows 2,3
+#undef RAFT_DPP64_STEP
+    return (long long)x;
 }
 
 __device__ __forceinline__ long long wave_reduce_add64(long long v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
-    return v;
+    const long long s = wave_incl_scan_add64(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)s, kWave - 1);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)s >> 32), kWave - 1);
+    return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
 // Sum over the wave, returned in a scalar register: the DPP scan's last lane.  (An xor-shuffle tree costs six
