@@ -124,8 +124,11 @@ void *raft_hip_get_stream(raft_hip_ctx *ctx);
 /* One pass of the hot path over inputs that already live in device memory
  * (int32 SoA columns, 4-byte aligned; read ids are FASTA indices).  Enqueues
  * every kernel; returns after the last launch, not after completion.  It waits
- * for the device twice on the way (sizes of the coverage array, choice of
- * interval path), which is part of the cost of a pass. */
+ * for the device once on the way (sizes of the coverage array and choice of
+ * interval path come back together), which is part of the cost of a pass.
+ * d_read_len must stay valid until the outputs have been fetched: the cut points
+ * (chop.hpp's final_stars) are materialised by the first raft_hip_fetch() /
+ * raft_hip_outputs_device() that asks for them, not by the pass. */
 int  raft_hip_run_device(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *d_read_len,
                          int64_t n_rec, const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
                          const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te);

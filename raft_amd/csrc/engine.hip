@@ -161,6 +161,8 @@ struct raft_hip_ctx {
     long long pending_err_index = -1;
     raft_hip_summary sum{};
     long long cap_rep = 0, cap_cut = 0;
+    FinalizeArgs fa{};                // of the last pass (the cut points are materialised on demand)
+    bool cuts_ready = false;
 };
 
 namespace {
@@ -550,8 +552,13 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     {
         const unsigned g = (unsigned)std::min<long long>((std::max(n_tiles, N) + 255) / 256, 512);
         hipLaunchKernelGGL(totals_kernel, dim3(std::max(g, 1u)), dim3(256), 0, st, (long long)n_sum_blocks, c->block_sums.as<long long>(),
-                           n_reads, d_len, ctrl->totals);
+                           n_reads, d_len, ctrl->totals, c->rep_off.as<long long>(), c->cut_off.as<long long>(),
+                           c->frag_off.as<long long>(), c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr,
+                           ctrl->out_totals);
     }
+    // everything finish() reports travels in one block, copied while the stream drains
+    HIP_TRY(c, hipMemcpyAsync(reinterpret_cast<char *>(c->pinned) + 1024, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+    c->fa = fa; c->cuts_ready = false;
     HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
@@ -589,16 +596,9 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->pending_err == RAFT_HIP_OK) {
             Ctrl hc;
-            HIP_TRY(c, hipMemcpy(&hc, c->ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost));
-            const long long N = c->sum.n_reads;
-            long long tails[4] = {0, 0, 0, 0};
-            HIP_TRY(c, hipMemcpy(&tails[0], c->rep_off.as<long long>() + N, 8, hipMemcpyDeviceToHost));
-            HIP_TRY(c, hipMemcpy(&tails[1], c->cut_off.as<long long>() + N, 8, hipMemcpyDeviceToHost));
-            HIP_TRY(c, hipMemcpy(&tails[2], c->frag_off.as<long long>() + N, 8, hipMemcpyDeviceToHost));
-            if (c->sum.interval_path == 1)
-                HIP_TRY(c, hipMemcpy(&tails[3], c->b_off.as<long long>() + N, 8, hipMemcpyDeviceToHost));
-            c->sum.n_repeats = tails[0]; c->sum.n_cuts = tails[1]; c->sum.n_fragments = tails[2];
-            if (c->sum.interval_path == 1) c->sum.n_intervals = tails[3];
+            memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));   // copied at the end of the pass
+            c->sum.n_repeats = hc.out_totals[0]; c->sum.n_cuts = hc.out_totals[1]; c->sum.n_fragments = hc.out_totals[2];
+            if (c->sum.interval_path == 1) c->sum.n_intervals = hc.out_totals[3];
             c->sum.total_coverage = (long long)hc.totals[0];
             c->sum.total_repeat_length = (long long)hc.totals[1];
             c->sum.total_read_length = (long long)hc.totals[2];
@@ -614,10 +614,26 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
     return c->pending_err;
 }
 
+// The cut points (one int per kept marker, 0.4 GB at human scale) are not written by the pass: the fragments are
+// derived while the markers are walked.  The first caller that asks for them pays for one more per-read kernel.
+static int materialise_cuts(raft_hip_ctx *c)
+{
+    if (c->cuts_ready) return RAFT_HIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->sum.n_reads > 0) {
+        hipLaunchKernelGGL(finalize_cuts_kernel, dim3((unsigned)((c->sum.n_reads + 255) / 256)), dim3(256), 0, c->stream, c->fa);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->cuts_ready = true;
+    return RAFT_HIP_OK;
+}
+
 int raft_hip_outputs_device(raft_hip_ctx *c, raft_hip_outputs *o)
 {
     if (!c || !o) return RAFT_HIP_ERR_PARAM;
     if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
+    { const int rc = materialise_cuts(c); if (rc != RAFT_HIP_OK) return rc; }
     o->cov_offset = c->cov_off.as<int64_t>(); o->cov = c->cov.as<int32_t>();
     o->rep_offset = c->rep_off.as<int64_t>(); o->rep_s = c->rep_s.as<int32_t>(); o->rep_e = c->rep_e.as<int32_t>();
     o->cut_offset = c->cut_off.as<int64_t>(); o->cuts = c->cuts.as<int32_t>();
@@ -633,6 +649,7 @@ int raft_hip_fetch(raft_hip_ctx *c, int64_t *cov_offset, int32_t *cov, int64_t *
     if (!c) return RAFT_HIP_ERR_PARAM;
     if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (cuts) { const int rc = materialise_cuts(c); if (rc != RAFT_HIP_OK) return rc; }
     const size_t N1 = (size_t)c->sum.n_reads + 1;
     struct { void *dst; const void *src; size_t bytes; } job[] = {
         {cov_offset, c->cov_off.p, N1 * 8}, {cov, c->cov.p, (size_t)c->sum.n_bins * 4},

@@ -120,6 +120,10 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
     a.frag_cnt[r] = nf;
 }
 
+// Compact repeats and the fragments of every read.  The cut points themselves (chop.hpp's final_stars, 4 B per
+// marker: 0.4 GB on the human-scale set) are neither stored nor walked here: fragment j begins at the kept marker
+// with index (j-1)*div and ends at the one with index j*div, the first marker is 0 and the last is the read length.
+// finalize_cuts_kernel materialises them when a caller asks for them.
 __global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,37 +132,69 @@ __global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
     const long long base = a.rep_res_off[r];
     const long long ro = a.rep_off[r];
     for (int i = 0; i < n; ++i) { a.rep_s[ro + i] = a.raw_s[base + i]; a.rep_e[ro + i] = a.raw_e[base + i]; }
-    const long long co = a.cut_off[r];
     const int len = a.read_len[r];
-    int32_t *F = a.cuts + co;
-    int w = 0;
-    const int nF = walk_cuts(len, a.interval_length, a.raw_s + base, a.raw_e + base, n, [&](int m) { F[w++] = m; });
+    const int nF = a.cut_cnt[r];
     const long long fo = a.frag_off[r];
     if (nF <= a.div + 1) {                        // chop.hpp:250-267: the read is kept whole
         a.frag_read[fo] = r; a.frag_begin[fo] = 0; a.frag_end[fo] = len;
         return;
     }
-    const int nf = (nF - 1 + a.div - 1) / a.div;
-    int pos = 0;
-    for (int j = 1; j <= nf; ++j) {               // chop.hpp:280-321
-        const int ovl = (j == 1) ? 0 : a.overlap_length;
-        const int last = (j == nf) ? F[nF - 1] : F[pos + a.div];
-        const int begin = F[pos] - ovl;
+    const int nf = (nF - 1 + a.div - 1) / a.div;  // chop.hpp:280-321
+    // Fragment j ends, and fragment j + 1 begins, at the kept marker with index t = j * div (an interior marker).
+    // Without repeats that is the multiple t * L; each flanked repeat removes the multiples inside it, so the t-th kept
+    // multiple is found by skipping the covered ranges in order (the same sweep as in finalize_count_kernel).
+    const int L = a.interval_length;
+    const int parts = len / L;
+    const int J = (len % L) ? parts : parts - 1;
+    a.frag_read[fo] = r; a.frag_begin[fo] = 0;
+    for (int j = 1; j < nf; ++j) {
+        int v = j * a.div, done = 0;
+        for (int k = 0; k < n && done < J; ++k) {
+            const int s = a.raw_s[base + k], e = a.raw_e[base + k];
+            int lo = s <= 0 ? 0 : (s + L - 1) / L;
+            lo = max(lo, done + 1);
+            const int hi = e < 0 ? -1 : min(e / L, J);
+            if (hi >= lo) {
+                if (v < lo) break;
+                v += hi - lo + 1;
+                done = hi;
+            }
+        }
+        const int m = v * L;
+        const int begin = m - a.overlap_length;
         if (begin < 0 || begin > len) {
             atomicOr(a.err_flags, kErrFragment);
             atomicMin((unsigned long long *)a.err_index, (unsigned long long)r);
         }
-        a.frag_read[fo + j - 1] = r; a.frag_begin[fo + j - 1] = begin; a.frag_end[fo + j - 1] = last;
-        pos += a.div;
+        a.frag_end[fo + j - 1] = m;
+        a.frag_read[fo + j] = r; a.frag_begin[fo + j] = begin;
     }
+    a.frag_end[fo + nf - 1] = len;                // the last kept marker is the read's end
+}
+
+// cut points of every read (final_stars), on demand
+__global__ __launch_bounds__(256) void finalize_cuts_kernel(FinalizeArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    int32_t *F = a.cuts + a.cut_off[r];
+    int w = 0;
+    (void)walk_cuts(a.read_len[r], a.interval_length, a.raw_s + a.rep_res_off[r], a.raw_e + a.rep_res_off[r], a.rep_cnt[r],
+                    [&](int m) { F[w++] = m; });
 }
 
 // totals[0] = sum coverage, [1] = sum unclamped repeat bp, [2] = sum read length.  One atomic per workgroup and
 // total (a few hundred per launch): with one per wave the three counters saw 12 k serialised atomics and the kernel
 // took 56 us for 13 MB of input.
 __global__ __launch_bounds__(256) void totals_kernel(long long n_tiles, const long long *tile_sums, int32_t n_reads,
-                                                     const int32_t *read_len, unsigned long long *totals)
+                                                     const int32_t *read_len, unsigned long long *totals,
+                                                     const long long *rep_off, const long long *cut_off,
+                                                     const long long *frag_off, const long long *bucket_off, long long *tails)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {    // output sizes, so that the host reads one block back
+        tails[0] = rep_off[n_reads]; tails[1] = cut_off[n_reads]; tails[2] = frag_off[n_reads];
+        tails[3] = bucket_off ? bucket_off[n_reads] : 0;
+    }
     __shared__ long long part[3][4];
     long long c = 0, rp = 0, l = 0;
     const long long stride = (long long)gridDim.x * blockDim.x;
