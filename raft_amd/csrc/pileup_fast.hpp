@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             int pclose = -1;             // slot at which the run inherited from before this wave closed
             int nq = 0;                  // runs this wave has parked for emission
             const int full_b = (off0 + 255) >> 8, full_e = t_end >> 8;   // rows [full_b, full_e) hold valid slots only
+            const uint32_t partial_rows = ((1u << full_b) - 1u) | ~((1u << full_e) - 1u);   // at most 25 rows
             // first slots of the tile's reads, two per lane (a run never continues across a read boundary,
             // repeat.hpp:111-112); also used to find the owner of a parked run
             const int ro0 = (lane < nr) ? tb.roff[lane] : 0x7fffffff;
@@ -312,7 +313,9 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             for (int row = row_b; row < row_e; ++row) {
                 const int base = row * 256, p0 = base + lane * 4;
                 const int4 d = dn;
-                if (row + 1 < row_e) dn = *reinterpret_cast<const int4 *>(&sm.diff[p0 + 256]);
+                // the next row, unconditionally: past the wave's last row this reads a row another wave owns (or the
+                // tables behind the array) and the value is never used
+                dn = *reinterpret_cast<const int4 *>(&sm.diff[p0 + 256]);
                 *reinterpret_cast<int4 *>(&sm.diff[p0]) = make_int4(0, 0, 0, 0);
                 // prefix sum of the row's 256 slots
                 const int x = d.x, y = x + d.y, z = y + d.z, w = z + d.w;
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 carry += __builtin_amdgcn_readlane(incl, 63);
                 const int c0 = excl + x, c1 = excl + y, c2 = excl + z, c3 = excl + w;
                 unsigned long long M0, M1, M2, M3;
-                if (row >= full_b && row < full_e) {
+                if (((partial_rows >> row) & 1u) == 0u) {
                     *reinterpret_cast<int4 *>(&cov0[p0]) = make_int4(c0, c1, c2, c3);
                     M0 = __ballot(c0 >= a.high_cov); M1 = __ballot(c1 >= a.high_cov);
                     M2 = __ballot(c2 >= a.high_cov); M3 = __ballot(c3 >= a.high_cov);
