@@ -65,6 +65,11 @@ int raft_host_write_repeats(const char *txt_path, const char *bed_path, const ra
 int raft_host_write_fasta(const char *path, const raft_host_reads *reads, const int64_t *frag_offset,
                           const int32_t *frag_begin, const int32_t *frag_end);
 
+/* The reference's stand-alone comparator tool (split_naive.cpp:10-44): every read of in_path cut into consecutive
+ * pieces of split_len bases, written to out_path as ">name_k" records, k from 1.  n_reads (may be NULL) receives the
+ * number of input records. */
+int raft_host_split_naive(const char *in_path, const char *out_path, int32_t split_len, int32_t *n_reads);
+
 #ifdef __cplusplus
 }
 #endif

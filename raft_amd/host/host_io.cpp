@@ -262,6 +262,8 @@ int write_ordered(const char *path, long long n, long long block, W weight, F fm
 } // namespace
 
 struct raft_host_reads {
+    bool allow_dup = false;           // split_naive keeps every record, repeated names included
+    std::vector<std::string> dup_names;   // (allow_dup) names in file order; `names` is not used then
     NameTable names;
     std::vector<int32_t> lens;
     std::vector<size_t> base_off;
@@ -282,6 +284,7 @@ namespace {
 // (chop.hpp:108), and the simulated-read fields (chop.hpp:25-70, 116-121).
 int add_read_meta(raft_host_reads *R, const std::string &name)
 {
+    if (R->allow_dup) { R->dup_names.push_back(name); return RAFT_HOST_OK; }
     if (R->names.size() == 0 && looks_simulated(name)) R->real_reads = 0;
     const int32_t id = R->names.add(name.data(), name.size());
     if (id < 0) return RAFT_HOST_ERR_DUP_NAME;
@@ -429,12 +432,17 @@ int raft_host_set_threads(int n)
 
 int raft_host_get_threads(void) { return host_threads(); }
 
-int raft_host_reads_load(const char *path, raft_host_reads **out)
+static int load_reads(const char *path, raft_host_reads **out, bool allow_dup);
+
+int raft_host_reads_load(const char *path, raft_host_reads **out) { return load_reads(path, out, false); }
+
+static int load_reads(const char *path, raft_host_reads **out, bool allow_dup)
 {
     if (!path || !out) return RAFT_HOST_ERR_ARG;
     *out = nullptr;
     {
         raft_host_reads *P = new raft_host_reads();
+        P->allow_dup = allow_dup;
         const int prc = load_plain_fasta_parallel(path, P);
         if (prc == RAFT_HOST_OK) { *out = P; return RAFT_HOST_OK; }
         delete P;
@@ -443,6 +451,7 @@ int raft_host_reads_load(const char *path, raft_host_reads **out)
     Stream in(path);
     if (!in.ok()) return RAFT_HOST_ERR_OPEN;
     raft_host_reads *R = new raft_host_reads();
+    R->allow_dup = allow_dup;
     int last = 0; // header byte already consumed by the previous record
     std::string name, seq, junk;
     int rc = RAFT_HOST_OK;
@@ -678,6 +687,32 @@ int raft_host_write_fasta(const char *path, const raft_host_reads *reads, const 
         }
     };
     return write_ordered(path, n, 8 << 20, [&](long long i) { return (long long)reads->lens[(size_t)i] + 64; }, one_read);
+}
+
+// split_naive.cpp:10-44: every read is cut into consecutive pieces of split_len bases, no overlaps, written as
+// ">name_k\n<piece>\n" with k counting from 1; a read without bases writes nothing.
+int raft_host_split_naive(const char *in_path, const char *out_path, int32_t split_len, int32_t *n_reads_out)
+{
+    if (!in_path || !out_path || split_len <= 0) return RAFT_HOST_ERR_ARG;
+    raft_host_reads *R = nullptr;
+    const int rc = load_reads(in_path, &R, true);
+    if (rc != RAFT_HOST_OK) return rc;
+    const long long n = (long long)R->lens.size();
+    if (n_reads_out) *n_reads_out = (int32_t)n;
+    const int wrc = write_ordered(out_path, n, 8 << 20, [&](long long i) { return (long long)R->lens[(size_t)i] + 64; },
+                                  [&](long long i, std::string &o) {
+                                      const std::string &name = R->dup_names[(size_t)i];
+                                      const char *seq = R->bases.data() + R->base_off[(size_t)i];
+                                      const long long len = R->lens[(size_t)i];
+                                      long long piece = 1;
+                                      for (long long b = 0; b < len; b += split_len, ++piece) {
+                                          o.push_back('>'); o.append(name); o.push_back('_'); put_num(o, piece); o.push_back('\n');
+                                          o.append(seq + b, (size_t)std::min<long long>(split_len, len - b));
+                                          o.push_back('\n');
+                                      }
+                                  });
+    delete R;
+    return wrc;
 }
 
 } // extern "C"

@@ -12,7 +12,7 @@ OK, ERR_OPEN, ERR_DUP_NAME, ERR_UNKNOWN_NAME, ERR_IO, ERR_ARG = range(6)
 EXPORTS = ("raft_host_reads_load", "raft_host_reads_free", "raft_host_reads_count", "raft_host_reads_lengths",
            "raft_host_reads_name", "raft_host_reads_bases", "raft_host_reads_real", "raft_host_paf_load", "raft_host_paf_free",
            "raft_host_paf_count", "raft_host_paf_column", "raft_host_write_coverage", "raft_host_write_repeats",
-           "raft_host_write_fasta", "raft_host_set_threads", "raft_host_get_threads")
+           "raft_host_write_fasta", "raft_host_set_threads", "raft_host_get_threads", "raft_host_split_naive")
 
 
 class HostError(RuntimeError):
@@ -46,6 +46,7 @@ def load_library():
         lib.raft_host_write_coverage.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp, vp]
         lib.raft_host_write_repeats.argtypes = [C.c_char_p, C.c_char_p, vp, vp, vp, vp]
         lib.raft_host_write_fasta.argtypes = [C.c_char_p, vp, vp, vp, vp]
+        lib.raft_host_split_naive.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
         lib.raft_host_set_threads.argtypes = [C.c_int]
         lib.raft_host_get_threads.argtypes = []
         _lib = lib
@@ -57,6 +58,15 @@ def set_threads(n: int) -> None:
     rc = load_library().raft_host_set_threads(int(n))
     if rc != OK:
         raise HostError(rc, f"set_threads({n})")
+
+
+def split_naive(in_path: str, out_path: str, split_len: int) -> int:
+    """split_naive.cpp: fixed-length pieces of every read; returns the number of input records."""
+    n = C.c_int32(0)
+    rc = load_library().raft_host_split_naive(in_path.encode(), out_path.encode(), int(split_len), C.byref(n))
+    if rc != OK:
+        raise HostError(rc, in_path)
+    return int(n.value)
 
 
 def get_threads() -> int:

@@ -210,3 +210,38 @@ def test_loaders_and_writers_thread_count_random(tmp_path):
         hostio.set_threads(0)
     assert outs[1] == outs[5]
     assert len(outs[1]["reads.fasta"]) > 0 and len(outs[1]["coverage.txt"]) > 0
+
+
+# ---- split_naive (the reference's comparator tool) ----------------------------------------------------------------
+
+SPLIT_INPUT = (">a first\nACGTACGTAC\nGTAC\n>empty\n>b\nTT\n>a\nCCCCCCCCCCCCCCCCCCCCCC\n"      # a repeated name, an empty read
+               "@q1\nACGTACGTA\n+\nIIIIIIIII\n")
+SPLIT_GOLDEN_7 = (">a_1\nACGTACG\n>a_2\nTACGTAC\n>b_1\nTT\n>a_1\nCCCCCCC\n>a_2\nCCCCCCC\n>a_3\nCCCCCCC\n>a_4\nC\n"
+                  ">q1_1\nACGTACG\n>q1_2\nTA\n")
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_split_naive_matches_reference(tmp_path, threads):
+    import subprocess
+    src = tmp_path / "in.fa"
+    src.write_text(SPLIT_INPUT)
+    try:
+        hostio.set_threads(threads)
+        assert hostio.split_naive(str(src), str(tmp_path / "ours.fa"), 7) == 5
+    finally:
+        hostio.set_threads(0)
+    ours = (tmp_path / "ours.fa").read_text()
+    assert ours == SPLIT_GOLDEN_7                      # golden captured from the compiled reference tool
+    ref = os.path.join(ROOT, "oracle", "_ref", "split_naive")
+    if os.path.exists(ref):                            # and against the tool itself where it is built
+        for L in (1, 7, 10, 1000):
+            subprocess.run([ref, str(src), str(tmp_path / "ref.fa"), str(L)], check=True)
+            hostio.split_naive(str(src), str(tmp_path / "ours.fa"), L)
+            assert (tmp_path / "ours.fa").read_bytes() == (tmp_path / "ref.fa").read_bytes(), L
+    cli = os.path.join(ROOT, "raft_amd", "bin", "split_naive")
+    if os.path.exists(cli):
+        r = subprocess.run([cli, str(src), str(tmp_path / "cli.fa"), "7"], stdout=subprocess.PIPE)
+        assert r.returncode == 0 and (tmp_path / "cli.fa").read_text() == SPLIT_GOLDEN_7
+        assert subprocess.run([cli, str(src)], stdout=subprocess.PIPE).returncode == 1     # usage
+    with pytest.raises(hostio.HostError):
+        hostio.split_naive(str(src), str(tmp_path / "x.fa"), 0)
