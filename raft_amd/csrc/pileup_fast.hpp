@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 const int c0 = excl + x, c1 = excl + y, c2 = excl + z, c3 = excl + w;
                 unsigned long long M0, M1, M2, M3;
                 if (((partial_rows >> row) & 1u) == 0u) {
-                    *reinterpret_cast<int4 *>(&cov0[p0]) = make_int4(c0, c1, c2, c3);
+                    // scalar base + this lane's 32-bit byte offset (the LDS address of the row): no 64-bit address arithmetic
+                    *reinterpret_cast<int4 *>(reinterpret_cast<char *>(cov0) + (unsigned)p0 * 4u) = make_int4(c0, c1, c2, c3);
                     M0 = __ballot(c0 >= a.high_cov); M1 = __ballot(c1 >= a.high_cov);
                     M2 = __ballot(c2 >= a.high_cov); M3 = __ballot(c3 >= a.high_cov);
                 } else {                         // first / last row of the tile: some slots lie outside [off0, t_end)
