@@ -125,8 +125,10 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     const unsigned tid = threadIdx.x;
     const int lane = (int)(tid & 63u);
     const int wid = uni((int)(tid >> 6));
-    const long long nb = gridDim.x;
-    const long long last_cut = a.n_tiles - 1;    // cuts[last_cut + 1] is the closing boundary
+    // tile indices fit 32 bits (the host checks n_tiles * 18 < 2^31): scalar compares, half the registers
+    const int nb = (int)gridDim.x;
+    const int n_tiles = (int)a.n_tiles;
+    const int last_cut = n_tiles - 1;            // cuts[last_cut + 1] is the closing boundary
     // runs are kept from ceil(repeat_length / reso) windows on; from 68 windows on, pass B can tell by whole lanes
     // of four windows that a row ends no such run (see there)
     const bool long_runs_only = ((long long)a.repeat_length + a.reso - 1) / a.reso >= 68;
@@ -157,18 +159,18 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     };
 
     const int32_t *cut_words = reinterpret_cast<const int32_t *>(cuts);
-    auto cut_word = [&](long long kc) -> int {   // dword `lane` of cuts[kc], cuts[kc + 1]; n_tiles * 8 < 2^31 (host check)
+    auto cut_word = [&](int kc) -> int {   // dword `lane` of cuts[kc], cuts[kc + 1]; n_tiles * 8 < 2^31 (host check)
         const unsigned idx = (unsigned)kc * 8u + (unsigned)lane;
         return lane < 16 ? cut_words[idx] : 0;
     };
-    long long k = blockIdx.x;
+    int k = (int)blockIdx.x;
     FastTile cur{}, nxt{};
     FastRegs<U> g{}, gn{};
     FastReadRegs rdn{};
     int pub_r_a = 0, pub_nr = 0;                 // tile whose repeat counts are still in LDS (set 1 - p)
     int p = 0;                                   // table / start-bit set of the current tile
     int raw_n = 0, raw_nn = 0;                   // cuts of the next tile (landed) / of the tile after next (in flight)
-    if (k < a.n_tiles) {
+    if (k < n_tiles) {
         int lo[NSEG], n[NSEG];
         cut_unpack<NSEG, ITER>(cut_word(k), cur, lo, n);
         if (cur.fast) {
@@ -181,14 +183,14 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     }
     wait_all_loads();
     lds_barrier();
-    while (k < a.n_tiles) {
-        const long long kn = k + nb;
+    while (k < n_tiles) {
+        const int kn = k + nb;
         if (DIAG && tid == 0 && a.dbg) { sm.stamps[0] = __builtin_amdgcn_s_memtime(); sm.stamps[9] = __builtin_amdgcn_s_memrealtime(); }
         {
             // raw_n always holds real cuts (the index is clamped), so the unpacking needs no guard
             int lo[NSEG], n[NSEG];
             cut_unpack<NSEG, ITER>(raw_n, nxt, lo, n);
-            if (kn >= a.n_tiles) nxt.fast = 0;
+            if (kn >= n_tiles) nxt.fast = 0;
             raw_nn = cut_word(min(kn + nb, last_cut));
             if (nxt.fast) fast_issue<NSEG, U>(a, tid, nxt, lo, n, gn, rdn);
         }
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
         RAFT_STAMP(7);
         if (DIAG && tid == 0 && a.dbg) {
             sm.stamps[10] = __builtin_amdgcn_s_memrealtime();
-            for (int i = 0; i < 16; ++i) a.dbg[k * 16 + i] = sm.stamps[i];
+            for (int i = 0; i < 16; ++i) a.dbg[(long long)k * 16 + i] = sm.stamps[i];
         }
         k = kn; cur = nxt; g = gn; p = 1 - p; raw_n = raw_nn;
     }
