@@ -27,15 +27,15 @@ namespace {
 // short_max windows always fits one LDS window.
 struct PileVariant { int fast, cap, wg_per_cu, short_max; };
 constexpr PileVariant kVariants[] = {
-    {1, 6144, 5, 1536},   // 0: default: fast kernel, 30.8 KB LDS, 5 workgroups/CU
+    {1, 7936, 4, 1280},   // 0: default: fast kernel, 36.4 KB LDS, 4 workgroups/CU, 6 prefetch slots per lane, Q = 6656
     {0, 6144, 5, 2048},   // 1: general kernel only
-    {1, 4864, 6, 1280},   // 2: fast kernel, 25.5 KB LDS, 6 workgroups/CU
-    {1, 6144, 5, 1536},   // 3: variant 0 with s_memtime stamps in the fast kernel (diagnostic; raft_hip_debug_stamps)
+    {1, 6144, 5, 1536},   // 2: fast kernel, 29.2 KB LDS, 5 workgroups/CU, 4 prefetch slots per lane, Q = 4608
+    {1, 7936, 4, 1280},   // 3: variant 0 with s_memtime stamps in the fast kernel (diagnostic; raft_hip_debug_stamps)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kDefaultVariant = 0;
 constexpr int kDiagVariant = 3;
-constexpr int kFastSlots = 4;     // prefetched intervals per lane and tile in the fast kernel
+constexpr int kFastSlots = 4;     // default number of prefetched intervals per lane and tile in the fast kernel
 
 template <int CAP, int MINW>
 void launch_general(hipStream_t st, unsigned grid, const PileupArgs &pa)
@@ -43,16 +43,17 @@ void launch_general(hipStream_t st, unsigned grid, const PileupArgs &pa)
     hipLaunchKernelGGL((pileup_kernel<256, CAP, MINW, 3, false>), dim3(grid), dim3(256), 0, st, pa);
 }
 
-template <int CAP, int MINW, bool DIAG>
+template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots>
 void launch_fast(hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
+    constexpr int S4 = SLOTS % 4 == 0 ? SLOTS : 4;   // four sorted runs need a multiple of four slots
     const size_t dyn = 0;
     if (n_seg <= 1)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else if (n_seg == 2)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, kFastSlots, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
 }
 
 // RAFT_PRINT_OCCUPANCY=1: what the runtime thinks of the pileup kernels (registers, LDS, resident workgroups per CU)
@@ -510,9 +511,9 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     if (pv.fast) {
         const TileCut *cuts = c->tile_cuts.as<TileCut>();
         switch (c->variant) {
-        case 0: launch_fast<6144, 5, false>(st, pgrid, pa.n_seg, cuts, pa); break;
-        case 2: launch_fast<4864, 6, false>(st, pgrid, pa.n_seg, cuts, pa); break;
-        default: launch_fast<6144, 5, true>(st, pgrid, pa.n_seg, cuts, pa); break;
+        case 0: launch_fast<7936, 4, false, 6>(st, pgrid, pa.n_seg, cuts, pa); break;
+        case 2: launch_fast<6144, 5, false, 4>(st, pgrid, pa.n_seg, cuts, pa); break;
+        default: launch_fast<7936, 4, true, 6>(st, pgrid, pa.n_seg, cuts, pa); break;
         }
         // the tiles the fast kernel does not take (reads longer than the LDS window, very many reads)
         PileupArgs ps = pa;
@@ -689,9 +690,9 @@ int raft_hip_selftest(int device_id)
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return RAFT_HIP_ERR_DEVICE;
     if (hipSetDevice(device_id) != hipSuccess) return RAFT_HIP_ERR_DEVICE;
     if (getenv("RAFT_PRINT_OCCUPANCY")) {
-        print_occupancy("fast<6144,2,4,5>", pileup_fast_kernel<6144, 2, kFastSlots, 5, false>);
-        print_occupancy("fast<6144,1,4,5>", pileup_fast_kernel<6144, 1, kFastSlots, 5, false>);
-        print_occupancy("fast<4864,2,4,6>", pileup_fast_kernel<4864, 2, kFastSlots, 6, false>);
+        print_occupancy("fast<7936,2,6,4>", pileup_fast_kernel<7936, 2, 6, 4, false>);
+        print_occupancy("fast<7936,1,6,4>", pileup_fast_kernel<7936, 1, 6, 4, false>);
+        print_occupancy("fast<6144,2,4,5>", pileup_fast_kernel<6144, 2, 4, 5, false>);
         print_occupancy("general<256,6144,5,3>", pileup_kernel<256, 6144, 5, 3, false>);
     }
     const int n = 256;

@@ -40,6 +40,7 @@ struct FastSmem {
     static constexpr int NW = 4;
     static constexpr int SLOTS = CAP + 256;  // window slots: 3 alignment + CAP + 1 sentinel, rounded to rows
     static constexpr int TAB = kFastMaxReads + 2;
+    static_assert(SLOTS / 256 <= 32, "pass B keeps one bit per row in a 32-bit mask");
     int32_t diff[SLOTS];                     // zero whenever no tile is between its interval phase and its pass B
     int32_t roff[2][TAB];                    // first slot of read r_a+j relative to a0 (j <= nr)
     int32_t rlen[2][TAB];
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             int pclose = -1;             // slot at which the run inherited from before this wave closed
             int nq = 0;                  // runs this wave has parked for emission
             const int full_b = (off0 + 255) >> 8, full_e = t_end >> 8;   // rows [full_b, full_e) hold valid slots only
-            const uint32_t partial_rows = ((1u << full_b) - 1u) | ~((1u << full_e) - 1u);   // at most 25 rows
+            const uint32_t partial_rows = ((1u << full_b) - 1u) | ~((1u << full_e) - 1u);   // rows 0 .. 31, full_e <= 31
             // first slots of the tile's reads, two per lane (a run never continues across a read boundary,
             // repeat.hpp:111-112); also used to find the owner of a parked run
             const int ro0 = (lane < nr) ? tb.roff[lane] : 0x7fffffff;

@@ -44,7 +44,7 @@ print("memtime ticks per 100MHz realtime tick:", np.median(life[rt > 0] / rt[rt 
 span = st[:, 7].max() - st[:, 0].min()
 print(f"span {span} ticks; sum lifetimes/span = {life.sum()/span:.1f} tiles in flight on average")
 # per-workgroup view (persistent grid: tile k belongs to workgroup k % grid)
-grid = int(os.environ.get("RAFT_PROBE_GRID", "1280"))
+grid = int(os.environ.get("RAFT_PROBE_GRID", "1024"))   # variant 3: 4 workgroups per CU
 full = eng.debug_stamps().astype(np.int64)
 kidx = np.nonzero(full[:, 7] > 0)[0]
 good = (full[kidx, 0] > 0) & (full[kidx, 7] > full[kidx, 0]) & (full[kidx, 7] - full[kidx, 0] < 10_000_000)
