@@ -138,6 +138,8 @@ __global__ void selftest_kernel(const int *in, int *out_dpp, int *out_shfl, unsi
 struct raft_hip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t side_stream = nullptr;   // the general pileup kernel runs beside the fast one
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     raft_hip_params prm{};
     int32_t high_cov = 0, div = 0, minbins = 1;
     int32_t tile_q = 0;               // 0 = variant default
@@ -250,6 +252,9 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     c->device = device_id;
     apply_params(c, params);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&c->ev_pass0) != hipSuccess || hipEventCreate(&c->ev_pass1) != hipSuccess ||
         hipEventCreate(&c->ev_pile0) != hipSuccess || hipEventCreate(&c->ev_pile1) != hipSuccess) {
@@ -277,6 +282,9 @@ void raft_hip_destroy(raft_hip_ctx *c)
     if (c->ev_pass1) (void)hipEventDestroy(c->ev_pass1);
     if (c->ev_pile0) (void)hipEventDestroy(c->ev_pile0);
     if (c->ev_pile1) (void)hipEventDestroy(c->ev_pile1);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -510,18 +518,24 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
     if (pv.fast) {
         const TileCut *cuts = c->tile_cuts.as<TileCut>();
-        switch (c->variant) {
-        case 0: launch_fast<7936, 4, false, 6>(st, pgrid, pa.n_seg, cuts, pa); break;
-        case 2: launch_fast<6144, 5, false, 4>(st, pgrid, pa.n_seg, cuts, pa); break;
-        default: launch_fast<7936, 4, true, 6>(st, pgrid, pa.n_seg, cuts, pa); break;
-        }
-        // the tiles the fast kernel does not take (reads longer than the LDS window, very many reads)
+        // The tiles the fast kernel does not take (reads longer than the LDS window, very many reads) go to the general
+        // kernel on a second stream: the two kernels touch disjoint reads, and the general kernel's workgroups move in
+        // wherever a workgroup of the fast kernel's persistent grid has retired instead of waiting for the whole grid.
         PileupArgs ps = pa;
         ps.slow_list = c->slow_list.as<int32_t>(); ps.n_slow = &ctrl->n_slow;
         ps.block_sums = pa.block_sums + 2 * (long long)pgrid;
         ps.dbg = nullptr;
         const unsigned sgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * 5));
-        launch_general<6144, 5>(st, sgrid, ps);
+        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
+        switch (c->variant) {
+        case 0: launch_fast<7936, 4, false, 6>(st, pgrid, pa.n_seg, cuts, pa); break;
+        case 2: launch_fast<6144, 5, false, 4>(st, pgrid, pa.n_seg, cuts, pa); break;
+        default: launch_fast<7936, 4, true, 6>(st, pgrid, pa.n_seg, cuts, pa); break;
+        }
+        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        launch_general<6144, 5>(c->side_stream, sgrid, ps);
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
         n_sum_blocks = pgrid + sgrid;
     } else {
         launch_general<6144, 5>(st, pgrid, pa);
