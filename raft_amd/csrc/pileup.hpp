@@ -93,6 +93,7 @@ struct PileupArgs {
     // When pileup_fast_kernel takes the tiles of whole reads, this kernel walks only the others:
     const int32_t *slow_list;     // tile ids (any order), or nullptr: every tile is handled here
     const int32_t *n_slow;        // device count of slow_list
+    int32_t *tile_counter;        // pileup_fast_kernel: tiles are handed out through this counter (zeroed by the host)
 };
 
 constexpr int kRunQ = 16; // parked runs per wave and window before falling back to immediate emission

@@ -48,6 +48,7 @@ struct FastSmem {
     int32_t rres[2][TAB];                    // its first reserved raw-repeat slot (rep_res_off, < 2^31 checked by the host)
     unsigned long long acc_cov, acc_rep;
     __attribute__((aligned(16))) int32_t wsum[NW];
+    int32_t next_tile;                       // tile index wave 0 drew for the workgroup (dynamic tile hand-out)
     int32_t wst[NW * 8];                     // per wave: rows, pclose, sfinal, hpfinal, hpin
     unsigned long long stamps[16];           // diagnostic build
     int32_t runq[NW * 2 * kRunQ];            // per wave: closed runs parked for emission (slots relative to a0)
@@ -164,13 +165,33 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
         const unsigned idx = (unsigned)kc * 8u + (unsigned)lane;
         return lane < 16 ? cut_words[idx] : 0;
     };
-    int k = (int)blockIdx.x;
+    // Tiles are handed out dynamically: a workgroup's first two tiles are blockIdx.x and blockIdx.x + gridDim.x, every
+    // later one comes from batches of kBatch consecutive tiles drawn from a device counter.  (With a fixed stride the
+    // workgroups finished between 2.2 and 3.0 ms -- tiles inside repeats cost more, and CUs are not equally fast --
+    // and the kernel lasted as long as the slowest.  One draw per tile is no option either: 3e5 returning atomics on
+    // one word take longer than the kernel.)  The draw for the batch after the current one is one returning atomic
+    // issued by thread 0 together with the prefetch loads; it lands before pass B like every other load and crosses to
+    // the other waves through LDS behind the last barrier of that iteration.
+    constexpr int kBatch = 8;
+    int k = (int)blockIdx.x;                     // current tile
+    int kn = k + nb;                             // next tile (its cuts are in raw_n)
+    int knn = n_tiles;                           // the tile after next
+    int bn = 0, be = 0;                          // rest of the current batch: tiles [bn, be)
+    int next_base = 0;                           // first tile of the batch drawn last
+    bool want_draw = true;                       // a draw is due (issued at the top of the next iteration)
+    bool drew = false;                           // a draw was issued in this iteration
+    int drawn = 0;                               // thread 0: result of the draw in flight
     FastTile cur{}, nxt{};
     FastRegs<U> g{}, gn{};
     FastReadRegs rdn{};
     int pub_r_a = 0, pub_nr = 0;                 // tile whose repeat counts are still in LDS (set 1 - p)
     int p = 0;                                   // table / start-bit set of the current tile
     int raw_n = 0, raw_nn = 0;                   // cuts of the next tile (landed) / of the tile after next (in flight)
+    auto draw = [&]() { if (tid == 0) drawn = 2 * nb + atomicAdd(a.tile_counter, kBatch); };
+    auto hand_out = [&]() -> int {               // next tile of this workgroup; switches to the drawn batch when needed
+        if (bn == be) { bn = next_base; be = bn + kBatch; want_draw = true; }
+        return bn++;
+    };
     if (k < n_tiles) {
         int lo[NSEG], n[NSEG];
         cut_unpack<NSEG, ITER>(cut_word(k), cur, lo, n);
@@ -180,19 +201,24 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             wait_all_loads();
             stage_reads(0, cur, rd);
         }
-        raw_n = cut_word(min(k + nb, last_cut));
+        raw_n = cut_word(min(kn, last_cut));
+        draw();
     }
     wait_all_loads();
+    if (tid == 0) sm.next_tile = drawn;
     lds_barrier();
+    next_base = uni(sm.next_tile);
+    knn = hand_out();                            // (this also asks for the next draw)
     while (k < n_tiles) {
-        const int kn = k + nb;
         if (DIAG && tid == 0 && a.dbg) { sm.stamps[0] = __builtin_amdgcn_s_memtime(); sm.stamps[9] = __builtin_amdgcn_s_memrealtime(); }
         {
             // raw_n always holds real cuts (the index is clamped), so the unpacking needs no guard
             int lo[NSEG], n[NSEG];
             cut_unpack<NSEG, ITER>(raw_n, nxt, lo, n);
             if (kn >= n_tiles) nxt.fast = 0;
-            raw_nn = cut_word(min(kn + nb, last_cut));
+            raw_nn = cut_word(min(knn, last_cut));
+            drew = want_draw;
+            if (want_draw) { draw(); want_draw = false; }
             if (nxt.fast) fast_issue<NSEG, U>(a, tid, nxt, lo, n, gn, rdn);
         }
         if (DIAG && tid == 0 && a.dbg) { sm.stamps[8] = (unsigned long long)cur.nwin; sm.stamps[12] = (unsigned long long)cur.more; }
@@ -280,6 +306,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             // coverage store: after the stores, any vmcnt wait would also wait for the stores.
             wait_all_loads();
             RAFT_STAMP(15);
+            if (drew && tid == 0) sm.next_tile = drawn;   // read by every wave behind barrier C
             // The other table set is free now (its tile's runs were emitted before the last barrier pair): publish
             // that tile's repeat counts, then stage the next tile's reads in it.
             publish_counts(1 - p, pub_r_a, pub_nr);
@@ -496,6 +523,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             // no work in this tile: keep the hand-over of the table sets going
             lds_barrier();                       // the previous tile's runs are all emitted
             wait_all_loads();
+            if (drew && tid == 0) sm.next_tile = drawn;
             publish_counts(1 - p, pub_r_a, pub_nr);
             if (nxt.fast) stage_reads(1 - p, nxt, rdn);
             lds_barrier();
@@ -506,7 +534,9 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             sm.stamps[10] = __builtin_amdgcn_s_memrealtime();
             for (int i = 0; i < 16; ++i) a.dbg[(long long)k * 16 + i] = sm.stamps[i];
         }
-        k = kn; cur = nxt; g = gn; p = 1 - p; raw_n = raw_nn;
+        if (drew) next_base = uni(sm.next_tile);     // (written before this iteration's last barrier)
+        k = kn; kn = knn; knn = hand_out();
+        cur = nxt; g = gn; p = 1 - p; raw_n = raw_nn;
     }
     lds_barrier();                               // the last tile's runs are all emitted
     publish_counts(1 - p, pub_r_a, pub_nr);
