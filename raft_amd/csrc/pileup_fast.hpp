@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     // one word take longer than the kernel.)  The draw for the batch after the current one is one returning atomic
     // issued by thread 0 together with the prefetch loads; it lands before pass B like every other load and crosses to
     // the other waves through LDS behind the last barrier of that iteration.
-    constexpr int kBatch = 8;
+    constexpr int kBatch = 8;                    // 2 .. 16 measured alike
     int k = (int)blockIdx.x;                     // current tile
     int kn = k + nb;                             // next tile (its cuts are in raw_n)
     int knn = n_tiles;                           // the tile after next
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             if (want_draw) { draw(); want_draw = false; }
             if (nxt.fast) fast_issue<NSEG, U>(a, tid, nxt, lo, n, gn, rdn);
         }
-        if (DIAG && tid == 0 && a.dbg) { sm.stamps[8] = (unsigned long long)cur.nwin; sm.stamps[12] = (unsigned long long)cur.more; }
+        if (DIAG && tid == 0 && a.dbg) { sm.stamps[8] = (unsigned long long)cur.nwin; sm.stamps[12] = (unsigned long long)cur.more; sm.stamps[14] = blockIdx.x; }
         RAFT_STAMP(1);
         if (cur.fast) {
             // ---- geometry of the LDS window: slots are windows relative to a0 (16-byte aligned in cov[])

@@ -43,13 +43,13 @@ print("memtime ticks per 100MHz realtime tick:", np.median(life[rt > 0] / rt[rt 
 # concurrency: kernel span vs sum of lifetimes
 span = st[:, 7].max() - st[:, 0].min()
 print(f"span {span} ticks; sum lifetimes/span = {life.sum()/span:.1f} tiles in flight on average")
-# per-workgroup view (persistent grid: tile k belongs to workgroup k % grid)
+# per-workgroup view (persistent grid)
 grid = int(os.environ.get("RAFT_PROBE_GRID", "1024"))   # variant 3: 4 workgroups per CU
 full = eng.debug_stamps().astype(np.int64)
 kidx = np.nonzero(full[:, 7] > 0)[0]
 good = (full[kidx, 0] > 0) & (full[kidx, 7] > full[kidx, 0]) & (full[kidx, 7] - full[kidx, 0] < 10_000_000)
 kidx = kidx[good]
-wg = kidx % grid
+wg = full[kidx, 14] % grid          # stamp 14: the workgroup that ran the tile (tiles are handed out dynamically)
 t0 = full[kidx, 0]; t7 = full[kidx, 7]
 first = np.full(grid, np.iinfo(np.int64).max); last = np.zeros(grid, np.int64); busy = np.zeros(grid, np.int64); cnt = np.zeros(grid, np.int64)
 np.minimum.at(first, wg, t0); np.maximum.at(last, wg, t7); np.add.at(busy, wg, t7 - t0); np.add.at(cnt, wg, 1)
