@@ -27,10 +27,10 @@ namespace {
 // short_max windows always fits one LDS window.
 struct PileVariant { int fast, cap, wg_per_cu, short_max; };
 constexpr PileVariant kVariants[] = {
-    {1, 7936, 4, 1280},   // 0: default: fast kernel, 36.4 KB LDS, 4 workgroups/CU, 6 prefetch slots per lane, Q = 6656
+    {1, 7936, 4, 1664},   // 0: default: fast kernel, 36.4 KB LDS, 4 workgroups/CU, 6 prefetch slots per lane, Q = 6272
     {0, 6144, 5, 2048},   // 1: general kernel only
     {1, 6144, 5, 1536},   // 2: fast kernel, 29.2 KB LDS, 5 workgroups/CU, 4 prefetch slots per lane, Q = 4608
-    {1, 7936, 4, 1280},   // 3: variant 0 with s_memtime stamps in the fast kernel (diagnostic; raft_hip_debug_stamps)
+    {1, 7936, 4, 1664},   // 3: variant 0 with s_memtime stamps in the fast kernel (diagnostic; raft_hip_debug_stamps)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kDefaultVariant = 0;
