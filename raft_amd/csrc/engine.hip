@@ -73,7 +73,7 @@ struct Ctrl {                         // device control block, cleared every pas
     int32_t n_slow;                   // tiles left to the general pileup kernel (fast configurations)
     long long err_index;              // (the first 16 bytes are what the pass's host wait reads back)
     int32_t next_tile;                // pileup_fast_kernel's tile hand-out counter
-    int32_t pad2;
+    int32_t slow_next;                // the general kernel's item hand-out counter (list mode)
     unsigned long long totals[4];     // coverage, repeat bp, read length
     InspectOut insp;
     long long out_totals[4];          // rep / cut / frag totals land here via the scan
@@ -449,7 +449,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     pa.cov = c->cov.as<int32_t>(); pa.rep_res_off = c->rep_res_off.as<long long>(); pa.rep_cnt = c->rep_cnt.as<int32_t>();
     pa.raw_key = c->raw_key.as<int32_t>(); pa.raw_s = c->raw_s.as<int32_t>(); pa.raw_e = c->raw_e.as<int32_t>();
     pa.block_sums = c->block_sums.as<long long>(); pa.err_flags = &ctrl->err_flags; pa.err_index = &ctrl->err_index;
-    pa.tile_counter = &ctrl->next_tile;
+    pa.tile_counter = &ctrl->next_tile; pa.slow_counter = &ctrl->slow_next;
     {   // n / reso as mulhi + shift, exact for 0 <= n < 2^31: with L = ceil(log2 reso) and
         // m = floor(2^(31+L) / reso) + 1 (< 2^32), n / reso == (n * m) >> (31 + L) == mulhi(n, m) >> (L - 1)
         const unsigned d = (unsigned)c->prm.reso;

@@ -94,6 +94,7 @@ struct PileupArgs {
     const int32_t *slow_list;     // tile ids (any order), or nullptr: every tile is handled here
     const int32_t *n_slow;        // device count of slow_list
     int32_t *tile_counter;        // pileup_fast_kernel: tiles are handed out through this counter (zeroed by the host)
+    int32_t *slow_counter;        // list mode of this kernel: the items of slow_list are handed out one by one
 };
 
 constexpr int kRunQ = 16; // parked runs per wave and window before falling back to immediate emission
@@ -119,6 +120,7 @@ struct PileupSmem {
     int32_t wsum[NW];
     int32_t wst[NW * 8];                    // per wave: rows, pclose, sfinal, hpfinal, hpin, need
     unsigned long long stamps[16];          // diagnostic build
+    int32_t item;                           // list mode: the item thread 0 drew for the workgroup
     int32_t runq_n[NW];                     // per wave: closed runs parked for emission (slots relative to a0)
     int32_t runq[NW * 2 * kRunQ];
 };
@@ -615,25 +617,36 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
     // items of this kernel: all tiles, or the tiles listed in slow_list
     const long long n_items = a.slow_list ? (long long)uni(*a.n_slow) : a.n_tiles;
     auto tile_at = [&](long long i) -> long long { return a.slow_list ? (long long)uni(a.slow_list[i]) : i; };
-    long long k = blockIdx.x;
+    // List mode (the tiles pileup_fast_kernel leaves): the items are heavy and very unequal -- reads longer than the LDS
+    // window, tiles with hundreds of reads -- so they are handed out one at a time from a device counter and every one
+    // takes the splitting path below with synchronous loads; one returning atomic and one descriptor fetch per item are
+    // nothing against the item.  Otherwise: fixed stride over all tiles, descriptors and intervals prefetched.
+    const bool dyn = a.slow_list != nullptr;
+    auto draw = [&]() -> long long {
+        lds_barrier();                          // every wave is done with the previous item (and with sm.item)
+        if (tid == 0) sm.item = atomicAdd(a.slow_counter, 1);
+        lds_barrier();
+        return (long long)uni(sm.item);
+    };
+    long long k = dyn ? draw() : (long long)blockIdx.x;
     TileRegs cur{};
     Prefetch<U> g{}, gn{};
     bool simple = false, nsimple = false;
     int raw_n = 0, raw_nn = 0;
     if (k < n_items) {
         unpack_desc(desc_word(tile_at(k)), cur);
-        simple = is_simple(cur);
+        simple = !dyn && is_simple(cur);
         if (simple) issue_prefetch<THREADS, U>(a, tid, cur.r_lo, cur.r_hi - cur.r_lo, cur.seg_lo, cur.seg_cum, g);
-        if (k + nb < n_items) raw_n = desc_word(tile_at(k + nb));
+        if (!dyn && k + nb < n_items) raw_n = desc_word(tile_at(k + nb));
     }
     wait_all_loads(); // loop invariant: nothing is pending at the loop head on any incoming edge
     while (k < n_items) {
-        const long long kn = k + nb;
         const long long stamp_row = a.slow_list ? tile_at(k) : k;
         if (DIAG && tid == 0 && a.dbg) { sm.stamps[0] = __builtin_amdgcn_s_memtime(); sm.stamps[9] = __builtin_amdgcn_s_memrealtime(); }
         // next tile: its descriptor was requested one iteration ago; start its loads now
         nsimple = false;
-        if (kn < n_items) {
+        if (!dyn && k + nb < n_items) {
+            const long long kn = k + nb;
             TileRegs nxt;
             unpack_desc(raw_n, nxt);
             nsimple = is_simple(nxt);
@@ -714,9 +727,14 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
             for (int i = 0; i < 16; ++i) a.dbg[stamp_row * 16 + i] = sm.stamps[i];
         }
 
-        k = kn; simple = nsimple; g = gn;
-        if (k < n_items) unpack_desc(raw_n, cur);
-        raw_n = raw_nn;
+        if (dyn) {
+            k = draw();
+            if (k < n_items) { unpack_desc(desc_word(tile_at(k)), cur); wait_all_loads(); }
+        } else {
+            k += nb; simple = nsimple; g = gn;
+            if (k < n_items) unpack_desc(raw_n, cur);
+            raw_n = raw_nn;
+        }
     }
     lds_barrier();
     if (tid == 0) {
