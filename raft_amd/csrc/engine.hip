@@ -392,7 +392,15 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     c->cap_rep = RU; c->cap_cut = CU;
     if (RU >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;   // reserved raw-repeat slots are indexed with 32 bits in LDS
     const PileVariant &pv = kVariants[c->variant];
-    const int Q = c->tile_q ? std::min(c->tile_q, pv.cap) : pv.cap - pv.short_max;
+    // Tile quantum: a tile's windows are Q minus the overhang of the previous tile's last read plus that of its own, so
+    // the room left above Q has to follow the read lengths or most tiles of a long-read set overflow the LDS window
+    // (measured optima, mean windows per read -> room: 600 -> 1.7 k, 1200 -> 2.7 k, 3000 -> 3.9 k of a 7936-window tile).
+    int Q = c->tile_q ? std::min(c->tile_q, pv.cap) : pv.cap - pv.short_max;
+    if (!c->tile_q && pv.fast && N > 0) {
+        const double mean_w = (double)B / (double)N;
+        const int room = (int)std::min<double>(pv.cap / 2, std::max<double>(1408.0, 600.0 + 1.75 * mean_w));
+        Q = std::max(256, ((pv.cap - room) / 128) * 128);
+    }
     const long long n_tiles = B / Q + 1;
     if (n_tiles * kDescDwords >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE; // descriptors are indexed with 32 bits
 
