@@ -219,17 +219,36 @@ class Engine:
         self._check(self._lib.raft_hip_last_timing(self._ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def fetch(self, coverage: bool = True) -> dict:
-        """Host copies (numpy) of the finished pass, CSR per read."""
+    def fetch(self, coverage: bool = True, pinned: bool = False, out: dict | None = None) -> dict:
+        """Host copies (numpy) of the finished pass, CSR per read.
+
+        pinned: allocate the arrays in page-locked memory (the copies then run at the link's rate instead of the
+        pageable path's).  out: arrays of an earlier fetch to reuse when their sizes still fit (a caller that keeps
+        one pinned set of buffers pays neither allocation nor page faults per pass)."""
         s = self.summary
         n1 = s.n_reads + 1
-        out = {
-            "cov_offset": np.empty(n1, np.int64), "cov": np.empty(s.n_bins if coverage else 0, np.int32),
-            "rep_offset": np.empty(n1, np.int64), "rep_s": np.empty(s.n_repeats, np.int32), "rep_e": np.empty(s.n_repeats, np.int32),
-            "cut_offset": np.empty(n1, np.int64), "cuts": np.empty(s.n_cuts, np.int32),
-            "frag_offset": np.empty(n1, np.int64), "frag_read": np.empty(s.n_fragments, np.int32),
-            "frag_begin": np.empty(s.n_fragments, np.int32), "frag_end": np.empty(s.n_fragments, np.int32),
+        spec = {
+            "cov_offset": (n1, np.int64), "cov": (s.n_bins if coverage else 0, np.int32),
+            "rep_offset": (n1, np.int64), "rep_s": (s.n_repeats, np.int32), "rep_e": (s.n_repeats, np.int32),
+            "cut_offset": (n1, np.int64), "cuts": (s.n_cuts, np.int32),
+            "frag_offset": (n1, np.int64), "frag_read": (s.n_fragments, np.int32),
+            "frag_begin": (s.n_fragments, np.int32), "frag_end": (s.n_fragments, np.int32),
         }
+
+        def alloc(n, dt):
+            if pinned and n:
+                import torch
+                return torch.empty(int(n), dtype=torch.int64 if dt == np.int64 else torch.int32, pin_memory=True).numpy()
+            return np.empty(n, dt)
+
+        res = {}
+        for key, (n, dt) in spec.items():
+            have = out.get(key) if out else None
+            if have is not None and have.dtype == dt and have.size >= n and have.flags["C_CONTIGUOUS"]:
+                res[key] = have[:n]
+            else:
+                res[key] = alloc(n, dt)
+        out = res
         order = ("cov_offset", "cov", "rep_offset", "rep_s", "rep_e", "cut_offset", "cuts", "frag_offset",
                  "frag_read", "frag_begin", "frag_end")
         ptr = [C.c_void_p(out[k].ctypes.data if out[k].size else 0) for k in order]
