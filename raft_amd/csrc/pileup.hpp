@@ -115,8 +115,8 @@ struct PileupSmem {
     int32_t rcnt[MAXR + 2];                 // raw repeats emitted so far for the read
     int32_t rres[MAXR + 2];                 // its first reserved raw-repeat slot (rep_res_off, < 2^31 checked by the host)
     unsigned long long acc_cov, acc_rep;
-    long long carry_open;
-    int32_t carry_hp;
+    long long carry_open[2];                // a long read's open run across chunks: chunk c reads [c & 1], writes [~c & 1]
+    int32_t carry_hp[2];
     int32_t wsum[NW];
     int32_t wst[NW * 8];                    // per wave: rows, pclose, sfinal, hpfinal, hpin, need
     unsigned long long stamps[16];          // diagnostic build
@@ -291,7 +291,7 @@ __device__ __forceinline__ void issue_prefetch(const PileupArgs &a, int tid, int
 // g holds the window's prefetched loads (issue_prefetch with the same arguments).
 template <int THREADS, int CAP, int U, bool DIAG>
 __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, int r_a, int r_b,
-                            long long w_lo, long long w_hi, bool single_read, bool first_chunk, bool last_chunk,
+                            long long w_lo, long long w_hi, bool single_read, bool first_chunk, bool last_chunk, int cpar,
                             const long long (&seg_lo)[kMaxSeg], const int (&seg_cum)[kMaxSeg + 1], Prefetch<U> &g,
                             long long stamp_row)
 {
@@ -392,7 +392,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     int carry = 0;
     for (int w = 0; w < wid; ++w) carry += uni(sm.wsum[w]);
     bool hp; // was the window just before this wave's first slot high (and in the same run domain)?
-    if (wid == 0) hp = single_read && !first_chunk && uni(sm.carry_hp) != 0;
+    if (wid == 0) hp = single_read && !first_chunk && uni(sm.carry_hp[cpar]) != 0;
     else hp = (row_b < rows) && (carry >= a.high_cov);
     const bool hp_in = hp;
     int S = hp ? kOpen : kNone;  // start slot of the run currently open
@@ -516,7 +516,9 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     //    valid slot closes the run that reaches the window end, or carries it into the next chunk.
     {
         const int v = (lane < NW * 8) ? sm.wst[lane] : 0;
-        const long long carry_open = (single_read && !first_chunk) ? uni(sm.carry_open) : -1;
+        // (read from the slot of this chunk's parity: the wave holding the last slot writes the next chunk's value in
+        // this same phase, and a slower wave must not pick that up -- it did, on 1 run in 3e5, before the slots existed)
+        const long long carry_open = (single_read && !first_chunk) ? uni(sm.carry_open[cpar]) : -1;
         auto run_start_before = [&](int w) -> long long { // start (global window) of the run open at the end of wave w
 #pragma unroll
             for (int y = NW - 1; y >= 0; --y) {
@@ -541,7 +543,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
             if (last_wave) {
                 const long long open = hp ? ((S != kOpen) ? a0 + S : (wid == 0 ? carry_open : run_start_before(wid - 1))) : -1;
                 if (last_chunk) { if (open >= 0) park(open, w_hi); }   // end of read closes the run (repeat.hpp:150)
-                if (single_read && lane == 0) { sm.carry_open = last_chunk ? -1 : open; sm.carry_hp = (!last_chunk && open >= 0) ? 1 : 0; }
+                if (single_read && lane == 0) { sm.carry_open[cpar ^ 1] = last_chunk ? -1 : open; sm.carry_hp[cpar ^ 1] = (!last_chunk && open >= 0) ? 1 : 0; }
             }
         }
     }
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const long long nb = gridDim.x;
     const int32_t *td_words = reinterpret_cast<const int32_t *>(a.td);
-    if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; sm.carry_open = -1; sm.carry_hp = 0; }
+    if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; sm.carry_open[0] = sm.carry_open[1] = -1; sm.carry_hp[0] = sm.carry_hp[1] = 0; }
     if (tid < Smem::NW) sm.runq_n[tid] = 0;
 
     // Descriptors travel as ONE VGPR (lane l holds dword l): raw_n = tile k+nb (landed), raw_nn = tile k+2nb (in
@@ -657,17 +659,19 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
         RAFT_STAMP(1);
 
         if (simple) {
-            pile_window<THREADS, CAP, U, DIAG>(a, sm, cur.r_lo, cur.r_hi, cur.g_lo, cur.g_hi, false, true, true, cur.seg_lo,
+            pile_window<THREADS, CAP, U, DIAG>(a, sm, cur.r_lo, cur.r_hi, cur.g_lo, cur.g_hi, false, true, true, 0, cur.seg_lo,
                                             cur.seg_cum, g, stamp_row);
         } else if (cur.r_hi > cur.r_lo) {
             // A tile holding a read longer than the LDS window (or very many reads) is split on the fly:
             // sub-batches of whole reads, long reads in chunks of CAP windows; loads are issued synchronously.
             int r = cur.r_lo;
             long long chunk_pos = -1, g_first = 0, g_end = 0;
+            int chunk_idx = 0;                  // chunks of the long read in hand so far (its parity picks the carry slot)
             for (;;) {
                 int r_a, r_b;
                 long long w_lo, w_hi;
                 bool single, first, last;
+                int cpar = 0;
                 if (chunk_pos < 0) {
                     if (r >= cur.r_hi) break;
                     const long long gl = (r == cur.r_lo) ? cur.g_lo : uni(a.cov_off[r]);
@@ -690,13 +694,14 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
                         r = r2;
                         if (w_hi == w_lo) continue;      // only reads without windows
                     } else {
-                        g_first = gl; g_end = uni(a.cov_off[r + 1]); chunk_pos = gl;
+                        g_first = gl; g_end = uni(a.cov_off[r + 1]); chunk_pos = gl; chunk_idx = 0;
                     }
                 }
                 if (chunk_pos >= 0) {
                     r_a = r; r_b = r + 1; w_lo = chunk_pos;
                     w_hi = (chunk_pos + CAP < g_end) ? chunk_pos + CAP : g_end;
                     single = true; first = (chunk_pos == g_first); last = (w_hi == g_end);
+                    cpar = chunk_idx & 1; ++chunk_idx;
                     if (last) { chunk_pos = -1; r = r + 1; } else chunk_pos = w_hi;
                 }
                 long long s_lo[kMaxSeg];
@@ -715,7 +720,7 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
                 }
                 Prefetch<U> gs;
                 issue_prefetch<THREADS, U>(a, tid, r_a, r_b - r_a, s_lo, s_cum, gs);
-                pile_window<THREADS, CAP, U, DIAG>(a, sm, r_a, r_b, w_lo, w_hi, single, first, last, s_lo, s_cum, gs, stamp_row);
+                pile_window<THREADS, CAP, U, DIAG>(a, sm, r_a, r_b, w_lo, w_hi, single, first, last, cpar, s_lo, s_cum, gs, stamp_row);
             }
             wait_all_loads(); // keep the "no load pending after a tile" invariant on this path too
         } else {
