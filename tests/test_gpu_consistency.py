@@ -18,6 +18,9 @@ SHAPES = [
     dict(n_reads=40_000, mean_len=150000.0, coverage=60.0, seed=103, max_len=1_500_000, sigma=0.7),
     dict(n_reads=400_000, mean_len=9000.0, coverage=25.0, seed=104),
     dict(n_reads=150_000, mean_len=20000.0, coverage=30.0, seed=105, symmetric=False, shuffle=True),
+    dict(n_reads=600_000, mean_len=2500.0, coverage=20.0, seed=106, min_len=300, sigma=0.6),       # > 86 reads per tile
+    dict(n_reads=60_000, mean_len=25000.0, coverage=120.0, seed=107),                               # dense tiles
+    dict(n_reads=100_000, mean_len=30000.0, coverage=32.0, seed=108, n_families=3000, copies=4),    # repeat-rich
 ]
 PARAMS = [RaftParams(est_cov=32), RaftParams(est_cov=20, reso=7, repeat_length=900, interval_length=400, read_length=1600,
                                             overlap_length=100, flanking_length=70),
@@ -30,15 +33,15 @@ def test_pileup_configurations_agree(si, pi):
     import torch
     from raft_amd import engine
     from raft_amd.synth import make_overlaps
-    if si >= 2 and pi == 1:
+    if si in (2, 3, 4) and pi == 1:
         pytest.skip("reso 7 on the long-read shapes exceeds the per-pass limits of this test's memory budget")
     o = make_overlaps(device="cuda:0", **SHAPES[si])
     cols = (o.read_len,) + o.columns()
     ref = None
-    for variant in (1, 0, 2):
+    for variant, bucket in ((1, False), (0, False), (2, False), (0, True)):
         eng = engine.Engine(PARAMS[pi], device=0)
         try:
-            eng.set_tuning(0, False, variant)
+            eng.set_tuning(0, bucket, variant)
             eng.run_device(*cols)
             s = eng.finish()
             out = {k: v.clone() for k, v in eng.outputs_device().items()}
@@ -50,6 +53,6 @@ def test_pileup_configurations_agree(si, pi):
             ref = (out, tot)
             assert s.n_bins > 0 and s.n_fragments >= o.n_reads
             continue
-        assert tot == ref[1], (SHAPES[si], variant)
+        assert tot == ref[1], (SHAPES[si], variant, bucket)
         for k in out:
-            assert torch.equal(out[k], ref[0][k]), (SHAPES[si], variant, k)
+            assert torch.equal(out[k], ref[0][k]), (SHAPES[si], variant, bucket, k)
