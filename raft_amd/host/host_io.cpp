@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <atomic>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -34,6 +35,7 @@ namespace {
 
 // Worker threads of the host layer: RAFT_HOST_THREADS (default: hardware threads, at most 32).  1 = everything
 // inline on the calling thread (the reference's own behaviour; used by tests to cross-check the parallel paths).
+constexpr int kMaxThreads = 128;
 std::atomic<int> g_threads{0};   // 0 = not chosen yet
 
 int host_threads()
@@ -42,7 +44,7 @@ int host_threads()
     if (n > 0) return n;
     const char *e = getenv("RAFT_HOST_THREADS");
     int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
-    n = std::min(std::max(v, 1), 32);
+    n = std::min(std::max(v, 1), kMaxThreads);
     g_threads.store(n, std::memory_order_relaxed);
     return n;
 }
@@ -229,7 +231,8 @@ inline void put_num(std::string &b, long long v)
 
 // Writes items 0..n-1 to `path` in order.  Items are grouped into blocks of about `block` weight units; up to
 // host_threads() blocks are formatted concurrently (fmt(i, buffer) appends item i) and then written in order, so
-// the bytes are exactly those of a sequential writer.
+// the bytes are exactly those of a sequential writer.  (Writing the blocks concurrently with pwrite at their offsets
+// was measured slower: writes to one file serialise on its inode.)
 template <class W, class F>
 int write_ordered(const char *path, long long n, long long block, W weight, F fmt)
 {
@@ -267,7 +270,10 @@ struct raft_host_reads {
     NameTable names;
     std::vector<int32_t> lens;
     std::vector<size_t> base_off;
-    std::string bases;
+    std::string bases;                // streaming reader: all sequences, concatenated
+    std::unique_ptr<char[]> raw_bases;   // mapped-file reader: the same, allocated without being touched (a GB-sized
+                                      // zero fill on one thread cost as much as the parallel copy that follows)
+    const char *base_ptr() const { return raw_bases ? raw_bases.get() : bases.data(); }
     int real_reads = 1;
     // simulated-read mode (chop.hpp:116-121): parsed from every name
     std::vector<int32_t> start_pos, end_pos;
@@ -390,7 +396,7 @@ int load_plain_fasta_parallel(const char *path, raft_host_reads *R)
     R->base_off.resize(n_rec);
     size_t total = 0;
     for (size_t i = 0; i < n_rec; ++i) { R->base_off[i] = total; total += (size_t)R->lens[i]; }
-    R->bases.resize(total);
+    R->raw_bases.reset(new char[total ? total : 1]);
 
     // pass 2: bases, lines joined
     parallel_for(T, [&](int t) {
@@ -398,7 +404,7 @@ int load_plain_fasta_parallel(const char *path, raft_host_reads *R)
         rec_range(t, a, b);
         for (size_t i = a; i < b; ++i) {
             const size_t end = i + 1 < n_rec ? rec[i + 1] : data_end;
-            char *dst = &R->bases[0] + R->base_off[i];
+            char *dst = R->raw_bases.get() + R->base_off[i];
             for (size_t p = seq_begin[i]; p < end;) {
                 const char *nl = static_cast<const char *>(memchr(d + p, '\n', end - p));
                 const size_t le = nl ? (size_t)(nl - d) : end;
@@ -426,7 +432,7 @@ extern "C" {
 int raft_host_set_threads(int n)
 {
     if (n < 0) return RAFT_HOST_ERR_ARG;
-    g_threads.store(n > 32 ? 32 : n, std::memory_order_relaxed);   // 0: back to RAFT_HOST_THREADS / hardware default
+    g_threads.store(n > kMaxThreads ? kMaxThreads : n, std::memory_order_relaxed);   // 0: back to RAFT_HOST_THREADS / hardware default
     return RAFT_HOST_OK;
 }
 
@@ -497,19 +503,47 @@ void raft_host_reads_free(raft_host_reads *r) { delete r; }
 int32_t raft_host_reads_count(const raft_host_reads *r) { return r ? (int32_t)r->lens.size() : 0; }
 const int32_t *raft_host_reads_lengths(const raft_host_reads *r) { return r ? r->lens.data() : nullptr; }
 const char *raft_host_reads_name(const raft_host_reads *r, int32_t i) { return r->names.name(i); }
-const char *raft_host_reads_bases(const raft_host_reads *r, int32_t i) { return r->bases.data() + r->base_off[i]; }
+const char *raft_host_reads_bases(const raft_host_reads *r, int32_t i) { return r->base_ptr() + r->base_off[i]; }
 int raft_host_reads_real(const raft_host_reads *r) { return r ? r->real_reads : 1; }
 
 int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host_paf **out, char *err_name, int err_cap)
 {
     if (!path || !reads || !out) return RAFT_HOST_ERR_ARG;
     *out = nullptr;
-    gzFile f = gzopen(path, "rb");
-    if (!f) return RAFT_HOST_ERR_OPEN;
-    gzbuffer(f, 1 << 20);
     std::vector<char> data;
-    {
+    bool have = false;
+    {   // an uncompressed regular file is read by all workers at once (one pread per slice of the page cache)
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) return RAFT_HOST_ERR_OPEN;
+        struct stat st;
+        unsigned char magic[2] = {0, 0};
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 2 && pread(fd, magic, 2, 0) == 2 &&
+            !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+            const size_t n = (size_t)st.st_size;
+            data.resize(n + 1);
+            const int T = host_threads();
+            std::vector<char> ok((size_t)T, 1);
+            parallel_for(T, [&](int t) {
+                size_t lo = n * (size_t)t / (size_t)T;
+                const size_t hi = n * ((size_t)t + 1) / (size_t)T;
+                while (lo < hi) {
+                    const ssize_t got = pread(fd, data.data() + lo, hi - lo, (off_t)lo);
+                    if (got <= 0) { ok[(size_t)t] = 0; break; }
+                    lo += (size_t)got;
+                }
+            });
+            have = true;
+            for (char o : ok) if (!o) have = false;
+            if (have) data[n] = '\n';             // a last line without newline is still a line
+        }
+        close(fd);
+    }
+    if (!have) {
+        gzFile f = gzopen(path, "rb");
+        if (!f) return RAFT_HOST_ERR_OPEN;
+        gzbuffer(f, 1 << 20);
         size_t used = 0;
+        data.clear();
         data.resize(8u << 20);
         for (;;) {
             if (data.size() - used < (4u << 20)) data.resize(data.size() * 2);
@@ -655,7 +689,7 @@ int raft_host_write_fasta(const char *path, const raft_host_reads *reads, const 
     auto one_read = [&](long long i, std::string &o) {
         const char *name = reads->names.name((int32_t)i);
         const size_t name_n = reads->names.name_len((int32_t)i);
-        const char *seq = reads->bases.data() + reads->base_off[(size_t)i];
+        const char *seq = reads->base_ptr() + reads->base_off[(size_t)i];
         const int64_t f0 = frag_offset[i], f1 = frag_offset[i + 1];
         const bool whole = (f1 - f0) == 1;             // kept in one piece (chop.hpp:250-267)
         for (int64_t f = f0; f < f1; ++f) {
@@ -702,7 +736,7 @@ int raft_host_split_naive(const char *in_path, const char *out_path, int32_t spl
     const int wrc = write_ordered(out_path, n, 8 << 20, [&](long long i) { return (long long)R->lens[(size_t)i] + 64; },
                                   [&](long long i, std::string &o) {
                                       const std::string &name = R->dup_names[(size_t)i];
-                                      const char *seq = R->bases.data() + R->base_off[(size_t)i];
+                                      const char *seq = R->base_ptr() + R->base_off[(size_t)i];
                                       const long long len = R->lens[(size_t)i];
                                       long long piece = 1;
                                       for (long long b = 0; b < len; b += split_len, ++piece) {
