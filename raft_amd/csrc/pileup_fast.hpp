@@ -2,18 +2,22 @@
 // HiFi-like read set).  Same algorithm as pileup.hpp (which keeps handling the other tiles: reads longer than the
 // LDS window, tiles with very many reads); what differs is the bookkeeping around the rows, which in the general
 // kernel costs four times the vector instructions of the rows themselves (rocprofv3 SQ_INSTS_VALU) and five
-// workgroup barriers per tile:
+// workgroup barriers per tile.  The kernel's time follows its instruction count, not its bytes.
+//   * tiles are handed out in batches from a device counter: with a fixed stride the persistent workgroups finished
+//     up to a third apart (tiles inside repeats cost more; CUs are not equally fast);
 //   * a tile is described by two adjacent 32-byte TileCut records (first read, first interval per segment, first
-//     window) that arrive through the scalar data cache (s_load) -- no per-lane descriptor, no readlane unpacking;
-//   * prefetch slot u of a lane is interval (u / NSEG) * 256 + lane-id of segment u % NSEG: the address is a scalar
-//     base plus the constant lane offset, no per-record index arithmetic; intervals beyond the prefetched slots
-//     (tiles inside repeats) are fetched synchronously afterwards;
+//     window); the pair for the tile after next travels as one VGPR, lane l holding dword l (scalar loads held in
+//     ten SGPRs across a tile were spilled on arrival and cost three exposed waits per tile);
+//   * prefetch slot u of a lane is interval (u / NSEG) * 256 + lane-id of segment u % NSEG: a per-tile scalar base
+//     plus the lane's constant offset, no per-record index arithmetic; intervals beyond the prefetched slots (tiles
+//     inside repeats) are fetched synchronously afterwards;
 //   * three barriers per tile: pass B zeroes each row of the difference array right after reading it, and the
-//     per-read tables and read-start bits are double-buffered -- those of tile i+1 are written from the prefetched
-//     registers just before pass B of tile i, the repeat counts of tile i-1 are published at the same point -- so
-//     no clearing phase, no table phase and no publish phase stand between barriers;
-//   * coverage totals accumulate per lane in registers and are reduced once per workgroup, not once per tile;
-//   * one row body (first/last rows of a tile only differ in masks), so the run scan is instantiated once.
+//     per-read tables are double-buffered -- those of tile i+1 are written from the prefetched registers just
+//     before pass B of tile i, the repeat counts of tile i-1 are published at the same point -- so no clearing
+//     phase, no table phase and no publish phase stand between barriers;
+//   * the run scan is scalar code on four 64-bit ballots per row; rows that cannot end a run long enough to be kept
+//     are recognised by whole lanes of four windows; read boundaries come from registers, not from an LDS bit array;
+//   * coverage totals accumulate per lane in registers and are reduced once per workgroup, not once per tile.
 // Reference semantics: repeat.hpp:28-79 (profileCoverage), repeat.hpp:111-168 (run scan); see pileup.hpp.
 #pragma once
 #include "pileup.hpp"
