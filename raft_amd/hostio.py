@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libraft_host.so")
+_LIB_PATH = os.environ.get("RAFT_HOST_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libraft_host.so")   # (override: sanitizer builds)
 OK, ERR_OPEN, ERR_DUP_NAME, ERR_UNKNOWN_NAME, ERR_IO, ERR_ARG = range(6)
 
 EXPORTS = ("raft_host_reads_load", "raft_host_reads_free", "raft_host_reads_count", "raft_host_reads_lengths",
