@@ -281,7 +281,8 @@ struct raft_host_reads {
 };
 
 struct raft_host_paf {
-    std::vector<int32_t> col[6];
+    std::unique_ptr<int32_t[]> col[6];   // allocated untouched: the workers' copies are the first writes
+    size_t n = 0;
 };
 
 namespace {
@@ -510,7 +511,8 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
 {
     if (!path || !reads || !out) return RAFT_HOST_ERR_ARG;
     *out = nullptr;
-    std::vector<char> data;
+    std::unique_ptr<char[]> data_buf;    // the file's bytes plus one '\n'; allocated untouched (no serial zero fill)
+    size_t data_n = 0;
     bool have = false;
     {   // an uncompressed regular file is read by all workers at once (one pread per slice of the page cache)
         const int fd = open(path, O_RDONLY);
@@ -520,21 +522,22 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
         if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 2 && pread(fd, magic, 2, 0) == 2 &&
             !(magic[0] == 0x1f && magic[1] == 0x8b)) {
             const size_t n = (size_t)st.st_size;
-            data.resize(n + 1);
+            data_buf.reset(new char[n + 1]);
+            char *const data_p = data_buf.get();
             const int T = host_threads();
             std::vector<char> ok((size_t)T, 1);
             parallel_for(T, [&](int t) {
                 size_t lo = n * (size_t)t / (size_t)T;
                 const size_t hi = n * ((size_t)t + 1) / (size_t)T;
                 while (lo < hi) {
-                    const ssize_t got = pread(fd, data.data() + lo, hi - lo, (off_t)lo);
+                    const ssize_t got = pread(fd, data_p + lo, hi - lo, (off_t)lo);
                     if (got <= 0) { ok[(size_t)t] = 0; break; }
                     lo += (size_t)got;
                 }
             });
             have = true;
             for (char o : ok) if (!o) have = false;
-            if (have) data[n] = '\n';             // a last line without newline is still a line
+            if (have) { data_p[n] = '\n'; data_n = n + 1; }   // a last line without newline is still a line
         }
         close(fd);
     }
@@ -543,23 +546,26 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
         if (!f) return RAFT_HOST_ERR_OPEN;
         gzbuffer(f, 1 << 20);
         size_t used = 0;
-        data.clear();
-        data.resize(8u << 20);
+        std::vector<char> grow(8u << 20);
         for (;;) {
-            if (data.size() - used < (4u << 20)) data.resize(data.size() * 2);
-            const int n = gzread(f, data.data() + used, (unsigned)std::min<size_t>(data.size() - used - 1, 1u << 30));
+            if (grow.size() - used < (4u << 20)) grow.resize(grow.size() * 2);
+            const int n = gzread(f, grow.data() + used, (unsigned)std::min<size_t>(grow.size() - used - 1, 1u << 30));
             if (n <= 0) break;
             used += (size_t)n;
         }
         gzclose(f);
-        data.resize(used + 1);
-        data[used] = '\n'; // a last line without newline is still a line
-        if (used == 0) data.clear();
+        if (used) {
+            data_buf.reset(new char[used + 1]);
+            memcpy(data_buf.get(), grow.data(), used);
+            data_buf[used] = '\n'; // a last line without newline is still a line
+            data_n = used + 1;
+        }
     }
+    char *const data = data_buf.get();
     // Lines are independent: the buffer is cut at newlines into one chunk per thread, each chunk is tokenised into
     // its own columns (paf.hpp:50-87 rules), and the chunks are concatenated in file order.
     struct Chunk { std::vector<int32_t> col[6]; size_t err_pos = (size_t)-1; std::string err_name; };
-    const size_t total = data.size();
+    const size_t total = data_n;
     int T = host_threads();
     if (total < (1u << 20)) T = 1;
     std::vector<size_t> cut((size_t)T + 1, total);
@@ -567,8 +573,8 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
     for (int t = 1; t < T; ++t) {
         size_t p0 = total / (size_t)T * (size_t)t;
         if (p0 < cut[t - 1]) p0 = cut[t - 1];
-        const char *nl = p0 < total ? (const char *)memchr(data.data() + p0, '\n', total - p0) : nullptr;
-        cut[t] = nl ? (size_t)(nl - data.data()) + 1 : total;
+        const char *nl = p0 < total ? (const char *)memchr(data + p0, '\n', total - p0) : nullptr;
+        cut[t] = nl ? (size_t)(nl - data) + 1 : total;
     }
     std::vector<Chunk> chunks((size_t)T);
     parallel_for(T, [&](int t) {
@@ -584,12 +590,13 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
         };
         size_t pos = cut[t];
         const size_t end = cut[t + 1];
+        for (auto &v : C.col) v.reserve((end - pos) / 48 + 16);     // a PAF line rarely has fewer than 48 bytes
         while (pos < end) {
-            char *line = data.data() + pos;
+            char *line = data + pos;
             char *nl = (char *)memchr(line, '\n', end - pos);
             if (!nl) break;
             size_t len = (size_t)(nl - line);
-            const bool is_last_sentinel = (size_t)(nl - data.data()) == total - 1;
+            const bool is_last_sentinel = (size_t)(nl - data) == total - 1;
             const size_t line_pos = pos;
             pos += len + 1;
             if (is_last_sentinel && len == 0) break;     // the newline we appended after a file that ended in '\n'
@@ -610,7 +617,16 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
             const int32_t a = resolve(fld[0], fl[0], lastq, lastq_n, lastq_id);
             const int32_t b = resolve(fld[5], fl[5], lastt, lastt_n, lastt_id);
             if (a < 0 || b < 0) { C.err_pos = line_pos; C.err_name = a < 0 ? fld[0] : fld[5]; break; }
-            auto num = [](const char *s) -> int32_t { return (int32_t)(uint32_t)strtol(s, nullptr, 10); }; // paf.hpp:64-75 -> chop.hpp:157-160
+            // paf.hpp:64-75 -> chop.hpp:157-160: strtol, then uint32, then int.  Plain runs of up to 18 digits (every
+            // real PAF field) take the short loop -- the value is the same, without glibc's locale and range machinery;
+            // anything else (blanks, signs, overflow) goes to strtol itself.
+            auto num = [](const char *s) -> int32_t {
+                unsigned long long v = 0;
+                int n = 0;
+                while (s[n] >= '0' && s[n] <= '9' && n < 19) { v = v * 10 + (unsigned)(s[n] - '0'); ++n; }
+                if (n == 0 || n == 19) return (int32_t)(uint32_t)strtol(s, nullptr, 10);
+                return (int32_t)(uint32_t)v;       // trailing garbage ends the number, as in strtol
+            };
             C.col[0].push_back(a); C.col[1].push_back(num(fld[2])); C.col[2].push_back(num(fld[3]));
             C.col[3].push_back(b); C.col[4].push_back(num(fld[7])); C.col[5].push_back(num(fld[8]));
         }
@@ -626,19 +642,20 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
     raft_host_paf *P = new raft_host_paf();
     std::vector<size_t> off((size_t)T + 1, 0);
     for (int t = 0; t < T; ++t) off[(size_t)t + 1] = off[(size_t)t] + chunks[(size_t)t].col[0].size();
-    for (int k = 0; k < 6; ++k) P->col[k].resize(off[(size_t)T]);
+    P->n = off[(size_t)T];
+    for (int k = 0; k < 6; ++k) P->col[k].reset(new int32_t[P->n ? P->n : 1]);
     parallel_for(T, [&](int t) {
         for (int k = 0; k < 6; ++k)
             if (!chunks[(size_t)t].col[k].empty())
-                memcpy(P->col[k].data() + off[(size_t)t], chunks[(size_t)t].col[k].data(), chunks[(size_t)t].col[k].size() * sizeof(int32_t));
+                memcpy(P->col[k].get() + off[(size_t)t], chunks[(size_t)t].col[k].data(), chunks[(size_t)t].col[k].size() * sizeof(int32_t));
     });
     *out = P;
     return RAFT_HOST_OK;
 }
 
 void raft_host_paf_free(raft_host_paf *p) { delete p; }
-int64_t raft_host_paf_count(const raft_host_paf *p) { return p ? (int64_t)p->col[0].size() : 0; }
-const int32_t *raft_host_paf_column(const raft_host_paf *p, int k) { return (p && k >= 0 && k < 6) ? p->col[k].data() : nullptr; }
+int64_t raft_host_paf_count(const raft_host_paf *p) { return p ? (int64_t)p->n : 0; }
+const int32_t *raft_host_paf_column(const raft_host_paf *p, int k) { return (p && k >= 0 && k < 6) ? p->col[k].get() : nullptr; }
 
 // repeat.hpp:105-108: "read <i> " then "<pos>,<cov> " per window, then newline
 int raft_host_write_coverage(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset, const int32_t *cov)
