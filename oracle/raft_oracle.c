@@ -22,6 +22,128 @@ static int event_by_start(const void *a, const void *b)
     return (x > y) - (x < y);
 }
 
+/*
+ * repeat.hpp:170 -- std::sort(long_repeats, compare_start_repeat): ordered by the (flanked, clamped) start only.
+ * Runs are emitted left to right and the flank/clamp is monotone, so the list arrives non-decreasing; but several
+ * repeats can clamp to start 0 (flanking_length larger than their distance from the read's begin), and std::sort is
+ * not stable: with more than 16 elements libstdc++'s introsort permutes such ties (with <= 16 its insertion sort
+ * leaves them alone).  The reference binary is built with GCC's libstdc++ (Makefile:2-6), whose algorithm has been
+ * the same since GCC 4: introsort loop (median of first+1 / middle / last-1 moved to first, unguarded partition,
+ * recursion on the right part, depth limit 2*floor(log2 n), heap sort fallback) followed by the final insertion sort
+ * with threshold 16.  This is a restatement of that published algorithm (bits/stl_algo.h, bits/stl_heap.h), pinned
+ * against the real std::sort through oracle/_ref/libraft_ref.so in tests/test_oracle_golden.py.
+ */
+typedef struct { int32_t s, e; } rep_t;
+#define REP_LESS(a, b) ((a).s < (b).s)
+
+static void rep_swap(rep_t *a, rep_t *b) { rep_t t = *a; *a = *b; *b = t; }
+
+static void rep_push_heap(rep_t *first, int64_t hole, int64_t top, rep_t value)
+{
+    int64_t parent = (hole - 1) / 2;
+    while (hole > top && REP_LESS(first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+
+static void rep_adjust_heap(rep_t *first, int64_t hole, int64_t len, rep_t value)
+{
+    const int64_t top = hole;
+    int64_t child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (REP_LESS(first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    rep_push_heap(first, hole, top, value);
+}
+
+static void rep_heap_sort(rep_t *first, rep_t *last)       /* __partial_sort(first, last, last) */
+{
+    const int64_t len = last - first;
+    if (len >= 2)
+        for (int64_t parent = (len - 2) / 2;; parent--) {
+            rep_adjust_heap(first, parent, len, first[parent]);
+            if (parent == 0) break;
+        }
+    while (last - first > 1) {
+        --last;
+        rep_t value = *last;
+        *last = *first;
+        rep_adjust_heap(first, 0, last - first, value);
+    }
+}
+
+static void rep_introsort_loop(rep_t *first, rep_t *last, int depth_limit)
+{
+    while (last - first > 16) {
+        if (depth_limit == 0) { rep_heap_sort(first, last); return; }
+        --depth_limit;
+        /* __unguarded_partition_pivot */
+        rep_t *mid = first + (last - first) / 2;
+        rep_t *a = first + 1, *b = mid, *c = last - 1;
+        if (REP_LESS(*a, *b)) {
+            if (REP_LESS(*b, *c)) rep_swap(first, b);
+            else if (REP_LESS(*a, *c)) rep_swap(first, c);
+            else rep_swap(first, a);
+        } else if (REP_LESS(*a, *c)) rep_swap(first, a);
+        else if (REP_LESS(*b, *c)) rep_swap(first, c);
+        else rep_swap(first, b);
+        rep_t *lo = first + 1, *hi = last;
+        for (;;) {
+            while (REP_LESS(*lo, *first)) ++lo;
+            --hi;
+            while (REP_LESS(*first, *hi)) --hi;
+            if (!(lo < hi)) break;
+            rep_swap(lo, hi);
+            ++lo;
+        }
+        rep_introsort_loop(lo, last, depth_limit);
+        last = lo;
+    }
+}
+
+static void rep_unguarded_linear_insert(rep_t *last)
+{
+    rep_t val = *last;
+    rep_t *next = last - 1;
+    while (REP_LESS(val, *next)) { *last = *next; last = next; --next; }
+    *last = val;
+}
+
+static void rep_insertion_sort(rep_t *first, rep_t *last)
+{
+    if (first == last) return;
+    for (rep_t *i = first + 1; i != last; ++i) {
+        if (REP_LESS(*i, *first)) {
+            rep_t val = *i;
+            memmove(first + 1, first, (size_t)(i - first) * sizeof(rep_t));
+            *first = val;
+        } else rep_unguarded_linear_insert(i);
+    }
+}
+
+static void rep_std_sort(rep_t *first, rep_t *last)
+{
+    if (first == last) return;
+    int lg = 0;
+    for (int64_t n = last - first; n > 1; n >>= 1) lg++;
+    rep_introsort_loop(first, last, 2 * lg);
+    if (last - first > 16) {
+        rep_insertion_sort(first, first + 16);
+        for (rep_t *i = first + 16; i != last; ++i) rep_unguarded_linear_insert(i);
+    } else rep_insertion_sort(first, last);
+}
+
 /* growable int32 column ------------------------------------------------------ */
 typedef struct { int32_t *v; int64_t n, cap; } ivec;
 
@@ -212,8 +334,17 @@ int raft_oracle_run(const raft_oracle_params *p, int32_t n_reads, const int32_t 
             if (j < nb) { start = j * reso + reso; end = start; }
         }
         o->rep_offset[r + 1] = reps.n;
-        /* repeat.hpp:170 sorts by start; runs are emitted left to right and the
-         * flank/clamp is monotone, so the list is already in that order. */
+        /* repeat.hpp:170: std::sort by the clamped start.  The list arrives non-decreasing; ties (several repeats
+         * clamped to 0) are permuted by libstdc++ once the read has more than 16 repeats: rep_std_sort above. */
+        if (reps.n - rep_first > 16) {
+            const int64_t nrep = reps.n - rep_first;
+            rep_t *tmp = (rep_t *)malloc((size_t)nrep * sizeof(rep_t));
+            if (!tmp) { rc = RAFT_ORACLE_ERR_NOMEM; goto fail_ev; }
+            for (int64_t k = 0; k < nrep; k++) { tmp[k].s = reps.v[rep_first + k]; tmp[k].e = repe.v[rep_first + k]; }
+            rep_std_sort(tmp, tmp + nrep);
+            for (int64_t k = 0; k < nrep; k++) { reps.v[rep_first + k] = tmp[k].s; repe.v[rep_first + k] = tmp[k].e; }
+            free(tmp);
+        }
 
         /* Stage 4a -- chop.hpp:209-223 candidate markers */
         init.n = 0;

@@ -70,6 +70,124 @@ __device__ void sort_repeats(int32_t *k, int32_t *s, int32_t *e, int n)
     }
 }
 
+// repeat.hpp:170 is std::sort by the flanked, CLAMPED start.  After the ordering by run start above the list is
+// non-decreasing in that key too, so there is nothing left to do -- unless several repeats clamp to 0 and the read has
+// more than 16 repeats: libstdc++'s introsort (what the reference binary links) then permutes the tied entries, and
+// long_repeats.txt/.bed list them in that order (the marker mask does not depend on it: tied entries all start at 0).
+// The permutation is a function of the algorithm alone, restated here from its published form (bits/stl_algo.h:
+// introsort loop with median-of-3 to first, unguarded partition, recursion on the right part, depth limit
+// 2*floor(log2 n), heap-sort fallback; final insertion sort with threshold 16) and pinned against the real std::sort
+// in oracle/ (tests/test_oracle_golden.py) and against the oracle on the device (tests/test_gpu_parity.py).
+struct RepPair { int32_t s, e; };
+
+struct RepView {                                  // (s[i], e[i]) of one read as one sequence
+    int32_t *s, *e;
+    __device__ RepPair get(int i) const { return RepPair{s[i], e[i]}; }
+    __device__ void set(int i, RepPair v) const { s[i] = v.s; e[i] = v.e; }
+    __device__ void swap(int i, int j) const { const RepPair a = get(i), b = get(j); set(i, b); set(j, a); }
+    __device__ bool less(int i, int j) const { return s[i] < s[j]; }
+};
+
+__device__ inline void rep_adjust_heap(const RepView &v, int first, int hole, int len, RepPair value)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (v.less(first + child, first + child - 1)) child--;
+        v.set(first + hole, v.get(first + child));
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        v.set(first + hole, v.get(first + child - 1));
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;                  // __push_heap
+    while (hole > top && v.s[first + parent] < value.s) {
+        v.set(first + hole, v.get(first + parent));
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    v.set(first + hole, value);
+}
+
+__device__ inline void rep_unguarded_linear_insert(const RepView &v, int last)
+{
+    const RepPair val = v.get(last);
+    int next = last - 1;
+    while (val.s < v.s[next]) { v.set(last, v.get(next)); last = next; --next; }
+    v.set(last, val);
+}
+
+__device__ inline void rep_insertion_sort(const RepView &v, int first, int last)
+{
+    for (int i = first + 1; i < last; ++i) {
+        if (v.less(i, first)) {
+            const RepPair val = v.get(i);
+            for (int j = i; j > first; --j) v.set(j, v.get(j - 1));
+            v.set(first, val);
+        } else rep_unguarded_linear_insert(v, i);
+    }
+}
+
+__device__ __noinline__ void rep_std_sort(int32_t *s, int32_t *e, int n)
+{
+    const RepView v{s, e};
+    if (n <= 0) return;
+    int lg = 0;
+    for (int m = n; m > 1; m >>= 1) ++lg;
+    // __introsort_loop: the recursive call (right part) becomes a stack entry; depth <= 2*lg <= 62
+    int stk_first[64], stk_last[64], stk_depth[64], sp = 0;
+    stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = 2 * lg; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
+        // the callee's own loop: partition, hand the right part to a (pending) recursive call, continue on the left.
+        // Right parts are independent of what happens on the left afterwards, so their order of execution is free.
+        while (last - first > 16) {
+            if (depth == 0) {                     // __partial_sort(first, last, last): make_heap + sort_heap
+                const int len = last - first;
+                for (int parent = (len - 2) / 2;; --parent) {
+                    rep_adjust_heap(v, first, parent, len, v.get(first + parent));
+                    if (parent == 0) break;
+                }
+                for (int end = last; end - first > 1;) {
+                    --end;
+                    const RepPair value = v.get(end);
+                    v.set(end, v.get(first));
+                    rep_adjust_heap(v, first, 0, end - first, value);
+                }
+                break;
+            }
+            --depth;
+            const int mid = first + (last - first) / 2, a = first + 1, b = mid, c = last - 1;
+            if (v.less(a, b)) {
+                if (v.less(b, c)) v.swap(first, b);
+                else if (v.less(a, c)) v.swap(first, c);
+                else v.swap(first, a);
+            } else if (v.less(a, c)) v.swap(first, a);
+            else if (v.less(b, c)) v.swap(first, c);
+            else v.swap(first, b);
+            int lo = first + 1, hi = last;
+            for (;;) {
+                while (v.less(lo, first)) ++lo;
+                --hi;
+                while (v.less(first, hi)) --hi;
+                if (!(lo < hi)) break;
+                v.swap(lo, hi);
+                ++lo;
+            }
+            if (sp < 64) { stk_first[sp] = lo; stk_last[sp] = last; stk_depth[sp] = depth; ++sp; }
+            last = lo;
+        }
+    }
+    if (n > 16) {
+        rep_insertion_sort(v, 0, 16);
+        for (int i = 16; i < n; ++i) rep_unguarded_linear_insert(v, i);
+    } else rep_insertion_sort(v, 0, n);
+}
+
 // Walks the candidate markers 0, L, 2L, ..., (+len) of one read (chop.hpp:209-223) and keeps
 // the first, the last, and every marker not inside a flanked repeat [s,e] (chop.hpp:225-246).
 // Calls keep(m) for each kept marker in ascending order; returns their number.
@@ -98,6 +216,7 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
     const int n = a.rep_cnt[r];
     const long long base = a.rep_res_off[r];
     if (n > 1) sort_repeats(a.raw_key + base, a.raw_s + base, a.raw_e + base, n);
+    if (n > 16 && a.raw_s[base + 1] == 0) rep_std_sort(a.raw_s + base, a.raw_e + base, n);   // tied starts: repeat.hpp:170
     // Number of markers walk_cuts() keeps, without walking them: the interior markers are L, 2L, .., J*L; a flanked
     // repeat [s,e] covers the multiples of L inside it; repeats are ordered by start and by end, so the union is
     // counted in one sweep over the read's (few) repeats.

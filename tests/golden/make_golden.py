@@ -161,6 +161,38 @@ def run_case(name, read_len, cols, p: RaftParams, root):
             "n_reads": int(len(read_len)), "n_rec": int(len(cols[0]))}
 
 
+def config1_case(root):
+    """BASELINE configs[0] (README.md:12-33: `raft -e 42 -o fragmented chr11-2M.fa.gz overlaps.paf`) restated as
+    SURVEY.md §8(d) prescribes, because the real chr11 reads are not obtainable offline: G = 2 Mbp, 42x,
+    HiFi-like lengths ~N(20 kb, 3 kb), symmetric PAF of all true overlaps >= 500 bp, `-e 42`, and BOTH inputs
+    gzip-compressed (the reference reads them through zlib: chop.hpp:93, paf.hpp:29)."""
+    gen = dict(n_reads=4200, seed=42, mean_len=20000.0, sigma=0.15, coverage=42.0, min_len=5000, max_len=40000, n_families=3)
+    o = make_overlaps(**gen)
+    read_len, cols = o.read_len.numpy(), [c.numpy() for c in o.columns()]
+    names = [f"m64011_{i}/ccs" for i in range(len(read_len))]
+    p = RaftParams(est_cov=42)
+    args = ["-e", "42", "-o", "fragmented"]
+    with tempfile.TemporaryDirectory() as tmp:
+        write_fasta(os.path.join(tmp, "reads.fa"), names, read_len)
+        write_paf(os.path.join(tmp, "overlaps.paf"), names, read_len, *cols)
+        for f in ("reads.fa", "overlaps.paf"):
+            with open(os.path.join(tmp, f), "rb") as i, gzip.open(os.path.join(tmp, f + ".gz"), "wb", compresslevel=1) as z:
+                shutil.copyfileobj(i, z)
+        rc, out = run_ref_binary(tmp, args, "reads.fa.gz", "overlaps.paf.gz")
+        assert rc == 0, (rc, out[-400:])
+        res = result_from_ref_files(os.path.join(tmp, "fragmented"), names)
+        digests = {f: md5(open(os.path.join(tmp, "fragmented." + f), "rb").read()) for f in OUT_FILES}
+        rc2, out2 = run_ref_binary(tmp, ["-e", "42", "-o", "plain"], "reads.fa", "overlaps.paf")   # gz == plain
+        assert rc2 == 0 and all(md5(open(os.path.join(tmp, "plain." + f), "rb").read()) == digests[f] for f in OUT_FILES)
+        stdout = strip_timing(out)
+    np.savez_compressed(os.path.join(root, "c1_chr11_standin.npz"), read_len=read_len.astype(np.int32),
+                        qid=cols[0], qs=cols[1], qe=cols[2], tid=cols[3], ts=cols[4], te=cols[5],
+                        **{"exp_" + k: v for k, v in res.items()})
+    return {"params": p.__dict__, "args": args, "md5": digests, "stdout": stdout, "generator": gen,
+            "symmetric": int("INFO, Symmetric overlaps 1 " in stdout), "n_reads": int(len(read_len)),
+            "n_rec": int(len(cols[0])), "name_format": "m64011_{i}/ccs", "inputs": ["reads.fa.gz", "overlaps.paf.gz"]}
+
+
 def main():
     assert os.path.exists(REF_BIN), "oracle/_ref/raft missing: run `make -C oracle` in the build container"
     man = {"micro": make_micro(HERE), "synthetic": {}}
@@ -170,6 +202,7 @@ def main():
         man["synthetic"][name]["generator"] = gen
     rl, cols, p = edge_case()
     man["synthetic"]["edge_reads"] = run_case("edge_reads", rl, cols, p, HERE)
+    man["config1"] = {"c1_chr11_standin": config1_case(HERE)}
     json.dump(man, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
     total = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(HERE) for f in fs)
     print(f"golden fixtures written, {total / 1e6:.2f} MB")

@@ -262,3 +262,109 @@ def result_from_ref_files(prefix_path: str, names) -> dict:
     np.cumsum(np.bincount(out["frag_read"], minlength=n), out=fo[1:])
     out["frag_offset"] = fo
     return out
+
+
+# ---- shared input generators ------------------------------------------------------------------------
+
+def tie_case(seed):
+    """One or more reads with MANY short high-coverage runs near the read's begin and a flank larger than their
+    distance from it: several repeats clamp to start 0 and, with more than 16 repeats in the read, libstdc++'s
+    std::sort (repeat.hpp:170) permutes them."""
+    rng = np.random.default_rng(1000 + seed)
+    reso = int(rng.choice([1, 5, 10]))
+    n_reads = int(rng.integers(1, 4))
+    run_w = int(rng.integers(2, 6))                     # windows per run
+    gap_w = int(rng.integers(1, 5))
+    rl, rec = [], []
+    for r in range(n_reads):
+        n_runs = int(rng.integers(2, 120))
+        pos = int(rng.integers(0, 4)) * reso
+        for _ in range(n_runs):
+            w = run_w + int(rng.integers(0, 3))
+            rec.append((r, pos, pos + w * reso))
+            pos += (w + gap_w + int(rng.integers(0, 3))) * reso
+        rl.append(pos + int(rng.integers(0, 50 * reso)))
+    rl = np.array(rl, np.int32)
+    qid = np.array([x[0] for x in rec], np.int32)
+    qs = np.array([x[1] for x in rec], np.int32)
+    qe = np.array([x[2] for x in rec], np.int32)
+    tid = qid.copy()                                    # self overlaps: query side only (chop.hpp:166)
+    L = int(rng.choice([100, 1000]))
+    p = RaftParams(reso=reso, est_cov=1, cov_mul=1.0, repeat_length=run_w * reso, interval_length=L,
+                   read_length=2 * L, overlap_length=0,
+                   flanking_length=int(rng.choice([0, 50, 400, 2000, 100000])))
+    p.repeat_length = run_w * reso
+    return p, [rl, qid, qs, qe, tid, qs.copy(), qe.copy()]
+
+
+# ---- tests/golden/ref_fuzz.npz: random text inputs with the outputs of the compiled reference binary ------------
+
+_fuzz = None
+
+
+def ref_fuzz_count() -> int:
+    global _fuzz
+    if _fuzz is None:
+        with np.load(os.path.join(GOLDEN, "ref_fuzz.npz")) as z:
+            _fuzz = {k: z[k] for k in z.files}          # (an NpzFile would inflate the member again on every access)
+    return int(_fuzz["seeds"].size)
+
+
+def ref_fuzz_case(i: int):
+    """-> (RaftParams, [read_len, qid, qs, qe, tid, ts, te], expected dict incl. 'symmetric', 'stats', 'md5')."""
+    ref_fuzz_count()
+    z = _fuzz
+    reso, est_cov, rep_len, iv_len, read_length, ovl, flank = (int(x) for x in z["params"][i])
+    p = RaftParams(reso=reso, est_cov=est_cov, cov_mul=float(z["cov_mul"][i]), repeat_length=rep_len, interval_length=iv_len,
+                   read_length=read_length, overlap_length=ovl, flanking_length=flank)
+    r0, r1 = (int(x) for x in z["off_reads"][i:i + 2])
+    c0, c1 = (int(x) for x in z["off_recs"][i:i + 2])
+    cols = [z["read_len"][r0:r1]] + [z[k][c0:c1] for k in ("qid", "qs", "qe", "tid", "ts", "te")]
+    b0, b1 = (int(x) for x in z["off_cov"][i:i + 2])
+    p0, p1 = (int(x) for x in z["off_rep"][i:i + 2])
+    f0, f1 = (int(x) for x in z["off_frag"][i:i + 2])
+    rep_offset = np.zeros(r1 - r0 + 1, np.int64)
+    np.cumsum(z["rep_cnt"][r0:r1], out=rep_offset[1:])
+    exp = {"cov": z["cov"][b0:b1], "rep_offset": rep_offset, "rep_s": z["rep_s"][p0:p1], "rep_e": z["rep_e"][p0:p1],
+           "frag_read": z["frag_read"][f0:f1], "frag_begin": z["frag_begin"][f0:f1], "frag_end": z["frag_end"][f0:f1],
+           "symmetric": int(z["symmetric"][i]), "stats": str(z["stats"][i]),
+           "md5": dict(zip(("reads.fasta", "coverage.txt", "long_repeats.txt", "long_repeats.bed"), (str(x) for x in z["md5"][i])))}
+    return p, cols, exp
+
+
+def assert_matches_ref_fuzz(got: dict, exp: dict, p: RaftParams, what: str = ""):
+    """Result dict (oracle or engine) against the parsed outputs + stdout statistics of the reference binary."""
+    assert int(got["symmetric"]) == exp["symmetric"], what
+    for k in ("cov", "rep_offset", "rep_s", "rep_e", "frag_read", "frag_begin", "frag_end"):
+        assert np.array_equal(np.asarray(got[k]), exp[k]), (what, k)
+    if int(got["total_windows"]) > 0 and int(got["total_read_length"]) > 0:   # the reference prints nan / inf otherwise
+        cpw = got["total_coverage"] / got["total_windows"]
+        want = ("coverage per window is %f \n" % cpw + "coverage per window/average coverage is %f \n" % (cpw / p.est_cov) +
+                "fraction_of_repeat_length %f " % (got["total_repeat_length"] / got["total_read_length"]))
+        assert want == exp["stats"], (what, want, exp["stats"])
+
+
+# ---- BASELINE configs[0] stand-in (tests/golden/c1_chr11_standin.npz, make_golden.py config1_case) ---------------
+
+def load_config1():
+    import json
+    meta = json.load(open(os.path.join(GOLDEN, "manifest.json")))["config1"]["c1_chr11_standin"]
+    with np.load(os.path.join(GOLDEN, "c1_chr11_standin.npz")) as z:
+        cols = [z[k] for k in ("read_len", "qid", "qs", "qe", "tid", "ts", "te")]
+        exp = {k[4:]: z[k] for k in z.files if k.startswith("exp_")}
+    return RaftParams(**meta["params"]), cols, exp, meta
+
+
+def write_config1_inputs(tmp, cols, meta):
+    """reads.fa.gz + overlaps.paf.gz exactly as make_golden.py wrote them for the reference run (the md5 of
+    fragmented.reads.fasta depends on the bases, which seq_of() regenerates)."""
+    import gzip
+    import shutil
+    names = [meta["name_format"].format(i=i) for i in range(len(cols[0]))]
+    write_fasta(os.path.join(tmp, "reads.fa"), names, cols[0])
+    write_paf(os.path.join(tmp, "overlaps.paf"), names, *cols)
+    for f in ("reads.fa", "overlaps.paf"):
+        with open(os.path.join(tmp, f), "rb") as i, gzip.open(os.path.join(tmp, f + ".gz"), "wb", compresslevel=1) as z:
+            shutil.copyfileobj(i, z)
+        os.remove(os.path.join(tmp, f))
+    return names

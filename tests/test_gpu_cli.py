@@ -52,6 +52,34 @@ def test_cli_synthetic_cases(tmp_path, name):
         assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, (name, f)
 
 
+def test_cli_config1_gz(tmp_path):
+    """BASELINE configs[0] (README.md:12-33 `raft -e 42 -o fragmented reads.fa.gz overlaps.paf`) on the SURVEY §8(d)
+    stand-in (2 Mbp, 42x), both inputs gzip-compressed: four files md5-identical to the reference's, stdout equal."""
+    from raft_testlib import load_config1, write_config1_inputs
+    p, cols, exp, meta = load_config1()
+    write_config1_inputs(str(tmp_path), cols, meta)
+    rc, out = run(tmp_path, meta["args"] + meta["inputs"])
+    assert rc == 0, out
+    assert strip_timing(out) == meta["stdout"]
+    for f, digest in meta["md5"].items():
+        assert md5(open(tmp_path / ("fragmented." + f), "rb").read()) == digest, f
+
+
+@pytest.mark.parametrize("i", range(0, 320, 13))
+def test_cli_ref_fuzz_subset(tmp_path, i):
+    """Every 13th case of tests/golden/ref_fuzz.npz through the CLI: the four files md5-identical to the reference's."""
+    from raft_testlib import ref_fuzz_case
+    p, cols, exp = ref_fuzz_case(i)
+    names = [f"r{k}" for k in range(len(cols[0]))]
+    write_fasta(tmp_path / "reads.fa", names, cols[0])
+    write_paf(tmp_path / "overlaps.paf", names, *cols)
+    rc, out = run(tmp_path, p.cli_args() + ["-o", "out", "reads.fa", "overlaps.paf"])
+    assert rc == 0, out
+    assert "INFO, Symmetric overlaps %d \n" % exp["symmetric"] in out
+    for f, digest in exp["md5"].items():
+        assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, (i, f)
+
+
 def test_cli_usage_and_input_errors(tmp_path):
     rc, out = run(tmp_path, [])
     assert rc == 1 and out.startswith("Usage: raft [options] <input-reads.fa> <in.paf>\n")

@@ -1,0 +1,193 @@
+"""GPU: BASELINE.json's configs at their own workloads, through the C ABI, bit-exact.
+
+  config 1  (configs[0]) 2 Mbp / 42x stand-in, expected arrays parsed from the reference binary's files
+  config 3  (configs[2]) the bench workload itself -- 3.3 M reads, 2.9e8 records -- by invariants, by the
+            counting-sort path against the sorted-segment path, and by the oracle on windows of reads cut out of it
+  config 5  (configs[4]) ultralong 60x / 150 kb reads with 50 kb tandem arrays: -p x -m x -r sweep vs the oracle
+  plus      tests/golden/ref_fuzz.npz (320 random inputs, outputs of the reference BINARY) and the std::sort tie corner
+"""
+import numpy as np
+import pytest
+from raft_testlib import (RaftParams, assert_matches_ref_fuzz, assert_same_result, load_config1, oracle_run, ref_fuzz_case,
+                          ref_fuzz_count, tie_case)
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_result(eng, s, fetch_kw=None):
+    got = eng.fetch(**(fetch_kw or {}))
+    got.update(symmetric=s.symmetric, high_cov=s.high_cov, total_coverage=s.total_coverage, total_windows=s.total_windows,
+               total_repeat_length=s.total_repeat_length, total_read_length=s.total_read_length)
+    return got
+
+
+def run_host(p, cols, **tuning):
+    from raft_amd import engine
+    eng = engine.Engine(p, device=0)
+    try:
+        if tuning:
+            eng.set_tuning(tuning.get("tile_bins", 0), tuning.get("force_bucket", False), tuning.get("variant", -1))
+        eng.run_host(*cols)
+        s = eng.finish()
+        return engine_result(eng, s), s
+    finally:
+        eng.close()
+
+
+# ---- config 1 -----------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("mode", ["auto", "bucket", "general"])
+def test_config1_standin_vs_reference_outputs(mode):
+    p, cols, exp, meta = load_config1()
+    got, s = run_host(p, cols, force_bucket=(mode == "bucket"), variant=1 if mode == "general" else -1)
+    assert s.symmetric == meta["symmetric"] and s.n_records == meta["n_rec"]
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), (mode, k)
+    assert "coverage per window is %f \n" % (s.total_coverage / s.total_windows) in meta["stdout"]
+    assert "fraction_of_repeat_length %f \n" % (s.total_repeat_length / s.total_read_length) in meta["stdout"]
+
+
+# ---- the reference binary's outputs on random inputs; the std::sort tie corner -----------------------------------------
+
+def test_engine_vs_reference_binary_fuzz():
+    assert ref_fuzz_count() >= 200
+    from raft_amd import engine
+    for i in range(ref_fuzz_count()):
+        p, cols, exp = ref_fuzz_case(i)
+        eng = engine.Engine(p, device=0)
+        try:
+            eng.set_tuning(0, i % 3 == 2, (-1, 1, 2)[i % 3] if i % 3 != 2 else -1)
+            eng.run_host(*cols)
+            s = eng.finish()
+            assert_matches_ref_fuzz(engine_result(eng, s), exp, p, f"ref_fuzz case {i}")
+        finally:
+            eng.close()
+
+
+@pytest.mark.parametrize("seed", range(0, 150, 3))
+def test_repeat_sort_ties_vs_oracle(seed):
+    """repeat.hpp:170 with > 16 repeats of which several clamp to start 0: libstdc++'s order (finalize.hpp rep_std_sort)."""
+    p, cols = tie_case(seed)
+    want = oracle_run(p, *cols)
+    got, s = run_host(p, cols)
+    assert_same_result(got, want, f"tie case {seed}")
+
+
+# ---- config 3 at full size ---------------------------------------------------------------------------------------------
+
+def window_subproblem(o, a, b):
+    """Reads [a, b) of a symmetric set as a closed problem for the oracle: every record whose QUERY is in the window
+    (in symmetric mode a read's outputs depend on nothing else), read ids rebased, targets outside the window mapped
+    to one extra dummy read; record 0's mirror is appended on the dummy read when it is not already in the window, so
+    that the oracle's detection (chop.hpp:175-184) arrives at symmetric = 1 like the full set."""
+    import torch
+    sel = (o.qid >= a) & (o.qid < b)
+    q, qs, qe, t, ts, te = (c[sel] for c in o.columns())
+    n = b - a
+    inside = (t >= a) & (t < b)
+    rl = torch.cat([o.read_len[a:b], o.read_len.max().reshape(1)])
+    q = q - a
+    t = torch.where(inside, t - a, torch.full_like(t, n))
+    cols = [c.cpu().numpy().astype(np.int32) for c in (q, qs, qe, t, ts, te)]
+    if cols[3][0] == n:                                   # record 0's target is outside: plant its mirror on the dummy
+        cols = [np.append(c, v).astype(np.int32) for c, v in
+                zip(cols, (n, cols[4][0], cols[5][0], cols[0][0], cols[1][0], cols[2][0]))]
+    return rl.cpu().numpy().astype(np.int32), cols
+
+
+def test_config3_full_size():
+    """The bench workload (BASELINE configs[2]: 3.3 M reads, ~2.9e8 records): invariants, both interval paths, oracle on
+    three 20 k-read windows cut from the full-size result."""
+    import torch
+    from raft_amd import engine
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(3_300_000, mean_len=30000.0, coverage=32.0, seed=20241008, device="cuda:0")
+    p = RaftParams(est_cov=32)
+    eng = engine.Engine(p, device=0)
+    eng.use_torch_stream()
+    eng.run_device(o.read_len, *o.columns())
+    s = eng.finish()
+    out = eng.outputs_device()
+    assert o.n_rec > 2.5e8 and s.n_records == o.n_rec and s.symmetric == 1 and s.interval_path == 0 and s.n_segments == 2
+    nb = (o.read_len.long() + p.reso - 1) // p.reso
+    assert s.n_bins == int(nb.sum()) == s.total_windows
+    assert torch.equal(out["cov_offset"][1:], torch.cumsum(nb, 0))
+    # sum of coverage == windows touched by the intervals == total_coverage
+    touched = ((o.qe.long() - 1) // p.reso - o.qs.long() // p.reso + 1).clamp(min=0)
+    assert s.total_coverage == int(touched.sum()) == int(out["cov"].sum(dtype=torch.int64))
+    # per read too: coverage summed over a read's windows == windows touched by that read's intervals
+    per_read = torch.zeros(o.n_reads, dtype=torch.int64, device="cuda:0").index_add_(0, o.qid.long(), touched)
+    csum = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda:0"), torch.cumsum(out["cov"], 0, dtype=torch.int64)])
+    assert torch.equal(csum[out["cov_offset"][1:]] - csum[out["cov_offset"][:-1]], per_read)
+    del csum, per_read, touched
+    assert s.total_read_length == int(o.read_len.long().sum())
+    # fragments tile every read with overlap_length back-overlap; read_num is dense (row index + 1)
+    fo, fb, fe, fr = out["frag_offset"], out["frag_begin"], out["frag_end"], out["frag_read"].long()
+    assert int(fo[-1]) == s.n_fragments >= o.n_reads
+    assert bool((fb[fo[:-1]] == 0).all()) and bool((fe[fo[1:] - 1] == o.read_len).all())
+    same = fr[1:] == fr[:-1]
+    assert bool(((fe[:-1] - fb[1:])[same] == p.overlap_length).all()) and bool((fr[1:] >= fr[:-1]).all())
+    assert bool(((fr[1:] - fr[:-1])[~same] == 1).all()) and bool((fe > fb).all())
+    # repeats: inside the read, ordered, at least repeat_length long before flanking
+    ro, rs, re_ = out["rep_offset"], out["rep_s"], out["rep_e"]
+    rr = torch.repeat_interleave(torch.arange(o.n_reads, device="cuda:0"), (ro[1:] - ro[:-1]))
+    assert s.n_repeats == int(ro[-1]) > 1e5
+    assert bool((rs >= 0).all()) and bool((re_ <= o.read_len[rr]).all()) and bool((re_ - rs >= p.repeat_length).all())
+    # the oracle on three windows of 20 k reads cut out of the full-size result
+    host = {k: v.cpu().numpy() for k, v in out.items() if k != "cov"}
+    for a in (0, 1_640_000, 3_280_000):
+        b = a + 20_000
+        rl, cols = window_subproblem(o, a, b)
+        want = oracle_run(p, rl, *cols)
+        assert want["symmetric"] == 1
+        n = b - a
+        c0, c1 = int(host["cov_offset"][a]), int(host["cov_offset"][b])
+        assert np.array_equal(out["cov"][c0:c1].cpu().numpy(), want["cov"][: int(want["cov_offset"][n])]), a
+        for key, arrs in (("rep", ("rep_s", "rep_e")), ("cut", ("cuts",)), ("frag", ("frag_begin", "frag_end"))):
+            off = host[key + "_offset"]
+            assert np.array_equal(off[a:b + 1] - off[a], want[key + "_offset"][: n + 1]), (a, key)
+            for k in arrs:
+                assert np.array_equal(host[k][off[a]:off[b]], want[k][: int(want[key + "_offset"][n])]), (a, k)
+        assert np.array_equal(host["frag_read"][host["frag_offset"][a]:host["frag_offset"][b]] - a,
+                              want["frag_read"][: int(want["frag_offset"][n])])
+    # the counting-sort path on the same set: identical outputs
+    keep = {k: v.clone() for k, v in out.items()}
+    tot = (s.n_bins, s.n_repeats, s.n_cuts, s.n_fragments, s.total_coverage, s.total_repeat_length, s.total_read_length)
+    eng.set_tuning(0, True)
+    eng.run_device(o.read_len, *o.columns())
+    s2 = eng.finish()
+    out2 = eng.outputs_device()
+    assert s2.interval_path == 1 and s2.n_intervals == o.n_rec
+    assert tot == (s2.n_bins, s2.n_repeats, s2.n_cuts, s2.n_fragments, s2.total_coverage, s2.total_repeat_length, s2.total_read_length)
+    for k in keep:
+        assert torch.equal(keep[k], out2[k]), k
+    eng.close()
+
+
+# ---- config 5: ultralong reads, tandem arrays, parameter sweep ---------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def ultralong_set():
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(500, mean_len=150000.0, sigma=0.7, min_len=10000, max_len=1_500_000, coverage=60.0, seed=55,
+                      n_families=2, copies=6, rep_len=(45000, 55000))
+    return [c.numpy() for c in (o.read_len,) + o.columns()]
+
+
+@pytest.mark.parametrize("reso", [10, 50])
+@pytest.mark.parametrize("cov_mul", [1.3, 1.5, 2.0])
+@pytest.mark.parametrize("plen", [5000, 10000, 50000])
+def test_config5_parameter_sweep(ultralong_set, plen, cov_mul, reso):
+    """-p {5000,10000,50000} x -m {1.3,1.5,2.0} x -r {10,50} on a 60x / 150 kb-mean set with
+    50 kb tandem arrays at 6 copies; -r 10 puts reads of up to 150 k windows through the chunked long-read path."""
+    cols = ultralong_set
+    p = RaftParams(reso=reso, est_cov=60, cov_mul=cov_mul, repeat_length=plen, interval_length=plen, read_length=2 * plen)
+    want = oracle_run(p, *cols)
+    assert want["rep_s"].size > 0 or cov_mul == 2.0
+    got, s = run_host(p, cols)
+    assert_same_result(got, want, f"-p {plen} -m {cov_mul} -r {reso}")
+    if (plen, cov_mul) in ((5000, 1.3), (50000, 1.5)):     # the general kernel alone and the counting-sort path as well
+        got, s = run_host(p, cols, variant=1)
+        assert_same_result(got, want, f"-p {plen} -m {cov_mul} -r {reso} general kernel")
+        got, s = run_host(p, cols, force_bucket=True)
+        assert_same_result(got, want, f"-p {plen} -m {cov_mul} -r {reso} counting sort")

@@ -76,6 +76,19 @@ def test_synthetic_cases_md5(tmp_path, name):
         assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, (name, f)
 
 
+def test_config1_gz_inputs_md5(tmp_path):
+    """BASELINE configs[0] stand-in: gz FASTA + gz PAF through the host readers (zlib path), oracle in between,
+    writers -> the md5 of the four files the reference wrote for the same gz inputs."""
+    from raft_testlib import load_config1, write_config1_inputs
+    p, cols, exp, meta = load_config1()
+    write_config1_inputs(str(tmp_path), cols, meta)
+    reads, got_cols, res = run_text_case(tmp_path, tmp_path / "reads.fa.gz", tmp_path / "overlaps.paf.gz", p, "fragmented")
+    for a, b in zip(got_cols, cols[1:]):
+        assert np.array_equal(a, b)
+    for f, digest in meta["md5"].items():
+        assert md5(open(tmp_path / ("fragmented." + f), "rb").read()) == digest, f
+
+
 def test_fastq_and_odd_fasta(tmp_path):
     fq = tmp_path / "r.fq"
     fq.write_text("@q1 some comment\nACGTAC\nGT\n+q1\nIIIIII\nII\n@q2\nAAAA\n+\n!!!!\n>f3\tx\nCC\r\n\r\nGG\r\n")

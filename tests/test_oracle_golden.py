@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 from raft_testlib import (GOLDEN, OracleError, RaftParams, assert_same_result, have_ref_lib, oracle_run,
-                          parse_coverage_txt, parse_fasta_headers, parse_long_repeats, ref_lib_run)
+                          parse_coverage_txt, parse_fasta_headers, parse_long_repeats, ref_lib_run, tie_case)
 
 MAN = json.load(open(os.path.join(GOLDEN, "manifest.json")))
 SYNTH = sorted(MAN["synthetic"])
@@ -131,7 +131,7 @@ def test_oracle_defined_errors():
 
 
 @pytest.mark.skipif(not have_ref_lib(), reason="oracle/_ref/libraft_ref.so not built (needs /root/reference)")
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(600))
 def test_oracle_vs_reference_code_fuzz(seed):
     """Differential fuzz against profileCoverage/repeat_annotate of the unmodified reference, in-process."""
     rng = np.random.default_rng(seed)
@@ -167,3 +167,53 @@ def test_oracle_vs_reference_code_fuzz(seed):
     assert got["symmetric"] == ref["symmetric"]
     for k in ("cov", "rep_offset", "rep_s", "rep_e"):
         assert np.array_equal(got[k], ref[k]), k
+
+
+@pytest.mark.skipif(not have_ref_lib(), reason="oracle/_ref/libraft_ref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", range(150))
+def test_oracle_repeat_sort_ties_vs_reference_code(seed):
+    """repeat.hpp:170 with tied starts and > 16 repeats: the oracle's restated libstdc++ introsort against the real
+    std::sort inside the unmodified repeat_annotate()."""
+    p, cols = tie_case(seed)
+    got = oracle_run(p, *cols)
+    ref = ref_lib_run(p, *cols)
+    for k in ("cov", "rep_offset", "rep_s", "rep_e"):
+        assert np.array_equal(got[k], ref[k]), k
+
+
+def test_tie_cases_do_permute():
+    """The tie fixture is not vacuous: in some seeds the order differs from the stable (emission) order."""
+    permuted = 0
+    for seed in range(150):
+        p, cols = tie_case(seed)
+        got = oracle_run(p, *cols)
+        for r in range(len(cols[0])):
+            e = got["rep_e"][got["rep_offset"][r]:got["rep_offset"][r + 1]]
+            s = got["rep_s"][got["rep_offset"][r]:got["rep_offset"][r + 1]]
+            assert np.all(np.diff(s) >= 0)
+            if np.any(np.diff(e) < 0):
+                permuted += 1
+    assert permuted >= 10, permuted
+
+
+def test_oracle_vs_reference_binary_fuzz():
+    """tests/golden/ref_fuzz.npz: 320 random text inputs run through the unmodified reference BINARY (make_ref_fuzz.py):
+    coverage, repeats (incl. the std::sort tie corner), fragment bounds / read_num and the stdout statistics."""
+    from raft_testlib import assert_matches_ref_fuzz, ref_fuzz_case, ref_fuzz_count
+    assert ref_fuzz_count() >= 200
+    for i in range(ref_fuzz_count()):
+        p, cols, exp = ref_fuzz_case(i)
+        assert_matches_ref_fuzz(oracle_run(p, *cols), exp, p, f"ref_fuzz case {i}")
+
+
+def test_oracle_config1_standin():
+    """BASELINE configs[0] restated: 2 Mbp / 42x / -e 42; expected arrays parsed from the files the
+    reference binary wrote for the gz inputs."""
+    from raft_testlib import load_config1
+    p, cols, exp, meta = load_config1()
+    got = oracle_run(p, *cols)
+    assert got["symmetric"] == meta["symmetric"] == 1 and len(cols[1]) == meta["n_rec"]
+    for k in EXP_KEYS:
+        assert np.array_equal(got[k], exp[k]), k
+    assert "coverage per window is %f \n" % (got["total_coverage"] / got["total_windows"]) in meta["stdout"]
+    assert "fraction_of_repeat_length %f \n" % (got["total_repeat_length"] / got["total_read_length"]) in meta["stdout"]
