@@ -71,7 +71,7 @@ typedef struct raft_hip_summary {
     int32_t symmetric;          /* resolved algoParams::symmetric_overlaps (chop.hpp:189) */
     int32_t high_cov;           /* repeat.hpp:90-91 */
     int32_t interval_path;      /* 0 = sorted-segment fast path (records already grouped by ascending query id in
-                                   <= 8 runs, query side only); 1 = counting-sort bucketing path */
+                                   <= 4 runs, query side only); 1 = counting-sort bucketing path */
     int32_t n_segments;         /* sorted runs found in the record stream (fast path) */
     int64_t n_records;          /* PAF records consumed ("length of alignments", chop.hpp:190) */
     int64_t n_intervals;        /* intervals piled up (query sides + target sides when not symmetric) */
@@ -81,7 +81,10 @@ typedef struct raft_hip_summary {
     int64_t total_windows;      /* repeat.hpp:95,117 (int in the reference; int64 here) */
     int64_t total_repeat_length;/* repeat.hpp:96,127,152 */
     int64_t total_read_length;  /* repeat.hpp:97,101 */
-    int64_t error_index;        /* record or read index that raised the returned error, -1 if none */
+    int64_t error_index;        /* what raised the returned error, -1 if none: the read index for a negative length or
+                                   RAFT_HIP_ERR_FRAGMENT; the PAF record index for RAFT_HIP_ERR_READ_ID and, on the
+                                   sorted-segment path, RAFT_HIP_ERR_COORD; on the counting-sort path (interval_path
+                                   == 1) RAFT_HIP_ERR_COORD reports the index into the BUCKETED interval array */
 } raft_hip_summary;
 
 /* Device-resident outputs of the last run (valid until the next run/destroy).
@@ -133,7 +136,8 @@ int  raft_hip_run_device(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *d_re
                          int64_t n_rec, const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
                          const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te);
 
-/* Same pass from host memory: stages the seven columns to the device first. */
+/* Same pass from host memory: stages the columns to the device first.  With symmetric_mode = 1 only read_len and the
+ * three query columns are uploaded; tid/ts/te are not read and may be NULL (also in raft_hip_run_device). */
 int  raft_hip_run_host(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_len,
                        int64_t n_rec, const int32_t *qid, const int32_t *qs, const int32_t *qe,
                        const int32_t *tid, const int32_t *ts, const int32_t *te);
@@ -151,6 +155,16 @@ int  raft_hip_fetch(raft_hip_ctx *ctx, int64_t *cov_offset, int32_t *cov,
                     int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
                     int64_t *cut_offset, int32_t *cuts,
                     int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end);
+
+/* The same outputs with the coverage array in its transfer encoding: one byte per window, cov8[i] = min(cov[i], 255),
+ * plus the windows with cov >= 255 as (exc_index, exc_value) pairs, ascending by window index (cov[] is two thirds of
+ * the bytes that cross PCIe; the reference's consumer is the text formatter of repeat.hpp:105-108, which
+ * raft_host_write_coverage_packed() serves from this form; raft_host_unpack_coverage() restores the int32 array).
+ * *n_exc receives the number of exceptions; when it exceeds exc_cap nothing is copied and RAFT_HIP_ERR_TOO_LARGE is
+ * returned -- call again with larger arrays.  Any pointer except n_exc may be NULL to skip that array. */
+int  raft_hip_fetch_packed(raft_hip_ctx *ctx, int64_t *cov_offset, uint8_t *cov8, int64_t exc_cap, int64_t *exc_index,
+                           int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
+                           int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end);
 
 /* Device seconds spent in the dominant kernel (coverage pileup + run scan) and
  * in all kernels of the last finished pass, from HIP events recorded on the

@@ -37,7 +37,7 @@ typedef struct raft_host_reads raft_host_reads;
 typedef struct raft_host_paf raft_host_paf;
 
 /* Worker threads used by the loaders and writers below (the reference is single-threaded; output bytes do not
- * depend on the count).  Default: RAFT_HOST_THREADS, else the hardware threads, capped at 32.  n = 0 restores the
+ * depend on the count).  Default: RAFT_HOST_THREADS, else the hardware threads, capped at 128.  n = 0 restores the
  * default, n = 1 runs everything on the calling thread. */
 int            raft_host_set_threads(int n);
 int            raft_host_get_threads(void);
@@ -57,6 +57,18 @@ int            raft_host_paf_load(const char *path, const raft_host_reads *reads
 void           raft_host_paf_free(raft_host_paf *p);
 int64_t        raft_host_paf_count(const raft_host_paf *p);                /* accepted records */
 const int32_t *raft_host_paf_column(const raft_host_paf *p, int k);        /* k: 0 qid 1 qs 2 qe 3 tid 4 ts 5 te */
+
+/* algoParams::symmetric_overlaps as create_pileup leaves it (chop.hpp:171-184): 1 when some accepted record after the
+ * first mirrors the first.  Found while the lines are tokenised; passed to the engine as symmetric_mode, which then
+ * neither runs its own detection nor needs the three target columns. */
+int            raft_host_paf_symmetric(const raft_host_paf *p);
+
+/* Coverage in the engine's transfer encoding (raft_hip_fetch_packed: one byte per window, 255 = look up the ascending
+ * exception list): back to int32, and straight to coverage.txt (repeat.hpp:105-108) without the int32 detour. */
+int raft_host_unpack_coverage(int64_t n_bins, const uint8_t *cov8, int64_t n_exc, const int64_t *exc_index,
+                              const int32_t *exc_value, int32_t *cov);
+int raft_host_write_coverage_packed(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset,
+                                    const uint8_t *cov8, int64_t n_exc, const int64_t *exc_index, const int32_t *exc_value);
 
 /* writers (CSR arrays as returned by raft_hip_fetch) */
 int raft_host_write_coverage(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset, const int32_t *cov);

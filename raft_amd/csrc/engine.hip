@@ -6,6 +6,7 @@
 #include "bucket.hpp"
 #include "device_scan.hpp"
 #include "finalize.hpp"
+#include "pack.hpp"
 #include "pileup.hpp"
 #include "pileup_fast.hpp"
 
@@ -15,6 +16,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 using namespace raft;
 
@@ -156,6 +159,9 @@ struct raft_hip_ctx {
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
     DevBuf dbg;                       // diagnostic variant only
+    DevBuf cov8, exc_idx, exc_val, exc_cnt;   // transfer encoding of cov[] (raft_hip_fetch_packed)
+    bool packed_ready = false;
+    long long n_exc = 0, exc_cap = 0;
     long long dbg_tiles = 0;
     void *pinned = nullptr;           // small pinned scratch for readbacks
     hipEvent_t ev_pass0 = nullptr, ev_pass1 = nullptr, ev_pile0 = nullptr, ev_pile1 = nullptr;
@@ -277,7 +283,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->dbg, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -335,12 +341,17 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     if (!c) return RAFT_HIP_ERR_PARAM;
     if (n_reads < 0 || n_rec < 0) return RAFT_HIP_ERR_PARAM;
     if (n_reads > 0 && !d_len) return RAFT_HIP_ERR_PARAM;
-    if (n_rec > 0 && (!d_qid || !d_qs || !d_qe || !d_tid || !d_ts || !d_te)) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && (!d_qid || !d_qs || !d_qe)) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && (!d_tid || !d_ts || !d_te)) {
+        // symmetric_mode = 1: the target columns are never read (query sides only, no detection) and may be omitted
+        if (c->prm.symmetric_mode != 1) return RAFT_HIP_ERR_PARAM;
+        d_tid = d_qid; d_ts = d_qs; d_te = d_qe;
+    }
     if (n_reads == INT32_MAX) return RAFT_HIP_ERR_TOO_LARGE;
     if (n_rec >= (1LL << 29)) return RAFT_HIP_ERR_TOO_LARGE;   // interval byte offsets are 32-bit (2 sides per record at most)
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1;
+    c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1; c->packed_ready = false;
     memset(&c->sum, 0, sizeof c->sum);
     c->sum.n_reads = n_reads; c->sum.n_records = n_rec; c->sum.high_cov = c->high_cov; c->sum.error_index = -1;
     const long long N = n_reads;
@@ -598,19 +609,23 @@ int raft_hip_run_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len,
     if (!c) return RAFT_HIP_ERR_PARAM;
     if (n_reads < 0 || n_rec < 0) return RAFT_HIP_ERR_PARAM;
     if (n_reads > 0 && !read_len) return RAFT_HIP_ERR_PARAM;
-    if (n_rec > 0 && (!qid || !qs || !qe || !tid || !ts || !te)) return RAFT_HIP_ERR_PARAM;
+    // With symmetric_mode = 1 (the tokeniser saw the mirror of record 0, chop.hpp:175-184) only the query side is piled
+    // up: the three target columns are neither needed nor uploaded (half of the H2D bytes) and may be NULL.
+    const int n_cols = c->prm.symmetric_mode == 1 ? 3 : 6;
+    if (n_rec > 0 && (!qid || !qs || !qe || (n_cols == 6 && (!tid || !ts || !te)))) return RAFT_HIP_ERR_PARAM;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     HIP_TRY(c, c->in_len.ensure((size_t)std::max<long long>(n_reads, 1) * 4));
     if (n_reads) HIP_TRY(c, hipMemcpyAsync(c->in_len.p, read_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
     const int32_t *src[6] = {qid, qs, qe, tid, ts, te};
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < n_cols; ++k) {
         HIP_TRY(c, c->in_col[k].ensure((size_t)std::max<long long>(n_rec, 1) * 4));
         if (n_rec) HIP_TRY(c, hipMemcpyAsync(c->in_col[k].p, src[k], (size_t)n_rec * 4, hipMemcpyHostToDevice, st));
     }
+    const bool six = n_cols == 6;
     return raft_hip_run_device(c, n_reads, c->in_len.as<int32_t>(), n_rec, c->in_col[0].as<int32_t>(),
-                               c->in_col[1].as<int32_t>(), c->in_col[2].as<int32_t>(), c->in_col[3].as<int32_t>(),
-                               c->in_col[4].as<int32_t>(), c->in_col[5].as<int32_t>());
+                               c->in_col[1].as<int32_t>(), c->in_col[2].as<int32_t>(), six ? c->in_col[3].as<int32_t>() : nullptr,
+                               six ? c->in_col[4].as<int32_t>() : nullptr, six ? c->in_col[5].as<int32_t>() : nullptr);
 }
 
 int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
@@ -684,8 +699,70 @@ int raft_hip_fetch(raft_hip_ctx *c, int64_t *cov_offset, int32_t *cov, int64_t *
         {cuts, c->cuts.p, (size_t)c->sum.n_cuts * 4}, {frag_offset, c->frag_off.p, N1 * 8},
         {frag_read, c->frag_read.p, (size_t)c->sum.n_fragments * 4}, {frag_begin, c->frag_begin.p, (size_t)c->sum.n_fragments * 4},
         {frag_end, c->frag_end.p, (size_t)c->sum.n_fragments * 4}};
+    for (auto &j : job)                            // all copies queued on the context's stream, one wait
+        if (j.dst && j.bytes) HIP_TRY(c, hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RAFT_HIP_OK;
+}
+
+// cov[] -> one byte per window + exception list (pack.hpp), on the device, once per pass
+static int pack_coverage(raft_hip_ctx *c)
+{
+    if (c->packed_ready) return RAFT_HIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const long long B = c->sum.n_bins;
+    HIP_TRY(c, c->cov8.ensure((size_t)std::max(B, 1LL)));
+    HIP_TRY(c, c->exc_cnt.ensure(8));
+    long long cap = std::max<long long>(c->exc_cap, std::max<long long>(4096, B / 512));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(c, c->exc_idx.ensure((size_t)cap * 8));
+        HIP_TRY(c, c->exc_val.ensure((size_t)cap * 4));
+        c->exc_cap = cap;
+        HIP_TRY(c, hipMemsetAsync(c->exc_cnt.p, 0, 8, c->stream));
+        if (B > 0) {
+            const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((B / 4 + 1023) / 1024, 256 * 16));
+            PackOut po{c->cov8.as<uint8_t>(), c->exc_cnt.as<unsigned long long>(), cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>()};
+            hipLaunchKernelGGL(pack_cov_kernel, dim3(grid), dim3(256), 0, c->stream, c->cov.as<int32_t>(), B, po);
+            HIP_TRY(c, hipGetLastError());
+        }
+        long long *h = reinterpret_cast<long long *>(c->pinned) + 16;
+        HIP_TRY(c, hipMemcpyAsync(h, c->exc_cnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->n_exc = *h;
+        if (c->n_exc <= cap) break;
+        cap = c->n_exc;                              // (rare) more windows at or above 255 than the list held: once more
+    }
+    c->packed_ready = true;
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_fetch_packed(raft_hip_ctx *c, int64_t *cov_offset, uint8_t *cov8, int64_t exc_cap, int64_t *exc_index,
+                          int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
+                          int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end)
+{
+    if (!c || !n_exc) return RAFT_HIP_ERR_PARAM;
+    if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
+    { const int rc = pack_coverage(c); if (rc != RAFT_HIP_OK) return rc; }
+    *n_exc = c->n_exc;
+    if (c->n_exc > exc_cap && cov8) return RAFT_HIP_ERR_TOO_LARGE;   // *n_exc tells the caller what to provide
+    const size_t N1 = (size_t)c->sum.n_reads + 1;
+    struct { void *dst; const void *src; size_t bytes; } job[] = {
+        {cov8, c->cov8.p, (size_t)c->sum.n_bins}, {cov_offset, c->cov_off.p, N1 * 8},
+        {exc_index, c->exc_idx.p, (size_t)c->n_exc * 8}, {exc_value, c->exc_val.p, (size_t)c->n_exc * 4},
+        {rep_offset, c->rep_off.p, N1 * 8}, {rep_s, c->rep_s.p, (size_t)c->sum.n_repeats * 4},
+        {rep_e, c->rep_e.p, (size_t)c->sum.n_repeats * 4}, {frag_offset, c->frag_off.p, N1 * 8},
+        {frag_read, c->frag_read.p, (size_t)c->sum.n_fragments * 4}, {frag_begin, c->frag_begin.p, (size_t)c->sum.n_fragments * 4},
+        {frag_end, c->frag_end.p, (size_t)c->sum.n_fragments * 4}};
     for (auto &j : job)
-        if (j.dst && j.bytes) HIP_TRY(c, hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost));
+        if (j.dst && j.bytes) HIP_TRY(c, hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the kernel appends exceptions in no particular order: hand them out ascending by window
+    if (exc_index && exc_value && c->n_exc > 1) {
+        std::vector<std::pair<int64_t, int32_t>> ex((size_t)c->n_exc);
+        for (size_t i = 0; i < ex.size(); ++i) ex[i] = {exc_index[i], exc_value[i]};
+        std::sort(ex.begin(), ex.end());
+        for (size_t i = 0; i < ex.size(); ++i) { exc_index[i] = ex[i].first; exc_value[i] = ex[i].second; }
+    }
     return RAFT_HIP_OK;
 }
 

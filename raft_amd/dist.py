@@ -9,8 +9,8 @@ counter read_num (chop.hpp:195) and the four stdout sums (repeat.hpp:93-97).
 Two ways to get each rank its intervals:
   * host-routed (default, no collective): whoever tokenises the PAF knows the owner of every interval.
   * pre-split PAF (BASELINE configs[3]): rank g holds an arbitrary contiguous slice of the records.  It
-    expands them to intervals, buckets them by owner and ONE all-to-all-v (RCCL over xGMI when the
-    tensors are on GPUs, gloo on CPU) delivers them.  xGMI is point-to-point, every ordered pair has its
+    expands them to intervals, buckets them by owner and ONE exchange step -- an all-to-all-v per int32 column (RCCL over xGMI
+    when the tensors are on GPUs, gloo on CPU) -- delivers them.  xGMI is point-to-point, every ordered pair has its
     own link, so the exchange is a single step of n*(n-1) independent transfers.
 
 Everything here is tensor plumbing (torch ops + torch.distributed); the per-rank compute is the HIP
@@ -85,7 +85,7 @@ def route_intervals_host(cols, bounds: torch.Tensor, symmetric: bool):
 
 
 def exchange_intervals(cols_local, bounds: torch.Tensor, symmetric: bool, group=None):
-    """Pre-split mode: one all-to-all-v routes this rank's intervals to the ranks owning their reads.
+    """Pre-split mode: one exchange step (all-to-all-v of the three columns) routes this rank's intervals to their owners.
 
     Returns (local_read, start, end) of the intervals this rank owns, as int32 tensors on the input device."""
     import torch.distributed as dist
@@ -99,10 +99,14 @@ def exchange_intervals(cols_local, bounds: torch.Tensor, symmetric: bool, group=
     recv_counts = torch.empty_like(send_counts)
     dist.all_to_all_single(recv_counts, send_counts, group=group)
     sc, rc = send_counts.tolist(), recv_counts.tolist()
-    payload = torch.stack([rid[order], s[order], e[order]], dim=1).contiguous()       # [n, 3] int32, grouped by owner
-    got = torch.empty((int(sum(rc)), 3), dtype=torch.int32, device=dev)
-    dist.all_to_all_single(got, payload, output_split_sizes=rc, input_split_sizes=sc, group=group)
-    return (got[:, 0] - int(bounds[rank])).contiguous(), got[:, 1].contiguous(), got[:, 2].contiguous()
+    n_recv = int(sum(rc))
+    out = []
+    for col in (rid, s, e):                              # SoA stays SoA: one all-to-all-v per int32 column
+        got = torch.empty(n_recv, dtype=torch.int32, device=dev)
+        dist.all_to_all_single(got, col[order].contiguous(), output_split_sizes=rc, input_split_sizes=sc, group=group)
+        out.append(got)
+    out[0] -= int(bounds[rank])                          # read ids local to this rank's range
+    return tuple(out)
 
 
 def global_symmetric_flag(cols_local, group=None) -> bool:

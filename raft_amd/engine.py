@@ -23,7 +23,7 @@ EXPORTS = (
     "raft_hip_abi_version", "raft_hip_strerror", "raft_hip_last_error", "raft_hip_create", "raft_hip_destroy",
     "raft_hip_set_params", "raft_hip_set_stream", "raft_hip_use_own_stream", "raft_hip_get_stream", "raft_hip_run_device", "raft_hip_run_host",
     "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
-    "raft_hip_selftest", "raft_hip_debug_stamps",
+    "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed",
 )
 
 
@@ -113,6 +113,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_finish.argtypes = [vp, C.POINTER(_Summary)]
     lib.raft_hip_outputs_device.argtypes = [vp, C.POINTER(_Outputs)]
     lib.raft_hip_fetch.argtypes = [vp] + [vp] * 11
+    lib.raft_hip_fetch_packed.argtypes = [vp, vp, vp, i64, vp, vp, C.POINTER(i64)] + [vp] * 7
     lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.raft_hip_set_tuning.argtypes = [vp, i32, i32, i32]
     lib.raft_hip_selftest.argtypes = [C.c_int]
@@ -196,14 +197,15 @@ class Engine:
         ptr = [C.c_void_p(t.data_ptr() if t.numel() else 0) for t in cols]
         self._check(self._lib.raft_hip_run_device(self._ctx, int(read_len.numel()), ptr[0], n_rec, *ptr[1:]))
 
-    def run_host(self, read_len, qid, qs, qe, tid, ts, te):
-        cols = [np.ascontiguousarray(np.asarray(a), dtype=np.int32) for a in (read_len, qid, qs, qe, tid, ts, te)]
+    def run_host(self, read_len, qid, qs, qe, tid=None, ts=None, te=None):
+        """tid/ts/te may be None when the params assert symmetric_mode = 1 (they are then neither read nor uploaded)."""
+        cols = [None if a is None else np.ascontiguousarray(np.asarray(a), dtype=np.int32) for a in (read_len, qid, qs, qe, tid, ts, te)]
         n_rec = cols[1].size
         for a in cols[2:]:
-            if a.size != n_rec:
+            if a is not None and a.size != n_rec:
                 raise ValueError("PAF columns differ in length")
         self._keep = cols
-        ptr = [C.c_void_p(a.ctypes.data if a.size else 0) for a in cols]
+        ptr = [C.c_void_p(a.ctypes.data if (a is not None and a.size) else 0) for a in cols]
         self._check(self._lib.raft_hip_run_host(self._ctx, cols[0].size, ptr[0], n_rec, *ptr[1:]))
 
     def finish(self) -> Summary:
@@ -254,6 +256,41 @@ class Engine:
         ptr = [C.c_void_p(out[k].ctypes.data if out[k].size else 0) for k in order]
         self._check(self._lib.raft_hip_fetch(self._ctx, *ptr))
         return out
+
+    def fetch_packed(self, pinned: bool = False, out: dict | None = None) -> dict:
+        """Host copies with the coverage array in its transfer encoding (raft_hip_fetch_packed): ``cov8`` (uint8 per
+        window, 255 = see exceptions), ``exc_index`` / ``exc_value`` (ascending), and the repeat / fragment tables.
+        ``out``: arrays of an earlier call to reuse (pinned buffers kept by the caller)."""
+        s = self.summary
+        n1 = s.n_reads + 1
+        n_exc = C.c_int64(0)
+        none = [C.c_void_p(0)] * 7
+        rc = self._lib.raft_hip_fetch_packed(self._ctx, None, None, 0, None, None, C.byref(n_exc), *none)
+        self._check(rc)
+        spec = {"cov_offset": (n1, np.int64), "cov8": (s.n_bins, np.uint8), "exc_index": (n_exc.value, np.int64),
+                "exc_value": (n_exc.value, np.int32), "rep_offset": (n1, np.int64), "rep_s": (s.n_repeats, np.int32),
+                "rep_e": (s.n_repeats, np.int32), "frag_offset": (n1, np.int64), "frag_read": (s.n_fragments, np.int32),
+                "frag_begin": (s.n_fragments, np.int32), "frag_end": (s.n_fragments, np.int32)}
+
+        def alloc(n, dt):
+            if pinned and n:
+                import torch
+                tdt = {np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8}[dt]
+                return torch.empty(int(n), dtype=tdt, pin_memory=True).numpy()
+            return np.empty(n, dt)
+
+        res = {}
+        for key, (n, dt) in spec.items():
+            have = out.get(key) if out else None
+            if have is not None and have.dtype == dt and have.size >= n and have.flags["C_CONTIGUOUS"]:
+                res[key] = have[:n]
+            else:
+                res[key] = alloc(n, dt)
+        ptr = {k: C.c_void_p(res[k].ctypes.data if res[k].size else 0) for k in res}
+        self._check(self._lib.raft_hip_fetch_packed(self._ctx, ptr["cov_offset"], ptr["cov8"], n_exc.value, ptr["exc_index"],
+                                                    ptr["exc_value"], C.byref(n_exc), ptr["rep_offset"], ptr["rep_s"], ptr["rep_e"],
+                                                    ptr["frag_offset"], ptr["frag_read"], ptr["frag_begin"], ptr["frag_end"]))
+        return res
 
     def debug_stamps(self, max_tiles: int = 1 << 20) -> np.ndarray:
         """Diagnostic kernel variant 3: per-tile s_memtime stamps [n, 16] of the last pass."""

@@ -33,7 +33,7 @@
 
 namespace {
 
-// Worker threads of the host layer: RAFT_HOST_THREADS (default: hardware threads, at most 32).  1 = everything
+// Worker threads of the host layer: RAFT_HOST_THREADS (default: hardware threads, at most kMaxThreads = 128).  1 = everything
 // inline on the calling thread (the reference's own behaviour; used by tests to cross-check the parallel paths).
 constexpr int kMaxThreads = 128;
 std::atomic<int> g_threads{0};   // 0 = not chosen yet
@@ -283,6 +283,7 @@ struct raft_host_reads {
 struct raft_host_paf {
     std::unique_ptr<int32_t[]> col[6];   // allocated untouched: the workers' copies are the first writes
     size_t n = 0;
+    int symmetric = 0;                   // chop.hpp:175-184: some record after the first mirrors the first
 };
 
 namespace {
@@ -564,8 +565,48 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
     char *const data = data_buf.get();
     // Lines are independent: the buffer is cut at newlines into one chunk per thread, each chunk is tokenised into
     // its own columns (paf.hpp:50-87 rules), and the chunks are concatenated in file order.
-    struct Chunk { std::vector<int32_t> col[6]; size_t err_pos = (size_t)-1; std::string err_name; };
+    struct Chunk { std::vector<int32_t> col[6]; size_t err_pos = (size_t)-1; std::string err_name; bool mirror = false; };
     const size_t total = data_n;
+    auto num = [](const char *s) -> int32_t {
+        // paf.hpp:64-75 -> chop.hpp:157-160: strtol, then uint32, then int.  Plain runs of up to 18 digits (every
+        // real PAF field) take the short loop -- the value is the same, without glibc's locale and range machinery;
+        // anything else (blanks, signs, overflow) goes to strtol itself.
+        unsigned long long v = 0;
+        int n = 0;
+        while (s[n] >= '0' && s[n] <= '9' && n < 19) { v = v * 10 + (unsigned)(s[n] - '0'); ++n; }
+        if (n == 0 || n == 19) return (int32_t)(uint32_t)strtol(s, nullptr, 10);
+        return (int32_t)(uint32_t)v;       // trailing garbage ends the number, as in strtol
+    };
+    // Record 0 (the first accepted line), read ahead without touching the buffer: every worker compares its records
+    // with it while they are in registers, which is the reference's symmetric-PAF detection (chop.hpp:171-184) at no
+    // extra pass over the columns.  The engine is then told the flag and neither detects nor uploads target columns.
+    bool have0 = false;
+    size_t rec0_pos = 0;
+    int32_t r0[6] = {0, 0, 0, 0, 0, 0};
+    for (size_t pos = 0; pos < total && !have0;) {
+        const char *line = data + pos;
+        const char *nl = (const char *)memchr(line, '\n', total - pos);
+        if (!nl) break;
+        size_t len = (size_t)(nl - line);
+        const size_t line_pos = pos;
+        pos += len + 1;
+        if (len > 1 && line[len - 1] == '\r') --len;
+        std::string f[9];
+        int nf = 0;
+        size_t b = 0;
+        for (size_t i = 0; i <= len; ++i) {
+            if (i < len && line[i] != '\t') continue;
+            if (nf < 9) f[nf].assign(line + b, i - b);
+            ++nf;
+            b = i + 1;
+        }
+        if (nf < 10) continue;
+        const int32_t a = reads->names.find(f[0].data(), f[0].size()), t = reads->names.find(f[5].data(), f[5].size());
+        if (a < 0 || t < 0) break;                       // the tokenising pass reports the unknown name
+        r0[0] = a; r0[1] = num(f[2].c_str()); r0[2] = num(f[3].c_str()); r0[3] = t; r0[4] = num(f[7].c_str()); r0[5] = num(f[8].c_str());
+        rec0_pos = line_pos;
+        have0 = true;
+    }
     int T = host_threads();
     if (total < (1u << 20)) T = 1;
     std::vector<size_t> cut((size_t)T + 1, total);
@@ -617,18 +658,12 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
             const int32_t a = resolve(fld[0], fl[0], lastq, lastq_n, lastq_id);
             const int32_t b = resolve(fld[5], fl[5], lastt, lastt_n, lastt_id);
             if (a < 0 || b < 0) { C.err_pos = line_pos; C.err_name = a < 0 ? fld[0] : fld[5]; break; }
-            // paf.hpp:64-75 -> chop.hpp:157-160: strtol, then uint32, then int.  Plain runs of up to 18 digits (every
-            // real PAF field) take the short loop -- the value is the same, without glibc's locale and range machinery;
-            // anything else (blanks, signs, overflow) goes to strtol itself.
-            auto num = [](const char *s) -> int32_t {
-                unsigned long long v = 0;
-                int n = 0;
-                while (s[n] >= '0' && s[n] <= '9' && n < 19) { v = v * 10 + (unsigned)(s[n] - '0'); ++n; }
-                if (n == 0 || n == 19) return (int32_t)(uint32_t)strtol(s, nullptr, 10);
-                return (int32_t)(uint32_t)v;       // trailing garbage ends the number, as in strtol
-            };
-            C.col[0].push_back(a); C.col[1].push_back(num(fld[2])); C.col[2].push_back(num(fld[3]));
-            C.col[3].push_back(b); C.col[4].push_back(num(fld[7])); C.col[5].push_back(num(fld[8]));
+            const int32_t v_qs = num(fld[2]), v_qe = num(fld[3]), v_ts = num(fld[7]), v_te = num(fld[8]);
+            C.col[0].push_back(a); C.col[1].push_back(v_qs); C.col[2].push_back(v_qe);
+            C.col[3].push_back(b); C.col[4].push_back(v_ts); C.col[5].push_back(v_te);
+            if (have0 && a == r0[3] && b == r0[0] && v_ts == r0[1] && v_te == r0[2] && v_qs == r0[4] && v_qe == r0[5] &&
+                line_pos != rec0_pos)
+                C.mirror = true;
         }
     });
     int rc = RAFT_HOST_OK;
@@ -643,6 +678,7 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
     std::vector<size_t> off((size_t)T + 1, 0);
     for (int t = 0; t < T; ++t) off[(size_t)t + 1] = off[(size_t)t] + chunks[(size_t)t].col[0].size();
     P->n = off[(size_t)T];
+    for (const Chunk &C : chunks) if (C.mirror) P->symmetric = 1;
     for (int k = 0; k < 6; ++k) P->col[k].reset(new int32_t[P->n ? P->n : 1]);
     parallel_for(T, [&](int t) {
         for (int k = 0; k < 6; ++k)
@@ -656,6 +692,43 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
 void raft_host_paf_free(raft_host_paf *p) { delete p; }
 int64_t raft_host_paf_count(const raft_host_paf *p) { return p ? (int64_t)p->n : 0; }
 const int32_t *raft_host_paf_column(const raft_host_paf *p, int k) { return (p && k >= 0 && k < 6) ? p->col[k].get() : nullptr; }
+int raft_host_paf_symmetric(const raft_host_paf *p) { return p ? p->symmetric : 0; }
+
+// cov8/exceptions (raft_hip_fetch_packed) -> the int32 coverage array
+int raft_host_unpack_coverage(int64_t n_bins, const uint8_t *cov8, int64_t n_exc, const int64_t *exc_index,
+                              const int32_t *exc_value, int32_t *cov)
+{
+    if (n_bins < 0 || n_exc < 0 || (n_bins && (!cov8 || !cov)) || (n_exc && (!exc_index || !exc_value))) return RAFT_HOST_ERR_ARG;
+    const int T = n_bins < (1 << 22) ? 1 : host_threads();
+    parallel_for(T, [&](int t) {
+        const int64_t lo = n_bins * t / T, hi = n_bins * (t + 1) / T;
+        for (int64_t i = lo; i < hi; ++i) cov[i] = cov8[i];
+    });
+    for (int64_t k = 0; k < n_exc; ++k) {
+        if (exc_index[k] < 0 || exc_index[k] >= n_bins || cov8[exc_index[k]] != 255) return RAFT_HOST_ERR_ARG;
+        cov[exc_index[k]] = exc_value[k];
+    }
+    return RAFT_HOST_OK;
+}
+
+// repeat.hpp:105-108 from the packed form: a byte of 255 stands for the next entry of the (ascending) exception list
+int raft_host_write_coverage_packed(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset,
+                                    const uint8_t *cov8, int64_t n_exc, const int64_t *exc_index, const int32_t *exc_value)
+{
+    return write_ordered(path, n_reads, 1 << 20,
+                         [&](long long i) { return (long long)(cov_offset[i + 1] - cov_offset[i]) + 4; },
+                         [&](long long i, std::string &o) {
+                             o.append("read ", 5); put_num(o, i); o.push_back(' ');
+                             const int64_t b = cov_offset[i], e = cov_offset[i + 1];
+                             const int64_t *x = n_exc ? std::lower_bound(exc_index, exc_index + n_exc, b) : exc_index;
+                             for (int64_t j = b; j < e; ++j) {
+                                 long long v = cov8[j];
+                                 if (v == 255) { v = exc_value[x - exc_index]; ++x; }
+                                 put_num(o, (long long)(j - b) * reso); o.push_back(','); put_num(o, v); o.push_back(' ');
+                             }
+                             o.push_back('\n');
+                         });
+}
 
 // repeat.hpp:105-108: "read <i> " then "<pos>,<cov> " per window, then newline
 int raft_host_write_coverage(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset, const int32_t *cov)

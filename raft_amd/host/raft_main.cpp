@@ -16,6 +16,8 @@
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <memory>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -146,9 +148,16 @@ int main(int argc, char *argv[])
     if (create_rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_create(), ") + raft_hip_strerror(create_rc));
     stage("device_wait");
 
+    // The tokeniser already knows whether the PAF is symmetric (chop.hpp:171-184, found while the lines were in
+    // registers): the engine is told, so it neither scans for the mirror of record 0 nor -- for a symmetric PAF -- is
+    // handed the target columns at all (half of the upload).
+    hp.symmetric_mode = raft_host_paf_symmetric(paf) ? 1 : 0;
+    rc = raft_hip_set_params(ctx, &hp);
+    if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_set_params(), ") + raft_hip_strerror(rc));
+    const bool sym = hp.symmetric_mode == 1;
     rc = raft_hip_run_host(ctx, n_reads, raft_host_reads_lengths(reads), n_rec, raft_host_paf_column(paf, 0),
-                           raft_host_paf_column(paf, 1), raft_host_paf_column(paf, 2), raft_host_paf_column(paf, 3),
-                           raft_host_paf_column(paf, 4), raft_host_paf_column(paf, 5));
+                           raft_host_paf_column(paf, 1), raft_host_paf_column(paf, 2), sym ? nullptr : raft_host_paf_column(paf, 3),
+                           sym ? nullptr : raft_host_paf_column(paf, 4), sym ? nullptr : raft_host_paf_column(paf, 5));
     raft_hip_summary s{};
     if (rc == RAFT_HIP_OK) rc = raft_hip_finish(ctx, &s);
     if (rc != RAFT_HIP_OK) {
@@ -163,19 +172,30 @@ int main(int argc, char *argv[])
     fprintf(stdout, "INFO, length of alignments  %d()\n", (int)s.n_records);
     fprintf(stdout, "high_cov %d\n", s.high_cov);                              // repeat.hpp:91
 
+    // coverage comes back in its transfer encoding (a byte per window + the windows at or above 255): a quarter of
+    // the int32 array's bytes over PCIe, and the formatter below reads it as it is
     std::vector<int64_t> cov_off((size_t)n_reads + 1), rep_off((size_t)n_reads + 1), frag_off((size_t)n_reads + 1);
-    std::vector<int32_t> cov((size_t)s.n_bins), rep_s((size_t)s.n_repeats), rep_e((size_t)s.n_repeats);
+    std::unique_ptr<uint8_t[]> cov8(new uint8_t[(size_t)s.n_bins + 1]);         // (not value-initialised: no zero fill)
+    std::vector<int32_t> rep_s((size_t)s.n_repeats), rep_e((size_t)s.n_repeats);
     std::vector<int32_t> fb((size_t)s.n_fragments), fe((size_t)s.n_fragments);
-    rc = raft_hip_fetch(ctx, cov_off.data(), cov.data(), rep_off.data(), rep_s.data(), rep_e.data(), nullptr, nullptr,
-                        frag_off.data(), nullptr, fb.data(), fe.data());
-    if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_fetch(), ") + raft_hip_strerror(rc));
+    std::vector<int64_t> exc_i;
+    std::vector<int32_t> exc_v;
+    int64_t n_exc = 0;
+    rc = raft_hip_fetch_packed(ctx, nullptr, nullptr, 0, nullptr, nullptr, &n_exc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc == RAFT_HIP_OK) {
+        exc_i.resize((size_t)n_exc); exc_v.resize((size_t)n_exc);
+        rc = raft_hip_fetch_packed(ctx, cov_off.data(), cov8.get(), n_exc, exc_i.data(), exc_v.data(), &n_exc, rep_off.data(),
+                                   rep_s.data(), rep_e.data(), frag_off.data(), nullptr, fb.data(), fe.data());
+    }
+    if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_fetch_packed(), ") + raft_hip_strerror(rc));
     stage("fetch");
 
     // the four output files are independent: the FASTA is written beside the coverage/repeat tables
     int fasta_rc = RAFT_HOST_OK;
     std::thread fasta_writer([&] { fasta_rc = raft_host_write_fasta(fasta_out.c_str(), reads, frag_off.data(), fb.data(), fe.data()); });
     g_background[1] = &fasta_writer;
-    if (raft_host_write_coverage((p.prefix + ".coverage.txt").c_str(), n_reads, p.reso, cov_off.data(), cov.data()) != RAFT_HOST_OK ||
+    if (raft_host_write_coverage_packed((p.prefix + ".coverage.txt").c_str(), n_reads, p.reso, cov_off.data(), cov8.get(), n_exc,
+                                        exc_i.data(), exc_v.data()) != RAFT_HOST_OK ||
         raft_host_write_repeats((p.prefix + ".long_repeats.txt").c_str(), (p.prefix + ".long_repeats.bed").c_str(), reads,
                                 rep_off.data(), rep_s.data(), rep_e.data()) != RAFT_HOST_OK) {
         die("ERROR, repeat_annotate(), cannot write output files");
@@ -202,8 +222,19 @@ int main(int argc, char *argv[])
     stage("stdout");
     // Everything is written and closed.  Unmapping a GB of reads, freeing the device buffers and tearing the HIP runtime
     // down cost 0.2-0.3 s of a run that takes a second: leave that to the kernel's process exit.
-    fflush(stdout); fflush(stderr);
-    if (!getenv("RAFT_CLEAN_EXIT")) _exit(0);
+    const bool out_ok = fflush(stdout) == 0 && !ferror(stdout) && std::cout.good();
+    fflush(stderr);
+    if (!out_ok) _exit(1);                           // a failed stdout write (closed pipe, full disk) is not a success
+    // The fast exit skips atexit handlers and static destructors, which tools that finalise at exit rely on (rocprofv3 /
+    // rocprofiler-sdk traces, gcov / llvm-cov counters, sanitizer reports): it is off whenever such a tool shows in
+    // the environment, and RAFT_CLEAN_EXIT=1 turns it off by hand.
+    auto has = [](const char *v) { const char *e = getenv(v); return e && *e; };
+    const char *preload = getenv("LD_PRELOAD");
+    const bool tooling = has("RAFT_CLEAN_EXIT") || has("ROCP_TOOL_LIBRARIES") || has("ROCPROFILER_REGISTER_FORCE_LOAD") ||
+                         has("HSA_TOOLS_LIB") || has("ROCP_TOOL_LIB") || has("LLVM_PROFILE_FILE") || has("GCOV_PREFIX") ||
+                         has("ASAN_OPTIONS") || has("LSAN_OPTIONS") || has("UBSAN_OPTIONS") ||
+                         (preload && (strstr(preload, "rocprof") || strstr(preload, "asan") || strstr(preload, "tsan")));
+    if (!tooling) _exit(0);
     raft_host_paf_free(paf);
     raft_host_reads_free(reads);
     raft_hip_destroy(ctx);

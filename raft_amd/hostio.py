@@ -12,7 +12,8 @@ OK, ERR_OPEN, ERR_DUP_NAME, ERR_UNKNOWN_NAME, ERR_IO, ERR_ARG = range(6)
 EXPORTS = ("raft_host_reads_load", "raft_host_reads_free", "raft_host_reads_count", "raft_host_reads_lengths",
            "raft_host_reads_name", "raft_host_reads_bases", "raft_host_reads_real", "raft_host_paf_load", "raft_host_paf_free",
            "raft_host_paf_count", "raft_host_paf_column", "raft_host_write_coverage", "raft_host_write_repeats",
-           "raft_host_write_fasta", "raft_host_set_threads", "raft_host_get_threads", "raft_host_split_naive")
+           "raft_host_write_fasta", "raft_host_set_threads", "raft_host_get_threads", "raft_host_split_naive",
+           "raft_host_paf_symmetric", "raft_host_unpack_coverage", "raft_host_write_coverage_packed")
 
 
 class HostError(RuntimeError):
@@ -48,6 +49,9 @@ def load_library():
         lib.raft_host_write_fasta.argtypes = [C.c_char_p, vp, vp, vp, vp]
         lib.raft_host_split_naive.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
         lib.raft_host_set_threads.argtypes = [C.c_int]
+        lib.raft_host_paf_symmetric.argtypes = [vp]
+        lib.raft_host_unpack_coverage.argtypes = [C.c_int64, vp, C.c_int64, vp, vp, vp]
+        lib.raft_host_write_coverage_packed.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp]
         lib.raft_host_get_threads.argtypes = []
         _lib = lib
     return _lib
@@ -103,8 +107,8 @@ class Reads:
             pass
 
 
-def load_paf(path: str, reads: Reads):
-    """-> six int32 numpy columns (qid, qs, qe, tid, ts, te)."""
+def load_paf(path: str, reads: Reads, with_flag: bool = False):
+    """-> six int32 numpy columns (qid, qs, qe, tid, ts, te) [, the symmetric flag the tokeniser found]."""
     lib = load_library()
     h = C.c_void_p()
     err = C.create_string_buffer(256)
@@ -113,8 +117,40 @@ def load_paf(path: str, reads: Reads):
         raise HostError(rc, err.value.decode())
     n = lib.raft_host_paf_count(h)
     cols = [np.ctypeslib.as_array(lib.raft_host_paf_column(h, k), shape=(n,)).copy() if n else np.empty(0, np.int32) for k in range(6)]
+    sym = int(lib.raft_host_paf_symmetric(h))
     lib.raft_host_paf_free(h)
-    return cols
+    return (cols, sym) if with_flag else cols
+
+
+def pack_coverage(cov):
+    """Reference encoder of the transfer form (tests): cov8 = min(cov, 255) + ascending exceptions (index, value)."""
+    cov = np.asarray(cov, np.int32)
+    idx = np.flatnonzero(cov >= 255).astype(np.int64)
+    return np.minimum(cov, 255).astype(np.uint8), idx, cov[idx].astype(np.int32)
+
+
+def unpack_coverage(cov8, exc_index, exc_value):
+    """raft_host_unpack_coverage: the int32 coverage array from the packed form."""
+    lib = load_library()
+    cov8 = np.ascontiguousarray(cov8, np.uint8)
+    xi, xv = np.ascontiguousarray(exc_index, np.int64), np.ascontiguousarray(exc_value, np.int32)
+    out = np.empty(cov8.size, np.int32)
+    rc = lib.raft_host_unpack_coverage(cov8.size, C.c_void_p(cov8.ctypes.data), xi.size, C.c_void_p(xi.ctypes.data),
+                                       C.c_void_p(xv.ctypes.data), C.c_void_p(out.ctypes.data))
+    if rc != OK:
+        raise HostError(rc, "unpack_coverage")
+    return out
+
+
+def write_coverage_packed(path: str, n_reads: int, reso: int, cov_offset, cov8, exc_index, exc_value):
+    lib = load_library()
+    co = np.ascontiguousarray(cov_offset, np.int64)
+    cov8 = np.ascontiguousarray(cov8, np.uint8)
+    xi, xv = np.ascontiguousarray(exc_index, np.int64), np.ascontiguousarray(exc_value, np.int32)
+    p = lambda x: C.c_void_p(x.ctypes.data)
+    rc = lib.raft_host_write_coverage_packed(path.encode(), n_reads, reso, p(co), p(cov8), xi.size, p(xi), p(xv))
+    if rc != OK:
+        raise HostError(rc, path)
 
 
 def write_outputs(prefix: str, reads: Reads, reso: int, res: dict):

@@ -60,6 +60,28 @@ class OverlapSet:
         return OverlapSet(self.read_len[:n].clone(), *[c[keep] for c in self.columns()], n_cis=n_cis)
 
 
+def query_window(o: OverlapSet, a: int, b: int) -> OverlapSet:
+    """Reads [a, b) of a SYMMETRIC set as a closed problem (a bounded sample of the same workload for CPU checkers).
+
+    In symmetric mode a read's outputs depend only on the records whose QUERY is that read (repeat.hpp:48-58), so the
+    window keeps every record with a query in [a, b), rebases the read ids, and maps targets outside the window to one
+    extra dummy read (index b - a, as long as the longest read).  Record 0's mirror is appended on the dummy read when
+    it is not already inside the window, so that the reference's detection (chop.hpp:175-184) still arrives at
+    symmetric = 1.  Outputs of reads 0 .. b-a-1 of the window equal those of reads a .. b-1 of the full set."""
+    sel = (o.qid >= a) & (o.qid < b)
+    q, qs, qe, t, ts, te = (c[sel] for c in o.columns())
+    n = b - a
+    inside = (t >= a) & (t < b)
+    rl = torch.cat([o.read_len[a:b], o.read_len.max().reshape(1)])
+    q = q - a
+    t = torch.where(inside, t - a, torch.full_like(t, n))
+    cols = [q, qs, qe, t, ts, te]
+    if q.numel() and int(t[0]) == n:                      # record 0's target is outside: plant its mirror on the dummy
+        extra = [t[:1], ts[:1], te[:1], q[:1], qs[:1], qe[:1]]
+        cols = [torch.cat([c, x]) for c, x in zip(cols, extra)]
+    return OverlapSet(rl.contiguous(), *[c.contiguous() for c in cols], n_cis=0)
+
+
 def _expand_ranges(lo: torch.Tensor, cnt: torch.Tensor):
     """For every row i emit (i, lo[i] + k) for k in [0, cnt[i])."""
     total = int(cnt.sum())

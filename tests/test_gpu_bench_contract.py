@@ -32,3 +32,34 @@ def test_bench_line_has_every_contract_field():
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     assert d["value"] > 0 and d["ms_per_step"] > 0
+    # round 2: whole-pass roofline, end-to-end leg, self-check, CPU description
+    assert 0 < rf["pass_frac"] <= rf["frac"] and rf["pass_device_ms"] >= rf["kernel_ms"] and len(rf["kernel_source_hash"]) == 16
+    e = d["e2e"]
+    for k in ("records_per_s", "fragments_per_s", "seconds", "first_pass_s", "h2d_bytes", "d2h_bytes", "host_memory"):
+        assert k in e, k
+    assert e["decoded_coverage_equals_device"] is True and e["records_per_s"] > 0 and e["d2h_bytes"] < e["h2d_bytes"] * 3
+    assert all(d["self_check"].values()) and len(d["self_check"]) == 3
+    assert cb["cpu_model"] and cb["node_logical_cpus"] >= 1 and "same seed" in cb["sample"]
+
+
+@pytest.mark.parametrize("extra", [[], ["--presplit"]])
+def test_bench_gpus_flag_spawns_the_ranks_itself(extra):
+    """`python bench.py --gpus 2` without a launcher: two ranks (sharing the box's one GPU, gloo) and n_gpus == 2 in the
+    line; with --presplit the all-to-all-v exchange runs inside the step and feeds the HIP engine."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "30000", "--steps", "2",
+                        "--warmup", "1"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["records_total"] > d["config"]["records_per_gpu"] > 0
+    assert ("pre-split" in d["config"]["sharding"]) == bool(extra)
+    assert "cpu_baseline" not in d and "e2e" not in d
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "1000"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600, env=env)
+    assert r.returncode != 0 and b"WORLD_SIZE" in r.stderr

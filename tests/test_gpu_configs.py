@@ -76,23 +76,10 @@ def test_repeat_sort_ties_vs_oracle(seed):
 # ---- config 3 at full size ---------------------------------------------------------------------------------------------
 
 def window_subproblem(o, a, b):
-    """Reads [a, b) of a symmetric set as a closed problem for the oracle: every record whose QUERY is in the window
-    (in symmetric mode a read's outputs depend on nothing else), read ids rebased, targets outside the window mapped
-    to one extra dummy read; record 0's mirror is appended on the dummy read when it is not already in the window, so
-    that the oracle's detection (chop.hpp:175-184) arrives at symmetric = 1 like the full set."""
-    import torch
-    sel = (o.qid >= a) & (o.qid < b)
-    q, qs, qe, t, ts, te = (c[sel] for c in o.columns())
-    n = b - a
-    inside = (t >= a) & (t < b)
-    rl = torch.cat([o.read_len[a:b], o.read_len.max().reshape(1)])
-    q = q - a
-    t = torch.where(inside, t - a, torch.full_like(t, n))
-    cols = [c.cpu().numpy().astype(np.int32) for c in (q, qs, qe, t, ts, te)]
-    if cols[3][0] == n:                                   # record 0's target is outside: plant its mirror on the dummy
-        cols = [np.append(c, v).astype(np.int32) for c, v in
-                zip(cols, (n, cols[4][0], cols[5][0], cols[0][0], cols[1][0], cols[2][0]))]
-    return rl.cpu().numpy().astype(np.int32), cols
+    """raft_amd.synth.query_window as numpy columns for the oracle."""
+    from raft_amd.synth import query_window
+    w = query_window(o, a, b)
+    return w.read_len.cpu().numpy(), [c.cpu().numpy() for c in w.columns()]
 
 
 def test_config3_full_size():
@@ -128,11 +115,11 @@ def test_config3_full_size():
     same = fr[1:] == fr[:-1]
     assert bool(((fe[:-1] - fb[1:])[same] == p.overlap_length).all()) and bool((fr[1:] >= fr[:-1]).all())
     assert bool(((fr[1:] - fr[:-1])[~same] == 1).all()) and bool((fe > fb).all())
-    # repeats: inside the read, ordered, at least repeat_length long before flanking
+    # repeats: inside the read, at least repeat_length long (a run's last window may be partial: up to reso - 1 bp less)
     ro, rs, re_ = out["rep_offset"], out["rep_s"], out["rep_e"]
     rr = torch.repeat_interleave(torch.arange(o.n_reads, device="cuda:0"), (ro[1:] - ro[:-1]))
     assert s.n_repeats == int(ro[-1]) > 1e5
-    assert bool((rs >= 0).all()) and bool((re_ <= o.read_len[rr]).all()) and bool((re_ - rs >= p.repeat_length).all())
+    assert bool((rs >= 0).all()) and bool((re_ <= o.read_len[rr]).all()) and bool((re_ - rs > p.repeat_length - p.reso).all())
     # the oracle on three windows of 20 k reads cut out of the full-size result
     host = {k: v.cpu().numpy() for k, v in out.items() if k != "cov"}
     for a in (0, 1_640_000, 3_280_000):
@@ -191,3 +178,40 @@ def test_config5_parameter_sweep(ultralong_set, plen, cov_mul, reso):
         assert_same_result(got, want, f"-p {plen} -m {cov_mul} -r {reso} general kernel")
         got, s = run_host(p, cols, force_bucket=True)
         assert_same_result(got, want, f"-p {plen} -m {cov_mul} -r {reso} counting sort")
+
+
+# ---- the transfer encoding of cov[] and the three-column upload -----------------------------------------------------------
+
+def test_packed_fetch_and_query_only_upload():
+    """raft_hip_fetch_packed + raft_host_unpack_coverage reproduce raft_hip_fetch; with symmetric_mode = 1 the target
+    columns are not passed at all.  Coverage >= 255 (exceptions) is forced by stacking records on a few reads."""
+    from raft_amd import engine, hostio
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(3000, seed=77, coverage=40.0)
+    cols = [c.numpy() for c in (o.read_len,) + o.columns()]
+    hot = np.flatnonzero(cols[1] == cols[1][len(cols[1]) // 2])[:1]
+    extra = [np.repeat(c[hot], 700) for c in cols[1:]]                    # 700 copies of one record: cov >= 255 there
+    cols = [cols[0]] + [np.concatenate([c, x]) for c, x in zip(cols[1:], extra)]
+    p = RaftParams(est_cov=40)
+    want = oracle_run(p, *cols)
+    assert want["symmetric"] == 1 and int(want["cov"].max()) >= 700
+    eng = engine.Engine(RaftParams(est_cov=40, symmetric_mode=1), device=0)
+    eng.run_host(cols[0], cols[1], cols[2], cols[3], None, None, None)      # query side only
+    s = eng.finish()
+    full = engine_result(eng, s)
+    assert_same_result(full, want, "symmetric_mode=1, three columns")
+    pk = eng.fetch_packed()
+    assert pk["cov8"].dtype == np.uint8 and pk["exc_index"].size == int((want["cov"] >= 255).sum()) > 0
+    assert bool((np.diff(pk["exc_index"]) > 0).all())
+    assert np.array_equal(hostio.unpack_coverage(pk["cov8"], pk["exc_index"], pk["exc_value"]), want["cov"])
+    for k in ("cov_offset", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_read", "frag_begin", "frag_end"):
+        assert np.array_equal(pk[k], want[k]), k
+    pk2 = eng.fetch_packed(pinned=True, out=None)                           # a second call serves the cached encoding
+    assert np.array_equal(pk2["cov8"], pk["cov8"])
+    eng.close()
+    with pytest.raises(engine.RaftError):                                   # detection mode needs the target columns
+        e2 = engine.Engine(RaftParams(est_cov=40), device=0)
+        try:
+            e2.run_host(cols[0], cols[1], cols[2], cols[3], None, None, None)
+        finally:
+            e2.close()

@@ -87,6 +87,10 @@ def test_config1_gz_inputs_md5(tmp_path):
         assert np.array_equal(a, b)
     for f, digest in meta["md5"].items():
         assert md5(open(tmp_path / ("fragmented." + f), "rb").read()) == digest, f
+    for threads in (1, 5):                               # 25 MB of PAF text: the multi-chunk tokeniser finds the flag too
+        hostio.set_threads(threads)
+        assert hostio.load_paf(str(tmp_path / "overlaps.paf.gz"), reads, with_flag=True)[1] == meta["symmetric"] == 1
+    hostio.set_threads(0)
 
 
 def test_fastq_and_odd_fasta(tmp_path):
@@ -258,3 +262,63 @@ def test_split_naive_matches_reference(tmp_path, threads):
         assert subprocess.run([cli, str(src)], stdout=subprocess.PIPE).returncode == 1     # usage
     with pytest.raises(hostio.HostError):
         hostio.split_naive(str(src), str(tmp_path / "x.fa"), 0)
+
+
+def test_packed_coverage_roundtrip_and_writer(tmp_path):
+    """The transfer encoding of cov[] (one byte per window + exceptions for values >= 255): the C++ decoder restores
+    the array and the packed writer's bytes equal the int32 writer's, for 1, 3 and 8 threads."""
+    rng = np.random.default_rng(5)
+    nb = rng.integers(0, 4000, 300)
+    off = np.zeros(len(nb) + 1, np.int64)
+    np.cumsum(nb, out=off[1:])
+    cov = rng.integers(0, 200, int(off[-1])).astype(np.int32)
+    hot = rng.integers(0, cov.size, 4000)
+    cov[hot] = rng.choice([254, 255, 256, 300, 70000, 2**31 - 1], hot.size)
+    cov[:3] = [255, 0, 1000]; cov[-2:] = [255, 999]
+    c8, xi, xv = hostio.pack_coverage(cov)
+    assert c8.dtype == np.uint8 and (c8 == 255).sum() == xi.size and bool((np.diff(xi) > 0).all())
+    assert np.array_equal(hostio.unpack_coverage(c8, xi, xv), cov)
+    with pytest.raises(hostio.HostError):                # an exception pointing at a window that is not 255
+        hostio.unpack_coverage(c8, np.array([1], np.int64), np.array([7], np.int32))
+    lib = hostio.load_library()
+    for threads in (1, 3, 8):
+        hostio.set_threads(threads)
+        a, b = str(tmp_path / f"a{threads}.txt"), str(tmp_path / f"b{threads}.txt")
+        assert lib.raft_host_write_coverage(a.encode(), len(nb), 50, off.ctypes.data, cov.ctypes.data) == 0
+        hostio.write_coverage_packed(b, len(nb), 50, off, c8, xi, xv)
+        assert open(a, "rb").read() == open(b, "rb").read()
+    hostio.set_threads(0)
+    empty = np.empty(0, np.int64)
+    assert hostio.unpack_coverage(np.empty(0, np.uint8), empty, np.empty(0, np.int32)).size == 0
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_paf_loader_reports_the_symmetric_flag(tmp_path, threads):
+    """chop.hpp:171-184 inside the tokeniser: the flag equals the oracle's on the golden cases and on edge shapes."""
+    hostio.set_threads(threads)
+    try:
+        for name in sorted(MAN["synthetic"]):
+            p, cols, exp, meta = load_case(name)
+            names = [f"r{i}" for i in range(len(cols[0]))]
+            write_fasta(tmp_path / "r.fa", names, cols[0])
+            write_paf(tmp_path / "o.paf", names, *cols)
+            reads = hostio.Reads(str(tmp_path / "r.fa"))
+            got, sym = hostio.load_paf(str(tmp_path / "o.paf"), reads, with_flag=True)
+            assert sym == meta["symmetric"], name
+        (tmp_path / "r.fa").write_text(">a\nACGTACGT\n>b\nACGTAC\n")
+        reads = hostio.Reads(str(tmp_path / "r.fa"))
+        line = lambda q, qs, qe, t, ts, te: f"{q}\t8\t{qs}\t{qe}\t+\t{t}\t6\t{ts}\t{te}\t1\t1\t60\n"
+        cases = {
+            "self-mirror record 0 alone is not a mirror": (line("a", 1, 5, "a", 1, 5), 0),
+            "self-mirror repeated later": (line("a", 1, 5, "a", 1, 5) * 2, 1),
+            "mirror after junk lines": ("junk\n" + line("a", 0, 4, "b", 1, 5) + "x\ty\n" + line("b", 1, 5, "a", 0, 4), 1),
+            "coordinates differ": (line("a", 0, 4, "b", 1, 5) + line("b", 1, 5, "a", 0, 3), 0),
+            "only record 0": (line("a", 0, 4, "b", 1, 5), 0),
+        }
+        for what, (text, want) in cases.items():
+            (tmp_path / "o.paf").write_text(text)
+            got, sym = hostio.load_paf(str(tmp_path / "o.paf"), reads, with_flag=True)
+            rl = np.array([8, 6], np.int32)
+            assert sym == want == oracle_run(RaftParams(est_cov=2), rl, *got)["symmetric"], what
+    finally:
+        hostio.set_threads(0)

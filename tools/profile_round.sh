@@ -8,7 +8,6 @@ python bench.py > gpurun_out/$TAG/bench.log 2>&1; echo "bench rc=$?"; grep '^{' 
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/$TAG/stats.log 2>&1; echo "stats rc=$?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$TAG/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/$TAG/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/$TAG/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/$TAG/pmc_write.log 2>&1; echo "pmc write rc=$?"
-python tools/pcie_rate.py > gpurun_out/$TAG/pcie.txt 2>&1; echo "pcie rc=$?"; tail -3 gpurun_out/$TAG/pcie.txt
 python3 - <<PY
 import csv, glob, json, collections
 tag = "$TAG"
@@ -27,7 +26,7 @@ if fetch is not None and write is not None:
     # MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of a wide coalesced read stream
     traffic = (2 * fetch + write) * 1024
     json.dump({"hbm_bytes_per_launch": traffic, "fetch_size_kib": fetch, "write_size_kib": write,
-               "records_per_gpu": b["config"]["records_per_gpu"],
+               "records_per_gpu": b["config"]["records_per_gpu"], "kernel_source_hash": b["roofline"]["kernel_source_hash"],
                "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), pileup_fast_kernel + pileup_kernel, means per launch summed; "
                          f"bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section; profiles/{tag}_pmc_traffic.json"},
               open(f"gpurun_out/{tag}/pmc_traffic.json", "w"), indent=1)
