@@ -166,6 +166,32 @@ int  raft_hip_fetch_packed(raft_hip_ctx *ctx, int64_t *cov_offset, uint8_t *cov8
                            int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
                            int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end);
 
+/* Caller-owned host arrays (page-locked for full PCIe rate) that receive the outputs of raft_hip_run_pipelined, with
+ * their capacities in elements.  Upper bounds the caller can compute from read_len alone:
+ *   cov8_cap >= sum ceil(len/reso);  frag_cap >= sum (len/interval_length + 2);
+ *   rep_cap  >= sum (ceil(len/reso) + 1) / (ceil(repeat_length/reso) + 1)   (<= n_reads for defaults and reads < 400 kb).
+ * cov_offset / rep_offset / frag_offset hold n_reads + 1 entries.  frag_read is not returned: fragment f of read i is
+ * every f in [frag_offset[i], frag_offset[i+1]).  n_exc is written by the call. */
+typedef struct raft_hip_host_outputs {
+    int64_t *cov_offset;  uint8_t *cov8;      int64_t cov8_cap;
+    int64_t *exc_index;   int32_t *exc_value; int64_t exc_cap;   int64_t n_exc;
+    int64_t *rep_offset;  int32_t *rep_s, *rep_e;               int64_t rep_cap;
+    int64_t *frag_offset; int32_t *frag_begin, *frag_end;       int64_t frag_cap;
+} raft_hip_host_outputs;
+
+/* One end-to-end pass, host memory to host memory: raft_hip_run_host + raft_hip_finish + raft_hip_fetch_packed in one
+ * call, with the three stages overlapped.  With symmetric_mode = 1 and a record stream of at most four runs sorted by
+ * query id (hifiasm's shape), the reads are cut into n_chunks ranges (0 = chosen from the record count) whose upload,
+ * pass and download run concurrently on separate streams; results are identical to the one-piece pass, to which the
+ * call falls back for any other input (and for any chunk that reports a data error, so that errors are reported
+ * exactly as by raft_hip_run_host).  tid/ts/te may be NULL when symmetric_mode = 1.  RAFT_HIP_ERR_TOO_LARGE: a
+ * capacity in `out` was too small (size them by the bounds above).  Device-resident outputs of the context are NOT valid
+ * after this call (raft_hip_fetch / raft_hip_outputs_device return RAFT_HIP_ERR_STATE). */
+int  raft_hip_run_pipelined(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                            const int32_t *qid, const int32_t *qs, const int32_t *qe,
+                            const int32_t *tid, const int32_t *ts, const int32_t *te,
+                            int32_t n_chunks, raft_hip_host_outputs *out, raft_hip_summary *summary);
+
 /* Device seconds spent in the dominant kernel (coverage pileup + run scan) and
  * in all kernels of the last finished pass, from HIP events recorded on the
  * context's stream around them. */

@@ -13,8 +13,11 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -166,6 +169,11 @@ struct raft_hip_ctx {
     void *pinned = nullptr;           // small pinned scratch for readbacks
     hipEvent_t ev_pass0 = nullptr, ev_pass1 = nullptr, ev_pile0 = nullptr, ev_pile1 = nullptr;
 
+    // chunked host pipeline (raft_hip_run_pipelined): sub-contexts on the same device, one upload stream
+    std::vector<raft_hip_ctx *> lanes;
+    hipStream_t up_stream = nullptr;
+    std::vector<hipEvent_t> lane_up_ev;
+
     // state of the last pass
     bool ran = false, finished = false;
     int pending_err = RAFT_HIP_OK;
@@ -279,6 +287,11 @@ void raft_hip_destroy(raft_hip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (raft_hip_ctx *l : c->lanes) raft_hip_destroy(l);
+    c->lanes.clear();
+    for (hipEvent_t e : c->lane_up_ev) (void)hipEventDestroy(e);
+    c->lane_up_ev.clear();
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
@@ -763,6 +776,324 @@ int raft_hip_fetch_packed(raft_hip_ctx *c, int64_t *cov_offset, uint8_t *cov8, i
         std::sort(ex.begin(), ex.end());
         for (size_t i = 0; i < ex.size(); ++i) { exc_index[i] = ex[i].first; exc_value[i] = ex[i].second; }
     }
+    return RAFT_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Chunked host pipeline: H2D, pass and D2H of consecutive read ranges overlap (PCIe is full duplex; the pass itself is
+// two orders of magnitude shorter than either transfer).
+//
+// A read's outputs depend on nothing but the records whose query is that read (symmetric PAF, repeat.hpp:48-58), so the
+// job is cut into chunks of consecutive reads.  hifiasm's PAF is a handful of runs sorted by query id (bucket.hpp), so
+// a chunk's records are one contiguous piece per run: the pieces are found on the host by binary search in the
+// page-locked qid column and uploaded back to back.  The cut is a guess from samples -- what makes it safe is the
+// device: the pieces tile [0, n_rec) by construction, and inspect_kernel rejects any record whose (rebased) query id
+// falls outside its chunk's reads; on any such report the whole job is redone in one piece.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Piece { long long lo, hi; };
+
+// Sorted runs of the record stream from 8 k samples + bisection; -1 when there are more than kMaxSeg.
+int guess_segments(const int32_t *q, long long n, long long (&start)[kMaxSeg + 1])
+{
+    const long long S = std::min<long long>(n, 8192);
+    int n_seg = 1;
+    start[0] = 0;
+    long long prev_pos = 0;
+    for (long long i = 1; i < S; ++i) {
+        const long long pos = i * (n - 1) / (S - 1);
+        if (q[pos] < q[prev_pos]) {                  // a run ends in (prev_pos, pos]: first position below q[prev_pos]
+            long long lo = prev_pos, hi = pos;
+            const int32_t v = q[prev_pos];
+            while (hi - lo > 1) {
+                const long long mid = lo + (hi - lo) / 2;
+                if (q[mid] >= v) lo = mid; else hi = mid;
+            }
+            if (n_seg == kMaxSeg) return -1;
+            start[n_seg++] = hi;
+        }
+        prev_pos = pos;
+    }
+    start[n_seg] = n;
+    return n_seg;
+}
+
+long long lower_bound_ids(const int32_t *q, long long lo, long long hi, int32_t r)   // first position in [lo, hi) with q >= r
+{
+    while (lo < hi) {
+        const long long mid = lo + (hi - lo) / 2;
+        if (q[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct ChunkPlan {
+    int32_t r0, r1;
+    Piece piece[kMaxSeg];
+    long long n_rec;
+};
+
+struct ChunkResult {
+    long long n_bins = 0, n_rep = 0, n_frag = 0, n_exc = 0, n_cuts = 0, n_iv = 0;
+    long long tot_cov = 0, tot_rep = 0, tot_len = 0;
+    int path = 0;
+};
+
+struct PipeShared {
+    std::mutex mu;
+    std::condition_variable cv;
+    int uploaded = 0;                               // chunks whose H2D has been enqueued (ticket of the upload stream)
+    int published = 0;                              // chunks whose sizes are known (bases of the next chunk)
+    long long base_bins = 0, base_rep = 0, base_frag = 0, base_exc = 0;
+    int error = RAFT_HIP_OK;                        // first failure; every lane stops at its next check
+    bool redo = false;                              // a chunk reported a data error: redo the job in one piece
+    std::string error_text;
+};
+
+} // namespace
+
+static int run_monolithic_to_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, const int32_t *qid,
+                                  const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts, const int32_t *te,
+                                  raft_hip_host_outputs *o, raft_hip_summary *summary)
+{
+    int rc = raft_hip_run_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te);
+    raft_hip_summary s{};
+    if (rc == RAFT_HIP_OK) rc = raft_hip_finish(c, &s);
+    if (summary) *summary = s;
+    if (rc != RAFT_HIP_OK) return rc;
+    if (s.n_bins > o->cov8_cap || s.n_repeats > o->rep_cap || s.n_fragments > o->frag_cap) return RAFT_HIP_ERR_TOO_LARGE;
+    int64_t n_exc = 0;
+    rc = raft_hip_fetch_packed(c, o->cov_offset, o->cov8, o->exc_cap, o->exc_index, o->exc_value, &n_exc, o->rep_offset, o->rep_s,
+                               o->rep_e, o->frag_offset, nullptr, o->frag_begin, o->frag_end);
+    o->n_exc = n_exc;
+    return rc;
+}
+
+int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, const int32_t *qid,
+                           const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts, const int32_t *te,
+                           int32_t n_chunks, raft_hip_host_outputs *o, raft_hip_summary *summary)
+{
+    if (!c || !o) return RAFT_HIP_ERR_PARAM;
+    if (n_reads < 0 || n_rec < 0 || n_chunks < 0) return RAFT_HIP_ERR_PARAM;
+    if (n_reads > 0 && !read_len) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && (!qid || !qs || !qe)) return RAFT_HIP_ERR_PARAM;
+    if (!o->cov_offset || !o->rep_offset || !o->frag_offset) return RAFT_HIP_ERR_PARAM;
+    o->n_exc = 0;
+    constexpr int kLanes = 3;
+    long long seg[kMaxSeg + 1];
+    int n_seg = -1;
+    // chunking needs: the symmetric flag asserted, enough work to split, a record stream of at most kMaxSeg sorted runs
+    // (an explicit n_chunks is honoured from tiny inputs on: that is how the tests reach every shape of the plan)
+    const bool big_enough = n_chunks > 0 ? (n_rec >= 2 && n_reads >= 2) : (n_rec >= (1 << 22) && n_reads >= 4096);
+    const bool eligible = c->prm.symmetric_mode == 1 && big_enough && !c->force_bucket;
+    if (eligible) n_seg = guess_segments(qid, n_rec, seg);
+    if (n_seg < 1) return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary);
+
+    int want = n_chunks > 0 ? std::min(n_chunks, n_reads)
+                            : (int)std::min<long long>(std::min<long long>(32, std::max<long long>(2, n_rec / (24LL << 20))), n_reads / 1024);
+    // ---- plan: read boundaries that balance the records, then one piece per run and chunk
+    std::vector<ChunkPlan> plan;
+    {
+        auto below = [&](int32_t r) {                // records with a query id < r (if the runs are sorted)
+            long long n = 0;
+            for (int k = 0; k < n_seg; ++k) n += lower_bound_ids(qid, seg[k], seg[k + 1], r) - seg[k];
+            return n;
+        };
+        std::vector<int32_t> bound{0};
+        for (int k = 1; k < want; ++k) {
+            const long long target = n_rec * k / want;
+            int32_t lo = bound.back(), hi = n_reads;
+            while (lo < hi) {
+                const int32_t mid = lo + (hi - lo) / 2;
+                if (below(mid) < target) lo = mid + 1; else hi = mid;
+            }
+            if (lo > bound.back() && lo < n_reads) bound.push_back(lo);
+        }
+        bound.push_back(n_reads);
+        std::vector<long long> cur(seg, seg + n_seg);
+        for (size_t k = 0; k + 1 < bound.size(); ++k) {
+            ChunkPlan cp{};
+            cp.r0 = bound[k]; cp.r1 = bound[k + 1]; cp.n_rec = 0;
+            for (int g = 0; g < n_seg; ++g) {
+                const long long hi = (k + 2 == bound.size()) ? seg[g + 1] : lower_bound_ids(qid, cur[g], seg[g + 1], cp.r1);
+                cp.piece[g] = Piece{cur[g], hi};
+                cp.n_rec += hi - cur[g];
+                cur[g] = hi;
+            }
+            plan.push_back(cp);
+        }
+    }
+    const int n_ch = (int)plan.size();
+    if (n_ch < 2) return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary);
+
+    // ---- lanes
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->up_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    while ((int)c->lanes.size() < kLanes) {
+        raft_hip_ctx *l = nullptr;
+        const int rc = raft_hip_create(c->device, &c->prm, &l);
+        if (rc != RAFT_HIP_OK) return rc;
+        c->lanes.push_back(l);
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->lane_up_ev.push_back(e);
+    }
+    for (raft_hip_ctx *l : c->lanes) {
+        apply_params(l, &c->prm);
+        l->tile_q = c->tile_q; l->variant = c->variant; l->force_bucket = 0;
+    }
+
+    std::vector<ChunkResult> res((size_t)n_ch);
+    PipeShared sh;
+    auto fail = [&](int code, const std::string &text) {
+        std::lock_guard<std::mutex> g(sh.mu);
+        if (sh.error == RAFT_HIP_OK) { sh.error = code; sh.error_text = text; }
+        sh.cv.notify_all();
+    };
+
+    auto lane_main = [&](int li) {
+        raft_hip_ctx *l = c->lanes[(size_t)li];
+        if (hipSetDevice(c->device) != hipSuccess) { fail(RAFT_HIP_ERR_DEVICE, "hipSetDevice"); return; }
+#define LANE_TRY(expr)                                                                  \
+        do {                                                                            \
+            hipError_t e_ = (expr);                                                     \
+            if (e_ != hipSuccess) { fail(fail_hip(l, e_, #expr), l->last_error); goto out; } \
+        } while (0)
+        for (int k = li; k < n_ch; k += kLanes) {
+            const ChunkPlan &cp = plan[(size_t)k];
+            ChunkResult &cr = res[(size_t)k];
+            const int32_t nr = cp.r1 - cp.r0;
+            raft_hip_summary s{};
+            long long b_bins, b_rep, b_frag, b_exc;
+            hipStream_t st = l->stream;
+            // -- upload, in chunk order on the one upload stream (the link is the bottleneck: first come, first served)
+            LANE_TRY(l->in_len.ensure((size_t)std::max(nr, 1) * 4));
+            for (int col = 0; col < 3; ++col) LANE_TRY(l->in_col[col].ensure((size_t)std::max<long long>(cp.n_rec, 1) * 4));
+            {
+                std::unique_lock<std::mutex> g(sh.mu);
+                sh.cv.wait(g, [&] { return sh.uploaded == k || sh.error != RAFT_HIP_OK || sh.redo; });
+                if (sh.error != RAFT_HIP_OK || sh.redo) goto out;
+            }
+            {
+                hipError_t e = hipMemcpyAsync(l->in_len.p, read_len + cp.r0, (size_t)nr * 4, hipMemcpyHostToDevice, c->up_stream);
+                const int32_t *src[3] = {qid, qs, qe};
+                for (int col = 0; col < 3 && e == hipSuccess; ++col) {
+                    long long at = 0;
+                    for (int g = 0; g < n_seg && e == hipSuccess; ++g) {
+                        const long long n = cp.piece[g].hi - cp.piece[g].lo;
+                        if (n > 0) e = hipMemcpyAsync(l->in_col[col].as<int32_t>() + at, src[col] + cp.piece[g].lo, (size_t)n * 4,
+                                                      hipMemcpyHostToDevice, c->up_stream);
+                        at += n;
+                    }
+                }
+                if (e == hipSuccess) e = hipEventRecord(c->lane_up_ev[(size_t)li], c->up_stream);
+                {
+                    std::lock_guard<std::mutex> g(sh.mu);
+                    sh.uploaded = k + 1;
+                    sh.cv.notify_all();
+                }
+                LANE_TRY(e);
+            }
+            LANE_TRY(hipStreamWaitEvent(st, c->lane_up_ev[(size_t)li], 0));
+            if (cp.n_rec > 0 && cp.r0 != 0) {
+                const unsigned grid = (unsigned)std::min<long long>((cp.n_rec + 255) / 256, 4096);
+                hipLaunchKernelGGL(rebase_ids_kernel, dim3(grid), dim3(256), 0, st, l->in_col[0].as<int32_t>(), cp.n_rec, cp.r0);
+            }
+            // -- the pass on this chunk
+            {
+                int rc = raft_hip_run_device(l, nr, l->in_len.as<int32_t>(), cp.n_rec, l->in_col[0].as<int32_t>(),
+                                             l->in_col[1].as<int32_t>(), l->in_col[2].as<int32_t>(), nullptr, nullptr, nullptr);
+                if (rc == RAFT_HIP_OK) rc = raft_hip_finish(l, &s);
+                if (rc == RAFT_HIP_ERR_READ_ID || rc == RAFT_HIP_ERR_COORD || rc == RAFT_HIP_ERR_FRAGMENT || rc == RAFT_HIP_ERR_PARAM) {
+                    // a data error (or a record outside the chunk it was cut into): the one-piece run reports it properly
+                    std::lock_guard<std::mutex> g(sh.mu);
+                    sh.redo = true;
+                    sh.cv.notify_all();
+                    goto out;
+                }
+                if (rc != RAFT_HIP_OK) { fail(rc, l->last_error); goto out; }
+                rc = pack_coverage(l);
+                if (rc != RAFT_HIP_OK) { fail(rc, l->last_error); goto out; }
+            }
+            cr.n_bins = s.n_bins; cr.n_rep = s.n_repeats; cr.n_frag = s.n_fragments; cr.n_exc = l->n_exc; cr.n_cuts = s.n_cuts;
+            cr.n_iv = s.n_intervals; cr.tot_cov = s.total_coverage; cr.tot_rep = s.total_repeat_length; cr.tot_len = s.total_read_length;
+            cr.path = s.interval_path;
+            // -- where this chunk's outputs go: after those of all earlier chunks
+            {
+                std::unique_lock<std::mutex> g(sh.mu);
+                sh.cv.wait(g, [&] { return sh.published == k || sh.error != RAFT_HIP_OK || sh.redo; });
+                if (sh.error != RAFT_HIP_OK || sh.redo) goto out;
+                b_bins = sh.base_bins; b_rep = sh.base_rep; b_frag = sh.base_frag; b_exc = sh.base_exc;
+                sh.base_bins += cr.n_bins; sh.base_rep += cr.n_rep; sh.base_frag += cr.n_frag; sh.base_exc += cr.n_exc;
+                sh.published = k + 1;
+                if (sh.base_bins > o->cov8_cap || sh.base_rep > o->rep_cap || sh.base_frag > o->frag_cap || sh.base_exc > o->exc_cap) {
+                    if (sh.error == RAFT_HIP_OK) { sh.error = RAFT_HIP_ERR_TOO_LARGE; sh.error_text = "host output capacity"; }
+                }
+                sh.cv.notify_all();
+                if (sh.error != RAFT_HIP_OK) goto out;
+            }
+            {
+                const long long n1 = (long long)nr + ((k == n_ch - 1) ? 1 : 0);   // the closing entry belongs to the last chunk
+                auto add_base = [&](DevBuf &b, long long n, long long base) {
+                    if (base != 0 && n > 0)
+                        hipLaunchKernelGGL(add_base_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st,
+                                           b.as<long long>(), n, base);
+                };
+                add_base(l->cov_off, n1, b_bins); add_base(l->rep_off, n1, b_rep); add_base(l->frag_off, n1, b_frag);
+                add_base(l->exc_idx, cr.n_exc, b_bins);
+                struct { void *dst; const void *src; size_t bytes; } job[] = {
+                    {o->cov8 ? o->cov8 + b_bins : nullptr, l->cov8.p, (size_t)cr.n_bins},
+                    {o->cov_offset + cp.r0, l->cov_off.p, (size_t)n1 * 8},
+                    {o->exc_index ? o->exc_index + b_exc : nullptr, l->exc_idx.p, (size_t)cr.n_exc * 8},
+                    {o->exc_value ? o->exc_value + b_exc : nullptr, l->exc_val.p, (size_t)cr.n_exc * 4},
+                    {o->rep_offset + cp.r0, l->rep_off.p, (size_t)n1 * 8},
+                    {o->rep_s ? o->rep_s + b_rep : nullptr, l->rep_s.p, (size_t)cr.n_rep * 4},
+                    {o->rep_e ? o->rep_e + b_rep : nullptr, l->rep_e.p, (size_t)cr.n_rep * 4},
+                    {o->frag_offset + cp.r0, l->frag_off.p, (size_t)n1 * 8},
+                    {o->frag_begin ? o->frag_begin + b_frag : nullptr, l->frag_begin.p, (size_t)cr.n_frag * 4},
+                    {o->frag_end ? o->frag_end + b_frag : nullptr, l->frag_end.p, (size_t)cr.n_frag * 4}};
+                for (auto &j : job)
+                    if (j.dst && j.bytes) LANE_TRY(hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, st));
+                LANE_TRY(hipStreamSynchronize(st));
+                if (o->exc_index && o->exc_value && cr.n_exc > 1) {    // ascending by window, like raft_hip_fetch_packed
+                    std::vector<std::pair<int64_t, int32_t>> ex((size_t)cr.n_exc);
+                    for (size_t i = 0; i < ex.size(); ++i) ex[i] = {o->exc_index[b_exc + (long long)i], o->exc_value[b_exc + (long long)i]};
+                    std::sort(ex.begin(), ex.end());
+                    for (size_t i = 0; i < ex.size(); ++i) { o->exc_index[b_exc + (long long)i] = ex[i].first; o->exc_value[b_exc + (long long)i] = ex[i].second; }
+                }
+            }
+        }
+    out:
+#undef LANE_TRY
+        {   // a lane that stops early must not leave the others waiting for its tickets
+            std::lock_guard<std::mutex> g(sh.mu);
+            sh.cv.notify_all();
+        }
+    };
+
+    {
+        std::vector<std::thread> th;
+        for (int li = 1; li < kLanes; ++li) th.emplace_back(lane_main, li);
+        lane_main(0);
+        for (auto &t : th) t.join();
+    }
+    (void)hipStreamSynchronize(c->up_stream);
+    for (raft_hip_ctx *l : c->lanes) (void)hipStreamSynchronize(l->stream);
+    if (sh.redo) return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary);
+
+    raft_hip_summary s{};
+    s.n_reads = n_reads; s.symmetric = 1; s.high_cov = c->high_cov; s.n_segments = n_seg; s.n_records = n_rec; s.error_index = -1;
+    for (const ChunkResult &cr : res) {
+        s.n_bins += cr.n_bins; s.n_repeats += cr.n_rep; s.n_fragments += cr.n_frag; s.n_cuts += cr.n_cuts; s.n_intervals += cr.n_iv;
+        s.total_coverage += cr.tot_cov; s.total_repeat_length += cr.tot_rep; s.total_read_length += cr.tot_len;
+        s.interval_path |= cr.path;
+    }
+    s.total_windows = s.n_bins;
+    o->n_exc = sh.base_exc;
+    if (summary) *summary = s;
+    c->ran = false; c->finished = false;           // the context itself holds no pass: fetch / outputs_device do not apply
+    if (sh.error != RAFT_HIP_OK) { c->last_error = sh.error_text; return sh.error; }
     return RAFT_HIP_OK;
 }
 

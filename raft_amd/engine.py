@@ -23,7 +23,7 @@ EXPORTS = (
     "raft_hip_abi_version", "raft_hip_strerror", "raft_hip_last_error", "raft_hip_create", "raft_hip_destroy",
     "raft_hip_set_params", "raft_hip_set_stream", "raft_hip_use_own_stream", "raft_hip_get_stream", "raft_hip_run_device", "raft_hip_run_host",
     "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
-    "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed",
+    "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed", "raft_hip_run_pipelined",
 )
 
 
@@ -41,6 +41,13 @@ class _Summary(C.Structure):
                 ("total_coverage", C.c_int64), ("total_windows", C.c_int64),
                 ("total_repeat_length", C.c_int64), ("total_read_length", C.c_int64),
                 ("error_index", C.c_int64)]
+
+
+class _HostOutputs(C.Structure):
+    _fields_ = [("cov_offset", C.c_void_p), ("cov8", C.c_void_p), ("cov8_cap", C.c_int64),
+                ("exc_index", C.c_void_p), ("exc_value", C.c_void_p), ("exc_cap", C.c_int64), ("n_exc", C.c_int64),
+                ("rep_offset", C.c_void_p), ("rep_s", C.c_void_p), ("rep_e", C.c_void_p), ("rep_cap", C.c_int64),
+                ("frag_offset", C.c_void_p), ("frag_begin", C.c_void_p), ("frag_end", C.c_void_p), ("frag_cap", C.c_int64)]
 
 
 class _Outputs(C.Structure):
@@ -114,6 +121,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_outputs_device.argtypes = [vp, C.POINTER(_Outputs)]
     lib.raft_hip_fetch.argtypes = [vp] + [vp] * 11
     lib.raft_hip_fetch_packed.argtypes = [vp, vp, vp, i64, vp, vp, C.POINTER(i64)] + [vp] * 7
+    lib.raft_hip_run_pipelined.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.raft_hip_set_tuning.argtypes = [vp, i32, i32, i32]
     lib.raft_hip_selftest.argtypes = [C.c_int]
@@ -256,6 +264,53 @@ class Engine:
         ptr = [C.c_void_p(out[k].ctypes.data if out[k].size else 0) for k in order]
         self._check(self._lib.raft_hip_fetch(self._ctx, *ptr))
         return out
+
+    def host_output_buffers(self, read_len, pinned: bool = True, exc_cap: int = 1 << 20) -> dict:
+        """Caller-owned arrays for ``run_pipelined`` sized by the upper bounds of include/raft_hip.h (page-locked when
+        ``pinned``): allocate once, reuse for every pass over inputs of this shape."""
+        p = self.params
+        rl = np.asarray(read_len, np.int64)
+        nb = (rl + p.reso - 1) // p.reso
+        minw = max((p.repeat_length + p.reso - 1) // p.reso, 1)
+        caps = {"cov8": int(nb.sum()), "rep": int(((nb + 1) // (minw + 1)).sum()), "frag": int((rl // p.interval_length + 2).sum()),
+                "exc": int(exc_cap)}
+        n1 = rl.size + 1
+
+        def alloc(n, dt):
+            n = max(int(n), 1)
+            if pinned:
+                import torch
+                tdt = {np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8}[dt]
+                return torch.empty(n, dtype=tdt, pin_memory=True).numpy()
+            return np.empty(n, dt)
+        return {"cov_offset": alloc(n1, np.int64), "cov8": alloc(caps["cov8"], np.uint8), "exc_index": alloc(caps["exc"], np.int64),
+                "exc_value": alloc(caps["exc"], np.int32), "rep_offset": alloc(n1, np.int64), "rep_s": alloc(caps["rep"], np.int32),
+                "rep_e": alloc(caps["rep"], np.int32), "frag_offset": alloc(n1, np.int64), "frag_begin": alloc(caps["frag"], np.int32),
+                "frag_end": alloc(caps["frag"], np.int32)}
+
+    def run_pipelined(self, read_len, qid, qs, qe, tid=None, ts=None, te=None, n_chunks: int = 0, out: dict | None = None):
+        """raft_hip_run_pipelined: host columns in, host outputs out, with upload / pass / download of consecutive read
+        ranges overlapped.  Returns (dict of arrays trimmed to their sizes -- views of ``out`` --, Summary)."""
+        cols = [None if a is None else np.ascontiguousarray(np.asarray(a), dtype=np.int32) for a in (read_len, qid, qs, qe, tid, ts, te)]
+        n_rec = cols[1].size
+        if out is None:
+            out = self.host_output_buffers(cols[0], pinned=False)
+        ho = _HostOutputs()
+        for k in ("cov_offset", "cov8", "exc_index", "exc_value", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
+            setattr(ho, k, out[k].ctypes.data)
+        ho.cov8_cap, ho.exc_cap, ho.rep_cap, ho.frag_cap = out["cov8"].size, out["exc_index"].size, out["rep_s"].size, out["frag_begin"].size
+        ptr = [C.c_void_p(a.ctypes.data if (a is not None and a.size) else 0) for a in cols]
+        s = _Summary()
+        rc = self._lib.raft_hip_run_pipelined(self._ctx, cols[0].size, ptr[0], n_rec, *ptr[1:], int(n_chunks), C.byref(ho), C.byref(s))
+        summ = Summary(**{f: int(getattr(s, f)) for f, _ in _Summary._fields_})
+        self.summary = summ
+        self._check(rc, summ.error_index)
+        n1 = summ.n_reads + 1
+        res = {"cov_offset": out["cov_offset"][:n1], "cov8": out["cov8"][:summ.n_bins], "exc_index": out["exc_index"][:ho.n_exc],
+               "exc_value": out["exc_value"][:ho.n_exc], "rep_offset": out["rep_offset"][:n1], "rep_s": out["rep_s"][:summ.n_repeats],
+               "rep_e": out["rep_e"][:summ.n_repeats], "frag_offset": out["frag_offset"][:n1],
+               "frag_begin": out["frag_begin"][:summ.n_fragments], "frag_end": out["frag_end"][:summ.n_fragments]}
+        return res, summ
 
     def fetch_packed(self, pinned: bool = False, out: dict | None = None) -> dict:
         """Host copies with the coverage array in its transfer encoding (raft_hip_fetch_packed): ``cov8`` (uint8 per

@@ -37,7 +37,7 @@ def test_bench_line_has_every_contract_field():
     e = d["e2e"]
     for k in ("records_per_s", "fragments_per_s", "seconds", "first_pass_s", "h2d_bytes", "d2h_bytes", "host_memory"):
         assert k in e, k
-    assert e["decoded_coverage_equals_device"] is True and e["records_per_s"] > 0 and e["d2h_bytes"] < e["h2d_bytes"] * 3
+    assert e["decoded_coverage_equals_device"] is True and e["chunked_equals_one_piece"] is True and e["records_per_s"] > 0 and e["d2h_bytes"] < e["h2d_bytes"] * 3
     assert all(d["self_check"].values()) and len(d["self_check"]) == 3
     assert cb["cpu_model"] and cb["node_logical_cpus"] >= 1 and "same seed" in cb["sample"]
 

@@ -215,3 +215,97 @@ def test_packed_fetch_and_query_only_upload():
             e2.run_host(cols[0], cols[1], cols[2], cols[3], None, None, None)
         finally:
             e2.close()
+
+
+# ---- chunked host pipeline (raft_hip_run_pipelined) -----------------------------------------------------------------------
+
+def check_pipelined(res, s, want, what):
+    from raft_amd import hostio
+    assert np.array_equal(hostio.unpack_coverage(res["cov8"], res["exc_index"], res["exc_value"]), want["cov"]), what
+    for k in ("cov_offset", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
+        assert np.array_equal(res[k], want[k]), (what, k)
+    assert (s.symmetric, s.high_cov, s.total_coverage, s.total_windows, s.total_repeat_length, s.total_read_length) == \
+        tuple(want[k] for k in ("symmetric", "high_cov", "total_coverage", "total_windows", "total_repeat_length", "total_read_length")), what
+    assert s.n_fragments == len(want["frag_read"]) and s.n_repeats == len(want["rep_s"]) and s.n_cuts == len(want["cuts"]), what
+    assert s.n_intervals == want["n_intervals"], what
+
+
+@pytest.mark.parametrize("kw,n_chunks", [(dict(n_reads=4000, seed=81), 5), (dict(n_reads=4000, seed=81), 2), (dict(n_reads=4000, seed=81), 23),
+                                         (dict(n_reads=1500, seed=82, mean_len=90000, sigma=0.9, max_len=1_200_000, coverage=25), 4),
+                                         (dict(n_reads=50000, seed=2), 0)])
+def test_pipelined_equals_oracle(kw, n_chunks):
+    """Upload / pass / download of consecutive read ranges overlapped: same outputs as the one-piece pass and the oracle.
+    n_chunks = 0 lets the engine choose (the 50 k-read set is just above its threshold)."""
+    from raft_amd import engine
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(**kw)
+    cols = [c.numpy() for c in (o.read_len,) + o.columns()]
+    p = RaftParams(est_cov=int(kw.get("coverage", 30)))
+    want = oracle_run(p, *cols)
+    eng = engine.Engine(RaftParams(**dict(p.__dict__, symmetric_mode=1)), device=0)
+    out = eng.host_output_buffers(cols[0], pinned=True)
+    for rep in range(2):                                  # a second pass reuses lanes and buffers
+        res, s = eng.run_pipelined(cols[0], cols[1], cols[2], cols[3], n_chunks=n_chunks, out=out)
+        check_pipelined(res, s, want, f"{kw} chunks {n_chunks} pass {rep}")
+        assert s.n_segments == 2
+    with pytest.raises(engine.RaftError) as e:            # the context itself holds no pass after a pipelined run
+        eng.fetch()
+    assert e.value.code == engine.ERR_STATE
+    eng.close()
+
+
+def test_pipelined_shapes_and_fallbacks():
+    from raft_amd import engine
+    rng = np.random.default_rng(91)
+    rl = rng.integers(3000, 40000, 900).astype(np.int32)
+
+    def sym_set(k_runs):
+        qid = np.concatenate([np.sort(rng.integers(0, len(rl), 5000)) for _ in range(k_runs)]).astype(np.int32)
+        a = (rng.random(len(qid)) * rl[qid]).astype(np.int32)
+        b = np.minimum(rl[qid], a + 1 + (rng.random(len(qid)) * rl[qid] * 0.5).astype(np.int32)).astype(np.int32)
+        return qid, a, b
+    p1 = RaftParams(est_cov=12, symmetric_mode=1)
+    eng = engine.Engine(p1, device=0)
+    for k_runs in (1, 3, 4, 6):                          # 6 sorted runs: more than the plan accepts -> one-piece fallback
+        qid, a, b = sym_set(k_runs)
+        want = oracle_run(RaftParams(est_cov=12), rl, qid, a, b, qid, a, b)      # self overlaps: query side only either way
+        res, s = eng.run_pipelined(rl, qid, a, b, n_chunks=4)
+        want["symmetric"] = 1
+        check_pipelined(res, s, want, f"{k_runs} runs")
+    qid, a, b = sym_set(2)
+    perm = rng.permutation(len(qid))                      # unsorted stream: the samples see many descents -> fallback
+    want = oracle_run(RaftParams(est_cov=12), rl, qid[perm], a[perm], b[perm], qid[perm], a[perm], b[perm]); want["symmetric"] = 1
+    res, s = eng.run_pipelined(rl, qid[perm], a[perm], b[perm], n_chunks=4)
+    check_pipelined(res, s, want, "shuffled")
+    # a stream that looks sorted to the samples but is not: two far-apart records swapped.  The chunk that receives a
+    # foreign read id reports it and the job is redone in one piece -- results still exact.
+    q2, a2, b2 = qid.copy(), a.copy(), b.copy()
+    i, j = 7, len(q2) // 2 - 11
+    for arr in (q2, a2, b2):
+        arr[i], arr[j] = arr[j], arr[i]
+    want = oracle_run(RaftParams(est_cov=12), rl, q2, a2, b2, q2, a2, b2); want["symmetric"] = 1
+    res, s = eng.run_pipelined(rl, q2, a2, b2, n_chunks=6)
+    check_pipelined(res, s, want, "swapped records")
+    # data errors come back as from run_host: same code, same index
+    bad = b.copy(); bad[1234] = rl[qid[1234]] + 5000
+    with pytest.raises(engine.RaftError) as e1:
+        eng.run_pipelined(rl, qid, a, bad, n_chunks=4)
+    with pytest.raises(engine.RaftError) as e2:
+        eng.run_host(rl, qid, a, bad, None, None, None); eng.finish()
+    assert e1.value.code == e2.value.code == engine.ERR_COORD and e1.value.index == e2.value.index == 1234
+    # capacities: too small -> defined error
+    small = eng.host_output_buffers(rl, pinned=False)
+    small["cov8"] = small["cov8"][: small["cov8"].size // 2]
+    with pytest.raises(engine.RaftError) as e3:
+        eng.run_pipelined(rl, qid, a, b, n_chunks=4, out=small)
+    assert e3.value.code == engine.ERR_TOO_LARGE
+    # detection mode (symmetric_mode = -1) and empty inputs take the one-piece path
+    eng.close()
+    eng = engine.Engine(RaftParams(est_cov=12), device=0)
+    want = oracle_run(RaftParams(est_cov=12), rl, qid, a, b, qid, a, b)
+    res, s = eng.run_pipelined(rl, qid, a, b, qid, a, b, n_chunks=4)
+    check_pipelined(res, s, want, "detection mode")
+    z = np.empty(0, np.int32)
+    res, s = eng.run_pipelined(rl, z, z, z, z, z, z)
+    assert s.n_fragments >= len(rl) and int(res["cov8"].sum()) == 0
+    eng.close()
