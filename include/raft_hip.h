@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_ABI_VERSION 1
+#define RAFT_HIP_ABI_VERSION 2
 
 /* error codes (0..5 are shared with oracle/raft_oracle.h) */
 enum {
@@ -191,6 +191,20 @@ int  raft_hip_run_pipelined(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *r
                             const int32_t *qid, const int32_t *qs, const int32_t *qe,
                             const int32_t *tid, const int32_t *ts, const int32_t *te,
                             int32_t n_chunks, raft_hip_host_outputs *out, raft_hip_summary *summary);
+
+/* The same job spread over several contexts -- one per GPU of the node (north_star: "reads and their overlaps shard
+ * embarrassingly across the 8 GPUs of one node"; SURVEY.md §8(e) host-routed mode, no collective): the host cuts the
+ * reads into consecutive ranges of equal record counts, context d gets the d-th group of ranges and runs the chunked
+ * pipeline on it with its own upload / download streams, all devices at once; outputs land in the caller's arrays in read
+ * order exactly as from one device.  ctxs[0]'s parameters and tuning apply to all.  Contexts are made with
+ * raft_hip_create(device_ids[d], ...) -- one call per device instead of SURVEY §8(b)'s create(device_ids[], n_dev): a
+ * context IS one device + its streams and buffers, and two contexts may share a device (how the single-GPU tests drive
+ * this path).  rep_cap / frag_cap must reach the bounds stated above (each device writes at its bound and the gaps are
+ * closed afterwards).  Falls back to ctxs[0] alone, one piece, exactly where raft_hip_run_pipelined does. */
+int  raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                        const int32_t *qid, const int32_t *qs, const int32_t *qe,
+                        const int32_t *tid, const int32_t *ts, const int32_t *te,
+                        int32_t n_chunks, raft_hip_host_outputs *out, raft_hip_summary *summary);
 
 /* Device seconds spent in the dominant kernel (coverage pileup + run scan) and
  * in all kernels of the last finished pass, from HIP events recorded on the

@@ -11,6 +11,8 @@
 #include "pileup_fast.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
@@ -171,8 +173,8 @@ struct raft_hip_ctx {
 
     // chunked host pipeline (raft_hip_run_pipelined): sub-contexts on the same device, one upload stream
     std::vector<raft_hip_ctx *> lanes;
-    hipStream_t up_stream = nullptr;
-    std::vector<hipEvent_t> lane_up_ev;
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    std::vector<hipEvent_t> lane_up_ev, lane_down_ev;
 
     // state of the last pass
     bool ran = false, finished = false;
@@ -290,8 +292,10 @@ void raft_hip_destroy(raft_hip_ctx *c)
     for (raft_hip_ctx *l : c->lanes) raft_hip_destroy(l);
     c->lanes.clear();
     for (hipEvent_t e : c->lane_up_ev) (void)hipEventDestroy(e);
-    c->lane_up_ev.clear();
+    for (hipEvent_t e : c->lane_down_ev) (void)hipEventDestroy(e);
+    c->lane_up_ev.clear(); c->lane_down_ev.clear();
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+    if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
@@ -840,14 +844,13 @@ struct ChunkResult {
     int path = 0;
 };
 
-struct PipeShared {
-    std::mutex mu;
+struct PipeShared {                                 // the chain of one context's chunks (positions within the context's job)
+    std::mutex mu, down_mu;
     std::condition_variable cv;
     int uploaded = 0;                               // chunks whose H2D has been enqueued (ticket of the upload stream)
     int published = 0;                              // chunks whose sizes are known (bases of the next chunk)
     long long base_bins = 0, base_rep = 0, base_frag = 0, base_exc = 0;
     int error = RAFT_HIP_OK;                        // first failure; every lane stops at its next check
-    bool redo = false;                              // a chunk reported a data error: redo the job in one piece
     std::string error_text;
 };
 
@@ -870,17 +873,70 @@ static int run_monolithic_to_host(raft_hip_ctx *c, int32_t n_reads, const int32_
     return rc;
 }
 
-int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, const int32_t *qid,
-                           const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts, const int32_t *te,
-                           int32_t n_chunks, raft_hip_host_outputs *o, raft_hip_summary *summary)
+namespace {
+
+constexpr int kLanes = 4;
+
+// Everything one context (one device) does in a multi-context job: its chunks, where its outputs start in the
+// caller's arrays, and the chain that hands each chunk the sizes of the chunks before it.
+struct DeviceJob {
+    raft_hip_ctx *c = nullptr;
+    int first_chunk = 0, n_chunks = 0;
+    // first entry of this job in the caller's arrays: windows are known in advance (read lengths); repeats, fragments and
+    // exceptions are not, so every job after the first starts at an upper bound and is moved down when all are done
+    long long bins0 = 0, rep0 = 0, frag0 = 0, exc0 = 0;
+    long long rep_room = 0, frag_room = 0, exc_room = 0;
+    PipeShared sh;
+    long long n_bins = 0, n_rep = 0, n_frag = 0, n_exc = 0;     // totals of the job (valid after the run)
+};
+
+int prepare_lanes(raft_hip_ctx *c)
 {
-    if (!c || !o) return RAFT_HIP_ERR_PARAM;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // Copies get streams of their own priority levels.  The runtime multiplexes streams onto a few hardware queues per
+    // priority level, and a copy holds its queue for its whole duration: on a queue shared with a lane's compute stream
+    // the kernels of one chunk sat behind the uploads of the next two (measured: 12 ms of a 0.4 ms pass).
+    if (!c->up_stream) {
+        int lo_p = 0, hi_p = 0;                      // numerically lowest = highest priority
+        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+        HIP_TRY(c, hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, hi_p));
+        HIP_TRY(c, hipStreamCreateWithPriority(&c->down_stream, hipStreamNonBlocking, lo_p));
+    }
+    while ((int)c->lanes.size() < kLanes) {
+        raft_hip_ctx *l = nullptr;
+        const int rc = raft_hip_create(c->device, &c->prm, &l);
+        if (rc != RAFT_HIP_OK) return rc;
+        c->lanes.push_back(l);
+        hipEvent_t e, d;
+        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->lane_up_ev.push_back(e);
+        HIP_TRY(c, hipEventCreateWithFlags(&d, hipEventDisableTiming));
+        c->lane_down_ev.push_back(d);
+    }
+    for (raft_hip_ctx *l : c->lanes) {
+        apply_params(l, &c->prm);
+        l->tile_q = c->tile_q; l->variant = c->variant; l->force_bucket = 0;
+    }
+    return RAFT_HIP_OK;
+}
+
+} // namespace
+
+int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                       const int32_t *qid, const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts,
+                       const int32_t *te, int32_t n_chunks, raft_hip_host_outputs *o, raft_hip_summary *summary)
+{
+    if (!ctxs || n_ctx < 1 || !ctxs[0] || !o) return RAFT_HIP_ERR_PARAM;
+    raft_hip_ctx *c = ctxs[0];
+    for (int d = 1; d < n_ctx; ++d) {
+        if (!ctxs[d]) return RAFT_HIP_ERR_PARAM;
+        for (int e = 0; e < d; ++e) if (ctxs[e] == ctxs[d]) return RAFT_HIP_ERR_PARAM;   // (two contexts may share a device)
+    }
     if (n_reads < 0 || n_rec < 0 || n_chunks < 0) return RAFT_HIP_ERR_PARAM;
     if (n_reads > 0 && !read_len) return RAFT_HIP_ERR_PARAM;
     if (n_rec > 0 && (!qid || !qs || !qe)) return RAFT_HIP_ERR_PARAM;
     if (!o->cov_offset || !o->rep_offset || !o->frag_offset) return RAFT_HIP_ERR_PARAM;
     o->n_exc = 0;
-    constexpr int kLanes = 3;
     long long seg[kMaxSeg + 1];
     int n_seg = -1;
     // chunking needs: the symmetric flag asserted, enough work to split, a record stream of at most kMaxSeg sorted runs
@@ -891,7 +947,8 @@ int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read
     if (n_seg < 1) return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary);
 
     int want = n_chunks > 0 ? std::min(n_chunks, n_reads)
-                            : (int)std::min<long long>(std::min<long long>(32, std::max<long long>(2, n_rec / (24LL << 20))), n_reads / 1024);
+                            : (int)std::min<long long>(std::min<long long>(32LL * n_ctx, std::max<long long>(2LL * n_ctx, n_rec / (24LL << 20))),
+                                                       n_reads / 1024);
     // ---- plan: read boundaries that balance the records, then one piece per run and chunk
     std::vector<ChunkPlan> plan;
     {
@@ -927,40 +984,71 @@ int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read
     const int n_ch = (int)plan.size();
     if (n_ch < 2) return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary);
 
-    // ---- lanes
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->up_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
-    while ((int)c->lanes.size() < kLanes) {
-        raft_hip_ctx *l = nullptr;
-        const int rc = raft_hip_create(c->device, &c->prm, &l);
-        if (rc != RAFT_HIP_OK) return rc;
-        c->lanes.push_back(l);
-        hipEvent_t e;
-        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->lane_up_ev.push_back(e);
-    }
-    for (raft_hip_ctx *l : c->lanes) {
-        apply_params(l, &c->prm);
-        l->tile_q = c->tile_q; l->variant = c->variant; l->force_bucket = 0;
+    // ---- contexts: consecutive chunks each (the plan balances records per chunk), parameters of the first
+    const int n_job = std::min(n_ctx, n_ch);
+    std::vector<DeviceJob> jobs((size_t)n_job);
+    {
+        const int minw = c->minbins, L = c->prm.interval_length, reso = c->prm.reso;
+        long long bins = 0, rep_cap = 0, frag_cap = 0;
+        int r = 0;
+        for (int d = 0; d < n_job; ++d) {
+            DeviceJob &J = jobs[(size_t)d];
+            J.c = ctxs[d];
+            J.first_chunk = n_ch * d / n_job; J.n_chunks = n_ch * (d + 1) / n_job - J.first_chunk;
+            if (d > 0) {
+                const int rc0 = raft_hip_set_params(J.c, &c->prm);
+                if (rc0 != RAFT_HIP_OK) return rc0;
+                J.c->tile_q = c->tile_q; J.c->variant = c->variant;
+            }
+            J.bins0 = bins; J.rep0 = rep_cap; J.frag0 = frag_cap;
+            const int r_end = plan[(size_t)(J.first_chunk + J.n_chunks - 1)].r1;
+            long long jr = 0, jf = 0;
+            for (; r < r_end; ++r) {                 // the upper bounds of include/raft_hip.h, per job
+                const long long len = read_len[r], nb = len / reso + ((len % reso) ? 1 : 0);
+                bins += nb; jr += (nb + 1) / ((long long)minw + 1); jf += len / L + 2;
+            }
+            J.rep_room = jr; J.frag_room = jf;
+            rep_cap += jr; frag_cap += jf;
+            J.exc0 = o->exc_cap * d / n_job; J.exc_room = o->exc_cap * (d + 1) / n_job - J.exc0;
+            const int rc = prepare_lanes(J.c);
+            if (rc != RAFT_HIP_OK) return rc;
+        }
+        if (n_job == 1) {                            // one context: the caller's capacities are the only limits
+            jobs[0].rep_room = o->rep_cap; jobs[0].frag_room = o->frag_cap;
+        } else if (rep_cap > o->rep_cap || frag_cap > o->frag_cap) {
+            c->last_error = "raft_hip_run_multi: rep_cap / frag_cap below the bounds stated in raft_hip.h";
+            return RAFT_HIP_ERR_TOO_LARGE;
+        }
+        if (bins > o->cov8_cap && o->cov8) { c->last_error = "cov8_cap below the number of windows"; return RAFT_HIP_ERR_TOO_LARGE; }
     }
 
     std::vector<ChunkResult> res((size_t)n_ch);
-    PipeShared sh;
-    auto fail = [&](int code, const std::string &text) {
-        std::lock_guard<std::mutex> g(sh.mu);
-        if (sh.error == RAFT_HIP_OK) { sh.error = code; sh.error_text = text; }
-        sh.cv.notify_all();
+    std::atomic<bool> redo{false};                  // a chunk reported a data error: the job is redone in one piece
+    const bool trace = getenv("RAFT_PIPE_TRACE") != nullptr;   // host-clock stamps per chunk and stage on stderr
+    const auto t_origin = std::chrono::steady_clock::now();
+    auto stamp = [&](int k, const char *what) {
+        if (trace) fprintf(stderr, "PIPE chunk %2d %-12s %8.3f ms\n", k, what,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_origin).count());
     };
 
-    auto lane_main = [&](int li) {
-        raft_hip_ctx *l = c->lanes[(size_t)li];
-        if (hipSetDevice(c->device) != hipSuccess) { fail(RAFT_HIP_ERR_DEVICE, "hipSetDevice"); return; }
+    auto lane_main = [&](DeviceJob &J, int li) {
+        raft_hip_ctx *jc = J.c;
+        raft_hip_ctx *l = jc->lanes[(size_t)li];
+        PipeShared &sh = J.sh;
+        auto fail = [&](int code, const std::string &text) {
+            std::lock_guard<std::mutex> g(sh.mu);
+            if (sh.error == RAFT_HIP_OK) { sh.error = code; sh.error_text = text; }
+            sh.cv.notify_all();
+        };
+        auto stop = [&]() { return sh.error != RAFT_HIP_OK || redo.load(); };
+        if (hipSetDevice(jc->device) != hipSuccess) { fail(RAFT_HIP_ERR_DEVICE, "hipSetDevice"); return; }
 #define LANE_TRY(expr)                                                                  \
         do {                                                                            \
             hipError_t e_ = (expr);                                                     \
             if (e_ != hipSuccess) { fail(fail_hip(l, e_, #expr), l->last_error); goto out; } \
         } while (0)
-        for (int k = li; k < n_ch; k += kLanes) {
+        for (int kk = li; kk < J.n_chunks; kk += kLanes) {
+            const int k = J.first_chunk + kk;        // global chunk index; kk = position in this job's chain
             const ChunkPlan &cp = plan[(size_t)k];
             ChunkResult &cr = res[(size_t)k];
             const int32_t nr = cp.r1 - cp.r0;
@@ -972,30 +1060,35 @@ int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read
             for (int col = 0; col < 3; ++col) LANE_TRY(l->in_col[col].ensure((size_t)std::max<long long>(cp.n_rec, 1) * 4));
             {
                 std::unique_lock<std::mutex> g(sh.mu);
-                sh.cv.wait(g, [&] { return sh.uploaded == k || sh.error != RAFT_HIP_OK || sh.redo; });
-                if (sh.error != RAFT_HIP_OK || sh.redo) goto out;
+                sh.cv.wait(g, [&] { return sh.uploaded == kk || stop(); });
+                if (stop()) goto out;
             }
             {
-                hipError_t e = hipMemcpyAsync(l->in_len.p, read_len + cp.r0, (size_t)nr * 4, hipMemcpyHostToDevice, c->up_stream);
+                hipError_t e = hipMemcpyAsync(l->in_len.p, read_len + cp.r0, (size_t)nr * 4, hipMemcpyHostToDevice, jc->up_stream);
                 const int32_t *src[3] = {qid, qs, qe};
                 for (int col = 0; col < 3 && e == hipSuccess; ++col) {
                     long long at = 0;
                     for (int g = 0; g < n_seg && e == hipSuccess; ++g) {
                         const long long n = cp.piece[g].hi - cp.piece[g].lo;
                         if (n > 0) e = hipMemcpyAsync(l->in_col[col].as<int32_t>() + at, src[col] + cp.piece[g].lo, (size_t)n * 4,
-                                                      hipMemcpyHostToDevice, c->up_stream);
+                                                      hipMemcpyHostToDevice, jc->up_stream);
                         at += n;
                     }
                 }
-                if (e == hipSuccess) e = hipEventRecord(c->lane_up_ev[(size_t)li], c->up_stream);
+                if (e == hipSuccess) e = hipEventRecord(jc->lane_up_ev[(size_t)li], jc->up_stream);
+                stamp(k, "h2d queued");
                 {
                     std::lock_guard<std::mutex> g(sh.mu);
-                    sh.uploaded = k + 1;
+                    sh.uploaded = kk + 1;
                     sh.cv.notify_all();
                 }
                 LANE_TRY(e);
             }
-            LANE_TRY(hipStreamWaitEvent(st, c->lane_up_ev[(size_t)li], 0));
+            // The lane's thread waits for the upload itself.  A wait-event parked in the lane's stream would sit in a
+            // hardware queue that other lanes' streams share, and hold THEIR kernels until this chunk's upload is done
+            // (measured: chunks whose pass was queued at 12 ms ran at 24 ms).
+            LANE_TRY(hipEventSynchronize(jc->lane_up_ev[(size_t)li]));
+            stamp(k, "h2d done");
             if (cp.n_rec > 0 && cp.r0 != 0) {
                 const unsigned grid = (unsigned)std::min<long long>((cp.n_rec + 255) / 256, 4096);
                 hipLaunchKernelGGL(rebase_ids_kernel, dim3(grid), dim3(256), 0, st, l->in_col[0].as<int32_t>(), cp.n_rec, cp.r0);
@@ -1004,31 +1097,32 @@ int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read
             {
                 int rc = raft_hip_run_device(l, nr, l->in_len.as<int32_t>(), cp.n_rec, l->in_col[0].as<int32_t>(),
                                              l->in_col[1].as<int32_t>(), l->in_col[2].as<int32_t>(), nullptr, nullptr, nullptr);
+                stamp(k, "pass queued");
                 if (rc == RAFT_HIP_OK) rc = raft_hip_finish(l, &s);
+                stamp(k, "pass done");
                 if (rc == RAFT_HIP_ERR_READ_ID || rc == RAFT_HIP_ERR_COORD || rc == RAFT_HIP_ERR_FRAGMENT || rc == RAFT_HIP_ERR_PARAM) {
                     // a data error (or a record outside the chunk it was cut into): the one-piece run reports it properly
-                    std::lock_guard<std::mutex> g(sh.mu);
-                    sh.redo = true;
-                    sh.cv.notify_all();
+                    redo.store(true);
                     goto out;
                 }
                 if (rc != RAFT_HIP_OK) { fail(rc, l->last_error); goto out; }
                 rc = pack_coverage(l);
                 if (rc != RAFT_HIP_OK) { fail(rc, l->last_error); goto out; }
+                stamp(k, "packed");
             }
             cr.n_bins = s.n_bins; cr.n_rep = s.n_repeats; cr.n_frag = s.n_fragments; cr.n_exc = l->n_exc; cr.n_cuts = s.n_cuts;
             cr.n_iv = s.n_intervals; cr.tot_cov = s.total_coverage; cr.tot_rep = s.total_repeat_length; cr.tot_len = s.total_read_length;
             cr.path = s.interval_path;
-            // -- where this chunk's outputs go: after those of all earlier chunks
+            // -- where this chunk's outputs go: after those of the job's earlier chunks
             {
                 std::unique_lock<std::mutex> g(sh.mu);
-                sh.cv.wait(g, [&] { return sh.published == k || sh.error != RAFT_HIP_OK || sh.redo; });
-                if (sh.error != RAFT_HIP_OK || sh.redo) goto out;
-                b_bins = sh.base_bins; b_rep = sh.base_rep; b_frag = sh.base_frag; b_exc = sh.base_exc;
+                sh.cv.wait(g, [&] { return sh.published == kk || stop(); });
+                if (stop()) goto out;
+                b_bins = J.bins0 + sh.base_bins; b_rep = J.rep0 + sh.base_rep; b_frag = J.frag0 + sh.base_frag; b_exc = J.exc0 + sh.base_exc;
                 sh.base_bins += cr.n_bins; sh.base_rep += cr.n_rep; sh.base_frag += cr.n_frag; sh.base_exc += cr.n_exc;
-                sh.published = k + 1;
-                if (sh.base_bins > o->cov8_cap || sh.base_rep > o->rep_cap || sh.base_frag > o->frag_cap || sh.base_exc > o->exc_cap) {
-                    if (sh.error == RAFT_HIP_OK) { sh.error = RAFT_HIP_ERR_TOO_LARGE; sh.error_text = "host output capacity"; }
+                sh.published = kk + 1;
+                if (sh.base_rep > J.rep_room || sh.base_frag > J.frag_room || sh.base_exc > J.exc_room) {
+                    if (sh.error == RAFT_HIP_OK) { sh.error = RAFT_HIP_ERR_TOO_LARGE; sh.error_text = "host output capacity (repeats / fragments / exceptions)"; }
                 }
                 sh.cv.notify_all();
                 if (sh.error != RAFT_HIP_OK) goto out;
@@ -1040,7 +1134,8 @@ int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read
                         hipLaunchKernelGGL(add_base_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st,
                                            b.as<long long>(), n, base);
                 };
-                add_base(l->cov_off, n1, b_bins); add_base(l->rep_off, n1, b_rep); add_base(l->frag_off, n1, b_frag);
+                // offsets count from the job's first entry (rep / frag of later jobs are moved down afterwards)
+                add_base(l->cov_off, n1, b_bins); add_base(l->rep_off, n1, b_rep - J.rep0); add_base(l->frag_off, n1, b_frag - J.frag0);
                 add_base(l->exc_idx, cr.n_exc, b_bins);
                 struct { void *dst; const void *src; size_t bytes; } job[] = {
                     {o->cov8 ? o->cov8 + b_bins : nullptr, l->cov8.p, (size_t)cr.n_bins},
@@ -1053,9 +1148,18 @@ int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read
                     {o->frag_offset + cp.r0, l->frag_off.p, (size_t)n1 * 8},
                     {o->frag_begin ? o->frag_begin + b_frag : nullptr, l->frag_begin.p, (size_t)cr.n_frag * 4},
                     {o->frag_end ? o->frag_end + b_frag : nullptr, l->frag_end.p, (size_t)cr.n_frag * 4}};
-                for (auto &j : job)
-                    if (j.dst && j.bytes) LANE_TRY(hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, st));
-                LANE_TRY(hipStreamSynchronize(st));
+                // the download stream takes over once the lane's last kernel is done; the lane waits for its own copies only
+                LANE_TRY(hipEventRecord(jc->lane_down_ev[(size_t)li], st));
+                {
+                    std::lock_guard<std::mutex> g(sh.down_mu);       // one chunk's copies stay together on the stream
+                    LANE_TRY(hipStreamWaitEvent(jc->down_stream, jc->lane_down_ev[(size_t)li], 0));
+                    for (auto &j : job)
+                        if (j.dst && j.bytes) LANE_TRY(hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, jc->down_stream));
+                    LANE_TRY(hipEventRecord(jc->lane_down_ev[(size_t)li], jc->down_stream));
+                }
+                stamp(k, "d2h queued");
+                LANE_TRY(hipEventSynchronize(jc->lane_down_ev[(size_t)li]));
+                stamp(k, "d2h done");
                 if (o->exc_index && o->exc_value && cr.n_exc > 1) {    // ascending by window, like raft_hip_fetch_packed
                     std::vector<std::pair<int64_t, int32_t>> ex((size_t)cr.n_exc);
                     for (size_t i = 0; i < ex.size(); ++i) ex[i] = {o->exc_index[b_exc + (long long)i], o->exc_value[b_exc + (long long)i]};
@@ -1074,13 +1178,24 @@ int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read
 
     {
         std::vector<std::thread> th;
-        for (int li = 1; li < kLanes; ++li) th.emplace_back(lane_main, li);
-        lane_main(0);
+        for (int d = 0; d < n_job; ++d)
+            for (int li = 0; li < kLanes; ++li)
+                if (d || li) th.emplace_back([&, d, li] { lane_main(jobs[(size_t)d], li); });
+        lane_main(jobs[0], 0);
         for (auto &t : th) t.join();
     }
-    (void)hipStreamSynchronize(c->up_stream);
-    for (raft_hip_ctx *l : c->lanes) (void)hipStreamSynchronize(l->stream);
-    if (sh.redo) return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary);
+    int err = RAFT_HIP_OK;
+    for (DeviceJob &J : jobs) {
+        (void)hipSetDevice(J.c->device);
+        (void)hipStreamSynchronize(J.c->up_stream);
+        (void)hipStreamSynchronize(J.c->down_stream);
+        for (raft_hip_ctx *l : J.c->lanes) (void)hipStreamSynchronize(l->stream);
+        J.c->ran = false; J.c->finished = false;   // the contexts hold no pass: fetch / outputs_device do not apply
+        J.n_bins = J.sh.base_bins; J.n_rep = J.sh.base_rep; J.n_frag = J.sh.base_frag; J.n_exc = J.sh.base_exc;
+        if (J.sh.error != RAFT_HIP_OK && err == RAFT_HIP_OK) { err = J.sh.error; c->last_error = J.sh.error_text; }
+    }
+    (void)hipSetDevice(c->device);
+    if (redo.load()) return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary);
 
     raft_hip_summary s{};
     s.n_reads = n_reads; s.symmetric = 1; s.high_cov = c->high_cov; s.n_segments = n_seg; s.n_records = n_rec; s.error_index = -1;
@@ -1090,11 +1205,37 @@ int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read
         s.interval_path |= cr.path;
     }
     s.total_windows = s.n_bins;
-    o->n_exc = sh.base_exc;
     if (summary) *summary = s;
-    c->ran = false; c->finished = false;           // the context itself holds no pass: fetch / outputs_device do not apply
-    if (sh.error != RAFT_HIP_OK) { c->last_error = sh.error_text; return sh.error; }
+    if (err != RAFT_HIP_OK) return err;
+    // ---- later jobs wrote repeats / fragments / exceptions at their upper-bound positions: close the gaps
+    {
+        long long rep_at = jobs[0].n_rep, frag_at = jobs[0].n_frag, exc_at = jobs[0].n_exc;
+        for (int d = 1; d < n_job; ++d) {
+            DeviceJob &J = jobs[(size_t)d];
+            const int32_t ra = plan[(size_t)J.first_chunk].r0, rb = plan[(size_t)(J.first_chunk + J.n_chunks - 1)].r1;
+            auto move32 = [](int32_t *a, long long to, long long from, long long n) { if (a && n && to != from) memmove(a + to, a + from, (size_t)n * 4); };
+            move32(o->rep_s, rep_at, J.rep0, J.n_rep); move32(o->rep_e, rep_at, J.rep0, J.n_rep);
+            move32(o->frag_begin, frag_at, J.frag0, J.n_frag); move32(o->frag_end, frag_at, J.frag0, J.n_frag);
+            move32(o->exc_value, exc_at, J.exc0, J.n_exc);
+            if (o->exc_index && J.n_exc && exc_at != J.exc0) memmove(o->exc_index + exc_at, o->exc_index + J.exc0, (size_t)J.n_exc * 8);
+            const int32_t r_hi = rb + ((d == n_job - 1) ? 1 : 0);
+            for (int32_t r = ra; r < r_hi; ++r) { o->rep_offset[r] += rep_at; o->frag_offset[r] += frag_at; }
+            rep_at += J.n_rep; frag_at += J.n_frag; exc_at += J.n_exc;
+        }
+        o->n_exc = exc_at;
+        if (n_job > 1 && s.n_fragments > 0) {        // (with one job the closing entries are already global)
+            // closing entries of jobs before the last are the first entries of their successors: nothing to patch
+        }
+    }
     return RAFT_HIP_OK;
+}
+
+int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, const int32_t *qid,
+                           const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts, const int32_t *te,
+                           int32_t n_chunks, raft_hip_host_outputs *o, raft_hip_summary *summary)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    return raft_hip_run_multi(&c, 1, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, n_chunks, o, summary);
 }
 
 int raft_hip_last_timing(raft_hip_ctx *c, double *pileup_seconds, double *pass_seconds)

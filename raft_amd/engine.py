@@ -23,7 +23,7 @@ EXPORTS = (
     "raft_hip_abi_version", "raft_hip_strerror", "raft_hip_last_error", "raft_hip_create", "raft_hip_destroy",
     "raft_hip_set_params", "raft_hip_set_stream", "raft_hip_use_own_stream", "raft_hip_get_stream", "raft_hip_run_device", "raft_hip_run_host",
     "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
-    "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed", "raft_hip_run_pipelined",
+    "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed", "raft_hip_run_pipelined", "raft_hip_run_multi",
 )
 
 
@@ -122,6 +122,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_fetch.argtypes = [vp] + [vp] * 11
     lib.raft_hip_fetch_packed.argtypes = [vp, vp, vp, i64, vp, vp, C.POINTER(i64)] + [vp] * 7
     lib.raft_hip_run_pipelined.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
+    lib.raft_hip_run_multi.argtypes = [C.POINTER(vp), i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.raft_hip_set_tuning.argtypes = [vp, i32, i32, i32]
     lib.raft_hip_selftest.argtypes = [C.c_int]
@@ -288,9 +289,11 @@ class Engine:
                 "rep_e": alloc(caps["rep"], np.int32), "frag_offset": alloc(n1, np.int64), "frag_begin": alloc(caps["frag"], np.int32),
                 "frag_end": alloc(caps["frag"], np.int32)}
 
-    def run_pipelined(self, read_len, qid, qs, qe, tid=None, ts=None, te=None, n_chunks: int = 0, out: dict | None = None):
+    def run_pipelined(self, read_len, qid, qs, qe, tid=None, ts=None, te=None, n_chunks: int = 0, out: dict | None = None,
+                      others: list | None = None):
         """raft_hip_run_pipelined: host columns in, host outputs out, with upload / pass / download of consecutive read
-        ranges overlapped.  Returns (dict of arrays trimmed to their sizes -- views of ``out`` --, Summary)."""
+        ranges overlapped.  ``others``: more Engines (other GPUs of the node, or the same one) to share the job with
+        (raft_hip_run_multi).  Returns (dict of arrays trimmed to their sizes -- views of ``out`` --, Summary)."""
         cols = [None if a is None else np.ascontiguousarray(np.asarray(a), dtype=np.int32) for a in (read_len, qid, qs, qe, tid, ts, te)]
         n_rec = cols[1].size
         if out is None:
@@ -301,7 +304,12 @@ class Engine:
         ho.cov8_cap, ho.exc_cap, ho.rep_cap, ho.frag_cap = out["cov8"].size, out["exc_index"].size, out["rep_s"].size, out["frag_begin"].size
         ptr = [C.c_void_p(a.ctypes.data if (a is not None and a.size) else 0) for a in cols]
         s = _Summary()
-        rc = self._lib.raft_hip_run_pipelined(self._ctx, cols[0].size, ptr[0], n_rec, *ptr[1:], int(n_chunks), C.byref(ho), C.byref(s))
+        if others:
+            ctxs = (C.c_void_p * (1 + len(others)))(self._ctx, *[e._ctx for e in others])
+            rc = self._lib.raft_hip_run_multi(ctxs, 1 + len(others), cols[0].size, ptr[0], n_rec, *ptr[1:], int(n_chunks),
+                                              C.byref(ho), C.byref(s))
+        else:
+            rc = self._lib.raft_hip_run_pipelined(self._ctx, cols[0].size, ptr[0], n_rec, *ptr[1:], int(n_chunks), C.byref(ho), C.byref(s))
         summ = Summary(**{f: int(getattr(s, f)) for f, _ in _Summary._fields_})
         self.summary = summ
         self._check(rc, summ.error_index)

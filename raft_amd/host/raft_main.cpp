@@ -15,6 +15,7 @@
 #include <chrono>
 #include <thread>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -121,11 +122,29 @@ int main(int argc, char *argv[])
         t_prev = now;
     };
 
-    // the device context comes up (runtime init, first allocations) while the host tokenises the inputs
-    raft_hip_ctx *ctx = nullptr;
-    const char *dev_env = getenv("RAFT_DEVICE");
-    int create_rc = RAFT_HIP_OK;
-    std::thread bring_up([&] { create_rc = raft_hip_create(dev_env ? atoi(dev_env) : 0, &hp, &ctx); });
+    // The device contexts come up (runtime init, first allocations) while the host tokenises the inputs.
+    // RAFT_DEVICES=0,1,...: the GPUs of the node that share the job (reads shard across them, host-routed, no collective;
+    // SURVEY.md §8e); RAFT_DEVICE=n: a single one; default: device 0.  A device may be named twice.
+    std::vector<int> devices;
+    if (const char *e = getenv("RAFT_DEVICES")) {
+        for (const char *q = e; *q;) {
+            char *end = nullptr;
+            const long v = strtol(q, &end, 10);
+            if (end == q) break;
+            devices.push_back((int)v);
+            q = (*end == ',') ? end + 1 : end;
+            if (*end != ',' && *end != '\0') break;
+        }
+    }
+    if (devices.empty()) { const char *e = getenv("RAFT_DEVICE"); devices.push_back(e ? atoi(e) : 0); }
+    std::vector<raft_hip_ctx *> ctxs(devices.size(), nullptr);
+    std::vector<int> create_rc(devices.size(), RAFT_HIP_OK);
+    std::thread bring_up([&] {
+        std::vector<std::thread> th;
+        for (size_t d = 1; d < devices.size(); ++d) th.emplace_back([&, d] { create_rc[d] = raft_hip_create(devices[d], &hp, &ctxs[d]); });
+        create_rc[0] = raft_hip_create(devices[0], &hp, &ctxs[0]);
+        for (auto &t : th) t.join();
+    });
     g_background[0] = &bring_up;
 
     raft_host_reads *reads = nullptr;
@@ -145,7 +164,10 @@ int main(int argc, char *argv[])
     const int64_t n_rec = raft_host_paf_count(paf);
     stage("paf_load");
     bring_up.join();
-    if (create_rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_create(), ") + raft_hip_strerror(create_rc));
+    for (size_t d = 0; d < devices.size(); ++d)
+        if (create_rc[d] != RAFT_HIP_OK)
+            die(std::string("ERROR, raft_hip_create(), device ") + std::to_string(devices[d]) + ": " + raft_hip_strerror(create_rc[d]));
+    raft_hip_ctx *ctx = ctxs[0];
     stage("device_wait");
 
     // The tokeniser already knows whether the PAF is symmetric (chop.hpp:171-184, found while the lines were in
@@ -155,11 +177,44 @@ int main(int argc, char *argv[])
     rc = raft_hip_set_params(ctx, &hp);
     if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_set_params(), ") + raft_hip_strerror(rc));
     const bool sym = hp.symmetric_mode == 1;
-    rc = raft_hip_run_host(ctx, n_reads, raft_host_reads_lengths(reads), n_rec, raft_host_paf_column(paf, 0),
-                           raft_host_paf_column(paf, 1), raft_host_paf_column(paf, 2), sym ? nullptr : raft_host_paf_column(paf, 3),
-                           sym ? nullptr : raft_host_paf_column(paf, 4), sym ? nullptr : raft_host_paf_column(paf, 5));
+
+    // Host arrays for everything that comes back, sized by the bounds of raft_hip.h (from the read lengths alone).
+    // Coverage returns in its transfer encoding (a byte per window + the windows at or above 255): a quarter of the
+    // int32 array's bytes over PCIe, and the formatter below reads it as it is.
+    const int32_t *rl = raft_host_reads_lengths(reads);
+    int64_t n_win = 0, rep_cap = 0, frag_cap = 0;
+    {
+        const int64_t minw = std::max<int64_t>(((int64_t)p.repeat_length + p.reso - 1) / p.reso, 1);
+        for (int32_t i = 0; i < n_reads; ++i) {
+            const int64_t nb = ((int64_t)rl[i] + p.reso - 1) / p.reso;
+            n_win += nb; rep_cap += (nb + 1) / (minw + 1); frag_cap += rl[i] / p.interval_length + 2;
+        }
+    }
+    std::vector<int64_t> cov_off((size_t)n_reads + 1), rep_off((size_t)n_reads + 1), frag_off((size_t)n_reads + 1);
+    std::unique_ptr<uint8_t[]> cov8(new uint8_t[(size_t)n_win + 1]);            // (not value-initialised: no zero fill)
+    std::unique_ptr<int32_t[]> rep_s(new int32_t[(size_t)rep_cap + 1]), rep_e(new int32_t[(size_t)rep_cap + 1]);
+    std::unique_ptr<int32_t[]> fb(new int32_t[(size_t)frag_cap + 1]), fe(new int32_t[(size_t)frag_cap + 1]);
+    std::vector<int64_t> exc_i;
+    std::vector<int32_t> exc_v;
     raft_hip_summary s{};
-    if (rc == RAFT_HIP_OK) rc = raft_hip_finish(ctx, &s);
+    int64_t n_exc = 0;
+    const char *chunks_env = getenv("RAFT_CHUNKS");   // 0 / unset: the engine decides (one piece for small inputs)
+    for (int64_t exc_cap = std::max<int64_t>(1 << 16, n_win / 64), attempt = 0; attempt < 2; ++attempt) {
+        exc_i.resize((size_t)exc_cap); exc_v.resize((size_t)exc_cap);
+        raft_hip_host_outputs ho{};
+        ho.cov_offset = cov_off.data(); ho.cov8 = cov8.get(); ho.cov8_cap = n_win;
+        ho.exc_index = exc_i.data(); ho.exc_value = exc_v.data(); ho.exc_cap = exc_cap;
+        ho.rep_offset = rep_off.data(); ho.rep_s = rep_s.get(); ho.rep_e = rep_e.get(); ho.rep_cap = rep_cap;
+        ho.frag_offset = frag_off.data(); ho.frag_begin = fb.get(); ho.frag_end = fe.get(); ho.frag_cap = frag_cap;
+        // upload, pass and download of consecutive read ranges overlap, on every device named (one piece for small inputs)
+        rc = raft_hip_run_multi(ctxs.data(), (int32_t)ctxs.size(), n_reads, rl, n_rec, raft_host_paf_column(paf, 0),
+                                raft_host_paf_column(paf, 1), raft_host_paf_column(paf, 2), sym ? nullptr : raft_host_paf_column(paf, 3),
+                                sym ? nullptr : raft_host_paf_column(paf, 4), sym ? nullptr : raft_host_paf_column(paf, 5),
+                                chunks_env ? atoi(chunks_env) : 0, &ho, &s);
+        n_exc = ho.n_exc;
+        if (rc != RAFT_HIP_ERR_TOO_LARGE || attempt == 1) break;
+        exc_cap = std::max<int64_t>(n_win, 1);        // (more windows at or above 255 than expected: room for all of them)
+    }
     if (rc != RAFT_HIP_OK) {
         std::string m = std::string("ERROR, raft_hip, ") + raft_hip_strerror(rc);
         if (s.error_index >= 0) m += " (index " + std::to_string(s.error_index) + ")";
@@ -167,37 +222,19 @@ int main(int argc, char *argv[])
         if (d && *d) m += std::string(" [") + d + "]";
         die(m);
     }
-    stage("engine");
+    stage("engine+fetch");
     fprintf(stdout, "INFO, Symmetric overlaps %d \n", s.symmetric);            // chop.hpp:189-190
     fprintf(stdout, "INFO, length of alignments  %d()\n", (int)s.n_records);
     fprintf(stdout, "high_cov %d\n", s.high_cov);                              // repeat.hpp:91
 
-    // coverage comes back in its transfer encoding (a byte per window + the windows at or above 255): a quarter of
-    // the int32 array's bytes over PCIe, and the formatter below reads it as it is
-    std::vector<int64_t> cov_off((size_t)n_reads + 1), rep_off((size_t)n_reads + 1), frag_off((size_t)n_reads + 1);
-    std::unique_ptr<uint8_t[]> cov8(new uint8_t[(size_t)s.n_bins + 1]);         // (not value-initialised: no zero fill)
-    std::vector<int32_t> rep_s((size_t)s.n_repeats), rep_e((size_t)s.n_repeats);
-    std::vector<int32_t> fb((size_t)s.n_fragments), fe((size_t)s.n_fragments);
-    std::vector<int64_t> exc_i;
-    std::vector<int32_t> exc_v;
-    int64_t n_exc = 0;
-    rc = raft_hip_fetch_packed(ctx, nullptr, nullptr, 0, nullptr, nullptr, &n_exc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    if (rc == RAFT_HIP_OK) {
-        exc_i.resize((size_t)n_exc); exc_v.resize((size_t)n_exc);
-        rc = raft_hip_fetch_packed(ctx, cov_off.data(), cov8.get(), n_exc, exc_i.data(), exc_v.data(), &n_exc, rep_off.data(),
-                                   rep_s.data(), rep_e.data(), frag_off.data(), nullptr, fb.data(), fe.data());
-    }
-    if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_fetch_packed(), ") + raft_hip_strerror(rc));
-    stage("fetch");
-
     // the four output files are independent: the FASTA is written beside the coverage/repeat tables
     int fasta_rc = RAFT_HOST_OK;
-    std::thread fasta_writer([&] { fasta_rc = raft_host_write_fasta(fasta_out.c_str(), reads, frag_off.data(), fb.data(), fe.data()); });
+    std::thread fasta_writer([&] { fasta_rc = raft_host_write_fasta(fasta_out.c_str(), reads, frag_off.data(), fb.get(), fe.get()); });
     g_background[1] = &fasta_writer;
     if (raft_host_write_coverage_packed((p.prefix + ".coverage.txt").c_str(), n_reads, p.reso, cov_off.data(), cov8.get(), n_exc,
                                         exc_i.data(), exc_v.data()) != RAFT_HOST_OK ||
         raft_host_write_repeats((p.prefix + ".long_repeats.txt").c_str(), (p.prefix + ".long_repeats.bed").c_str(), reads,
-                                rep_off.data(), rep_s.data(), rep_e.data()) != RAFT_HOST_OK) {
+                                rep_off.data(), rep_s.get(), rep_e.get()) != RAFT_HOST_OK) {
         die("ERROR, repeat_annotate(), cannot write output files");
     }
     stage("write_tables");
@@ -237,6 +274,6 @@ int main(int argc, char *argv[])
     if (!tooling) _exit(0);
     raft_host_paf_free(paf);
     raft_host_reads_free(reads);
-    raft_hip_destroy(ctx);
+    for (raft_hip_ctx *c : ctxs) raft_hip_destroy(c);
     return 0;
 }

@@ -18,9 +18,15 @@ def strip_timing(out: str) -> str:
                      if not l.startswith("INFO, main(), program completed after") and not l.startswith("INFO, main(), CMD:"))
 
 
-def run(cwd, args):
-    r = subprocess.run([RAFT] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+def run(cwd, args, env=None):
+    r = subprocess.run([RAFT] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                       env=dict(os.environ, **env) if env else None)
     return r.returncode, r.stdout.decode()
+
+
+# the C++ host on several contexts / chunked: RAFT_DEVICES names the GPUs that share the job (the box has one, so it is
+# named twice or three times: same code path, two or three contexts), RAFT_CHUNKS forces the chunked pipeline on small inputs
+MULTI = [None, {"RAFT_CHUNKS": "3"}, {"RAFT_DEVICES": "0,0", "RAFT_CHUNKS": "5"}, {"RAFT_DEVICES": "0,0,0", "RAFT_CHUNKS": "7"}]
 
 
 @pytest.mark.parametrize("name", sorted(MAN["micro"]))
@@ -39,26 +45,28 @@ def test_cli_micro_cases(tmp_path, name):
         assert open(tmp_path / f, "rb").read() == open(os.path.join(d, "expect." + f), "rb").read(), (name, f)
 
 
+@pytest.mark.parametrize("env", MULTI, ids=lambda e: "one" if e is None else "-".join(f"{k[5:]}{v}" for k, v in e.items()))
 @pytest.mark.parametrize("name", sorted(MAN["synthetic"]))
-def test_cli_synthetic_cases(tmp_path, name):
+def test_cli_synthetic_cases(tmp_path, name, env):
     p, cols, exp, meta = load_case(name)
     names = [f"r{i}" for i in range(len(cols[0]))]
     write_fasta(tmp_path / "reads.fa", names, cols[0])
     write_paf(tmp_path / "overlaps.paf", names, *cols)
-    rc, out = run(tmp_path, meta["args"] + ["reads.fa", "overlaps.paf"])
+    rc, out = run(tmp_path, meta["args"] + ["reads.fa", "overlaps.paf"], env)
     assert rc == 0, out
     assert strip_timing(out) == meta["stdout"]
     for f, digest in meta["md5"].items():
         assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, (name, f)
 
 
-def test_cli_config1_gz(tmp_path):
+@pytest.mark.parametrize("env", [None, {"RAFT_DEVICES": "0,0", "RAFT_CHUNKS": "6"}], ids=["one", "two-contexts"])
+def test_cli_config1_gz(tmp_path, env):
     """BASELINE configs[0] (README.md:12-33 `raft -e 42 -o fragmented reads.fa.gz overlaps.paf`) on the SURVEY §8(d)
     stand-in (2 Mbp, 42x), both inputs gzip-compressed: four files md5-identical to the reference's, stdout equal."""
     from raft_testlib import load_config1, write_config1_inputs
     p, cols, exp, meta = load_config1()
     write_config1_inputs(str(tmp_path), cols, meta)
-    rc, out = run(tmp_path, meta["args"] + meta["inputs"])
+    rc, out = run(tmp_path, meta["args"] + meta["inputs"], env)
     assert rc == 0, out
     assert strip_timing(out) == meta["stdout"]
     for f, digest in meta["md5"].items():
@@ -97,3 +105,5 @@ def test_cli_usage_and_input_errors(tmp_path):
     (tmp_path / "b.paf").write_text("x\t4\t0\t400\t+\tx\t4\t0\t4\t1\t1\t1\n")  # reaches past the last window: defined error
     rc, out = run(tmp_path, ["-e", "30", "a.fa", "b.paf"])
     assert rc == 1 and "ERROR, raft_hip, PAF coordinate" in out
+    rc, out = run(tmp_path, ["-e", "30", "a.fa", "b.paf"], {"RAFT_DEVICES": "0,7"})   # a device that does not exist
+    assert rc == 1 and "ERROR, raft_hip_create(), device 7" in out

@@ -230,10 +230,11 @@ def check_pipelined(res, s, want, what):
     assert s.n_intervals == want["n_intervals"], what
 
 
+@pytest.mark.parametrize("n_ctx", [1, 2, 3])
 @pytest.mark.parametrize("kw,n_chunks", [(dict(n_reads=4000, seed=81), 5), (dict(n_reads=4000, seed=81), 2), (dict(n_reads=4000, seed=81), 23),
                                          (dict(n_reads=1500, seed=82, mean_len=90000, sigma=0.9, max_len=1_200_000, coverage=25), 4),
                                          (dict(n_reads=50000, seed=2), 0)])
-def test_pipelined_equals_oracle(kw, n_chunks):
+def test_pipelined_equals_oracle(kw, n_chunks, n_ctx):
     """Upload / pass / download of consecutive read ranges overlapped: same outputs as the one-piece pass and the oracle.
     n_chunks = 0 lets the engine choose (the 50 k-read set is just above its threshold)."""
     from raft_amd import engine
@@ -243,15 +244,19 @@ def test_pipelined_equals_oracle(kw, n_chunks):
     p = RaftParams(est_cov=int(kw.get("coverage", 30)))
     want = oracle_run(p, *cols)
     eng = engine.Engine(RaftParams(**dict(p.__dict__, symmetric_mode=1)), device=0)
+    # more contexts share the job (raft_hip_run_multi): on this box they sit on the same GPU; their own parameters are
+    # overwritten by the first context's
+    others = [engine.Engine(RaftParams(est_cov=3, reso=7), device=0) for _ in range(n_ctx - 1)]
     out = eng.host_output_buffers(cols[0], pinned=True)
     for rep in range(2):                                  # a second pass reuses lanes and buffers
-        res, s = eng.run_pipelined(cols[0], cols[1], cols[2], cols[3], n_chunks=n_chunks, out=out)
-        check_pipelined(res, s, want, f"{kw} chunks {n_chunks} pass {rep}")
+        res, s = eng.run_pipelined(cols[0], cols[1], cols[2], cols[3], n_chunks=n_chunks, out=out, others=others)
+        check_pipelined(res, s, want, f"{kw} chunks {n_chunks} contexts {n_ctx} pass {rep}")
         assert s.n_segments == 2
     with pytest.raises(engine.RaftError) as e:            # the context itself holds no pass after a pipelined run
         eng.fetch()
     assert e.value.code == engine.ERR_STATE
-    eng.close()
+    for e2 in [eng] + others:
+        e2.close()
 
 
 def test_pipelined_shapes_and_fallbacks():

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""One chunked end-to-end pass of the bench workload with RAFT_PIPE_TRACE=1 (stage clock per chunk on stderr)."""
+import os, sys, time
+os.environ["RAFT_PIPE_TRACE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from raft_amd import engine
+from raft_amd.params import RaftParams
+from raft_amd.synth import make_overlaps
+
+reads = int(sys.argv[1]) if len(sys.argv) > 1 else 3_300_000
+chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+o = make_overlaps(reads, mean_len=30000.0, coverage=32.0, seed=20241008, device="cuda:0")
+host = [c.cpu().pin_memory().numpy() for c in (o.read_len, o.qid, o.qs, o.qe)]
+eng = engine.Engine(RaftParams(est_cov=32, symmetric_mode=1))
+out = eng.host_output_buffers(host[0], pinned=True)
+for it in range(3):
+    sys.stderr.write(f"---- pass {it}\n")
+    t = time.perf_counter()
+    res, s = eng.run_pipelined(*host, n_chunks=chunks, out=out)
+    dt = time.perf_counter() - t
+    sys.stderr.write(f"pass {it}: {dt*1e3:.1f} ms -> {o.n_rec/dt:.3e} records/s\n")
