@@ -84,6 +84,33 @@ __global__ __launch_bounds__(256) void inspect_kernel(long long n_rec, int32_t n
     }
 }
 
+// Sorted runs of the record stream as 8 k evenly spaced samples show them: where one sample is smaller than the one
+// before, a run ends in between, and a bisection (left part >= the earlier sample, right part below it) finds the first
+// record of the next run.  One workgroup, ~30 dependent loads deep.  This is what a speculative pass starts from
+// (engine.hip run_pass); inspect_kernel, which looks at every record, confirms or refutes it while the pass runs.
+struct GuessOut {
+    int32_t n_desc, pad;
+    long long desc_pos[kMaxSeg];
+};
+
+__global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const int32_t *qid, GuessOut *out)
+{
+    const long long S = n_rec < 8192 ? n_rec : 8192;      // (out->n_desc was zeroed with the control block)
+    for (long long i = 1 + threadIdx.x; i < S; i += blockDim.x) {
+        const long long p0 = (i - 1) * (n_rec - 1) / (S - 1), p1 = i * (n_rec - 1) / (S - 1);
+        const int32_t v = qid[p0];
+        if (qid[p1] < v) {
+            long long lo = p0, hi = p1;
+            while (hi - lo > 1) {
+                const long long mid = lo + (hi - lo) / 2;
+                if (qid[mid] >= v) lo = mid; else hi = mid;
+            }
+            const int slot = atomicAdd(&out->n_desc, 1);
+            if (slot < kMaxSeg) out->desc_pos[slot] = hi;
+        }
+    }
+}
+
 // tile_first[k] = first read whose first window lies in tile k or later (tiles of Q windows).
 __global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const long long *cov_off, int Q,
                                                          long long n_tiles, int32_t *tile_first)

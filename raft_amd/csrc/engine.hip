@@ -85,6 +85,7 @@ struct Ctrl {                         // device control block, cleared every pas
     unsigned long long totals[4];     // coverage, repeat bp, read length
     InspectOut insp;
     long long out_totals[4];          // rep / cut / frag totals land here via the scan
+    GuessOut guess;                   // sorted runs as seen from samples (speculative pass)
 };
 
 struct DevBuf {
@@ -150,6 +151,8 @@ struct raft_hip_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t side_stream = nullptr;   // the general pileup kernel runs beside the fast one
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t insp_stream = nullptr;   // speculative pass: the full look at the record stream runs beside the pass
+    hipEvent_t ev_ifork = nullptr, ev_ijoin = nullptr;
     raft_hip_params prm{};
     int32_t high_cov = 0, div = 0, minbins = 1;
     int32_t tile_q = 0;               // 0 = variant default
@@ -175,6 +178,12 @@ struct raft_hip_ctx {
     std::vector<raft_hip_ctx *> lanes;
     hipStream_t up_stream = nullptr, down_stream = nullptr;
     std::vector<hipEvent_t> lane_up_ev, lane_down_ev;
+
+    // speculation (see run_pass): what the pass assumed, and the arguments to run it again if the assumption fails
+    bool spec = false;
+    int spec_sym = 1;                  // what a detecting context (symmetric_mode = -1) assumes: the last pass's answer
+    GuessOut spec_guess{};
+    struct PassArgs { int32_t n_reads; const int32_t *len; int64_t n_rec; const int32_t *col[6]; } args{};
 
     // state of the last pass
     bool ran = false, finished = false;
@@ -271,6 +280,9 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     apply_params(c, params);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->insp_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_ifork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_ijoin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
@@ -309,6 +321,9 @@ void raft_hip_destroy(raft_hip_ctx *c)
     if (c->ev_pile1) (void)hipEventDestroy(c->ev_pile1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_ifork) (void)hipEventDestroy(c->ev_ifork);
+    if (c->ev_ijoin) (void)hipEventDestroy(c->ev_ijoin);
+    if (c->insp_stream) (void)hipStreamDestroy(c->insp_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -351,9 +366,16 @@ int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket
     return RAFT_HIP_OK;
 }
 
-int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int64_t n_rec,
-                        const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
-                        const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te)
+// One pass.  `speculate`: do not wait for the full look at the record stream (inspect_kernel: ids in range, sorted runs,
+// mirror of record 0 -- one read of the qid column, 0.22 ms at human scale, all of it ahead of the pass's host wait).
+// Instead a one-workgroup kernel guesses the sorted runs from 8 k samples, a detecting context assumes the answer of
+// its previous pass (symmetric at first: hifiasm's shape), the pass starts on that, and inspect_kernel runs BESIDE it
+// on a stream of its own -- the pileup kernel is bound by instruction issue and leaves the memory system room for it.
+// raft_hip_finish() compares: if the records hold anything the guess did not say (another descent, an id out of
+// range, no mirror after all), the pass is run again without speculation, from the same arguments.
+static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int64_t n_rec,
+                    const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
+                    const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te, bool speculate)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
     if (n_reads < 0 || n_rec < 0) return RAFT_HIP_ERR_PARAM;
@@ -369,6 +391,11 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1; c->packed_ready = false;
+    c->args = {n_reads, d_len, n_rec, {d_qid, d_qs, d_qe, d_tid, d_ts, d_te}};
+    static const bool no_spec_env = getenv("RAFT_NO_SPECULATION") != nullptr;
+    const bool spec = speculate && !no_spec_env && n_rec > 0 && c->prm.symmetric_mode != 0 && !c->force_bucket &&
+                      (c->prm.symmetric_mode == 1 || c->spec_sym == 1);
+    c->spec = spec;
     memset(&c->sum, 0, sizeof c->sum);
     c->sum.n_reads = n_reads; c->sum.n_records = n_rec; c->sum.high_cov = c->high_cov; c->sum.error_index = -1;
     const long long N = n_reads;
@@ -395,13 +422,23 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     long long *h = reinterpret_cast<long long *>(c->pinned);
     HIP_TRY(c, hipMemcpyAsync(h, scan_totals, 3 * sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(h + 4, ctrl, 16, hipMemcpyDeviceToHost, st));
-    // ---- look at the record stream in the same trip: symmetric PAF? sorted runs? ids in range?
+    // ---- look at the record stream: symmetric PAF? sorted runs? ids in range?  In the same trip as the sizes -- or, when
+    //      speculating, beside the pass, with only the sampled guess in this trip
     InspectOut *hi = reinterpret_cast<InspectOut *>(h + 8);
+    GuessOut *hg = reinterpret_cast<GuessOut *>(h + 32);
     if (n_rec > 0) {
         const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((n_rec / 4 + 255) / 256, 256 * 8));
-        hipLaunchKernelGGL(inspect_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads,
+        hipStream_t ist = spec ? c->insp_stream : st;
+        if (spec) {
+            HIP_TRY(c, hipEventRecord(c->ev_ifork, st));                    // (behind the memsets of the control block)
+            HIP_TRY(c, hipStreamWaitEvent(ist, c->ev_ifork, 0));
+            hipLaunchKernelGGL(guess_runs_kernel, dim3(1), dim3(256), 0, st, (long long)n_rec, d_qid, &ctrl->guess);
+            HIP_TRY(c, hipMemcpyAsync(hg, &ctrl->guess, sizeof(GuessOut), hipMemcpyDeviceToHost, st));
+        }
+        hipLaunchKernelGGL(inspect_kernel, dim3(grid), dim3(256), 0, ist, (long long)n_rec, n_reads,
                            c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
-        HIP_TRY(c, hipMemcpyAsync(hi, &ctrl->insp, sizeof(InspectOut), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(hi, &ctrl->insp, sizeof(InspectOut), hipMemcpyDeviceToHost, ist));
+        if (spec) HIP_TRY(c, hipEventRecord(c->ev_ijoin, ist));
     }
     HIP_TRY(c, hipStreamSynchronize(st));                                   // the pass's only host wait: sizes + path choice
     const long long B = h[0], RU = h[1], CU = h[2];
@@ -463,7 +500,12 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     int symmetric = c->prm.symmetric_mode == 1 ? 1 : 0;
     int n_desc = 0;
     long long desc[kMaxSeg];
-    if (n_rec > 0) {
+    if (spec) {
+        symmetric = 1;
+        c->spec_guess = *hg;
+        n_desc = hg->n_desc;
+        for (int i = 0; i < std::min(n_desc, kMaxSeg); ++i) desc[i] = hg->desc_pos[i];
+    } else if (n_rec > 0) {
         if (hi->err_flags) {
             c->pending_err = code_from_flags(hi->err_flags);
             c->pending_err_index = hi->err_index;
@@ -472,7 +514,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
             HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
             return RAFT_HIP_OK;
         }
-        if (c->prm.symmetric_mode < 0) symmetric = hi->sym_found ? 1 : 0;
+        if (c->prm.symmetric_mode < 0) { symmetric = hi->sym_found ? 1 : 0; c->spec_sym = symmetric; }
         n_desc = hi->n_desc;
         for (int i = 0; i < std::min(n_desc, kMaxSeg); ++i) desc[i] = hi->desc_pos[i];
     }
@@ -610,6 +652,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
                            c->frag_off.as<long long>(), c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr,
                            ctrl->out_totals);
     }
+    if (spec) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_ijoin, 0));           // the pass is over when its verification is
     // everything finish() reports travels in one block, copied while the stream drains
     HIP_TRY(c, hipMemcpyAsync(reinterpret_cast<char *>(c->pinned) + 1024, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
     c->fa = fa; c->cuts_ready = false;
@@ -617,6 +660,13 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
     return RAFT_HIP_OK;
+}
+
+int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int64_t n_rec,
+                        const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
+                        const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te)
+{
+    return run_pass(c, n_reads, d_len, n_rec, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, true);
 }
 
 int raft_hip_run_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
@@ -652,6 +702,29 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->finished) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->spec && c->pending_err == RAFT_HIP_OK) {
+            // what the full look at the records found, against what the pass assumed
+            HIP_TRY(c, hipStreamSynchronize(c->insp_stream));
+            const InspectOut *hi = reinterpret_cast<const InspectOut *>(reinterpret_cast<long long *>(c->pinned) + 8);
+            bool ok = hi->err_flags == 0;
+            if (c->prm.symmetric_mode < 0) { ok = ok && hi->sym_found == 1; c->spec_sym = hi->sym_found ? 1 : 0; }
+            const GuessOut &g = c->spec_guess;
+            if (g.n_desc + 1 <= kMaxSeg || hi->n_desc + 1 <= kMaxSeg) {   // (otherwise both mean the counting-sort path)
+                ok = ok && hi->n_desc == g.n_desc;
+                for (int i = 0; ok && i < g.n_desc; ++i) {
+                    bool found = false;
+                    for (int j = 0; j < hi->n_desc; ++j) found = found || hi->desc_pos[j] == g.desc_pos[i];
+                    ok = found;
+                }
+            }
+            c->spec = false;
+            if (!ok) {                               // run it again, this time waiting for the facts
+                const auto a = c->args;
+                const int rc = run_pass(c, a.n_reads, a.len, a.n_rec, a.col[0], a.col[1], a.col[2], a.col[3], a.col[4], a.col[5], false);
+                if (rc != RAFT_HIP_OK) return rc;
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+            }
+        }
         if (c->pending_err == RAFT_HIP_OK) {
             Ctrl hc;
             memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));   // copied at the end of the pass

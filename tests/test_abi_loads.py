@@ -36,7 +36,7 @@ def test_cli_binary_fails_loudly_without_device(tmp_path):
     (tmp_path / "a.fa").write_text(">x\nACGT\n")
     (tmp_path / "b.paf").write_text("x\t4\t0\t4\t+\tx\t4\t0\t4\t1\t1\t1\n")
     r = subprocess.run([exe, "-e", "3", "a.fa", "b.paf"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    assert r.returncode == 1 and b"ERROR, raft_hip_create(), HIP device/runtime error" in r.stdout
+    assert r.returncode == 1 and b"ERROR, raft_hip_create(), device 0: HIP device/runtime error" in r.stdout
 
 
 def test_no_cpu_fallback_without_device():
