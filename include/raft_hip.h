@@ -167,9 +167,9 @@ int  raft_hip_fetch_packed(raft_hip_ctx *ctx, int64_t *cov_offset, uint8_t *cov8
                            int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end);
 
 /* Caller-owned host arrays (page-locked for full PCIe rate) that receive the outputs of raft_hip_run_pipelined, with
- * their capacities in elements.  Upper bounds the caller can compute from read_len alone:
- *   cov8_cap >= sum ceil(len/reso);  frag_cap >= sum (len/interval_length + 2);
- *   rep_cap  >= sum (ceil(len/reso) + 1) / (ceil(repeat_length/reso) + 1)   (<= n_reads for defaults and reads < 400 kb).
+ * their capacities in elements.  Upper bounds the caller can compute from read_len alone, with W = sum ceil(len/reso)
+ * and N = n_reads:
+ *   cov8_cap >= W;   frag_cap >= (sum len) / interval_length + 2 N;   rep_cap >= (W + N) / (ceil(repeat_length/reso) + 1).
  * cov_offset / rep_offset / frag_offset hold n_reads + 1 entries.  frag_read is not returned: fragment f of read i is
  * every f in [frag_offset[i], frag_offset[i+1]).  n_exc is written by the call. */
 typedef struct raft_hip_host_outputs {

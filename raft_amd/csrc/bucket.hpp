@@ -88,26 +88,30 @@ __global__ __launch_bounds__(256) void inspect_kernel(long long n_rec, int32_t n
 // before, a run ends in between, and a bisection (left part >= the earlier sample, right part below it) finds the first
 // record of the next run.  One workgroup, ~30 dependent loads deep.  This is what a speculative pass starts from
 // (engine.hip run_pass); inspect_kernel, which looks at every record, confirms or refutes it while the pass runs.
+// (16 k samples: ~14 bisection steps per run end)
 struct GuessOut {
     int32_t n_desc, pad;
     long long desc_pos[kMaxSeg];
 };
 
+constexpr int kGuessBlocks = 64;                           // x 256 threads: one pair of adjacent samples per thread
+
 __global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const int32_t *qid, GuessOut *out)
 {
-    const long long S = n_rec < 8192 ? n_rec : 8192;      // (out->n_desc was zeroed with the control block)
-    for (long long i = 1 + threadIdx.x; i < S; i += blockDim.x) {
-        const long long p0 = (i - 1) * (n_rec - 1) / (S - 1), p1 = i * (n_rec - 1) / (S - 1);
-        const int32_t v = qid[p0];
-        if (qid[p1] < v) {
-            long long lo = p0, hi = p1;
-            while (hi - lo > 1) {
-                const long long mid = lo + (hi - lo) / 2;
-                if (qid[mid] >= v) lo = mid; else hi = mid;
-            }
-            const int slot = atomicAdd(&out->n_desc, 1);
-            if (slot < kMaxSeg) out->desc_pos[slot] = hi;
+    const long long T = (long long)kGuessBlocks * 256;
+    const long long S = n_rec < T + 1 ? n_rec : T + 1;    // samples (out->n_desc was zeroed with the control block)
+    const long long i = 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    const long long p0 = (i - 1) * (n_rec - 1) / (S - 1), p1 = i * (n_rec - 1) / (S - 1);
+    const int32_t v = qid[p0];
+    if (qid[p1] < v) {
+        long long lo = p0, hi = p1;
+        while (hi - lo > 1) {
+            const long long mid = lo + (hi - lo) / 2;
+            if (qid[mid] >= v) lo = mid; else hi = mid;
         }
+        const int slot = atomicAdd(&out->n_desc, 1);
+        if (slot < kMaxSeg) out->desc_pos[slot] = hi;
     }
 }
 

@@ -135,6 +135,29 @@ template <int K> struct CountLoader {
     }
 };
 
+// What the host reads back goes straight into its page-locked block (device-visible host memory): a copy command per
+// few bytes cost ~25 us each on the device timeline (three of them ahead of the pass's host wait).
+__global__ void publish_sizes_kernel(const long long *scan_totals, const Ctrl *ctrl, long long *host)
+{
+    const int t = threadIdx.x;
+    if (t < 3) host[t] = scan_totals[t];
+    const long long *c8 = reinterpret_cast<const long long *>(ctrl);
+    if (t < 2) host[4 + t] = c8[t];                                           // err_flags, n_slow, err_index
+    constexpr int kInsp = (int)(sizeof(InspectOut) / 8), kGuess = (int)(sizeof(GuessOut) / 8);
+    const long long *in = reinterpret_cast<const long long *>(&ctrl->insp), *gu = reinterpret_cast<const long long *>(&ctrl->guess);
+    if (t < kInsp) host[8 + t] = in[t];
+    if (t < kGuess) host[32 + t] = gu[t];
+    __threadfence_system();
+}
+
+__global__ void publish_ctrl_kernel(const Ctrl *ctrl, long long *host)
+{
+    constexpr int kWords = (int)(sizeof(Ctrl) / 8);
+    static_assert(sizeof(Ctrl) % 8 == 0 && kWords <= 64, "one wave copies the control block");
+    if ((int)threadIdx.x < kWords) host[threadIdx.x] = reinterpret_cast<const long long *>(ctrl)[threadIdx.x];
+    __threadfence_system();
+}
+
 __global__ void selftest_kernel(const int *in, int *out_dpp, int *out_shfl, unsigned long long *ballots)
 {
     const int v = in[threadIdx.x];
@@ -172,6 +195,8 @@ struct raft_hip_ctx {
     long long n_exc = 0, exc_cap = 0;
     long long dbg_tiles = 0;
     void *pinned = nullptr;           // small pinned scratch for readbacks
+    long long *pinned_dev = nullptr;  // the same block as the device addresses it
+    hipEvent_t ev_gjoin = nullptr;
     hipEvent_t ev_pass0 = nullptr, ev_pass1 = nullptr, ev_pile0 = nullptr, ev_pile1 = nullptr;
 
     // chunked host pipeline (raft_hip_run_pipelined): sub-contexts on the same device, one upload stream
@@ -286,6 +311,8 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&c->pinned_dev), c->pinned, 0) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_gjoin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev_pass0) != hipSuccess || hipEventCreate(&c->ev_pass1) != hipSuccess ||
         hipEventCreate(&c->ev_pile0) != hipSuccess || hipEventCreate(&c->ev_pile1) != hipSuccess) {
         raft_hip_destroy(c);
@@ -322,6 +349,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_ifork) (void)hipEventDestroy(c->ev_ifork);
+    if (c->ev_gjoin) (void)hipEventDestroy(c->ev_gjoin);
     if (c->ev_ijoin) (void)hipEventDestroy(c->ev_ijoin);
     if (c->insp_stream) (void)hipStreamDestroy(c->insp_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
@@ -407,6 +435,24 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     HIP_TRY(c, hipMemsetAsync(&ctrl->err_index, 0xFF, sizeof(long long), st));
     HIP_TRY(c, hipMemsetAsync(&ctrl->insp.err_index, 0xFF, sizeof(long long), st));
 
+    // ---- look at the record stream: symmetric PAF? sorted runs? ids in range?  In the same trip as the sizes -- or, when
+    //      speculating, on a stream of its own: the sampled guess beside the geometry scans, the full look beside the pass
+    long long *h = reinterpret_cast<long long *>(c->pinned);
+    InspectOut *hi = reinterpret_cast<InspectOut *>(h + 8);
+    GuessOut *hg = reinterpret_cast<GuessOut *>(h + 32);
+    const unsigned igrid = (unsigned)std::max<long long>(1, std::min<long long>((n_rec / 4 + 255) / 256, 256 * 8));
+    if (spec) {
+        hipStream_t ist = c->insp_stream;
+        HIP_TRY(c, hipEventRecord(c->ev_ifork, st));                        // (the control block is clear)
+        HIP_TRY(c, hipStreamWaitEvent(ist, c->ev_ifork, 0));
+        hipLaunchKernelGGL(guess_runs_kernel, dim3(kGuessBlocks), dim3(256), 0, ist, (long long)n_rec, d_qid, &ctrl->guess);
+        HIP_TRY(c, hipEventRecord(c->ev_gjoin, ist));
+        hipLaunchKernelGGL(inspect_kernel, dim3(igrid), dim3(256), 0, ist, (long long)n_rec, n_reads,
+                           c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
+        HIP_TRY(c, hipMemcpyAsync(hi, &ctrl->insp, sizeof(InspectOut), hipMemcpyDeviceToHost, ist));
+        HIP_TRY(c, hipEventRecord(c->ev_ijoin, ist));
+    }
+
     // ---- per-read geometry: windows, reserved repeat slots, marker capacity (one scan, three sums)
     const int nb_scan = std::max(scan_blocks(N), 1);
     HIP_TRY(c, c->scan_tmp.ensure(((size_t)nb_scan * 3 + 8) * sizeof(long long)));
@@ -419,27 +465,11 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
         ScanOut<3> so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), c->cutcap_off.as<long long>()}};
         exclusive_scan<ReadPrepLoader, 3>(st, ld, N, c->scan_tmp.as<long long>(), so, &scan_totals);
     }
-    long long *h = reinterpret_cast<long long *>(c->pinned);
-    HIP_TRY(c, hipMemcpyAsync(h, scan_totals, 3 * sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(h + 4, ctrl, 16, hipMemcpyDeviceToHost, st));
-    // ---- look at the record stream: symmetric PAF? sorted runs? ids in range?  In the same trip as the sizes -- or, when
-    //      speculating, beside the pass, with only the sampled guess in this trip
-    InspectOut *hi = reinterpret_cast<InspectOut *>(h + 8);
-    GuessOut *hg = reinterpret_cast<GuessOut *>(h + 32);
-    if (n_rec > 0) {
-        const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((n_rec / 4 + 255) / 256, 256 * 8));
-        hipStream_t ist = spec ? c->insp_stream : st;
-        if (spec) {
-            HIP_TRY(c, hipEventRecord(c->ev_ifork, st));                    // (behind the memsets of the control block)
-            HIP_TRY(c, hipStreamWaitEvent(ist, c->ev_ifork, 0));
-            hipLaunchKernelGGL(guess_runs_kernel, dim3(1), dim3(256), 0, st, (long long)n_rec, d_qid, &ctrl->guess);
-            HIP_TRY(c, hipMemcpyAsync(hg, &ctrl->guess, sizeof(GuessOut), hipMemcpyDeviceToHost, st));
-        }
-        hipLaunchKernelGGL(inspect_kernel, dim3(grid), dim3(256), 0, ist, (long long)n_rec, n_reads,
+    if (spec) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_gjoin, 0));
+    else if (n_rec > 0)
+        hipLaunchKernelGGL(inspect_kernel, dim3(igrid), dim3(256), 0, st, (long long)n_rec, n_reads,
                            c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
-        HIP_TRY(c, hipMemcpyAsync(hi, &ctrl->insp, sizeof(InspectOut), hipMemcpyDeviceToHost, ist));
-        if (spec) HIP_TRY(c, hipEventRecord(c->ev_ijoin, ist));
-    }
+    hipLaunchKernelGGL(publish_sizes_kernel, dim3(1), dim3(64), 0, st, scan_totals, ctrl, c->pinned_dev);
     HIP_TRY(c, hipStreamSynchronize(st));                                   // the pass's only host wait: sizes + path choice
     const long long B = h[0], RU = h[1], CU = h[2];
     {
@@ -654,7 +684,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     }
     if (spec) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_ijoin, 0));           // the pass is over when its verification is
     // everything finish() reports travels in one block, copied while the stream drains
-    HIP_TRY(c, hipMemcpyAsync(reinterpret_cast<char *>(c->pinned) + 1024, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(publish_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl, c->pinned_dev + 128);   // (+1024 bytes)
     c->fa = fa; c->cuts_ready = false;
     HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
     HIP_TRY(c, hipGetLastError());
@@ -1061,7 +1091,19 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
     const int n_job = std::min(n_ctx, n_ch);
     std::vector<DeviceJob> jobs((size_t)n_job);
     {
-        const int minw = c->minbins, L = c->prm.interval_length, reso = c->prm.reso;
+        // Where each context's outputs start in the caller's arrays.  Windows are exact (sum of ceil(len / reso) over the
+        // reads before: one multiply-high per read, the division the kernels use); repeats and fragments start at the
+        // bounds of raft_hip.h and are moved down when all contexts are done.  One context needs none of this.
+        const long long minw = c->minbins, L = c->prm.interval_length;
+        const unsigned reso = (unsigned)c->prm.reso;
+        int lg = 0;
+        while ((1ull << lg) < reso) ++lg;
+        const unsigned long long magic = reso > 1 ? ((1ull << (31 + lg)) / reso + 1ull) : 0ull;
+        auto windows = [&](int32_t len) -> long long {       // exact for 0 <= len < 2^31 (engine.hip run_pass, div_magic)
+            if (reso == 1) return len;
+            const unsigned q = (unsigned)((((unsigned long long)(unsigned)len * magic) >> 32) >> (lg - 1));
+            return (long long)q + ((unsigned)len - q * reso ? 1 : 0);
+        };
         long long bins = 0, rep_cap = 0, frag_cap = 0;
         int r = 0;
         for (int d = 0; d < n_job; ++d) {
@@ -1074,25 +1116,25 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
                 J.c->tile_q = c->tile_q; J.c->variant = c->variant;
             }
             J.bins0 = bins; J.rep0 = rep_cap; J.frag0 = frag_cap;
-            const int r_end = plan[(size_t)(J.first_chunk + J.n_chunks - 1)].r1;
-            long long jr = 0, jf = 0;
-            for (; r < r_end; ++r) {                 // the upper bounds of include/raft_hip.h, per job
-                const long long len = read_len[r], nb = len / reso + ((len % reso) ? 1 : 0);
-                bins += nb; jr += (nb + 1) / ((long long)minw + 1); jf += len / L + 2;
+            if (n_job > 1) {
+                const int r_end = plan[(size_t)(J.first_chunk + J.n_chunks - 1)].r1;
+                long long jb = 0, jl = 0;
+                for (; r < r_end; ++r) { jb += windows(read_len[r]); jl += read_len[r]; }
+                const long long n_r = r_end - plan[(size_t)J.first_chunk].r0;
+                // sum floor(x_i / m) <= floor(sum x_i / m): the per-read bounds of raft_hip.h, summed, are at least these
+                J.rep_room = (jb + n_r) / (minw + 1); J.frag_room = jl / L + 2 * n_r;
+                bins += jb; rep_cap += J.rep_room; frag_cap += J.frag_room;
             }
-            J.rep_room = jr; J.frag_room = jf;
-            rep_cap += jr; frag_cap += jf;
             J.exc0 = o->exc_cap * d / n_job; J.exc_room = o->exc_cap * (d + 1) / n_job - J.exc0;
             const int rc = prepare_lanes(J.c);
             if (rc != RAFT_HIP_OK) return rc;
         }
         if (n_job == 1) {                            // one context: the caller's capacities are the only limits
             jobs[0].rep_room = o->rep_cap; jobs[0].frag_room = o->frag_cap;
-        } else if (rep_cap > o->rep_cap || frag_cap > o->frag_cap) {
-            c->last_error = "raft_hip_run_multi: rep_cap / frag_cap below the bounds stated in raft_hip.h";
+        } else if (rep_cap > o->rep_cap || frag_cap > o->frag_cap || (o->cov8 && bins > o->cov8_cap)) {
+            c->last_error = "raft_hip_run_multi: cov8_cap / rep_cap / frag_cap below the bounds stated in raft_hip.h";
             return RAFT_HIP_ERR_TOO_LARGE;
         }
-        if (bins > o->cov8_cap && o->cov8) { c->last_error = "cov8_cap below the number of windows"; return RAFT_HIP_ERR_TOO_LARGE; }
     }
 
     std::vector<ChunkResult> res((size_t)n_ch);
@@ -1194,7 +1236,8 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
                 b_bins = J.bins0 + sh.base_bins; b_rep = J.rep0 + sh.base_rep; b_frag = J.frag0 + sh.base_frag; b_exc = J.exc0 + sh.base_exc;
                 sh.base_bins += cr.n_bins; sh.base_rep += cr.n_rep; sh.base_frag += cr.n_frag; sh.base_exc += cr.n_exc;
                 sh.published = kk + 1;
-                if (sh.base_rep > J.rep_room || sh.base_frag > J.frag_room || sh.base_exc > J.exc_room) {
+                if (sh.base_rep > J.rep_room || sh.base_frag > J.frag_room || sh.base_exc > J.exc_room ||
+                    (o->cov8 && J.bins0 + sh.base_bins > o->cov8_cap)) {
                     if (sh.error == RAFT_HIP_OK) { sh.error = RAFT_HIP_ERR_TOO_LARGE; sh.error_text = "host output capacity (repeats / fragments / exceptions)"; }
                 }
                 sh.cv.notify_all();

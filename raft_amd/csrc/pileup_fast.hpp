@@ -243,11 +243,14 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             bool bad_any = false;
             auto win = [&](unsigned n) -> int { return (int)(((n & win_m1) | __umulhi(n, a.div_magic)) >> win_sh); };
             auto one = [&](int rid, int st, int en) {
-                const unsigned j = min((unsigned)(rid - r_a), (unsigned)nr);      // (an empty slot would read entry nr)
+                const unsigned jr = (unsigned)(rid - r_a);
+                const unsigned j = min(jr, (unsigned)nr);                         // (an empty slot would read entry nr)
                 const int b0 = tb.roff[j], nb_r = tb.roff[j + 1] - b0;
                 const int first = win((unsigned)st);
                 const int last1 = win((unsigned)(en - 1)) + 1;                    // meaningful for en >= 1
-                const bool valid = rid >= 0, sign_ok = (st | en) >= 0, pos = en > 0;
+                // valid: a record of one of the tile's reads.  Empty slots carry -1; a foreign read id can only come from
+                // a mis-speculated pass (engine.hip run_pass), whose results are thrown away -- it must not reach the tables
+                const bool valid = jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
                 const bool over = last1 > first && last1 > nb_r;                   // repeat.hpp:69-72 writes past its vector
                 const int pf = b0 + first, pl1 = b0 + min(last1, nb_r);
                 bad_any |= valid && (!sign_ok || (pos && over));
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             if (__ballot(bad_any) != 0ull) {     // rare: find the offending records again and report the first index
                 const TileCut d0 = cuts[k], d1 = cuts[k + 1];
                 auto is_bad = [&](int rid, int st, int en) -> bool {
+                    if ((unsigned)(rid - r_a) >= (unsigned)nr) return false;
                     const int j = rid - r_a;
                     const int nb_r = tb.roff[j + 1] - tb.roff[j];
                     const int first = (int)win_of(a, (unsigned)st), last1 = (int)win_of(a, (unsigned)(en - 1)) + 1;

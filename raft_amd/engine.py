@@ -273,7 +273,7 @@ class Engine:
         rl = np.asarray(read_len, np.int64)
         nb = (rl + p.reso - 1) // p.reso
         minw = max((p.repeat_length + p.reso - 1) // p.reso, 1)
-        caps = {"cov8": int(nb.sum()), "rep": int(((nb + 1) // (minw + 1)).sum()), "frag": int((rl // p.interval_length + 2).sum()),
+        caps = {"cov8": int(nb.sum()), "rep": (int(nb.sum()) + rl.size) // (minw + 1), "frag": int(rl.sum()) // p.interval_length + 2 * rl.size,
                 "exc": int(exc_cap)}
         n1 = rl.size + 1
 

@@ -185,10 +185,10 @@ int main(int argc, char *argv[])
     int64_t n_win = 0, rep_cap = 0, frag_cap = 0;
     {
         const int64_t minw = std::max<int64_t>(((int64_t)p.repeat_length + p.reso - 1) / p.reso, 1);
-        for (int32_t i = 0; i < n_reads; ++i) {
-            const int64_t nb = ((int64_t)rl[i] + p.reso - 1) / p.reso;
-            n_win += nb; rep_cap += (nb + 1) / (minw + 1); frag_cap += rl[i] / p.interval_length + 2;
-        }
+        int64_t sum_len = 0;
+        for (int32_t i = 0; i < n_reads; ++i) { n_win += ((int64_t)rl[i] + p.reso - 1) / p.reso; sum_len += rl[i]; }
+        rep_cap = (n_win + n_reads) / (minw + 1);
+        frag_cap = sum_len / p.interval_length + 2 * (int64_t)n_reads;
     }
     std::vector<int64_t> cov_off((size_t)n_reads + 1), rep_off((size_t)n_reads + 1), frag_off((size_t)n_reads + 1);
     std::unique_ptr<uint8_t[]> cov8(new uint8_t[(size_t)n_win + 1]);            // (not value-initialised: no zero fill)

@@ -314,3 +314,43 @@ def test_pipelined_shapes_and_fallbacks():
     res, s = eng.run_pipelined(rl, z, z, z, z, z, z)
     assert s.n_fragments >= len(rl) and int(res["cov8"].sum()) == 0
     eng.close()
+
+
+def test_misspeculated_pass_is_redone():
+    """A pass starts from a sampled guess of the sorted runs while inspect_kernel looks at every record (engine.hip
+    run_pass).  Streams the samples misjudge -- disorder between two samples, a read id out of range between two samples,
+    a detecting context meeting a non-symmetric PAF -- must come out exactly as without speculation."""
+    from raft_amd import engine
+    rng = np.random.default_rng(123)
+    rl = rng.integers(3000, 40000, 2000).astype(np.int32)
+    n = 60000                                             # > 16 k samples: most records are never sampled
+    qid = np.sort(rng.integers(0, len(rl), n)).astype(np.int32)
+    a = (rng.random(n) * rl[qid]).astype(np.int32)
+    b = np.minimum(rl[qid], a + 1 + (rng.random(n) * rl[qid] * 0.5).astype(np.int32)).astype(np.int32)
+    p = RaftParams(est_cov=12)
+    eng = engine.Engine(RaftParams(est_cov=12, symmetric_mode=1), device=0)
+    for trial in range(6):
+        q2, a2, b2 = qid.copy(), a.copy(), b.copy()
+        i, j = sorted(rng.integers(1, n - 1, 2).tolist())
+        for arr in (q2, a2, b2):
+            arr[i], arr[j] = arr[j], arr[i]               # two far-apart records swapped: two hidden dips in the order
+        want = oracle_run(p, rl, q2, a2, b2, q2, a2, b2); want["symmetric"] = 1
+        eng.run_host(rl, q2, a2, b2, None, None, None)
+        s = eng.finish()
+        assert_same_result(engine_result(eng, s), want, f"swap {i} <-> {j}")
+    q3 = qid.copy(); q3[n // 3 + 5] = len(rl) + 7         # an id out of range that no sample sees
+    with pytest.raises(engine.RaftError) as e:
+        eng.run_host(rl, q3, a, b, None, None, None); eng.finish()
+    assert e.value.code == engine.ERR_READ_ID and e.value.index == n // 3 + 5
+    eng.close()
+    # detection mode: the first pass assumes a symmetric PAF, is refuted, and the context remembers the answer
+    tid = ((qid.astype(np.int64) + 1) % len(rl)).astype(np.int32)
+    ts = np.zeros(n, np.int32); te = np.minimum(rl[tid], 100).astype(np.int32)
+    want = oracle_run(p, rl, qid, a, b, tid, ts, te)
+    assert want["symmetric"] == 0
+    eng = engine.Engine(p, device=0)
+    for rep in range(2):
+        eng.run_host(rl, qid, a, b, tid, ts, te)
+        s = eng.finish()
+        assert_same_result(engine_result(eng, s), want, f"non-symmetric, pass {rep}")
+    eng.close()
