@@ -188,6 +188,7 @@ struct raft_hip_ctx {
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
+    DevBuf run_start;                 // [kMaxSeg][n_reads + 1] first record of each read in each sorted run (inspect_kernel)
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
     DevBuf dbg;                       // diagnostic variant only
     DevBuf cov8, exc_idx, exc_val, exc_cnt;   // transfer encoding of cov[] (raft_hip_fetch_packed)
@@ -302,10 +303,12 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     raft_hip_ctx *c = new (std::nothrow) raft_hip_ctx();
     if (!c) return RAFT_HIP_ERR_NOMEM;
     c->device = device_id;
+    int prio_lo = 0, prio_hi = 0;
     apply_params(c, params);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->insp_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->insp_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||   // lowest priority
         hipEventCreateWithFlags(&c->ev_ifork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ijoin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -339,7 +342,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->dbg, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->run_start, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -435,40 +438,44 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     HIP_TRY(c, hipMemsetAsync(&ctrl->err_index, 0xFF, sizeof(long long), st));
     HIP_TRY(c, hipMemsetAsync(&ctrl->insp.err_index, 0xFF, sizeof(long long), st));
 
-    // ---- look at the record stream: symmetric PAF? sorted runs? ids in range?  In the same trip as the sizes -- or, when
-    //      speculating, on a stream of its own: the sampled guess beside the geometry scans, the full look beside the pass
+    // ---- two things have to be known before the host can size and launch the rest, and they run side by side:
+    //  (main stream) what the record stream looks like -- sorted runs sampled by guess_runs_kernel, then every record by
+    //      inspect_kernel: ids in range? the runs exactly as sampled? mirror of record 0?  On the way it writes the table
+    //      of run starts per read that turns the tile cuts into look-ups;
+    //  (side stream) the per-read geometry: windows, reserved repeat slots, marker capacity (one scan, three sums).
+    //  A speculating pass (RAFT_SPECULATE=1) only waits for the samples and lets inspect_kernel run beside the pileup.
     long long *h = reinterpret_cast<long long *>(c->pinned);
     InspectOut *hi = reinterpret_cast<InspectOut *>(h + 8);
     GuessOut *hg = reinterpret_cast<GuessOut *>(h + 32);
     const unsigned igrid = (unsigned)std::max<long long>(1, std::min<long long>((n_rec / 4 + 255) / 256, 256 * 8));
-    if (spec) {
-        hipStream_t ist = c->insp_stream;
-        HIP_TRY(c, hipEventRecord(c->ev_ifork, st));                        // (the control block is clear)
-        HIP_TRY(c, hipStreamWaitEvent(ist, c->ev_ifork, 0));
-        hipLaunchKernelGGL(guess_runs_kernel, dim3(kGuessBlocks), dim3(256), 0, ist, (long long)n_rec, d_qid, &ctrl->guess);
-        HIP_TRY(c, hipEventRecord(c->ev_gjoin, ist));
-        hipLaunchKernelGGL(inspect_kernel, dim3(igrid), dim3(256), 0, ist, (long long)n_rec, n_reads,
-                           c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
-        HIP_TRY(c, hipMemcpyAsync(hi, &ctrl->insp, sizeof(InspectOut), hipMemcpyDeviceToHost, ist));
-        HIP_TRY(c, hipEventRecord(c->ev_ijoin, ist));
-    }
-
-    // ---- per-read geometry: windows, reserved repeat slots, marker capacity (one scan, three sums)
     const int nb_scan = std::max(scan_blocks(N), 1);
     HIP_TRY(c, c->scan_tmp.ensure(((size_t)nb_scan * 3 + 8) * sizeof(long long)));
     HIP_TRY(c, c->cov_off.ensure((size_t)(N + 1) * 8));
     HIP_TRY(c, c->rep_res_off.ensure((size_t)(N + 1) * 8));
     HIP_TRY(c, c->cutcap_off.ensure((size_t)(N + 1) * 8));
+    const bool want_table = n_rec > 0 && !spec && c->prm.symmetric_mode != 0 && !c->force_bucket;
+    if (want_table) HIP_TRY(c, c->run_start.ensure((size_t)kMaxSeg * (size_t)(N + 1) * 4));
     long long *scan_totals = nullptr;
     {
+        hipStream_t gst = c->side_stream;
+        HIP_TRY(c, hipEventRecord(c->ev_ifork, st));                        // (the control block is clear)
+        HIP_TRY(c, hipStreamWaitEvent(gst, c->ev_ifork, 0));
         ReadPrepLoader ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, &ctrl->err_flags, &ctrl->err_index};
         ScanOut<3> so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), c->cutcap_off.as<long long>()}};
-        exclusive_scan<ReadPrepLoader, 3>(st, ld, N, c->scan_tmp.as<long long>(), so, &scan_totals);
+        exclusive_scan<ReadPrepLoader, 3>(gst, ld, N, c->scan_tmp.as<long long>(), so, &scan_totals);
+        HIP_TRY(c, hipEventRecord(c->ev_gjoin, gst));
     }
-    if (spec) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_gjoin, 0));
-    else if (n_rec > 0)
-        hipLaunchKernelGGL(inspect_kernel, dim3(igrid), dim3(256), 0, st, (long long)n_rec, n_reads,
-                           c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
+    if (n_rec > 0) {
+        if (want_table) HIP_TRY(c, hipMemsetAsync(c->run_start.p, 0xFF, (size_t)kMaxSeg * (size_t)(N + 1) * 4, st));
+        if (want_table || spec)
+            hipLaunchKernelGGL(guess_runs_kernel, dim3(kGuessBlocks), dim3(256), 0, st, (long long)n_rec, d_qid, &ctrl->guess);
+        if (!spec) {
+            const RunTable rt{want_table ? c->run_start.as<int32_t>() : nullptr, &ctrl->guess};
+            hipLaunchKernelGGL(inspect_kernel, dim3(igrid), dim3(256), 0, st, (long long)n_rec, n_reads,
+                               c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp, rt);
+        }
+    }
+    HIP_TRY(c, hipStreamWaitEvent(st, c->ev_gjoin, 0));
     hipLaunchKernelGGL(publish_sizes_kernel, dim3(1), dim3(64), 0, st, scan_totals, ctrl, c->pinned_dev);
     HIP_TRY(c, hipStreamSynchronize(st));                                   // the pass's only host wait: sizes + path choice
     const long long B = h[0], RU = h[1], CU = h[2];
@@ -530,6 +537,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     int symmetric = c->prm.symmetric_mode == 1 ? 1 : 0;
     int n_desc = 0;
     long long desc[kMaxSeg];
+    bool table_ok = false;
     if (spec) {
         symmetric = 1;
         c->spec_guess = *hg;
@@ -547,6 +555,13 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
         if (c->prm.symmetric_mode < 0) { symmetric = hi->sym_found ? 1 : 0; c->spec_sym = symmetric; }
         n_desc = hi->n_desc;
         for (int i = 0; i < std::min(n_desc, kMaxSeg); ++i) desc[i] = hi->desc_pos[i];
+        // the table of run starts is good when the sampled run ends are exactly the ones the full pass found
+        table_ok = want_table && n_desc + 1 <= kMaxSeg && hg->n_desc == n_desc;
+        for (int i = 0; table_ok && i < n_desc; ++i) {
+            bool found = false;
+            for (int j = 0; j < n_desc; ++j) found = found || hg->desc_pos[j] == desc[i];
+            table_ok = found;
+        }
     }
     c->sum.symmetric = symmetric;
 
@@ -612,8 +627,22 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
                        pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>(),
                        pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, pv.cap, kFastMaxReads,
-                       pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow);
+                       pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow, n_reads,
+                       (fast && table_ok) ? c->run_start.as<int32_t>() : nullptr,
+                       c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr);
 
+    if (spec) {
+        // The full look at the records starts here, beside the pileup kernels: on the lowest-priority stream and with a
+        // grid of two workgroups per CU, so that the persistent pileup grid still gets every slot it asks for.  (Started
+        // at the top of the pass it filled the device and the geometry scans waited behind it: 207 us instead of 13.)
+        hipStream_t ist = c->insp_stream;
+        HIP_TRY(c, hipEventRecord(c->ev_ifork, st));
+        HIP_TRY(c, hipStreamWaitEvent(ist, c->ev_ifork, 0));
+        hipLaunchKernelGGL(inspect_kernel, dim3(std::min(igrid, 512u)), dim3(256), 0, ist, (long long)n_rec, n_reads,
+                           c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp, RunTable{nullptr, nullptr});
+        HIP_TRY(c, hipMemcpyAsync(hi, &ctrl->insp, sizeof(InspectOut), hipMemcpyDeviceToHost, ist));
+        HIP_TRY(c, hipEventRecord(c->ev_ijoin, ist));
+    }
     pa.dbg = nullptr;
     if (c->variant == kDiagVariant) {
         HIP_TRY(c, c->dbg.ensure((size_t)n_tiles * 16 * 8));
@@ -696,7 +725,8 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
                         const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
                         const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te)
 {
-    return run_pass(c, n_reads, d_len, n_rec, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, true);
+    static const bool speculate = getenv("RAFT_SPECULATE") != nullptr;   // measured: no gain; kept for experiments
+    return run_pass(c, n_reads, d_len, n_rec, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, speculate);
 }
 
 int raft_hip_run_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec,

@@ -758,7 +758,8 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                                                         const int32_t *iv_rid, const int32_t *tile_first,
                                                         const long long *cov_off, TileDesc *td, TileCut *cuts,
                                                         int fast_cap, int fast_max_reads, int32_t *slow_list,
-                                                        int32_t *n_slow)
+                                                        int32_t *n_slow, int32_t n_reads, const int32_t *run_start,
+                                                        const long long *bucket_off)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -787,37 +788,41 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
             if (own_end) { blo[kMaxSeg + s] = sb.start[s]; bhi[kMaxSeg + s] = seg_e; }
         }
     }
-    // Eight-way instead of two-way: every round probes the seven interior cut points of each open range at once, so the
-    // chain of dependent loads is a third as long (10 rounds for 2^30 records instead of 30; 117 us -> measured in
-    // DESIGN.md) for 2.3x the probes.
-    constexpr int KA = 8;
-    for (;;) {
-        int v[2 * kMaxSeg][KA - 1];
-        bool any = false;
+    // Where a table of run starts per read exists, a boundary is a look-up: run_start (inspect_kernel's, sorted-segment
+    // path; -1 = the read has no record in that run: walk up to the next read that has) or the counting sort's own
+    // offsets.  What is left open after that -- no table, or a gap of more than 16 reads -- is bisected below.
+    if (bucket_off || run_start) {
 #pragma unroll
         for (int q = 0; q < 2 * kMaxSeg; ++q) {
             if (blo[q] < bhi[q]) {
-                any = true;
-                const long long len = bhi[q] - blo[q];
-#pragma unroll
-                for (int j = 1; j < KA; ++j) v[q][j - 1] = iv_rid[blo[q] + ((len * j) >> 3)];
+                const int key = q < kMaxSeg ? d.r_lo : d.r_hi;
+                if (bucket_off) blo[q] = bhi[q] = bucket_off[key];
+                else {
+                    const int32_t *row = run_start + (long long)(q % kMaxSeg) * ((long long)n_reads + 1);
+                    for (int step = 0; step < 16; ++step) {
+                        const int r = min(key + step, n_reads);
+                        const int v = row[r];
+                        if (v >= 0) { blo[q] = bhi[q] = v; break; }
+                        if (r == n_reads) break;
+                    }
+                }
             }
+        }
+    }
+    for (;;) {
+        int v[2 * kMaxSeg];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 2 * kMaxSeg; ++q) {
+            v[q] = 0;
+            if (blo[q] < bhi[q]) { v[q] = iv_rid[(blo[q] + bhi[q]) >> 1]; any = true; }
         }
         if (!any) break;
 #pragma unroll
         for (int q = 0; q < 2 * kMaxSeg; ++q) {
             if (blo[q] < bhi[q]) {
-                const int key = q < kMaxSeg ? d.r_lo : d.r_hi;
-                const long long lo0 = blo[q], len = bhi[q] - lo0;
-                bool open = true;                    // no probe at or above the key seen yet
-#pragma unroll
-                for (int j = 1; j < KA; ++j) {
-                    const long long pos = lo0 + ((len * j) >> 3);
-                    if (open) {
-                        if (v[q][j - 1] < key) blo[q] = pos + 1;
-                        else { bhi[q] = pos; open = false; }
-                    }
-                }
+                const long long mid = (blo[q] + bhi[q]) >> 1;
+                if (v[q] < (q < kMaxSeg ? d.r_lo : d.r_hi)) blo[q] = mid + 1; else bhi[q] = mid;
             }
         }
     }

@@ -13,6 +13,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last pass: from the last ReadPrepLoader partials kernel on
 idx = [i for i, r in enumerate(rows) if "scan_partials_kernel" in r["Kernel_Name"] and "ReadPrep" in r["Kernel_Name"]]
 start = idx[-1]
+g = [i for i, r in enumerate(rows) if "guess_runs_kernel" in r["Kernel_Name"]]
+if g and g[-1] < start and start - g[-1] < 4: start = g[-1]     # (speculative pass: the guess starts beside the scans)
 t0 = int(rows[start]["Start_Timestamp"])
 out = open("gpurun_out/$TAG/timeline.txt", "w")
 for r in rows[start:]:
