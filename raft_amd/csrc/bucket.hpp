@@ -34,38 +34,20 @@ struct InspectOut {            // device words written by inspect_kernel
 
 // One pass over qid (and over the other columns only where qid matches tid[0]): 16-byte loads, four records
 // per lane, so that the pass streams at HBM rate (it reads 4 B per record of the 12-24 B the pileup reads).
-//
-// The same pass writes, for every sorted run g and every read q that has a record in it, the position of that run's
-// first record of q (start[g * (n_reads + 1) + q]; entry n_reads closes the run; the table is preset to -1, so reads
-// without a record in the run stay unset and a look-up walks up to the next set entry).  With that table a tile's
-// interval range is a look-up instead of a binary search per tile boundary and run into a GB-sized column
-// (tile_desc_kernel: 117 us of dependent probes at human scale).  Which run a position belongs to comes from the sampled
-// guess (guess_runs_kernel, finished before this kernel starts); the host uses the table only when this pass -- which
-// sees every record -- found exactly the run ends the guess named.
-struct RunTable {
-    int32_t *start;            // [kMaxSeg][n_reads + 1], or nullptr: no table wanted
-    const struct GuessOut *guess;
-};
-
-struct GuessOut {
-    int32_t n_desc, pad;
-    long long desc_pos[kMaxSeg];
-};
-
+// (Measured and dropped: writing a table "first record of every read in every run" from this pass, to turn the tile
+// cuts into look-ups -- the extra stores and index arithmetic took the pass from 220 to 310-440 us, more than the
+// searches in tile_desc_kernel cost.)
 __device__ __forceinline__ void inspect_one(long long i, int32_t q, int32_t prev, int32_t n_reads, int detect_sym,
                                             const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts,
                                             const int32_t *te, int32_t q0, int32_t t0, int32_t qs0, int32_t qe0,
-                                            int32_t ts0, int32_t te0, InspectOut *out, const RunTable &rt, long long n_rec,
-                                            int g_n, long long g0, long long g1, long long g2)
+                                            int32_t ts0, int32_t te0, InspectOut *out)
 {
-    const bool q_ok = q >= 0 && q < n_reads;
-    if (!q_ok) {
+    if (q < 0 || q >= n_reads) {
         atomicOr(&out->err_flags, kErrReadId);
         atomicMin((unsigned long long *)&out->err_index, (unsigned long long)i);
     }
-    const bool descent = i > 0 && q < prev;
     if (i > 0) {
-        if (descent) {
+        if (q < prev) {
             const int slot = atomicAdd(&out->n_desc, 1);
             if (slot < kMaxSeg) out->desc_pos[slot] = i;
         }
@@ -73,33 +55,14 @@ __device__ __forceinline__ void inspect_one(long long i, int32_t q, int32_t prev
             if (tid[i] == q0 && ts[i] == qs0 && te[i] == qe0 && qs[i] == ts0 && qe[i] == te0) out->sym_found = 1;
         }
     }
-    if (rt.start && q_ok && g_n + 1 <= kMaxSeg && (i == 0 || q != prev || i == n_rec - 1)) {
-        // run of position i: the guessed run ends at or before it (a wrong guess makes a wrong table, which nobody uses)
-        const int g = (g_n > 0 && g0 <= i) + (g_n > 1 && g1 <= i) + (g_n > 2 && g2 <= i);
-        int32_t *row = rt.start + (long long)g * ((long long)n_reads + 1);
-        if (i == 0 || q != prev) row[q] = (int32_t)i;                      // the first record of read q in this run
-        if (descent && g > 0) row[-1] = (int32_t)i;                        // ... and the run before ends here (its entry n_reads)
-        if (i == n_rec - 1) row[n_reads] = (int32_t)n_rec;                 // the last record closes the last run
-    }
 }
 
 __global__ __launch_bounds__(256) void inspect_kernel(long long n_rec, int32_t n_reads, int detect_sym,
                                                       const int32_t *qid, const int32_t *qs, const int32_t *qe,
                                                       const int32_t *tid, const int32_t *ts, const int32_t *te,
-                                                      InspectOut *out, RunTable rt)
+                                                      InspectOut *out)
 {
     const int32_t q0 = qid[0], t0 = tid[0], qs0 = qs[0], qe0 = qe[0], ts0 = ts[0], te0 = te[0];
-    int g_n = 0;
-    long long g0 = 0, g1 = 0, g2 = 0;
-    if (rt.start) {                                  // the guessed run ends, ascending (at most three are of use)
-        g_n = rt.guess->n_desc;
-        if (g_n + 1 <= kMaxSeg) {
-            long long a = g_n > 0 ? rt.guess->desc_pos[0] : 0, b = g_n > 1 ? rt.guess->desc_pos[1] : 0, c = g_n > 2 ? rt.guess->desc_pos[2] : 0;
-            if (g_n > 1 && b < a) { const long long x = a; a = b; b = x; }
-            if (g_n > 2) { if (c < a) { const long long x = c; c = b; b = a; a = x; } else if (c < b) { const long long x = c; c = b; b = x; } }
-            g0 = a; g1 = b; g2 = c;
-        }
-    }
     // records [0, head) bring qid to a 16-byte boundary, then groups of four, then a tail
     long long head = (long long)(((16u - (unsigned)(reinterpret_cast<unsigned long long>(qid) & 15u)) & 15u) >> 2);
     if (head > n_rec) head = n_rec;
@@ -107,42 +70,45 @@ __global__ __launch_bounds__(256) void inspect_kernel(long long n_rec, int32_t n
     const long long tail = head + (n_groups << 2);
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long t0i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-#define RAFT_INSPECT(i_, q_, p_) inspect_one(i_, q_, p_, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out, rt, n_rec, g_n, g0, g1, g2)
     for (long long g = t0i; g < n_groups; g += stride) {
         const long long i = head + (g << 2);
         const int4 v = *reinterpret_cast<const int4 *>(qid + i);
         const int32_t prev = i > 0 ? qid[i - 1] : 0;
-        RAFT_INSPECT(i + 0, v.x, prev);
-        RAFT_INSPECT(i + 1, v.y, v.x);
-        RAFT_INSPECT(i + 2, v.z, v.y);
-        RAFT_INSPECT(i + 3, v.w, v.z);
+        inspect_one(i + 0, v.x, prev, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out);
+        inspect_one(i + 1, v.y, v.x, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out);
+        inspect_one(i + 2, v.z, v.y, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out);
+        inspect_one(i + 3, v.w, v.z, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out);
     }
     if (blockIdx.x == 0) {
         for (long long i = threadIdx.x; i < head + (n_rec - tail); i += blockDim.x) {
             const long long j = i < head ? i : tail + (i - head);
-            RAFT_INSPECT(j, qid[j], j > 0 ? qid[j - 1] : 0);
+            inspect_one(j, qid[j], j > 0 ? qid[j - 1] : 0, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out);
         }
     }
-#undef RAFT_INSPECT
 }
 
-// Sorted runs of the record stream as 8 k evenly spaced samples show them: where one sample is smaller than the one
+// Sorted runs of the record stream as 16 k evenly spaced samples show them: where one sample is smaller than the one
 // before, a run ends in between, and a bisection (left part >= the earlier sample, right part below it) finds the first
-// record of the next run.  One workgroup, ~30 dependent loads deep.  This is what a speculative pass starts from
-// (engine.hip run_pass); inspect_kernel, which looks at every record, confirms or refutes it while the pass runs.
-// (16 k samples: ~14 bisection steps per run end; GuessOut is declared above)
+// record of the next run.  inspect_kernel, which looks at every record, confirms or refutes it.
+// The samples themselves are kept (64 KB): they are a coarse index of the stream.  tile_desc_kernel bisects them first
+// -- cache hits -- and then only the 9 k records between two samples, instead of 28 dependent probes spread over a
+// GB-sized column (every one of them a TLB miss).
+struct GuessOut {
+    int32_t n_desc, pad;
+    long long desc_pos[kMaxSeg];
+};
 
-constexpr int kGuessBlocks = 64;                           // x 256 threads: one pair of adjacent samples per thread
 
-__global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const int32_t *qid, GuessOut *out)
+__global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const int32_t *qid, GuessOut *out, int32_t *samples)
 {
-    const long long T = (long long)kGuessBlocks * 256;
-    const long long S = n_rec < T + 1 ? n_rec : T + 1;    // samples (out->n_desc was zeroed with the control block)
+    const long long S = n_rec < kSamples + 1 ? n_rec : kSamples + 1;     // (out->n_desc was zeroed with the control block)
     const long long i = 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 1 && samples) samples[0] = qid[0];
     if (i >= S) return;
-    const long long p0 = (i - 1) * (n_rec - 1) / (S - 1), p1 = i * (n_rec - 1) / (S - 1);
-    const int32_t v = qid[p0];
-    if (qid[p1] < v) {
+    const long long p0 = sample_pos(i - 1, n_rec, S), p1 = sample_pos(i, n_rec, S);
+    const int32_t v = qid[p0], w = qid[p1];
+    if (samples) samples[i] = w;
+    if (w < v) {
         long long lo = p0, hi = p1;
         while (hi - lo > 1) {
             const long long mid = lo + (hi - lo) / 2;

@@ -188,7 +188,7 @@ struct raft_hip_ctx {
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
-    DevBuf run_start;                 // [kMaxSeg][n_reads + 1] first record of each read in each sorted run (inspect_kernel)
+    DevBuf samples;                   // kSamples + 1 read ids at evenly spaced records (guess_runs_kernel): coarse index
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
     DevBuf dbg;                       // diagnostic variant only
     DevBuf cov8, exc_idx, exc_val, exc_cnt;   // transfer encoding of cov[] (raft_hip_fetch_packed)
@@ -342,7 +342,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->dbg, &c->run_start, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->samples, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -453,8 +453,8 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     HIP_TRY(c, c->cov_off.ensure((size_t)(N + 1) * 8));
     HIP_TRY(c, c->rep_res_off.ensure((size_t)(N + 1) * 8));
     HIP_TRY(c, c->cutcap_off.ensure((size_t)(N + 1) * 8));
-    const bool want_table = n_rec > 0 && !spec && c->prm.symmetric_mode != 0 && !c->force_bucket;
-    if (want_table) HIP_TRY(c, c->run_start.ensure((size_t)kMaxSeg * (size_t)(N + 1) * 4));
+    const bool want_guess = n_rec > 1 && c->prm.symmetric_mode != 0 && !c->force_bucket;   // (the sorted-segment path is possible)
+    if (want_guess) HIP_TRY(c, c->samples.ensure((size_t)(kSamples + 1) * 4));
     long long *scan_totals = nullptr;
     {
         hipStream_t gst = c->side_stream;
@@ -466,14 +466,12 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
         HIP_TRY(c, hipEventRecord(c->ev_gjoin, gst));
     }
     if (n_rec > 0) {
-        if (want_table) HIP_TRY(c, hipMemsetAsync(c->run_start.p, 0xFF, (size_t)kMaxSeg * (size_t)(N + 1) * 4, st));
-        if (want_table || spec)
-            hipLaunchKernelGGL(guess_runs_kernel, dim3(kGuessBlocks), dim3(256), 0, st, (long long)n_rec, d_qid, &ctrl->guess);
-        if (!spec) {
-            const RunTable rt{want_table ? c->run_start.as<int32_t>() : nullptr, &ctrl->guess};
+        if (want_guess)
+            hipLaunchKernelGGL(guess_runs_kernel, dim3(kGuessBlocks), dim3(256), 0, st, (long long)n_rec, d_qid, &ctrl->guess,
+                               c->samples.as<int32_t>());
+        if (!spec)
             hipLaunchKernelGGL(inspect_kernel, dim3(igrid), dim3(256), 0, st, (long long)n_rec, n_reads,
-                               c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp, rt);
-        }
+                               c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
     }
     HIP_TRY(c, hipStreamWaitEvent(st, c->ev_gjoin, 0));
     hipLaunchKernelGGL(publish_sizes_kernel, dim3(1), dim3(64), 0, st, scan_totals, ctrl, c->pinned_dev);
@@ -555,8 +553,8 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
         if (c->prm.symmetric_mode < 0) { symmetric = hi->sym_found ? 1 : 0; c->spec_sym = symmetric; }
         n_desc = hi->n_desc;
         for (int i = 0; i < std::min(n_desc, kMaxSeg); ++i) desc[i] = hi->desc_pos[i];
-        // the table of run starts is good when the sampled run ends are exactly the ones the full pass found
-        table_ok = want_table && n_desc + 1 <= kMaxSeg && hg->n_desc == n_desc;
+        // the samples index the stream when the sampled run ends are exactly the ones the full pass found
+        table_ok = want_guess && n_desc + 1 <= kMaxSeg && hg->n_desc == n_desc;
         for (int i = 0; table_ok && i < n_desc; ++i) {
             bool found = false;
             for (int j = 0; j < n_desc; ++j) found = found || hg->desc_pos[j] == desc[i];
@@ -627,8 +625,8 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
                        pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>(),
                        pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, pv.cap, kFastMaxReads,
-                       pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow, n_reads,
-                       (fast && table_ok) ? c->run_start.as<int32_t>() : nullptr,
+                       pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow,
+                       (fast && (table_ok || spec)) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
                        c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr);
 
     if (spec) {
@@ -639,7 +637,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
         HIP_TRY(c, hipEventRecord(c->ev_ifork, st));
         HIP_TRY(c, hipStreamWaitEvent(ist, c->ev_ifork, 0));
         hipLaunchKernelGGL(inspect_kernel, dim3(std::min(igrid, 512u)), dim3(256), 0, ist, (long long)n_rec, n_reads,
-                           c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp, RunTable{nullptr, nullptr});
+                           c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
         HIP_TRY(c, hipMemcpyAsync(hi, &ctrl->insp, sizeof(InspectOut), hipMemcpyDeviceToHost, ist));
         HIP_TRY(c, hipEventRecord(c->ev_ijoin, ist));
     }

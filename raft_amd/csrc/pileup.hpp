@@ -97,6 +97,12 @@ struct PileupArgs {
     int32_t *slow_counter;        // list mode of this kernel: the items of slow_list are handed out one by one
 };
 
+// coarse index of the record stream (bucket.hpp guess_runs_kernel writes it, tile_desc_kernel reads it)
+constexpr int kGuessBlocks = 64;                           // x 256 threads: one sample per thread
+constexpr int kSamples = kGuessBlocks * 256;               // samples 0 .. kSamples (the last one is the last record)
+// position of sample j of a stream of n records (j = 0 .. S - 1, S = min(n, kSamples + 1))
+__host__ __device__ __forceinline__ long long sample_pos(long long j, long long n, long long S) { return S > 1 ? j * (n - 1) / (S - 1) : 0; }
+
 constexpr int kRunQ = 16; // parked runs per wave and window before falling back to immediate emission
 constexpr int kOpen = -2; // run began before this wave's first window
 constexpr int kNone = -1;
@@ -758,7 +764,7 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                                                         const int32_t *iv_rid, const int32_t *tile_first,
                                                         const long long *cov_off, TileDesc *td, TileCut *cuts,
                                                         int fast_cap, int fast_max_reads, int32_t *slow_list,
-                                                        int32_t *n_slow, int32_t n_reads, const int32_t *run_start,
+                                                        int32_t *n_slow, const int32_t *samples, long long n_rec,
                                                         const long long *bucket_off)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -788,23 +794,33 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
             if (own_end) { blo[kMaxSeg + s] = sb.start[s]; bhi[kMaxSeg + s] = seg_e; }
         }
     }
-    // Where a table of run starts per read exists, a boundary is a look-up: run_start (inspect_kernel's, sorted-segment
-    // path; -1 = the read has no record in that run: walk up to the next read that has) or the counting sort's own
-    // offsets.  What is left open after that -- no table, or a gap of more than 16 reads -- is bisected below.
-    if (bucket_off || run_start) {
+    // Before bisecting the record stream itself: the counting sort's own offsets answer directly; on the sorted-segment
+    // path the 16 k samples guess_runs_kernel kept (a coarse index, cache-resident) are bisected first, which leaves the
+    // ~9 k records between two samples -- 13 probes into one or two pages instead of 28 all over a GB-sized column.
+    if (bucket_off) {
+#pragma unroll
+        for (int q = 0; q < 2 * kMaxSeg; ++q)
+            if (blo[q] < bhi[q]) blo[q] = bhi[q] = bucket_off[q < kMaxSeg ? d.r_lo : d.r_hi];
+    } else if (samples) {
+        const long long S = n_rec < kSamples + 1 ? n_rec : kSamples + 1;
 #pragma unroll
         for (int q = 0; q < 2 * kMaxSeg; ++q) {
             if (blo[q] < bhi[q]) {
                 const int key = q < kMaxSeg ? d.r_lo : d.r_hi;
-                if (bucket_off) blo[q] = bhi[q] = bucket_off[key];
-                else {
-                    const int32_t *row = run_start + (long long)(q % kMaxSeg) * ((long long)n_reads + 1);
-                    for (int step = 0; step < 16; ++step) {
-                        const int r = min(key + step, n_reads);
-                        const int v = row[r];
-                        if (v >= 0) { blo[q] = bhi[q] = v; break; }
-                        if (r == n_reads) break;
+                // samples inside this run: jl = first with position >= run start, jh = last with position < run end
+                long long jl = (blo[q] * (S - 1) + (n_rec - 2)) / (n_rec - 1), jh = ((bhi[q] - 1) * (S - 1)) / (n_rec - 1);
+                while (jl < S && sample_pos(jl, n_rec, S) < blo[q]) ++jl;
+                while (jl > 0 && sample_pos(jl - 1, n_rec, S) >= blo[q]) --jl;
+                while (jh + 1 < S && sample_pos(jh + 1, n_rec, S) < bhi[q]) ++jh;
+                while (jh >= 0 && sample_pos(jh, n_rec, S) >= bhi[q]) --jh;
+                if (jl <= jh) {
+                    long long x = jl, y = jh + 1;          // first sample in [jl, jh] with an id >= key, or jh + 1
+                    while (x < y) {
+                        const long long m = (x + y) >> 1;
+                        if (samples[m] < key) x = m + 1; else y = m;
                     }
+                    if (x > jl) blo[q] = sample_pos(x - 1, n_rec, S) + 1;
+                    if (x <= jh) bhi[q] = sample_pos(x, n_rec, S);
                 }
             }
         }
