@@ -164,7 +164,11 @@ __global__ __launch_bounds__(256) void bucket_hist_kernel(long long n_rec, int32
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         const bool valid = i < n_rec;
         int q = valid ? qid[i] : -1;
-        bool okq = valid && q >= 0 && q < n_reads;   // out-of-range ids were already flagged by inspect_kernel
+        bool okq = valid && q >= 0 && q < n_reads;
+        if (valid && !okq) {                         // (inspect_kernel reports the same when it runs; a verified pass has no inspect)
+            atomicOr(err_flags, kErrReadId);
+            atomicMin((unsigned long long *)err_index, (unsigned long long)i);
+        }
         int len; bool head;
         run_head(okq, q, lane, &len, &head);
         // the fold assumes valid lanes form a prefix; a bad id in the middle breaks that, so fall back per lane

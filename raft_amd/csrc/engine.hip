@@ -85,7 +85,7 @@ struct Ctrl {                         // device control block, cleared every pas
     unsigned long long totals[4];     // coverage, repeat bp, read length
     InspectOut insp;
     long long out_totals[4];          // rep / cut / frag totals land here via the scan
-    GuessOut guess;                   // sorted runs as seen from samples (speculative pass)
+    GuessOut guess;                   // sorted runs as seen from samples
 };
 
 struct DevBuf {
@@ -174,8 +174,7 @@ struct raft_hip_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t side_stream = nullptr;   // the general pileup kernel runs beside the fast one
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t insp_stream = nullptr;   // speculative pass: the full look at the record stream runs beside the pass
-    hipEvent_t ev_ifork = nullptr, ev_ijoin = nullptr;
+    hipEvent_t ev_ifork = nullptr;
     raft_hip_params prm{};
     int32_t high_cov = 0, div = 0, minbins = 1;
     int32_t tile_q = 0;               // 0 = variant default
@@ -205,10 +204,8 @@ struct raft_hip_ctx {
     hipStream_t up_stream = nullptr, down_stream = nullptr;
     std::vector<hipEvent_t> lane_up_ev, lane_down_ev;
 
-    // speculation (see run_pass): what the pass assumed, and the arguments to run it again if the assumption fails
+    // a pass that verifies in its kernels (see run_pass), and the arguments to run it again if a kernel objects
     bool spec = false;
-    int spec_sym = 1;                  // what a detecting context (symmetric_mode = -1) assumes: the last pass's answer
-    GuessOut spec_guess{};
     struct PassArgs { int32_t n_reads; const int32_t *len; int64_t n_rec; const int32_t *col[6]; } args{};
 
     // state of the last pass
@@ -261,7 +258,7 @@ int code_from_flags(int flags)
     if (flags & kErrReadId) return RAFT_HIP_ERR_READ_ID;
     if (flags & kErrCoord) return RAFT_HIP_ERR_COORD;
     if (flags & kErrFragment) return RAFT_HIP_ERR_FRAGMENT;
-    if (flags & kErrInternal) return RAFT_HIP_ERR_DEVICE;
+    if (flags & (kErrInternal | kErrOrder)) return RAFT_HIP_ERR_DEVICE;   // (kErrOrder never outlives raft_hip_finish's second run)
     return RAFT_HIP_OK;
 }
 
@@ -303,14 +300,10 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     raft_hip_ctx *c = new (std::nothrow) raft_hip_ctx();
     if (!c) return RAFT_HIP_ERR_NOMEM;
     c->device = device_id;
-    int prio_lo = 0, prio_hi = 0;
     apply_params(c, params);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->insp_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||   // lowest priority
         hipEventCreateWithFlags(&c->ev_ifork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_ijoin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
@@ -353,8 +346,6 @@ void raft_hip_destroy(raft_hip_ctx *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_ifork) (void)hipEventDestroy(c->ev_ifork);
     if (c->ev_gjoin) (void)hipEventDestroy(c->ev_gjoin);
-    if (c->ev_ijoin) (void)hipEventDestroy(c->ev_ijoin);
-    if (c->insp_stream) (void)hipStreamDestroy(c->insp_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -397,16 +388,20 @@ int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket
     return RAFT_HIP_OK;
 }
 
-// One pass.  `speculate`: do not wait for the full look at the record stream (inspect_kernel: ids in range, sorted runs,
-// mirror of record 0 -- one read of the qid column, 0.22 ms at human scale, all of it ahead of the pass's host wait).
-// Instead a one-workgroup kernel guesses the sorted runs from 8 k samples, a detecting context assumes the answer of
-// its previous pass (symmetric at first: hifiasm's shape), the pass starts on that, and inspect_kernel runs BESIDE it
-// on a stream of its own -- the pileup kernel is bound by instruction issue and leaves the memory system room for it.
-// raft_hip_finish() compares: if the records hold anything the guess did not say (another descent, an id out of
-// range, no mirror after all), the pass is run again without speculation, from the same arguments.
+// One pass.  `verify_in_kernels` (the default when the caller asserts symmetric_mode = 1): no full look at the record
+// stream at all (inspect_kernel: ids in range, sorted runs -- one read of the qid column, 0.22-0.24 ms at human scale,
+// all of it ahead of the pass's host wait).  A one-workgroup-per-CU kernel samples the stream and names the sorted runs;
+// the pass is built on that, and what makes it safe is that tile_desc_kernel and the pileup kernels enforce what they
+// rely on: tile ranges tile every run exactly, and every record is checked against the reads of the tile (sub-batch,
+// chunk) that processes it.  A record that refutes the guess -- an id out of range, a dip in the order between two
+// samples -- raises kErrOrder, and raft_hip_finish() then runs the pass again from the same arguments, this time after
+// inspect_kernel has looked at every record (which also reports errors exactly as before).  A detecting context
+// (symmetric_mode = -1) has to look at every record anyway (mirror of record 0) and always takes that second form.
+// (Measured and dropped: starting on the guess and running inspect_kernel BESIDE the pileup kernels on a low-priority
+// stream -- it costs the pileup what it would cost alone, 0.15-0.2 ms; the pass did not get shorter.)
 static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int64_t n_rec,
                     const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
-                    const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te, bool speculate)
+                    const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te, bool verify_in_kernels)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
     if (n_reads < 0 || n_rec < 0) return RAFT_HIP_ERR_PARAM;
@@ -423,9 +418,8 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     hipStream_t st = c->stream;
     c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1; c->packed_ready = false;
     c->args = {n_reads, d_len, n_rec, {d_qid, d_qs, d_qe, d_tid, d_ts, d_te}};
-    static const bool no_spec_env = getenv("RAFT_NO_SPECULATION") != nullptr;
-    const bool spec = speculate && !no_spec_env && n_rec > 0 && c->prm.symmetric_mode != 0 && !c->force_bucket &&
-                      (c->prm.symmetric_mode == 1 || c->spec_sym == 1);
+    static const bool no_verify_env = getenv("RAFT_ALWAYS_INSPECT") != nullptr;   // (A/B measurements)
+    const bool spec = verify_in_kernels && !no_verify_env && n_rec > 1 && c->prm.symmetric_mode == 1 && !c->force_bucket;
     c->spec = spec;
     memset(&c->sum, 0, sizeof c->sum);
     c->sum.n_reads = n_reads; c->sum.n_records = n_rec; c->sum.high_cov = c->high_cov; c->sum.error_index = -1;
@@ -439,11 +433,9 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     HIP_TRY(c, hipMemsetAsync(&ctrl->insp.err_index, 0xFF, sizeof(long long), st));
 
     // ---- two things have to be known before the host can size and launch the rest, and they run side by side:
-    //  (main stream) what the record stream looks like -- sorted runs sampled by guess_runs_kernel, then every record by
-    //      inspect_kernel: ids in range? the runs exactly as sampled? mirror of record 0?  On the way it writes the table
-    //      of run starts per read that turns the tile cuts into look-ups;
+    //  (main stream) what the record stream looks like -- sorted runs sampled by guess_runs_kernel and, unless the pass
+    //      verifies in its kernels, every record by inspect_kernel: ids in range? the runs as sampled? mirror of record 0?
     //  (side stream) the per-read geometry: windows, reserved repeat slots, marker capacity (one scan, three sums).
-    //  A speculating pass (RAFT_SPECULATE=1) only waits for the samples and lets inspect_kernel run beside the pileup.
     long long *h = reinterpret_cast<long long *>(c->pinned);
     InspectOut *hi = reinterpret_cast<InspectOut *>(h + 8);
     GuessOut *hg = reinterpret_cast<GuessOut *>(h + 32);
@@ -538,9 +530,9 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     bool table_ok = false;
     if (spec) {
         symmetric = 1;
-        c->spec_guess = *hg;
         n_desc = hg->n_desc;
         for (int i = 0; i < std::min(n_desc, kMaxSeg); ++i) desc[i] = hg->desc_pos[i];
+        table_ok = n_desc + 1 <= kMaxSeg;            // (the samples index the stream the pass is built on)
     } else if (n_rec > 0) {
         if (hi->err_flags) {
             c->pending_err = code_from_flags(hi->err_flags);
@@ -550,7 +542,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
             HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
             return RAFT_HIP_OK;
         }
-        if (c->prm.symmetric_mode < 0) { symmetric = hi->sym_found ? 1 : 0; c->spec_sym = symmetric; }
+        if (c->prm.symmetric_mode < 0) symmetric = hi->sym_found ? 1 : 0;
         n_desc = hi->n_desc;
         for (int i = 0; i < std::min(n_desc, kMaxSeg); ++i) desc[i] = hi->desc_pos[i];
         // the samples index the stream when the sampled run ends are exactly the ones the full pass found
@@ -626,21 +618,9 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
                        pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>(),
                        pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, pv.cap, kFastMaxReads,
                        pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow,
-                       (fast && (table_ok || spec)) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
-                       c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr);
+                       (fast && table_ok) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
+                       c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags);
 
-    if (spec) {
-        // The full look at the records starts here, beside the pileup kernels: on the lowest-priority stream and with a
-        // grid of two workgroups per CU, so that the persistent pileup grid still gets every slot it asks for.  (Started
-        // at the top of the pass it filled the device and the geometry scans waited behind it: 207 us instead of 13.)
-        hipStream_t ist = c->insp_stream;
-        HIP_TRY(c, hipEventRecord(c->ev_ifork, st));
-        HIP_TRY(c, hipStreamWaitEvent(ist, c->ev_ifork, 0));
-        hipLaunchKernelGGL(inspect_kernel, dim3(std::min(igrid, 512u)), dim3(256), 0, ist, (long long)n_rec, n_reads,
-                           c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
-        HIP_TRY(c, hipMemcpyAsync(hi, &ctrl->insp, sizeof(InspectOut), hipMemcpyDeviceToHost, ist));
-        HIP_TRY(c, hipEventRecord(c->ev_ijoin, ist));
-    }
     pa.dbg = nullptr;
     if (c->variant == kDiagVariant) {
         HIP_TRY(c, c->dbg.ensure((size_t)n_tiles * 16 * 8));
@@ -709,7 +689,6 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
                            c->frag_off.as<long long>(), c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr,
                            ctrl->out_totals);
     }
-    if (spec) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_ijoin, 0));           // the pass is over when its verification is
     // everything finish() reports travels in one block, copied while the stream drains
     hipLaunchKernelGGL(publish_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl, c->pinned_dev + 128);   // (+1024 bytes)
     c->fa = fa; c->cuts_ready = false;
@@ -723,8 +702,7 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
                         const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
                         const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te)
 {
-    static const bool speculate = getenv("RAFT_SPECULATE") != nullptr;   // measured: no gain; kept for experiments
-    return run_pass(c, n_reads, d_len, n_rec, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, speculate);
+    return run_pass(c, n_reads, d_len, n_rec, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, true);
 }
 
 int raft_hip_run_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
@@ -761,22 +739,11 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
     if (!c->finished) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->spec && c->pending_err == RAFT_HIP_OK) {
-            // what the full look at the records found, against what the pass assumed
-            HIP_TRY(c, hipStreamSynchronize(c->insp_stream));
-            const InspectOut *hi = reinterpret_cast<const InspectOut *>(reinterpret_cast<long long *>(c->pinned) + 8);
-            bool ok = hi->err_flags == 0;
-            if (c->prm.symmetric_mode < 0) { ok = ok && hi->sym_found == 1; c->spec_sym = hi->sym_found ? 1 : 0; }
-            const GuessOut &g = c->spec_guess;
-            if (g.n_desc + 1 <= kMaxSeg || hi->n_desc + 1 <= kMaxSeg) {   // (otherwise both mean the counting-sort path)
-                ok = ok && hi->n_desc == g.n_desc;
-                for (int i = 0; ok && i < g.n_desc; ++i) {
-                    bool found = false;
-                    for (int j = 0; j < hi->n_desc; ++j) found = found || hi->desc_pos[j] == g.desc_pos[i];
-                    ok = found;
-                }
-            }
+            // did a kernel meet a record that refutes the sampled guess the pass was built on?
+            Ctrl hc;
+            memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));
             c->spec = false;
-            if (!ok) {                               // run it again, this time waiting for the facts
+            if (hc.err_flags & (kErrOrder | kErrReadId)) {   // run it again, this time after looking at every record
                 const auto a = c->args;
                 const int rc = run_pass(c, a.n_reads, a.len, a.n_rec, a.col[0], a.col[1], a.col[2], a.col[3], a.col[4], a.col[5], false);
                 if (rc != RAFT_HIP_OK) return rc;

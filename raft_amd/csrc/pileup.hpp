@@ -42,7 +42,9 @@ enum : int {
     kErrCoord = 1 << 1,
     kErrFragment = 1 << 2,
     kErrInternal = 1 << 3,
-    kErrLen = 1 << 4
+    kErrLen = 1 << 4,
+    kErrOrder = 1 << 5          // a pass that trusted a sampled guess of the sorted runs met a record that refutes it (not an
+                               // error of the input: the engine runs the pass again after looking at every record)
 };
 
 struct SegStarts { long long start[kMaxSeg + 1]; int32_t n_seg; };
@@ -339,6 +341,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     //    per record (the two LDS adds); malformed records only set a lane flag that is looked at once per window.
     int covsum = 0;
     int bad_v = -1;                              // a record of this lane with a coordinate error (virtual index)
+    bool bad_order = false;                      // a record whose read is not one of this window's (see kErrOrder)
     for (int v0 = tid; v0 < n_iv; v0 += THREADS * U) {
         if (v0 != tid) load_intervals<THREADS, U>(a, v0, seg_lo, seg_cum, g);
 #pragma unroll
@@ -347,6 +350,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
             // (a record of a read outside this window can only come from a mis-speculated pass -- engine.hip run_pass --
             // whose results are thrown away; it must not index the tables)
             const bool valid = (unsigned)(g.rid[u] - r_a) < (unsigned)nr;
+            if (!valid && v0 + u * THREADS < n_iv) bad_order = true;     // a real record (not an empty slot) of a foreign read
             const int j = valid ? g.rid[u] - r_a : 0;
             const int b0 = sm.roff[j], nb_r = sm.roff[j + 1] - b0;
             const int first = (int)win_of(a, (unsigned)st);
@@ -367,6 +371,7 @@ __device__ void pile_window(const PileupArgs &a, PileupSmem<THREADS, CAP> &sm, i
     if (__ballot(bad_v >= 0) != 0ull) {          // rare
         if (bad_v >= 0) raise_error(a, kErrCoord, seg_lo[0] + (long long)iv_rel_of(seg_lo, seg_cum, bad_v));
     }
+    if (__ballot(bad_order) != 0ull && lane == 0) atomicOr(a.err_flags, kErrOrder);
     {
         const long long cs = wave_reduce_add64((long long)covsum);
         if (lane == 0 && cs) atomicAdd(&sm.acc_cov, (unsigned long long)cs);
@@ -719,9 +724,13 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
                 for (int s = 0; s < kMaxSeg; ++s) {
                     long long lo = cur.seg_lo[s], hi = cur.seg_lo[s] + (cur.seg_cum[s + 1] - cur.seg_cum[s]);
                     if (s < a.n_seg && !(r_a == cur.r_lo && r_b == cur.r_hi)) {
-                        const long long l2 = lower_bound_rid_uni(a.iv_rid, lo, hi, r_a);
-                        hi = lower_bound_rid_uni(a.iv_rid, lo, hi, r_b);
-                        lo = l2;
+                        // The sub-ranges tile the tile's range: the first begins where the tile's does, the last ends where
+                        // it ends, neighbours meet at the same search result.  Every record is therefore looked at by
+                        // exactly one sub-batch, which flags it if it belongs to a read outside (kErrOrder).
+                        const long long l2 = (r_a == cur.r_lo) ? lo : lower_bound_rid_uni(a.iv_rid, lo, hi, r_a);
+                        long long h2 = (r_b == cur.r_hi) ? hi : lower_bound_rid_uni(a.iv_rid, lo, hi, r_b);
+                        if (h2 < l2) { if (tid == 0) atomicOr(a.err_flags, kErrOrder); h2 = l2; }
+                        hi = h2; lo = l2;
                     }
                     s_lo[s] = lo;
                     s_cum[s + 1] = s_cum[s] + (int)(hi - lo);
@@ -765,7 +774,7 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                                                         const long long *cov_off, TileDesc *td, TileCut *cuts,
                                                         int fast_cap, int fast_max_reads, int32_t *slow_list,
                                                         int32_t *n_slow, const int32_t *samples, long long n_rec,
-                                                        const long long *bucket_off)
+                                                        const long long *bucket_off, int32_t *err_flags)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -842,14 +851,27 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
             }
         }
     }
+    // The cuts of a run tile it: the first tile begins where the run begins, the closing boundary is its end, and they
+    // never step back.  On sorted runs the searches give exactly that; a pass that only trusts a sampled guess of the
+    // runs (engine.hip run_pass) relies on it being enforced -- whatever the records are, every one of them then lies in
+    // exactly one tile's range, and the pileup kernels flag those that belong to another tile's reads (kErrOrder).
+    bool back = false;
 #pragma unroll
     for (int s = 0; s < kMaxSeg; ++s) {
+        if (s < sb.n_seg) {
+            const long long seg_e = seg_end_dev ? *seg_end_dev : sb.start[s + 1];
+            if (k == 0) blo[s] = sb.start[s];
+            if (k == n_tiles) blo[s] = seg_e;
+            if (own_end && k + 1 == n_tiles) blo[kMaxSeg + s] = seg_e;
+        }
         const long long lo = blo[s];
         long long hi = __shfl_down(lo, 1, kWave);
         if (own_end) hi = blo[kMaxSeg + s];
+        if (live && hi < lo) { back = true; hi = lo; }
         d.iv_lo[s] = lo;
         d.n_iv[s] = (int)(hi - lo);
     }
+    if (__ballot(back) != 0ull && lane == 0) atomicOr(err_flags, kErrOrder);
     const int nr = d.r_hi - d.r_lo;
     const long long nwin = d.g_hi - d.g_lo;
     const bool fast = cuts && live && nr >= 1 && nr <= fast_max_reads && nwin > 0 && nwin <= fast_cap;

@@ -107,7 +107,7 @@ __device__ __forceinline__ void fast_issue(const PileupArgs &a, unsigned tid, co
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int s = u % NSEG, first = (u / NSEG) * 256;
-        g.rid[u] = -1; g.st[u] = 0; g.en[u] = 0;
+        g.rid[u] = t.r_a; g.st[u] = 0; g.en[u] = 0;   // an empty slot is an empty interval of the tile's first read: no effect
         if ((int)tid < n[s] - first) {
             const long long base = (long long)lo[s] + first;
             g.rid[u] = at(a.iv_rid + base, b4);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             // 1. intervals -> +1 / -1 (profileCoverage, closed form).  (Tried and measured slower: issuing the table
             //    look-ups of all slots first and predicating only the two LDS adds -- more live state, more spills.)
             int covsum = 0;
-            bool bad_any = false;
+            bool bad_any = false, bad_order = false;
             auto win = [&](unsigned n) -> int { return (int)(((n & win_m1) | __umulhi(n, a.div_magic)) >> win_sh); };
             auto one = [&](int rid, int st, int en) {
                 const unsigned jr = (unsigned)(rid - r_a);
@@ -248,12 +248,14 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 const int b0 = tb.roff[j], nb_r = tb.roff[j + 1] - b0;
                 const int first = win((unsigned)st);
                 const int last1 = win((unsigned)(en - 1)) + 1;                    // meaningful for en >= 1
-                // valid: a record of one of the tile's reads.  Empty slots carry -1; a foreign read id can only come from
-                // a mis-speculated pass (engine.hip run_pass), whose results are thrown away -- it must not reach the tables
+                // valid: a record of one of the tile's reads.  Anything else refutes the sampled guess of the sorted runs
+                // this pass may be built on (engine.hip run_pass): it is flagged, must not reach the tables, and the pass
+                // is run again
                 const bool valid = jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
                 const bool over = last1 > first && last1 > nb_r;                   // repeat.hpp:69-72 writes past its vector
                 const int pf = b0 + first, pl1 = b0 + min(last1, nb_r);
                 bad_any |= valid && (!sign_ok || (pos && over));
+                bad_order |= !valid;             // a record of a read outside this tile (see kErrOrder in pileup.hpp)
                 if (valid && sign_ok && pos && pf < pl1) {
                     __hip_atomic_fetch_add(&sm.diff[pf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&sm.diff[pl1], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 }
             };
 #pragma unroll
-            for (int u = 0; u < U; ++u) if (g.rid[u] >= 0) one(g.rid[u], g.st[u], g.en[u]);
+            for (int u = 0; u < U; ++u) one(g.rid[u], g.st[u], g.en[u]);
             if (cur.more) {                      // intervals beyond the prefetched slots (dense tiles): synchronous loads
                 const TileCut d0 = cuts[k], d1 = cuts[k + 1];
 #pragma unroll
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                         one((a.iv_rid + base)[i], (a.iv_s + base)[i], (a.iv_e + base)[i]);
                 }
             }
+            if (__ballot(bad_order) != 0ull && tid == 0) atomicOr(a.err_flags, kErrOrder);
             if (__ballot(bad_any) != 0ull) {     // rare: find the offending records again and report the first index
                 const TileCut d0 = cuts[k], d1 = cuts[k + 1];
                 auto is_bad = [&](int rid, int st, int en) -> bool {
