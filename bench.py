@@ -215,6 +215,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--detect", action="store_true", help="symmetric_mode = -1: the engine detects the symmetric PAF itself (full inspect pass)")
     ap.add_argument("--presplit", action="store_true", help="BASELINE configs[3]: records pre-split across ranks, all-to-all-v in the step")
     ap.add_argument("--tile-bins", type=int, default=0)
     ap.add_argument("--force-bucket", action="store_true")
@@ -288,7 +289,13 @@ def main():
         my_len = read_len_all[b0:b1].contiguous()
     torch.cuda.synchronize()
 
-    eng = engine.Engine(p if not (args.presplit and world > 1) else RaftParams(**dict(p.__dict__, symmetric_mode=1)), device=local)
+    # The engine runs as the `raft` CLI runs it: the tokeniser has seen every record on its way in and hands over the
+    # symmetric flag (raft_host_paf_symmetric), so symmetric_mode = 1 -- the pass then neither searches for the mirror of
+    # record 0 nor re-reads the qid column to establish the sorted runs (it verifies them in its kernels).  --detect times
+    # the self-contained form (symmetric_mode = -1: inspect_kernel looks at every record first); the default line carries
+    # that figure as roofline.pass_device_ms_detect.
+    p_run = p if (args.detect and not (args.presplit and world > 1)) else RaftParams(**dict(p.__dict__, symmetric_mode=1))
+    eng = engine.Engine(p_run, device=local)
     eng.set_tuning(args.tile_bins, args.force_bucket, args.variant)
     eng.use_torch_stream()
 
@@ -349,6 +356,22 @@ def main():
         if not all(check.values()):
             raise SystemExit(f"bench.py: self-check failed: {check}")
 
+    detect_ms = None
+    if n_gpus == 1 and not args.presplit and not args.detect:
+        # the same pass without the tokeniser's hand-over: the engine looks at every record itself before it starts
+        e2 = engine.Engine(p, device=local)
+        e2.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+        e2.use_torch_stream()
+        tt = []
+        for it in range(4):
+            e2.run_device(*cols)
+            s2 = e2.finish()
+            if it:
+                tt.append(e2.timing()[1])
+        assert (s2.n_fragments, s2.n_repeats, s2.total_coverage, s2.symmetric) == (s.n_fragments, s.n_repeats, s.total_coverage, 1)
+        detect_ms = sum(tt) / len(tt) * 1e3
+        e2.close()
+
     if rank == 0:
         per_step = elapsed / args.steps
         # dominant kernel: pileup + prefix scan + coverage store + run scan (pileup.hpp).
@@ -377,7 +400,9 @@ def main():
                                    + ("" if args.variant < 0 else f" variant {args.variant}"),
                          "kernel_ms": pile * 1e3, "bytes_algorithmic": bytes_alg,
                          "pass_device_ms": pass_dev * 1e3, "pass_achieved": bytes_alg / pass_dev / 1e9,
-                         "pass_frac": bytes_alg / pass_dev / 1e9 / HBM_PEAK_GBS, "kernel_source_hash": kernel_source_hash()},
+                         "pass_frac": bytes_alg / pass_dev / 1e9 / HBM_PEAK_GBS, "kernel_source_hash": kernel_source_hash(),
+                         "symmetric_mode": "detected by the engine (inspect pass)" if args.detect else "handed over by the tokeniser (as the CLI does)",
+                         "pass_device_ms_detect": detect_ms},
             "self_check": check,
         }
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")

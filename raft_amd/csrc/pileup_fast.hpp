@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                         one((a.iv_rid + base)[i], (a.iv_s + base)[i], (a.iv_e + base)[i]);
                 }
             }
-            if (__ballot(bad_order) != 0ull && tid == 0) atomicOr(a.err_flags, kErrOrder);
+            if (__ballot(bad_order) != 0ull && lane == 0) atomicOr(a.err_flags, kErrOrder);   // (every wave for itself)
             if (__ballot(bad_any) != 0ull) {     // rare: find the offending records again and report the first index
                 const TileCut d0 = cuts[k], d1 = cuts[k + 1];
                 auto is_bad = [&](int rid, int st, int en) -> bool {
