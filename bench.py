@@ -216,6 +216,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--detect", action="store_true", help="symmetric_mode = -1: the engine detects the symmetric PAF itself (full inspect pass)")
+    ap.add_argument("--no-detect-leg", action="store_true", help="skip the extra passes that time symmetric_mode = -1")
     ap.add_argument("--presplit", action="store_true", help="BASELINE configs[3]: records pre-split across ranks, all-to-all-v in the step")
     ap.add_argument("--tile-bins", type=int, default=0)
     ap.add_argument("--force-bucket", action="store_true")
@@ -357,7 +358,7 @@ def main():
             raise SystemExit(f"bench.py: self-check failed: {check}")
 
     detect_ms = None
-    if n_gpus == 1 and not args.presplit and not args.detect:
+    if n_gpus == 1 and not args.presplit and not args.detect and not args.no_detect_leg:
         # the same pass without the tokeniser's hand-over: the engine looks at every record itself before it starts
         e2 = engine.Engine(p, device=local)
         e2.set_tuning(args.tile_bins, args.force_bucket, args.variant)

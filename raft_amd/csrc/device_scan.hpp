@@ -89,21 +89,14 @@ __global__ __launch_bounds__(1024) void scan_partials_scan_kernel(long long *par
     }
 }
 
-struct NoPost {
-    template <int K> __device__ void operator()(long long, const long long (&)[K], const long long (&)[K]) const {}
-};
-
-// `post(i, offset[K], value[K])` is called for every item once its K exclusive prefixes are known: work that needs the
-// offsets of an item and nothing else (e.g. filling its slice of a CSR array) rides in this kernel instead of a launch
-// of its own that would read the offsets back.
-template <class Loader, int K, class Post>
+template <class Loader, int K>
 __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, long long n, const long long *partials,
-                                                                  const long long *totals, ScanOut<K> out, Post post)
+                                                                  const long long *totals, ScanOut<K> out)
 {
     __shared__ long long lds[kScanThreads / 64 + 1];
     __shared__ long long stage[kScanTile];      // blocked -> striped, so that the stores are coalesced
     long long v[kScanItems][K];
-    long long acc[K], first[K];
+    long long acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0;
     const long long block0 = (long long)blockIdx.x * kScanTile;
@@ -123,7 +116,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, lon
     for (int k = 0; k < K; ++k) {
         long long tot;
         long long run = partials[(long long)blockIdx.x * K + k] + block_excl_scan64<kScanThreads>(acc[k], &tot, lds);
-        first[k] = run;
 #pragma unroll
         for (int j = 0; j < kScanItems; ++j) {
             stage[threadIdx.x * kScanItems + j] = run;
@@ -141,35 +133,20 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, lon
 #pragma unroll
         for (int k = 0; k < K; ++k) out.p[k][n] = totals[k];
     }
-#pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
-        if (i0 + j < n) post(i0 + j, first, v[j]);
-#pragma unroll
-        for (int k = 0; k < K; ++k) first[k] += v[j][k];
-    }
 }
 
-// Host driver.  partials must hold (scan_blocks(n) * K) + K int64; totals = partials + nblocks*K.  `first` loads the
-// items in the pass that sums the blocks (it may compute them and put them by), `again` loads them in the pass that
-// writes the prefixes.
-template <class LoaderA, class LoaderB, int K, class Post = NoPost>
-inline void exclusive_scan2(hipStream_t st, LoaderA first, LoaderB again, long long n, long long *partials, ScanOut<K> out,
-                            long long **totals_dev = nullptr, Post post = Post())
-{
-    int nb = scan_blocks(n);
-    if (nb < 1) nb = 1;
-    long long *totals = partials + (long long)nb * K;
-    hipLaunchKernelGGL((scan_partials_kernel<LoaderA, K>), dim3(nb), dim3(kScanThreads), 0, st, first, n, partials);
-    hipLaunchKernelGGL((scan_partials_scan_kernel<K>), dim3(1), dim3(1024), 0, st, partials, nb, totals);
-    hipLaunchKernelGGL((scan_apply_kernel<LoaderB, K, Post>), dim3(nb), dim3(kScanThreads), 0, st, again, n, partials, totals, out, post);
-    if (totals_dev) *totals_dev = totals;
-}
-
+// Host driver.  partials must hold (scan_blocks(n) * K) + K int64; totals = partials + nblocks*K.
 template <class Loader, int K>
 inline void exclusive_scan(hipStream_t st, Loader ld, long long n, long long *partials, ScanOut<K> out,
                            long long **totals_dev = nullptr)
 {
-    exclusive_scan2<Loader, Loader, K, NoPost>(st, ld, ld, n, partials, out, totals_dev, NoPost());
+    int nb = scan_blocks(n);
+    if (nb < 1) nb = 1;
+    long long *totals = partials + (long long)nb * K;
+    hipLaunchKernelGGL((scan_partials_kernel<Loader, K>), dim3(nb), dim3(kScanThreads), 0, st, ld, n, partials);
+    hipLaunchKernelGGL((scan_partials_scan_kernel<K>), dim3(1), dim3(1024), 0, st, partials, nb, totals);
+    hipLaunchKernelGGL((scan_apply_kernel<Loader, K>), dim3(nb), dim3(kScanThreads), 0, st, ld, n, partials, totals, out);
+    if (totals_dev) *totals_dev = totals;
 }
 
 } // namespace raft

@@ -209,11 +209,10 @@ __device__ __forceinline__ int walk_cuts(int len, int L, const int32_t *s, const
     return kept;
 }
 
-// Per read: order its repeats, count kept markers and fragments (chop.hpp:209-276).  The body of the first pass of the
-// output scan (device_scan.hpp exclusive_scan2): the three counts are what that pass sums, and they are put by for the
-// second pass.
-__device__ __forceinline__ void finalize_count(const FinalizeArgs &a, int r, long long (&v)[3])
+__global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
 {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
     const int n = a.rep_cnt[r];
     const long long base = a.rep_res_off[r];
     if (n > 1) sort_repeats(a.raw_key + base, a.raw_s + base, a.raw_e + base, n);
@@ -238,24 +237,23 @@ __device__ __forceinline__ void finalize_count(const FinalizeArgs &a, int r, lon
     if (nF > a.div + 1) nf = (nF - 1 + a.div - 1) / a.div;
     a.cut_cnt[r] = nF;
     a.frag_cnt[r] = nf;
-    v[0] = n; v[1] = nF; v[2] = nf;
 }
 
-struct FinalizeCountLoader {
-    FinalizeArgs a;
-    __device__ void operator()(long long i, long long (&v)[3]) const { finalize_count(a, (int)i, v); }
-};
-
-// Compact repeats and the fragments of one read, given where its slices of the output arrays begin (ro, fo) and its
-// counts.  The cut points themselves (chop.hpp's final_stars, 4 B per marker: 0.4 GB on the human-scale set) are
-// neither stored nor walked here: fragment j begins at the kept marker with index (j-1)*div and ends at the one with
-// index j*div, the first marker is 0 and the last is the read length.  finalize_cuts_kernel materialises them when a
-// caller asks for them.  Rides in the second pass of the output scan, which has just computed the offsets.
-__device__ __forceinline__ void finalize_fill(const FinalizeArgs &a, int r, long long ro, long long fo, int n, int nF)
+// Compact repeats and the fragments of every read.  The cut points themselves (chop.hpp's final_stars, 4 B per
+// marker: 0.4 GB on the human-scale set) are neither stored nor walked here: fragment j begins at the kept marker
+// with index (j-1)*div and ends at the one with index j*div, the first marker is 0 and the last is the read length.
+// finalize_cuts_kernel materialises them when a caller asks for them.
+__global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
 {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    const int n = a.rep_cnt[r];
     const long long base = a.rep_res_off[r];
+    const long long ro = a.rep_off[r];
     for (int i = 0; i < n; ++i) { a.rep_s[ro + i] = a.raw_s[base + i]; a.rep_e[ro + i] = a.raw_e[base + i]; }
     const int len = a.read_len[r];
+    const int nF = a.cut_cnt[r];
+    const long long fo = a.frag_off[r];
     if (nF <= a.div + 1) {                        // chop.hpp:250-267: the read is kept whole
         a.frag_read[fo] = r; a.frag_begin[fo] = 0; a.frag_end[fo] = len;
         return;
@@ -263,7 +261,7 @@ __device__ __forceinline__ void finalize_fill(const FinalizeArgs &a, int r, long
     const int nf = (nF - 1 + a.div - 1) / a.div;  // chop.hpp:280-321
     // Fragment j ends, and fragment j + 1 begins, at the kept marker with index t = j * div (an interior marker).
     // Without repeats that is the multiple t * L; each flanked repeat removes the multiples inside it, so the t-th kept
-    // multiple is found by skipping the covered ranges in order (the same sweep as in finalize_count).
+    // multiple is found by skipping the covered ranges in order (the same sweep as in finalize_count_kernel).
     const int L = a.interval_length;
     const int parts = len / L;
     const int J = (len % L) ? parts : parts - 1;
@@ -292,14 +290,6 @@ __device__ __forceinline__ void finalize_fill(const FinalizeArgs &a, int r, long
     }
     a.frag_end[fo + nf - 1] = len;                // the last kept marker is the read's end
 }
-
-struct FinalizeFillPost {
-    FinalizeArgs a;
-    __device__ void operator()(long long i, const long long (&off)[3], const long long (&cnt)[3]) const
-    {
-        finalize_fill(a, (int)i, off[0], off[2], (int)cnt[0], (int)cnt[1]);
-    }
-};
 
 // cut points of every read (final_stars), on demand
 __global__ __launch_bounds__(256) void finalize_cuts_kernel(FinalizeArgs a)
