@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void inspect_kernel(long long n_rec, int32_t n
     }
 }
 
-// Sorted runs of the record stream as 16 k evenly spaced samples show them: where one sample is smaller than the one
+// Sorted runs of the record stream as up to 16 k evenly spaced samples show them: where one sample is smaller than the one
 // before, a run ends in between, and a bisection (left part >= the earlier sample, right part below it) finds the first
 // record of the next run.  inspect_kernel, which looks at every record, confirms or refutes it.
 // The samples themselves are kept (64 KB): they are a coarse index of the stream.  tile_desc_kernel bisects them first
@@ -101,11 +101,12 @@ struct GuessOut {
 
 __global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const int32_t *qid, GuessOut *out, int32_t *samples)
 {
-    const long long S = n_rec < kSamples + 1 ? n_rec : kSamples + 1;     // (out->n_desc was zeroed with the control block)
+    const int sh = sample_shift(n_rec);                   // (out->n_desc was zeroed with the control block)
+    const long long S = n_samples(n_rec, sh);
     const long long i = 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 1 && samples) samples[0] = qid[0];
     if (i >= S) return;
-    const long long p0 = sample_pos(i - 1, n_rec, S), p1 = sample_pos(i, n_rec, S);
+    const long long p0 = sample_pos(i - 1, n_rec, sh), p1 = sample_pos(i, n_rec, sh);
     const int32_t v = qid[p0], w = qid[p1];
     if (samples) samples[i] = w;
     if (w < v) {

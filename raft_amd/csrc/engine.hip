@@ -187,7 +187,7 @@ struct raft_hip_ctx {
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
-    DevBuf samples;                   // kSamples + 1 read ids at evenly spaced records (guess_runs_kernel): coarse index
+    DevBuf samples;                   // up to kSamples + 2 read ids at evenly spaced records (guess_runs_kernel): coarse index
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
     DevBuf dbg;                       // diagnostic variant only
     DevBuf cov8, exc_idx, exc_val, exc_cnt;   // transfer encoding of cov[] (raft_hip_fetch_packed)
@@ -446,7 +446,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     HIP_TRY(c, c->rep_res_off.ensure((size_t)(N + 1) * 8));
     HIP_TRY(c, c->cutcap_off.ensure((size_t)(N + 1) * 8));
     const bool want_guess = n_rec > 1 && c->prm.symmetric_mode != 0 && !c->force_bucket;   // (the sorted-segment path is possible)
-    if (want_guess) HIP_TRY(c, c->samples.ensure((size_t)(kSamples + 1) * 4));
+    if (want_guess) HIP_TRY(c, c->samples.ensure((size_t)(kSamples + 2) * 4));
     long long *scan_totals = nullptr;
     {
         hipStream_t gst = c->side_stream;

@@ -99,11 +99,23 @@ struct PileupArgs {
     int32_t *slow_counter;        // list mode of this kernel: the items of slow_list are handed out one by one
 };
 
-// coarse index of the record stream (bucket.hpp guess_runs_kernel writes it, tile_desc_kernel reads it)
+// Coarse index of the record stream (bucket.hpp guess_runs_kernel writes it, tile_desc_kernel reads it): the read id of
+// every 2^sh-th record and of the last one, with sh the smallest shift that leaves at most kSamples strides.
 constexpr int kGuessBlocks = 64;                           // x 256 threads: one sample per thread
-constexpr int kSamples = kGuessBlocks * 256;               // samples 0 .. kSamples (the last one is the last record)
-// position of sample j of a stream of n records (j = 0 .. S - 1, S = min(n, kSamples + 1))
-__host__ __device__ __forceinline__ long long sample_pos(long long j, long long n, long long S) { return S > 1 ? j * (n - 1) / (S - 1) : 0; }
+constexpr int kSamples = kGuessBlocks * 256;
+__host__ __device__ __forceinline__ int sample_shift(long long n)
+{
+    int sh = 0;
+    while (((n - 1) >> sh) >= kSamples) ++sh;
+    return sh;
+}
+// samples j = 0 .. n_samples - 1 sit at min(j << sh, n - 1)
+__host__ __device__ __forceinline__ long long n_samples(long long n, int sh) { return ((n - 1) >> sh) + 2; }
+__host__ __device__ __forceinline__ long long sample_pos(long long j, long long n, int sh)
+{
+    const long long p = j << sh;
+    return p < n - 1 ? p : n - 1;
+}
 
 constexpr int kRunQ = 16; // parked runs per wave and window before falling back to immediate emission
 constexpr int kOpen = -2; // run began before this wave's first window
@@ -811,25 +823,22 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
         for (int q = 0; q < 2 * kMaxSeg; ++q)
             if (blo[q] < bhi[q]) blo[q] = bhi[q] = bucket_off[q < kMaxSeg ? d.r_lo : d.r_hi];
     } else if (samples) {
-        const long long S = n_rec < kSamples + 1 ? n_rec : kSamples + 1;
+        const int sh = sample_shift(n_rec);
 #pragma unroll
         for (int q = 0; q < 2 * kMaxSeg; ++q) {
             if (blo[q] < bhi[q]) {
                 const int key = q < kMaxSeg ? d.r_lo : d.r_hi;
-                // samples inside this run: jl = first with position >= run start, jh = last with position < run end
-                long long jl = (blo[q] * (S - 1) + (n_rec - 2)) / (n_rec - 1), jh = ((bhi[q] - 1) * (S - 1)) / (n_rec - 1);
-                while (jl < S && sample_pos(jl, n_rec, S) < blo[q]) ++jl;
-                while (jl > 0 && sample_pos(jl - 1, n_rec, S) >= blo[q]) --jl;
-                while (jh + 1 < S && sample_pos(jh + 1, n_rec, S) < bhi[q]) ++jh;
-                while (jh >= 0 && sample_pos(jh, n_rec, S) >= bhi[q]) --jh;
+                // samples inside this run: jl = first at or after its start, jh = last before its end (the closing sample
+                // n_samples - 1 repeats the last record and is not needed: the run's own end bounds the search)
+                const long long jl = (blo[q] + (1LL << sh) - 1) >> sh, jh = (bhi[q] - 1) >> sh;
                 if (jl <= jh) {
                     long long x = jl, y = jh + 1;          // first sample in [jl, jh] with an id >= key, or jh + 1
                     while (x < y) {
                         const long long m = (x + y) >> 1;
                         if (samples[m] < key) x = m + 1; else y = m;
                     }
-                    if (x > jl) blo[q] = sample_pos(x - 1, n_rec, S) + 1;
-                    if (x <= jh) bhi[q] = sample_pos(x, n_rec, S);
+                    if (x > jl) blo[q] = ((x - 1) << sh) + 1;
+                    if (x <= jh) bhi[q] = x << sh;
                 }
             }
         }
