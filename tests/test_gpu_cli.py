@@ -107,3 +107,35 @@ def test_cli_usage_and_input_errors(tmp_path):
     assert rc == 1 and "ERROR, raft_hip, PAF coordinate" in out
     rc, out = run(tmp_path, ["-e", "30", "a.fa", "b.paf"], {"RAFT_DEVICES": "0,7"})   # a device that does not exist
     assert rc == 1 and "ERROR, raft_hip_create(), device 7" in out
+
+
+BOUND = os.path.join(ROOT, "oracle", "_ref", "raft_bound")
+
+
+@pytest.mark.skipif(not os.path.exists(BOUND), reason="oracle/_ref/raft_bound not built (needs /root/reference: build container)")
+@pytest.mark.parametrize("name", ["g1", "g2", "g3", "g4", "s300_default", "s300_nonsym_shuffled", "edge_reads"])
+def test_reference_side_binding(tmp_path, name):
+    """INTEGRATION.md §B compiled (oracle/ref_binding.cpp): the reference's OWN loaders, name table and types, with the
+    three hot calls of break_long_reads() replaced by the C ABI -- same four files as the unmodified reference."""
+    if name in MAN["micro"]:
+        d = os.path.join(GOLDEN, "micro", name)
+        meta = MAN["micro"][name]
+        shutil.copy(os.path.join(d, "reads.fa"), tmp_path)
+        shutil.copy(os.path.join(d, "overlaps.paf"), tmp_path)
+        args, want_stdout = meta["args"], open(os.path.join(d, "expect.stdout")).read()
+        expect = {f: open(os.path.join(d, "expect." + f), "rb").read() for f in meta["outputs"]}
+    else:
+        p, cols, exp, meta = load_case(name)
+        names = [f"r{i}" for i in range(len(cols[0]))]
+        write_fasta(tmp_path / "reads.fa", names, cols[0])
+        write_paf(tmp_path / "overlaps.paf", names, *cols)
+        args, want_stdout, expect = meta["args"], meta["stdout"], None
+    r = subprocess.run([BOUND] + args + ["reads.fa", "overlaps.paf"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()[-500:]
+    assert strip_timing(r.stdout.decode()) == want_stdout
+    if expect is not None:
+        for f, want in expect.items():
+            assert open(tmp_path / f, "rb").read() == want, (name, f)
+    else:
+        for f, digest in meta["md5"].items():
+            assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, (name, f)
