@@ -633,6 +633,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     if (const char *e = getenv("RAFT_PILEUP_WG_PER_CU")) bpc = std::max(1, std::min(atoi(e), pv.wg_per_cu)); // occupancy experiments
     const unsigned pgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * bpc));
     unsigned n_sum_blocks = pgrid;
+    pa.tile_batch = n_tiles >= 64LL * pgrid ? 8 : (n_tiles >= 16LL * pgrid ? 2 : 1);
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
     if (pv.fast) {
         const TileCut *cuts = c->tile_cuts.as<TileCut>();

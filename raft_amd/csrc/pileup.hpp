@@ -96,6 +96,7 @@ struct PileupArgs {
     const int32_t *slow_list;     // tile ids (any order), or nullptr: every tile is handled here
     const int32_t *n_slow;        // device count of slow_list
     int32_t *tile_counter;        // pileup_fast_kernel: tiles are handed out through this counter (zeroed by the host)
+    int32_t tile_batch;           // ... in batches of this many consecutive tiles
     int32_t *slow_counter;        // list mode of this kernel: the items of slow_list are handed out one by one
 };
 

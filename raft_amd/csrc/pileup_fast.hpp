@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     // one word take longer than the kernel.)  The draw for the batch after the current one is one returning atomic
     // issued by thread 0 together with the prefetch loads; it lands before pass B like every other load and crosses to
     // the other waves through LDS behind the last barrier of that iteration.
-    constexpr int kBatch = 8;                    // 2 .. 16 measured alike
+    // (batches of 2 .. 16 measured alike at human scale; a set with few tiles per workgroup gets them one by one, or the
+    // last batches -- eight tiles in a row on one workgroup -- are the kernel's tail: 50 k reads took 171 us instead of 60)
+    const int kBatch = a.tile_batch;
     int k = (int)blockIdx.x;                     // current tile
     int kn = k + nb;                             // next tile (its cuts are in raw_n)
     int knn = n_tiles;                           // the tile after next
