@@ -480,12 +480,13 @@ static int load_reads(const char *path, raft_host_reads **out, bool allow_dup)
             in.get_line(seq);
         }
         last = (c == '>' || c == '@') ? c : 0;
-        bool stop_after = false;
         if (c == '+') {
             while ((c = in.getc()) >= 0 && c != '\n') {}
             if (c < 0) break;                       // no quality string: record and the rest are dropped
             std::string qual;
-            while (qual.size() < seq.size() && in.get_line(qual)) {}
+            // kseq.h:290: one quality line is read in any case (also for an empty sequence), more while it is shorter
+            // than the sequence -- so a quality line that starts with '@' or '>' is never taken for a header
+            while (in.get_line(qual) && qual.size() < seq.size()) {}
             last = 0;
             if (qual.size() != seq.size()) break;   // kseq_read returns -2: loadFASTA's loop ends
         }
@@ -494,7 +495,6 @@ static int load_reads(const char *path, raft_host_reads **out, bool allow_dup)
         R->lens.push_back((int32_t)seq.size());
         R->base_off.push_back(R->bases.size());
         R->bases.append(seq);
-        if (stop_after) break;
     }
     if (rc != RAFT_HOST_OK) { delete R; return rc; }
     *out = R;

@@ -322,3 +322,25 @@ def test_paf_loader_reports_the_symmetric_flag(tmp_path, threads):
             assert sym == want == oracle_run(RaftParams(est_cov=2), rl, *got)["symmetric"], what
     finally:
         hostio.set_threads(0)
+
+
+def test_fastq_empty_sequence_consumes_its_quality_line(tmp_path):
+    """kseq.h:290 reads one quality line in any case: after an empty-sequence FASTQ record its (empty) quality line is
+    consumed and the next record parses; a quality line starting with '@' is not a header; a non-empty quality string
+    after an empty sequence ends the file there (kseq returns -2), exactly as the compiled reference does."""
+    import subprocess
+    from raft_testlib import REF_BIN, have_ref_bin
+    cases = {"empty_ok": "@a\nACGT\n+\n@@II\n@e\n\n+\n\n@b\nAC\n+\nII\n",
+             "empty_then_garbage": "@a\nACGT\n+\nIIII\n@e\n\n+\n@x\n@b\nAC\n+\nII\n"}
+    want = {"empty_ok": [("a", 4), ("e", 0), ("b", 2)], "empty_then_garbage": [("a", 4)]}
+    for name, text in cases.items():
+        fq = tmp_path / f"{name}.fq"
+        fq.write_text(text)
+        reads = hostio.Reads(str(fq))
+        got = [(reads.name(i), int(reads.lengths[i])) for i in range(reads.n)]
+        assert got == want[name], (name, got)
+        if have_ref_bin():                               # and the reference itself: one coverage line per read it loaded
+            (tmp_path / "o.paf").write_text("a\t4\t0\t4\t+\ta\t4\t0\t4\t1\t1\t1\n")
+            r = subprocess.run([REF_BIN, "-e", "2", "-o", name, fq.name, "o.paf"], cwd=tmp_path, stdout=subprocess.PIPE)
+            assert r.returncode == 0
+            assert len(open(tmp_path / f"{name}.coverage.txt").read().splitlines()) == len(want[name]), name
