@@ -26,7 +26,9 @@
 #include <cstdlib>
 #include <atomic>
 #include <cstring>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -60,15 +62,37 @@ template <class F> void parallel_for(int n_tasks, F fn)   // fn(task) for task i
 }
 
 // ---- buffered byte stream over gz/plain files --------------------------------------------------
+// With more than one host thread the file is inflated / read by a helper thread that keeps a few 4 MB blocks ahead of
+// the parser (gz inputs -- the reference's own quick-start shape, chop.hpp:93, paf.hpp:29 -- are bound by zlib's
+// single-stream inflate; the parser's work now hides beside it instead of adding to it).  One thread: read in place.
 class Stream {
 public:
-    explicit Stream(const char *path) : f_(gzopen(path, "rb")), buf_(1 << 20) { if (f_) gzbuffer(f_, 1 << 20); }
-    ~Stream() { if (f_) gzclose(f_); }
+    explicit Stream(const char *path) : f_(gzopen(path, "rb"))
+    {
+        if (!f_) return;
+        gzbuffer(f_, 1 << 20);
+        async_ = host_threads() > 1;
+        if (async_) {
+            for (auto &b : ring_) b.data.resize(kBlock);
+            producer_ = std::thread([this] { produce(); });
+        } else ring_[0].data.resize(1 << 20);
+    }
+    ~Stream()
+    {
+        if (async_) {
+            { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+            cv_.notify_all();
+            if (producer_.joinable()) producer_.join();
+        }
+        if (f_) gzclose(f_);
+    }
+    Stream(const Stream &) = delete;
+    Stream &operator=(const Stream &) = delete;
     bool ok() const { return f_ != nullptr; }
     int getc()
     {
         if (b_ >= e_ && !fill()) return -1;
-        return buf_[b_++];
+        return cur_[b_++];
     }
     // Appends bytes up to (not including) the first byte for which is_delim holds and consumes that byte.
     // Returns false only when the stream was already exhausted (nothing at all could be looked at).
@@ -80,10 +104,10 @@ public:
             if (b_ >= e_ && !fill()) break;
             gotany = true;
             size_t i = b_;
-            while (i < e_ && !is_delim(buf_[i])) ++i;
-            out.append(reinterpret_cast<const char *>(&buf_[b_]), i - b_);
+            while (i < e_ && !is_delim(cur_[i])) ++i;
+            out.append(reinterpret_cast<const char *>(&cur_[b_]), i - b_);
             b_ = i + 1;
-            if (i < e_) { if (delim) *delim = buf_[i]; break; }
+            if (i < e_) { if (delim) *delim = cur_[i]; break; }
             b_ = e_;
         }
         return gotany;
@@ -94,20 +118,75 @@ public:
         if (any && out.size() > 1 && out.back() == '\r') out.pop_back();
         return any;
     }
+    // Bulk form for callers that want the whole rest of the stream: hands out the blocks as they come.
+    // Returns the number of bytes placed at *p (valid until the next call), 0 at the end.
+    size_t next_block(const unsigned char **p)
+    {
+        if (b_ >= e_ && !fill()) return 0;
+        *p = cur_ + b_;
+        const size_t n = e_ - b_;
+        b_ = e_;
+        return n;
+    }
 
 private:
+    static constexpr size_t kBlock = 4u << 20;
+    static constexpr int kRing = 4;
+    struct Block { std::vector<unsigned char> data; size_t n = 0; bool full = false; };
+    void produce()
+    {
+        for (int w = 0;; w = (w + 1) % kRing) {
+            Block &blk = ring_[w];
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return !blk.full || stop_; });
+                if (stop_) return;
+            }
+            const int n = gzread(f_, blk.data.data(), (unsigned)kBlock);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                blk.n = n > 0 ? (size_t)n : 0;
+                blk.full = true;
+                if (n <= 0) done_ = true;
+            }
+            cv_.notify_all();
+            if (n <= 0) return;
+        }
+    }
     bool fill()
     {
         if (eof_ || !f_) return false;
-        const int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
-        if (n <= 0) { eof_ = true; b_ = e_ = 0; return false; }
-        b_ = 0; e_ = (size_t)n;
+        if (!async_) {
+            const int n = gzread(f_, ring_[0].data.data(), (unsigned)ring_[0].data.size());
+            if (n <= 0) { eof_ = true; b_ = e_ = 0; return false; }
+            cur_ = ring_[0].data.data(); b_ = 0; e_ = (size_t)n;
+            return true;
+        }
+        if (have_) {                                   // give the block just consumed back to the producer
+            { std::lock_guard<std::mutex> g(mu_); ring_[r_].full = false; }
+            cv_.notify_all();
+            r_ = (r_ + 1) % kRing;
+            have_ = false;
+        }
+        Block &blk = ring_[r_];
+        {
+            std::unique_lock<std::mutex> g(mu_);
+            cv_.wait(g, [&] { return blk.full; });
+        }
+        if (blk.n == 0) { eof_ = true; b_ = e_ = 0; return false; }
+        cur_ = blk.data.data(); b_ = 0; e_ = blk.n; have_ = true;
         return true;
     }
     gzFile f_;
-    std::vector<unsigned char> buf_;
+    Block ring_[kRing];
+    const unsigned char *cur_ = nullptr;
     size_t b_ = 0, e_ = 0;
-    bool eof_ = false;
+    bool eof_ = false, async_ = false, have_ = false;
+    int r_ = 0;
+    std::thread producer_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false, done_ = false;
 };
 
 // ---- name table: open addressing over (offset, length) into one arena ---------------------------
@@ -543,22 +622,25 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
         close(fd);
     }
     if (!have) {
-        gzFile f = gzopen(path, "rb");
-        if (!f) return RAFT_HOST_ERR_OPEN;
-        gzbuffer(f, 1 << 20);
-        size_t used = 0;
-        std::vector<char> grow(8u << 20);
-        for (;;) {
-            if (grow.size() - used < (4u << 20)) grow.resize(grow.size() * 2);
-            const int n = gzread(f, grow.data() + used, (unsigned)std::min<size_t>(grow.size() - used - 1, 1u << 30));
-            if (n <= 0) break;
-            used += (size_t)n;
+        // gz (or not a regular file): inflated by the stream's helper thread while this thread gathers the blocks
+        Stream in(path);
+        if (!in.ok()) return RAFT_HOST_ERR_OPEN;
+        size_t used = 0, cap = 64u << 20;
+        std::unique_ptr<char[]> grow(new char[cap]);
+        const unsigned char *blk = nullptr;
+        for (size_t n; (n = in.next_block(&blk)) != 0;) {
+            if (used + n + 1 > cap) {
+                while (used + n + 1 > cap) cap *= 2;
+                std::unique_ptr<char[]> bigger(new char[cap]);
+                memcpy(bigger.get(), grow.get(), used);
+                grow.swap(bigger);
+            }
+            memcpy(grow.get() + used, blk, n);
+            used += n;
         }
-        gzclose(f);
         if (used) {
-            data_buf.reset(new char[used + 1]);
-            memcpy(data_buf.get(), grow.data(), used);
-            data_buf[used] = '\n'; // a last line without newline is still a line
+            grow[used] = '\n';                          // a last line without newline is still a line
+            data_buf.swap(grow);
             data_n = used + 1;
         }
     }
