@@ -1043,7 +1043,7 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
     int n_seg = -1;
     // chunking needs: the symmetric flag asserted, enough work to split, a record stream of at most kMaxSeg sorted runs
     // (an explicit n_chunks is honoured from tiny inputs on: that is how the tests reach every shape of the plan)
-    const bool big_enough = n_chunks > 0 ? (n_rec >= 2 && n_reads >= 2) : (n_rec >= (1 << 22) && n_reads >= 4096);
+    const bool big_enough = n_chunks > 0 ? (n_rec >= 2 && n_reads >= 2) : (n_rec >= (1 << 24) && n_reads >= 4096);   // (~200 MB up: below that one piece is as fast)
     const bool eligible = c->prm.symmetric_mode == 1 && big_enough && !c->force_bucket;
     if (eligible) n_seg = guess_segments(qid, n_rec, seg);
     if (n_seg < 1) return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary);

@@ -236,7 +236,7 @@ def check_pipelined(res, s, want, what):
                                          (dict(n_reads=50000, seed=2), 0)])
 def test_pipelined_equals_oracle(kw, n_chunks, n_ctx):
     """Upload / pass / download of consecutive read ranges overlapped: same outputs as the one-piece pass and the oracle.
-    n_chunks = 0 lets the engine choose (the 50 k-read set is just above its threshold)."""
+    n_chunks = 0 lets the engine choose (one piece for the 50 k-read set: the threshold is 2^24 records)."""
     from raft_amd import engine
     from raft_amd.synth import make_overlaps
     o = make_overlaps(**kw)
