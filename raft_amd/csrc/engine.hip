@@ -82,6 +82,7 @@ struct Ctrl {                         // device control block, cleared every pas
     long long err_index;              // (the first 16 bytes are what the pass's host wait reads back)
     int32_t next_tile;                // pileup_fast_kernel's tile hand-out counter
     int32_t slow_next;                // the general kernel's item hand-out counter (list mode)
+    int32_t n_extra, pad_extra;       // extra tiles tile_desc_kernel cut out of the tiles that do not fit the fast kernel
     unsigned long long totals[4];     // coverage, repeat bp, read length
     InspectOut insp;
     long long out_totals[4];          // rep / cut / frag totals land here via the scan
@@ -109,6 +110,7 @@ struct DevBuf {
 struct ReadPrepLoader {               // per read: windows, reserved repeat slots, marker capacity
     const int32_t *len;
     int32_t reso, minbins, L;
+    int32_t long_windows, piece_w;    // reads longer than long_windows are piled up in pieces of piece_w windows
     int32_t *err_flags;
     long long *err_index;
     __device__ void operator()(long long i, long long (&v)[3]) const
@@ -122,6 +124,7 @@ struct ReadPrepLoader {               // per read: windows, reserved repeat slot
         const long long nb = l / reso + ((l % reso) ? 1 : 0);   // repeat.hpp:32-37
         v[0] = nb;
         v[1] = (nb + 1) / ((long long)minbins + 1);              // most runs of >= minbins windows a read can hold
+        if (nb > long_windows) v[1] += 2 * ((nb + piece_w - 1) / piece_w);   // + two runs per piece that touch its edges
         v[2] = l / L + 2;                                        // chop.hpp:209-223
     }
 };
@@ -180,6 +183,7 @@ struct raft_hip_ctx {
     int32_t tile_q = 0;               // 0 = variant default
     int32_t variant = kDefaultVariant;
     int32_t force_bucket = 0;
+    bool no_recut = false;            // leave tiles that do not fit the fast kernel to the general kernel (fallback, A/B)
     std::string last_error;
 
     // device buffers
@@ -258,7 +262,7 @@ int code_from_flags(int flags)
     if (flags & kErrReadId) return RAFT_HIP_ERR_READ_ID;
     if (flags & kErrCoord) return RAFT_HIP_ERR_COORD;
     if (flags & kErrFragment) return RAFT_HIP_ERR_FRAGMENT;
-    if (flags & (kErrInternal | kErrOrder)) return RAFT_HIP_ERR_DEVICE;   // (kErrOrder never outlives raft_hip_finish's second run)
+    if (flags & (kErrInternal | kErrOrder | kErrExtra)) return RAFT_HIP_ERR_DEVICE;   // (kErrOrder never outlives raft_hip_finish's second run)
     return RAFT_HIP_OK;
 }
 
@@ -452,7 +456,10 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
         hipStream_t gst = c->side_stream;
         HIP_TRY(c, hipEventRecord(c->ev_ifork, st));                        // (the control block is clear)
         HIP_TRY(c, hipStreamWaitEvent(gst, c->ev_ifork, 0));
-        ReadPrepLoader ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, &ctrl->err_flags, &ctrl->err_index};
+        const PileVariant &pv0 = kVariants[c->variant];
+        const bool recut0 = pv0.fast && !c->no_recut && getenv("RAFT_NO_RECUT") == nullptr;
+        ReadPrepLoader ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, recut0 ? pv0.cap : INT32_MAX, pv0.cap,
+                          &ctrl->err_flags, &ctrl->err_index};
         ScanOut<3> so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), c->cutcap_off.as<long long>()}};
         exclusive_scan<ReadPrepLoader, 3>(gst, ld, N, c->scan_tmp.as<long long>(), so, &scan_totals);
         HIP_TRY(c, hipEventRecord(c->ev_gjoin, gst));
@@ -499,8 +506,16 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
     HIP_TRY(c, c->tile_first.ensure((size_t)(n_tiles + 1) * 4));
     HIP_TRY(c, c->tile_desc.ensure((size_t)n_tiles * sizeof(TileDesc)));
+    // extra tiles (tiles re-cut for the fast kernel: groups of whole reads, pieces of long reads) follow the regular cuts
+    static const bool no_recut_env = getenv("RAFT_NO_RECUT") != nullptr;
+    const bool recut = pv.fast && !c->no_recut && !no_recut_env;
+    long long extra_cap = 0;
+    if (recut) {
+        extra_cap = n_tiles + B / pv.cap + N / 8 + 1024;
+        if ((n_tiles + 1 + 2 * extra_cap) * 8 >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;   // cut words are indexed with 32 bits
+    }
     if (pv.fast) {
-        HIP_TRY(c, c->tile_cuts.ensure((size_t)(n_tiles + 1) * sizeof(TileCut)));
+        HIP_TRY(c, c->tile_cuts.ensure((size_t)(n_tiles + 1 + 2 * extra_cap) * sizeof(TileCut)));
         HIP_TRY(c, c->slow_list.ensure((size_t)n_tiles * 4));
     }
     HIP_TRY(c, c->block_sums.ensure((size_t)256 * 8 * 16 * 2));
@@ -619,7 +634,10 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
                        pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, pv.cap, kFastMaxReads,
                        pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow,
                        (fast && table_ok) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
-                       c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags);
+                       c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags,
+                       recut ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap);
+    pa.n_extra = recut ? &ctrl->n_extra : nullptr;
+    pa.piece_w = pv.cap;
 
     pa.dbg = nullptr;
     if (c->variant == kDiagVariant) {
@@ -671,6 +689,8 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     fa.rep_s = c->rep_s.as<int32_t>(); fa.rep_e = c->rep_e.as<int32_t>(); fa.cuts = c->cuts.as<int32_t>();
     fa.frag_read = c->frag_read.as<int32_t>(); fa.frag_begin = c->frag_begin.as<int32_t>(); fa.frag_end = c->frag_end.as<int32_t>();
     fa.err_flags = &ctrl->err_flags; fa.err_index = &ctrl->err_index;
+    fa.long_windows = recut ? pv.cap : INT32_MAX; fa.reso = c->prm.reso; fa.repeat_length = c->prm.repeat_length;
+    fa.flank = c->prm.flanking_length; fa.rep_cnt_rw = c->rep_cnt.as<int32_t>(); fa.total_repeat = &ctrl->totals[1];
     if (N > 0) {
         // (Measured and dropped: the count riding in the scan's first pass and the fill in its last, which has the offsets in
         // registers -- the scan walks eight consecutive reads per thread, and the fill's stores from that shape took 320 us
@@ -752,6 +772,19 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
                 const int rc = run_pass(c, a.n_reads, a.len, a.n_rec, a.col[0], a.col[1], a.col[2], a.col[3], a.col[4], a.col[5], false);
                 if (rc != RAFT_HIP_OK) return rc;
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
+            }
+        }
+        if (c->pending_err == RAFT_HIP_OK) {
+            Ctrl hc;
+            memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));
+            if (hc.err_flags & kErrExtra) {                  // more extra tiles than room: this pass with the general kernel
+                const auto a = c->args;
+                c->no_recut = true;
+                const int rc = run_pass(c, a.n_reads, a.len, a.n_rec, a.col[0], a.col[1], a.col[2], a.col[3], a.col[4], a.col[5], false);
+                c->no_recut = false;
+                if (rc != RAFT_HIP_OK) return rc;
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                c->spec = false;
             }
         }
         if (c->pending_err == RAFT_HIP_OK) {

@@ -17,6 +17,11 @@ struct FinalizeArgs {
     const int32_t *rep_cnt;
     int32_t *raw_key, *raw_s, *raw_e;     // sorted in place by finalize_count_kernel
     int32_t interval_length, div, overlap_length;
+    // reads with more than long_windows windows were piled up in pieces (pileup_fast.hpp emit_piece_run): their raw
+    // records are unflanked [start, end) runs per piece, to be joined, tested, flanked and clamped here
+    int32_t long_windows, reso, repeat_length, flank;
+    int32_t *rep_cnt_rw;                  // (rep_cnt, writable: the joined count replaces the pieces' count)
+    unsigned long long *total_repeat;     // repeat.hpp:127,152 for those reads
     int32_t *cut_cnt, *frag_cnt;          // [n_reads]
     const long long *rep_off, *cut_off, *frag_off; // [n_reads+1] (fill kernel)
     int32_t *rep_s, *rep_e, *cuts, *frag_read, *frag_begin, *frag_end;
@@ -213,9 +218,37 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_reads) return;
-    const int n = a.rep_cnt[r];
+    int n = a.rep_cnt[r];
     const long long base = a.rep_res_off[r];
     if (n > 1) sort_repeats(a.raw_key + base, a.raw_s + base, a.raw_e + base, n);
+    {
+        const int len = a.read_len[r];
+        const int nb = len / a.reso + ((len % a.reso) ? 1 : 0);
+        if (nb > a.long_windows && n > 0) {
+            // a long read, piled up in pieces: runs that meet at a piece boundary are one run (repeat.hpp:111-168 on the
+            // whole read); then the length test, the flanks and the clamp, as pileup.hpp emit_run_of does for other reads
+            int32_t *S = a.raw_s + base, *E = a.raw_e + base, *K = a.raw_key + base;
+            int m = 0;
+            long long rep_bp = 0;
+            for (int i = 0; i < n;) {
+                const int start = S[i];
+                int end = E[i];
+                int j = i + 1;
+                while (j < n && S[j] == end) { end = E[j]; ++j; }
+                if (end - start >= a.repeat_length) {
+                    rep_bp += end - start;
+                    int s = start - a.flank, e = end + a.flank;
+                    if (s <= 0) s = 0;
+                    if (e >= len) e = len;
+                    K[m] = start; S[m] = s; E[m] = e; ++m;
+                }
+                i = j;
+            }
+            n = m;
+            a.rep_cnt_rw[r] = m;
+            if (rep_bp) atomicAdd(a.total_repeat, (unsigned long long)rep_bp);
+        }
+    }
     if (n > 16 && a.raw_s[base + 1] == 0) rep_std_sort(a.raw_s + base, a.raw_e + base, n);   // tied starts: repeat.hpp:170
     // Number of markers walk_cuts() keeps, without walking them: the interior markers are L, 2L, .., J*L; a flanked
     // repeat [s,e] covers the multiples of L inside it; repeats are ordered by start and by end, so the union is

@@ -43,6 +43,8 @@ enum : int {
     kErrFragment = 1 << 2,
     kErrInternal = 1 << 3,
     kErrLen = 1 << 4,
+    kErrExtra = 1 << 6,         // the list of extra tiles (split tiles, pieces of long reads) overflowed: the engine runs
+                               // the pass again with the general kernel for those tiles
     kErrOrder = 1 << 5          // a pass that trusted a sampled guess of the sorted runs met a record that refutes it (not an
                                // error of the input: the engine runs the pass again after looking at every record)
 };
@@ -66,7 +68,10 @@ struct TileCut {
     long long g_lo;            // first window of tile k in cov[]
 };
 static_assert(sizeof(TileCut) == 32, "two adjacent cuts are one 64-byte scalar load");
-enum : int { kCutFast = 1 };
+enum : int {
+    kCutFast = 1,              // tile k holds whole reads that fit one LDS window
+    kCutPiece = 2              // (extra entries only) the tile is a piece of ONE read longer than the LDS window
+};
 static_assert(sizeof(TileDesc) == 72, "descriptor is fetched as 18 dwords, one per lane");
 
 struct PileupArgs {
@@ -97,6 +102,12 @@ struct PileupArgs {
     const int32_t *n_slow;        // device count of slow_list
     int32_t *tile_counter;        // pileup_fast_kernel: tiles are handed out through this counter (zeroed by the host)
     int32_t tile_batch;           // ... in batches of this many consecutive tiles
+    // Tiles that do not fit the fast kernel as they are (more windows than the LDS window, more reads than its tables, a
+    // read longer than the window) are re-cut by tile_desc_kernel into EXTRA tiles that do: groups of whole reads, and
+    // pieces of piece_w windows of a long read.  They follow the regular boundaries in the cut array as explicit
+    // (begin, end) pairs: extra tile j = cuts[n_tiles + 1 + 2j], cuts[n_tiles + 2 + 2j].
+    const int32_t *n_extra;       // device count of extra tiles (nullptr: none, the general kernel takes those tiles)
+    int32_t piece_w;
     int32_t *slow_counter;        // list mode of this kernel: the items of slow_list are handed out one by one
 };
 
@@ -787,7 +798,8 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                                                         const long long *cov_off, TileDesc *td, TileCut *cuts,
                                                         int fast_cap, int fast_max_reads, int32_t *slow_list,
                                                         int32_t *n_slow, const int32_t *samples, long long n_rec,
-                                                        const long long *bucket_off, int32_t *err_flags)
+                                                        const long long *bucket_off, int32_t *err_flags, TileCut *extra,
+                                                        int32_t *n_extra, int32_t extra_cap, int32_t piece_w)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -893,8 +905,66 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
         for (int s = 0; s < kMaxSeg; ++s) c.iv_lo[s] = (int32_t)d.iv_lo[s];
         cuts[k] = c;
     }
+    // ---- a tile the fast kernel cannot take as it is becomes EXTRA tiles that it can (see PileupArgs::n_extra): its reads
+    // are walked once; a read longer than the LDS window is cut into pieces of piece_w windows (each piece is handed ALL
+    // intervals of the read and clips them), the reads between are grouped greedily into LDS-window-sized tiles.  The
+    // interval ranges of the entries tile the tile's range: first entry begins where the tile's range begins, the last
+    // ends where it ends, neighbours meet at the same search result (what the kernels' kErrOrder check relies on).
+    bool recut = false;
+    if (extra && cuts && live && nr >= 1 && !fast) {
+        recut = true;
+        long long t_lo[kMaxSeg], t_hi[kMaxSeg];
+#pragma unroll
+        for (int s = 0; s < kMaxSeg; ++s) { t_lo[s] = d.iv_lo[s]; t_hi[s] = d.iv_lo[s] + d.n_iv[s]; }
+        auto bound = [&](int s, int r) -> long long {      // first interval of read r in run s, inside the tile's range
+            if (r <= d.r_lo) return t_lo[s];
+            if (r >= d.r_hi) return t_hi[s];
+            return lower_bound_rid(iv_rid, t_lo[s], t_hi[s], r);
+        };
+        auto emit = [&](int slot, int r_a, int r_b, long long g_a, long long g_b, int flags) {
+            TileCut b{}, e{};
+            b.r_lo = r_a; b.flags = flags; b.g_lo = g_a;
+            e.r_lo = r_b; e.flags = 0; e.g_lo = g_b;
+#pragma unroll
+            for (int s = 0; s < kMaxSeg; ++s) {
+                b.iv_lo[s] = s < sb.n_seg ? (int32_t)bound(s, r_a) : 0;
+                e.iv_lo[s] = s < sb.n_seg ? (int32_t)bound(s, r_b) : 0;
+            }
+            extra[2 * (long long)slot] = b; extra[2 * (long long)slot + 1] = e;
+        };
+        int r = d.r_lo;
+        long long g_r = d.g_lo;                            // cov_off[r]
+        while (r < d.r_hi) {
+            const long long g_n = (r + 1 == d.r_hi) ? d.g_hi : cov_off[r + 1];
+            const long long nb = g_n - g_r;
+            if (nb > fast_cap) {                           // pieces of one long read
+                const int P = (int)((nb + piece_w - 1) / piece_w);
+                const int base = atomicAdd(n_extra, P);
+                if (base + P > extra_cap) { atomicOr(err_flags, kErrExtra); break; }
+                for (int q = 0; q < P; ++q) {
+                    const long long w0 = (long long)q * piece_w, w1 = min(nb, w0 + piece_w);
+                    emit(base + q, r, r + 1, g_r + w0, g_r + w1, kCutFast | kCutPiece);
+                }
+                ++r; g_r = g_n;
+            } else {                                       // a group of whole reads that fits the window and the tables
+                int r2 = r + 1;
+                long long g2 = g_n;
+                while (r2 < d.r_hi && r2 - r < fast_max_reads) {
+                    const long long g3 = (r2 + 1 == d.r_hi) ? d.g_hi : cov_off[r2 + 1];
+                    if (g3 - g2 > fast_cap || g3 - g_r > fast_cap) break;   // a long read ends the group; so does a full window
+                    ++r2; g2 = g3;
+                }
+                {   // (also a group of reads without windows: its records still have to be looked at)
+                    const int slot = atomicAdd(n_extra, 1);
+                    if (slot + 1 > extra_cap) { atomicOr(err_flags, kErrExtra); break; }
+                    emit(slot, r, r2, g_r, g2, kCutFast);
+                }
+                r = r2; g_r = g2;
+            }
+        }
+    }
     // tiles left to the general kernel: one append per wave (one atomic per tile on the same word serialises)
-    const bool slow = cuts && live && nr >= 1 && !fast;
+    const bool slow = cuts && live && nr >= 1 && !fast && !recut;
     const unsigned long long sm = __ballot(slow);
     if (sm) {
         const int leader = (int)__builtin_ctzll(sm);

@@ -34,6 +34,7 @@ struct FastReadRegs {           // per read of a tile (thread j <-> read r_a + j
 
 struct FastTile {               // scalars of one tile
     int r_a, nr, nwin, fast, more;   // more: a segment holds intervals beyond the prefetched slots
+    int piece;                       // the tile is a piece of one read longer than the LDS window (kCutPiece)
     long long g_lo;
 };
 
@@ -72,7 +73,7 @@ __device__ __forceinline__ void cut_unpack(int raw, FastTile &t, int (&lo)[NSEG]
     auto d = [&](int i) -> int { return __builtin_amdgcn_readlane(raw, i); };
     auto q = [&](int i) -> long long { return (long long)(((unsigned long long)(unsigned)d(i + 1) << 32) | (unsigned)d(i)); };
     const int r0 = d(0);
-    t.r_a = r0; t.nr = d(8) - r0; t.fast = d(1) & kCutFast; t.g_lo = q(6);
+    t.r_a = r0; t.nr = d(8) - r0; t.fast = d(1) & kCutFast; t.piece = d(1) & kCutPiece; t.g_lo = q(6);
     t.nwin = d(14) - d(6);                        // low dwords suffice: a fast tile has at most CAP windows
     t.more = 0;
 #pragma unroll
@@ -117,6 +118,22 @@ __device__ __forceinline__ void fast_issue(const PileupArgs &a, unsigned tid, co
     }
 }
 
+// A run of high windows inside a piece of a long read (slots [sS, sT) of the piece's LDS window): recorded as it is --
+// unflanked [start, end) in bases of the read -- because it may continue in the neighbouring piece; finalize_count_kernel
+// joins the pieces' runs, applies the length test, the flanks and the clamp (repeat.hpp:125-140), and adds the read's
+// repeat bases to the total.  Pieces of one read are processed by different workgroups: slots come from a global counter.
+__device__ __forceinline__ void emit_piece_run(const PileupArgs &a, const FastTables &tb, int r, int sS, int sT)
+{
+    const int r0 = tb.rres[0], r1 = tb.rres[1];
+    const int slot = atomicAdd(&a.rep_cnt[r], 1);
+    if (slot >= r1 - r0) { raise_error(a, kErrInternal, r); return; }
+    const int start = (sS - tb.roff[0]) * a.reso;    // (roff[0]: the read's first window, before the piece's slots)
+    const long long idx = (long long)r0 + slot;
+    a.raw_key[idx] = start;
+    a.raw_s[idx] = start;
+    a.raw_e[idx] = start + (sT - sS) * a.reso;
+}
+
 template <int CAP, int NSEG, int U, int MINW, bool DIAG>
 __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *__restrict__ cuts, PileupArgs a)
 {
@@ -133,8 +150,12 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     const int wid = uni((int)(tid >> 6));
     // tile indices fit 32 bits (the host checks n_tiles * 18 < 2^31): scalar compares, half the registers
     const int nb = (int)gridDim.x;
-    const int n_tiles = (int)a.n_tiles;
-    const int last_cut = n_tiles - 1;            // cuts[last_cut + 1] is the closing boundary
+    // regular tiles 0 .. n_reg - 1 are bounded by adjacent cuts; extra tiles (tile_desc_kernel re-cut what does not fit:
+    // PileupArgs::n_extra) follow as explicit (begin, end) pairs behind the closing boundary
+    const int n_reg = (int)a.n_tiles;
+    const int n_tiles = n_reg + (a.n_extra ? uni(*a.n_extra) : 0);
+    const int last_cut = n_tiles - 1;            // (tile index: the word index below maps it)
+    auto cut_of = [&](int t) -> int { return t < n_reg ? t : n_reg + 1 + 2 * (t - n_reg); };   // index of tile t's first cut
     // runs are kept from ceil(repeat_length / reso) windows on; from 68 windows on, pass B can tell by whole lanes
     // of four windows that a row ends no such run (see there)
     const bool long_runs_only = ((long long)a.repeat_length + a.reso - 1) / a.reso >= 68;
@@ -200,14 +221,14 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     };
     if (k < n_tiles) {
         int lo[NSEG], n[NSEG];
-        cut_unpack<NSEG, ITER>(cut_word(k), cur, lo, n);
+        cut_unpack<NSEG, ITER>(cut_word(cut_of(k)), cur, lo, n);
         if (cur.fast) {
             FastReadRegs rd;
             fast_issue<NSEG, U>(a, tid, cur, lo, n, g, rd);
             wait_all_loads();
             stage_reads(0, cur, rd);
         }
-        raw_n = cut_word(min(kn, last_cut));
+        raw_n = cut_word(cut_of(min(kn, last_cut)));
         draw();
     }
     wait_all_loads();
@@ -222,7 +243,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             int lo[NSEG], n[NSEG];
             cut_unpack<NSEG, ITER>(raw_n, nxt, lo, n);
             if (kn >= n_tiles) nxt.fast = 0;
-            raw_nn = cut_word(min(knn, last_cut));
+            raw_nn = cut_word(cut_of(min(knn, last_cut)));
             drew = want_draw;
             if (want_draw) { draw(); want_draw = false; }
             if (nxt.fast) fast_issue<NSEG, U>(a, tid, nxt, lo, n, gn, rdn);
@@ -255,7 +276,8 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 // is run again
                 const bool valid = jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
                 const bool over = last1 > first && last1 > nb_r;                   // repeat.hpp:69-72 writes past its vector
-                const int pf = b0 + first, pl1 = b0 + min(last1, nb_r);
+                // (clipped to the tile's slots: a no-op for tiles of whole reads, the cut for a piece of a long read)
+                const int pf = max(b0 + first, off0), pl1 = min(b0 + min(last1, nb_r), t_end);
                 bad_any |= valid && (!sign_ok || (pos && over));
                 bad_order |= !valid;             // a record of a read outside this tile (see kErrOrder in pileup.hpp)
                 if (valid && sign_ok && pos && pf < pl1) {
@@ -267,7 +289,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
 #pragma unroll
             for (int u = 0; u < U; ++u) one(g.rid[u], g.st[u], g.en[u]);
             if (cur.more) {                      // intervals beyond the prefetched slots (dense tiles): synchronous loads
-                const TileCut d0 = cuts[k], d1 = cuts[k + 1];
+                const TileCut d0 = cuts[cut_of(k)], d1 = cuts[cut_of(k) + 1];
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) {
                     const int n_s = d1.iv_lo[s] - d0.iv_lo[s];
@@ -278,7 +300,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             }
             if (__ballot(bad_order) != 0ull && lane == 0) atomicOr(a.err_flags, kErrOrder);   // (every wave for itself)
             if (__ballot(bad_any) != 0ull) {     // rare: find the offending records again and report the first index
-                const TileCut d0 = cuts[k], d1 = cuts[k + 1];
+                const TileCut d0 = cuts[cut_of(k)], d1 = cuts[cut_of(k) + 1];
                 auto is_bad = [&](int rid, int st, int en) -> bool {
                     if ((unsigned)(rid - r_a) >= (unsigned)nr) return false;
                     const int j = rid - r_a;
@@ -343,12 +365,15 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             // repeat.hpp:111-112); also used to find the owner of a parked run
             const int ro0 = (lane < nr) ? tb.roff[lane] : 0x7fffffff;
             const int ro1 = (lane + 64 < nr) ? tb.roff[lane + 64] : 0x7fffffff;
+            const int piece = cur.piece;
             auto park = [&](int sS, int sT) {    // wave-uniform arguments
-                if ((long long)(sT - sS) * a.reso < (long long)a.repeat_length) return;   // repeat.hpp:125,150
+                // repeat.hpp:125,150 -- except that a run touching an edge of a PIECE of a long read may continue in the
+                // neighbouring piece: it is kept whatever its length and judged when finalize has joined the pieces
+                if ((long long)(sT - sS) * a.reso < (long long)a.repeat_length && !(piece && (sS == off0 || sT == t_end))) return;
                 if (nq < kRunQ) {
                     if (lane == 0) { sm.runq[(wid * kRunQ + nq) * 2] = sS; sm.runq[(wid * kRunQ + nq) * 2 + 1] = sT; }
                     ++nq;
-                } else if (lane == 0) emit_run(a, tb, nr, sS, sT);
+                } else if (lane == 0) { if (piece) emit_piece_run(a, tb, r_a, sS, sT); else emit_run(a, tb, nr, sS, sT); }
             };
 
             int4 dn = make_int4(0, 0, 0, 0);
@@ -528,7 +553,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                     const int jq = __popcll(__ballot(ro0 <= s0)) + __popcll(__ballot(ro1 <= s0)) - 1;
                     if (lane == q) j = jq;
                 }
-                if (lane < nq) emit_run_of(a, tb, j, sS, sT);
+                if (lane < nq) { if (piece) emit_piece_run(a, tb, r_a, sS, sT); else emit_run_of(a, tb, j, sS, sT); }
             }
             RAFT_STAMP(13);
             pub_r_a = r_a; pub_nr = nr;          // counts are final once every wave is past its next barrier
@@ -545,7 +570,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
         RAFT_STAMP(7);
         if (DIAG && tid == 0 && a.dbg) {
             sm.stamps[10] = __builtin_amdgcn_s_memrealtime();
-            for (int i = 0; i < 16; ++i) a.dbg[(long long)k * 16 + i] = sm.stamps[i];
+            if (k < n_reg) for (int i = 0; i < 16; ++i) a.dbg[(long long)k * 16 + i] = sm.stamps[i];
         }
         if (drew) next_base = uni(sm.next_tile);     // (written before this iteration's last barrier)
         k = kn; kn = knn; knn = hand_out();
