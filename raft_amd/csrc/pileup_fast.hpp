@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 // read start; if it ends in the first 16 lanes of the row it came in from the previous row.  Rows without
                 // such an end only update the two facts later rows need: is the last slot high, and where did the run that
                 // is open there begin.
-                if (long_runs_only && !tail) {
+                if (long_runs_only && !tail && !piece) {   // (a piece keeps short runs at its edges: they go through the exact scan)
                     const unsigned long long Af = A & ~start_lanes;
                     unsigned long long E = Af;               // E bit i: lanes i-15 .. i are full
                     E &= E << 1; E &= E << 2; E &= E << 4; E &= E << 8;
