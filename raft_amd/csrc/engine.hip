@@ -51,17 +51,17 @@ void launch_general(hipStream_t st, unsigned grid, const PileupArgs &pa)
     hipLaunchKernelGGL((pileup_kernel<256, CAP, MINW, 3, false>), dim3(grid), dim3(256), 0, st, pa);
 }
 
-template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots>
+template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, bool EXTRA = false>
 void launch_fast(hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
     constexpr int S4 = SLOTS % 4 == 0 ? SLOTS : 4;   // four sorted runs need a multiple of four slots
     const size_t dyn = 0;
     if (n_seg <= 1)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG, EXTRA>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else if (n_seg == 2)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG, EXTRA>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG, EXTRA>), dim3(grid), dim3(256), dyn, st, cuts, pa);
 }
 
 // RAFT_PRINT_OCCUPANCY=1: what the runtime thinks of the pileup kernels (registers, LDS, resident workgroups per CU)
@@ -670,10 +670,18 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
         default: launch_fast<7936, 4, true, 6>(st, pgrid, pa.n_seg, cuts, pa); break;
         }
         HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-        launch_general<6144, 5>(c->side_stream, sgrid, ps);
+        if (recut) {
+            // the tiles that did not fit as they are, re-cut by tile_desc_kernel: the same kernel, its other instantiation
+            ps.slow_list = nullptr; ps.tile_counter = &ctrl->slow_next; ps.n_extra = &ctrl->n_extra; ps.tile_batch = 1;
+            switch (c->variant) {
+            case 0: launch_fast<7936, 4, false, 6, true>(c->side_stream, pgrid, pa.n_seg, cuts, ps); break;
+            case 2: launch_fast<6144, 5, false, 4, true>(c->side_stream, pgrid, pa.n_seg, cuts, ps); break;
+            default: launch_fast<7936, 4, false, 6, true>(c->side_stream, pgrid, pa.n_seg, cuts, ps); break;
+            }
+        } else launch_general<6144, 5>(c->side_stream, sgrid, ps);
         HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
-        n_sum_blocks = pgrid + sgrid;
+        n_sum_blocks = pgrid + (recut ? pgrid : sgrid);
     } else {
         launch_general<6144, 5>(st, pgrid, pa);
     }
@@ -1412,9 +1420,9 @@ int raft_hip_selftest(int device_id)
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return RAFT_HIP_ERR_DEVICE;
     if (hipSetDevice(device_id) != hipSuccess) return RAFT_HIP_ERR_DEVICE;
     if (getenv("RAFT_PRINT_OCCUPANCY")) {
-        print_occupancy("fast<7936,2,6,4>", pileup_fast_kernel<7936, 2, 6, 4, false>);
-        print_occupancy("fast<7936,1,6,4>", pileup_fast_kernel<7936, 1, 6, 4, false>);
-        print_occupancy("fast<6144,2,4,5>", pileup_fast_kernel<6144, 2, 4, 5, false>);
+        print_occupancy("fast<7936,2,6,4>", pileup_fast_kernel<7936, 2, 6, 4, false, false>);
+        print_occupancy("fast<7936,1,6,4>", pileup_fast_kernel<7936, 1, 6, 4, false, false>);
+        print_occupancy("fast<6144,2,4,5>", pileup_fast_kernel<6144, 2, 4, 5, false, false>);
         print_occupancy("general<256,6144,5,3>", pileup_kernel<256, 6144, 5, 3, false>);
     }
     const int n = 256;

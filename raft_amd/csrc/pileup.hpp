@@ -921,19 +921,24 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
             if (r >= d.r_hi) return t_hi[s];
             return lower_bound_rid(iv_rid, t_lo[s], t_hi[s], r);
         };
+        // (the interval bounds of a read are searched once: the pieces of a long read share them, and a group begins where
+        // the entry before it ended)
+        int32_t ib[kMaxSeg], ie[kMaxSeg];
+        auto bounds_of = [&](int r, int32_t (&out)[kMaxSeg]) {
+#pragma unroll
+            for (int s = 0; s < kMaxSeg; ++s) out[s] = s < sb.n_seg ? (int32_t)bound(s, r) : 0;
+        };
         auto emit = [&](int slot, int r_a, int r_b, long long g_a, long long g_b, int flags) {
             TileCut b{}, e{};
             b.r_lo = r_a; b.flags = flags; b.g_lo = g_a;
             e.r_lo = r_b; e.flags = 0; e.g_lo = g_b;
 #pragma unroll
-            for (int s = 0; s < kMaxSeg; ++s) {
-                b.iv_lo[s] = s < sb.n_seg ? (int32_t)bound(s, r_a) : 0;
-                e.iv_lo[s] = s < sb.n_seg ? (int32_t)bound(s, r_b) : 0;
-            }
+            for (int s = 0; s < kMaxSeg; ++s) { b.iv_lo[s] = ib[s]; e.iv_lo[s] = ie[s]; }
             extra[2 * (long long)slot] = b; extra[2 * (long long)slot + 1] = e;
         };
         int r = d.r_lo;
         long long g_r = d.g_lo;                            // cov_off[r]
+        bounds_of(r, ib);
         while (r < d.r_hi) {
             const long long g_n = (r + 1 == d.r_hi) ? d.g_hi : cov_off[r + 1];
             const long long nb = g_n - g_r;
@@ -941,6 +946,7 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                 const int P = (int)((nb + piece_w - 1) / piece_w);
                 const int base = atomicAdd(n_extra, P);
                 if (base + P > extra_cap) { atomicOr(err_flags, kErrExtra); break; }
+                bounds_of(r + 1, ie);
                 for (int q = 0; q < P; ++q) {
                     const long long w0 = (long long)q * piece_w, w1 = min(nb, w0 + piece_w);
                     emit(base + q, r, r + 1, g_r + w0, g_r + w1, kCutFast | kCutPiece);
@@ -957,10 +963,13 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                 {   // (also a group of reads without windows: its records still have to be looked at)
                     const int slot = atomicAdd(n_extra, 1);
                     if (slot + 1 > extra_cap) { atomicOr(err_flags, kErrExtra); break; }
+                    bounds_of(r2, ie);
                     emit(slot, r, r2, g_r, g2, kCutFast);
                 }
                 r = r2; g_r = g2;
             }
+#pragma unroll
+            for (int s = 0; s < kMaxSeg; ++s) ib[s] = ie[s];   // the next entry begins where this one ended
         }
     }
     // tiles left to the general kernel: one append per wave (one atomic per tile on the same word serialises)

@@ -134,7 +134,10 @@ __device__ __forceinline__ void emit_piece_run(const PileupArgs &a, const FastTa
     a.raw_e[idx] = start + (sT - sS) * a.reso;
 }
 
-template <int CAP, int NSEG, int U, int MINW, bool DIAG>
+// EXTRA = false: the regular tiles (bounded by adjacent cuts).  EXTRA = true: the same kernel over the extra tiles that
+// tile_desc_kernel cut out of what does not fit (explicit cut pairs; intervals clipped to the tile; pieces of long reads):
+// an instantiation of its own, so that the regular tiles' code carries none of that.
+template <int CAP, int NSEG, int U, int MINW, bool DIAG, bool EXTRA>
 __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *__restrict__ cuts, PileupArgs a)
 {
     constexpr int THREADS = 256, NW = 4, ITER = U / NSEG;
@@ -151,11 +154,11 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     // tile indices fit 32 bits (the host checks n_tiles * 18 < 2^31): scalar compares, half the registers
     const int nb = (int)gridDim.x;
     // regular tiles 0 .. n_reg - 1 are bounded by adjacent cuts; extra tiles (tile_desc_kernel re-cut what does not fit:
-    // PileupArgs::n_extra) follow as explicit (begin, end) pairs behind the closing boundary
+    // PileupArgs::n_extra) follow as explicit (begin, end) pairs behind the closing boundary, numbered from 0 here
     const int n_reg = (int)a.n_tiles;
-    const int n_tiles = n_reg + (a.n_extra ? uni(*a.n_extra) : 0);
+    const int n_tiles = EXTRA ? uni(*a.n_extra) : n_reg;
     const int last_cut = n_tiles - 1;            // (tile index: the word index below maps it)
-    auto cut_of = [&](int t) -> int { return t < n_reg ? t : n_reg + 1 + 2 * (t - n_reg); };   // index of tile t's first cut
+    auto cut_of = [&](int t) -> int { return EXTRA ? n_reg + 1 + 2 * t : t; };   // index of tile t's first cut
     // runs are kept from ceil(repeat_length / reso) windows on; from 68 windows on, pass B can tell by whole lanes
     // of four windows that a row ends no such run (see there)
     const bool long_runs_only = ((long long)a.repeat_length + a.reso - 1) / a.reso >= 68;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 const bool valid = jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
                 const bool over = last1 > first && last1 > nb_r;                   // repeat.hpp:69-72 writes past its vector
                 // (clipped to the tile's slots: a no-op for tiles of whole reads, the cut for a piece of a long read)
-                const int pf = max(b0 + first, off0), pl1 = min(b0 + min(last1, nb_r), t_end);
+                const int pf = EXTRA ? max(b0 + first, off0) : b0 + first, pl1 = EXTRA ? min(b0 + min(last1, nb_r), t_end) : b0 + min(last1, nb_r);
                 bad_any |= valid && (!sign_ok || (pos && over));
                 bad_order |= !valid;             // a record of a read outside this tile (see kErrOrder in pileup.hpp)
                 if (valid && sign_ok && pos && pf < pl1) {
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             // repeat.hpp:111-112); also used to find the owner of a parked run
             const int ro0 = (lane < nr) ? tb.roff[lane] : 0x7fffffff;
             const int ro1 = (lane + 64 < nr) ? tb.roff[lane + 64] : 0x7fffffff;
-            const int piece = cur.piece;
+            const int piece = EXTRA ? cur.piece : 0;
             auto park = [&](int sS, int sT) {    // wave-uniform arguments
                 // repeat.hpp:125,150 -- except that a run touching an edge of a PIECE of a long read may continue in the
                 // neighbouring piece: it is kept whatever its length and judged when finalize has joined the pieces
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
         RAFT_STAMP(7);
         if (DIAG && tid == 0 && a.dbg) {
             sm.stamps[10] = __builtin_amdgcn_s_memrealtime();
-            if (k < n_reg) for (int i = 0; i < 16; ++i) a.dbg[(long long)k * 16 + i] = sm.stamps[i];
+            if (!EXTRA) for (int i = 0; i < 16; ++i) a.dbg[(long long)k * 16 + i] = sm.stamps[i];
         }
         if (drew) next_base = uni(sm.next_tile);     // (written before this iteration's last barrier)
         k = kn; kn = knn; knn = hand_out();
