@@ -512,6 +512,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     long long extra_cap = 0;
     if (recut) {
         extra_cap = n_tiles + B / pv.cap + N / 8 + 1024;
+        if (const char *ec = getenv("RAFT_EXTRA_CAP")) extra_cap = std::max(0, atoi(ec));   // (tests: force the overflow fallback)
         if ((n_tiles + 1 + 2 * extra_cap) * 8 >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;   // cut words are indexed with 32 bits
     }
     if (pv.fast) {

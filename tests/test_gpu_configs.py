@@ -355,3 +355,73 @@ def test_misspeculated_pass_is_redone():
         s = eng.finish()
         assert_same_result(engine_result(eng, s), want, f"non-symmetric, pass {rep}")
     eng.close()
+
+
+# ---- tiles re-cut for the fast kernel (groups of reads, pieces of long reads) ----------------------------------------------
+
+def _long_read_set(seed):
+    """Short reads with a few reads far longer than the LDS window between them (default reso: > 397 kb), coverage thin in
+    places and thick in others so that runs begin, end and cross piece boundaries; hundreds of tiny reads in a row."""
+    rng = np.random.default_rng(seed)
+    rl = rng.integers(5000, 40000, 260).astype(np.int32)
+    rl[[3, 90, 91, 200]] = [1_450_000, 820_000, 2_100_000, 400_050]
+    rl = np.concatenate([rl, rng.integers(0, 300, 400).astype(np.int32), rng.integers(5000, 40000, 30).astype(np.int32)])
+    parts = []
+    for _ in range(2):
+        q = np.sort(np.concatenate([rng.integers(0, len(rl), 20000), np.repeat([3, 90, 91, 200], 4000)])).astype(np.int32)
+        parts.append(q)
+    qid = np.concatenate(parts)
+    ln = rl[qid].astype(np.int64)
+    a = (rng.random(len(qid)) * ln).astype(np.int64)
+    b = np.minimum(ln, a + 1 + (rng.random(len(qid)) * np.minimum(ln, 60000)).astype(np.int64))
+    return rl, qid, a.astype(np.int32), b.astype(np.int32)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["default", "extra_cap_0", "no_recut", "variant2"])
+def test_recut_tiles_and_pieces(seed, mode, monkeypatch):
+    """Tiles that do not fit the fast kernel are re-cut into groups and pieces (pileup.hpp tile_desc_kernel); with no room
+    for extra tiles the pass falls back to the general kernel (kErrExtra); RAFT_NO_RECUT keeps the round-1 split.  All
+    four must equal the oracle, incl. runs crossing piece boundaries and the repeat-length total."""
+    from raft_amd import engine
+    if mode == "extra_cap_0":
+        monkeypatch.setenv("RAFT_EXTRA_CAP", "0")
+    if mode == "no_recut":
+        monkeypatch.setenv("RAFT_NO_RECUT", "1")
+    rl, qid, a, b = _long_read_set(seed)
+    for p in (RaftParams(est_cov=14, symmetric_mode=1), RaftParams(est_cov=9, reso=37, repeat_length=3000, interval_length=3000,
+                                                                  read_length=9000, flanking_length=5000, symmetric_mode=1)):
+        want = oracle_run(RaftParams(**dict(p.__dict__, symmetric_mode=-1)), rl, qid, a, b, qid, a, b)
+        want["symmetric"] = 1
+        assert want["rep_s"].size > 20
+        eng = engine.Engine(p, device=0)
+        try:
+            eng.set_tuning(0, False, 2 if mode == "variant2" else -1)
+            eng.run_host(rl, qid, a, b, None, None, None)
+            s = eng.finish()
+            assert_same_result(engine_result(eng, s), want, f"seed {seed} {mode} reso {p.reso}")
+        finally:
+            eng.close()
+
+
+def test_groups_of_reads_without_windows_are_still_checked():
+    """A tile of nothing but zero-length reads: its (valid, empty) records pass, a record that needs a window is the
+    COORD error the oracle reports."""
+    from raft_amd import engine
+    from raft_testlib import OracleError
+    rl = np.concatenate([np.full(300, 0, np.int32), np.array([5000, 0, 0, 7000], np.int32)])
+    qid = np.sort(np.concatenate([np.arange(300), [300, 303, 303]])).astype(np.int32)
+    s_ = np.zeros(len(qid), np.int32); e_ = np.zeros(len(qid), np.int32)
+    e_[qid == 300] = 5000; e_[qid == 303] = 6000
+    p = RaftParams(est_cov=1, symmetric_mode=1)
+    want = oracle_run(RaftParams(est_cov=1), rl, qid, s_, e_, qid, s_, e_); want["symmetric"] = 1
+    eng = engine.Engine(p, device=0)
+    eng.run_host(rl, qid, s_, e_, None, None, None)
+    assert_same_result(engine_result(eng, eng.finish()), want, "zero-length reads")
+    bad = e_.copy(); bad[7] = 3                          # an interval on a read that has no window
+    with pytest.raises(OracleError):
+        oracle_run(RaftParams(est_cov=1), rl, qid, s_, bad, qid, s_, bad)
+    with pytest.raises(engine.RaftError) as err:
+        eng.run_host(rl, qid, s_, bad, None, None, None); eng.finish()
+    assert err.value.code == engine.ERR_COORD
+    eng.close()
