@@ -429,6 +429,9 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     c->sum.n_reads = n_reads; c->sum.n_records = n_rec; c->sum.high_cov = c->high_cov; c->sum.error_index = -1;
     const long long N = n_reads;
 
+    const PileVariant &pv = kVariants[c->variant];
+    // tiles that do not fit the fast kernel are re-cut for it (pileup.hpp tile_desc_kernel) unless told otherwise
+    const bool recut = pv.fast && !c->no_recut && getenv("RAFT_NO_RECUT") == nullptr;
     HIP_TRY(c, hipEventRecord(c->ev_pass0, st));
     HIP_TRY(c, c->ctrl.ensure(sizeof(Ctrl)));
     Ctrl *ctrl = c->ctrl.as<Ctrl>();
@@ -456,9 +459,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
         hipStream_t gst = c->side_stream;
         HIP_TRY(c, hipEventRecord(c->ev_ifork, st));                        // (the control block is clear)
         HIP_TRY(c, hipStreamWaitEvent(gst, c->ev_ifork, 0));
-        const PileVariant &pv0 = kVariants[c->variant];
-        const bool recut0 = pv0.fast && !c->no_recut && getenv("RAFT_NO_RECUT") == nullptr;
-        ReadPrepLoader ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, recut0 ? pv0.cap : INT32_MAX, pv0.cap,
+        ReadPrepLoader ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, recut ? pv.cap : INT32_MAX, pv.cap,
                           &ctrl->err_flags, &ctrl->err_index};
         ScanOut<3> so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), c->cutcap_off.as<long long>()}};
         exclusive_scan<ReadPrepLoader, 3>(gst, ld, N, c->scan_tmp.as<long long>(), so, &scan_totals);
@@ -490,7 +491,6 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     c->sum.n_bins = B; c->sum.total_windows = B;
     c->cap_rep = RU; c->cap_cut = CU;
     if (RU >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;   // reserved raw-repeat slots are indexed with 32 bits in LDS
-    const PileVariant &pv = kVariants[c->variant];
     // Tile quantum: a tile's windows are Q minus the overhang of the previous tile's last read plus that of its own, so
     // the room left above Q has to follow the read lengths or most tiles of a long-read set overflow the LDS window
     // (measured optima, mean windows per read -> room: 600 -> 1.7 k, 1200 -> 2.7 k, 3000 -> 3.9 k of a 7936-window tile).
@@ -507,8 +507,6 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     HIP_TRY(c, c->tile_first.ensure((size_t)(n_tiles + 1) * 4));
     HIP_TRY(c, c->tile_desc.ensure((size_t)n_tiles * sizeof(TileDesc)));
     // extra tiles (tiles re-cut for the fast kernel: groups of whole reads, pieces of long reads) follow the regular cuts
-    static const bool no_recut_env = getenv("RAFT_NO_RECUT") != nullptr;
-    const bool recut = pv.fast && !c->no_recut && !no_recut_env;
     long long extra_cap = 0;
     if (recut) {
         extra_cap = n_tiles + B / pv.cap + N / 8 + 1024;
