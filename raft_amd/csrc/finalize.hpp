@@ -214,10 +214,9 @@ __device__ __forceinline__ int walk_cuts(int len, int L, const int32_t *s, const
     return kept;
 }
 
-__global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
+// one read: order (and, for a long read, join) its repeats; count its kept markers and fragments
+__device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, int r, int &n_out, int &nF_out, int &nf_out)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_reads) return;
     int n = a.rep_cnt[r];
     const long long base = a.rep_res_off[r];
     if (n > 1) sort_repeats(a.raw_key + base, a.raw_s + base, a.raw_e + base, n);
@@ -270,23 +269,26 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
     if (nF > a.div + 1) nf = (nF - 1 + a.div - 1) / a.div;
     a.cut_cnt[r] = nF;
     a.frag_cnt[r] = nf;
+    n_out = n; nF_out = nF; nf_out = nf;
+}
+
+__global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    int n, nF, nf;
+    finalize_count_one(a, r, n, nF, nf);
 }
 
 // Compact repeats and the fragments of every read.  The cut points themselves (chop.hpp's final_stars, 4 B per
 // marker: 0.4 GB on the human-scale set) are neither stored nor walked here: fragment j begins at the kept marker
 // with index (j-1)*div and ends at the one with index j*div, the first marker is 0 and the last is the read length.
 // finalize_cuts_kernel materialises them when a caller asks for them.
-__global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
+__device__ __forceinline__ void finalize_fill_one(const FinalizeArgs &a, int r, long long ro, long long fo, int n, int nF)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_reads) return;
-    const int n = a.rep_cnt[r];
     const long long base = a.rep_res_off[r];
-    const long long ro = a.rep_off[r];
     for (int i = 0; i < n; ++i) { a.rep_s[ro + i] = a.raw_s[base + i]; a.rep_e[ro + i] = a.raw_e[base + i]; }
     const int len = a.read_len[r];
-    const int nF = a.cut_cnt[r];
-    const long long fo = a.frag_off[r];
     if (nF <= a.div + 1) {                        // chop.hpp:250-267: the read is kept whole
         a.frag_read[fo] = r; a.frag_begin[fo] = 0; a.frag_end[fo] = len;
         return;
@@ -322,6 +324,86 @@ __global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
         a.frag_read[fo + j] = r; a.frag_begin[fo + j] = begin;
     }
     a.frag_end[fo + nf - 1] = len;                // the last kept marker is the read's end
+}
+
+__global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    finalize_fill_one(a, r, a.rep_off[r], a.frag_off[r], a.rep_cnt[r], a.cut_cnt[r]);
+}
+
+// ---- count, offsets and fill in ONE launch: a single-pass scan with decoupled look-back -----------------------------
+// finalize_count -> three-launch scan -> finalize_fill is five dependent launches over the reads (0.18 ms at human scale,
+// most of it waiting on a handful of dependent loads per thread).  Here a workgroup of 256 reads counts, scans its three
+// counts, learns what all earlier workgroups add up to by looking back over their published sums, writes the offsets and
+// fills -- with counts and offsets still in registers.  Workgroups take their position from a ticket counter, so one only
+// ever waits for workgroups that are already running.  state[b * 3 + k]: bits 63:62 = 0 nothing yet, 1 the workgroup's own
+// sum of count k, 2 the sum of all workgroups up to and including b; bits 61:0 the value (one 64-bit word: no fence needed
+// between flag and value).  Waves 0..2 look back for k = 0..2, 64 predecessors per step.
+__global__ __launch_bounds__(256) void finalize_fused_kernel(FinalizeArgs a, unsigned long long *state, int32_t *ticket,
+                                                             long long *rep_off, long long *cut_off, long long *frag_off)
+{
+    __shared__ int s_b;
+    __shared__ int s_wsum[3][4];
+    __shared__ long long s_prefix[3];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_b = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int b = s_b;
+    const int r = b * 256 + tid;
+    const bool live = r < a.n_reads;
+    int v[3] = {0, 0, 0};
+    if (live) finalize_count_one(a, r, v[0], v[1], v[2]);
+    int excl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int incl = wave_incl_scan_add(v[k]);
+        excl[k] = incl - v[k];
+        if (lane == 63) s_wsum[k][wid] = incl;
+    }
+    __syncthreads();
+    int tot[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int x = s_wsum[k][w]; if (w < wid) before += x; all += x; }
+        excl[k] += before; tot[k] = all;
+    }
+    if (wid < 3) {
+        const int k = wid;
+        const unsigned long long mine = (unsigned long long)(k == 0 ? tot[0] : k == 1 ? tot[1] : tot[2]);
+        unsigned long long *word = state + (long long)b * 3 + k;
+        if (lane == 0) __hip_atomic_store(word, ((b == 0 ? 2ull : 1ull) << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long prefix = 0;
+        for (int p = b - 1; p >= 0;) {                // predecessors p, p-1, .., p-63: one per lane
+            const int idx = p - lane;
+            unsigned long long w = 2ull << 62;         // before the first workgroup: everything summed up, nothing
+            if (idx >= 0) {
+                do w = __hip_atomic_load(state + (long long)idx * 3 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while ((w >> 62) == 0);
+            }
+            const unsigned long long done = __ballot((w >> 62) == 2);
+            const unsigned long long val = w & ((1ull << 62) - 1);
+            const int stop = done ? (int)__builtin_ctzll(done) : 64;      // the nearest predecessor with a full prefix
+            const long long part = wave_reduce_add64(lane <= stop ? (long long)val : 0);
+            prefix += (unsigned long long)part;
+            if (done) break;
+            p -= 64;
+        }
+        if (lane == 0) {
+            if (b > 0) __hip_atomic_store(word, (2ull << 62) | (prefix + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix[k] = (long long)prefix;
+        }
+    }
+    __syncthreads();
+    const long long ro = s_prefix[0] + excl[0], co = s_prefix[1] + excl[1], fo = s_prefix[2] + excl[2];
+    if (live) {
+        rep_off[r] = ro; cut_off[r] = co; frag_off[r] = fo;
+        if (r == a.n_reads - 1) { rep_off[r + 1] = ro + v[0]; cut_off[r + 1] = co + v[1]; frag_off[r + 1] = fo + v[2]; }
+        finalize_fill_one(a, r, ro, fo, v[0], v[1]);
+    }
 }
 
 // cut points of every read (final_stars), on demand
