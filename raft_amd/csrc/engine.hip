@@ -82,7 +82,7 @@ struct Ctrl {                         // device control block, cleared every pas
     long long err_index;              // (the first 16 bytes are what the pass's host wait reads back)
     int32_t next_tile;                // pileup_fast_kernel's tile hand-out counter
     int32_t slow_next;                // the general kernel's item hand-out counter (list mode)
-    int32_t n_extra, fin_ticket;      // extra tiles tile_desc_kernel cut out of the tiles that do not fit the fast kernel
+    int32_t n_extra, pad_extra;       // extra tiles tile_desc_kernel cut out of the tiles that do not fit the fast kernel
     unsigned long long totals[4];     // coverage, repeat bp, read length
     InspectOut insp;
     long long out_totals[4];          // rep / cut / frag totals land here via the scan
@@ -191,7 +191,6 @@ struct raft_hip_ctx {
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
-    DevBuf lookback;                  // finalize_fused_kernel: published sums per workgroup
     DevBuf samples;                   // up to kSamples + 2 read ids at evenly spaced records (guess_runs_kernel): coarse index
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
     DevBuf dbg;                       // diagnostic variant only
@@ -340,7 +339,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->dbg, &c->samples, &c->lookback, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->samples, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -700,23 +699,15 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     fa.long_windows = recut ? pv.cap : INT32_MAX; fa.reso = c->prm.reso; fa.repeat_length = c->prm.repeat_length;
     fa.flank = c->prm.flanking_length; fa.rep_cnt_rw = c->rep_cnt.as<int32_t>(); fa.total_repeat = &ctrl->totals[1];
     if (N > 0) {
-        // count, offsets and fill in one launch (single-pass scan with decoupled look-back, finalize.hpp); RAFT_FINALIZE_CHAIN=1
-        // keeps the five-launch chain (count, three-launch scan, fill) for A/B.  (Also measured and dropped: count and fill
-        // riding in the three-launch scan's first / last pass -- that scan walks eight consecutive reads per thread, and the
-        // fill's stores from that shape took 320 us against 65 us for one read per thread.)
+        // (Measured and dropped: count and fill riding in the scan's first / last pass -- the scan walks eight consecutive
+        // reads per thread, and the fill's stores from that shape took 320 us against 65 us; and a single-launch version
+        // with decoupled look-back, finalize.hpp.)
         const unsigned rgrid = (unsigned)((N + 255) / 256);
-        if (getenv("RAFT_FINALIZE_CHAIN") == nullptr) {
-            HIP_TRY(c, c->lookback.ensure((size_t)rgrid * 3 * 8));
-            HIP_TRY(c, hipMemsetAsync(c->lookback.p, 0, (size_t)rgrid * 3 * 8, st));
-            hipLaunchKernelGGL(finalize_fused_kernel, dim3(rgrid), dim3(256), 0, st, fa, c->lookback.as<unsigned long long>(),
-                               &ctrl->fin_ticket, c->rep_off.as<long long>(), c->cut_off.as<long long>(), c->frag_off.as<long long>());
-        } else {
-            hipLaunchKernelGGL(finalize_count_kernel, dim3(rgrid), dim3(256), 0, st, fa);
-            CountLoader<3> ld{{c->rep_cnt.as<int32_t>(), c->cut_cnt.as<int32_t>(), c->frag_cnt.as<int32_t>()}};
-            ScanOut<3> so{{c->rep_off.as<long long>(), c->cut_off.as<long long>(), c->frag_off.as<long long>()}};
-            exclusive_scan<CountLoader<3>, 3>(st, ld, N, c->scan_tmp.as<long long>(), so);
-            hipLaunchKernelGGL(finalize_fill_kernel, dim3(rgrid), dim3(256), 0, st, fa);
-        }
+        hipLaunchKernelGGL(finalize_count_kernel, dim3(rgrid), dim3(256), 0, st, fa);
+        CountLoader<3> ld{{c->rep_cnt.as<int32_t>(), c->cut_cnt.as<int32_t>(), c->frag_cnt.as<int32_t>()}};
+        ScanOut<3> so{{c->rep_off.as<long long>(), c->cut_off.as<long long>(), c->frag_off.as<long long>()}};
+        exclusive_scan<CountLoader<3>, 3>(st, ld, N, c->scan_tmp.as<long long>(), so);
+        hipLaunchKernelGGL(finalize_fill_kernel, dim3(rgrid), dim3(256), 0, st, fa);
     } else {
         HIP_TRY(c, hipMemsetAsync(c->rep_off.p, 0, 8, st));
         HIP_TRY(c, hipMemsetAsync(c->cut_off.p, 0, 8, st));

@@ -333,78 +333,10 @@ __global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
     finalize_fill_one(a, r, a.rep_off[r], a.frag_off[r], a.rep_cnt[r], a.cut_cnt[r]);
 }
 
-// ---- count, offsets and fill in ONE launch: a single-pass scan with decoupled look-back -----------------------------
-// finalize_count -> three-launch scan -> finalize_fill is five dependent launches over the reads (0.18 ms at human scale,
-// most of it waiting on a handful of dependent loads per thread).  Here a workgroup of 256 reads counts, scans its three
-// counts, learns what all earlier workgroups add up to by looking back over their published sums, writes the offsets and
-// fills -- with counts and offsets still in registers.  Workgroups take their position from a ticket counter, so one only
-// ever waits for workgroups that are already running.  state[b * 3 + k]: bits 63:62 = 0 nothing yet, 1 the workgroup's own
-// sum of count k, 2 the sum of all workgroups up to and including b; bits 61:0 the value (one 64-bit word: no fence needed
-// between flag and value).  Waves 0..2 look back for k = 0..2, 64 predecessors per step.
-__global__ __launch_bounds__(256) void finalize_fused_kernel(FinalizeArgs a, unsigned long long *state, int32_t *ticket,
-                                                             long long *rep_off, long long *cut_off, long long *frag_off)
-{
-    __shared__ int s_b;
-    __shared__ int s_wsum[3][4];
-    __shared__ long long s_prefix[3];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) s_b = atomicAdd(ticket, 1);
-    __syncthreads();
-    const int b = s_b;
-    const int r = b * 256 + tid;
-    const bool live = r < a.n_reads;
-    int v[3] = {0, 0, 0};
-    if (live) finalize_count_one(a, r, v[0], v[1], v[2]);
-    int excl[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int incl = wave_incl_scan_add(v[k]);
-        excl[k] = incl - v[k];
-        if (lane == 63) s_wsum[k][wid] = incl;
-    }
-    __syncthreads();
-    int tot[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        int before = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { const int x = s_wsum[k][w]; if (w < wid) before += x; all += x; }
-        excl[k] += before; tot[k] = all;
-    }
-    if (wid < 3) {
-        const int k = wid;
-        const unsigned long long mine = (unsigned long long)(k == 0 ? tot[0] : k == 1 ? tot[1] : tot[2]);
-        unsigned long long *word = state + (long long)b * 3 + k;
-        if (lane == 0) __hip_atomic_store(word, ((b == 0 ? 2ull : 1ull) << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long prefix = 0;
-        for (int p = b - 1; p >= 0;) {                // predecessors p, p-1, .., p-63: one per lane
-            const int idx = p - lane;
-            unsigned long long w = 2ull << 62;         // before the first workgroup: everything summed up, nothing
-            if (idx >= 0) {
-                do w = __hip_atomic_load(state + (long long)idx * 3 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while ((w >> 62) == 0);
-            }
-            const unsigned long long done = __ballot((w >> 62) == 2);
-            const unsigned long long val = w & ((1ull << 62) - 1);
-            const int stop = done ? (int)__builtin_ctzll(done) : 64;      // the nearest predecessor with a full prefix
-            const long long part = wave_reduce_add64(lane <= stop ? (long long)val : 0);
-            prefix += (unsigned long long)part;
-            if (done) break;
-            p -= 64;
-        }
-        if (lane == 0) {
-            if (b > 0) __hip_atomic_store(word, (2ull << 62) | (prefix + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_prefix[k] = (long long)prefix;
-        }
-    }
-    __syncthreads();
-    const long long ro = s_prefix[0] + excl[0], co = s_prefix[1] + excl[1], fo = s_prefix[2] + excl[2];
-    if (live) {
-        rep_off[r] = ro; cut_off[r] = co; frag_off[r] = fo;
-        if (r == a.n_reads - 1) { rep_off[r + 1] = ro + v[0]; cut_off[r + 1] = co + v[1]; frag_off[r + 1] = fo + v[2]; }
-        finalize_fill_one(a, r, ro, fo, v[0], v[1]);
-    }
-}
+// (Measured and dropped: count, offsets and fill in ONE launch -- a single-pass scan with decoupled look-back over
+// per-workgroup sums, 256 or 1024 reads per workgroup.  Bit-exact on the whole suite, but 0.07-0.17 ms SLOWER than the
+// five-launch chain on the human-scale set: every resident workgroup reaches its look-back at about the same time and
+// walks over all the others, and the fill cannot start before that.)
 
 // cut points of every read (final_stars), on demand
 __global__ __launch_bounds__(256) void finalize_cuts_kernel(FinalizeArgs a)
