@@ -35,10 +35,13 @@ while time.time() < t_end:
     if o.n_rec >= (1 << 29) - 1:
         seed += 1
         continue
-    for variant in (1, 0, 2):
+    sym_set = kw.get("symmetric", True)
+    # 1 = the general kernel alone (independent code path); 0 / 2 = fast kernel, tiles that do not fit re-cut for it;
+    # 10 = configuration 0 with the symmetric flag handed over (the pass verifies the sorted runs in its kernels)
+    for variant in (1, 0, 2) + ((10,) if sym_set else ()):
         print("  variant", variant, flush=True)
-        eng = engine.Engine(p, device=0)
-        eng.set_tuning(0, False, variant)
+        eng = engine.Engine(RaftParams(**dict(p.__dict__, symmetric_mode=1)) if variant == 10 else p, device=0)
+        eng.set_tuning(0, False, variant % 10)
         try:
             eng.run_device(*cols); s = eng.finish()
         except engine.RaftError as e:
@@ -57,4 +60,4 @@ while time.time() < t_end:
                 sys.exit(1)
     n_ok += ref != "skip"
     seed += 1
-print(f"{n_ok} random sets agree across configurations 1, 0, 2 (seeds up to {seed - 1})")
+print(f"{n_ok} random sets agree across configurations 1, 0, 2 and 0 with the symmetric flag handed over (seeds up to {seed - 1})")
