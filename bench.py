@@ -131,19 +131,10 @@ def e2e_leg(args, torch, engine, o, p, n_iter=3):
     assert p.symmetric_mode == -1
     pe = type(p)(**dict(p.__dict__, symmetric_mode=1))
     host = [c.cpu().pin_memory().numpy() for c in (o.read_len, o.qid, o.qs, o.qe)]
-    n_bins = int(((o.read_len.long() + p.reso - 1) // p.reso).sum())
-    n_reads = o.n_reads
-    cap_frag = int((o.read_len.long() // p.interval_length + 2).sum())
-
-    def pinned(n, dt):
-        return torch.empty(max(int(n), 1), dtype=dt, pin_memory=True).numpy()
-    out = {"cov_offset": pinned(n_reads + 1, torch.int64), "cov8": pinned(n_bins, torch.uint8),
-           "exc_index": pinned(1 << 20, torch.int64), "exc_value": pinned(1 << 20, torch.int32),
-           "rep_offset": pinned(n_reads + 1, torch.int64), "rep_s": pinned(n_reads, torch.int32), "rep_e": pinned(n_reads, torch.int32),
-           "frag_offset": pinned(n_reads + 1, torch.int64), "frag_read": pinned(cap_frag, torch.int32),
-           "frag_begin": pinned(cap_frag, torch.int32), "frag_end": pinned(cap_frag, torch.int32)}
     eng = engine.Engine(pe, device=torch.cuda.current_device())
     eng.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+    out = eng.host_output_buffers(host[0], pinned=True)   # sized by the bounds of include/raft_hip.h, from the read lengths
+    out["frag_read"] = torch.empty(out["frag_begin"].size, dtype=torch.int32, pin_memory=True).numpy()
     # (a) chunked: upload, pass and download of consecutive read ranges overlap (raft_hip_run_pipelined)
     ptimes = []
     for it in range(n_iter + 1):
