@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_ABI_VERSION 2
+#define RAFT_HIP_ABI_VERSION 3
 
 /* error codes (0..5 are shared with oracle/raft_oracle.h) */
 enum {
@@ -165,6 +165,13 @@ int  raft_hip_fetch(raft_hip_ctx *ctx, int64_t *cov_offset, int32_t *cov,
 int  raft_hip_fetch_packed(raft_hip_ctx *ctx, int64_t *cov_offset, uint8_t *cov8, int64_t exc_cap, int64_t *exc_index,
                            int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
                            int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end);
+/* The same with the width of the encoding chosen by the caller: width = 1 as above (limit 255), width = 2 -- uint16 per
+ * window, limit 65535 -- for deep sets whose repeats pile up beyond a byte (at 60x with six-copy tandem arrays half of
+ * all windows are at or above 255 and a byte per window has to list them one by one).  cov_packed holds
+ * n_bins * width bytes. */
+int  raft_hip_fetch_packed_w(raft_hip_ctx *ctx, int32_t width, int64_t *cov_offset, void *cov_packed, int64_t exc_cap,
+                             int64_t *exc_index, int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s,
+                             int32_t *rep_e, int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end);
 
 /* Caller-owned host arrays (page-locked for full PCIe rate) that receive the outputs of raft_hip_run_pipelined, with
  * their capacities in elements.  Upper bounds the caller can compute from read_len alone, with W = sum ceil(len/reso)
@@ -177,6 +184,8 @@ typedef struct raft_hip_host_outputs {
     int64_t *exc_index;   int32_t *exc_value; int64_t exc_cap;   int64_t n_exc;
     int64_t *rep_offset;  int32_t *rep_s, *rep_e;               int64_t rep_cap;
     int64_t *frag_offset; int32_t *frag_begin, *frag_end;       int64_t frag_cap;
+    int32_t cov_width;    /* bytes per window of the coverage encoding: 0 or 1 = one (cov8 as declared), 2 = cov8 points
+                             at cov8_cap uint16 codes (limit 65535; see raft_hip_fetch_packed_w) */
 } raft_hip_host_outputs;
 
 /* One end-to-end pass, host memory to host memory: raft_hip_run_host + raft_hip_finish + raft_hip_fetch_packed in one

@@ -69,6 +69,11 @@ int raft_host_unpack_coverage(int64_t n_bins, const uint8_t *cov8, int64_t n_exc
                               const int32_t *exc_value, int32_t *cov);
 int raft_host_write_coverage_packed(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset,
                                     const uint8_t *cov8, int64_t n_exc, const int64_t *exc_index, const int32_t *exc_value);
+/* ... and for either width of the encoding (1: uint8 codes, escape 255; 2: uint16 codes, escape 65535) */
+int raft_host_unpack_coverage_w(int32_t width, int64_t n_bins, const void *cov_packed, int64_t n_exc, const int64_t *exc_index,
+                                const int32_t *exc_value, int32_t *cov);
+int raft_host_write_coverage_packed_w(int32_t width, const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset,
+                                      const void *cov_packed, int64_t n_exc, const int64_t *exc_index, const int32_t *exc_value);
 
 /* writers (CSR arrays as returned by raft_hip_fetch) */
 int raft_host_write_coverage(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset, const int32_t *cov);

@@ -195,7 +195,7 @@ struct raft_hip_ctx {
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
     DevBuf dbg;                       // diagnostic variant only
     DevBuf cov8, exc_idx, exc_val, exc_cnt;   // transfer encoding of cov[] (raft_hip_fetch_packed)
-    bool packed_ready = false;
+    int packed_width = 0;             // width (bytes per window) of the encoding the buffers hold, 0 = none
     long long n_exc = 0, exc_cap = 0;
     long long dbg_tiles = 0;
     void *pinned = nullptr;           // small pinned scratch for readbacks
@@ -420,7 +420,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     if (n_rec >= (1LL << 29)) return RAFT_HIP_ERR_TOO_LARGE;   // interval byte offsets are 32-bit (2 sides per record at most)
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1; c->packed_ready = false;
+    c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1; c->packed_width = 0;
     c->args = {n_reads, d_len, n_rec, {d_qid, d_qs, d_qe, d_tid, d_ts, d_te}};
     static const bool no_verify_env = getenv("RAFT_ALWAYS_INSPECT") != nullptr;   // (A/B measurements)
     const bool spec = verify_in_kernels && !no_verify_env && n_rec > 1 && c->prm.symmetric_mode == 1 && !c->force_bucket;
@@ -864,13 +864,13 @@ int raft_hip_fetch(raft_hip_ctx *c, int64_t *cov_offset, int32_t *cov, int64_t *
     return RAFT_HIP_OK;
 }
 
-// cov[] -> one byte per window + exception list (pack.hpp), on the device, once per pass
-static int pack_coverage(raft_hip_ctx *c)
+// cov[] -> one or two bytes per window + exception list (pack.hpp), on the device, once per pass and width
+static int pack_coverage(raft_hip_ctx *c, int width)
 {
-    if (c->packed_ready) return RAFT_HIP_OK;
+    if (c->packed_width == width) return RAFT_HIP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const long long B = c->sum.n_bins;
-    HIP_TRY(c, c->cov8.ensure((size_t)std::max(B, 1LL)));
+    HIP_TRY(c, c->cov8.ensure((size_t)std::max(B, 1LL) * (size_t)width));
     HIP_TRY(c, c->exc_cnt.ensure(8));
     long long cap = std::max<long long>(c->exc_cap, std::max<long long>(4096, B / 512));
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -880,8 +880,13 @@ static int pack_coverage(raft_hip_ctx *c)
         HIP_TRY(c, hipMemsetAsync(c->exc_cnt.p, 0, 8, c->stream));
         if (B > 0) {
             const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((B / 4 + 1023) / 1024, 256 * 16));
-            PackOut po{c->cov8.as<uint8_t>(), c->exc_cnt.as<unsigned long long>(), cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>()};
-            hipLaunchKernelGGL(pack_cov_kernel, dim3(grid), dim3(256), 0, c->stream, c->cov.as<int32_t>(), B, po);
+            if (width == 1) {
+                PackOut<uint8_t> po{c->cov8.as<uint8_t>(), c->exc_cnt.as<unsigned long long>(), cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>()};
+                hipLaunchKernelGGL(pack_cov_kernel<uint8_t>, dim3(grid), dim3(256), 0, c->stream, c->cov.as<int32_t>(), B, po);
+            } else {
+                PackOut<uint16_t> po{c->cov8.as<uint16_t>(), c->exc_cnt.as<unsigned long long>(), cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>()};
+                hipLaunchKernelGGL(pack_cov_kernel<uint16_t>, dim3(grid), dim3(256), 0, c->stream, c->cov.as<int32_t>(), B, po);
+            }
             HIP_TRY(c, hipGetLastError());
         }
         long long *h = reinterpret_cast<long long *>(c->pinned) + 16;
@@ -889,24 +894,24 @@ static int pack_coverage(raft_hip_ctx *c)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->n_exc = *h;
         if (c->n_exc <= cap) break;
-        cap = c->n_exc;                              // (rare) more windows at or above 255 than the list held: once more
+        cap = c->n_exc;                              // (rare) more windows at or above the limit than the list held: once more
     }
-    c->packed_ready = true;
+    c->packed_width = width;
     return RAFT_HIP_OK;
 }
 
-int raft_hip_fetch_packed(raft_hip_ctx *c, int64_t *cov_offset, uint8_t *cov8, int64_t exc_cap, int64_t *exc_index,
-                          int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
-                          int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end)
+int raft_hip_fetch_packed_w(raft_hip_ctx *c, int32_t width, int64_t *cov_offset, void *cov_packed, int64_t exc_cap, int64_t *exc_index,
+                            int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
+                            int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end)
 {
-    if (!c || !n_exc) return RAFT_HIP_ERR_PARAM;
+    if (!c || !n_exc || (width != 1 && width != 2)) return RAFT_HIP_ERR_PARAM;
     if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
-    { const int rc = pack_coverage(c); if (rc != RAFT_HIP_OK) return rc; }
+    { const int rc = pack_coverage(c, width); if (rc != RAFT_HIP_OK) return rc; }
     *n_exc = c->n_exc;
-    if (c->n_exc > exc_cap && cov8) return RAFT_HIP_ERR_TOO_LARGE;   // *n_exc tells the caller what to provide
+    if (c->n_exc > exc_cap && cov_packed) return RAFT_HIP_ERR_TOO_LARGE;   // *n_exc tells the caller what to provide
     const size_t N1 = (size_t)c->sum.n_reads + 1;
     struct { void *dst; const void *src; size_t bytes; } job[] = {
-        {cov8, c->cov8.p, (size_t)c->sum.n_bins}, {cov_offset, c->cov_off.p, N1 * 8},
+        {cov_packed, c->cov8.p, (size_t)c->sum.n_bins * (size_t)width}, {cov_offset, c->cov_off.p, N1 * 8},
         {exc_index, c->exc_idx.p, (size_t)c->n_exc * 8}, {exc_value, c->exc_val.p, (size_t)c->n_exc * 4},
         {rep_offset, c->rep_off.p, N1 * 8}, {rep_s, c->rep_s.p, (size_t)c->sum.n_repeats * 4},
         {rep_e, c->rep_e.p, (size_t)c->sum.n_repeats * 4}, {frag_offset, c->frag_off.p, N1 * 8},
@@ -923,6 +928,14 @@ int raft_hip_fetch_packed(raft_hip_ctx *c, int64_t *cov_offset, uint8_t *cov8, i
         for (size_t i = 0; i < ex.size(); ++i) { exc_index[i] = ex[i].first; exc_value[i] = ex[i].second; }
     }
     return RAFT_HIP_OK;
+}
+
+int raft_hip_fetch_packed(raft_hip_ctx *c, int64_t *cov_offset, uint8_t *cov8, int64_t exc_cap, int64_t *exc_index,
+                          int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
+                          int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end)
+{
+    return raft_hip_fetch_packed_w(c, 1, cov_offset, cov8, exc_cap, exc_index, exc_value, n_exc, rep_offset, rep_s, rep_e, frag_offset,
+                                   frag_read, frag_begin, frag_end);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1009,8 +1022,8 @@ static int run_monolithic_to_host(raft_hip_ctx *c, int32_t n_reads, const int32_
     if (rc != RAFT_HIP_OK) return rc;
     if (s.n_bins > o->cov8_cap || s.n_repeats > o->rep_cap || s.n_fragments > o->frag_cap) return RAFT_HIP_ERR_TOO_LARGE;
     int64_t n_exc = 0;
-    rc = raft_hip_fetch_packed(c, o->cov_offset, o->cov8, o->exc_cap, o->exc_index, o->exc_value, &n_exc, o->rep_offset, o->rep_s,
-                               o->rep_e, o->frag_offset, nullptr, o->frag_begin, o->frag_end);
+    rc = raft_hip_fetch_packed_w(c, o->cov_width == 2 ? 2 : 1, o->cov_offset, o->cov8, o->exc_cap, o->exc_index, o->exc_value, &n_exc,
+                                 o->rep_offset, o->rep_s, o->rep_e, o->frag_offset, nullptr, o->frag_begin, o->frag_end);
     o->n_exc = n_exc;
     return rc;
 }
@@ -1079,6 +1092,8 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
     if (n_rec > 0 && (!qid || !qs || !qe)) return RAFT_HIP_ERR_PARAM;
     if (!o->cov_offset || !o->rep_offset || !o->frag_offset) return RAFT_HIP_ERR_PARAM;
     o->n_exc = 0;
+    if (o->cov_width != 0 && o->cov_width != 1 && o->cov_width != 2) return RAFT_HIP_ERR_PARAM;
+    const int cov_width = o->cov_width == 2 ? 2 : 1;   // bytes per window of the coverage's transfer encoding
     long long seg[kMaxSeg + 1];
     int n_seg = -1;
     // chunking needs: the symmetric flag asserted, enough work to split, a record stream of at most kMaxSeg sorted runs
@@ -1260,7 +1275,7 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
                     goto out;
                 }
                 if (rc != RAFT_HIP_OK) { fail(rc, l->last_error); goto out; }
-                rc = pack_coverage(l);
+                rc = pack_coverage(l, cov_width);
                 if (rc != RAFT_HIP_OK) { fail(rc, l->last_error); goto out; }
                 stamp(k, "packed");
             }
@@ -1293,7 +1308,7 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
                 add_base(l->cov_off, n1, b_bins); add_base(l->rep_off, n1, b_rep - J.rep0); add_base(l->frag_off, n1, b_frag - J.frag0);
                 add_base(l->exc_idx, cr.n_exc, b_bins);
                 struct { void *dst; const void *src; size_t bytes; } job[] = {
-                    {o->cov8 ? o->cov8 + b_bins : nullptr, l->cov8.p, (size_t)cr.n_bins},
+                    {o->cov8 ? o->cov8 + b_bins * cov_width : nullptr, l->cov8.p, (size_t)cr.n_bins * (size_t)cov_width},
                     {o->cov_offset + cp.r0, l->cov_off.p, (size_t)n1 * 8},
                     {o->exc_index ? o->exc_index + b_exc : nullptr, l->exc_idx.p, (size_t)cr.n_exc * 8},
                     {o->exc_value ? o->exc_value + b_exc : nullptr, l->exc_val.p, (size_t)cr.n_exc * 4},

@@ -23,7 +23,7 @@ EXPORTS = (
     "raft_hip_abi_version", "raft_hip_strerror", "raft_hip_last_error", "raft_hip_create", "raft_hip_destroy",
     "raft_hip_set_params", "raft_hip_set_stream", "raft_hip_use_own_stream", "raft_hip_get_stream", "raft_hip_run_device", "raft_hip_run_host",
     "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
-    "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed", "raft_hip_run_pipelined", "raft_hip_run_multi",
+    "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed", "raft_hip_fetch_packed_w", "raft_hip_run_pipelined", "raft_hip_run_multi",
 )
 
 
@@ -47,7 +47,8 @@ class _HostOutputs(C.Structure):
     _fields_ = [("cov_offset", C.c_void_p), ("cov8", C.c_void_p), ("cov8_cap", C.c_int64),
                 ("exc_index", C.c_void_p), ("exc_value", C.c_void_p), ("exc_cap", C.c_int64), ("n_exc", C.c_int64),
                 ("rep_offset", C.c_void_p), ("rep_s", C.c_void_p), ("rep_e", C.c_void_p), ("rep_cap", C.c_int64),
-                ("frag_offset", C.c_void_p), ("frag_begin", C.c_void_p), ("frag_end", C.c_void_p), ("frag_cap", C.c_int64)]
+                ("frag_offset", C.c_void_p), ("frag_begin", C.c_void_p), ("frag_end", C.c_void_p), ("frag_cap", C.c_int64),
+                ("cov_width", C.c_int32)]
 
 
 class _Outputs(C.Structure):
@@ -121,6 +122,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_outputs_device.argtypes = [vp, C.POINTER(_Outputs)]
     lib.raft_hip_fetch.argtypes = [vp] + [vp] * 11
     lib.raft_hip_fetch_packed.argtypes = [vp, vp, vp, i64, vp, vp, C.POINTER(i64)] + [vp] * 7
+    lib.raft_hip_fetch_packed_w.argtypes = [vp, i32, vp, vp, i64, vp, vp, C.POINTER(i64)] + [vp] * 7
     lib.raft_hip_run_pipelined.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_run_multi.argtypes = [C.POINTER(vp), i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -266,7 +268,7 @@ class Engine:
         self._check(self._lib.raft_hip_fetch(self._ctx, *ptr))
         return out
 
-    def host_output_buffers(self, read_len, pinned: bool = True, exc_cap: int = 1 << 20) -> dict:
+    def host_output_buffers(self, read_len, pinned: bool = True, exc_cap: int = 1 << 20, width: int = 1) -> dict:
         """Caller-owned arrays for ``run_pipelined`` sized by the upper bounds of include/raft_hip.h (page-locked when
         ``pinned``): allocate once, reuse for every pass over inputs of this shape."""
         p = self.params
@@ -281,10 +283,13 @@ class Engine:
             n = max(int(n), 1)
             if pinned:
                 import torch
+                if dt == np.uint16:      # (torch has no uint16 everywhere: page-locked bytes, viewed as uint16)
+                    return torch.empty(2 * n, dtype=torch.uint8, pin_memory=True).numpy().view(np.uint16)
                 tdt = {np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8}[dt]
                 return torch.empty(n, dtype=tdt, pin_memory=True).numpy()
             return np.empty(n, dt)
-        return {"cov_offset": alloc(n1, np.int64), "cov8": alloc(caps["cov8"], np.uint8), "exc_index": alloc(caps["exc"], np.int64),
+        return {"cov_offset": alloc(n1, np.int64), "cov8": alloc(caps["cov8"], np.uint16 if width == 2 else np.uint8),
+                "exc_index": alloc(caps["exc"], np.int64),
                 "exc_value": alloc(caps["exc"], np.int32), "rep_offset": alloc(n1, np.int64), "rep_s": alloc(caps["rep"], np.int32),
                 "rep_e": alloc(caps["rep"], np.int32), "frag_offset": alloc(n1, np.int64), "frag_begin": alloc(caps["frag"], np.int32),
                 "frag_end": alloc(caps["frag"], np.int32)}
@@ -302,6 +307,7 @@ class Engine:
         for k in ("cov_offset", "cov8", "exc_index", "exc_value", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
             setattr(ho, k, out[k].ctypes.data)
         ho.cov8_cap, ho.exc_cap, ho.rep_cap, ho.frag_cap = out["cov8"].size, out["exc_index"].size, out["rep_s"].size, out["frag_begin"].size
+        ho.cov_width = 2 if out["cov8"].dtype == np.uint16 else 1          # the buffer's dtype chooses the encoding's width
         ptr = [C.c_void_p(a.ctypes.data if (a is not None and a.size) else 0) for a in cols]
         s = _Summary()
         if others:
@@ -320,17 +326,21 @@ class Engine:
                "frag_begin": out["frag_begin"][:summ.n_fragments], "frag_end": out["frag_end"][:summ.n_fragments]}
         return res, summ
 
-    def fetch_packed(self, pinned: bool = False, out: dict | None = None) -> dict:
-        """Host copies with the coverage array in its transfer encoding (raft_hip_fetch_packed): ``cov8`` (uint8 per
-        window, 255 = see exceptions), ``exc_index`` / ``exc_value`` (ascending), and the repeat / fragment tables.
-        ``out``: arrays of an earlier call to reuse (pinned buffers kept by the caller)."""
+    def fetch_packed(self, pinned: bool = False, out: dict | None = None, width: int = 1) -> dict:
+        """Host copies with the coverage array in its transfer encoding (raft_hip_fetch_packed_w): ``cov8`` (uint8 per
+        window, 255 = see exceptions; with ``width=2`` uint16, 65535), ``exc_index`` / ``exc_value`` (ascending), and the
+        repeat / fragment tables.  ``out``: arrays of an earlier call to reuse (pinned buffers kept by the caller; the
+        dtype of its ``cov8`` decides the width)."""
         s = self.summary
         n1 = s.n_reads + 1
+        if out is not None and out.get("cov8") is not None:
+            width = 2 if out["cov8"].dtype == np.uint16 else 1
+        cdt = np.uint16 if width == 2 else np.uint8
         n_exc = C.c_int64(0)
         none = [C.c_void_p(0)] * 7
-        rc = self._lib.raft_hip_fetch_packed(self._ctx, None, None, 0, None, None, C.byref(n_exc), *none)
+        rc = self._lib.raft_hip_fetch_packed_w(self._ctx, width, None, None, 0, None, None, C.byref(n_exc), *none)
         self._check(rc)
-        spec = {"cov_offset": (n1, np.int64), "cov8": (s.n_bins, np.uint8), "exc_index": (n_exc.value, np.int64),
+        spec = {"cov_offset": (n1, np.int64), "cov8": (s.n_bins, cdt), "exc_index": (n_exc.value, np.int64),
                 "exc_value": (n_exc.value, np.int32), "rep_offset": (n1, np.int64), "rep_s": (s.n_repeats, np.int32),
                 "rep_e": (s.n_repeats, np.int32), "frag_offset": (n1, np.int64), "frag_read": (s.n_fragments, np.int32),
                 "frag_begin": (s.n_fragments, np.int32), "frag_end": (s.n_fragments, np.int32)}
@@ -338,6 +348,8 @@ class Engine:
         def alloc(n, dt):
             if pinned and n:
                 import torch
+                if dt == np.uint16:
+                    return torch.empty(2 * int(n), dtype=torch.uint8, pin_memory=True).numpy().view(np.uint16)
                 tdt = {np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8}[dt]
                 return torch.empty(int(n), dtype=tdt, pin_memory=True).numpy()
             return np.empty(n, dt)
@@ -350,9 +362,9 @@ class Engine:
             else:
                 res[key] = alloc(n, dt)
         ptr = {k: C.c_void_p(res[k].ctypes.data if res[k].size else 0) for k in res}
-        self._check(self._lib.raft_hip_fetch_packed(self._ctx, ptr["cov_offset"], ptr["cov8"], n_exc.value, ptr["exc_index"],
-                                                    ptr["exc_value"], C.byref(n_exc), ptr["rep_offset"], ptr["rep_s"], ptr["rep_e"],
-                                                    ptr["frag_offset"], ptr["frag_read"], ptr["frag_begin"], ptr["frag_end"]))
+        self._check(self._lib.raft_hip_fetch_packed_w(self._ctx, width, ptr["cov_offset"], ptr["cov8"], n_exc.value, ptr["exc_index"],
+                                                      ptr["exc_value"], C.byref(n_exc), ptr["rep_offset"], ptr["rep_s"], ptr["rep_e"],
+                                                      ptr["frag_offset"], ptr["frag_read"], ptr["frag_begin"], ptr["frag_end"]))
         return res
 
     def debug_stamps(self, max_tiles: int = 1 << 20) -> np.ndarray:

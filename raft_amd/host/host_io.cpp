@@ -508,6 +508,45 @@ int load_plain_fasta_parallel(const char *path, raft_host_reads *R)
 
 } // namespace
 
+// codes/exceptions (raft_hip_fetch_packed[_w]) -> the int32 coverage array
+template <class T>
+static int unpack_coverage_t(int64_t n_bins, const T *code, int64_t n_exc, const int64_t *exc_index, const int32_t *exc_value, int32_t *cov)
+{
+    constexpr int32_t kEscape = sizeof(T) == 1 ? 255 : 65535;
+    if (n_bins < 0 || n_exc < 0 || (n_bins && (!code || !cov)) || (n_exc && (!exc_index || !exc_value))) return RAFT_HOST_ERR_ARG;
+    const int T_ = n_bins < (1 << 22) ? 1 : host_threads();
+    parallel_for(T_, [&](int t) {
+        const int64_t lo = n_bins * t / T_, hi = n_bins * (t + 1) / T_;
+        for (int64_t i = lo; i < hi; ++i) cov[i] = code[i];
+    });
+    for (int64_t k = 0; k < n_exc; ++k) {
+        if (exc_index[k] < 0 || exc_index[k] >= n_bins || code[exc_index[k]] != kEscape) return RAFT_HOST_ERR_ARG;
+        cov[exc_index[k]] = exc_value[k];
+    }
+    return RAFT_HOST_OK;
+}
+
+// repeat.hpp:105-108 from the packed form: the escape code stands for the next entry of the (ascending) exception list
+template <class T>
+static int write_coverage_packed_t(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset, const T *code,
+                                   int64_t n_exc, const int64_t *exc_index, const int32_t *exc_value)
+{
+    constexpr long long kEscape = sizeof(T) == 1 ? 255 : 65535;
+    return write_ordered(path, n_reads, 1 << 20,
+                         [&](long long i) { return (long long)(cov_offset[i + 1] - cov_offset[i]) + 4; },
+                         [&](long long i, std::string &o) {
+                             o.append("read ", 5); put_num(o, i); o.push_back(' ');
+                             const int64_t b = cov_offset[i], e = cov_offset[i + 1];
+                             const int64_t *x = n_exc ? std::lower_bound(exc_index, exc_index + n_exc, b) : exc_index;
+                             for (int64_t j = b; j < e; ++j) {
+                                 long long v = code[j];
+                                 if (v == kEscape) { v = exc_value[x - exc_index]; ++x; }
+                                 put_num(o, (long long)(j - b) * reso); o.push_back(','); put_num(o, v); o.push_back(' ');
+                             }
+                             o.push_back('\n');
+                         });
+}
+
 extern "C" {
 
 int raft_host_set_threads(int n)
@@ -776,40 +815,32 @@ int64_t raft_host_paf_count(const raft_host_paf *p) { return p ? (int64_t)p->n :
 const int32_t *raft_host_paf_column(const raft_host_paf *p, int k) { return (p && k >= 0 && k < 6) ? p->col[k].get() : nullptr; }
 int raft_host_paf_symmetric(const raft_host_paf *p) { return p ? p->symmetric : 0; }
 
-// cov8/exceptions (raft_hip_fetch_packed) -> the int32 coverage array
+int raft_host_unpack_coverage_w(int32_t width, int64_t n_bins, const void *cov_packed, int64_t n_exc, const int64_t *exc_index,
+                                const int32_t *exc_value, int32_t *cov)
+{
+    if (width == 1) return unpack_coverage_t(n_bins, static_cast<const uint8_t *>(cov_packed), n_exc, exc_index, exc_value, cov);
+    if (width == 2) return unpack_coverage_t(n_bins, static_cast<const uint16_t *>(cov_packed), n_exc, exc_index, exc_value, cov);
+    return RAFT_HOST_ERR_ARG;
+}
+
+int raft_host_write_coverage_packed_w(int32_t width, const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset,
+                                      const void *cov_packed, int64_t n_exc, const int64_t *exc_index, const int32_t *exc_value)
+{
+    if (width == 1) return write_coverage_packed_t(path, n_reads, reso, cov_offset, static_cast<const uint8_t *>(cov_packed), n_exc, exc_index, exc_value);
+    if (width == 2) return write_coverage_packed_t(path, n_reads, reso, cov_offset, static_cast<const uint16_t *>(cov_packed), n_exc, exc_index, exc_value);
+    return RAFT_HOST_ERR_ARG;
+}
+
 int raft_host_unpack_coverage(int64_t n_bins, const uint8_t *cov8, int64_t n_exc, const int64_t *exc_index,
                               const int32_t *exc_value, int32_t *cov)
 {
-    if (n_bins < 0 || n_exc < 0 || (n_bins && (!cov8 || !cov)) || (n_exc && (!exc_index || !exc_value))) return RAFT_HOST_ERR_ARG;
-    const int T = n_bins < (1 << 22) ? 1 : host_threads();
-    parallel_for(T, [&](int t) {
-        const int64_t lo = n_bins * t / T, hi = n_bins * (t + 1) / T;
-        for (int64_t i = lo; i < hi; ++i) cov[i] = cov8[i];
-    });
-    for (int64_t k = 0; k < n_exc; ++k) {
-        if (exc_index[k] < 0 || exc_index[k] >= n_bins || cov8[exc_index[k]] != 255) return RAFT_HOST_ERR_ARG;
-        cov[exc_index[k]] = exc_value[k];
-    }
-    return RAFT_HOST_OK;
+    return raft_host_unpack_coverage_w(1, n_bins, cov8, n_exc, exc_index, exc_value, cov);
 }
 
-// repeat.hpp:105-108 from the packed form: a byte of 255 stands for the next entry of the (ascending) exception list
 int raft_host_write_coverage_packed(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset,
                                     const uint8_t *cov8, int64_t n_exc, const int64_t *exc_index, const int32_t *exc_value)
 {
-    return write_ordered(path, n_reads, 1 << 20,
-                         [&](long long i) { return (long long)(cov_offset[i + 1] - cov_offset[i]) + 4; },
-                         [&](long long i, std::string &o) {
-                             o.append("read ", 5); put_num(o, i); o.push_back(' ');
-                             const int64_t b = cov_offset[i], e = cov_offset[i + 1];
-                             const int64_t *x = n_exc ? std::lower_bound(exc_index, exc_index + n_exc, b) : exc_index;
-                             for (int64_t j = b; j < e; ++j) {
-                                 long long v = cov8[j];
-                                 if (v == 255) { v = exc_value[x - exc_index]; ++x; }
-                                 put_num(o, (long long)(j - b) * reso); o.push_back(','); put_num(o, v); o.push_back(' ');
-                             }
-                             o.push_back('\n');
-                         });
+    return raft_host_write_coverage_packed_w(1, path, n_reads, reso, cov_offset, cov8, n_exc, exc_index, exc_value);
 }
 
 // repeat.hpp:105-108: "read <i> " then "<pos>,<cov> " per window, then newline

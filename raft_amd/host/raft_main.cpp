@@ -191,7 +191,10 @@ int main(int argc, char *argv[])
         frag_cap = sum_len / p.interval_length + 2 * (int64_t)n_reads;
     }
     std::vector<int64_t> cov_off((size_t)n_reads + 1), rep_off((size_t)n_reads + 1), frag_off((size_t)n_reads + 1);
-    std::unique_ptr<uint8_t[]> cov8(new uint8_t[(size_t)n_win + 1]);            // (not value-initialised: no zero fill)
+    // one byte per window unless the expected coverage lets repeats pile up beyond it (from 40x on: two), and two in any
+    // case when the first attempt meets more windows at or above 255 than the exception list holds
+    int cov_width = p.est_cov >= 40 ? 2 : 1;
+    std::unique_ptr<uint8_t[]> cov8(new uint8_t[((size_t)n_win + 1) * 2]);      // (not value-initialised: no zero fill)
     std::unique_ptr<int32_t[]> rep_s(new int32_t[(size_t)rep_cap + 1]), rep_e(new int32_t[(size_t)rep_cap + 1]);
     std::unique_ptr<int32_t[]> fb(new int32_t[(size_t)frag_cap + 1]), fe(new int32_t[(size_t)frag_cap + 1]);
     std::vector<int64_t> exc_i;
@@ -199,10 +202,10 @@ int main(int argc, char *argv[])
     raft_hip_summary s{};
     int64_t n_exc = 0;
     const char *chunks_env = getenv("RAFT_CHUNKS");   // 0 / unset: the engine decides (one piece for small inputs)
-    for (int64_t exc_cap = std::max<int64_t>(1 << 16, n_win / 64), attempt = 0; attempt < 2; ++attempt) {
+    for (int64_t exc_cap = std::max<int64_t>(1 << 16, n_win / 64), attempt = 0; attempt < 3; ++attempt) {
         exc_i.resize((size_t)exc_cap); exc_v.resize((size_t)exc_cap);
         raft_hip_host_outputs ho{};
-        ho.cov_offset = cov_off.data(); ho.cov8 = cov8.get(); ho.cov8_cap = n_win;
+        ho.cov_offset = cov_off.data(); ho.cov8 = cov8.get(); ho.cov8_cap = n_win; ho.cov_width = cov_width;
         ho.exc_index = exc_i.data(); ho.exc_value = exc_v.data(); ho.exc_cap = exc_cap;
         ho.rep_offset = rep_off.data(); ho.rep_s = rep_s.get(); ho.rep_e = rep_e.get(); ho.rep_cap = rep_cap;
         ho.frag_offset = frag_off.data(); ho.frag_begin = fb.get(); ho.frag_end = fe.get(); ho.frag_cap = frag_cap;
@@ -212,8 +215,9 @@ int main(int argc, char *argv[])
                                 sym ? nullptr : raft_host_paf_column(paf, 4), sym ? nullptr : raft_host_paf_column(paf, 5),
                                 chunks_env ? atoi(chunks_env) : 0, &ho, &s);
         n_exc = ho.n_exc;
-        if (rc != RAFT_HIP_ERR_TOO_LARGE || attempt == 1) break;
-        exc_cap = std::max<int64_t>(n_win, 1);        // (more windows at or above 255 than expected: room for all of them)
+        if (rc != RAFT_HIP_ERR_TOO_LARGE || attempt == 2) break;
+        if (cov_width == 1) cov_width = 2;            // more windows at or above 255 than expected: two bytes per window,
+        else exc_cap = std::max<int64_t>(n_win, 1);   // then room for every window
     }
     if (rc != RAFT_HIP_OK) {
         std::string m = std::string("ERROR, raft_hip, ") + raft_hip_strerror(rc);
@@ -231,8 +235,8 @@ int main(int argc, char *argv[])
     int fasta_rc = RAFT_HOST_OK;
     std::thread fasta_writer([&] { fasta_rc = raft_host_write_fasta(fasta_out.c_str(), reads, frag_off.data(), fb.get(), fe.get()); });
     g_background[1] = &fasta_writer;
-    if (raft_host_write_coverage_packed((p.prefix + ".coverage.txt").c_str(), n_reads, p.reso, cov_off.data(), cov8.get(), n_exc,
-                                        exc_i.data(), exc_v.data()) != RAFT_HOST_OK ||
+    if (raft_host_write_coverage_packed_w(cov_width, (p.prefix + ".coverage.txt").c_str(), n_reads, p.reso, cov_off.data(), cov8.get(), n_exc,
+                                          exc_i.data(), exc_v.data()) != RAFT_HOST_OK ||
         raft_host_write_repeats((p.prefix + ".long_repeats.txt").c_str(), (p.prefix + ".long_repeats.bed").c_str(), reads,
                                 rep_off.data(), rep_s.get(), rep_e.get()) != RAFT_HOST_OK) {
         die("ERROR, repeat_annotate(), cannot write output files");

@@ -13,7 +13,8 @@ EXPORTS = ("raft_host_reads_load", "raft_host_reads_free", "raft_host_reads_coun
            "raft_host_reads_name", "raft_host_reads_bases", "raft_host_reads_real", "raft_host_paf_load", "raft_host_paf_free",
            "raft_host_paf_count", "raft_host_paf_column", "raft_host_write_coverage", "raft_host_write_repeats",
            "raft_host_write_fasta", "raft_host_set_threads", "raft_host_get_threads", "raft_host_split_naive",
-           "raft_host_paf_symmetric", "raft_host_unpack_coverage", "raft_host_write_coverage_packed")
+           "raft_host_paf_symmetric", "raft_host_unpack_coverage", "raft_host_write_coverage_packed",
+           "raft_host_unpack_coverage_w", "raft_host_write_coverage_packed_w")
 
 
 class HostError(RuntimeError):
@@ -52,6 +53,8 @@ def load_library():
         lib.raft_host_paf_symmetric.argtypes = [vp]
         lib.raft_host_unpack_coverage.argtypes = [C.c_int64, vp, C.c_int64, vp, vp, vp]
         lib.raft_host_write_coverage_packed.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp]
+        lib.raft_host_unpack_coverage_w.argtypes = [C.c_int32, C.c_int64, vp, C.c_int64, vp, vp, vp]
+        lib.raft_host_write_coverage_packed_w.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp]
         lib.raft_host_get_threads.argtypes = []
         _lib = lib
     return _lib
@@ -122,33 +125,41 @@ def load_paf(path: str, reads: Reads, with_flag: bool = False):
     return (cols, sym) if with_flag else cols
 
 
-def pack_coverage(cov):
-    """Reference encoder of the transfer form (tests): cov8 = min(cov, 255) + ascending exceptions (index, value)."""
+def pack_coverage(cov, width: int = 1):
+    """Reference encoder of the transfer form (tests): code = min(cov, limit) + ascending exceptions (index, value);
+    width 1: uint8, limit 255; width 2: uint16, limit 65535."""
     cov = np.asarray(cov, np.int32)
-    idx = np.flatnonzero(cov >= 255).astype(np.int64)
-    return np.minimum(cov, 255).astype(np.uint8), idx, cov[idx].astype(np.int32)
+    limit, dt = (255, np.uint8) if width == 1 else (65535, np.uint16)
+    idx = np.flatnonzero(cov >= limit).astype(np.int64)
+    return np.minimum(cov, limit).astype(dt), idx, cov[idx].astype(np.int32)
 
 
-def unpack_coverage(cov8, exc_index, exc_value):
-    """raft_host_unpack_coverage: the int32 coverage array from the packed form."""
+def _width_of(code) -> int:
+    return 2 if np.asarray(code).dtype == np.uint16 else 1
+
+
+def unpack_coverage(code, exc_index, exc_value):
+    """raft_host_unpack_coverage_w: the int32 coverage array from the packed form (uint8 or uint16 codes)."""
     lib = load_library()
-    cov8 = np.ascontiguousarray(cov8, np.uint8)
+    width = _width_of(code)
+    code = np.ascontiguousarray(code, np.uint16 if width == 2 else np.uint8)
     xi, xv = np.ascontiguousarray(exc_index, np.int64), np.ascontiguousarray(exc_value, np.int32)
-    out = np.empty(cov8.size, np.int32)
-    rc = lib.raft_host_unpack_coverage(cov8.size, C.c_void_p(cov8.ctypes.data), xi.size, C.c_void_p(xi.ctypes.data),
-                                       C.c_void_p(xv.ctypes.data), C.c_void_p(out.ctypes.data))
+    out = np.empty(code.size, np.int32)
+    rc = lib.raft_host_unpack_coverage_w(width, code.size, C.c_void_p(code.ctypes.data), xi.size, C.c_void_p(xi.ctypes.data),
+                                         C.c_void_p(xv.ctypes.data), C.c_void_p(out.ctypes.data))
     if rc != OK:
         raise HostError(rc, "unpack_coverage")
     return out
 
 
-def write_coverage_packed(path: str, n_reads: int, reso: int, cov_offset, cov8, exc_index, exc_value):
+def write_coverage_packed(path: str, n_reads: int, reso: int, cov_offset, code, exc_index, exc_value):
     lib = load_library()
+    width = _width_of(code)
     co = np.ascontiguousarray(cov_offset, np.int64)
-    cov8 = np.ascontiguousarray(cov8, np.uint8)
+    code = np.ascontiguousarray(code, np.uint16 if width == 2 else np.uint8)
     xi, xv = np.ascontiguousarray(exc_index, np.int64), np.ascontiguousarray(exc_value, np.int32)
     p = lambda x: C.c_void_p(x.ctypes.data)
-    rc = lib.raft_host_write_coverage_packed(path.encode(), n_reads, reso, p(co), p(cov8), xi.size, p(xi), p(xv))
+    rc = lib.raft_host_write_coverage_packed_w(width, path.encode(), n_reads, reso, p(co), p(code), xi.size, p(xi), p(xv))
     if rc != OK:
         raise HostError(rc, path)
 

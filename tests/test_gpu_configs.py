@@ -208,6 +208,13 @@ def test_packed_fetch_and_query_only_upload():
         assert np.array_equal(pk[k], want[k]), k
     pk2 = eng.fetch_packed(pinned=True, out=None)                           # a second call serves the cached encoding
     assert np.array_equal(pk2["cov8"], pk["cov8"])
+    pk16 = eng.fetch_packed(width=2)                                        # two bytes per window: nothing reaches 65535 here
+    assert pk16["cov8"].dtype == np.uint16 and pk16["exc_index"].size == 0
+    assert np.array_equal(hostio.unpack_coverage(pk16["cov8"], pk16["exc_index"], pk16["exc_value"]), want["cov"])
+    res16, s16 = eng.run_pipelined(cols[0], cols[1], cols[2], cols[3], n_chunks=4,
+                                   out=eng.host_output_buffers(cols[0], pinned=False, width=2))
+    assert res16["cov8"].dtype == np.uint16
+    assert np.array_equal(hostio.unpack_coverage(res16["cov8"], res16["exc_index"], res16["exc_value"]), want["cov"])
     eng.close()
     with pytest.raises(engine.RaftError):                                   # detection mode needs the target columns
         e2 = engine.Engine(RaftParams(est_cov=40), device=0)

@@ -278,6 +278,9 @@ def test_packed_coverage_roundtrip_and_writer(tmp_path):
     c8, xi, xv = hostio.pack_coverage(cov)
     assert c8.dtype == np.uint8 and (c8 == 255).sum() == xi.size and bool((np.diff(xi) > 0).all())
     assert np.array_equal(hostio.unpack_coverage(c8, xi, xv), cov)
+    c16, yi, yv = hostio.pack_coverage(cov, width=2)      # two bytes per window: escape 65535
+    assert c16.dtype == np.uint16 and (c16 == 65535).sum() == yi.size and 0 < yi.size < xi.size
+    assert np.array_equal(hostio.unpack_coverage(c16, yi, yv), cov)
     with pytest.raises(hostio.HostError):                # an exception pointing at a window that is not 255
         hostio.unpack_coverage(c8, np.array([1], np.int64), np.array([7], np.int32))
     lib = hostio.load_library()
@@ -286,6 +289,8 @@ def test_packed_coverage_roundtrip_and_writer(tmp_path):
         a, b = str(tmp_path / f"a{threads}.txt"), str(tmp_path / f"b{threads}.txt")
         assert lib.raft_host_write_coverage(a.encode(), len(nb), 50, off.ctypes.data, cov.ctypes.data) == 0
         hostio.write_coverage_packed(b, len(nb), 50, off, c8, xi, xv)
+        assert open(a, "rb").read() == open(b, "rb").read()
+        hostio.write_coverage_packed(b, len(nb), 50, off, c16, yi, yv)
         assert open(a, "rb").read() == open(b, "rb").read()
     hostio.set_threads(0)
     empty = np.empty(0, np.int64)
