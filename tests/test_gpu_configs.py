@@ -211,6 +211,22 @@ def test_packed_fetch_and_query_only_upload():
     pk16 = eng.fetch_packed(width=2)                                        # two bytes per window: nothing reaches 65535 here
     assert pk16["cov8"].dtype == np.uint16 and pk16["exc_index"].size == 0
     assert np.array_equal(hostio.unpack_coverage(pk16["cov8"], pk16["exc_index"], pk16["exc_value"]), want["cov"])
+    # chunked, one byte per window: the exceptions of every chunk land in the caller's list at the right place, also when
+    # several contexts share the job (later contexts' exceptions are moved down behind the earlier ones')
+    extra_hot = [np.repeat(c[len(c) // 7: len(c) // 7 + 1], 400) for c in cols[1:]]       # a second pile, on another read
+    cols2 = [cols[0]] + [np.concatenate([c, x]) for c, x in zip(cols[1:], extra_hot)]
+    order = np.argsort(cols2[1], kind="stable")                                           # keep the stream one sorted run
+    cols2 = [cols2[0]] + [c[order] for c in cols2[1:]]
+    want2 = oracle_run(p, *cols2)
+    others = [engine.Engine(RaftParams(est_cov=40, symmetric_mode=1), device=0) for _ in range(2)]
+    for oth, nch in (([], 5), (others[:1], 6), (others, 9)):
+        r8, s8 = eng.run_pipelined(cols2[0], cols2[1], cols2[2], cols2[3], n_chunks=nch, others=oth)
+        assert r8["exc_index"].size == int((want2["cov"] >= 255).sum()) > 700 and bool((np.diff(r8["exc_index"]) > 0).all())
+        assert np.array_equal(hostio.unpack_coverage(r8["cov8"], r8["exc_index"], r8["exc_value"]), want2["cov"]), (len(oth), nch)
+        for k in ("rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
+            assert np.array_equal(r8[k], want2[k]), (k, len(oth), nch)
+    for e2 in others:
+        e2.close()
     res16, s16 = eng.run_pipelined(cols[0], cols[1], cols[2], cols[3], n_chunks=4,
                                    out=eng.host_output_buffers(cols[0], pinned=False, width=2))
     assert res16["cov8"].dtype == np.uint16
