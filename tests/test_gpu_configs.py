@@ -221,7 +221,9 @@ def test_packed_fetch_and_query_only_upload():
     others = [engine.Engine(RaftParams(est_cov=40, symmetric_mode=1), device=0) for _ in range(2)]
     for oth, nch in (([], 5), (others[:1], 6), (others, 9)):
         r8, s8 = eng.run_pipelined(cols2[0], cols2[1], cols2[2], cols2[3], n_chunks=nch, others=oth)
-        assert r8["exc_index"].size == int((want2["cov"] >= 255).sum()) > 700 and bool((np.diff(r8["exc_index"]) > 0).all())
+        n_want = int((want2["cov"] >= 255).sum())
+        assert n_want > 100 and r8["exc_index"].size == n_want, (r8["exc_index"].size, n_want, len(oth), nch)
+        assert bool((np.diff(r8["exc_index"]) > 0).all()), (len(oth), nch)
         assert np.array_equal(hostio.unpack_coverage(r8["cov8"], r8["exc_index"], r8["exc_value"]), want2["cov"]), (len(oth), nch)
         for k in ("rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
             assert np.array_equal(r8[k], want2[k]), (k, len(oth), nch)
