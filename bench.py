@@ -208,8 +208,8 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--detect", action="store_true", help="symmetric_mode = -1: the engine detects the symmetric PAF itself (full inspect pass)")
-    ap.add_argument("--no-detect-leg", action="store_true", help="skip the extra passes that time symmetric_mode = -1")
+    ap.add_argument("--handover", action="store_true", help="symmetric_mode = 1: the symmetric flag is handed over, as the CLI does")
+    ap.add_argument("--no-detect-leg", action="store_true", help="skip the extra passes that time the inspect-first form")
     ap.add_argument("--presplit", action="store_true", help="BASELINE configs[3]: records pre-split across ranks, all-to-all-v in the step")
     ap.add_argument("--tile-bins", type=int, default=0)
     ap.add_argument("--force-bucket", action="store_true")
@@ -283,12 +283,12 @@ def main():
         my_len = read_len_all[b0:b1].contiguous()
     torch.cuda.synchronize()
 
-    # The engine runs as the `raft` CLI runs it: the tokeniser has seen every record on its way in and hands over the
-    # symmetric flag (raft_host_paf_symmetric), so symmetric_mode = 1 -- the pass then neither searches for the mirror of
-    # record 0 nor re-reads the qid column to establish the sorted runs (it verifies them in its kernels).  --detect times
-    # the self-contained form (symmetric_mode = -1: inspect_kernel looks at every record first); the default line carries
-    # that figure as roofline.pass_device_ms_detect.
-    p_run = p if (args.detect and not (args.presplit and world > 1)) else RaftParams(**dict(p.__dict__, symmetric_mode=1))
+    # The engine is self-contained here (symmetric_mode = -1: it finds out by itself that the PAF is symmetric).  Its pass is
+    # built on a sampled guess of the sorted runs and the assumption of a symmetric PAF, both verified while it runs (the
+    # runs in the pileup kernels, the mirror of record 0 by a one-workgroup kernel beside them); `--handover` runs it as
+    # the `raft` CLI does, with the flag the tokeniser found (symmetric_mode = 1: no target columns needed at all).  The
+    # default line also times the form that looks at every record first (inspect pass): roofline.pass_device_ms_inspect_first.
+    p_run = RaftParams(**dict(p.__dict__, symmetric_mode=1)) if (args.handover or (args.presplit and world > 1)) else p
     eng = engine.Engine(p_run, device=local)
     eng.set_tuning(args.tile_bins, args.force_bucket, args.variant)
     eng.use_torch_stream()
@@ -350,21 +350,25 @@ def main():
         if not all(check.values()):
             raise SystemExit(f"bench.py: self-check failed: {check}")
 
-    detect_ms = None
-    if n_gpus == 1 and not args.presplit and not args.detect and not args.no_detect_leg:
-        # the same pass without the tokeniser's hand-over: the engine looks at every record itself before it starts
-        e2 = engine.Engine(p, device=local)
-        e2.set_tuning(args.tile_bins, args.force_bucket, args.variant)
-        e2.use_torch_stream()
-        tt = []
-        for it in range(4):
-            e2.run_device(*cols)
-            s2 = e2.finish()
-            if it:
-                tt.append(e2.timing()[1])
-        assert (s2.n_fragments, s2.n_repeats, s2.total_coverage, s2.symmetric) == (s.n_fragments, s.n_repeats, s.total_coverage, 1)
-        detect_ms = sum(tt) / len(tt) * 1e3
-        e2.close()
+    inspect_ms = None
+    if n_gpus == 1 and not args.presplit and not args.no_detect_leg:
+        # the same pass in its round-1 form: inspect_kernel looks at every record before anything else starts
+        os.environ["RAFT_ALWAYS_INSPECT"] = "1"
+        try:
+            e2 = engine.Engine(p_run, device=local)
+            e2.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+            e2.use_torch_stream()
+            tt = []
+            for it in range(4):
+                e2.run_device(*cols)
+                s2 = e2.finish()
+                if it:
+                    tt.append(e2.timing()[1])
+            assert (s2.n_fragments, s2.n_repeats, s2.total_coverage, s2.symmetric) == (s.n_fragments, s.n_repeats, s.total_coverage, 1)
+            inspect_ms = sum(tt) / len(tt) * 1e3
+            e2.close()
+        finally:
+            del os.environ["RAFT_ALWAYS_INSPECT"]
 
     if rank == 0:
         per_step = elapsed / args.steps
@@ -395,8 +399,8 @@ def main():
                          "kernel_ms": pile * 1e3, "bytes_algorithmic": bytes_alg,
                          "pass_device_ms": pass_dev * 1e3, "pass_achieved": bytes_alg / pass_dev / 1e9,
                          "pass_frac": bytes_alg / pass_dev / 1e9 / HBM_PEAK_GBS, "kernel_source_hash": kernel_source_hash(),
-                         "symmetric_mode": "detected by the engine (inspect pass)" if args.detect else "handed over by the tokeniser (as the CLI does)",
-                         "pass_device_ms_detect": detect_ms},
+                         "symmetric_mode": "handed over by the tokeniser (as the CLI does)" if args.handover else "detected by the engine (mirror of record 0 found beside the pileup)",
+                         "pass_device_ms_inspect_first": inspect_ms},
             "self_check": check,
         }
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -177,7 +177,8 @@ struct raft_hip_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t side_stream = nullptr;   // the general pileup kernel runs beside the fast one
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_ifork = nullptr;
+    hipEvent_t ev_ifork = nullptr, ev_mjoin = nullptr;
+    hipStream_t mirror_stream = nullptr;   // mirror_kernel (symmetric detection of a verified pass) runs beside the pileup
     raft_hip_params prm{};
     int32_t high_cov = 0, div = 0, minbins = 1;
     int32_t tile_q = 0;               // 0 = variant default
@@ -210,6 +211,7 @@ struct raft_hip_ctx {
 
     // a pass that verifies in its kernels (see run_pass), and the arguments to run it again if a kernel objects
     bool spec = false;
+    bool assume_sym = true;            // what a detecting context's verified pass assumes (the last detection's answer)
     struct PassArgs { int32_t n_reads; const int32_t *len; int64_t n_rec; const int32_t *col[6]; } args{};
 
     // state of the last pass
@@ -308,6 +310,8 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ifork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_mjoin, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->mirror_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
@@ -349,6 +353,8 @@ void raft_hip_destroy(raft_hip_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_ifork) (void)hipEventDestroy(c->ev_ifork);
+    if (c->ev_mjoin) (void)hipEventDestroy(c->ev_mjoin);
+    if (c->mirror_stream) (void)hipStreamDestroy(c->mirror_stream);
     if (c->ev_gjoin) (void)hipEventDestroy(c->ev_gjoin);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -422,8 +428,10 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     hipStream_t st = c->stream;
     c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1; c->packed_width = 0;
     c->args = {n_reads, d_len, n_rec, {d_qid, d_qs, d_qe, d_tid, d_ts, d_te}};
-    static const bool no_verify_env = getenv("RAFT_ALWAYS_INSPECT") != nullptr;   // (A/B measurements)
-    const bool spec = verify_in_kernels && !no_verify_env && n_rec > 1 && c->prm.symmetric_mode == 1 && !c->force_bucket;
+    const bool no_verify_env = getenv("RAFT_ALWAYS_INSPECT") != nullptr;   // (A/B measurements; bench.py times both forms)
+    // (a detecting context assumes a symmetric PAF -- hifiasm's shape -- until a pass of its own has found otherwise)
+    const bool spec = verify_in_kernels && !no_verify_env && n_rec > 1 && !c->force_bucket &&
+                      (c->prm.symmetric_mode == 1 || (c->prm.symmetric_mode < 0 && c->assume_sym));
     c->spec = spec;
     memset(&c->sum, 0, sizeof c->sum);
     c->sum.n_reads = n_reads; c->sum.n_records = n_rec; c->sum.high_cov = c->high_cov; c->sum.error_index = -1;
@@ -547,6 +555,8 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
         n_desc = hg->n_desc;
         for (int i = 0; i < std::min(n_desc, kMaxSeg); ++i) desc[i] = hg->desc_pos[i];
         table_ok = n_desc + 1 <= kMaxSeg;            // (the samples index the stream the pass is built on)
+        if (c->prm.symmetric_mode < 0 && !table_ok)  // detecting, and not a handful of sorted runs: look at every record after all
+            return run_pass(c, n_reads, d_len, n_rec, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, false);
     } else if (n_rec > 0) {
         if (hi->err_flags) {
             c->pending_err = code_from_flags(hi->err_flags);
@@ -556,7 +566,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
             HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
             return RAFT_HIP_OK;
         }
-        if (c->prm.symmetric_mode < 0) symmetric = hi->sym_found ? 1 : 0;
+        if (c->prm.symmetric_mode < 0) { symmetric = hi->sym_found ? 1 : 0; c->assume_sym = symmetric != 0; }
         n_desc = hi->n_desc;
         for (int i = 0; i < std::min(n_desc, kMaxSeg); ++i) desc[i] = hi->desc_pos[i];
         // the samples index the stream when the sampled run ends are exactly the ones the full pass found
@@ -638,6 +648,13 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     pa.n_extra = recut ? &ctrl->n_extra : nullptr;
     pa.piece_w = pv.cap;
 
+    if (spec && c->prm.symmetric_mode < 0 && fast) {
+        // the detection itself: the mirror of record 0 can only sit among the records of record 0's target (bucket.hpp)
+        HIP_TRY(c, hipEventRecord(c->ev_ifork, st));
+        HIP_TRY(c, hipStreamWaitEvent(c->mirror_stream, c->ev_ifork, 0));
+        hipLaunchKernelGGL(mirror_kernel, dim3(1), dim3(256), 0, c->mirror_stream, sb, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp.sym_found);
+        HIP_TRY(c, hipEventRecord(c->ev_mjoin, c->mirror_stream));
+    }
     pa.dbg = nullptr;
     if (c->variant == kDiagVariant) {
         HIP_TRY(c, c->dbg.ensure((size_t)n_tiles * 16 * 8));
@@ -721,6 +738,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
                            ctrl->out_totals);
     }
     // everything finish() reports travels in one block, copied while the stream drains
+    if (spec && c->prm.symmetric_mode < 0 && fast) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_mjoin, 0));
     hipLaunchKernelGGL(publish_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl, c->pinned_dev + 128);   // (+1024 bytes)
     c->fa = fa; c->cuts_ready = false;
     HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
@@ -774,7 +792,9 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
             Ctrl hc;
             memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));
             c->spec = false;
-            if (hc.err_flags & (kErrOrder | kErrReadId)) {   // run it again, this time after looking at every record
+            const bool no_mirror = c->prm.symmetric_mode < 0 && hc.insp.sym_found == 0;   // assumed symmetric, found no mirror
+            if (no_mirror) c->assume_sym = false;
+            if ((hc.err_flags & (kErrOrder | kErrReadId)) || no_mirror) {   // run it again, this time after looking at every record
                 const auto a = c->args;
                 const int rc = run_pass(c, a.n_reads, a.len, a.n_rec, a.col[0], a.col[1], a.col[2], a.col[3], a.col[4], a.col[5], false);
                 if (rc != RAFT_HIP_OK) return rc;
