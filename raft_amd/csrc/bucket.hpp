@@ -120,23 +120,6 @@ __global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const 
     }
 }
 
-// Is the PAF symmetric (chop.hpp:171-184: does a record after the first mirror the first)?  A mirror of record 0 has
-// record 0's target as its query, so -- in a stream of runs sorted by query id -- it sits among that read's records:
-// two bisections per run and a look at a few hundred records, instead of a pass over all of them.  One workgroup,
-// beside the pileup kernels.  (Only sound when the runs are as the samples say; a pass whose kernels find otherwise is
-// run again after inspect_kernel has looked at every record.)
-__global__ __launch_bounds__(256) void mirror_kernel(SegStarts sb, const int32_t *qid, const int32_t *qs, const int32_t *qe,
-                                                     const int32_t *tid, const int32_t *ts, const int32_t *te, int32_t *sym_found)
-{
-    const int32_t q0 = qid[0], t0 = tid[0], qs0 = qs[0], qe0 = qe[0], ts0 = ts[0], te0 = te[0];
-    for (int s = 0; s < sb.n_seg; ++s) {
-        const long long lo = lower_bound_rid(qid, sb.start[s], sb.start[s + 1], t0);
-        const long long hi = lower_bound_rid(qid, lo, sb.start[s + 1], t0 + 1);
-        for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x)
-            if (i > 0 && qid[i] == t0 && tid[i] == q0 && ts[i] == qs0 && te[i] == qe0 && qs[i] == ts0 && qe[i] == te0) *sym_found = 1;
-    }
-}
-
 // tile_first[k] = first read whose first window lies in tile k or later (tiles of Q windows).
 __global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const long long *cov_off, int Q,
                                                          long long n_tiles, int32_t *tile_first)

@@ -177,8 +177,7 @@ struct raft_hip_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t side_stream = nullptr;   // the general pileup kernel runs beside the fast one
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_ifork = nullptr, ev_mjoin = nullptr;
-    hipStream_t mirror_stream = nullptr;   // mirror_kernel (symmetric detection of a verified pass) runs beside the pileup
+    hipEvent_t ev_ifork = nullptr;
     raft_hip_params prm{};
     int32_t high_cov = 0, div = 0, minbins = 1;
     int32_t tile_q = 0;               // 0 = variant default
@@ -310,8 +309,6 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ifork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_mjoin, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->mirror_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess ||
@@ -353,8 +350,6 @@ void raft_hip_destroy(raft_hip_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_ifork) (void)hipEventDestroy(c->ev_ifork);
-    if (c->ev_mjoin) (void)hipEventDestroy(c->ev_mjoin);
-    if (c->mirror_stream) (void)hipStreamDestroy(c->mirror_stream);
     if (c->ev_gjoin) (void)hipEventDestroy(c->ev_gjoin);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -398,7 +393,7 @@ int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket
     return RAFT_HIP_OK;
 }
 
-// One pass.  `verify_in_kernels` (the default when the caller asserts symmetric_mode = 1): no full look at the record
+// One pass.  `verify_in_kernels` (the default): no full look at the record
 // stream at all (inspect_kernel: ids in range, sorted runs -- one read of the qid column, 0.22-0.24 ms at human scale,
 // all of it ahead of the pass's host wait).  A one-workgroup-per-CU kernel samples the stream and names the sorted runs;
 // the pass is built on that, and what makes it safe is that tile_desc_kernel and the pileup kernels enforce what they
@@ -406,7 +401,9 @@ int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket
 // chunk) that processes it.  A record that refutes the guess -- an id out of range, a dip in the order between two
 // samples -- raises kErrOrder, and raft_hip_finish() then runs the pass again from the same arguments, this time after
 // inspect_kernel has looked at every record (which also reports errors exactly as before).  A detecting context
-// (symmetric_mode = -1) has to look at every record anyway (mirror of record 0) and always takes that second form.
+// (symmetric_mode = -1) assumes the symmetric PAF hifiasm writes and has tile_desc_kernel search for the mirror of
+// record 0 where sorted runs keep it (among the records of record 0's target: pileup.hpp MirrorArgs); none found sends
+// the pass to the second form too, and the context then stops assuming until a pass of its own detects a symmetric PAF.
 // (Measured and dropped: starting on the guess and running inspect_kernel BESIDE the pileup kernels on a low-priority
 // stream -- it costs the pileup what it would cost alone, 0.15-0.2 ms; the pass did not get shorter.)
 static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int64_t n_rec,
@@ -638,23 +635,19 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
         pa.iv_rid = c->b_rid.as<int32_t>(); pa.iv_s = c->b_s.as<int32_t>(); pa.iv_e = c->b_e.as<int32_t>(); pa.n_seg = 1;
         c->sum.interval_path = 1; c->sum.n_segments = n_desc + 1; c->sum.n_intervals = -1; // read back in finish
     }
-    hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
+    // the detection of a pass that assumes a symmetric PAF: one more boundary search of this kernel (pileup.hpp MirrorArgs)
+    MirrorArgs mir{};
+    if (spec && c->prm.symmetric_mode < 0 && fast) mir = {d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp.sym_found};
+    hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 2 + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
                        pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>(),
                        pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, pv.cap, kFastMaxReads,
                        pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow,
                        (fast && table_ok) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
                        c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags,
-                       recut ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap);
+                       recut ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir);
     pa.n_extra = recut ? &ctrl->n_extra : nullptr;
     pa.piece_w = pv.cap;
 
-    if (spec && c->prm.symmetric_mode < 0 && fast) {
-        // the detection itself: the mirror of record 0 can only sit among the records of record 0's target (bucket.hpp)
-        HIP_TRY(c, hipEventRecord(c->ev_ifork, st));
-        HIP_TRY(c, hipStreamWaitEvent(c->mirror_stream, c->ev_ifork, 0));
-        hipLaunchKernelGGL(mirror_kernel, dim3(1), dim3(256), 0, c->mirror_stream, sb, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp.sym_found);
-        HIP_TRY(c, hipEventRecord(c->ev_mjoin, c->mirror_stream));
-    }
     pa.dbg = nullptr;
     if (c->variant == kDiagVariant) {
         HIP_TRY(c, c->dbg.ensure((size_t)n_tiles * 16 * 8));
@@ -738,7 +731,6 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
                            ctrl->out_totals);
     }
     // everything finish() reports travels in one block, copied while the stream drains
-    if (spec && c->prm.symmetric_mode < 0 && fast) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_mjoin, 0));
     hipLaunchKernelGGL(publish_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl, c->pinned_dev + 128);   // (+1024 bytes)
     c->fa = fa; c->cuts_ready = false;
     HIP_TRY(c, hipEventRecord(c->ev_pass1, st));

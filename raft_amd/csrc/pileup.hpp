@@ -789,6 +789,15 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
     }
 }
 
+// What a pass that assumes a symmetric PAF (engine.hip run_pass, detecting contexts) still has to find: the mirror of
+// record 0 (chop.hpp:171-184).  It can only sit among the records of record 0's target read, and where those lie in each
+// sorted run is one more pair of the boundary searches tile_desc_kernel does anyway: the thread behind the closing
+// boundary searches for "tile" [tid[0], tid[0] + 1) and its wave then looks at those few records.
+struct MirrorArgs {
+    const int32_t *qs, *qe, *tid, *ts, *te;   // the record columns besides the id column the kernel searches (tid == nullptr: no search)
+    int32_t *found;                          // set to 1 when a record i > 0 mirrors record 0
+};
+
 // One thread per tile boundary: the descriptor the general pileup workgroups fetch (reads, windows, interval
 // ranges) and, when `cuts` is given, the compact boundary record of pileup_fast_kernel plus the list of tiles that
 // kernel leaves to the general one.  A tile's interval range ends where the next tile's begins, so each lane
@@ -799,12 +808,13 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                                                         int fast_cap, int fast_max_reads, int32_t *slow_list,
                                                         int32_t *n_slow, const int32_t *samples, long long n_rec,
                                                         const long long *bucket_off, int32_t *err_flags, TileCut *extra,
-                                                        int32_t *n_extra, int32_t extra_cap, int32_t piece_w)
+                                                        int32_t *n_extra, int32_t extra_cap, int32_t piece_w, MirrorArgs mir)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool live = k < n_tiles;
     const bool edge = k <= n_tiles;                 // boundary n_tiles closes the last tile
+    const bool mirror = mir.tid && k == n_tiles + 1;   // (see MirrorArgs)
     TileDesc d{};
     if (live) {
         d.r_lo = tile_first[k]; d.r_hi = tile_first[k + 1];
@@ -812,19 +822,21 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
     } else if (edge) {
         d.r_lo = d.r_hi = tile_first[k];
         d.g_lo = d.g_hi = cov_off[d.r_lo];
+    } else if (mirror) {
+        d.r_lo = mir.tid[0]; d.r_hi = d.r_lo < INT32_MAX ? d.r_lo + 1 : d.r_lo;
     }
     // A tile's interval range ends where the next tile's begins: every lane takes that from its neighbour (the last
     // lane of a wave searches for its own end as well).  The kernel's time is the chain of dependent probes (~1.3 us
     // each into a GB-sized array), so all bisections of a thread advance together: each round issues the probes of
     // every segment -- and of the own-end searches -- back to back and only then looks at them.
-    const bool own_end = live && lane == 63;
+    const bool own_end = (live && lane == 63) || mirror;
     long long blo[2 * kMaxSeg], bhi[2 * kMaxSeg];
 #pragma unroll
     for (int s = 0; s < kMaxSeg; ++s) {
         blo[s] = bhi[s] = blo[kMaxSeg + s] = bhi[kMaxSeg + s] = 0;
         if (s < sb.n_seg) {                         // uniform
             const long long seg_e = seg_end_dev ? *seg_end_dev : sb.start[s + 1];
-            if (edge) { blo[s] = sb.start[s]; bhi[s] = seg_e; }
+            if (edge || mirror) { blo[s] = sb.start[s]; bhi[s] = seg_e; }
             if (own_end) { blo[kMaxSeg + s] = sb.start[s]; bhi[kMaxSeg + s] = seg_e; }
         }
     }
@@ -872,6 +884,20 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                 if (v[q] < (q < kMaxSeg ? d.r_lo : d.r_hi)) blo[q] = mid + 1; else bhi[q] = mid;
             }
         }
+    }
+    if (mir.tid && __ballot(mirror) != 0ull) {      // the mirror thread's wave: look at the records of record 0's target
+        const int src = __ffsll((long long)__ballot(mirror)) - 1;
+        const int32_t q0 = iv_rid[0], t0 = mir.tid[0], qs0 = mir.qs[0], qe0 = mir.qe[0], ts0 = mir.ts[0], te0 = mir.te[0];
+        bool hit = false;
+#pragma unroll
+        for (int s = 0; s < kMaxSeg; ++s) {
+            const long long lo = __shfl(blo[s], src, kWave), hi = __shfl(blo[kMaxSeg + s], src, kWave);
+            if (s < sb.n_seg)
+                for (long long i = lo + lane; i < hi; i += kWave)
+                    hit |= i > 0 && iv_rid[i] == t0 && mir.tid[i] == q0 && mir.ts[i] == qs0 && mir.te[i] == qe0 &&
+                           mir.qs[i] == ts0 && mir.qe[i] == te0;
+        }
+        if (__ballot(hit) != 0ull && lane == 0) *mir.found = 1;
     }
     // The cuts of a run tile it: the first tile begins where the run begins, the closing boundary is its end, and they
     // never step back.  On sorted runs the searches give exactly that; a pass that only trusts a sampled guess of the
