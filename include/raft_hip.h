@@ -173,6 +173,20 @@ int  raft_hip_fetch_packed_w(raft_hip_ctx *ctx, int32_t width, int64_t *cov_offs
                              int64_t *exc_index, int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s,
                              int32_t *rep_e, int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end);
 
+/* Output width of the context's later passes: 4 (the default) -- cov[] is written as int32; 1 or 2 -- the pileup kernel
+ * writes the transfer encoding above directly (four fifths of a pass's HBM traffic is this array, and its consumer,
+ * repeat.hpp:105-108, is a text formatter) and the int32 array exists only if somebody asks for it: raft_hip_fetch() and
+ * raft_hip_outputs_device() decode it on the device at their first call, raft_hip_fetch_packed_w() of the same width is a
+ * plain copy, raft_hip_packed_device() hands out the device arrays.  Results are the same in every width; a width whose
+ * limit most windows reach (width 1 on a 60x set) costs a second pass, because the list of exceptions is sized for the
+ * usual case first.  The host pipelines below set the width their caller's buffers ask for by themselves. */
+int  raft_hip_set_output_width(raft_hip_ctx *ctx, int32_t width);
+
+/* Device arrays of the encoding the finished pass holds (width 0: none -- the pass wrote int32; call
+ * raft_hip_fetch_packed_w once to have it encoded).  The exceptions are in no particular order. */
+int  raft_hip_packed_device(raft_hip_ctx *ctx, int32_t *width, const void **cov_packed, const int64_t **exc_index,
+                            const int32_t **exc_value, int64_t *n_exc);
+
 /* Caller-owned host arrays (page-locked for full PCIe rate) that receive the outputs of raft_hip_run_pipelined, with
  * their capacities in elements.  Upper bounds the caller can compute from read_len alone, with W = sum ceil(len/reso)
  * and N = n_reads:

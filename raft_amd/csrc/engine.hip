@@ -51,17 +51,34 @@ void launch_general(hipStream_t st, unsigned grid, const PileupArgs &pa)
     hipLaunchKernelGGL((pileup_kernel<256, CAP, MINW, 3, false>), dim3(grid), dim3(256), 0, st, pa);
 }
 
-template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, bool EXTRA = false>
+template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, bool EXTRA = false, int OW = 4>
 void launch_fast(hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
     constexpr int S4 = SLOTS % 4 == 0 ? SLOTS : 4;   // four sorted runs need a multiple of four slots
     const size_t dyn = 0;
     if (n_seg <= 1)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG, EXTRA>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG, EXTRA, OW>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else if (n_seg == 2)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG, EXTRA>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG, EXTRA, OW>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG, EXTRA>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG, EXTRA, OW>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+}
+
+// the fast kernel's configurations by output width (pileup_fast.hpp OW; the diagnostic build writes int32 only)
+template <bool EXTRA>
+void launch_fast_variant(int variant, int ow, hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
+{
+    if (variant == 2) {
+        if (ow == 1) launch_fast<6144, 5, false, 4, EXTRA, 1>(st, grid, n_seg, cuts, pa);
+        else if (ow == 2) launch_fast<6144, 5, false, 4, EXTRA, 2>(st, grid, n_seg, cuts, pa);
+        else launch_fast<6144, 5, false, 4, EXTRA, 4>(st, grid, n_seg, cuts, pa);
+    } else if (variant == kDiagVariant && !EXTRA) {
+        launch_fast<7936, 4, true, 6, false, 4>(st, grid, n_seg, cuts, pa);
+    } else {
+        if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1>(st, grid, n_seg, cuts, pa);
+        else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2>(st, grid, n_seg, cuts, pa);
+        else launch_fast<7936, 4, false, 6, EXTRA, 4>(st, grid, n_seg, cuts, pa);
+    }
 }
 
 // RAFT_PRINT_OCCUPANCY=1: what the runtime thinks of the pileup kernels (registers, LDS, resident workgroups per CU)
@@ -87,6 +104,7 @@ struct Ctrl {                         // device control block, cleared every pas
     InspectOut insp;
     long long out_totals[4];          // rep / cut / frag totals land here via the scan
     GuessOut guess;                   // sorted runs as seen from samples
+    unsigned long long n_exc;         // windows at or above the limit of the encoding a pass wrote directly (PileupArgs::n_exc)
 };
 
 struct DevBuf {
@@ -197,6 +215,9 @@ struct raft_hip_ctx {
     DevBuf cov8, exc_idx, exc_val, exc_cnt;   // transfer encoding of cov[] (raft_hip_fetch_packed)
     int packed_width = 0;             // width (bytes per window) of the encoding the buffers hold, 0 = none
     long long n_exc = 0, exc_cap = 0;
+    int out_width = 4;                // raft_hip_set_output_width: 1 / 2 = the pass writes the encoding, cov[] only on request
+    int pass_width = 4;               // what the last pass wrote (4 where the general kernel had to take part)
+    bool cov_valid = false;           // c->cov holds the int32 array of the last pass
     long long dbg_tiles = 0;
     void *pinned = nullptr;           // small pinned scratch for readbacks
     long long *pinned_dev = nullptr;  // the same block as the device addresses it
@@ -306,6 +327,10 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     if (!c) return RAFT_HIP_ERR_NOMEM;
     c->device = device_id;
     apply_params(c, params);
+    if (const char *w = getenv("RAFT_COV_WIDTH")) {           // (test sweeps: every context of the process in that width)
+        const int v = atoi(w);
+        if (v == 1 || v == 2 || v == 4) c->out_width = v;
+    }
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ifork, hipEventDisableTiming) != hipSuccess ||
@@ -424,6 +449,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1; c->packed_width = 0;
+    c->cov_valid = false; c->pass_width = 4; c->n_exc = 0;
     c->args = {n_reads, d_len, n_rec, {d_qid, d_qs, d_qe, d_tid, d_ts, d_te}};
     const bool no_verify_env = getenv("RAFT_ALWAYS_INSPECT") != nullptr;   // (A/B measurements; bench.py times both forms)
     // (a detecting context assumes a symmetric PAF -- hifiasm's shape -- until a pass of its own has found otherwise)
@@ -437,6 +463,9 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     const PileVariant &pv = kVariants[c->variant];
     // tiles that do not fit the fast kernel are re-cut for it (pileup.hpp tile_desc_kernel) unless told otherwise
     const bool recut = pv.fast && !c->no_recut && getenv("RAFT_NO_RECUT") == nullptr;
+    // the encoding of cov[] is written directly when every tile goes through the fast kernel (pileup_fast.hpp OW); a pass
+    // the general kernel takes part in writes int32 and raft_hip_fetch_packed_w encodes it afterwards, as it always did
+    const int ow = (c->out_width != 4 && recut && c->variant != kDiagVariant) ? c->out_width : 4;
     HIP_TRY(c, hipEventRecord(c->ev_pass0, st));
     HIP_TRY(c, c->ctrl.ensure(sizeof(Ctrl)));
     Ctrl *ctrl = c->ctrl.as<Ctrl>();
@@ -508,7 +537,14 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     const long long n_tiles = B / Q + 1;
     if (n_tiles * kDescDwords >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE; // descriptors are indexed with 32 bits
 
-    HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
+    if (ow == 4) HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
+    else {
+        HIP_TRY(c, c->cov8.ensure((size_t)std::max(B, 1LL) * (size_t)ow + 16));
+        const long long cap = std::max<long long>(c->exc_cap, std::max<long long>(4096, B / 64));
+        HIP_TRY(c, c->exc_idx.ensure((size_t)cap * 8));
+        HIP_TRY(c, c->exc_val.ensure((size_t)cap * 4));
+        c->exc_cap = cap;
+    }
     HIP_TRY(c, c->tile_first.ensure((size_t)(n_tiles + 1) * 4));
     HIP_TRY(c, c->tile_desc.ensure((size_t)n_tiles * sizeof(TileDesc)));
     // extra tiles (tiles re-cut for the fast kernel: groups of whole reads, pieces of long reads) follow the regular cuts
@@ -580,7 +616,10 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     pa.read_len = d_len; pa.cov_off = c->cov_off.as<long long>();
     pa.td = c->tile_desc.as<TileDesc>(); pa.n_tiles = n_tiles; pa.n_reads = n_reads;
     pa.reso = c->prm.reso; pa.high_cov = c->high_cov; pa.repeat_length = c->prm.repeat_length; pa.flank = c->prm.flanking_length;
-    pa.cov = c->cov.as<int32_t>(); pa.rep_res_off = c->rep_res_off.as<long long>(); pa.rep_cnt = c->rep_cnt.as<int32_t>();
+    pa.cov = ow == 4 ? c->cov.as<int32_t>() : nullptr;
+    pa.covp = ow == 4 ? nullptr : c->cov8.p; pa.n_exc = &ctrl->n_exc; pa.exc_cap = c->exc_cap;
+    pa.exc_idx = c->exc_idx.as<long long>(); pa.exc_val = c->exc_val.as<int32_t>();
+    pa.rep_res_off = c->rep_res_off.as<long long>(); pa.rep_cnt = c->rep_cnt.as<int32_t>();
     pa.raw_key = c->raw_key.as<int32_t>(); pa.raw_s = c->raw_s.as<int32_t>(); pa.raw_e = c->raw_e.as<int32_t>();
     pa.block_sums = c->block_sums.as<long long>(); pa.err_flags = &ctrl->err_flags; pa.err_index = &ctrl->err_index;
     pa.tile_counter = &ctrl->next_tile; pa.slow_counter = &ctrl->slow_next;
@@ -673,20 +712,12 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
         ps.dbg = nullptr;
         const unsigned sgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * 5));
         HIP_TRY(c, hipEventRecord(c->ev_fork, st));
-        switch (c->variant) {
-        case 0: launch_fast<7936, 4, false, 6>(st, pgrid, pa.n_seg, cuts, pa); break;
-        case 2: launch_fast<6144, 5, false, 4>(st, pgrid, pa.n_seg, cuts, pa); break;
-        default: launch_fast<7936, 4, true, 6>(st, pgrid, pa.n_seg, cuts, pa); break;
-        }
+        launch_fast_variant<false>(c->variant, ow, st, pgrid, pa.n_seg, cuts, pa);
         HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
         if (recut) {
             // the tiles that did not fit as they are, re-cut by tile_desc_kernel: the same kernel, its other instantiation
             ps.slow_list = nullptr; ps.tile_counter = &ctrl->slow_next; ps.n_extra = &ctrl->n_extra; ps.tile_batch = 1;
-            switch (c->variant) {
-            case 0: launch_fast<7936, 4, false, 6, true>(c->side_stream, pgrid, pa.n_seg, cuts, ps); break;
-            case 2: launch_fast<6144, 5, false, 4, true>(c->side_stream, pgrid, pa.n_seg, cuts, ps); break;
-            default: launch_fast<7936, 4, false, 6, true>(c->side_stream, pgrid, pa.n_seg, cuts, ps); break;
-            }
+            launch_fast_variant<true>(c->variant, ow, c->side_stream, pgrid, pa.n_seg, cuts, ps);
         } else launch_general<6144, 5>(c->side_stream, sgrid, ps);
         HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
@@ -733,6 +764,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     // everything finish() reports travels in one block, copied while the stream drains
     hipLaunchKernelGGL(publish_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl, c->pinned_dev + 128);   // (+1024 bytes)
     c->fa = fa; c->cuts_ready = false;
+    c->pass_width = ow; c->cov_valid = ow == 4;
     HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
@@ -806,9 +838,23 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
                 c->spec = false;
             }
         }
+        if (c->pending_err == RAFT_HIP_OK && c->pass_width != 4) {
+            Ctrl hc;
+            memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));
+            if ((long long)hc.n_exc > c->exc_cap && !(hc.err_flags & ~(kErrOrder | kErrExtra))) {
+                // more windows at or above the encoding's limit than the list held: once more with room for all of them
+                const auto a = c->args;
+                c->exc_cap = (long long)hc.n_exc;
+                const int rc = run_pass(c, a.n_reads, a.len, a.n_rec, a.col[0], a.col[1], a.col[2], a.col[3], a.col[4], a.col[5], false);
+                if (rc != RAFT_HIP_OK) return rc;
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                c->spec = false;
+            }
+        }
         if (c->pending_err == RAFT_HIP_OK) {
             Ctrl hc;
             memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));   // copied at the end of the pass
+            if (c->pass_width != 4) { c->n_exc = (long long)hc.n_exc; c->packed_width = c->pass_width; }
             c->sum.n_repeats = hc.out_totals[0]; c->sum.n_cuts = hc.out_totals[1]; c->sum.n_fragments = hc.out_totals[2];
             if (c->sum.interval_path == 1) c->sum.n_intervals = hc.out_totals[3];
             c->sum.total_coverage = (long long)hc.totals[0];
@@ -841,11 +887,54 @@ static int materialise_cuts(raft_hip_ctx *c)
     return RAFT_HIP_OK;
 }
 
+// cov[] as int32 after a pass that wrote its encoding directly: decoded on the device, once, for the caller that asks
+static int materialise_cov(raft_hip_ctx *c)
+{
+    if (c->cov_valid) return RAFT_HIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const long long B = c->sum.n_bins;
+    HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
+    if (B > 0) {
+        const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((B / 4 + 255) / 256, 256 * 16));
+        if (c->pass_width == 1) hipLaunchKernelGGL(unpack_cov_kernel<uint8_t>, dim3(grid), dim3(256), 0, c->stream, c->cov8.as<uint8_t>(), B, c->cov.as<int32_t>());
+        else hipLaunchKernelGGL(unpack_cov_kernel<uint16_t>, dim3(grid), dim3(256), 0, c->stream, c->cov8.as<uint16_t>(), B, c->cov.as<int32_t>());
+        if (c->n_exc > 0)
+            hipLaunchKernelGGL(scatter_exceptions_kernel, dim3((unsigned)std::min<long long>((c->n_exc + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                               c->exc_idx.as<long long>(), c->exc_val.as<int32_t>(), c->n_exc, c->cov.as<int32_t>());
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->cov_valid = true;
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_set_output_width(raft_hip_ctx *c, int32_t width)
+{
+    if (!c || (width != 1 && width != 2 && width != 4)) return RAFT_HIP_ERR_PARAM;
+    c->out_width = width;
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_packed_device(raft_hip_ctx *c, int32_t *width, const void **cov_packed, const int64_t **exc_index,
+                           const int32_t **exc_value, int64_t *n_exc)
+{
+    if (!c || !width) return RAFT_HIP_ERR_PARAM;
+    if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
+    *width = c->packed_width;
+    const bool have = c->packed_width != 0;
+    if (cov_packed) *cov_packed = have ? c->cov8.p : nullptr;
+    if (exc_index) *exc_index = have ? c->exc_idx.as<int64_t>() : nullptr;
+    if (exc_value) *exc_value = have ? c->exc_val.as<int32_t>() : nullptr;
+    if (n_exc) *n_exc = have ? c->n_exc : 0;
+    return RAFT_HIP_OK;
+}
+
 int raft_hip_outputs_device(raft_hip_ctx *c, raft_hip_outputs *o)
 {
     if (!c || !o) return RAFT_HIP_ERR_PARAM;
     if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
     { const int rc = materialise_cuts(c); if (rc != RAFT_HIP_OK) return rc; }
+    { const int rc = materialise_cov(c); if (rc != RAFT_HIP_OK) return rc; }
     o->cov_offset = c->cov_off.as<int64_t>(); o->cov = c->cov.as<int32_t>();
     o->rep_offset = c->rep_off.as<int64_t>(); o->rep_s = c->rep_s.as<int32_t>(); o->rep_e = c->rep_e.as<int32_t>();
     o->cut_offset = c->cut_off.as<int64_t>(); o->cuts = c->cuts.as<int32_t>();
@@ -862,6 +951,7 @@ int raft_hip_fetch(raft_hip_ctx *c, int64_t *cov_offset, int32_t *cov, int64_t *
     if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
     HIP_TRY(c, hipSetDevice(c->device));
     if (cuts) { const int rc = materialise_cuts(c); if (rc != RAFT_HIP_OK) return rc; }
+    if (cov) { const int rc = materialise_cov(c); if (rc != RAFT_HIP_OK) return rc; }
     const size_t N1 = (size_t)c->sum.n_reads + 1;
     struct { void *dst; const void *src; size_t bytes; } job[] = {
         {cov_offset, c->cov_off.p, N1 * 8}, {cov, c->cov.p, (size_t)c->sum.n_bins * 4},
@@ -881,8 +971,9 @@ static int pack_coverage(raft_hip_ctx *c, int width)
 {
     if (c->packed_width == width) return RAFT_HIP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    { const int rc = materialise_cov(c); if (rc != RAFT_HIP_OK) return rc; }   // (a pass that wrote the other width)
     const long long B = c->sum.n_bins;
-    HIP_TRY(c, c->cov8.ensure((size_t)std::max(B, 1LL) * (size_t)width));
+    HIP_TRY(c, c->cov8.ensure((size_t)std::max(B, 1LL) * (size_t)width + 16));
     HIP_TRY(c, c->exc_cnt.ensure(8));
     long long cap = std::max<long long>(c->exc_cap, std::max<long long>(4096, B / 512));
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1027,9 +1118,12 @@ static int run_monolithic_to_host(raft_hip_ctx *c, int32_t n_reads, const int32_
                                   const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts, const int32_t *te,
                                   raft_hip_host_outputs *o, raft_hip_summary *summary)
 {
+    const int keep_width = c->out_width;
+    c->out_width = o->cov_width == 2 ? 2 : 1;             // the pass writes the encoding the caller takes
     int rc = raft_hip_run_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te);
     raft_hip_summary s{};
     if (rc == RAFT_HIP_OK) rc = raft_hip_finish(c, &s);
+    c->out_width = keep_width;
     if (summary) *summary = s;
     if (rc != RAFT_HIP_OK) return rc;
     if (s.n_bins > o->cov8_cap || s.n_repeats > o->rep_cap || s.n_fragments > o->frag_cap) return RAFT_HIP_ERR_TOO_LARGE;
@@ -1276,6 +1370,7 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
             }
             // -- the pass on this chunk
             {
+                l->out_width = cov_width;            // the pass writes the encoding that travels
                 int rc = raft_hip_run_device(l, nr, l->in_len.as<int32_t>(), cp.n_rec, l->in_col[0].as<int32_t>(),
                                              l->in_col[1].as<int32_t>(), l->in_col[2].as<int32_t>(), nullptr, nullptr, nullptr);
                 stamp(k, "pass queued");

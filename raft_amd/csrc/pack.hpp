@@ -7,7 +7,9 @@
 // with LIMIT = 255 in one byte per window -- a quarter of the bytes -- or, for deep sets whose repeats pile up beyond
 // that (60x with six-copy tandem arrays: half of the windows), LIMIT = 65535 in two; decoded exactly
 // (raft_host_unpack_coverage_w / raft_host_write_coverage_packed_w).
-// The engine's own output stays the int32 array; this is a copy made on request (raft_hip_fetch_packed).
+// pack_cov_kernel makes it from an int32 cov[] on request (raft_hip_fetch_packed_w); a context whose output width is set
+// to 1 or 2 (raft_hip_set_output_width) has the pileup kernel write it directly and never holds the int32 array at all
+// unless asked for it (unpack_cov_kernel).
 #pragma once
 #include "wave.hpp"
 
@@ -68,6 +70,37 @@ __global__ __launch_bounds__(256) void pack_cov_kernel(const int32_t *__restrict
         o.covp[i] = (T)min((unsigned)v, PackLimit<T>::value);
         pack_note(v, i, o);
     }
+}
+
+// The other direction, for a caller that asks for cov[] as int32 after a pass that wrote the encoding directly
+// (pileup_fast.hpp OW = 1 / 2): codes widened, then the listed windows overwritten with their values.
+template <class T>
+__global__ __launch_bounds__(256) void unpack_cov_kernel(const T *__restrict__ codes, long long n_bins, int32_t *__restrict__ cov)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n4 = n_bins >> 2;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
+        int4 v;
+        if (sizeof(T) == 1) {
+            const unsigned w = reinterpret_cast<const unsigned *>(codes)[g];
+            v = make_int4((int)(w & 255u), (int)((w >> 8) & 255u), (int)((w >> 16) & 255u), (int)(w >> 24));
+        } else {
+            const uint2 w = reinterpret_cast<const uint2 *>(codes)[g];
+            v = make_int4((int)(w.x & 65535u), (int)(w.x >> 16), (int)(w.y & 65535u), (int)(w.y >> 16));
+        }
+        reinterpret_cast<int4 *>(cov)[g] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n_bins & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        cov[i] = (int32_t)codes[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_exceptions_kernel(const long long *__restrict__ idx, const int32_t *__restrict__ val,
+                                                                 long long n, int32_t *__restrict__ cov)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) cov[idx[i]] = val[i];
 }
 
 // chunked pipeline: read ids of a chunk's records are rebased to the chunk's first read

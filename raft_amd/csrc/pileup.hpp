@@ -90,6 +90,13 @@ struct PileupArgs {
     int32_t div_shift;            // -1: reso == 1
     // outputs
     int32_t *cov;
+    // pileup_fast_kernel instantiated with OW = 1 or 2 writes the transfer encoding of cov[] instead (pack.hpp: OW bytes per
+    // window, min(cov, 255 / 65535), plus the list of the windows at or above that limit) and leaves `cov` alone
+    void *covp;
+    unsigned long long *n_exc;    // windows at or above the limit (counted even when the list is full)
+    long long exc_cap;
+    long long *exc_idx;
+    int32_t *exc_val;
     const long long *rep_res_off; // [n_reads+1] reserved slots for raw repeats
     int32_t *rep_cnt;             // [n_reads], zeroed
     int32_t *raw_key, *raw_s, *raw_e;

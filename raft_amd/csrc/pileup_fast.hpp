@@ -35,6 +35,7 @@ struct FastReadRegs {           // per read of a tile (thread j <-> read r_a + j
 struct FastTile {               // scalars of one tile
     int r_a, nr, nwin, fast, more;   // more: a segment holds intervals beyond the prefetched slots
     int piece;                       // the tile is a piece of one read longer than the LDS window (kCutPiece)
+    int cnt[kMaxSeg];                // intervals per segment
     long long g_lo;
 };
 
@@ -79,6 +80,7 @@ __device__ __forceinline__ void cut_unpack(int raw, FastTile &t, int (&lo)[NSEG]
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         lo[s] = d(2 + s); n[s] = d(10 + s) - lo[s];
+        t.cnt[s] = n[s];
         if (n[s] > ITER * 256) t.more = 1;
     }
 }
@@ -134,10 +136,21 @@ __device__ __forceinline__ void emit_piece_run(const PileupArgs &a, const FastTa
     a.raw_e[idx] = start + (sT - sS) * a.reso;
 }
 
+// A window at or above the limit of the one- or two-byte encoding (rare by the choice of the width).  (Inlined: a call
+// from the row loop costs the kernel 46 registers and a stack.)
+__device__ __forceinline__ void note_exception(const PileupArgs &a, long long window, int v)
+{
+    const unsigned long long slot = atomicAdd(a.n_exc, 1ull);
+    if ((long long)slot < a.exc_cap) { a.exc_idx[slot] = window; a.exc_val[slot] = v; }
+}
+
 // EXTRA = false: the regular tiles (bounded by adjacent cuts).  EXTRA = true: the same kernel over the extra tiles that
 // tile_desc_kernel cut out of what does not fit (explicit cut pairs; intervals clipped to the tile; pieces of long reads):
 // an instantiation of its own, so that the regular tiles' code carries none of that.
-template <int CAP, int NSEG, int U, int MINW, bool DIAG, bool EXTRA>
+// OW = bytes per window of the coverage written: 4 = cov[] as int32; 1 / 2 = its transfer encoding (PileupArgs::covp) --
+// the consumer of cov[] is a text formatter on the host, four fifths of the kernel's HBM traffic is this array, and real
+// coverage fits a byte.
+template <int CAP, int NSEG, int U, int MINW, bool DIAG, bool EXTRA, int OW = 4>
 __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *__restrict__ cuts, PileupArgs a)
 {
     constexpr int THREADS = 256, NW = 4, ITER = U / NSEG;
@@ -219,7 +232,10 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     int pub_r_a = 0, pub_nr = 0;                 // tile whose repeat counts are still in LDS (set 1 - p)
     int p = 0;                                   // table / start-bit set of the current tile
     int raw_n = 0, raw_nn = 0;                   // cuts of the next tile (landed) / of the tile after next (in flight)
-    auto draw = [&]() { if (tid == 0) drawn = 2 * nb + atomicAdd(a.tile_counter, kBatch); };
+    // (the result is not touched before the loads of the iteration are waited for anyway: used right away -- or with the
+    // compiler's wave-aggregation of atomics, which reads the result back at once (Makefile) -- wave 0 would sit out the
+    // round trip AND the previous tile's coverage stores, vmcnt counts both, with three waves waiting at the next barrier)
+    auto draw = [&]() { if (tid == 0) drawn = atomicAdd(a.tile_counter, kBatch); };
     auto hand_out = [&]() -> int {               // next tile of this workgroup; switches to the drawn batch when needed
         if (bn == be) { bn = next_base; be = bn + kBatch; want_draw = true; }
         return bn++;
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
         draw();
     }
     wait_all_loads();
-    if (tid == 0) sm.next_tile = drawn;
+    if (tid == 0) sm.next_tile = 2 * nb + drawn;
     lds_barrier();
     next_base = uni(sm.next_tile);
     knn = hand_out();                            // (this also asks for the next draw)
@@ -262,7 +278,9 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             const int off0 = (int)(cur.g_lo - a0);       // first valid slot
             const int t_end = off0 + cur.nwin;           // one past the last valid slot (the sentinel slot)
             const int rows = (t_end + 1 + 255) >> 8;
-            int32_t *const cov0 = a.cov + a0;
+            int32_t *const cov0 = OW == 4 ? a.cov + a0 : nullptr;
+            char *const covp0 = OW == 4 ? nullptr : reinterpret_cast<char *>(a.covp) + a0 * OW;   // slot p -> covp0 + p * OW
+            constexpr unsigned kLimit = OW == 1 ? 255u : 65535u;
             FastTables tb{sm.roff[p], sm.rlen[p], sm.rcnt[p], sm.rres[p], sm.acc_rep};
 
             // 1. intervals -> +1 / -1 (profileCoverage, closed form).  (Tried and measured slower: issuing the table
@@ -291,8 +309,13 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                     covsum += pl1 - pf;          // sum of coverage over the window == windows touched by its intervals
                 }
             };
+            // (slots behind the first of a segment are mostly empty for three waves in four -- a segment of a HiFi tile
+            // holds ~520 intervals, the third slot's lanes begin at 512 -- and an empty slot still costs its ~30 vector
+            // instructions: a wave skips the slots none of its lanes holds a record in)
 #pragma unroll
-            for (int u = 0; u < U; ++u) one(g.rid[u], g.st[u], g.en[u]);
+            for (int u = 0; u < U; ++u) {
+                if (u < NSEG || cur.cnt[u % NSEG] > (u / NSEG) * 256 + wid * 64) one(g.rid[u], g.st[u], g.en[u]);
+            }
             if (cur.more) {                      // intervals beyond the prefetched slots (dense tiles): synchronous loads
                 const TileCut d0 = cuts[cut_of(k)], d1 = cuts[cut_of(k) + 1];
 #pragma unroll
@@ -346,7 +369,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             // coverage store: after the stores, any vmcnt wait would also wait for the stores.
             wait_all_loads();
             RAFT_STAMP(15);
-            if (drew && tid == 0) sm.next_tile = drawn;   // read by every wave behind barrier C
+            if (drew && tid == 0) sm.next_tile = 2 * nb + drawn;   // read by every wave behind barrier C
             // The other table set is free now (its tile's runs were emitted before the last barrier pair): publish
             // that tile's repeat counts, then stage the next tile's reads in it.
             publish_counts(1 - p, pub_r_a, pub_nr);
@@ -397,20 +420,58 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 carry += __builtin_amdgcn_readlane(incl, 63);
                 const int c0 = excl + x, c1 = excl + y, c2 = excl + z, c3 = excl + w;
                 unsigned long long M0, M1, M2, M3;
+                // (coverage is never negative -- every interval's +1 / -1 balance out -- so one unsigned compare of the OR finds
+                // any value at or above the limit)
+                const unsigned k0 = min((unsigned)c0, kLimit), k1 = min((unsigned)c1, kLimit), k2 = min((unsigned)c2, kLimit), k3 = min((unsigned)c3, kLimit);
+                const bool big = OW != 4 && ((unsigned)c0 | (unsigned)c1 | (unsigned)c2 | (unsigned)c3) >= kLimit;
                 if (((partial_rows >> row) & 1u) == 0u) {
                     // scalar base + this lane's 32-bit byte offset (the LDS address of the row): no 64-bit address arithmetic
-                    *reinterpret_cast<int4 *>(reinterpret_cast<char *>(cov0) + (unsigned)p0 * 4u) = make_int4(c0, c1, c2, c3);
+                    if (OW == 4) *reinterpret_cast<int4 *>(reinterpret_cast<char *>(cov0) + (unsigned)p0 * 4u) = make_int4(c0, c1, c2, c3);
+                    else if (OW == 1) *reinterpret_cast<unsigned *>(covp0 + (unsigned)p0) = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);
+                    else *reinterpret_cast<uint2 *>(covp0 + (unsigned)p0 * 2u) = make_uint2(k0 | (k1 << 16), k2 | (k3 << 16));
+                    if (big) {
+                        if ((unsigned)c0 >= kLimit) note_exception(a, a0 + p0, c0);
+                        if ((unsigned)c1 >= kLimit) note_exception(a, a0 + p0 + 1, c1);
+                        if ((unsigned)c2 >= kLimit) note_exception(a, a0 + p0 + 2, c2);
+                        if ((unsigned)c3 >= kLimit) note_exception(a, a0 + p0 + 3, c3);
+                    }
                     M0 = __ballot(c0 >= a.high_cov); M1 = __ballot(c1 >= a.high_cov);
                     M2 = __ballot(c2 >= a.high_cov); M3 = __ballot(c3 >= a.high_cov);
                 } else {                         // first / last row of the tile: some slots lie outside [off0, t_end)
                     const unsigned q0 = (unsigned)(p0 - off0), nw_u = (unsigned)cur.nwin;
                     const bool v0 = q0 < nw_u, v1 = q0 + 1u < nw_u, v2 = q0 + 2u < nw_u, v3 = q0 + 3u < nw_u;
-                    if (v0 && v3) *reinterpret_cast<int4 *>(&cov0[p0]) = make_int4(c0, c1, c2, c3);
-                    else {
-                        if (v0) cov0[p0 + 0] = c0;
-                        if (v1) cov0[p0 + 1] = c1;
-                        if (v2) cov0[p0 + 2] = c2;
-                        if (v3) cov0[p0 + 3] = c3;
+                    if (OW == 4) {
+                        if (v0 && v3) *reinterpret_cast<int4 *>(&cov0[p0]) = make_int4(c0, c1, c2, c3);
+                        else {
+                            if (v0) cov0[p0 + 0] = c0;
+                            if (v1) cov0[p0 + 1] = c1;
+                            if (v2) cov0[p0 + 2] = c2;
+                            if (v3) cov0[p0 + 3] = c3;
+                        }
+                    } else if (OW == 1) {
+                        uint8_t *const o = reinterpret_cast<uint8_t *>(covp0) + p0;
+                        if (v0 && v3) *reinterpret_cast<unsigned *>(o) = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);
+                        else {          // (the neighbouring tile owns the other bytes of this dword)
+                            if (v0) o[0] = (uint8_t)k0;
+                            if (v1) o[1] = (uint8_t)k1;
+                            if (v2) o[2] = (uint8_t)k2;
+                            if (v3) o[3] = (uint8_t)k3;
+                        }
+                    } else {
+                        uint16_t *const o = reinterpret_cast<uint16_t *>(covp0) + p0;
+                        if (v0 && v3) *reinterpret_cast<uint2 *>(o) = make_uint2(k0 | (k1 << 16), k2 | (k3 << 16));
+                        else {
+                            if (v0) o[0] = (uint16_t)k0;
+                            if (v1) o[1] = (uint16_t)k1;
+                            if (v2) o[2] = (uint16_t)k2;
+                            if (v3) o[3] = (uint16_t)k3;
+                        }
+                    }
+                    if (big) {
+                        if (v0 && (unsigned)c0 >= kLimit) note_exception(a, a0 + p0, c0);
+                        if (v1 && (unsigned)c1 >= kLimit) note_exception(a, a0 + p0 + 1, c1);
+                        if (v2 && (unsigned)c2 >= kLimit) note_exception(a, a0 + p0 + 2, c2);
+                        if (v3 && (unsigned)c3 >= kLimit) note_exception(a, a0 + p0 + 3, c3);
                     }
                     M0 = __ballot(v0 && c0 >= a.high_cov); M1 = __ballot(v1 && c1 >= a.high_cov);
                     M2 = __ballot(v2 && c2 >= a.high_cov); M3 = __ballot(v3 && c3 >= a.high_cov);
@@ -566,7 +627,7 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
             // no work in this tile: keep the hand-over of the table sets going
             lds_barrier();                       // the previous tile's runs are all emitted
             wait_all_loads();
-            if (drew && tid == 0) sm.next_tile = drawn;
+            if (drew && tid == 0) sm.next_tile = 2 * nb + drawn;
             publish_counts(1 - p, pub_r_a, pub_nr);
             if (nxt.fast) stage_reads(1 - p, nxt, rdn);
             lds_barrier();

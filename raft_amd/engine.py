@@ -24,6 +24,7 @@ EXPORTS = (
     "raft_hip_set_params", "raft_hip_set_stream", "raft_hip_use_own_stream", "raft_hip_get_stream", "raft_hip_run_device", "raft_hip_run_host",
     "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
     "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed", "raft_hip_fetch_packed_w", "raft_hip_run_pipelined", "raft_hip_run_multi",
+    "raft_hip_set_output_width", "raft_hip_packed_device",
 )
 
 
@@ -127,6 +128,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_run_multi.argtypes = [C.POINTER(vp), i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.raft_hip_set_tuning.argtypes = [vp, i32, i32, i32]
+    lib.raft_hip_set_output_width.argtypes = [vp, i32]
+    lib.raft_hip_packed_device.argtypes = [vp, C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
     lib.raft_hip_selftest.argtypes = [C.c_int]
     lib.raft_hip_debug_stamps.argtypes = [vp, vp, i64, C.POINTER(i64)]
     if path is None:
@@ -186,6 +189,10 @@ class Engine:
 
     def set_tuning(self, tile_bins: int = 0, force_bucket_path: bool = False, variant: int = -1):
         self._check(self._lib.raft_hip_set_tuning(self._ctx, tile_bins, int(force_bucket_path), variant))
+
+    def set_output_width(self, width: int):
+        """4: cov[] as int32 (default); 1 / 2: later passes write the transfer encoding directly (raft_hip_set_output_width)."""
+        self._check(self._lib.raft_hip_set_output_width(self._ctx, width))
 
     def use_torch_stream(self):
         import torch
@@ -394,6 +401,26 @@ class Engine:
             else:
                 res[k] = torch.as_tensor(_DevArray(getattr(o, k), n, ts, self), device=f"cuda:{self.device}")
         return res
+
+
+    def packed_device(self) -> dict | None:
+        """Zero-copy torch views of the encoding the finished pass holds (raft_hip_packed_device), or None when the pass
+        wrote int32: ``cov8`` (uint8; for width 2 the uint16 codes as an int16 tensor -- same bits, ``.view(torch.uint16)`` or
+        ``& 0xFFFF`` after widening), ``exc_index`` / ``exc_value`` in no particular order."""
+        import torch
+        w, n = C.c_int32(0), C.c_int64(0)
+        codes, ei, ev = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self._lib.raft_hip_packed_device(self._ctx, C.byref(w), C.byref(codes), C.byref(ei), C.byref(ev), C.byref(n)))
+        if w.value == 0:
+            return None
+        dev = f"cuda:{self.device}"
+        def view(ptr, count, ts, dt):
+            if count == 0:
+                return torch.empty(0, dtype=dt, device=dev)
+            return torch.as_tensor(_DevArray(ptr.value, count, ts, self), device=dev)
+        return {"width": w.value,
+                "cov8": view(codes, self.summary.n_bins, "|u1" if w.value == 1 else "<i2", torch.uint8 if w.value == 1 else torch.int16),
+                "exc_index": view(ei, n.value, "<i8", torch.int64), "exc_value": view(ev, n.value, "<i4", torch.int32)}
 
 
 def selftest(device: int = 0) -> int:
