@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_ABI_VERSION 3
+#define RAFT_HIP_ABI_VERSION 4
 
 /* error codes (0..5 are shared with oracle/raft_oracle.h) */
 enum {

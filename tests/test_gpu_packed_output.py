@@ -131,10 +131,9 @@ def test_long_reads_and_pieces_in_every_width(width, seed):
 def test_existing_suites_with_every_context_in_that_width(width):
     """RAFT_COV_WIDTH puts every context of a process into the width: the parity and consistency suites, whose checks all go
     through the int32 array, must not notice."""
-    env = dict(os.environ, RAFT_COV_WIDTH=str(width))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_consistency.py")],
-                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+                       cwd=ROOT, env=dict(os.environ, RAFT_COV_WIDTH=str(width)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0, tail
     assert " passed" in tail
