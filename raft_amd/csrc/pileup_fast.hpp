@@ -232,10 +232,14 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     int pub_r_a = 0, pub_nr = 0;                 // tile whose repeat counts are still in LDS (set 1 - p)
     int p = 0;                                   // table / start-bit set of the current tile
     int raw_n = 0, raw_nn = 0;                   // cuts of the next tile (landed) / of the tile after next (in flight)
-    // (the result is not touched before the loads of the iteration are waited for anyway: used right away -- or with the
-    // compiler's wave-aggregation of atomics, which reads the result back at once (Makefile) -- wave 0 would sit out the
-    // round trip AND the previous tile's coverage stores, vmcnt counts both, with three waves waiting at the next barrier)
-    auto draw = [&]() { if (tid == 0) drawn = atomicAdd(a.tile_counter, kBatch); };
+    // (the result is not touched before the loads of the iteration are waited for anyway: used right away, wave 0 would sit
+    // out the round trip AND the previous tile's coverage stores -- vmcnt counts both -- with three waves waiting at the next
+    // barrier.  The counter's address passes through an empty asm: to the compiler it may differ by lane, which keeps its
+    // wave-aggregation of atomics off this one -- that reads the result back at once, and one lane is all there is)
+    typedef __attribute__((address_space(1))) int32_t *global_i32_ptr;   // (stays a global_ -- not a flat_ -- atomic)
+    global_i32_ptr draw_from = (global_i32_ptr)a.tile_counter;
+    asm volatile("" : "+v"(draw_from));
+    auto draw = [&]() { if (tid == 0) drawn = __hip_atomic_fetch_add(draw_from, kBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto hand_out = [&]() -> int {               // next tile of this workgroup; switches to the drawn batch when needed
         if (bn == be) { bn = next_base; be = bn + kBatch; want_draw = true; }
         return bn++;
