@@ -737,6 +737,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     fa.rep_s = c->rep_s.as<int32_t>(); fa.rep_e = c->rep_e.as<int32_t>(); fa.cuts = c->cuts.as<int32_t>();
     fa.frag_read = c->frag_read.as<int32_t>(); fa.frag_begin = c->frag_begin.as<int32_t>(); fa.frag_end = c->frag_end.as<int32_t>();
     fa.err_flags = &ctrl->err_flags; fa.err_index = &ctrl->err_index;
+    fa.by_L = make_fast_div(c->prm.interval_length); fa.by_div = make_fast_div(c->div); fa.by_reso = make_fast_div(c->prm.reso);
     fa.long_windows = recut ? pv.cap : INT32_MAX; fa.reso = c->prm.reso; fa.repeat_length = c->prm.repeat_length;
     fa.flank = c->prm.flanking_length; fa.rep_cnt_rw = c->rep_cnt.as<int32_t>(); fa.total_repeat = &ctrl->totals[1];
     if (N > 0) {

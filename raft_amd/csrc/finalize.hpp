@@ -10,6 +10,27 @@
 
 namespace raft {
 
+// n / d for 0 <= n < 2^31 and d >= 1 without a hardware divide (a 32-bit signed division is ~35 instructions; the sweeps
+// below do two per repeat and fragment, and the longest read's thread is what a long-read set waits for): with
+// L = ceil(log2 d) and m = floor(2^(31+L) / d) + 1 (< 2^32), n / d == mulhi(n, m) >> (L - 1)  (the identity pileup.hpp's
+// win_of uses for the windows)
+struct FastDiv {
+    uint32_t magic;
+    int32_t shift;                        // -1: d == 1
+};
+inline FastDiv make_fast_div(int d)
+{
+    FastDiv f{0u, -1};
+    if (d > 1) {
+        int L = 0;
+        while ((1ull << L) < (unsigned long long)d) ++L;
+        f.magic = (uint32_t)((1ull << (31 + L)) / (unsigned)d + 1ull);
+        f.shift = L - 1;
+    }
+    return f;
+}
+__device__ __forceinline__ int fdiv(const FastDiv &f, int n) { return f.shift < 0 ? n : (int)(__umulhi((unsigned)n, f.magic) >> f.shift); }
+
 struct FinalizeArgs {
     int32_t n_reads;
     const int32_t *read_len;
@@ -17,6 +38,7 @@ struct FinalizeArgs {
     const int32_t *rep_cnt;
     int32_t *raw_key, *raw_s, *raw_e;     // sorted in place by finalize_count_kernel
     int32_t interval_length, div, overlap_length;
+    FastDiv by_L, by_div, by_reso;        // interval_length, div, reso as divisors
     // reads with more than long_windows windows were piled up in pieces (pileup_fast.hpp emit_piece_run): their raw
     // records are unflanked [start, end) runs per piece, to be joined, tested, flanked and clamped here
     int32_t long_windows, reso, repeat_length, flank;
@@ -222,7 +244,8 @@ __device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, int r,
     if (n > 1) sort_repeats(a.raw_key + base, a.raw_s + base, a.raw_e + base, n);
     {
         const int len = a.read_len[r];
-        const int nb = len / a.reso + ((len % a.reso) ? 1 : 0);
+        const int nbq = fdiv(a.by_reso, len);
+        const int nb = nbq + ((len - nbq * a.reso) ? 1 : 0);
         if (nb > a.long_windows && n > 0) {
             // a long read, piled up in pieces: runs that meet at a piece boundary are one run (repeat.hpp:111-168 on the
             // whole read); then the length test, the flanks and the clamp, as pileup.hpp emit_run_of does for other reads
@@ -253,20 +276,20 @@ __device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, int r,
     // repeat [s,e] covers the multiples of L inside it; repeats are ordered by start and by end, so the union is
     // counted in one sweep over the read's (few) repeats.
     const int len = a.read_len[r], L = a.interval_length;
-    const int parts = len / L;
-    const int tail = (len % L) ? 1 : 0;
+    const int parts = fdiv(a.by_L, len);
+    const int tail = (len - parts * L) ? 1 : 0;
     const int J = tail ? parts : parts - 1;       // last interior marker is J * L
     int covered = 0, done = 0;                    // multiples 1 .. done are accounted for
     for (int k = 0; k < n && done < J; ++k) {
         const int s = a.raw_s[base + k], e = a.raw_e[base + k];
-        int lo = s <= 0 ? 0 : (s + L - 1) / L;
+        int lo = s <= 0 ? 0 : fdiv(a.by_L, s + L - 1);
         lo = max(lo, done + 1);
-        const int hi = e < 0 ? -1 : min(e / L, J);
+        const int hi = e < 0 ? -1 : min(fdiv(a.by_L, e), J);
         if (hi >= lo) { covered += hi - lo + 1; done = hi; }
     }
     const int nF = parts + 1 + tail - covered;
     int nf = 1;                                   // chop.hpp:250-276
-    if (nF > a.div + 1) nf = (nF - 1 + a.div - 1) / a.div;
+    if (nF > a.div + 1) nf = fdiv(a.by_div, nF - 1 + a.div - 1);
     a.cut_cnt[r] = nF;
     a.frag_cnt[r] = nf;
     n_out = n; nF_out = nF; nf_out = nf;
@@ -293,26 +316,30 @@ __device__ __forceinline__ void finalize_fill_one(const FinalizeArgs &a, int r, 
         a.frag_read[fo] = r; a.frag_begin[fo] = 0; a.frag_end[fo] = len;
         return;
     }
-    const int nf = (nF - 1 + a.div - 1) / a.div;  // chop.hpp:280-321
+    const int nf = fdiv(a.by_div, nF - 1 + a.div - 1);  // chop.hpp:280-321
     // Fragment j ends, and fragment j + 1 begins, at the kept marker with index t = j * div (an interior marker).
     // Without repeats that is the multiple t * L; each flanked repeat removes the multiples inside it, so the t-th kept
-    // multiple is found by skipping the covered ranges in order (the same sweep as in finalize_count_kernel).
+    // multiple is t plus the sizes of the covered ranges that begin at or before it -- the same sweep as in
+    // finalize_count_one, and ONE sweep for all fragments: t grows with j, so a range passed for one fragment is passed for
+    // every later one (a 1.5 Mb read has 75 fragments and dozens of repeats, and its thread is what the kernel waits for).
     const int L = a.interval_length;
-    const int parts = len / L;
-    const int J = (len % L) ? parts : parts - 1;
+    const int parts = fdiv(a.by_L, len);
+    const int J = (len - parts * L) ? parts : parts - 1;
     a.frag_read[fo] = r; a.frag_begin[fo] = 0;
+    int k = 0, done = 0, passed = 0;              // next repeat, last covered multiple, covered multiples passed so far
     for (int j = 1; j < nf; ++j) {
-        int v = j * a.div, done = 0;
-        for (int k = 0; k < n && done < J; ++k) {
+        int v = j * a.div + passed;
+        while (k < n && done < J) {
             const int s = a.raw_s[base + k], e = a.raw_e[base + k];
-            int lo = s <= 0 ? 0 : (s + L - 1) / L;
+            int lo = s <= 0 ? 0 : fdiv(a.by_L, s + L - 1);
             lo = max(lo, done + 1);
-            const int hi = e < 0 ? -1 : min(e / L, J);
+            const int hi = e < 0 ? -1 : min(fdiv(a.by_L, e), J);
             if (hi >= lo) {
-                if (v < lo) break;
-                v += hi - lo + 1;
+                if (v < lo) break;                // (this fragment ends before the range; a later one may pass it)
+                v += hi - lo + 1; passed += hi - lo + 1;
                 done = hi;
             }
+            ++k;
         }
         const int m = v * L;
         const int begin = m - a.overlap_length;
