@@ -44,11 +44,14 @@ while time.time() < t_end:
         continue
     sym_set = kw.get("symmetric", True)
     # 1 = the general kernel alone (independent code path); 0 / 2 = fast kernel, tiles that do not fit re-cut for it;
-    # 10 = configuration 0 with the symmetric flag handed over (the pass verifies the sorted runs in its kernels)
-    for variant in (1, 0, 2) + ((10,) if sym_set else ()):
+    # 10 = configuration 0 with the symmetric flag handed over; 20 / 30 = configuration 0 writing the one- / two-byte
+    # encoding of cov[] (decoded on the device for the comparison)
+    for variant in (1, 0, 2, 20, 30) + ((10,) if sym_set else ()):
         print("  variant", variant, flush=True)
         eng = engine.Engine(RaftParams(**dict(p.__dict__, symmetric_mode=1)) if variant == 10 else p, device=0)
-        eng.set_tuning(0, False, variant % 10)
+        eng.set_tuning(0, False, 0 if variant >= 10 else variant)
+        if variant in (20, 30):
+            eng.set_output_width(1 if variant == 20 else 2)
         try:
             eng.run_device(*cols); s = eng.finish()
         except engine.RaftError as e:
@@ -69,4 +72,4 @@ while time.time() < t_end:
     seed += 1
     del o, out, ref
     torch.cuda.empty_cache()
-print(f"{n_ok} random sets agree across configurations 1, 0, 2 and 0 with the symmetric flag handed over (seeds up to {seed - 1})")
+print(f"{n_ok} random sets agree across configurations 1, 0, 2, 0 with the symmetric flag handed over and 0 writing the one- and two-byte encodings (seeds up to {seed - 1})")
