@@ -38,6 +38,13 @@ sub = np.stack([st[:, 11] - st[:, 6], st[:, 13] - st[:, 11]], 1)
 for n, c in zip(["  6->11 resolve seams", "  11->13 emit parked runs"], sub.T):
     print(f"{n:28s} median {np.median(c):8.0f} mean {c.mean():8.0f}")
 print(f"tiles with intervals beyond the prefetched slots: {(st[:, 12] != 0).mean():.3f}")
+# per-row cost of the two passes: the stamping wave (wave 0) owns ceil(rows / 4) rows of a tile with stamp 8 windows
+rpw = (((st[:, 8] + 2 + 1 + 255) >> 8) + 3) // 4
+for nm, col in (("pass A + barrier B", 3), ("stage + pass B", 4)):
+    A = np.stack([np.ones(len(rpw)), rpw.astype(np.float64)], 1)
+    coef, *_ = np.linalg.lstsq(A, d[:, col].astype(np.float64), rcond=None)
+    by = {int(r): float(np.median(d[rpw == r, col])) for r in np.unique(rpw) if (rpw == r).sum() > 200}
+    print(f"  {nm}: {coef[0]:.0f} cycles + {coef[1]:.0f} per row of wave 0; medians by rows of wave 0: {by}")
 rt = (st[:, 10] - st[:, 9])
 print("memtime ticks per 100MHz realtime tick:", np.median(life[rt > 0] / rt[rt > 0]))
 # concurrency: kernel span vs sum of lifetimes
