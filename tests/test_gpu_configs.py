@@ -382,6 +382,36 @@ def test_misspeculated_pass_is_redone():
     eng.close()
 
 
+def test_detecting_context_alternating_inputs():
+    """A detecting context assumes a symmetric PAF and has tile_desc_kernel look for the mirror of record 0 (pileup.hpp
+    MirrorArgs); after a PAF without one it stops assuming until a pass of its own has detected one again.  Symmetric and
+    non-symmetric inputs in turn on ONE context: every pass equals the oracle, whichever way it was run."""
+    from raft_amd import engine
+    rng = np.random.default_rng(77)
+    rl = rng.integers(3000, 40000, 1500).astype(np.int32)
+    n = 40000
+    qid = np.sort(rng.integers(0, len(rl), n)).astype(np.int32)
+    tid = rng.integers(0, len(rl), n).astype(np.int32)
+    a = (rng.random(n) * rl[qid] * 0.8).astype(np.int32)
+    b = np.minimum(rl[qid], a + 1 + (rng.random(n) * rl[qid] * 0.2).astype(np.int32)).astype(np.int32)
+    ta = (rng.random(n) * rl[tid] * 0.8).astype(np.int32)
+    tb = np.minimum(rl[tid], ta + 1 + (rng.random(n) * rl[tid] * 0.2).astype(np.int32)).astype(np.int32)
+    order = np.argsort(tid, kind="stable")               # the mirrored records, sorted by THEIR query: a second sorted run
+    sym = tuple(np.concatenate([x, y[order]]) for x, y in ((qid, tid), (a, ta), (b, tb), (tid, qid), (ta, a), (tb, b)))
+    nonsym = (qid, a, b, tid, ta, tb)
+    p = RaftParams(est_cov=10)
+    want = {"sym": oracle_run(p, rl, *sym), "nonsym": oracle_run(p, rl, *nonsym)}
+    assert want["sym"]["symmetric"] == 1 and want["nonsym"]["symmetric"] == 0
+    eng = engine.Engine(p, device=0)
+    try:
+        for step, which in enumerate(["sym", "sym", "nonsym", "nonsym", "sym", "sym", "nonsym", "sym"]):
+            eng.run_host(rl, *(sym if which == "sym" else nonsym))
+            s = eng.finish()
+            assert_same_result(engine_result(eng, s), want[which], f"step {step}: {which}")
+    finally:
+        eng.close()
+
+
 # ---- tiles re-cut for the fast kernel (groups of reads, pieces of long reads) ----------------------------------------------
 
 def _long_read_set(seed):
