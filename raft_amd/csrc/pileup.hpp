@@ -736,7 +736,9 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
                         r_a = r; r_b = r2; w_lo = gl; w_hi = (r2 == cur.r_hi) ? cur.g_hi : uni(a.cov_off[r2]);
                         single = false; first = true; last = true;
                         r = r2;
-                        if (w_hi == w_lo) continue;      // only reads without windows
+                        // (only reads without windows: piled up all the same -- on an empty window -- because their records
+                        // still have to be looked at: an interval on a read without windows is repeat.hpp:69-72's write past
+                        // the vector, and a record of some other read here refutes the order the pass relies on)
                     } else {
                         g_first = gl; g_end = uni(a.cov_off[r + 1]); chunk_pos = gl; chunk_idx = 0;
                     }

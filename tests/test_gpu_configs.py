@@ -459,10 +459,13 @@ def test_recut_tiles_and_pieces(seed, mode, monkeypatch):
             eng.close()
 
 
-def test_groups_of_reads_without_windows_are_still_checked():
+@pytest.mark.parametrize("mode", ["default", "no_recut", "general"])
+def test_groups_of_reads_without_windows_are_still_checked(mode, monkeypatch):
     """A tile of nothing but zero-length reads: its (valid, empty) records pass, a record that needs a window is the
-    COORD error the oracle reports."""
+    COORD error the oracle reports -- from the re-cut tiles of the fast kernel and from the general kernel alike."""
     from raft_amd import engine
+    if mode == "no_recut":
+        monkeypatch.setenv("RAFT_NO_RECUT", "1")
     from raft_testlib import OracleError
     rl = np.concatenate([np.full(300, 0, np.int32), np.array([5000, 0, 0, 7000], np.int32)])
     qid = np.sort(np.concatenate([np.arange(300), [300, 303, 303]])).astype(np.int32)
@@ -471,6 +474,7 @@ def test_groups_of_reads_without_windows_are_still_checked():
     p = RaftParams(est_cov=1, symmetric_mode=1)
     want = oracle_run(RaftParams(est_cov=1), rl, qid, s_, e_, qid, s_, e_); want["symmetric"] = 1
     eng = engine.Engine(p, device=0)
+    eng.set_tuning(0, False, 1 if mode == "general" else -1)
     eng.run_host(rl, qid, s_, e_, None, None, None)
     assert_same_result(engine_result(eng, eng.finish()), want, "zero-length reads")
     bad = e_.copy(); bad[7] = 3                          # an interval on a read that has no window
