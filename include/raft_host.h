@@ -54,6 +54,14 @@ int            raft_host_reads_real(const raft_host_reads *r);             /* al
 /* overlaps: name -> id resolution against `reads`; err_name (may be NULL) receives the offending name */
 int            raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host_paf **out,
                                   char *err_name, int err_name_cap);
+/* The same in two steps: the file's bytes (read by all workers, or inflated when it is .gz, paf.hpp:29) need nothing of
+ * the reads and can be fetched on a thread of the caller's while raft_host_reads_load is still running; the parse
+ * (paf.hpp:50-87, chop.hpp:155-165) tokenises the text in place and consumes it.  load == read + parse. */
+typedef struct raft_host_text raft_host_text;
+int            raft_host_text_read(const char *path, raft_host_text **out);
+void           raft_host_text_free(raft_host_text *t);
+int            raft_host_paf_parse(raft_host_text *text, const raft_host_reads *reads, raft_host_paf **out,
+                                   char *err_name, int err_name_cap);
 void           raft_host_paf_free(raft_host_paf *p);
 int64_t        raft_host_paf_count(const raft_host_paf *p);                /* accepted records */
 const int32_t *raft_host_paf_column(const raft_host_paf *p, int k);        /* k: 0 qid 1 qs 2 qe 3 tid 4 ts 5 te */

@@ -359,6 +359,11 @@ struct raft_host_reads {
     std::vector<std::string> align, chr;
 };
 
+struct raft_host_text {                  // a file's bytes in memory (inflated if it was gz), newline-terminated
+    std::unique_ptr<char[]> buf;
+    size_t n = 0;
+};
+
 struct raft_host_paf {
     std::unique_ptr<int32_t[]> col[6];   // allocated untouched: the workers' copies are the first writes
     size_t n = 0;
@@ -626,9 +631,11 @@ const char *raft_host_reads_name(const raft_host_reads *r, int32_t i) { return r
 const char *raft_host_reads_bases(const raft_host_reads *r, int32_t i) { return r->base_ptr() + r->base_off[i]; }
 int raft_host_reads_real(const raft_host_reads *r) { return r ? r->real_reads : 1; }
 
-int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host_paf **out, char *err_name, int err_cap)
+// The bytes of a PAF file -- needs nothing of the reads, so a caller may fetch them (and inflate a .gz) on a thread of
+// its own while the reads are still being loaded (raft_main.cpp does: on gz inputs the two inflations are the run time).
+int raft_host_text_read(const char *path, raft_host_text **out)
 {
-    if (!path || !reads || !out) return RAFT_HOST_ERR_ARG;
+    if (!path || !out) return RAFT_HOST_ERR_ARG;
     *out = nullptr;
     std::unique_ptr<char[]> data_buf;    // the file's bytes plus one '\n'; allocated untouched (no serial zero fill)
     size_t data_n = 0;
@@ -683,7 +690,32 @@ int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host
             data_n = used + 1;
         }
     }
-    char *const data = data_buf.get();
+    raft_host_text *T = new raft_host_text();
+    T->buf.swap(data_buf);
+    T->n = data_n;
+    *out = T;
+    return RAFT_HOST_OK;
+}
+
+void raft_host_text_free(raft_host_text *t) { delete t; }
+
+int raft_host_paf_load(const char *path, const raft_host_reads *reads, raft_host_paf **out, char *err_name, int err_cap)
+{
+    if (!path || !reads || !out) return RAFT_HOST_ERR_ARG;
+    *out = nullptr;
+    raft_host_text *text = nullptr;
+    int rc = raft_host_text_read(path, &text);
+    if (rc == RAFT_HOST_OK) rc = raft_host_paf_parse(text, reads, out, err_name, err_cap);
+    raft_host_text_free(text);
+    return rc;
+}
+
+int raft_host_paf_parse(raft_host_text *text, const raft_host_reads *reads, raft_host_paf **out, char *err_name, int err_cap)
+{
+    if (!text || !reads || !out) return RAFT_HOST_ERR_ARG;
+    *out = nullptr;
+    const size_t data_n = text->n;
+    char *const data = text->buf.get();     // (tokenised in place: the text is consumed)
     // Lines are independent: the buffer is cut at newlines into one chunk per thread, each chunk is tokenised into
     // its own columns (paf.hpp:50-87 rules), and the chunks are concatenated in file order.
     struct Chunk { std::vector<int32_t> col[6]; size_t err_pos = (size_t)-1; std::string err_name; bool mirror = false; };

@@ -54,7 +54,7 @@ bool missing_or_empty(const char *fn) // chop.hpp:326-329,336-349
     return !f || f.peek() == std::ifstream::traits_type::eof();
 }
 
-std::thread *g_background[2] = {nullptr, nullptr};   // helpers that must be finished before the process exits
+std::thread *g_background[3] = {nullptr, nullptr, nullptr};   // helpers that must be finished before the process exits
 
 [[noreturn]] void die(const std::string &msg)
 {
@@ -147,6 +147,13 @@ int main(int argc, char *argv[])
     });
     g_background[0] = &bring_up;
 
+    // The overlaps file's bytes need nothing of the reads: they are read -- inflated, for a .gz -- beside the loading of
+    // the reads (on gz inputs, the reference's own quick-start shape, the two inflations are most of the run).
+    raft_host_text *paf_text = nullptr;
+    int paf_text_rc = RAFT_HOST_OK;
+    std::thread paf_reader([&] { paf_text_rc = raft_host_text_read(paf_fn, &paf_text); });
+    g_background[2] = &paf_reader;
+
     raft_host_reads *reads = nullptr;
     int rc = raft_host_reads_load(reads_fn, &reads);
     stage("reads_load");
@@ -158,7 +165,11 @@ int main(int argc, char *argv[])
 
     raft_host_paf *paf = nullptr;
     char bad[256] = {0};
-    rc = raft_host_paf_load(paf_fn, reads, &paf, bad, sizeof bad);
+    paf_reader.join();
+    stage("paf_read (rest)");
+    rc = paf_text_rc;
+    if (rc == RAFT_HOST_OK) rc = raft_host_paf_parse(paf_text, reads, &paf, bad, sizeof bad);
+    raft_host_text_free(paf_text);
     if (rc == RAFT_HOST_ERR_UNKNOWN_NAME) die(std::string("ERROR, create_pileup(), read ") + bad + " of the overlaps file is not in the reads file");
     if (rc != RAFT_HOST_OK) die(std::string("ERROR, create_pileup(), cannot read ") + paf_fn);
     const int64_t n_rec = raft_host_paf_count(paf);

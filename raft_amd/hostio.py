@@ -14,7 +14,8 @@ EXPORTS = ("raft_host_reads_load", "raft_host_reads_free", "raft_host_reads_coun
            "raft_host_paf_count", "raft_host_paf_column", "raft_host_write_coverage", "raft_host_write_repeats",
            "raft_host_write_fasta", "raft_host_set_threads", "raft_host_get_threads", "raft_host_split_naive",
            "raft_host_paf_symmetric", "raft_host_unpack_coverage", "raft_host_write_coverage_packed",
-           "raft_host_unpack_coverage_w", "raft_host_write_coverage_packed_w")
+           "raft_host_unpack_coverage_w", "raft_host_write_coverage_packed_w", "raft_host_text_read", "raft_host_text_free",
+           "raft_host_paf_parse")
 
 
 class HostError(RuntimeError):
@@ -42,6 +43,10 @@ def load_library():
         lib.raft_host_reads_bases.argtypes = [vp, C.c_int32]; lib.raft_host_reads_bases.restype = C.POINTER(C.c_char)
         lib.raft_host_reads_real.argtypes = [vp]
         lib.raft_host_paf_load.argtypes = [C.c_char_p, vp, C.POINTER(vp), C.c_char_p, C.c_int]
+        lib.raft_host_text_read.argtypes = [C.c_char_p, C.POINTER(vp)]
+        lib.raft_host_text_free.argtypes = [vp]
+        lib.raft_host_text_free.restype = None
+        lib.raft_host_paf_parse.argtypes = [vp, vp, C.POINTER(vp), C.c_char_p, C.c_int]
         lib.raft_host_paf_free.argtypes = [vp]; lib.raft_host_paf_free.restype = None
         lib.raft_host_paf_count.argtypes = [vp]; lib.raft_host_paf_count.restype = C.c_int64
         lib.raft_host_paf_column.argtypes = [vp, C.c_int]; lib.raft_host_paf_column.restype = C.POINTER(C.c_int32)
@@ -110,12 +115,20 @@ class Reads:
             pass
 
 
-def load_paf(path: str, reads: Reads, with_flag: bool = False):
-    """-> six int32 numpy columns (qid, qs, qe, tid, ts, te) [, the symmetric flag the tokeniser found]."""
+def load_paf(path: str, reads: Reads, with_flag: bool = False, two_steps: bool = False):
+    """-> six int32 numpy columns (qid, qs, qe, tid, ts, te) [, the symmetric flag the tokeniser found].
+    ``two_steps``: raft_host_text_read + raft_host_paf_parse (what the CLI does, the first beside the loading of the reads)."""
     lib = load_library()
     h = C.c_void_p()
     err = C.create_string_buffer(256)
-    rc = lib.raft_host_paf_load(path.encode(), reads._h, C.byref(h), err, 256)
+    if two_steps:
+        t = C.c_void_p()
+        rc = lib.raft_host_text_read(path.encode(), C.byref(t))
+        if rc == OK:
+            rc = lib.raft_host_paf_parse(t, reads._h, C.byref(h), err, 256)
+        lib.raft_host_text_free(t)
+    else:
+        rc = lib.raft_host_paf_load(path.encode(), reads._h, C.byref(h), err, 256)
     if rc != OK:
         raise HostError(rc, err.value.decode())
     n = lib.raft_host_paf_count(h)

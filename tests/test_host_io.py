@@ -90,6 +90,9 @@ def test_config1_gz_inputs_md5(tmp_path):
     for threads in (1, 5):                               # 25 MB of PAF text: the multi-chunk tokeniser finds the flag too
         hostio.set_threads(threads)
         assert hostio.load_paf(str(tmp_path / "overlaps.paf.gz"), reads, with_flag=True)[1] == meta["symmetric"] == 1
+        # the two-step form the CLI uses (text fetched beside the reads, then parsed): the same columns and flag
+        two, sym2 = hostio.load_paf(str(tmp_path / "overlaps.paf.gz"), reads, with_flag=True, two_steps=True)
+        assert sym2 == 1 and all(np.array_equal(a, b) for a, b in zip(two, cols[1:]))
     hostio.set_threads(0)
 
 
@@ -216,6 +219,8 @@ def test_loaders_and_writers_thread_count_random(tmp_path):
             reads = hostio.Reads(str(tmp_path / "r.fa"))
             got = hostio.load_paf(str(tmp_path / "o.paf"), reads)
             for a, b in zip(got, cols[1:]):
+                assert np.array_equal(a, b)
+            for a, b in zip(hostio.load_paf(str(tmp_path / "o.paf"), reads, two_steps=True), cols[1:]):
                 assert np.array_equal(a, b)
             assert reads.lengths.tolist() == lens.tolist()
             res = oracle_run(p, reads.lengths, *got)
