@@ -532,49 +532,67 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                     }
                 }
 
-                // ---- exact run scan of the row: scalar bit logic on the four >= high_cov ballots
-                unsigned long long VE0 = ~0ull, VE1 = ~0ull, VE2 = ~0ull, VE3 = ~0ull;   // slot is inside the tile
-                if (tail) {
-                    VE0 = __ballot(p0 + 0 < t_end); VE1 = __ballot(p0 + 1 < t_end);
-                    VE2 = __ballot(p0 + 2 < t_end); VE3 = __ballot(p0 + 3 < t_end);
-                }
-                // P_k: the slot before (lane,k) is a high window; the carried-in bit belongs to the first valid slot:
-                // slot off0 of row 0, else slot 0 of the row
-                const unsigned long long hb = hp ? 1ull : 0ull;
-                const int hk = (row == 0) ? off0 : 0;
-                const unsigned long long P0 = (M3 << 1) | (hk == 0 ? hb : 0ull), P1 = M0 | (hk == 1 ? hb : 0ull),
-                                         P2 = M1 | (hk == 2 ? hb : 0ull), P3 = M2 | (hk == 3 ? hb : 0ull);
-                unsigned long long CL0 = P0 & (~M0 | SB0) & VE0, CL1 = P1 & (~M1 | SB1) & VE1,
-                                   CL2 = P2 & (~M2 | SB2) & VE2, CL3 = P3 & (~M3 | SB3) & VE3; // run ends before this slot
-                const unsigned long long CA0 = M0 & (~P0 | SB0), CA1 = M1 & (~P1 | SB1),
-                                         CA2 = M2 & (~P2 | SB2), CA3 = M3 & (~P3 | SB3);       // run starts at this slot
-                unsigned long long any_cl = CL0 | CL1 | CL2 | CL3;
-                while (any_cl) {                         // ends of runs, in slot order (rarely more than one per row)
-                    const int l = (int)__builtin_ctzll(any_cl);
-                    const unsigned long long bl = 1ull << l, lt = bl - 1ull, le = lt | bl;
-                    int kk;
-                    if (CL0 & bl) { kk = 0; CL0 &= ~bl; } else if (CL1 & bl) { kk = 1; CL1 &= ~bl; }
-                    else if (CL2 & bl) { kk = 2; CL2 &= ~bl; } else { kk = 3; CL3 &= ~bl; }
-                    any_cl = CL0 | CL1 | CL2 | CL3;
-                    int best = S;                        // latest run start at a slot before (l, kk)
-                    unsigned long long m;
-                    m = CA0 & (0 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 0);
-                    m = CA1 & (1 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 1);
-                    m = CA2 & (2 < kk ? le : lt); if (m) best = max(best, base + 4 * top_bit(m) + 2);
-                    m = CA3 & lt;                 if (m) best = max(best, base + 4 * top_bit(m) + 3);
-                    const int t = base + 4 * l + kk;
-                    if (best == kOpen) pclose = t;       // the inherited run: its start is known after the barrier
-                    else park(best, t);
-                }
-                if (CA0) S = max(S, base + 4 * top_bit(CA0) + 0);
-                if (CA1) S = max(S, base + 4 * top_bit(CA1) + 1);
-                if (CA2) S = max(S, base + 4 * top_bit(CA2) + 2);
-                if (CA3) S = max(S, base + 4 * top_bit(CA3) + 3);
-                if (!tail) hp = (M3 >> 63) != 0ull;
-                else if (t_end > base) {
-                    const int tl = t_end - 1 - base; // last valid slot of the row
-                    const unsigned long long Mk = (tl & 3) == 0 ? M0 : (tl & 3) == 1 ? M1 : (tl & 3) == 2 ? M2 : M3;
-                    hp = ((Mk >> (tl >> 2)) & 1ull) != 0ull;
+                // ---- exact run scan of the row, per lane: every lane knows which of its four slots is high, begins a read, or
+                // lies inside the tile; what it lacks -- is the slot before mine high, and where did the run that reaches me
+                // begin -- comes from one wave shift and one max-scan.  (The first version did this as scalar bit logic on
+                // twenty 64-bit masks: 250-300 scalar instructions per row under the kernel's worst register pressure, for the
+                // 17 % of the rows in which a kept run may end.)
+                {
+                    const int hk = (row == 0) ? off0 : 0;     // the carried-in "previous slot is high" belongs to the first valid slot
+                    int hv[4], sbv[4], prv[4];
+                    hv[0] = (int)((M0 >> lane) & 1ull); hv[1] = (int)((M1 >> lane) & 1ull);
+                    hv[2] = (int)((M2 >> lane) & 1ull); hv[3] = (int)((M3 >> lane) & 1ull);
+                    sbv[0] = sbv[1] = sbv[2] = sbv[3] = 0;
+                    if (start_lanes) {
+                        sbv[0] = (int)((SB0 >> lane) & 1ull); sbv[1] = (int)((SB1 >> lane) & 1ull);
+                        sbv[2] = (int)((SB2 >> lane) & 1ull); sbv[3] = (int)((SB3 >> lane) & 1ull);
+                    }
+                    prv[0] = wave_shr1(hv[3], 0); prv[1] = hv[0]; prv[2] = hv[1]; prv[3] = hv[2];
+                    if (hp && lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (hk == k) prv[k] = 1;
+                    }
+                    int ls = -0x40000000;                     // last slot of this lane at which a run starts
+                    int ls_before[4];                         // ... among the slots before slot k
+                    int endb[4];                              // a run ends before slot k
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        ls_before[k] = ls;
+                        const int inside = tail ? (p0 + k < t_end ? 1 : 0) : 1;
+                        endb[k] = prv[k] & ((hv[k] ^ 1) | sbv[k]) & inside;
+                        if (hv[k] & ((prv[k] ^ 1) | sbv[k])) ls = p0 + k;
+                    }
+                    const int incl = wave_incl_scan_max(ls, -0x40000000);
+                    const int carried = max(S, wave_shr1(incl, -0x40000000));      // start of the run that reaches this lane's first slot
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned long long em = __ballot(endb[k] != 0);
+                        if (em == 0ull) continue;
+                        const int best = max(carried, ls_before[k]);
+                        const int t = p0 + k;
+                        const unsigned long long inh = __ballot(endb[k] != 0 && best == kOpen);
+                        if (inh) pclose = __builtin_amdgcn_readlane(t, (int)__builtin_ctzll(inh));   // the inherited run: its start is known after the barrier
+                        // repeat.hpp:125,150 -- except at the edges of a PIECE of a long read (see park())
+                        const bool keep = endb[k] != 0 && best >= 0 &&
+                                          ((long long)(t - best) * a.reso >= (long long)a.repeat_length || (piece && (best == off0 || t == t_end)));
+                        const unsigned long long km = __ballot(keep);
+                        if (km) {
+                            const int idx = nq + (int)__popcll(km & ((1ull << lane) - 1ull));
+                            if (keep) {
+                                if (idx < kRunQ) { sm.runq[(wid * kRunQ + idx) * 2] = best; sm.runq[(wid * kRunQ + idx) * 2 + 1] = t; }
+                                else if (piece) emit_piece_run(a, tb, r_a, best, t);
+                                else emit_run(a, tb, nr, best, t);
+                            }
+                            nq = min(kRunQ, nq + (int)__popcll(km));
+                        }
+                    }
+                    S = max(S, __builtin_amdgcn_readlane(incl, 63));
+                    if (!tail) hp = (M3 >> 63) != 0ull;
+                    else if (t_end > base) {
+                        const int tl = t_end - 1 - base; // last valid slot of the row
+                        const unsigned long long Mk = (tl & 3) == 0 ? M0 : (tl & 3) == 1 ? M1 : (tl & 3) == 2 ? M2 : M3;
+                        hp = ((Mk >> (tl >> 2)) & 1ull) != 0ull;
+                    }
                 }
             }
 
