@@ -174,9 +174,6 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     const int n_tiles = EXTRA ? uni(*a.n_extra) : n_reg;
     const int last_cut = n_tiles - 1;            // (tile index: the word index below maps it)
     auto cut_of = [&](int t) -> int { return EXTRA ? n_reg + 1 + 2 * t : t; };   // index of tile t's first cut
-    // runs are kept from ceil(repeat_length / reso) windows on; from 68 windows on, pass B can tell by whole lanes
-    // of four windows that a row ends no such run (see there)
-    const bool long_runs_only = ((long long)a.repeat_length + a.reso - 1) / a.reso >= 68;
     // window of base n without a branch: n / reso == ((n & win_m1) | mulhi(n, div_magic)) >> win_sh  (div_magic is 0 and
     // win_m1 all ones when reso == 1, see win_of)
     const unsigned win_m1 = a.div_shift < 0 ? ~0u : 0u;
@@ -487,66 +484,31 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 // a run passes through the whole row (all high, no read begins, no tile end)
                 if (hp && !tail && (RS0 | RS1) == 0ull && A == ~0ull) continue;
 
-                // ---- reads that begin in the row: their slots (SB_k), their lanes, the last of them
-                unsigned long long SB0 = 0ull, SB1 = 0ull, SB2 = 0ull, SB3 = 0ull, start_lanes = 0ull;
-                int last_start = -3;
+                // ---- reads that begin in the row: bit k of sbm <=> a read begins at this lane's slot k (a run never continues
+                // across a read boundary, repeat.hpp:111-112)
+                int sbm = 0;
                 auto mark_starts = [&](unsigned long long rs, int ro) {
                     while (rs) {
                         const int pos = __builtin_amdgcn_readlane(ro, (int)__builtin_ctzll(rs)) & 255;
                         rs &= rs - 1ull;
-                        const unsigned long long bit = 1ull << (pos >> 2);
-                        const int sk = pos & 3;              // selects, not a 4-entry array (that would live in scratch)
-                        SB0 |= sk == 0 ? bit : 0ull; SB1 |= sk == 1 ? bit : 0ull; SB2 |= sk == 2 ? bit : 0ull; SB3 |= sk == 3 ? bit : 0ull;
-                        start_lanes |= bit;
-                        last_start = max(last_start, base + pos);
+                        if ((pos >> 2) == lane) sbm |= 1 << (pos & 3);
                     }
                 };
                 mark_starts(RS0, ro0);
                 mark_starts(RS1, ro1);
 
-                // ---- most rows with high windows neither end nor could end a run long enough to be kept (coverage noise,
-                // the inside of a long run, the first part of one).  A kept run has Lmin = ceil(repeat_length / reso) >= 68
-                // windows, so the 16 lanes (of four slots) below the lane in which it ends are completely high and hold no
-                // read start; if it ends in the first 16 lanes of the row it came in from the previous row.  Rows without
-                // such an end only update the two facts later rows need: is the last slot high, and where did the run that
-                // is open there begin.
-                if (long_runs_only && !tail && !piece) {   // (a piece keeps short runs at its edges: they go through the exact scan)
-                    const unsigned long long Af = A & ~start_lanes;
-                    unsigned long long E = Af;               // E bit i: lanes i-15 .. i are full
-                    E &= E << 1; E &= E << 2; E &= E << 4; E &= E << 8;
-                    const unsigned long long ends = E & ~(Af >> 1) & 0x7fffffffffffffffull;   // full lanes, then one that is not
-                    const bool inherited_ends = hp && (Af & 0xffffull) != 0xffffull;
-                    if (ends == 0ull && !inherited_ends) {
-                        const bool open = (M3 >> 63) != 0ull;
-                        if (open) {                          // start of the run open at the end of the row
-                            int ns = hp ? -3 : base + ((row == 0) ? off0 : 0);
-                            unsigned long long z;
-                            z = ~M0; if (z) ns = max(ns, base + 4 * top_bit(z) + 1);
-                            z = ~M1; if (z) ns = max(ns, base + 4 * top_bit(z) + 2);
-                            z = ~M2; if (z) ns = max(ns, base + 4 * top_bit(z) + 3);
-                            z = ~M3; if (z) ns = max(ns, base + 4 * top_bit(z) + 4);
-                            S = max(S, max(ns, last_start));
-                        }
-                        hp = open;
-                        continue;
-                    }
-                }
-
-                // ---- exact run scan of the row, per lane: every lane knows which of its four slots is high, begins a read, or
-                // lies inside the tile; what it lacks -- is the slot before mine high, and where did the run that reaches me
-                // begin -- comes from one wave shift and one max-scan.  (The first version did this as scalar bit logic on
-                // twenty 64-bit masks: 250-300 scalar instructions per row under the kernel's worst register pressure, for the
-                // 17 % of the rows in which a kept run may end.)
+                // ---- run scan of the row, per lane: every lane knows which of its four slots is high, begins a read, or lies
+                // inside the tile; what it lacks -- is the slot before mine high, and where did the run that reaches me begin --
+                // comes from one wave shift and one max-scan.  (The first version did this as scalar bit logic on twenty 64-bit
+                // masks -- 250-300 scalar instructions per row under the kernel's worst register pressure -- behind a filter
+                // that recognised by whole lanes the rows in which no run long enough to be kept could end; with the scan at
+                // ~60 vector instructions the filter costs more than it saves.)
                 {
                     const int hk = (row == 0) ? off0 : 0;     // the carried-in "previous slot is high" belongs to the first valid slot
                     int hv[4], sbv[4], prv[4];
                     hv[0] = (int)((M0 >> lane) & 1ull); hv[1] = (int)((M1 >> lane) & 1ull);
                     hv[2] = (int)((M2 >> lane) & 1ull); hv[3] = (int)((M3 >> lane) & 1ull);
-                    sbv[0] = sbv[1] = sbv[2] = sbv[3] = 0;
-                    if (start_lanes) {
-                        sbv[0] = (int)((SB0 >> lane) & 1ull); sbv[1] = (int)((SB1 >> lane) & 1ull);
-                        sbv[2] = (int)((SB2 >> lane) & 1ull); sbv[3] = (int)((SB3 >> lane) & 1ull);
-                    }
+                    sbv[0] = sbm & 1; sbv[1] = (sbm >> 1) & 1; sbv[2] = (sbm >> 2) & 1; sbv[3] = (sbm >> 3) & 1;
                     prv[0] = wave_shr1(hv[3], 0); prv[1] = hv[0]; prv[2] = hv[1]; prv[3] = hv[2];
                     if (hp && lane == 0) {
 #pragma unroll
