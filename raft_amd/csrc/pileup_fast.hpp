@@ -504,38 +504,31 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                 // that recognised by whole lanes the rows in which no run long enough to be kept could end; with the scan at
                 // ~60 vector instructions the filter costs more than it saves.)
                 {
+                    // the lane's four slots as four bits: high, read begins, previous slot high, run starts, run ends before
                     const int hk = (row == 0) ? off0 : 0;     // the carried-in "previous slot is high" belongs to the first valid slot
-                    int hv[4], sbv[4], prv[4];
-                    hv[0] = (int)((M0 >> lane) & 1ull); hv[1] = (int)((M1 >> lane) & 1ull);
-                    hv[2] = (int)((M2 >> lane) & 1ull); hv[3] = (int)((M3 >> lane) & 1ull);
-                    sbv[0] = sbm & 1; sbv[1] = (sbm >> 1) & 1; sbv[2] = (sbm >> 2) & 1; sbv[3] = (sbm >> 3) & 1;
-                    prv[0] = wave_shr1(hv[3], 0); prv[1] = hv[0]; prv[2] = hv[1]; prv[3] = hv[2];
-                    if (hp && lane == 0) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) if (hk == k) prv[k] = 1;
-                    }
-                    int ls = -0x40000000;                     // last slot of this lane at which a run starts
-                    int ls_before[4];                         // ... among the slots before slot k
-                    int endb[4];                              // a run ends before slot k
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        ls_before[k] = ls;
-                        const int inside = tail ? (p0 + k < t_end ? 1 : 0) : 1;
-                        endb[k] = prv[k] & ((hv[k] ^ 1) | sbv[k]) & inside;
-                        if (hv[k] & ((prv[k] ^ 1) | sbv[k])) ls = p0 + k;
-                    }
+                    const int hvn = (int)((M0 >> lane) & 1ull) | ((int)((M1 >> lane) & 1ull) << 1) | ((int)((M2 >> lane) & 1ull) << 2) |
+                                    ((int)((M3 >> lane) & 1ull) << 3);
+                    int prvn = ((hvn << 1) & 15) | wave_shr1(hvn >> 3, 0);
+                    if (hp && lane == 0) prvn |= 1 << hk;
+                    int inside = 15;
+                    if (tail) inside = (1 << min(max(t_end - p0, 0), 4)) - 1;
+                    const int starts = hvn & ((prvn ^ 15) | sbm);
+                    int ends = prvn & ((hvn ^ 15) | sbm) & inside;
+                    const int ls = starts ? p0 + (31 - __clz(starts)) : -0x40000000;      // last slot of this lane at which a run starts
                     const int incl = wave_incl_scan_max(ls, -0x40000000);
                     const int carried = max(S, wave_shr1(incl, -0x40000000));      // start of the run that reaches this lane's first slot
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const unsigned long long em = __ballot(endb[k] != 0);
-                        if (em == 0ull) continue;
-                        const int best = max(carried, ls_before[k]);
+                    // ends of runs: every lane takes its first, then (rarely) its second
+                    while (__ballot(ends != 0) != 0ull) {
+                        const bool has = ends != 0;
+                        const int k = has ? __builtin_ctz(ends) : 0;
+                        const int below = starts & ((1 << k) - 1);                 // starts in this lane before slot k
+                        const int best = max(carried, below ? p0 + (31 - __clz(below)) : -0x40000000);
                         const int t = p0 + k;
-                        const unsigned long long inh = __ballot(endb[k] != 0 && best == kOpen);
+                        ends &= ends - 1;
+                        const unsigned long long inh = __ballot(has && best == kOpen);
                         if (inh) pclose = __builtin_amdgcn_readlane(t, (int)__builtin_ctzll(inh));   // the inherited run: its start is known after the barrier
                         // repeat.hpp:125,150 -- except at the edges of a PIECE of a long read (see park())
-                        const bool keep = endb[k] != 0 && best >= 0 &&
+                        const bool keep = has && best >= 0 &&
                                           ((long long)(t - best) * a.reso >= (long long)a.repeat_length || (piece && (best == off0 || t == t_end)));
                         const unsigned long long km = __ballot(keep);
                         if (km) {
