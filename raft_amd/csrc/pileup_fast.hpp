@@ -15,8 +15,9 @@
 //     per-read tables are double-buffered -- those of tile i+1 are written from the prefetched registers just
 //     before pass B of tile i, the repeat counts of tile i-1 are published at the same point -- so no clearing
 //     phase, no table phase and no publish phase stand between barriers;
-//   * the run scan is scalar code on four 64-bit ballots per row; rows that cannot end a run long enough to be kept
-//     are recognised by whole lanes of four windows; read boundaries come from registers, not from an LDS bit array;
+//   * four ballots per row tell whether it holds a high window at all; the run scan of the rows that do is done per
+//     lane on the lane's four slots as four bits (one wave shift for "is the slot before mine high", one max-scan for
+//     "where did the run that reaches me begin"); read boundaries come from registers, not from an LDS bit array;
 //   * coverage totals accumulate per lane in registers and are reduced once per workgroup, not once per tile.
 // Reference semantics: repeat.hpp:28-79 (profileCoverage), repeat.hpp:111-168 (run scan); see pileup.hpp.
 #pragma once
