@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_ABI_VERSION 4
+#define RAFT_HIP_ABI_VERSION 5
 
 /* error codes (0..5 are shared with oracle/raft_oracle.h) */
 enum {
@@ -129,9 +129,13 @@ void *raft_hip_get_stream(raft_hip_ctx *ctx);
  * every kernel; returns after the last launch, not after completion.  It waits
  * for the device once on the way (sizes of the coverage array and choice of
  * interval path come back together), which is part of the cost of a pass.
- * d_read_len must stay valid until the outputs have been fetched: the cut points
- * (chop.hpp's final_stars) are materialised by the first raft_hip_fetch() /
- * raft_hip_outputs_device() that asks for them, not by the pass. */
+ * Every input column must stay valid and unchanged until raft_hip_finish() has
+ * returned: a pass that a kernel refutes (a stream that is not what its samples
+ * suggested, an exception list that overflowed) is run again from the same
+ * pointers inside raft_hip_finish().  d_read_len must stay valid until the outputs
+ * have been fetched: the cut points (chop.hpp's final_stars) are materialised by
+ * the first raft_hip_fetch() / raft_hip_outputs_device() that asks for them, not
+ * by the pass. */
 int  raft_hip_run_device(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *d_read_len,
                          int64_t n_rec, const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
                          const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te);
@@ -141,6 +145,30 @@ int  raft_hip_run_device(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *d_re
 int  raft_hip_run_host(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_len,
                        int64_t n_rec, const int32_t *qid, const int32_t *qs, const int32_t *qe,
                        const int32_t *tid, const int32_t *ts, const int32_t *te);
+
+/* The same pass over GROUPED input.  hifiasm writes its PAF grouped by query (reference README.md:36-38; the records
+ * reach create_pileup in that order, chop.hpp:147-169) and a tokeniser that resolves every name knows where each read's
+ * records begin: the record stream is n_runs (1..4) runs, each sorted by query id, and
+ *     rec_offset[k * (n_reads + 1) + r]  =  index of the first record of read r in run k,
+ * entry n_reads of a run closing it: rec_offset[0] = 0, run k + 1 begins where run k ends, the last run ends at n_rec,
+ * offsets never step back (raft_host_paf_grouped() builds this from the tokenised columns).  What create_pileup's
+ * bucketing has to find out is then handed over -- query sides only, so the context must assert symmetric_mode = 1:
+ *   * no look at the record stream before the pass, no searches for the tile cuts (look-ups in rec_offset);
+ *   * d_qid may be NULL: the ids ARE the offsets and are rebuilt on the device (4 of the 12 bytes per record need not
+ *     cross PCIe -- the host forms below never upload them).  When it is given, every record is checked against the
+ *     reads of the tile that processes it, and a record that does not sit where the offsets say sends the pass to the
+ *     plain form above (results as from raft_hip_run_device, whatever the offsets were);
+ *   * n_bins >= 0: the caller's sum of ceil(len / reso) over the reads (the loader of the reads has the lengths).  The
+ *     host then sizes every buffer without waiting for the device -- the pass is one uninterrupted sequence of launches;
+ *     a count that is not what the lengths give is noticed on the device and costs a second pass.  n_bins = -1: unknown,
+ *     the pass waits for the device once, as raft_hip_run_device does.
+ * Errors: offsets that step back or do not chain from 0 to n_rec -> RAFT_HIP_ERR_PARAM (error_index = the read). */
+int  raft_hip_run_device_grouped(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *d_read_len, int64_t n_rec, int32_t n_runs,
+                                 const int64_t *d_rec_offset, const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
+                                 int64_t n_bins);
+/* ... from host memory: uploads read_len, rec_offset, qs, qe (8 bytes per record instead of 12); n_bins = -1: counted here. */
+int  raft_hip_run_host_grouped(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec, int32_t n_runs,
+                               const int64_t *rec_offset, const int32_t *qs, const int32_t *qe, int64_t n_bins);
 
 /* Waits for the pass, reads back its scalars and reports data errors found on
  * the device (RAFT_HIP_ERR_READ_ID / _COORD / _FRAGMENT). */
@@ -160,8 +188,9 @@ int  raft_hip_fetch(raft_hip_ctx *ctx, int64_t *cov_offset, int32_t *cov,
  * plus the windows with cov >= 255 as (exc_index, exc_value) pairs, ascending by window index (cov[] is two thirds of
  * the bytes that cross PCIe; the reference's consumer is the text formatter of repeat.hpp:105-108, which
  * raft_host_write_coverage_packed() serves from this form; raft_host_unpack_coverage() restores the int32 array).
- * *n_exc receives the number of exceptions; when it exceeds exc_cap nothing is copied and RAFT_HIP_ERR_TOO_LARGE is
- * returned -- call again with larger arrays.  Any pointer except n_exc may be NULL to skip that array. */
+ * *n_exc receives the number of exceptions; when it exceeds exc_cap and any of cov8 / exc_index / exc_value is asked
+ * for, nothing is copied and RAFT_HIP_ERR_TOO_LARGE is returned -- call again with larger arrays (the size query, all
+ * three NULL, always succeeds).  Any pointer except n_exc may be NULL to skip that array. */
 int  raft_hip_fetch_packed(raft_hip_ctx *ctx, int64_t *cov_offset, uint8_t *cov8, int64_t exc_cap, int64_t *exc_index,
                            int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
                            int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end);
@@ -192,7 +221,9 @@ int  raft_hip_packed_device(raft_hip_ctx *ctx, int32_t *width, const void **cov_
  * and N = n_reads:
  *   cov8_cap >= W;   frag_cap >= (sum len) / interval_length + 2 N;   rep_cap >= (W + N) / (ceil(repeat_length/reso) + 1).
  * cov_offset / rep_offset / frag_offset hold n_reads + 1 entries.  frag_read is not returned: fragment f of read i is
- * every f in [frag_offset[i], frag_offset[i+1]).  n_exc is written by the call. */
+ * every f in [frag_offset[i], frag_offset[i+1]).  n_exc is written by the call; exc_cap is one limit for the whole job
+ * however many devices share it, and when it is too small the call returns RAFT_HIP_ERR_TOO_LARGE with the number of
+ * exceptions the job has in n_exc (one retry with that much room suffices). */
 typedef struct raft_hip_host_outputs {
     int64_t *cov_offset;  uint8_t *cov8;      int64_t cov8_cap;
     int64_t *exc_index;   int32_t *exc_value; int64_t exc_cap;   int64_t n_exc;
@@ -228,6 +259,13 @@ int  raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_read
                         const int32_t *qid, const int32_t *qs, const int32_t *qe,
                         const int32_t *tid, const int32_t *ts, const int32_t *te,
                         int32_t n_chunks, raft_hip_host_outputs *out, raft_hip_summary *summary);
+
+/* raft_hip_run_multi (n_ctx = 1: raft_hip_run_pipelined) over grouped input (see raft_hip_run_device_grouped): the
+ * caller's offsets replace the query column -- a third of the upload that bounds the host-to-host rate -- and the host's
+ * plan needs no search in the record stream.  Contexts must assert symmetric_mode = 1.  Same outputs, same errors. */
+int  raft_hip_run_multi_grouped(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                                int32_t n_runs, const int64_t *rec_offset, const int32_t *qs, const int32_t *qe,
+                                int32_t n_chunks, raft_hip_host_outputs *out, raft_hip_summary *summary);
 
 /* Device seconds spent in the dominant kernel (coverage pileup + run scan) and
  * in all kernels of the last finished pass, from HIP events recorded on the

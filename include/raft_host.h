@@ -71,6 +71,15 @@ const int32_t *raft_host_paf_column(const raft_host_paf *p, int k);        /* k:
  * neither runs its own detection nor needs the three target columns. */
 int            raft_host_paf_symmetric(const raft_host_paf *p);
 
+/* The grouped form of a tokenised query column, for raft_hip_run_*_grouped (include/raft_hip.h): hifiasm writes its PAF
+ * grouped by query (reference README.md:36-38; create_pileup meets the records in that order, chop.hpp:147-169), so the
+ * column is a handful of runs sorted by read id.  When it is at most max_runs such runs and every id lies in
+ * [0, n_reads), *n_runs receives their number and rec_offset[k * (n_reads + 1) + r] the index of the first record of
+ * read r in run k (entry n_reads closes the run); otherwise *n_runs = 0 and the caller stays with the per-record ids.
+ * rec_offset holds max_runs * (n_reads + 1) entries (page-locked when it is to be uploaded at the link's rate). */
+int raft_host_group_offsets(int32_t n_reads, int64_t n_rec, const int32_t *qid, int32_t max_runs, int32_t *n_runs,
+                            int64_t *rec_offset);
+
 /* Coverage in the engine's transfer encoding (raft_hip_fetch_packed: one byte per window, 255 = look up the ascending
  * exception list): back to int32, and straight to coverage.txt (repeat.hpp:105-108) without the int32 detour. */
 int raft_host_unpack_coverage(int64_t n_bins, const uint8_t *cov8, int64_t n_exc, const int64_t *exc_index,

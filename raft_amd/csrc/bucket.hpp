@@ -122,13 +122,37 @@ __global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const 
 
 // tile_first[k] = first read whose first window lies in tile k or later (tiles of Q windows).
 __global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const long long *cov_off, int Q,
-                                                         long long n_tiles, int32_t *tile_first)
+                                                         long long n_tiles, int32_t *tile_first, const int32_t *err_flags)
 {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > n_reads) return;
+    if (*(volatile const int32_t *)err_flags & kErrStop) return;   // (n_tiles comes from a window count the device found wrong)
     const long long t_r = (r < n_reads) ? cov_off[r] / Q : n_tiles;
     const long long t_p = (r > 0) ? cov_off[r - 1] / Q : -1;
     for (long long k = t_p + 1; k <= t_r; ++k) tile_first[k] = (int32_t)r;
+}
+
+// Grouped input without a query column: the ids are what the offsets say.  One wave per 64 consecutive reads and run: the
+// lanes hold their reads' ranges, and the wave writes each read's id over its range (a read has ~45 records in a run:
+// one store instruction per read, two for a read inside a repeat).
+__global__ __launch_bounds__(256) void expand_ids_kernel(int32_t n_reads, int32_t n_runs, GroupedOff grp, int32_t *qid,
+                                                         const int32_t *err_flags)
+{
+    if (*(volatile const int32_t *)err_flags & kErrStop) return;   // (offsets that step back or leave [0, n_rec])
+    const int lane = threadIdx.x & 63;
+    const long long n_groups = ((long long)n_reads + 63) >> 6;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long w = wave0; w < n_groups * n_runs; w += n_waves) {
+        const int s = (int)(w / n_groups);
+        const long long r0 = (w - (long long)s * n_groups) << 6;
+        const long long r = r0 + lane;
+        const long long lo = r < n_reads ? grp.at(s, r) : 0, hi = r < n_reads ? grp.at(s, r + 1) : 0;
+        const int n_in = (int)min(64LL, (long long)n_reads - r0);
+        for (int l = 0; l < n_in; ++l) {
+            const long long a = __shfl(lo, l, kWave), b = __shfl(hi, l, kWave);
+            for (long long i = a + lane; i < b; i += kWave) qid[i] = (int32_t)(r0 + l);
+        }
+    }
 }
 
 // ---- counting sort by read id ------------------------------------------------

@@ -131,8 +131,25 @@ struct ReadPrepLoader {               // per read: windows, reserved repeat slot
     int32_t long_windows, piece_w;    // reads longer than long_windows are piled up in pieces of piece_w windows
     int32_t *err_flags;
     long long *err_index;
+    // grouped input: the offsets of every run must not step back, and the runs must chain from record 0 to record n_rec
+    GroupedOff grp;
+    int32_t n_runs, n_reads;
+    long long n_rec;
     __device__ void operator()(long long i, long long (&v)[3]) const
     {
+        if (grp.off) {
+            bool bad = false;
+            for (int s = 0; s < n_runs; ++s) bad |= grp.at(s, i) > grp.at(s, i + 1);
+            if (i == 0) {
+                long long at = 0;
+                for (int s = 0; s < n_runs; ++s) { bad |= grp.at(s, 0) != at; at = grp.at(s, n_reads); }
+                bad |= at != n_rec;
+            }
+            if (bad) {
+                atomicOr(err_flags, kErrGroup);
+                atomicMin((unsigned long long *)err_index, (unsigned long long)i);
+            }
+        }
         int l = len[i];
         if (l < 0) {
             atomicOr(err_flags, kErrLen);
@@ -158,9 +175,12 @@ template <int K> struct CountLoader {
 
 // What the host reads back goes straight into its page-locked block (device-visible host memory): a copy command per
 // few bytes cost ~25 us each on the device timeline (three of them ahead of the pass's host wait).
-__global__ void publish_sizes_kernel(const long long *scan_totals, const Ctrl *ctrl, long long *host)
+__global__ void publish_sizes_kernel(const long long *scan_totals, Ctrl *ctrl, long long *host, long long hint_bins)
 {
     const int t = threadIdx.x;
+    // a pass without a host wait was sized by the caller's window count: if that is not what the lengths give, every later
+    // kernel returns at once (kErrHint) and raft_hip_finish runs the pass again, waiting for the sizes this time
+    if (t == 0 && hint_bins >= 0 && scan_totals[0] != hint_bins) atomicOr(&ctrl->err_flags, kErrHint);
     if (t < 3) host[t] = scan_totals[t];
     const long long *c8 = reinterpret_cast<const long long *>(ctrl);
     if (t < 2) host[4 + t] = c8[t];                                           // err_flags, n_slow, err_index
@@ -232,7 +252,15 @@ struct raft_hip_ctx {
     // a pass that verifies in its kernels (see run_pass), and the arguments to run it again if a kernel objects
     bool spec = false;
     bool assume_sym = true;            // what a detecting context's verified pass assumes (the last detection's answer)
-    struct PassArgs { int32_t n_reads; const int32_t *len; int64_t n_rec; const int32_t *col[6]; } args{};
+    // grp_*: the grouped form (raft_hip_run_device_grouped): per-run record offsets instead of searches; hint_bins >= 0: the
+    // caller's window count, which sizes the pass without a host wait
+    struct PassArgs {
+        int32_t n_reads; const int32_t *len; int64_t n_rec; const int32_t *col[6];
+        int32_t n_runs; const long long *rec_off; long long adj[kMaxSeg]; long long hint_bins;
+    } args{};
+    bool grouped = false;              // the last pass was built on the caller's offsets (verified in its kernels)
+    bool no_wait = false;              // ... and sized by the caller's window count: nothing was read back on the way
+    DevBuf exp_qid, in_off;            // grouped input without a query column: the ids rebuilt from the offsets; staged offsets
 
     // state of the last pass
     bool ran = false, finished = false;
@@ -280,11 +308,11 @@ void apply_params(raft_hip_ctx *c, const raft_hip_params *p)
 
 int code_from_flags(int flags)
 {
-    if (flags & kErrLen) return RAFT_HIP_ERR_PARAM;
+    if (flags & (kErrLen | kErrGroup)) return RAFT_HIP_ERR_PARAM;
     if (flags & kErrReadId) return RAFT_HIP_ERR_READ_ID;
     if (flags & kErrCoord) return RAFT_HIP_ERR_COORD;
     if (flags & kErrFragment) return RAFT_HIP_ERR_FRAGMENT;
-    if (flags & (kErrInternal | kErrOrder | kErrExtra)) return RAFT_HIP_ERR_DEVICE;   // (kErrOrder never outlives raft_hip_finish's second run)
+    if (flags & (kErrInternal | kErrOrder | kErrExtra | kErrHint)) return RAFT_HIP_ERR_DEVICE;   // (kErrOrder / kErrHint never outlive raft_hip_finish's second run)
     return RAFT_HIP_OK;
 }
 
@@ -365,7 +393,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->dbg, &c->samples, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -431,31 +459,49 @@ int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket
 // the pass to the second form too, and the context then stops assuming until a pass of its own detects a symmetric PAF.
 // (Measured and dropped: starting on the guess and running inspect_kernel BESIDE the pileup kernels on a low-priority
 // stream -- it costs the pileup what it would cost alone, 0.15-0.2 ms; the pass did not get shorter.)
-static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int64_t n_rec,
-                    const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
-                    const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te, bool verify_in_kernels)
+//
+// The grouped form (raft_hip_run_device_grouped; `in.rec_off`): the caller says where every read's records begin in every
+// run, so nothing is guessed or searched -- the runs are what the offsets say, tile cuts are look-ups -- and, as in a
+// verified pass, every record is still checked against the reads of the tile that processes it (with a query column
+// at hand; without one the ids ARE the offsets, expanded on the device).  A record that does not sit where the offsets
+// say sends the pass to the plain form above.  With the caller's window count (`in.hint_bins`) the host sizes everything
+// without waiting for the device: the pass is one uninterrupted sequence of launches.
+static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool verify_in_kernels)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
+    const int32_t n_reads = in.n_reads;
+    const int64_t n_rec = in.n_rec;
+    const int32_t *d_len = in.len, *d_qid = in.col[0], *d_qs = in.col[1], *d_qe = in.col[2], *d_tid = in.col[3], *d_ts = in.col[4],
+                  *d_te = in.col[5];
+    const bool grouped = in.rec_off != nullptr;
     if (n_reads < 0 || n_rec < 0) return RAFT_HIP_ERR_PARAM;
     if (n_reads > 0 && !d_len) return RAFT_HIP_ERR_PARAM;
-    if (n_rec > 0 && (!d_qid || !d_qs || !d_qe)) return RAFT_HIP_ERR_PARAM;
+    if (grouped && (in.n_runs < 1 || in.n_runs > kMaxSeg || c->prm.symmetric_mode != 1)) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && ((!d_qid && !grouped) || !d_qs || !d_qe)) return RAFT_HIP_ERR_PARAM;
+    if (n_reads == INT32_MAX) return RAFT_HIP_ERR_TOO_LARGE;
+    if (n_rec >= (1LL << 29)) return RAFT_HIP_ERR_TOO_LARGE;   // interval byte offsets are 32-bit (2 sides per record at most)
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    bool expand = false;
+    if (n_rec > 0 && grouped && !d_qid) {                      // no query column: the ids are rebuilt from the offsets
+        HIP_TRY(c, c->exp_qid.ensure((size_t)n_rec * 4));
+        d_qid = c->exp_qid.as<int32_t>();
+        expand = true;
+    }
     if (n_rec > 0 && (!d_tid || !d_ts || !d_te)) {
         // symmetric_mode = 1: the target columns are never read (query sides only, no detection) and may be omitted
         if (c->prm.symmetric_mode != 1) return RAFT_HIP_ERR_PARAM;
         d_tid = d_qid; d_ts = d_qs; d_te = d_qe;
     }
-    if (n_reads == INT32_MAX) return RAFT_HIP_ERR_TOO_LARGE;
-    if (n_rec >= (1LL << 29)) return RAFT_HIP_ERR_TOO_LARGE;   // interval byte offsets are 32-bit (2 sides per record at most)
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t st = c->stream;
     c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1; c->packed_width = 0;
     c->cov_valid = false; c->pass_width = 4; c->n_exc = 0;
-    c->args = {n_reads, d_len, n_rec, {d_qid, d_qs, d_qe, d_tid, d_ts, d_te}};
+    c->args = in;
     const bool no_verify_env = getenv("RAFT_ALWAYS_INSPECT") != nullptr;   // (A/B measurements; bench.py times both forms)
     // (a detecting context assumes a symmetric PAF -- hifiasm's shape -- until a pass of its own has found otherwise)
-    const bool spec = verify_in_kernels && !no_verify_env && n_rec > 1 && !c->force_bucket &&
+    const bool spec = !grouped && verify_in_kernels && !no_verify_env && n_rec > 1 && !c->force_bucket &&
                       (c->prm.symmetric_mode == 1 || (c->prm.symmetric_mode < 0 && c->assume_sym));
     c->spec = spec;
+    c->grouped = grouped;
     memset(&c->sum, 0, sizeof c->sum);
     c->sum.n_reads = n_reads; c->sum.n_records = n_rec; c->sum.high_cov = c->high_cov; c->sum.error_index = -1;
     const long long N = n_reads;
@@ -466,6 +512,9 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     // the encoding of cov[] is written directly when every tile goes through the fast kernel (pileup_fast.hpp OW); a pass
     // the general kernel takes part in writes int32 and raft_hip_fetch_packed_w encodes it afterwards, as it always did
     const int ow = (c->out_width != 4 && recut && c->variant != kDiagVariant) ? c->out_width : 4;
+    // a grouped pass whose caller announced the window count needs nothing back from the device on the way
+    const bool no_wait = grouped && in.hint_bins >= 0 && getenv("RAFT_NO_HINT") == nullptr;
+    c->no_wait = no_wait;
     HIP_TRY(c, hipEventRecord(c->ev_pass0, st));
     HIP_TRY(c, c->ctrl.ensure(sizeof(Ctrl)));
     Ctrl *ctrl = c->ctrl.as<Ctrl>();
@@ -477,6 +526,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     //  (main stream) what the record stream looks like -- sorted runs sampled by guess_runs_kernel and, unless the pass
     //      verifies in its kernels, every record by inspect_kernel: ids in range? the runs as sampled? mirror of record 0?
     //  (side stream) the per-read geometry: windows, reserved repeat slots, marker capacity (one scan, three sums).
+    // (a grouped pass has nothing to find out about the stream: the scan runs on the main stream, nothing beside it)
     long long *h = reinterpret_cast<long long *>(c->pinned);
     InspectOut *hi = reinterpret_cast<InspectOut *>(h + 8);
     GuessOut *hg = reinterpret_cast<GuessOut *>(h + 32);
@@ -486,20 +536,27 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     HIP_TRY(c, c->cov_off.ensure((size_t)(N + 1) * 8));
     HIP_TRY(c, c->rep_res_off.ensure((size_t)(N + 1) * 8));
     HIP_TRY(c, c->cutcap_off.ensure((size_t)(N + 1) * 8));
-    const bool want_guess = n_rec > 1 && c->prm.symmetric_mode != 0 && !c->force_bucket;   // (the sorted-segment path is possible)
+    const bool want_guess = !grouped && n_rec > 1 && c->prm.symmetric_mode != 0 && !c->force_bucket;   // (the sorted-segment path is possible)
     if (want_guess) HIP_TRY(c, c->samples.ensure((size_t)(kSamples + 2) * 4));
+    GroupedOff grp{};
+    if (grouped) {
+        grp.off = in.rec_off; grp.stride = N + 1;
+        for (int s2 = 0; s2 < kMaxSeg; ++s2) grp.adj[s2] = in.adj[s2];
+    }
     long long *scan_totals = nullptr;
     {
-        hipStream_t gst = c->side_stream;
-        HIP_TRY(c, hipEventRecord(c->ev_ifork, st));                        // (the control block is clear)
-        HIP_TRY(c, hipStreamWaitEvent(gst, c->ev_ifork, 0));
+        hipStream_t gst = grouped ? st : c->side_stream;
+        if (!grouped) {
+            HIP_TRY(c, hipEventRecord(c->ev_ifork, st));                    // (the control block is clear)
+            HIP_TRY(c, hipStreamWaitEvent(gst, c->ev_ifork, 0));
+        }
         ReadPrepLoader ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, recut ? pv.cap : INT32_MAX, pv.cap,
-                          &ctrl->err_flags, &ctrl->err_index};
+                          &ctrl->err_flags, &ctrl->err_index, grp, in.n_runs, n_reads, (long long)n_rec};
         ScanOut<3> so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), c->cutcap_off.as<long long>()}};
         exclusive_scan<ReadPrepLoader, 3>(gst, ld, N, c->scan_tmp.as<long long>(), so, &scan_totals);
-        HIP_TRY(c, hipEventRecord(c->ev_gjoin, gst));
+        if (!grouped) HIP_TRY(c, hipEventRecord(c->ev_gjoin, gst));
     }
-    if (n_rec > 0) {
+    if (n_rec > 0 && !grouped) {
         if (want_guess)
             hipLaunchKernelGGL(guess_runs_kernel, dim3(kGuessBlocks), dim3(256), 0, st, (long long)n_rec, d_qid, &ctrl->guess,
                                c->samples.as<int32_t>());
@@ -507,11 +564,19 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
             hipLaunchKernelGGL(inspect_kernel, dim3(igrid), dim3(256), 0, st, (long long)n_rec, n_reads,
                                c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
     }
-    HIP_TRY(c, hipStreamWaitEvent(st, c->ev_gjoin, 0));
-    hipLaunchKernelGGL(publish_sizes_kernel, dim3(1), dim3(64), 0, st, scan_totals, ctrl, c->pinned_dev);
-    HIP_TRY(c, hipStreamSynchronize(st));                                   // the pass's only host wait: sizes + path choice
-    const long long B = h[0], RU = h[1], CU = h[2];
-    {
+    if (!grouped) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_gjoin, 0));
+    hipLaunchKernelGGL(publish_sizes_kernel, dim3(1), dim3(64), 0, st, scan_totals, ctrl, c->pinned_dev, no_wait ? in.hint_bins : -1LL);
+    long long B, RU, CU;
+    if (no_wait) {
+        // sizes from the caller's window count: B as announced (checked on the device, kErrHint); bounds for the rest --
+        // reserved raw-repeat slots sum_r ((w_r + 1) / (minbins + 1) + two per piece of a long read), markers sum_r (len_r / L + 2)
+        B = in.hint_bins;
+        RU = (B + N) / ((long long)c->minbins + 1) + 4 * (B / pv.cap) + 4;
+        CU = B / std::max(1, c->prm.interval_length / c->prm.reso) + 2 * N + 2;
+        if (c->prm.interval_length < c->prm.reso) CU = B * ((long long)c->prm.reso / c->prm.interval_length + 1) + 2 * N + 2;
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(st));                               // the pass's only host wait: sizes + path choice
+        B = h[0]; RU = h[1]; CU = h[2];
         const int32_t flags = reinterpret_cast<int32_t *>(h + 4)[0];
         if (flags) {
             c->pending_err = code_from_flags(flags);
@@ -577,19 +642,25 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     HIP_TRY(c, hipMemsetAsync(c->rep_cnt.p, 0, (size_t)std::max(N, 1LL) * 4, st));
 
     hipLaunchKernelGGL(tile_first_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, st, n_reads,
-                       c->cov_off.as<long long>(), Q, n_tiles, c->tile_first.as<int32_t>());
+                       c->cov_off.as<long long>(), Q, n_tiles, c->tile_first.as<int32_t>(), &ctrl->err_flags);
+    if (expand)
+        hipLaunchKernelGGL(expand_ids_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(((N + 63) / 64 * in.n_runs + 3) / 4, 256 * 16))),
+                           dim3(256), 0, st, n_reads, in.n_runs, grp, c->exp_qid.as<int32_t>(), &ctrl->err_flags);
 
     int symmetric = c->prm.symmetric_mode == 1 ? 1 : 0;
     int n_desc = 0;
     long long desc[kMaxSeg];
     bool table_ok = false;
-    if (spec) {
+    if (grouped) {
+        symmetric = 1;
+        n_desc = in.n_runs - 1;
+    } else if (spec) {
         symmetric = 1;
         n_desc = hg->n_desc;
         for (int i = 0; i < std::min(n_desc, kMaxSeg); ++i) desc[i] = hg->desc_pos[i];
         table_ok = n_desc + 1 <= kMaxSeg;            // (the samples index the stream the pass is built on)
         if (c->prm.symmetric_mode < 0 && !table_ok)  // detecting, and not a handful of sorted runs: look at every record after all
-            return run_pass(c, n_reads, d_len, n_rec, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, false);
+            return run_pass(c, in, false);
     } else if (n_rec > 0) {
         if (hi->err_flags) {
             c->pending_err = code_from_flags(hi->err_flags);
@@ -641,6 +712,10 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
     if (n_rec == 0) {
         pa.n_seg = 0;
         c->sum.interval_path = 0; c->sum.n_segments = 0; c->sum.n_intervals = 0;
+    } else if (grouped) {
+        sb.n_seg = in.n_runs;                         // (where the runs begin is in the offsets, on the device)
+        pa.iv_rid = d_qid; pa.iv_s = d_qs; pa.iv_e = d_qe; pa.n_seg = sb.n_seg;
+        c->sum.interval_path = 0; c->sum.n_segments = sb.n_seg; c->sum.n_intervals = n_rec;
     } else if (fast) {
         std::sort(desc, desc + n_desc);
         sb.n_seg = n_desc + 1;
@@ -683,7 +758,7 @@ static int run_pass(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int6
                        pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow,
                        (fast && table_ok) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
                        c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags,
-                       recut ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir);
+                       recut ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp);
     pa.n_extra = recut ? &ctrl->n_extra : nullptr;
     pa.piece_w = pv.cap;
 
@@ -776,7 +851,33 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
                         const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
                         const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te)
 {
-    return run_pass(c, n_reads, d_len, n_rec, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, true);
+    raft_hip_ctx::PassArgs in{};
+    in.n_reads = n_reads; in.len = d_len; in.n_rec = n_rec;
+    in.col[0] = d_qid; in.col[1] = d_qs; in.col[2] = d_qe; in.col[3] = d_tid; in.col[4] = d_ts; in.col[5] = d_te;
+    in.hint_bins = -1;
+    return run_pass(c, in, true);
+}
+
+static int run_grouped(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int64_t n_rec, int32_t n_runs, const int64_t *d_rec_offset,
+                       const long long *adj, const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe, int64_t n_bins)
+{
+    if (!c || !d_rec_offset) return RAFT_HIP_ERR_PARAM;
+    if (c->force_bucket && d_qid && c->prm.symmetric_mode == 1)          // (tests, A/B: the counting-sort path needs no offsets)
+        return raft_hip_run_device(c, n_reads, d_len, n_rec, d_qid, d_qs, d_qe, nullptr, nullptr, nullptr);
+    raft_hip_ctx::PassArgs in{};
+    in.n_reads = n_reads; in.len = d_len; in.n_rec = n_rec;
+    in.col[0] = d_qid; in.col[1] = d_qs; in.col[2] = d_qe;
+    in.n_runs = n_runs; in.rec_off = reinterpret_cast<const long long *>(d_rec_offset);
+    for (int s = 0; s < kMaxSeg; ++s) in.adj[s] = adj ? adj[s] : 0;
+    in.hint_bins = n_bins >= 0 ? n_bins : -1;
+    return run_pass(c, in, true);
+}
+
+int raft_hip_run_device_grouped(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int64_t n_rec, int32_t n_runs,
+                                const int64_t *d_rec_offset, const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
+                                int64_t n_bins)
+{
+    return run_grouped(c, n_reads, d_len, n_rec, n_runs, d_rec_offset, nullptr, d_qid, d_qs, d_qe, n_bins);
 }
 
 int raft_hip_run_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
@@ -812,44 +913,62 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->finished) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        auto ctrl_block = [&]() { Ctrl hc; memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl)); return hc; };
+        auto again = [&](const raft_hip_ctx::PassArgs &a) -> int {       // the pass once more, this time nothing assumed
+            const int rc = run_pass(c, a, false);
+            if (rc != RAFT_HIP_OK) return rc;
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->spec = false;
+            return RAFT_HIP_OK;
+        };
+        if (c->grouped && c->pending_err == RAFT_HIP_OK) {
+            const Ctrl hc = ctrl_block();
+            if (hc.err_flags & kErrHint) {
+                // the caller's window count is not what the read lengths give: the same pass, sized by the device's own count
+                auto a = c->args;
+                a.hint_bins = -1;
+                const int rc = again(a);
+                if (rc != RAFT_HIP_OK) return rc;
+            }
+        }
+        if (c->grouped && c->pending_err == RAFT_HIP_OK) {
+            const Ctrl hc = ctrl_block();
+            if ((hc.err_flags & (kErrOrder | kErrReadId)) && !(hc.err_flags & kErrStop) && c->args.col[0]) {
+                // a record does not sit where the caller's offsets say: the offsets are dropped and the query column is
+                // taken for what it is (the plain pass, after a look at every record)
+                auto a = c->args;
+                a.rec_off = nullptr; a.n_runs = 0; a.hint_bins = -1;
+                const int rc = again(a);
+                if (rc != RAFT_HIP_OK) return rc;
+            }
+        }
         if (c->spec && c->pending_err == RAFT_HIP_OK) {
             // did a kernel meet a record that refutes the sampled guess the pass was built on?
-            Ctrl hc;
-            memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));
+            const Ctrl hc = ctrl_block();
             c->spec = false;
             const bool no_mirror = c->prm.symmetric_mode < 0 && hc.insp.sym_found == 0;   // assumed symmetric, found no mirror
             if (no_mirror) c->assume_sym = false;
             if ((hc.err_flags & (kErrOrder | kErrReadId)) || no_mirror) {   // run it again, this time after looking at every record
-                const auto a = c->args;
-                const int rc = run_pass(c, a.n_reads, a.len, a.n_rec, a.col[0], a.col[1], a.col[2], a.col[3], a.col[4], a.col[5], false);
+                const int rc = again(c->args);
                 if (rc != RAFT_HIP_OK) return rc;
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
             }
         }
         if (c->pending_err == RAFT_HIP_OK) {
-            Ctrl hc;
-            memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));
-            if (hc.err_flags & kErrExtra) {                  // more extra tiles than room: this pass with the general kernel
-                const auto a = c->args;
+            const Ctrl hc = ctrl_block();
+            if ((hc.err_flags & kErrExtra) && !(hc.err_flags & kErrStop)) {   // more extra tiles than room: this pass with the general kernel
                 c->no_recut = true;
-                const int rc = run_pass(c, a.n_reads, a.len, a.n_rec, a.col[0], a.col[1], a.col[2], a.col[3], a.col[4], a.col[5], false);
+                const int rc = again(c->args);
                 c->no_recut = false;
                 if (rc != RAFT_HIP_OK) return rc;
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                c->spec = false;
             }
         }
         if (c->pending_err == RAFT_HIP_OK && c->pass_width != 4) {
-            Ctrl hc;
-            memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));
+            const Ctrl hc = ctrl_block();
             if ((long long)hc.n_exc > c->exc_cap && !(hc.err_flags & ~(kErrOrder | kErrExtra))) {
                 // more windows at or above the encoding's limit than the list held: once more with room for all of them
-                const auto a = c->args;
                 c->exc_cap = (long long)hc.n_exc;
-                const int rc = run_pass(c, a.n_reads, a.len, a.n_rec, a.col[0], a.col[1], a.col[2], a.col[3], a.col[4], a.col[5], false);
+                const int rc = again(c->args);
                 if (rc != RAFT_HIP_OK) return rc;
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                c->spec = false;
             }
         }
         if (c->pending_err == RAFT_HIP_OK) {
@@ -1012,7 +1131,8 @@ int raft_hip_fetch_packed_w(raft_hip_ctx *c, int32_t width, int64_t *cov_offset,
     if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
     { const int rc = pack_coverage(c, width); if (rc != RAFT_HIP_OK) return rc; }
     *n_exc = c->n_exc;
-    if (c->n_exc > exc_cap && cov_packed) return RAFT_HIP_ERR_TOO_LARGE;   // *n_exc tells the caller what to provide
+    // (*n_exc tells the caller what to provide; the size query -- every pointer NULL -- always succeeds)
+    if (c->n_exc > exc_cap && (cov_packed || exc_index || exc_value)) return RAFT_HIP_ERR_TOO_LARGE;
     const size_t N1 = (size_t)c->sum.n_reads + 1;
     struct { void *dst; const void *src; size_t bytes; } job[] = {
         {cov_packed, c->cov8.p, (size_t)c->sum.n_bins * (size_t)width}, {cov_offset, c->cov_off.p, N1 * 8},
@@ -1108,20 +1228,66 @@ struct PipeShared {                                 // the chain of one context'
     std::condition_variable cv;
     int uploaded = 0;                               // chunks whose H2D has been enqueued (ticket of the upload stream)
     int published = 0;                              // chunks whose sizes are known (bases of the next chunk)
-    long long base_bins = 0, base_rep = 0, base_frag = 0, base_exc = 0;
+    long long base_bins = 0, base_rep = 0, base_frag = 0;
     int error = RAFT_HIP_OK;                        // first failure; every lane stops at its next check
     std::string error_text;
 };
 
 } // namespace
 
+// windows of n reads: sum ceil(len / reso), the multiply-high division the kernels use (exact for 0 <= len < 2^31); -1 when
+// a length is negative (the pass reports it)
+static long long count_windows(const int32_t *len, long long n, int32_t reso_i)
+{
+    const unsigned reso = (unsigned)reso_i;
+    int lg = 0;
+    while ((1ull << lg) < reso) ++lg;
+    const unsigned long long magic = reso > 1 ? ((1ull << (31 + lg)) / reso + 1ull) : 0ull;
+    long long w = 0;
+    int32_t any_neg = 0;
+    for (long long i = 0; i < n; ++i) {
+        const unsigned l = (unsigned)len[i];
+        any_neg |= len[i];
+        const unsigned q = reso == 1 ? l : (unsigned)(((l * magic) >> 32) >> (lg - 1));
+        w += (long long)q + (l - q * reso ? 1 : 0);
+    }
+    return any_neg < 0 ? -1 : w;
+}
+
+int raft_hip_run_host_grouped(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, int32_t n_runs,
+                              const int64_t *rec_offset, const int32_t *qs, const int32_t *qe, int64_t n_bins)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    if (n_reads < 0 || n_rec < 0 || n_runs < 1 || n_runs > kMaxSeg || !rec_offset) return RAFT_HIP_ERR_PARAM;
+    if (n_reads > 0 && !read_len) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && (!qs || !qe)) return RAFT_HIP_ERR_PARAM;
+    if (c->prm.symmetric_mode != 1) return RAFT_HIP_ERR_PARAM;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t n_off = (size_t)n_runs * ((size_t)n_reads + 1);
+    HIP_TRY(c, c->in_len.ensure((size_t)std::max<long long>(n_reads, 1) * 4));
+    HIP_TRY(c, c->in_off.ensure(n_off * 8));
+    if (n_reads) HIP_TRY(c, hipMemcpyAsync(c->in_len.p, read_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->in_off.p, rec_offset, n_off * 8, hipMemcpyHostToDevice, st));
+    const int32_t *src[3] = {nullptr, qs, qe};
+    for (int k = 1; k < 3; ++k) {
+        HIP_TRY(c, c->in_col[k].ensure((size_t)std::max<long long>(n_rec, 1) * 4));
+        if (n_rec) HIP_TRY(c, hipMemcpyAsync(c->in_col[k].p, src[k], (size_t)n_rec * 4, hipMemcpyHostToDevice, st));
+    }
+    if (n_bins < 0) n_bins = count_windows(read_len, n_reads, c->prm.reso);      // (while the copies run)
+    return run_grouped(c, n_reads, c->in_len.as<int32_t>(), n_rec, n_runs, c->in_off.as<int64_t>(), nullptr, nullptr,
+                       c->in_col[1].as<int32_t>(), c->in_col[2].as<int32_t>(), n_bins);
+}
+
 static int run_monolithic_to_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, const int32_t *qid,
                                   const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts, const int32_t *te,
-                                  raft_hip_host_outputs *o, raft_hip_summary *summary)
+                                  raft_hip_host_outputs *o, raft_hip_summary *summary, int32_t n_runs = 0,
+                                  const int64_t *rec_offset = nullptr)
 {
     const int keep_width = c->out_width;
     c->out_width = o->cov_width == 2 ? 2 : 1;             // the pass writes the encoding the caller takes
-    int rc = raft_hip_run_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te);
+    int rc = rec_offset ? raft_hip_run_host_grouped(c, n_reads, read_len, n_rec, n_runs, rec_offset, qs, qe, -1)
+                        : raft_hip_run_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te);
     raft_hip_summary s{};
     if (rc == RAFT_HIP_OK) rc = raft_hip_finish(c, &s);
     c->out_width = keep_width;
@@ -1146,10 +1312,10 @@ struct DeviceJob {
     int first_chunk = 0, n_chunks = 0;
     // first entry of this job in the caller's arrays: windows are known in advance (read lengths); repeats, fragments and
     // exceptions are not, so every job after the first starts at an upper bound and is moved down when all are done
-    long long bins0 = 0, rep0 = 0, frag0 = 0, exc0 = 0;
-    long long rep_room = 0, frag_room = 0, exc_room = 0;
+    long long bins0 = 0, rep0 = 0, frag0 = 0;
+    long long rep_room = 0, frag_room = 0;
     PipeShared sh;
-    long long n_bins = 0, n_rep = 0, n_frag = 0, n_exc = 0;     // totals of the job (valid after the run)
+    long long n_bins = 0, n_rep = 0, n_frag = 0;     // totals of the job (valid after the run)
 };
 
 int prepare_lanes(raft_hip_ctx *c)
@@ -1184,21 +1350,28 @@ int prepare_lanes(raft_hip_ctx *c)
 
 } // namespace
 
-int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
-                       const int32_t *qid, const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts,
-                       const int32_t *te, int32_t n_chunks, raft_hip_host_outputs *o, raft_hip_summary *summary)
+// (n_runs, rec_offset): the grouped form -- the caller's offsets instead of the query column (raft_hip_run_multi_grouped)
+static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                          const int32_t *qid, const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts,
+                          const int32_t *te, int32_t n_runs, const int64_t *rec_offset, int32_t n_chunks, raft_hip_host_outputs *o,
+                          raft_hip_summary *summary)
 {
     if (!ctxs || n_ctx < 1 || !ctxs[0] || !o) return RAFT_HIP_ERR_PARAM;
     raft_hip_ctx *c = ctxs[0];
+    const bool grouped = rec_offset != nullptr;
+    if (grouped && (n_runs < 1 || n_runs > kMaxSeg || ctxs[0]->prm.symmetric_mode != 1)) return RAFT_HIP_ERR_PARAM;
+    const long long ostride = (long long)n_reads + 1;
+    auto off_at = [&](int g, long long r) -> long long { return rec_offset[(long long)g * ostride + r]; };
     for (int d = 1; d < n_ctx; ++d) {
         if (!ctxs[d]) return RAFT_HIP_ERR_PARAM;
         for (int e = 0; e < d; ++e) if (ctxs[e] == ctxs[d]) return RAFT_HIP_ERR_PARAM;   // (two contexts may share a device)
     }
     if (n_reads < 0 || n_rec < 0 || n_chunks < 0) return RAFT_HIP_ERR_PARAM;
     if (n_reads > 0 && !read_len) return RAFT_HIP_ERR_PARAM;
-    if (n_rec > 0 && (!qid || !qs || !qe)) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && ((!qid && !grouped) || !qs || !qe)) return RAFT_HIP_ERR_PARAM;
     if (!o->cov_offset || !o->rep_offset || !o->frag_offset) return RAFT_HIP_ERR_PARAM;
     o->n_exc = 0;
+    auto one_piece = [&]() { return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary, n_runs, rec_offset); };
     if (o->cov_width != 0 && o->cov_width != 1 && o->cov_width != 2) return RAFT_HIP_ERR_PARAM;
     const int cov_width = o->cov_width == 2 ? 2 : 1;   // bytes per window of the coverage's transfer encoding
     long long seg[kMaxSeg + 1];
@@ -1207,8 +1380,15 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
     // (an explicit n_chunks is honoured from tiny inputs on: that is how the tests reach every shape of the plan)
     const bool big_enough = n_chunks > 0 ? (n_rec >= 2 && n_reads >= 2) : (n_rec >= (1 << 24) && n_reads >= 4096);   // (~200 MB up: below that one piece is as fast)
     const bool eligible = c->prm.symmetric_mode == 1 && big_enough && !c->force_bucket;
-    if (eligible) n_seg = guess_segments(qid, n_rec, seg);
-    if (n_seg < 1) return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary);
+    if (eligible && grouped) {                       // the runs are what the offsets say (looked at where the plan uses them)
+        n_seg = n_runs;
+        for (int g = 0; g < n_runs; ++g) seg[g] = off_at(g, 0);
+        seg[n_runs] = n_rec;
+        for (int g = 0; g < n_runs; ++g)
+            if (seg[g] < 0 || seg[g] > seg[g + 1] || off_at(g, n_reads) != seg[g + 1]) n_seg = -1;   // (the one-piece pass reports it)
+        if (seg[0] != 0) n_seg = -1;
+    } else if (eligible) n_seg = guess_segments(qid, n_rec, seg);
+    if (n_seg < 1) return one_piece();
 
     int want = n_chunks > 0 ? std::min(n_chunks, n_reads)
                             : (int)std::min<long long>(std::min<long long>(32LL * n_ctx, std::max<long long>(2LL * n_ctx, n_rec / (24LL << 20))),
@@ -1216,9 +1396,13 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
     // ---- plan: read boundaries that balance the records, then one piece per run and chunk
     std::vector<ChunkPlan> plan;
     {
+        auto first_of = [&](int g, long long lo, int32_t r) {   // first record of read r in run g, at or after lo
+            if (!grouped) return lower_bound_ids(qid, lo, seg[g + 1], r);
+            return std::min(std::max(off_at(g, r), lo), seg[g + 1]);   // (offsets that step back: the device reports them)
+        };
         auto below = [&](int32_t r) {                // records with a query id < r (if the runs are sorted)
             long long n = 0;
-            for (int k = 0; k < n_seg; ++k) n += lower_bound_ids(qid, seg[k], seg[k + 1], r) - seg[k];
+            for (int k = 0; k < n_seg; ++k) n += first_of(k, seg[k], r) - seg[k];
             return n;
         };
         std::vector<int32_t> bound{0};
@@ -1237,7 +1421,7 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
             ChunkPlan cp{};
             cp.r0 = bound[k]; cp.r1 = bound[k + 1]; cp.n_rec = 0;
             for (int g = 0; g < n_seg; ++g) {
-                const long long hi = (k + 2 == bound.size()) ? seg[g + 1] : lower_bound_ids(qid, cur[g], seg[g + 1], cp.r1);
+                const long long hi = (k + 2 == bound.size()) ? seg[g + 1] : first_of(g, cur[g], cp.r1);
                 cp.piece[g] = Piece{cur[g], hi};
                 cp.n_rec += hi - cur[g];
                 cur[g] = hi;
@@ -1246,7 +1430,7 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
         }
     }
     const int n_ch = (int)plan.size();
-    if (n_ch < 2) return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary);
+    if (n_ch < 2) return one_piece();
 
     // ---- contexts: consecutive chunks each (the plan balances records per chunk), parameters of the first
     const int n_job = std::min(n_ctx, n_ch);
@@ -1280,13 +1464,16 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
             if (n_job > 1) {
                 const int r_end = plan[(size_t)(J.first_chunk + J.n_chunks - 1)].r1;
                 long long jb = 0, jl = 0;
-                for (; r < r_end; ++r) { jb += windows(read_len[r]); jl += read_len[r]; }
+                for (; r < r_end; ++r) {
+                    if (read_len[r] < 0)             // (reported as RAFT_HIP_ERR_PARAM with its index by the one-piece pass)
+                        return one_piece();
+                    jb += windows(read_len[r]); jl += read_len[r];
+                }
                 const long long n_r = r_end - plan[(size_t)J.first_chunk].r0;
                 // sum floor(x_i / m) <= floor(sum x_i / m): the per-read bounds of raft_hip.h, summed, are at least these
                 J.rep_room = (jb + n_r) / (minw + 1); J.frag_room = jl / L + 2 * n_r;
                 bins += jb; rep_cap += J.rep_room; frag_cap += J.frag_room;
             }
-            J.exc0 = o->exc_cap * d / n_job; J.exc_room = o->exc_cap * (d + 1) / n_job - J.exc0;
             const int rc = prepare_lanes(J.c);
             if (rc != RAFT_HIP_OK) return rc;
         }
@@ -1299,6 +1486,12 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
     }
 
     std::vector<ChunkResult> res((size_t)n_ch);
+    // Exceptions (windows at or above the encoding's limit) have no useful bound per device -- one device may hold all the
+    // repeat-rich reads -- so every chunk takes its room from ONE cursor over the caller's list; chunks of different
+    // devices interleave there and are put into read order when all are done.  A chunk that no longer fits still counts:
+    // the call then returns RAFT_HIP_ERR_TOO_LARGE with the total in out->n_exc, and one retry suffices.
+    std::atomic<long long> exc_cursor{0};
+    std::vector<long long> exc_at((size_t)n_ch, 0);
     std::atomic<bool> redo{false};                  // a chunk reported a data error: the job is redone in one piece
     const bool trace = getenv("RAFT_PIPE_TRACE") != nullptr;   // host-clock stamps per chunk and stage on stderr
     const auto t_origin = std::chrono::steady_clock::now();
@@ -1330,10 +1523,12 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
             const int32_t nr = cp.r1 - cp.r0;
             raft_hip_summary s{};
             long long b_bins, b_rep, b_frag, b_exc;
+            bool exc_fits;
             hipStream_t st = l->stream;
             // -- upload, in chunk order on the one upload stream (the link is the bottleneck: first come, first served)
             LANE_TRY(l->in_len.ensure((size_t)std::max(nr, 1) * 4));
-            for (int col = 0; col < 3; ++col) LANE_TRY(l->in_col[col].ensure((size_t)std::max<long long>(cp.n_rec, 1) * 4));
+            for (int col = grouped ? 1 : 0; col < 3; ++col) LANE_TRY(l->in_col[col].ensure((size_t)std::max<long long>(cp.n_rec, 1) * 4));
+            if (grouped) LANE_TRY(l->in_off.ensure((size_t)n_seg * ((size_t)nr + 1) * 8));
             {
                 std::unique_lock<std::mutex> g(sh.mu);
                 sh.cv.wait(g, [&] { return sh.uploaded == kk || stop(); });
@@ -1342,7 +1537,11 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
             {
                 hipError_t e = hipMemcpyAsync(l->in_len.p, read_len + cp.r0, (size_t)nr * 4, hipMemcpyHostToDevice, jc->up_stream);
                 const int32_t *src[3] = {qid, qs, qe};
-                for (int col = 0; col < 3 && e == hipSuccess; ++col) {
+                // (grouped: a slice of every run's offsets instead of the query column -- 8 bytes per read and run, not 4 per record)
+                for (int g = 0; grouped && g < n_seg && e == hipSuccess; ++g)
+                    e = hipMemcpyAsync(l->in_off.as<long long>() + (long long)g * (nr + 1), rec_offset + (long long)g * ostride + cp.r0,
+                                       (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, jc->up_stream);
+                for (int col = grouped ? 1 : 0; col < 3 && e == hipSuccess; ++col) {
                     long long at = 0;
                     for (int g = 0; g < n_seg && e == hipSuccess; ++g) {
                         const long long n = cp.piece[g].hi - cp.piece[g].lo;
@@ -1365,14 +1564,23 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
             // (measured: chunks whose pass was queued at 12 ms ran at 24 ms).
             LANE_TRY(hipEventSynchronize(jc->lane_up_ev[(size_t)li]));
             stamp(k, "h2d done");
-            if (cp.n_rec > 0 && cp.r0 != 0) {
+            if (cp.n_rec > 0 && cp.r0 != 0 && !grouped) {
                 const unsigned grid = (unsigned)std::min<long long>((cp.n_rec + 255) / 256, 4096);
                 hipLaunchKernelGGL(rebase_ids_kernel, dim3(grid), dim3(256), 0, st, l->in_col[0].as<int32_t>(), cp.n_rec, cp.r0);
             }
             // -- the pass on this chunk
             {
                 l->out_width = cov_width;            // the pass writes the encoding that travels
-                int rc = raft_hip_run_device(l, nr, l->in_len.as<int32_t>(), cp.n_rec, l->in_col[0].as<int32_t>(),
+                int rc;
+                if (grouped) {
+                    // the chunk's pieces lie back to back on the device: run g's slice of offsets counts from the caller's
+                    // stream and is moved by adj[g] to where the piece went
+                    long long adj[kMaxSeg] = {0, 0, 0, 0}, at = 0;
+                    for (int g = 0; g < n_seg; ++g) { adj[g] = at - cp.piece[g].lo; at += cp.piece[g].hi - cp.piece[g].lo; }
+                    rc = run_grouped(l, nr, l->in_len.as<int32_t>(), cp.n_rec, n_seg, l->in_off.as<int64_t>(), adj, nullptr,
+                                     l->in_col[1].as<int32_t>(), l->in_col[2].as<int32_t>(), count_windows(read_len + cp.r0, nr, c->prm.reso));
+                } else
+                    rc = raft_hip_run_device(l, nr, l->in_len.as<int32_t>(), cp.n_rec, l->in_col[0].as<int32_t>(),
                                              l->in_col[1].as<int32_t>(), l->in_col[2].as<int32_t>(), nullptr, nullptr, nullptr);
                 stamp(k, "pass queued");
                 if (rc == RAFT_HIP_OK) rc = raft_hip_finish(l, &s);
@@ -1395,12 +1603,15 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
                 std::unique_lock<std::mutex> g(sh.mu);
                 sh.cv.wait(g, [&] { return sh.published == kk || stop(); });
                 if (stop()) goto out;
-                b_bins = J.bins0 + sh.base_bins; b_rep = J.rep0 + sh.base_rep; b_frag = J.frag0 + sh.base_frag; b_exc = J.exc0 + sh.base_exc;
-                sh.base_bins += cr.n_bins; sh.base_rep += cr.n_rep; sh.base_frag += cr.n_frag; sh.base_exc += cr.n_exc;
+                b_bins = J.bins0 + sh.base_bins; b_rep = J.rep0 + sh.base_rep; b_frag = J.frag0 + sh.base_frag;
+                b_exc = exc_cursor.fetch_add(cr.n_exc);
+                exc_at[(size_t)k] = b_exc;
+                exc_fits = b_exc + cr.n_exc <= o->exc_cap;
+                sh.base_bins += cr.n_bins; sh.base_rep += cr.n_rep; sh.base_frag += cr.n_frag;
                 sh.published = kk + 1;
-                if (sh.base_rep > J.rep_room || sh.base_frag > J.frag_room || sh.base_exc > J.exc_room ||
+                if (sh.base_rep > J.rep_room || sh.base_frag > J.frag_room ||
                     (o->cov8 && J.bins0 + sh.base_bins > o->cov8_cap)) {
-                    if (sh.error == RAFT_HIP_OK) { sh.error = RAFT_HIP_ERR_TOO_LARGE; sh.error_text = "host output capacity (repeats / fragments / exceptions)"; }
+                    if (sh.error == RAFT_HIP_OK) { sh.error = RAFT_HIP_ERR_TOO_LARGE; sh.error_text = "host output capacity (coverage / repeats / fragments)"; }
                 }
                 sh.cv.notify_all();
                 if (sh.error != RAFT_HIP_OK) goto out;
@@ -1418,8 +1629,8 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
                 struct { void *dst; const void *src; size_t bytes; } job[] = {
                     {o->cov8 ? o->cov8 + b_bins * cov_width : nullptr, l->cov8.p, (size_t)cr.n_bins * (size_t)cov_width},
                     {o->cov_offset + cp.r0, l->cov_off.p, (size_t)n1 * 8},
-                    {o->exc_index ? o->exc_index + b_exc : nullptr, l->exc_idx.p, (size_t)cr.n_exc * 8},
-                    {o->exc_value ? o->exc_value + b_exc : nullptr, l->exc_val.p, (size_t)cr.n_exc * 4},
+                    {(o->exc_index && exc_fits) ? o->exc_index + b_exc : nullptr, l->exc_idx.p, (size_t)cr.n_exc * 8},
+                    {(o->exc_value && exc_fits) ? o->exc_value + b_exc : nullptr, l->exc_val.p, (size_t)cr.n_exc * 4},
                     {o->rep_offset + cp.r0, l->rep_off.p, (size_t)n1 * 8},
                     {o->rep_s ? o->rep_s + b_rep : nullptr, l->rep_s.p, (size_t)cr.n_rep * 4},
                     {o->rep_e ? o->rep_e + b_rep : nullptr, l->rep_e.p, (size_t)cr.n_rep * 4},
@@ -1438,7 +1649,7 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
                 stamp(k, "d2h queued");
                 LANE_TRY(hipEventSynchronize(jc->lane_down_ev[(size_t)li]));
                 stamp(k, "d2h done");
-                if (o->exc_index && o->exc_value && cr.n_exc > 1) {    // ascending by window, like raft_hip_fetch_packed
+                if (o->exc_index && o->exc_value && cr.n_exc > 1 && exc_fits) {    // ascending by window, like raft_hip_fetch_packed
                     std::vector<std::pair<int64_t, int32_t>> ex((size_t)cr.n_exc);
                     for (size_t i = 0; i < ex.size(); ++i) ex[i] = {o->exc_index[b_exc + (long long)i], o->exc_value[b_exc + (long long)i]};
                     std::sort(ex.begin(), ex.end());
@@ -1469,11 +1680,11 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
         (void)hipStreamSynchronize(J.c->down_stream);
         for (raft_hip_ctx *l : J.c->lanes) (void)hipStreamSynchronize(l->stream);
         J.c->ran = false; J.c->finished = false;   // the contexts hold no pass: fetch / outputs_device do not apply
-        J.n_bins = J.sh.base_bins; J.n_rep = J.sh.base_rep; J.n_frag = J.sh.base_frag; J.n_exc = J.sh.base_exc;
+        J.n_bins = J.sh.base_bins; J.n_rep = J.sh.base_rep; J.n_frag = J.sh.base_frag;
         if (J.sh.error != RAFT_HIP_OK && err == RAFT_HIP_OK) { err = J.sh.error; c->last_error = J.sh.error_text; }
     }
     (void)hipSetDevice(c->device);
-    if (redo.load()) return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary);
+    if (redo.load()) return one_piece();
 
     raft_hip_summary s{};
     s.n_reads = n_reads; s.symmetric = 1; s.high_cov = c->high_cov; s.n_segments = n_seg; s.n_records = n_rec; s.error_index = -1;
@@ -1485,27 +1696,61 @@ int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads
     s.total_windows = s.n_bins;
     if (summary) *summary = s;
     if (err != RAFT_HIP_OK) return err;
-    // ---- later jobs wrote repeats / fragments / exceptions at their upper-bound positions: close the gaps
+    o->n_exc = exc_cursor.load();
+    if (o->n_exc > o->exc_cap) {
+        c->last_error = "raft_hip_run_multi: more windows at or above the encoding's limit than exc_cap (out->n_exc holds the number)";
+        return RAFT_HIP_ERR_TOO_LARGE;
+    }
+    // ---- exceptions: chunks of different devices took their room in the order they finished; hand them out in read order
+    if (n_job > 1 && o->n_exc > 0) {
+        bool ordered = true;
+        long long at = 0;
+        for (int k = 0; k < n_ch; ++k) { ordered = ordered && exc_at[(size_t)k] == at; at += res[(size_t)k].n_exc; }
+        if (!ordered) {
+            std::vector<int64_t> ti((size_t)o->n_exc);
+            std::vector<int32_t> tv((size_t)o->n_exc);
+            at = 0;
+            for (int k = 0; k < n_ch; ++k) {
+                const long long n = res[(size_t)k].n_exc, from = exc_at[(size_t)k];
+                if (o->exc_index) memcpy(ti.data() + at, o->exc_index + from, (size_t)n * 8);
+                if (o->exc_value) memcpy(tv.data() + at, o->exc_value + from, (size_t)n * 4);
+                at += n;
+            }
+            if (o->exc_index) memcpy(o->exc_index, ti.data(), (size_t)o->n_exc * 8);
+            if (o->exc_value) memcpy(o->exc_value, tv.data(), (size_t)o->n_exc * 4);
+        }
+    }
+    // ---- later jobs wrote repeats / fragments at their upper-bound positions: close the gaps
     {
-        long long rep_at = jobs[0].n_rep, frag_at = jobs[0].n_frag, exc_at = jobs[0].n_exc;
+        long long rep_at = jobs[0].n_rep, frag_at = jobs[0].n_frag;
         for (int d = 1; d < n_job; ++d) {
             DeviceJob &J = jobs[(size_t)d];
             const int32_t ra = plan[(size_t)J.first_chunk].r0, rb = plan[(size_t)(J.first_chunk + J.n_chunks - 1)].r1;
             auto move32 = [](int32_t *a, long long to, long long from, long long n) { if (a && n && to != from) memmove(a + to, a + from, (size_t)n * 4); };
             move32(o->rep_s, rep_at, J.rep0, J.n_rep); move32(o->rep_e, rep_at, J.rep0, J.n_rep);
             move32(o->frag_begin, frag_at, J.frag0, J.n_frag); move32(o->frag_end, frag_at, J.frag0, J.n_frag);
-            move32(o->exc_value, exc_at, J.exc0, J.n_exc);
-            if (o->exc_index && J.n_exc && exc_at != J.exc0) memmove(o->exc_index + exc_at, o->exc_index + J.exc0, (size_t)J.n_exc * 8);
             const int32_t r_hi = rb + ((d == n_job - 1) ? 1 : 0);
             for (int32_t r = ra; r < r_hi; ++r) { o->rep_offset[r] += rep_at; o->frag_offset[r] += frag_at; }
-            rep_at += J.n_rep; frag_at += J.n_frag; exc_at += J.n_exc;
-        }
-        o->n_exc = exc_at;
-        if (n_job > 1 && s.n_fragments > 0) {        // (with one job the closing entries are already global)
-            // closing entries of jobs before the last are the first entries of their successors: nothing to patch
+            rep_at += J.n_rep; frag_at += J.n_frag;
         }
     }
     return RAFT_HIP_OK;
+}
+
+int raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                       const int32_t *qid, const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts,
+                       const int32_t *te, int32_t n_chunks, raft_hip_host_outputs *o, raft_hip_summary *summary)
+{
+    return run_multi_impl(ctxs, n_ctx, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, 0, nullptr, n_chunks, o, summary);
+}
+
+int raft_hip_run_multi_grouped(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                               int32_t n_runs, const int64_t *rec_offset, const int32_t *qs, const int32_t *qe, int32_t n_chunks,
+                               raft_hip_host_outputs *o, raft_hip_summary *summary)
+{
+    if (!rec_offset) return RAFT_HIP_ERR_PARAM;
+    return run_multi_impl(ctxs, n_ctx, n_reads, read_len, n_rec, nullptr, qs, qe, nullptr, nullptr, nullptr, n_runs, rec_offset, n_chunks, o,
+                          summary);
 }
 
 int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, const int32_t *qid,

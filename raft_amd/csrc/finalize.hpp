@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_reads) return;
+    if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
     int n, nF, nf;
     finalize_count_one(a, r, n, nF, nf);
 }
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_reads) return;
+    if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
     finalize_fill_one(a, r, a.rep_off[r], a.frag_off[r], a.rep_cnt[r], a.cut_cnt[r]);
 }
 
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(256) void finalize_cuts_kernel(FinalizeArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_reads) return;
+    if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
     int32_t *F = a.cuts + a.cut_off[r];
     int w = 0;
     (void)walk_cuts(a.read_len[r], a.interval_length, a.raw_s + a.rep_res_off[r], a.raw_e + a.rep_res_off[r], a.rep_cnt[r],

@@ -45,8 +45,25 @@ enum : int {
     kErrLen = 1 << 4,
     kErrExtra = 1 << 6,         // the list of extra tiles (split tiles, pieces of long reads) overflowed: the engine runs
                                // the pass again with the general kernel for those tiles
-    kErrOrder = 1 << 5          // a pass that trusted a sampled guess of the sorted runs met a record that refutes it (not an
+    kErrOrder = 1 << 5,         // a pass that trusted a sampled guess of the sorted runs met a record that refutes it (not an
                                // error of the input: the engine runs the pass again after looking at every record)
+    kErrHint = 1 << 7,          // the number of windows the caller announced (a pass without a host wait is sized by it) is not
+                               // what the read lengths give: every later kernel of the pass returns at once, the engine
+                               // runs the pass again with the host wait
+    kErrGroup = 1 << 8,         // grouped input (raft_hip_run_device_grouped): the per-read record offsets step back or do not
+                               // chain from 0 to n_rec
+    kErrStop = kErrHint | kErrGroup   // what a pass without a host wait cannot go on after: its later kernels return at once
+};
+
+// Grouped input (include/raft_hip.h raft_hip_run_device_grouped): the record stream is n_runs runs sorted by query id and
+// the caller says where each read's records begin in each run -- off[s * stride + r] (+ adj[s]: a chunk of the host
+// pipelines uploads slices of the caller's arrays and of its record columns) is the first record of read r in run s,
+// entry n_reads closes the run.  Tile cuts are then look-ups, not searches.
+struct GroupedOff {
+    const long long *off;      // nullptr: not grouped
+    long long stride;          // n_reads + 1
+    long long adj[kMaxSeg];
+    __device__ __forceinline__ long long at(int s, long long r) const { return off[s * stride + r] + adj[s]; }
 };
 
 struct SegStarts { long long start[kMaxSeg + 1]; int32_t n_seg; };
@@ -644,6 +661,7 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
     __shared__ __attribute__((aligned(16))) Smem sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const long long nb = gridDim.x;
+    if (uni(*(volatile int32_t *)a.err_flags) & kErrStop) return;   // (see kErrStop)
     const int32_t *td_words = reinterpret_cast<const int32_t *>(a.td);
     if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; sm.carry_open[0] = sm.carry_open[1] = -1; sm.carry_hp[0] = sm.carry_hp[1] = 0; }
     if (tid < Smem::NW) sm.runq_n[tid] = 0;
@@ -817,8 +835,10 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                                                         int fast_cap, int fast_max_reads, int32_t *slow_list,
                                                         int32_t *n_slow, const int32_t *samples, long long n_rec,
                                                         const long long *bucket_off, int32_t *err_flags, TileCut *extra,
-                                                        int32_t *n_extra, int32_t extra_cap, int32_t piece_w, MirrorArgs mir)
+                                                        int32_t *n_extra, int32_t extra_cap, int32_t piece_w, MirrorArgs mir,
+                                                        GroupedOff grp)
 {
+    if (*(volatile int32_t *)err_flags & kErrStop) return;   // (sizes or offsets the device found wrong: nothing here is safe)
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool live = k < n_tiles;
@@ -843,10 +863,19 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
 #pragma unroll
     for (int s = 0; s < kMaxSeg; ++s) {
         blo[s] = bhi[s] = blo[kMaxSeg + s] = bhi[kMaxSeg + s] = 0;
-        if (s < sb.n_seg) {                         // uniform
+        if (s < sb.n_seg && !grp.off) {             // uniform
             const long long seg_e = seg_end_dev ? *seg_end_dev : sb.start[s + 1];
             if (edge || mirror) { blo[s] = sb.start[s]; bhi[s] = seg_e; }
             if (own_end) { blo[kMaxSeg + s] = sb.start[s]; bhi[kMaxSeg + s] = seg_e; }
+        }
+    }
+    if (grp.off) {                                  // grouped input: the caller's offsets answer directly
+#pragma unroll
+        for (int s = 0; s < kMaxSeg; ++s) {
+            if (s < sb.n_seg) {
+                if (edge) blo[s] = bhi[s] = grp.at(s, d.r_lo);
+                if (own_end) blo[kMaxSeg + s] = bhi[kMaxSeg + s] = grp.at(s, d.r_hi);
+            }
         }
     }
     // Before bisecting the record stream itself: the counting sort's own offsets answer directly; on the sorted-segment
@@ -915,7 +944,7 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
     bool back = false;
 #pragma unroll
     for (int s = 0; s < kMaxSeg; ++s) {
-        if (s < sb.n_seg) {
+        if (s < sb.n_seg && !grp.off) {             // (grouped offsets begin and end where the runs do: checked by the scan's loader)
             const long long seg_e = seg_end_dev ? *seg_end_dev : sb.start[s + 1];
             if (k == 0) blo[s] = sb.start[s];
             if (k == n_tiles) blo[s] = seg_e;
@@ -925,6 +954,10 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
         long long hi = __shfl_down(lo, 1, kWave);
         if (own_end) hi = blo[kMaxSeg + s];
         if (live && hi < lo) { back = true; hi = lo; }
+        // A tile in which no read begins is handed to no kernel, so it must not own records.  On sorted runs its range is
+        // empty -- except behind the last read, where ids >= n_reads end up (the closing boundary is forced to the run's
+        // end): such records refute the guess like any other record outside its tile's reads.
+        if (live && d.r_hi == d.r_lo && hi > lo) back = true;
         d.iv_lo[s] = lo;
         d.n_iv[s] = (int)(hi - lo);
     }
@@ -954,6 +987,7 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
         auto bound = [&](int s, int r) -> long long {      // first interval of read r in run s, inside the tile's range
             if (r <= d.r_lo) return t_lo[s];
             if (r >= d.r_hi) return t_hi[s];
+            if (grp.off) return min(max(grp.at(s, r), t_lo[s]), t_hi[s]);
             return lower_bound_rid(iv_rid, t_lo[s], t_hi[s], r);
         };
         // (the interval bounds of a read are searched once: the pieces of a long read share them, and a group begins where

@@ -170,8 +170,9 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     // regular tiles 0 .. n_reg - 1 are bounded by adjacent cuts; extra tiles (tile_desc_kernel re-cut what does not fit:
     // PileupArgs::n_extra) follow as explicit (begin, end) pairs behind the closing boundary, numbered from 0 here
     const int n_reg = (int)a.n_tiles;
-    // (an overflowed list -- kErrExtra -- counts tiles that were never written: nothing to do, the engine runs the pass again)
-    if (EXTRA && (uni(*(volatile int32_t *)a.err_flags) & kErrExtra)) return;
+    // (an overflowed list -- kErrExtra -- counts tiles that were never written: nothing to do, the engine runs the pass again;
+    // kErrStop: the pass was sized by a window count, or cut by offsets, that the device found wrong, see pileup.hpp)
+    if (uni(*(volatile int32_t *)a.err_flags) & (EXTRA ? (kErrExtra | kErrStop) : kErrStop)) return;
     const int n_tiles = EXTRA ? uni(*a.n_extra) : n_reg;
     const int last_cut = n_tiles - 1;            // (tile index: the word index below maps it)
     auto cut_of = [&](int t) -> int { return EXTRA ? n_reg + 1 + 2 * t : t; };   // index of tile t's first cut

@@ -24,7 +24,8 @@ EXPORTS = (
     "raft_hip_set_params", "raft_hip_set_stream", "raft_hip_use_own_stream", "raft_hip_get_stream", "raft_hip_run_device", "raft_hip_run_host",
     "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
     "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed", "raft_hip_fetch_packed_w", "raft_hip_run_pipelined", "raft_hip_run_multi",
-    "raft_hip_set_output_width", "raft_hip_packed_device",
+    "raft_hip_set_output_width", "raft_hip_packed_device", "raft_hip_run_device_grouped", "raft_hip_run_host_grouped",
+    "raft_hip_run_multi_grouped",
 )
 
 
@@ -126,6 +127,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_fetch_packed_w.argtypes = [vp, i32, vp, vp, i64, vp, vp, C.POINTER(i64)] + [vp] * 7
     lib.raft_hip_run_pipelined.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_run_multi.argtypes = [C.POINTER(vp), i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
+    lib.raft_hip_run_device_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, vp, i64]
+    lib.raft_hip_run_host_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, i64]
+    lib.raft_hip_run_multi_grouped.argtypes = [C.POINTER(vp), i32, i32, vp, i64, i32, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.raft_hip_set_tuning.argtypes = [vp, i32, i32, i32]
     lib.raft_hip_set_output_width.argtypes = [vp, i32]
@@ -215,6 +219,38 @@ class Engine:
         ptr = [C.c_void_p(t.data_ptr() if t.numel() else 0) for t in cols]
         self._check(self._lib.raft_hip_run_device(self._ctx, int(read_len.numel()), ptr[0], n_rec, *ptr[1:]))
 
+    def run_device_grouped(self, read_len, rec_offset, qid, qs, qe, n_bins: int = -1):
+        """raft_hip_run_device_grouped: ``rec_offset`` int64 CUDA tensor [n_runs, n_reads + 1] (first record of every read in
+        every sorted run), ``qid`` may be None (the ids are then rebuilt from the offsets on the device), ``n_bins`` the
+        caller's sum of ceil(len / reso) (-1: unknown; >= 0: the pass runs without a host wait).  symmetric_mode must be 1."""
+        import torch
+        n_reads = int(read_len.numel())
+        if rec_offset.dtype != torch.int64 or not rec_offset.is_cuda or not rec_offset.is_contiguous() or rec_offset.dim() != 2 \
+                or rec_offset.shape[1] != n_reads + 1:
+            raise TypeError("run_device_grouped needs rec_offset as a contiguous int64 CUDA tensor [n_runs, n_reads + 1]")
+        cols = (read_len, qs, qe) + (() if qid is None else (qid,))
+        for t in cols:
+            if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+                raise TypeError("run_device_grouped needs contiguous int32 CUDA tensors")
+        n_rec = int(qs.numel())
+        if int(qe.numel()) != n_rec or (qid is not None and int(qid.numel()) != n_rec):
+            raise ValueError("PAF columns differ in length")
+        self._keep = cols + (rec_offset,)
+        self.use_torch_stream()
+        P = lambda t: C.c_void_p(t.data_ptr() if (t is not None and t.numel()) else 0)
+        self._check(self._lib.raft_hip_run_device_grouped(self._ctx, n_reads, P(read_len), n_rec, int(rec_offset.shape[0]), P(rec_offset),
+                                                          P(qid), P(qs), P(qe), int(n_bins)))
+
+    def run_host_grouped(self, read_len, rec_offset, qs, qe, n_bins: int = -1):
+        """raft_hip_run_host_grouped: numpy arrays; ``rec_offset`` int64 [n_runs, n_reads + 1]."""
+        rl, a, b = (np.ascontiguousarray(np.asarray(x), dtype=np.int32) for x in (read_len, qs, qe))
+        off = np.ascontiguousarray(np.asarray(rec_offset), dtype=np.int64)
+        if off.ndim != 2 or off.shape[1] != rl.size + 1 or a.size != b.size:
+            raise ValueError("run_host_grouped: rec_offset must be [n_runs, n_reads + 1], qs/qe of equal length")
+        self._keep = (rl, a, b, off)
+        P = lambda x: C.c_void_p(x.ctypes.data if x.size else 0)
+        self._check(self._lib.raft_hip_run_host_grouped(self._ctx, rl.size, P(rl), a.size, off.shape[0], P(off), P(a), P(b), int(n_bins)))
+
     def run_host(self, read_len, qid, qs, qe, tid=None, ts=None, te=None):
         """tid/ts/te may be None when the params assert symmetric_mode = 1 (they are then neither read nor uploaded)."""
         cols = [None if a is None else np.ascontiguousarray(np.asarray(a), dtype=np.int32) for a in (read_len, qid, qs, qe, tid, ts, te)]
@@ -301,6 +337,44 @@ class Engine:
                 "rep_e": alloc(caps["rep"], np.int32), "frag_offset": alloc(n1, np.int64), "frag_begin": alloc(caps["frag"], np.int32),
                 "frag_end": alloc(caps["frag"], np.int32)}
 
+    def run_pipelined_grouped(self, read_len, rec_offset, qs, qe, n_chunks: int = 0, out: dict | None = None,
+                              others: list | None = None):
+        """raft_hip_run_multi_grouped: as ``run_pipelined`` with the caller's per-read record offsets (int64
+        [n_runs, n_reads + 1]) in place of the query column."""
+        rl, a, b = (np.ascontiguousarray(np.asarray(x), dtype=np.int32) for x in (read_len, qs, qe))
+        off = np.ascontiguousarray(np.asarray(rec_offset), dtype=np.int64)
+        if off.ndim != 2 or off.shape[1] != rl.size + 1 or a.size != b.size:
+            raise ValueError("run_pipelined_grouped: rec_offset must be [n_runs, n_reads + 1], qs/qe of equal length")
+        if out is None:
+            out = self.host_output_buffers(rl, pinned=False)
+        ho = self._host_outputs(out)
+        P = lambda x: C.c_void_p(x.ctypes.data if x.size else 0)
+        s = _Summary()
+        ctxs = (C.c_void_p * (1 + len(others or [])))(self._ctx, *[e._ctx for e in (others or [])])
+        rc = self._lib.raft_hip_run_multi_grouped(ctxs, len(ctxs), rl.size, P(rl), a.size, off.shape[0], P(off), P(a), P(b), int(n_chunks),
+                                                  C.byref(ho), C.byref(s))
+        return self._pipelined_result(rc, s, ho, out)
+
+    def _host_outputs(self, out: dict) -> "_HostOutputs":
+        ho = _HostOutputs()
+        for k in ("cov_offset", "cov8", "exc_index", "exc_value", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
+            setattr(ho, k, out[k].ctypes.data)
+        ho.cov8_cap, ho.exc_cap, ho.rep_cap, ho.frag_cap = out["cov8"].size, out["exc_index"].size, out["rep_s"].size, out["frag_begin"].size
+        ho.cov_width = 2 if out["cov8"].dtype == np.uint16 else 1          # the buffer's dtype chooses the encoding's width
+        return ho
+
+    def _pipelined_result(self, rc, s, ho, out):
+        summ = Summary(**{f: int(getattr(s, f)) for f, _ in _Summary._fields_})
+        self.summary = summ
+        self.last_n_exc = int(ho.n_exc)
+        self._check(rc, summ.error_index)
+        n1 = summ.n_reads + 1
+        res = {"cov_offset": out["cov_offset"][:n1], "cov8": out["cov8"][:summ.n_bins], "exc_index": out["exc_index"][:ho.n_exc],
+               "exc_value": out["exc_value"][:ho.n_exc], "rep_offset": out["rep_offset"][:n1], "rep_s": out["rep_s"][:summ.n_repeats],
+               "rep_e": out["rep_e"][:summ.n_repeats], "frag_offset": out["frag_offset"][:n1],
+               "frag_begin": out["frag_begin"][:summ.n_fragments], "frag_end": out["frag_end"][:summ.n_fragments]}
+        return res, summ
+
     def run_pipelined(self, read_len, qid, qs, qe, tid=None, ts=None, te=None, n_chunks: int = 0, out: dict | None = None,
                       others: list | None = None):
         """raft_hip_run_pipelined: host columns in, host outputs out, with upload / pass / download of consecutive read
@@ -310,11 +384,7 @@ class Engine:
         n_rec = cols[1].size
         if out is None:
             out = self.host_output_buffers(cols[0], pinned=False)
-        ho = _HostOutputs()
-        for k in ("cov_offset", "cov8", "exc_index", "exc_value", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
-            setattr(ho, k, out[k].ctypes.data)
-        ho.cov8_cap, ho.exc_cap, ho.rep_cap, ho.frag_cap = out["cov8"].size, out["exc_index"].size, out["rep_s"].size, out["frag_begin"].size
-        ho.cov_width = 2 if out["cov8"].dtype == np.uint16 else 1          # the buffer's dtype chooses the encoding's width
+        ho = self._host_outputs(out)
         ptr = [C.c_void_p(a.ctypes.data if (a is not None and a.size) else 0) for a in cols]
         s = _Summary()
         if others:
@@ -323,15 +393,7 @@ class Engine:
                                               C.byref(ho), C.byref(s))
         else:
             rc = self._lib.raft_hip_run_pipelined(self._ctx, cols[0].size, ptr[0], n_rec, *ptr[1:], int(n_chunks), C.byref(ho), C.byref(s))
-        summ = Summary(**{f: int(getattr(s, f)) for f, _ in _Summary._fields_})
-        self.summary = summ
-        self._check(rc, summ.error_index)
-        n1 = summ.n_reads + 1
-        res = {"cov_offset": out["cov_offset"][:n1], "cov8": out["cov8"][:summ.n_bins], "exc_index": out["exc_index"][:ho.n_exc],
-               "exc_value": out["exc_value"][:ho.n_exc], "rep_offset": out["rep_offset"][:n1], "rep_s": out["rep_s"][:summ.n_repeats],
-               "rep_e": out["rep_e"][:summ.n_repeats], "frag_offset": out["frag_offset"][:n1],
-               "frag_begin": out["frag_begin"][:summ.n_fragments], "frag_end": out["frag_end"][:summ.n_fragments]}
-        return res, summ
+        return self._pipelined_result(rc, s, ho, out)
 
     def fetch_packed(self, pinned: bool = False, out: dict | None = None, width: int = 1) -> dict:
         """Host copies with the coverage array in its transfer encoding (raft_hip_fetch_packed_w): ``cov8`` (uint8 per

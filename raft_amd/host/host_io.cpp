@@ -842,6 +842,54 @@ int raft_host_paf_parse(raft_host_text *text, const raft_host_reads *reads, raft
     return RAFT_HOST_OK;
 }
 
+// The grouped form of a tokenised query column (include/raft_hip.h raft_hip_run_device_grouped): hifiasm writes its PAF
+// grouped by query (reference README.md:36-38), so the column is a handful of runs sorted by read id.  Pass 1 finds the
+// places where the id steps back (and ids outside [0, n_reads)); pass 2 turns every run into its per-read offsets by a
+// linear merge of "read r" against the run, a range of reads per worker.
+int raft_host_group_offsets(int32_t n_reads, int64_t n_rec, const int32_t *qid, int32_t max_runs, int32_t *n_runs, int64_t *rec_offset)
+{
+    if (!n_runs || n_reads < 0 || n_rec < 0 || max_runs < 1 || (n_rec > 0 && !qid) || !rec_offset) return RAFT_HOST_ERR_ARG;
+    *n_runs = 0;
+    int T = host_threads();
+    if (n_rec < (1 << 20)) T = 1;
+    std::vector<std::vector<int64_t>> desc((size_t)T);
+    std::vector<int> bad((size_t)T, 0);
+    parallel_for(T, [&](int t) {
+        const int64_t lo = n_rec * t / T, hi = n_rec * (t + 1) / T;
+        int32_t prev = lo > 0 ? qid[lo - 1] : INT32_MIN;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int32_t q = qid[i];
+            if (q < prev && (int)desc[(size_t)t].size() <= max_runs) desc[(size_t)t].push_back(i);
+            if ((uint32_t)q >= (uint32_t)n_reads) bad[(size_t)t] = 1;
+            prev = q;
+        }
+    });
+    std::vector<int64_t> start{0};
+    for (int t = 0; t < T; ++t) {
+        if (bad[(size_t)t]) return RAFT_HOST_OK;          // an id outside the reads: not grouped (the plain pass reports it)
+        for (int64_t d : desc[(size_t)t]) start.push_back(d);
+    }
+    if ((int64_t)start.size() > max_runs) return RAFT_HOST_OK;   // more runs than the engine takes: not grouped
+    const int R = (int)start.size();
+    start.push_back(n_rec);
+    const int64_t stride = (int64_t)n_reads + 1;
+    const int Tr = n_reads < (1 << 16) ? 1 : T;
+    parallel_for(Tr, [&](int t) {
+        const int64_t r_lo = stride * t / Tr, r_hi = stride * (t + 1) / Tr;     // entries [r_lo, r_hi) of every run
+        for (int k = 0; k < R; ++k) {
+            const int64_t a = start[(size_t)k], b = start[(size_t)k + 1];
+            int64_t pos = std::lower_bound(qid + a, qid + b, (int32_t)std::min<int64_t>(r_lo, INT32_MAX)) - qid;
+            int64_t *o = rec_offset + (int64_t)k * stride;
+            for (int64_t r = r_lo; r < r_hi; ++r) {
+                while (pos < b && qid[pos] < r) ++pos;
+                o[r] = pos;
+            }
+        }
+    });
+    *n_runs = R;
+    return RAFT_HOST_OK;
+}
+
 void raft_host_paf_free(raft_host_paf *p) { delete p; }
 int64_t raft_host_paf_count(const raft_host_paf *p) { return p ? (int64_t)p->n : 0; }
 const int32_t *raft_host_paf_column(const raft_host_paf *p, int k) { return (p && k >= 0 && k < 6) ? p->col[k].get() : nullptr; }

@@ -226,9 +226,11 @@ int main(int argc, char *argv[])
                                 sym ? nullptr : raft_host_paf_column(paf, 4), sym ? nullptr : raft_host_paf_column(paf, 5),
                                 chunks_env ? atoi(chunks_env) : 0, &ho, &s);
         n_exc = ho.n_exc;
-        if (rc != RAFT_HIP_ERR_TOO_LARGE || attempt == 2) break;
-        if (cov_width == 1) cov_width = 2;            // more windows at or above 255 than expected: two bytes per window,
-        else exc_cap = std::max<int64_t>(n_win, 1);   // then room for every window
+        if (rc != RAFT_HIP_ERR_TOO_LARGE || attempt == 2 || n_exc <= exc_cap) break;
+        // more windows at or above the limit than the list holds (n_exc says how many): two bytes per window when a byte
+        // leaves more than one window in 16 on the list, else room for exactly those
+        if (cov_width == 1 && n_exc > n_win / 16) cov_width = 2;
+        else exc_cap = n_exc;
     }
     if (rc != RAFT_HIP_OK) {
         std::string m = std::string("ERROR, raft_hip, ") + raft_hip_strerror(rc);

@@ -15,7 +15,7 @@ EXPORTS = ("raft_host_reads_load", "raft_host_reads_free", "raft_host_reads_coun
            "raft_host_write_fasta", "raft_host_set_threads", "raft_host_get_threads", "raft_host_split_naive",
            "raft_host_paf_symmetric", "raft_host_unpack_coverage", "raft_host_write_coverage_packed",
            "raft_host_unpack_coverage_w", "raft_host_write_coverage_packed_w", "raft_host_text_read", "raft_host_text_free",
-           "raft_host_paf_parse")
+           "raft_host_paf_parse", "raft_host_group_offsets")
 
 
 class HostError(RuntimeError):
@@ -61,6 +61,7 @@ def load_library():
         lib.raft_host_unpack_coverage_w.argtypes = [C.c_int32, C.c_int64, vp, C.c_int64, vp, vp, vp]
         lib.raft_host_write_coverage_packed_w.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp]
         lib.raft_host_get_threads.argtypes = []
+        lib.raft_host_group_offsets.argtypes = [C.c_int32, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32), vp]
         _lib = lib
     return _lib
 
@@ -70,6 +71,25 @@ def set_threads(n: int) -> None:
     rc = load_library().raft_host_set_threads(int(n))
     if rc != OK:
         raise HostError(rc, f"set_threads({n})")
+
+
+def group_offsets(n_reads: int, qid, max_runs: int = 4, out=None):
+    """raft_host_group_offsets: per-read record offsets of a query column that is at most ``max_runs`` runs sorted by read
+    id -> int64 array [n_runs, n_reads + 1]; None when the column is not of that shape (more runs, ids out of range).
+    ``out``: a caller-owned int64 array of at least max_runs * (n_reads + 1) entries (e.g. page-locked) to fill."""
+    q = np.ascontiguousarray(np.asarray(qid), dtype=np.int32)
+    need = max_runs * (n_reads + 1)
+    buf = out if out is not None else np.empty(need, np.int64)
+    if buf.dtype != np.int64 or buf.size < need or not buf.flags["C_CONTIGUOUS"]:
+        raise ValueError("group_offsets: out must be a contiguous int64 array of max_runs * (n_reads + 1) entries")
+    n_runs = C.c_int32(0)
+    rc = load_library().raft_host_group_offsets(int(n_reads), int(q.size), C.c_void_p(q.ctypes.data if q.size else 0), int(max_runs),
+                                                C.byref(n_runs), C.c_void_p(buf.ctypes.data))
+    if rc != OK:
+        raise HostError(rc, "group_offsets")
+    if n_runs.value == 0:
+        return None
+    return buf[: n_runs.value * (n_reads + 1)].reshape(n_runs.value, n_reads + 1)
 
 
 def split_naive(in_path: str, out_path: str, split_len: int) -> int:

@@ -382,6 +382,77 @@ def test_misspeculated_pass_is_redone():
     eng.close()
 
 
+@pytest.mark.parametrize("tile_bins", [0, 256, 1024])
+def test_ids_beyond_the_last_read_at_a_run_tail(tile_bins):
+    """A verified pass (no inspect_kernel) must not lose the records behind the last read's: ids >= n_reads sort to the
+    tail of a run, where the only tile boundary left is the closing one -- a tile in which no read begins owns them, and
+    no kernel walks such a tile.  They have to refute the pass (tile_desc_kernel), so that the redo reports
+    RAFT_HIP_ERR_READ_ID with the first such record, in every form of the pass: symmetric flag handed over, detecting
+    context, chunked pipeline."""
+    from raft_amd import engine
+    rng = np.random.default_rng(2024 + tile_bins)
+    rl = rng.integers(3000, 40000, 1200).astype(np.int32)
+    rl[-1] = 39999                                        # the last read crosses tile boundaries: read-less tiles behind it
+    n = 50000
+    qid = np.sort(rng.integers(0, len(rl), n)).astype(np.int32)
+    tid = rng.integers(0, len(rl), n).astype(np.int32)
+    a = (rng.random(n) * rl[qid] * 0.8).astype(np.int32)
+    b = np.minimum(rl[qid], a + 1 + (rng.random(n) * rl[qid] * 0.2).astype(np.int32)).astype(np.int32)
+    ta = (rng.random(n) * rl[tid] * 0.8).astype(np.int32)
+    tb = np.minimum(rl[tid], ta + 1 + (rng.random(n) * rl[tid] * 0.2).astype(np.int32)).astype(np.int32)
+    order = np.argsort(tid, kind="stable")               # mirrored records, sorted by their query: the second run
+    sym = [np.concatenate([x, y[order]]) for x, y in ((qid, tid), (a, ta), (b, tb), (tid, qid), (ta, a), (tb, b))]
+    bad = len(rl) + 7
+    for where in ("first run", "second run"):
+        cols = [c.copy() for c in sym]
+        at = n - 3 if where == "first run" else 2 * n - 3   # the last three records of the run name a read that does not exist
+        cols[0][at:at + 3] = bad
+        for mode in (1, -1):
+            eng = engine.Engine(RaftParams(est_cov=12, symmetric_mode=mode), device=0)
+            eng.set_tuning(tile_bins, False)
+            with pytest.raises(engine.RaftError) as e:
+                if mode == 1:
+                    eng.run_host(rl, cols[0], cols[1], cols[2], None, None, None)
+                else:
+                    eng.run_host(rl, *cols)
+                eng.finish()
+            assert e.value.code == engine.ERR_READ_ID and e.value.index == at, (where, mode, e.value.code, e.value.index)
+            if mode == 1:
+                for n_chunks in (2, 5):
+                    with pytest.raises(engine.RaftError) as e:
+                        eng.run_pipelined(rl, cols[0], cols[1], cols[2], n_chunks=n_chunks)
+                    assert e.value.code == engine.ERR_READ_ID and e.value.index == at, (where, n_chunks, e.value.index)
+            eng.close()
+
+
+def test_chunked_pipeline_with_records_out_of_place():
+    """symmetric_mode = 1 on a stream that is NOT sorted: single records of late reads planted in early parts of a run.  The
+    host's chunk cuts (bisections of the qid column) may or may not land on them; whatever they do, a record that ends up
+    in a chunk whose reads it does not belong to has to send the job to the one-piece pass: results equal the oracle."""
+    from raft_amd import engine
+    rng = np.random.default_rng(99)
+    rl = rng.integers(3000, 40000, 1500).astype(np.int32)
+    n = 40000
+    qid = np.sort(rng.integers(0, len(rl), n)).astype(np.int32)
+    a = (rng.random(n) * rl[qid] * 0.8).astype(np.int32)
+    b = np.minimum(rl[qid], a + 1 + (rng.random(n) * rl[qid] * 0.2).astype(np.int32)).astype(np.int32)
+    p = RaftParams(est_cov=12)
+    eng = engine.Engine(RaftParams(est_cov=12, symmetric_mode=1), device=0)
+    for trial in range(8):
+        q2, a2, b2 = qid.copy(), a.copy(), b.copy()
+        for _ in range(1 + trial % 3):
+            src = int(rng.integers(n * 3 // 4, n))           # a record of a late read ...
+            dst = int(rng.integers(0, n // 2))               # ... moved into the early part of the run
+            for arr in (q2, a2, b2):
+                v = arr[src]
+                arr[dst + 1:src + 1] = arr[dst:src].copy()
+                arr[dst] = v
+        want = oracle_run(p, rl, q2, a2, b2, q2, a2, b2); want["symmetric"] = 1
+        res, s = eng.run_pipelined(rl, q2, a2, b2, n_chunks=2 + trial)
+        check_pipelined(res, s, want, f"trial {trial}")
+    eng.close()
+
+
 def test_detecting_context_alternating_inputs():
     """A detecting context assumes a symmetric PAF and has tile_desc_kernel look for the mirror of record 0 (pileup.hpp
     MirrorArgs); after a PAF without one it stops assuming until a pass of its own has detected one again.  Symmetric and

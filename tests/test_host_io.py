@@ -354,3 +354,39 @@ def test_fastq_empty_sequence_consumes_its_quality_line(tmp_path):
             r = subprocess.run([REF_BIN, "-e", "2", "-o", name, fq.name, "o.paf"], cwd=tmp_path, stdout=subprocess.PIPE)
             assert r.returncode == 0
             assert len(open(tmp_path / f"{name}.coverage.txt").read().splitlines()) == len(want[name]), name
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_group_offsets(threads):
+    """raft_host_group_offsets: per-read record offsets of a query column that is a handful of sorted runs, against
+    numpy's searchsorted; streams of another shape have no grouped form."""
+    hostio.set_threads(threads)
+    try:
+        rng = np.random.default_rng(4)
+        for n_reads, per_run, k in ((1, 5, 1), (700, 3000, 2), (70000, 600000, 2), (70000, 400000, 4), (50, 0, 1), (300, 40, 3)):
+            runs = [np.sort(rng.integers(0, n_reads, per_run)).astype(np.int32) for _ in range(k)]
+            if per_run and k > 1:
+                for i in range(1, k):                      # make sure a new run really steps back
+                    runs[i][0] = 0
+                    runs[i - 1][-1] = n_reads - 1
+            qid = np.concatenate(runs) if per_run else np.empty(0, np.int32)
+            off = hostio.group_offsets(n_reads, qid, max_runs=4)
+            k_eff = k if per_run else 1
+            assert off is not None and off.shape == (k_eff, n_reads + 1), (n_reads, per_run, k)
+            base = 0
+            for i in range(k_eff):
+                r = runs[i] if per_run else qid
+                want = base + np.searchsorted(r, np.arange(n_reads + 1), side="left")
+                assert np.array_equal(off[i], want), (n_reads, per_run, k, i)
+                base += len(r)
+            assert off[-1, -1] == qid.size
+        q = np.sort(rng.integers(0, 100, 5000)).astype(np.int32)
+        assert hostio.group_offsets(100, np.concatenate([q] * 5), max_runs=4) is None          # five runs
+        assert hostio.group_offsets(100, np.concatenate([q] * 5), max_runs=5).shape == (5, 101)
+        assert hostio.group_offsets(100, rng.permutation(q), max_runs=4) is None                 # shuffled
+        bad = q.copy(); bad[-1] = 100
+        assert hostio.group_offsets(100, bad) is None                                            # id out of range
+        bad[-1] = 99; bad[0] = -1
+        assert hostio.group_offsets(100, bad) is None
+    finally:
+        hostio.set_threads(0)
