@@ -1,29 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- RAFT hot path (PAF overlaps -> coverage -> repeat mask -> fragments) on MI355X.
 
-One "step" = one full pass of the engine (raft_hip_run_device + raft_hip_finish) over one
-synthetic all-vs-all overlap set that is already resident in HBM when the clock starts:
-record inspection, per-tile interval ranges (or counting-sort bucketing), the pileup /
-prefix-sum / run-scan kernel, repeat ordering, cut points, fragment table and the stdout
-statistics.  Outputs stay in HBM.
+One "step" = one full pass of the engine over one synthetic all-vs-all overlap set that is already resident in HBM when the
+clock starts: tile cuts, the pileup / prefix-sum / run-scan kernel, repeat ordering, cut-point counts, fragment table and
+the stdout statistics.  Outputs stay in HBM.  (The cut points themselves -- chop.hpp's final_stars, 4 B per kept marker --
+are materialised by the first caller that asks for them and are not part of a pass; the fragments are derived without
+them.)
 
-Workload (config.workload), default `hg002`: BASELINE.json configs[2] restated synthetically (SURVEY.md §8d,
-config 3): HG002-like 32x set, 3.3 M reads of 30 kb mean length, ~2.9e8 symmetric PAF records
-written as a cis file followed by a trans file, each grouped by ascending query id.  With
---gpus N every rank owns an independent shard of that size (reads and their overlaps shard
-embarrassingly; no data-path collective) -- weak scaling; the only collective is the
-all-gather of per-rank fragment totals that turns local fragment ids into global read_num.
-Other workloads (never the headline line): `ultralong` = configs[4] (60x, 150 kb mean, reads up to 1.5 Mb, 50 kb
-tandem arrays), `s50k` = configs[1] (50 k reads, 20 kb, 30x).
+Input form (`--input`): `grouped` (default) -- what the `raft` CLI hands the engine: the tokeniser's columns plus, per
+sorted run of the stream, where every read's records begin (raft_hip_run_device_grouped; hifiasm writes its PAF grouped by
+query, reference README.md:36-38) and the window count the loader of the reads knows; the pass then needs no look at the
+stream, no searches, no host wait, and still checks every record against the reads of the tile that processes it.
+`columns` -- the six plain columns into a detecting context (symmetric_mode = -1), the form of rounds 1-2; at N = 1 it is
+timed beside the headline as `six_column`.
 
-The line also carries `e2e` (N = 1): the same workload from page-locked host columns to every output back on the
-host (SURVEY.md §8d `t_e2e`; never the headline `value`), and `roofline.pass_frac`: algorithmic bytes over the device
-time of the WHOLE pass, not only the dominant kernel.
+Workload (config.workload), default `hg002`: BASELINE.json configs[2] restated synthetically:
+HG002-like 32x set, 3.3 M reads of 30 kb mean length, ~2.9e8 symmetric PAF records written as a cis file followed by a
+trans file, each grouped by ascending query id.  Other workloads (never the headline line): `ultralong` = configs[4]
+(60x, 150 kb mean, reads up to 1.5 Mb, 50 kb tandem arrays), `s50k` = configs[1] (50 k reads, 20 kb, 30x).
 
-`python bench.py --gpus N` without a launcher starts the N ranks itself (child processes, before any GPU call);
-under `python -m torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE.  `--presplit` puts BASELINE
-configs[3]'s exchange into the timed step: every rank holds a contiguous slice of the record stream and one
-all-to-all-v (RCCL over xGMI) routes the intervals to the ranks that own their reads.
+Several GPUs (`--gpus N`, one process per GPU): by default every rank owns an independent shard of the workload's size
+(reads and their overlaps shard embarrassingly; no data-path collective) -- "scaling": "weak"; the only collective is the
+all-gather of per-rank fragment totals that turns local fragment ids into global read_num.  The same line carries a
+`strong` object: BASELINE configs[3]'s setting -- the ONE set of configs[2] cut into N contiguous read ranges (host-routed:
+every rank is handed the records of its reads), timed the same way, the ranks' totals checked against a single-GPU pass.
+`--strong` makes that the headline ("scaling": "strong"); `--presplit` adds configs[3]'s exchange to it: every rank holds a
+contiguous slice of the record stream and one all-to-all-v (RCCL over xGMI) per step routes the intervals to their owners.
+
+The line also carries (N = 1): `packed_output` -- the pass exactly as the CLI and the host pipelines run it (grouped, no
+query column, coverage written as one byte per window by the pileup kernel itself); `e2e` -- the same workload from
+page-locked host columns to every output back on the host (SURVEY.md §8d `t_e2e`; never the headline `value`);
+`roofline.pass_frac` -- algorithmic bytes over the device time of the WHOLE pass; `cpu_baseline`.
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (child processes, before any GPU call); under
+`python -m torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
 Prints ONE JSON line (rank 0).
 """
@@ -53,7 +63,7 @@ WORKLOADS = {
     "ultralong": (dict(mean_len=150000.0, coverage=60.0, sigma=0.7, min_len=10000, max_len=1_500_000, copies=6,
                        rep_len=(45000, 55000)), 60,
                   "ultralong 60x, 150 kb mean / reads up to 1.5 Mb, 50 kb tandem arrays at 6 copies (BASELINE configs[4]), "
-                  "raft -e 60 defaults; reads longer than the LDS window take the chunked general kernel"),
+                  "raft -e 60 defaults; reads longer than the LDS window are piled up in pieces"),
     "s50k": (dict(mean_len=20000.0, coverage=30.0), 30,
              "50 k reads, 20 kb mean, 30x (BASELINE configs[1]), raft -e 30 -r 50 -l 20000; launch-bound parity config"),
 }
@@ -120,35 +130,60 @@ def cpu_baseline(args, o, p):
     return out, (w, res)
 
 
-def e2e_leg(args, torch, engine, o, p, n_iter=3):
-    """SURVEY.md §8(d) t_e2e: int32 SoA columns in page-locked host memory -> engine -> repeats, fragments and the
+def windows_of(read_len, reso: int) -> int:
+    return int(((read_len.long() + (reso - 1)) // reso).sum())
+
+
+def grouped_form(torch, hostio, n_reads: int, qid, pinned: bool = False):
+    """What the tokeniser knows beside the columns (raft_host_group_offsets): per sorted run, where every read's records
+    begin.  Outside every clock, like the tokenisation itself.  Returns an int64 numpy array [n_runs, n_reads + 1]."""
+    out = torch.empty(4 * (n_reads + 1), dtype=torch.int64, pin_memory=True).numpy() if pinned else None
+    off = hostio.group_offsets(n_reads, qid.cpu().numpy(), max_runs=4, out=out)
+    if off is None:
+        raise SystemExit("bench.py: the synthetic record stream is not a handful of sorted runs")
+    return off
+
+
+def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
+    """SURVEY.md §8(d) t_e2e: the tokeniser's arrays in page-locked host memory -> engine -> repeats, fragments and the
     coverage array (transfer encoding: a byte per window + exceptions) back in page-locked host memory.
 
-    The tokeniser hands the engine the symmetric flag (raft_host_paf_symmetric), so symmetric_mode = 1 and only the
-    three query columns are uploaded.  Host buffers are allocated (page-locked) before the clock; `first_pass_s` is the
-    first pass of a fresh context -- device allocations included -- `seconds` the median of the following ones."""
+    The tokeniser hands the engine the symmetric flag (raft_host_paf_symmetric) and the grouped form of the query column
+    (raft_host_group_offsets), so what is uploaded is read_len, the per-read record offsets, qs and qe -- 8 bytes per
+    record.  Host buffers are allocated (page-locked) before the clock; `first_pass_s` is the first pass of a fresh
+    context -- device allocations included -- `seconds` the median of the following ones.  `six_column_input`: the same
+    through raft_hip_run_pipelined with the query column (12 bytes per record, rounds 1-2)."""
     import numpy as np
-    assert p.symmetric_mode == -1
     pe = type(p)(**dict(p.__dict__, symmetric_mode=1))
     host = [c.cpu().pin_memory().numpy() for c in (o.read_len, o.qid, o.qs, o.qe)]
+    off = grouped_form(torch, hostio, o.n_reads, o.qid, pinned=True)
     eng = engine.Engine(pe, device=torch.cuda.current_device())
     eng.set_tuning(args.tile_bins, args.force_bucket, args.variant)
     width = 2 if p.est_cov >= 40 else 1                   # as the CLI chooses: deep sets pile up beyond a byte in repeats
     out = eng.host_output_buffers(host[0], pinned=True, width=width)   # sized by the bounds of include/raft_hip.h, from the read lengths
     out["frag_read"] = torch.empty(out["frag_begin"].size, dtype=torch.int32, pin_memory=True).numpy()
-    # (a) chunked: upload, pass and download of consecutive read ranges overlap (raft_hip_run_pipelined)
+    # (a) chunked, grouped input: upload, pass and download of consecutive read ranges overlap (raft_hip_run_multi_grouped)
     ptimes = []
     for it in range(n_iter + 1):
         t0 = time.perf_counter()
-        pres, ps = eng.run_pipelined(host[0], host[1], host[2], host[3], out=out)
+        pres, ps = eng.run_pipelined_grouped(host[0], off, host[2], host[3], out=out)
         ptimes.append(time.perf_counter() - t0)
     psum = (ps.n_bins, ps.n_repeats, ps.n_fragments, ps.total_coverage, ps.total_repeat_length)
     pcopy = {k: pres[k].copy() for k in ("cov8", "rep_s", "rep_e", "frag_begin", "frag_end", "cov_offset", "rep_offset", "frag_offset")}
-    # (b) one piece: H2D, pass, pack, D2H one after the other (raft_hip_run_host + raft_hip_fetch_packed)
-    times, split = [], None
-    for it in range(n_iter + 1):
+    # (b) chunked, six-column input (query column uploaded, runs guessed from samples, cuts searched)
+    ctimes = []
+    for it in range(n_iter):
         t0 = time.perf_counter()
-        eng.run_host(host[0], host[1], host[2], host[3], None, None, None)
+        cres, cs = eng.run_pipelined(host[0], host[1], host[2], host[3], out=out)
+        ctimes.append(time.perf_counter() - t0)
+    same_c = psum == (cs.n_bins, cs.n_repeats, cs.n_fragments, cs.total_coverage, cs.total_repeat_length) and \
+        all(np.array_equal(pcopy[k], cres[k]) for k in pcopy)
+    # (c) one piece: H2D, pass, D2H one after the other (raft_hip_run_host_grouped + raft_hip_fetch_packed)
+    times, split = [], None
+    eng.set_output_width(width)
+    for it in range(n_iter):
+        t0 = time.perf_counter()
+        eng.run_host_grouped(host[0], off, host[2], host[3])
         s = eng.finish()
         t1 = time.perf_counter()
         got = eng.fetch_packed(out=out)
@@ -163,18 +198,22 @@ def e2e_leg(args, torch, engine, o, p, n_iter=3):
     dev8 = torch.from_numpy(got["cov8"].astype(np.int32) if width == 2 else got["cov8"]).to(o.read_len.device)
     cov = eng.outputs_device()["cov"]
     ok = bool((dev8.to(torch.int32) == cov.clamp(max=limit)).all()) and int((cov >= limit).sum()) == got["exc_index"].size
-    in_bytes = sum(a.nbytes for a in host)
+    in_bytes = host[0].nbytes + off.nbytes + host[2].nbytes + host[3].nbytes
     out_bytes = sum(a.nbytes for a in got.values())
     eng.close()
-    steady = sorted(ptimes[1:])[len(ptimes[1:]) // 2]
-    one_piece = sorted(times[1:])[len(times[1:]) // 2]
+    med = lambda v: sorted(v)[len(v) // 2]
+    steady, six, one_piece = med(ptimes[1:]), med(ctimes[1:]) if len(ctimes) > 1 else ctimes[0], med(times[1:]) if len(times) > 1 else times[0]
     return {"records_per_s": o.n_rec / steady, "fragments_per_s": s.n_fragments / steady, "seconds": steady,
-            "first_pass_s": ptimes[0], "mode": "chunked: H2D / pass / D2H of consecutive read ranges overlapped (raft_hip_run_pipelined)",
+            "first_pass_s": ptimes[0],
+            "mode": "chunked, grouped input: H2D / pass / D2H of consecutive read ranges overlapped (raft_hip_run_multi_grouped); "
+                    "no query column crosses PCIe",
+            "six_column_input": {"records_per_s": o.n_rec / six, "seconds": six, "h2d_bytes": sum(a.nbytes for a in host),
+                                 "mode": "raft_hip_run_pipelined (query column uploaded)", "equals_grouped": bool(same_c)},
             "one_piece": {"records_per_s": o.n_rec / one_piece, "seconds": one_piece, "h2d_plus_pass_s": split[0], "pack_plus_d2h_s": split[1]},
             "chunked_equals_one_piece": bool(same),
             "host_memory": "page-locked, allocated before the clock, caller-owned and reused" if reused else "page-locked (grown inside the clock)",
             "h2d_bytes": in_bytes, "d2h_bytes": out_bytes, "coverage_encoding": f"uint{8 * width} per window + (index, value) for windows >= {limit}",
-            "exceptions": int(got["exc_index"].size), "symmetric_mode": "asserted by the tokeniser: query columns only",
+            "exceptions": int(got["exc_index"].size), "symmetric_mode": "asserted by the tokeniser: query sides only",
             "decoded_coverage_equals_device": ok, "passes": n_iter}
 
 
@@ -203,20 +242,27 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="hg002")
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's own size)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's own size); with --strong / --presplit: reads of the ONE set")
     ap.add_argument("--seed", type=int, default=20241008)
+    ap.add_argument("--input", choices=["grouped", "columns"], default="grouped",
+                    help="grouped: columns + per-read record offsets + window count (what the CLI hands over); columns: six plain columns, detecting context")
+    ap.add_argument("--no-qid", action="store_true", help="grouped input without the query column (rebuilt from the offsets on the device)")
     ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cov-width", type=int, default=4, choices=[1, 2, 4], help="bytes per window the timed pass writes (4 = int32 cov[]; 1 / 2 = its transfer encoding)")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the extra passes that time the pass writing the transfer encoding")
-    ap.add_argument("--handover", action="store_true", help="symmetric_mode = 1: the symmetric flag is handed over, as the CLI does")
-    ap.add_argument("--no-detect-leg", action="store_true", help="skip the extra passes that time the inspect-first form")
-    ap.add_argument("--presplit", action="store_true", help="BASELINE configs[3]: records pre-split across ranks, all-to-all-v in the step")
+    ap.add_argument("--handover", action="store_true", help="--input columns with symmetric_mode = 1: the symmetric flag is handed over")
+    ap.add_argument("--no-six-column-leg", action="store_true", help="skip the extra passes that time the six-column detecting form")
+    ap.add_argument("--strong", action="store_true", help="ONE set cut into --gpus contiguous read ranges (BASELINE configs[3] without the exchange)")
+    ap.add_argument("--presplit", action="store_true", help="BASELINE configs[3]: --strong with the records pre-split across ranks, all-to-all-v in the step")
+    ap.add_argument("--no-strong-leg", action="store_true", help="weak multi-GPU runs: skip the strong-scaling leg")
     ap.add_argument("--tile-bins", type=int, default=0)
     ap.add_argument("--force-bucket", action="store_true")
     ap.add_argument("--variant", type=int, default=-1, help="pileup kernel variant (engine.hip kVariants), -1 = default")
     args = ap.parse_args()
+    if args.presplit:
+        args.strong = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -224,7 +270,7 @@ def main():
     import torch
 
     from raft_amd import dist as rdist
-    from raft_amd import engine
+    from raft_amd import engine, hostio
     from raft_amd.params import RaftParams
     from raft_amd.synth import make_overlaps
 
@@ -258,89 +304,152 @@ def main():
     gen_kw, est_cov, workload_text = WORKLOADS[args.workload]
     n_reads = args.reads or DEFAULT_READS[args.workload]
     p = RaftParams(est_cov=est_cov)
-
-    # ---- synthetic shard, generated on the device (resident in HBM before the clock starts)
-    if not args.presplit or world == 1:
-        o = make_overlaps(n_reads, seed=args.seed + rank, device=dev, **gen_kw)
-        cols = (o.read_len,) + o.columns()
-        my_rec = o.n_rec
-    else:
-        # BASELINE configs[3]: ONE global record stream, rank g holds its g-th contiguous slice.  The stream is built so
-        # that every slice holds records of every rank's reads: set h (seed + h, reads [h*n, (h+1)*n) globally) is
-        # generated in turn and its g-th n-th part is appended to rank g's slice.
-        parts, lens = [], []
-        for h in range(world):
-            oh = make_overlaps(n_reads, seed=args.seed + h, device=dev, **gen_kw)
-            lo, hi = oh.n_rec * rank // world, oh.n_rec * (rank + 1) // world
-            q, qs, qe, t, ts, te = (c[lo:hi] for c in oh.columns())
-            parts.append((q + h * n_reads, qs, qe, t + h * n_reads, ts, te))
-            lens.append(oh.read_len)
-            del oh
-        slice_cols = [torch.cat([pp[k] for pp in parts]).contiguous() for k in range(6)]
-        read_len_all = torch.cat(lens)
-        del parts, lens
-        my_rec = int(slice_cols[0].numel())
-        bounds = rdist.partition_reads(read_len_all, p.reso, world)
-        b0, b1 = int(bounds[rank]), int(bounds[rank + 1])
-        my_len = read_len_all[b0:b1].contiguous()
-    torch.cuda.synchronize()
-
-    # The engine is self-contained here (symmetric_mode = -1: it finds out by itself that the PAF is symmetric).  Its pass is
-    # built on a sampled guess of the sorted runs and the assumption of a symmetric PAF, both verified while it runs (the
-    # runs in the pileup kernels, the mirror of record 0 by a one-workgroup kernel beside them); `--handover` runs it as
-    # the `raft` CLI does, with the flag the tokeniser found (symmetric_mode = 1: no target columns needed at all).  The
-    # default line also times the form that looks at every record first (inspect pass): roofline.pass_device_ms_inspect_first.
-    p_run = RaftParams(**dict(p.__dict__, symmetric_mode=1)) if (args.handover or (args.presplit and world > 1)) else p
-    eng = engine.Engine(p_run, device=local)
-    eng.set_tuning(args.tile_bins, args.force_bucket, args.variant)
-    eng.set_output_width(args.cov_width)
-    eng.use_torch_stream()
-
-    def step():
-        if args.presplit and world > 1:
-            cl = [c if not shared else c.cpu() for c in slice_cols]
-            sym = rdist.global_symmetric_flag(cl)                         # broadcast of record 0 + MAX all-reduce
-            iv = rdist.exchange_intervals(cl, bounds, sym)                # ONE all-to-all-v (RCCL over xGMI)
-            iv = tuple(t.to(dev) for t in iv)
-            s = rdist.run_shard(eng, my_len, iv)
-        else:
-            eng.run_device(*cols)
-            s = eng.finish()
-        if dist is not None:  # global read_num base of this shard's fragments + the stdout sums (chop.hpp:195, repeat.hpp:93-97)
-            rdist.combine_totals(s.n_fragments, s.total_coverage, s.total_windows, s.total_repeat_length,
-                                 s.total_read_length, device=coll_dev)
-        return s
-
-    for _ in range(args.warmup):
-        s = step()
-    pile_t, pass_t = [], []
+    p_sym = RaftParams(**dict(p.__dict__, symmetric_mode=1))
+    grouped_in = args.input == "grouped" and not args.force_bucket
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s = step()
-        a, b = eng.timing()
-        pile_t.append(a); pass_t.append(b)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([my_rec, s.n_fragments, s.n_bins, s.n_intervals], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        tot_rec, tot_frag, tot_bins, tot_iv = (int(x) for x in cnt.tolist())
-    else:
-        tot_rec, tot_frag, tot_bins, tot_iv = my_rec, s.n_fragments, s.n_bins, s.n_intervals
+    class Shard:
+        """One rank's inputs, resident in HBM: read lengths, the tokeniser's columns and (grouped input) the per-read
+        record offsets + the window count."""
+        def __init__(self, read_len, cols, want_grouped):
+            self.read_len, self.cols = read_len.contiguous(), tuple(c.contiguous() for c in cols)
+            self.n_reads, self.n_rec = int(read_len.numel()), int(cols[0].numel())
+            self.off = self.n_bins = None
+            if want_grouped:
+                self.off = torch.as_tensor(grouped_form(torch, hostio, self.n_reads, self.cols[0])).to(dev)
+                self.n_bins = windows_of(self.read_len, p.reso)
 
-    # ---- self-check of the last timed pass (outside the clock): size-independent invariants of the outputs
-    check = {}
-    if not (args.presplit and world > 1):
+    def make_engine(sh: Shard, width: int):
+        e = engine.Engine(p_sym if (sh.off is not None or args.handover) else p, device=local)
+        e.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+        e.set_output_width(width)
+        e.use_torch_stream()
+        return e
+
+    def pass_of(e, sh: Shard, qid=True):
+        if sh.off is not None:
+            e.run_device_grouped(sh.read_len, sh.off, sh.cols[0] if qid else None, sh.cols[1], sh.cols[2], n_bins=sh.n_bins)
+        else:
+            e.run_device(sh.read_len, *sh.cols)
+        return e.finish()
+
+    def combine(s):
+        # global read_num base of this shard's fragments + the stdout sums (chop.hpp:195, repeat.hpp:93-97)
+        if dist is not None:
+            rdist.combine_totals(s.n_fragments, s.total_coverage, s.total_windows, s.total_repeat_length, s.total_read_length, device=coll_dev)
+
+    def timed(step_fn, e, warmup, steps):
+        for _ in range(warmup):
+            s = step_fn()
+        pile_t, pass_t = [], []
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s = step_fn()
+            a, b = e.timing()
+            pile_t.append(a); pass_t.append(b)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return s, elapsed, sum(pile_t) / len(pile_t), sum(pass_t) / len(pass_t)
+
+    def strong_shard(full, presplit):
+        """BASELINE configs[3]: the ONE set cut into `world` contiguous read ranges of near-equal weight.  Host-routed: this
+        rank is handed the records whose query is one of its reads (a sub-sequence of every sorted run: still grouped).
+        Pre-split: this rank holds the rank-th contiguous slice of the record stream and the step routes it."""
+        ipr = torch.bincount(full.qid.long(), minlength=full.n_reads)
+        bounds = rdist.partition_reads(full.read_len, p.reso, world, intervals_per_read=ipr)
+        b0, b1 = int(bounds[rank]), int(bounds[rank + 1])
+        my_len = full.read_len[b0:b1].contiguous()
+        if presplit:
+            lo, hi = full.n_rec * rank // world, full.n_rec * (rank + 1) // world
+            return bounds, my_len, [c[lo:hi].contiguous() for c in full.columns()]
+        sel = (full.qid >= b0) & (full.qid < b1)
+        cols = [c[sel] for c in full.columns()]
+        cols[0] = cols[0] - b0
+        return bounds, my_len, cols
+
+    def single_gpu_totals(full):
+        e = engine.Engine(p, device=local)
+        e.use_torch_stream()
+        e.run_device(full.read_len, *full.columns())
+        s = e.finish()
+        e.close()
+        return [s.n_fragments, s.n_repeats, s.total_coverage, s.total_repeat_length, s.n_bins]
+
+    def strong_run(full, presplit, warmup, steps):
+        """Times the strong-scaling step on this rank's share of `full`; returns (summary, elapsed, kernel s, pass s, records
+        of the whole set, totals-equal-single-GPU or None)."""
+        bounds, my_len, cols = strong_shard(full, presplit)
+        if presplit:
+            e = engine.Engine(p_sym, device=local)
+            e.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+            e.use_torch_stream()
+
+            def step():
+                cl = [c if not shared else c.cpu() for c in cols]
+                sym = rdist.global_symmetric_flag(cl)                         # broadcast of record 0 + MAX all-reduce
+                iv = rdist.exchange_intervals(cl, bounds, sym)                # ONE all-to-all-v (RCCL over xGMI)
+                iv = tuple(t.to(dev) for t in iv)
+                s = rdist.run_shard(e, my_len, iv)
+                combine(s)
+                return s
+        else:
+            sh = Shard(my_len, cols, grouped_in)
+            e = make_engine(sh, args.cov_width)
+
+            def step():
+                s = pass_of(e, sh, qid=not args.no_qid)
+                combine(s)
+                return s
+        s, elapsed, pile, pass_dev = timed(step, e, warmup, steps)
+        mine = torch.tensor([s.n_fragments, s.n_repeats, s.total_coverage, s.total_repeat_length, s.n_bins, s.n_intervals], dtype=torch.int64, device=coll_dev or dev)
+        if dist is not None:
+            dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        e.close()
+        ok = None
+        if rank == 0:
+            ok = single_gpu_totals(full) == [int(x) for x in mine[:5].tolist()]
+        return s, elapsed, pile, pass_dev, [int(x) for x in mine.tolist()], ok
+
+    # ---- the timed region
+    strong_info = None
+    if args.strong and world > 1:
+        full = make_overlaps(n_reads, seed=args.seed, device=dev, **gen_kw)
+        torch.cuda.synchronize()
+        s, elapsed, pile, pass_dev, tot, ok = strong_run(full, args.presplit, args.warmup, args.steps)
+        tot_rec, tot_frag, tot_bins, tot_iv = full.n_rec, tot[0], tot[4], tot[5]
+        my_rec = s.n_records
+        if rank == 0 and not ok:
+            raise SystemExit("bench.py: the ranks' totals differ from the single-GPU pass over the same set")
+        o, eng, check = full, None, {"ranks_totals_equal_single_gpu_pass": bool(ok)} if rank == 0 else {}
+    else:
+        o = make_overlaps(n_reads, seed=args.seed + rank, device=dev, **gen_kw)
+        sh = Shard(o.read_len, o.columns(), grouped_in)
+        torch.cuda.synchronize()
+        eng = make_engine(sh, args.cov_width)
+        my_rec = o.n_rec
+
+        def step():
+            s = pass_of(eng, sh, qid=not args.no_qid)
+            combine(s)
+            return s
+        s, elapsed, pile, pass_dev = timed(step, eng, args.warmup, args.steps)
+        if dist is not None:
+            cnt = torch.tensor([my_rec, s.n_fragments, s.n_bins, s.n_intervals], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            tot_rec, tot_frag, tot_bins, tot_iv = (int(x) for x in cnt.tolist())
+        else:
+            tot_rec, tot_frag, tot_bins, tot_iv = my_rec, s.n_fragments, s.n_bins, s.n_intervals
+
+        # ---- self-check of the last timed pass (outside the clock): size-independent invariants of the outputs
         out = eng.outputs_device()
         touched = ((o.qe.long() - 1) // p.reso - o.qs.long() // p.reso + 1).clamp(min=0)
         fo, fb, fe = out["frag_offset"], out["frag_begin"], out["frag_end"]
@@ -353,13 +462,29 @@ def main():
         if not all(check.values()):
             raise SystemExit(f"bench.py: self-check failed: {check}")
 
-    # ---- the pass as the CLI and the host pipelines run it: the pileup kernel writes the transfer encoding of cov[] (one
-    # byte per window, two from -e 40 on, + the windows at or above the limit) instead of int32.  Same job, a third of the
-    # HBM bytes; reported beside the int32 line, checked against it here (outside the clock).
+        # ---- several GPUs, weak headline: BASELINE configs[3]'s setting beside it -- the ONE set of configs[2] in `world` read ranges
+        if world > 1 and not args.no_strong_leg:
+            full = make_overlaps(n_reads, seed=args.seed, device=dev, **gen_kw) if rank else o   # (rank 0's weak shard IS that set)
+            torch.cuda.synchronize()
+            s2, el2, pile2, pass2, tot2, ok2 = strong_run(full, False, args.warmup, args.steps)
+            if rank == 0:
+                strong_info = {"scaling": "strong", "value": full.n_rec / (el2 / args.steps), "unit": "PAF records/s", "ms_per_step": el2 / args.steps * 1e3,
+                               "fragments_per_s": tot2[0] / (el2 / args.steps), "records_total": full.n_rec, "reads_total": full.n_reads,
+                               "rank0_reads": s2.n_reads, "rank0_records": s2.n_records, "rank0_kernel_ms": pile2 * 1e3, "rank0_pass_device_ms": pass2 * 1e3,
+                               "sharding": f"the ONE set of {full.n_reads} reads in {world} contiguous read ranges, host-routed (every rank is handed the records "
+                                           "of its reads), no data-path collective; BASELINE configs[3] without the exchange (that: --presplit)",
+                               "ranks_totals_equal_single_gpu_pass": bool(ok2)}
+            if rank:
+                del full
+
+    # ---- the pass exactly as the CLI and the host pipelines run it: grouped input WITHOUT the query column (it never crosses
+    # PCIe: rebuilt from the offsets on the device), the pileup kernel writing the transfer encoding of cov[] (one byte per
+    # window, two from -e 40 on, + the windows at or above the limit).  Checked against the int32 pass (outside the clock).
     packed = None
-    if n_gpus == 1 and not args.presplit and not args.no_packed_leg and args.cov_width == 4:
+    if n_gpus == 1 and not args.no_packed_leg and args.cov_width == 4:
         w = 2 if p.est_cov >= 40 else 1
-        e3 = engine.Engine(p_run, device=local)
+        shp = sh if sh.off is not None else Shard(o.read_len, o.columns(), True)
+        e3 = engine.Engine(p_sym, device=local)
         e3.set_tuning(args.tile_bins, args.force_bucket, args.variant)
         e3.set_output_width(w)
         e3.use_torch_stream()
@@ -367,8 +492,7 @@ def main():
         for it in range(6):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            e3.run_device(*cols)
-            s3 = e3.finish()
+            s3 = pass_of(e3, shp, qid=False)
             torch.cuda.synchronize()
             if it:
                 wall.append(time.perf_counter() - t1)
@@ -385,70 +509,98 @@ def main():
         ok = ok and (s3.n_fragments, s3.n_repeats, s3.total_coverage, s3.total_repeat_length) == (s.n_fragments, s.n_repeats, s.total_coverage, s.total_repeat_length)
         if not ok:
             raise SystemExit("bench.py: the packed-output pass differs from the int32 pass")
-        bytes_p = 12 * s3.n_intervals + w * s3.n_bins + 12 * int(pk["exc_index"].numel()) + 4 * s3.n_reads + 8 * s3.n_repeats
+        # algorithmic bytes of this form: 8 B per record read (qs, qe; the id comes from 8 B per read and run), w per window written
+        bytes_p = 8 * s3.n_intervals + 16 * s3.n_reads * shp.off.shape[0] + w * s3.n_bins + 12 * int(pk["exc_index"].numel()) + 4 * s3.n_reads + 8 * s3.n_repeats
         k_s, p_s, w_s = sum(kt) / len(kt), sum(pt) / len(pt), sum(wall) / len(wall)
-        packed = {"cov_width": w, "value": my_rec / w_s, "unit": "PAF records/s", "ms_per_step": w_s * 1e3, "kernel_ms": k_s * 1e3,
-                  "pass_device_ms": p_s * 1e3, "bytes_algorithmic": bytes_p, "kernel_frac": bytes_p / k_s / 1e9 / HBM_PEAK_GBS,
-                  "pass_frac": bytes_p / p_s / 1e9 / HBM_PEAK_GBS, "n_exceptions": int(pk["exc_index"].numel()),
-                  "equals_int32_pass": ok}
+        packed = {"cov_width": w, "input": "grouped, no query column (ids rebuilt from the offsets on the device)", "value": my_rec / w_s, "unit": "PAF records/s",
+                  "ms_per_step": w_s * 1e3, "kernel_ms": k_s * 1e3, "pass_device_ms": p_s * 1e3, "bytes_algorithmic": bytes_p,
+                  "kernel_frac": bytes_p / k_s / 1e9 / HBM_PEAK_GBS, "pass_frac": bytes_p / p_s / 1e9 / HBM_PEAK_GBS,
+                  "n_exceptions": int(pk["exc_index"].numel()), "equals_int32_pass": ok}
         del ref_cov, codes, big, order, pk
         e3.close()
 
-    inspect_ms = None
-    if n_gpus == 1 and not args.presplit and not args.no_detect_leg:
-        # the same pass in its round-1 form: inspect_kernel looks at every record before anything else starts
-        os.environ["RAFT_ALWAYS_INSPECT"] = "1"
-        try:
-            e2 = engine.Engine(p_run, device=local)
-            e2.set_tuning(args.tile_bins, args.force_bucket, args.variant)
-            e2.use_torch_stream()
-            tt = []
-            for it in range(4):
-                e2.run_device(*cols)
-                s2 = e2.finish()
-                if it:
-                    tt.append(e2.timing()[1])
-            assert (s2.n_fragments, s2.n_repeats, s2.total_coverage, s2.symmetric) == (s.n_fragments, s.n_repeats, s.total_coverage, 1)
-            inspect_ms = sum(tt) / len(tt) * 1e3
-            e2.close()
-        finally:
-            del os.environ["RAFT_ALWAYS_INSPECT"]
+    # ---- the six plain columns into a detecting context (rounds 1-2's headline form), and its inspect-first form
+    six = None
+    if n_gpus == 1 and not args.no_six_column_leg and grouped_in:
+        def six_passes(env=None):
+            if env:
+                os.environ[env] = "1"
+            try:
+                e2 = engine.Engine(p, device=local)
+                e2.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+                e2.use_torch_stream()
+                kt, pt, wall = [], [], []
+                for it in range(5):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    e2.run_device(o.read_len, *o.columns())
+                    s2 = e2.finish()
+                    torch.cuda.synchronize()
+                    if it:
+                        wall.append(time.perf_counter() - t1)
+                        a, b = e2.timing(); kt.append(a); pt.append(b)
+                assert (s2.n_fragments, s2.n_repeats, s2.total_coverage, s2.symmetric) == (s.n_fragments, s.n_repeats, s.total_coverage, 1)
+                e2.close()
+                return sum(kt) / len(kt), sum(pt) / len(pt), sum(wall) / len(wall)
+            finally:
+                if env:
+                    del os.environ[env]
+        k2, p2, w2 = six_passes()
+        _, p2i, _ = six_passes("RAFT_ALWAYS_INSPECT")
+        six = {"value": my_rec / w2, "unit": "PAF records/s", "ms_per_step": w2 * 1e3, "kernel_ms": k2 * 1e3, "pass_device_ms": p2 * 1e3,
+               "pass_device_ms_inspect_first": p2i * 1e3,
+               "form": "raft_hip_run_device, symmetric_mode = -1: sorted runs guessed from samples, tile cuts searched, mirror of record 0 found beside the pileup, one host wait"}
 
     if rank == 0:
         per_step = elapsed / args.steps
-        # dominant kernel: pileup + prefix scan + coverage store + run scan (pileup.hpp).
+        # dominant kernel: pileup + prefix scan + coverage store + run scan (pileup_fast.hpp).
         # algorithmic bytes per launch (this rank): 12 B per interval read once, 4 B per window written once,
         # 4 B per read (length) and 8 B per repeat emitted
         bytes_alg = 12 * s.n_intervals + args.cov_width * s.n_bins + 4 * s.n_reads + 8 * s.n_repeats
-        pile = sum(pile_t) / len(pile_t)
-        pass_dev = sum(pass_t) / len(pass_t)
         achieved = bytes_alg / pile / 1e9
+        strong_line = args.strong and world > 1
+        if args.presplit and world > 1:
+            input_text = "records pre-split across ranks; the received intervals enter as query-side records (raft_hip_run_device, symmetric_mode = 1)"
+        elif grouped_in:
+            input_text = ("grouped (raft_hip_run_device_grouped): columns + per-read record offsets of every sorted run + window count, as the CLI hands them over"
+                          + ("; no query column" if args.no_qid else "; every record checked against its tile's reads"))
+        else:
+            input_text = "six plain columns (raft_hip_run_device)" + (", symmetric flag handed over" if args.handover else ", detecting context")
         line = {
             "metric": "PAF overlap records/s + fragments/s, 32x human all-vs-all; HBM GB/s vs peak",
             "value": tot_rec / per_step, "unit": "PAF records/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "strong" if strong_line else "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "fragments_per_s": tot_frag / per_step,
-            "config": {"workload": workload_text, "workload_name": args.workload,
+            "config": {"workload": workload_text, "workload_name": args.workload, "input": input_text,
                        "reads_per_gpu": s.n_reads, "records_per_gpu": my_rec, "records_total": tot_rec,
                        "windows_total": tot_bins, "intervals_total": tot_iv, "fragments_total": tot_frag,
                        "repeats_rank0": s.n_repeats, "mean_read_len": gen_kw["mean_len"], "coverage": gen_kw["coverage"],
                        "interval_path": "sorted-segments" if s.interval_path == 0 else "counting-sort",
                        "segments": s.n_segments,
-                       "sharding": (f"reads x{n_gpus}, records pre-split, one all-to-all-v per step" if args.presplit and world > 1
-                                    else f"reads x{n_gpus}, no data-path collective") + (", ranks share GPUs (gloo check run)" if shared else "")},
+                       "cut_points": "materialised on demand by the first fetch that asks for them (finalize_cuts_kernel), outside the pass and the clock; "
+                                     "fragment bounds are derived without them",
+                       "sharding": (f"the ONE set of {o.n_reads} reads in {n_gpus} contiguous read ranges, "
+                                    + ("records pre-split, one all-to-all-v per step" if args.presplit else "host-routed, no data-path collective") if strong_line
+                                    else f"reads x{n_gpus}, independent shards, no data-path collective") + (", ranks share GPUs (gloo check run)" if shared else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": ("pileup_fast_kernel (+ pileup_kernel for the tiles it leaves)" if args.variant != 1 else "pileup_kernel")
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": ("pileup_fast_kernel (regular + re-cut tiles)" if args.variant != 1 else "pileup_kernel")
                                    + ("" if args.variant < 0 else f" variant {args.variant}"),
                          "kernel_ms": pile * 1e3, "bytes_algorithmic": bytes_alg,
                          "pass_device_ms": pass_dev * 1e3, "pass_achieved": bytes_alg / pass_dev / 1e9,
-                         "pass_frac": bytes_alg / pass_dev / 1e9 / HBM_PEAK_GBS, "kernel_source_hash": kernel_source_hash(),
-                         "symmetric_mode": "handed over by the tokeniser (as the CLI does)" if args.handover else "detected by the engine (mirror of record 0 found beside the pileup)",
-                         "pass_device_ms_inspect_first": inspect_ms},
+                         "pass_frac": bytes_alg / pass_dev / 1e9 / HBM_PEAK_GBS, "kernel_source_hash": kernel_source_hash()},
             "self_check": check,
         }
         if packed is not None:
+            # the product path (what the CLI runs) next to the int32 figures: a byte per window written, no query column read
+            line["roofline"].update(product_path_kernel_ms=packed["kernel_ms"], product_path_frac=packed["kernel_frac"],
+                                    product_path_pass_device_ms=packed["pass_device_ms"], product_path_pass_frac=packed["pass_frac"],
+                                    product_path_bytes_algorithmic=packed["bytes_algorithmic"])
             line["packed_output"] = packed
+        if six is not None:
+            line["six_column"] = six
+        if strong_info is not None:
+            line["strong"] = strong_info
         if args.cov_width != 4:
             line["config"]["cov_width"] = args.cov_width
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -463,20 +615,19 @@ def main():
                     line["roofline"]["traffic_note"] = "profiles/pmc_traffic.json is from another workload or kernel build (stale): not used"
             except Exception:
                 pass
-        if n_gpus == 1 and not args.presplit:
+        if n_gpus == 1:
             if not args.no_e2e:
                 try:
-                    line["e2e"] = e2e_leg(args, torch, engine, o, p)
+                    line["e2e"] = e2e_leg(args, torch, engine, hostio, o, p)
                 except engine.RaftError as ex:
-                    # e.g. the ultralong workload: tandem arrays at 6 copies put half of all windows at or above 255, where
-                    # the byte-per-window transfer encoding has to list them one by one -- more than the leg's buffers hold
-                    line["e2e"] = {"error": str(ex), "note": "transfer encoding of cov[] (uint8 + exceptions) not suited to this "
-                                   "coverage: the caller has to provide room for one exception per window at or above 255"}
+                    line["e2e"] = {"error": str(ex), "note": "transfer encoding of cov[] not suited to this coverage: the caller has to "
+                                   "provide room for one exception per window at or above the limit"}
             if not args.no_cpu_baseline:
                 cb, _ = cpu_baseline(args, o, p)
                 line["cpu_baseline"] = cb
         print(json.dumps(line))
-    eng.close()
+    if eng is not None:
+        eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

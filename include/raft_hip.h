@@ -267,6 +267,13 @@ int  raft_hip_run_multi_grouped(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_
                                 int32_t n_runs, const int64_t *rec_offset, const int32_t *qs, const int32_t *qe,
                                 int32_t n_chunks, raft_hip_host_outputs *out, raft_hip_summary *summary);
 
+/* Page-locks / releases a range of the caller's host memory (hipHostRegister, every device of the node).  Arrays handed to
+ * the host-to-host entry points move at the link's rate (53 GB/s each way on MI355X) only from page-locked memory; pages
+ * that have been written before are pinned at ~120 GB/s, untouched ones at the cost of their first touch.  A caller that
+ * cannot register (not its memory, already registered) may ignore the error: the copies then take the pageable path. */
+int  raft_hip_host_register(void *ptr, uint64_t bytes);
+int  raft_hip_host_unregister(void *ptr);
+
 /* Device seconds spent in the dominant kernel (coverage pileup + run scan) and
  * in all kernels of the last finished pass, from HIP events recorded on the
  * context's stream around them. */

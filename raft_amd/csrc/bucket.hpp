@@ -120,13 +120,30 @@ __global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const 
     }
 }
 
-// tile_first[k] = first read whose first window lies in tile k or later (tiles of Q windows).
+// tile_first[k] = first read whose first window lies in tile k or later (tiles of Q windows).  For grouped input the same
+// threads -- one per read, coalesced -- check the caller's offsets: they must not step back and the runs must chain from
+// record 0 to record n_rec (kErrGroup; every later kernel of the pass then returns at once).
 __global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const long long *cov_off, int Q,
-                                                         long long n_tiles, int32_t *tile_first, const int32_t *err_flags)
+                                                         long long n_tiles, int32_t *tile_first, int32_t *err_flags,
+                                                         long long *err_index, GroupedOff grp, int32_t n_runs, long long n_rec)
 {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > n_reads) return;
     if (*(volatile const int32_t *)err_flags & kErrStop) return;   // (n_tiles comes from a window count the device found wrong)
+    if (grp.off) {
+        bool bad = false;
+        if (r < n_reads)
+            for (int s = 0; s < n_runs; ++s) bad |= grp.at(s, r) > grp.at(s, r + 1);
+        if (r == 0) {
+            long long at = 0;
+            for (int s = 0; s < n_runs; ++s) { bad |= grp.at(s, 0) != at; at = grp.at(s, n_reads); }
+            bad |= at != n_rec;
+        }
+        if (bad) {
+            atomicOr(err_flags, kErrGroup);
+            atomicMin((unsigned long long *)err_index, (unsigned long long)r);
+        }
+    }
     const long long t_r = (r < n_reads) ? cov_off[r] / Q : n_tiles;
     const long long t_p = (r > 0) ? cov_off[r - 1] / Q : -1;
     for (long long k = t_p + 1; k <= t_r; ++k) tile_first[k] = (int32_t)r;

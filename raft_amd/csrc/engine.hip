@@ -131,25 +131,8 @@ struct ReadPrepLoader {               // per read: windows, reserved repeat slot
     int32_t long_windows, piece_w;    // reads longer than long_windows are piled up in pieces of piece_w windows
     int32_t *err_flags;
     long long *err_index;
-    // grouped input: the offsets of every run must not step back, and the runs must chain from record 0 to record n_rec
-    GroupedOff grp;
-    int32_t n_runs, n_reads;
-    long long n_rec;
     __device__ void operator()(long long i, long long (&v)[3]) const
     {
-        if (grp.off) {
-            bool bad = false;
-            for (int s = 0; s < n_runs; ++s) bad |= grp.at(s, i) > grp.at(s, i + 1);
-            if (i == 0) {
-                long long at = 0;
-                for (int s = 0; s < n_runs; ++s) { bad |= grp.at(s, 0) != at; at = grp.at(s, n_reads); }
-                bad |= at != n_rec;
-            }
-            if (bad) {
-                atomicOr(err_flags, kErrGroup);
-                atomicMin((unsigned long long *)err_index, (unsigned long long)i);
-            }
-        }
         int l = len[i];
         if (l < 0) {
             atomicOr(err_flags, kErrLen);
@@ -189,6 +172,14 @@ __global__ void publish_sizes_kernel(const long long *scan_totals, Ctrl *ctrl, l
     if (t < kInsp) host[8 + t] = in[t];
     if (t < kGuess) host[32 + t] = gu[t];
     __threadfence_system();
+}
+
+__global__ void clear_ctrl_kernel(Ctrl *ctrl)
+{
+    constexpr int kWords = (int)(sizeof(Ctrl) / 8);
+    if ((int)threadIdx.x < kWords) reinterpret_cast<long long *>(ctrl)[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) { ctrl->err_index = -1; ctrl->insp.err_index = -1; }
 }
 
 __global__ void publish_ctrl_kernel(const Ctrl *ctrl, long long *host)
@@ -518,9 +509,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     HIP_TRY(c, hipEventRecord(c->ev_pass0, st));
     HIP_TRY(c, c->ctrl.ensure(sizeof(Ctrl)));
     Ctrl *ctrl = c->ctrl.as<Ctrl>();
-    HIP_TRY(c, hipMemsetAsync(ctrl, 0, sizeof(Ctrl), st));
-    HIP_TRY(c, hipMemsetAsync(&ctrl->err_index, 0xFF, sizeof(long long), st));
-    HIP_TRY(c, hipMemsetAsync(&ctrl->insp.err_index, 0xFF, sizeof(long long), st));
+    hipLaunchKernelGGL(clear_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl);      // (three fill commands before: ~5 us each on the device)
 
     // ---- two things have to be known before the host can size and launch the rest, and they run side by side:
     //  (main stream) what the record stream looks like -- sorted runs sampled by guess_runs_kernel and, unless the pass
@@ -551,7 +540,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
             HIP_TRY(c, hipStreamWaitEvent(gst, c->ev_ifork, 0));
         }
         ReadPrepLoader ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, recut ? pv.cap : INT32_MAX, pv.cap,
-                          &ctrl->err_flags, &ctrl->err_index, grp, in.n_runs, n_reads, (long long)n_rec};
+                          &ctrl->err_flags, &ctrl->err_index};
         ScanOut<3> so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), c->cutcap_off.as<long long>()}};
         exclusive_scan<ReadPrepLoader, 3>(gst, ld, N, c->scan_tmp.as<long long>(), so, &scan_totals);
         if (!grouped) HIP_TRY(c, hipEventRecord(c->ev_gjoin, gst));
@@ -642,7 +631,8 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     HIP_TRY(c, hipMemsetAsync(c->rep_cnt.p, 0, (size_t)std::max(N, 1LL) * 4, st));
 
     hipLaunchKernelGGL(tile_first_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, st, n_reads,
-                       c->cov_off.as<long long>(), Q, n_tiles, c->tile_first.as<int32_t>(), &ctrl->err_flags);
+                       c->cov_off.as<long long>(), Q, n_tiles, c->tile_first.as<int32_t>(), &ctrl->err_flags, &ctrl->err_index, grp,
+                       in.n_runs, (long long)n_rec);
     if (expand)
         hipLaunchKernelGGL(expand_ids_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(((N + 63) / 64 * in.n_runs + 3) / 4, 256 * 16))),
                            dim3(256), 0, st, n_reads, in.n_runs, grp, c->exp_qid.as<int32_t>(), &ctrl->err_flags);
@@ -1759,6 +1749,27 @@ int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
     return raft_hip_run_multi(&c, 1, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, n_chunks, o, summary);
+}
+
+// Page-locking of caller memory.  The host pipelines move gigabytes each way; from pageable memory the runtime stages them
+// through its own bounce buffers.  Measured on the MI355X box (tools/pin_rate.py): hipHostRegister pins pages that have been
+// touched at ~120 GB/s (16 ms for 2 GB) and untouched ones at ~20 GB/s (their first touch), after which copies run at the
+// link's 53 GB/s.
+int raft_hip_host_register(void *ptr, uint64_t bytes)
+{
+    if (!ptr || bytes == 0) return RAFT_HIP_ERR_PARAM;
+    const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable);
+    if (e == hipSuccess) return RAFT_HIP_OK;
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? RAFT_HIP_ERR_NOMEM : RAFT_HIP_ERR_DEVICE;
+}
+
+int raft_hip_host_unregister(void *ptr)
+{
+    if (!ptr) return RAFT_HIP_ERR_PARAM;
+    if (hipHostUnregister(ptr) == hipSuccess) return RAFT_HIP_OK;
+    (void)hipGetLastError();
+    return RAFT_HIP_ERR_DEVICE;
 }
 
 int raft_hip_last_timing(raft_hip_ctx *c, double *pileup_seconds, double *pass_seconds)

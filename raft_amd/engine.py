@@ -25,7 +25,7 @@ EXPORTS = (
     "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
     "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed", "raft_hip_fetch_packed_w", "raft_hip_run_pipelined", "raft_hip_run_multi",
     "raft_hip_set_output_width", "raft_hip_packed_device", "raft_hip_run_device_grouped", "raft_hip_run_host_grouped",
-    "raft_hip_run_multi_grouped",
+    "raft_hip_run_multi_grouped", "raft_hip_host_register", "raft_hip_host_unregister",
 )
 
 
@@ -130,6 +130,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_run_device_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, vp, i64]
     lib.raft_hip_run_host_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, i64]
     lib.raft_hip_run_multi_grouped.argtypes = [C.POINTER(vp), i32, i32, vp, i64, i32, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
+    lib.raft_hip_host_register.argtypes = [vp, C.c_uint64]
+    lib.raft_hip_host_unregister.argtypes = [vp]
     lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.raft_hip_set_tuning.argtypes = [vp, i32, i32, i32]
     lib.raft_hip_set_output_width.argtypes = [vp, i32]

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <memory>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -54,7 +55,7 @@ bool missing_or_empty(const char *fn) // chop.hpp:326-329,336-349
     return !f || f.peek() == std::ifstream::traits_type::eof();
 }
 
-std::thread *g_background[3] = {nullptr, nullptr, nullptr};   // helpers that must be finished before the process exits
+std::thread *g_background[4] = {nullptr, nullptr, nullptr, nullptr};   // helpers that must be finished before the process exits
 
 [[noreturn]] void die(const std::string &msg)
 {
@@ -139,13 +140,23 @@ int main(int argc, char *argv[])
     if (devices.empty()) { const char *e = getenv("RAFT_DEVICE"); devices.push_back(e ? atoi(e) : 0); }
     std::vector<raft_hip_ctx *> ctxs(devices.size(), nullptr);
     std::vector<int> create_rc(devices.size(), RAFT_HIP_OK);
+    std::promise<void> devices_up_p;
+    std::shared_future<void> devices_up = devices_up_p.get_future().share();
     std::thread bring_up([&] {
         std::vector<std::thread> th;
         for (size_t d = 1; d < devices.size(); ++d) th.emplace_back([&, d] { create_rc[d] = raft_hip_create(devices[d], &hp, &ctxs[d]); });
         create_rc[0] = raft_hip_create(devices[0], &hp, &ctxs[0]);
         for (auto &t : th) t.join();
+        devices_up_p.set_value();
     });
     g_background[0] = &bring_up;
+    // Arrays that cross PCIe are page-locked once the runtime is up (raft_hip_host_register: the link's 53 GB/s instead of
+    // the runtime's staging of pageable memory); not worth the calls for small inputs.  A failed registration is not an
+    // error: the copy then takes the pageable path.
+    const bool no_pin = getenv("RAFT_NO_PIN") != nullptr;
+    auto pin = [&](const void *ptr, size_t bytes) {
+        if (!no_pin && ptr && bytes >= (size_t)(8u << 20)) (void)raft_hip_host_register(const_cast<void *>(ptr), bytes);
+    };
 
     // The overlaps file's bytes need nothing of the reads: they are read -- inflated, for a .gz -- beside the loading of
     // the reads (on gz inputs, the reference's own quick-start shape, the two inflations are most of the run).
@@ -162,6 +173,33 @@ int main(int argc, char *argv[])
     const int32_t n_reads = raft_host_reads_count(reads);
     std::cout.flush();
     if (n_reads > 0) fprintf(stdout, "Real Reads %d \n", raft_host_reads_real(reads)); // chop.hpp:105
+
+    // Host arrays for everything that comes back, sized by the bounds of raft_hip.h (from the read lengths alone).
+    // Coverage returns in its transfer encoding (a byte per window + the windows at or above 255): a quarter of the
+    // int32 array's bytes over PCIe, and the formatter below reads it as it is.  They are allocated and page-locked beside
+    // the tokenising of the overlaps (pinning untouched pages costs their first touch: 0.1 s for the 2 GB of a human set).
+    const int32_t *rl = raft_host_reads_lengths(reads);
+    int64_t n_win = 0, rep_cap = 0, frag_cap = 0;
+    std::vector<int64_t> cov_off((size_t)n_reads + 1), rep_off((size_t)n_reads + 1), frag_off((size_t)n_reads + 1);
+    std::unique_ptr<uint8_t[]> cov8;
+    std::unique_ptr<int32_t[]> rep_s, rep_e, fb, fe;
+    std::thread out_prep([&] {
+        const int64_t minw = std::max<int64_t>(((int64_t)p.repeat_length + p.reso - 1) / p.reso, 1);
+        int64_t sum_len = 0;
+        for (int32_t i = 0; i < n_reads; ++i) { n_win += ((int64_t)rl[i] + p.reso - 1) / p.reso; sum_len += rl[i]; }
+        rep_cap = (n_win + n_reads) / (minw + 1);
+        frag_cap = sum_len / p.interval_length + 2 * (int64_t)n_reads;
+        cov8.reset(new uint8_t[((size_t)n_win + 1) * 2]);                         // (not value-initialised: no zero fill)
+        rep_s.reset(new int32_t[(size_t)rep_cap + 1]); rep_e.reset(new int32_t[(size_t)rep_cap + 1]);
+        fb.reset(new int32_t[(size_t)frag_cap + 1]); fe.reset(new int32_t[(size_t)frag_cap + 1]);
+        devices_up.wait();
+        if (create_rc[0] != RAFT_HIP_OK) return;
+        pin(cov8.get(), ((size_t)n_win + 1) * (p.est_cov >= 40 ? 2 : 1));
+        pin(fb.get(), ((size_t)frag_cap + 1) * 4); pin(fe.get(), ((size_t)frag_cap + 1) * 4);
+        pin(cov_off.data(), cov_off.size() * 8); pin(frag_off.data(), frag_off.size() * 8); pin(rep_off.data(), rep_off.size() * 8);
+        pin(rl, (size_t)n_reads * 4);
+    });
+    g_background[3] = &out_prep;
 
     raft_host_paf *paf = nullptr;
     char bad[256] = {0};
@@ -189,25 +227,23 @@ int main(int argc, char *argv[])
     if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_set_params(), ") + raft_hip_strerror(rc));
     const bool sym = hp.symmetric_mode == 1;
 
-    // Host arrays for everything that comes back, sized by the bounds of raft_hip.h (from the read lengths alone).
-    // Coverage returns in its transfer encoding (a byte per window + the windows at or above 255): a quarter of the
-    // int32 array's bytes over PCIe, and the formatter below reads it as it is.
-    const int32_t *rl = raft_host_reads_lengths(reads);
-    int64_t n_win = 0, rep_cap = 0, frag_cap = 0;
-    {
-        const int64_t minw = std::max<int64_t>(((int64_t)p.repeat_length + p.reso - 1) / p.reso, 1);
-        int64_t sum_len = 0;
-        for (int32_t i = 0; i < n_reads; ++i) { n_win += ((int64_t)rl[i] + p.reso - 1) / p.reso; sum_len += rl[i]; }
-        rep_cap = (n_win + n_reads) / (minw + 1);
-        frag_cap = sum_len / p.interval_length + 2 * (int64_t)n_reads;
+    // hifiasm writes its PAF grouped by query (reference README.md:36-38): a symmetric stream of at most four runs sorted by
+    // read id is handed over in its grouped form -- per run, where every read's records begin -- and the query column stays
+    // on the host (a third of the upload); any other stream goes up as it is.
+    std::unique_ptr<int64_t[]> rec_off;
+    int32_t n_runs = 0;
+    if (sym && n_rec > 0 && !getenv("RAFT_NO_GROUPED")) {
+        rec_off.reset(new int64_t[(size_t)4 * ((size_t)n_reads + 1)]);
+        if (raft_host_group_offsets(n_reads, n_rec, raft_host_paf_column(paf, 0), 4, &n_runs, rec_off.get()) != RAFT_HOST_OK) n_runs = 0;
     }
-    std::vector<int64_t> cov_off((size_t)n_reads + 1), rep_off((size_t)n_reads + 1), frag_off((size_t)n_reads + 1);
+    stage("group_offsets");
+    if (n_runs > 0) pin(rec_off.get(), (size_t)n_runs * ((size_t)n_reads + 1) * 8);
+    for (int k = n_runs > 0 ? 1 : 0; k < (sym ? 3 : 6); ++k) pin(raft_host_paf_column(paf, k), (size_t)n_rec * 4);
+    out_prep.join();
+    stage("page-lock");
     // one byte per window unless the expected coverage lets repeats pile up beyond it (from 40x on: two), and two in any
     // case when the first attempt meets more windows at or above 255 than the exception list holds
     int cov_width = p.est_cov >= 40 ? 2 : 1;
-    std::unique_ptr<uint8_t[]> cov8(new uint8_t[((size_t)n_win + 1) * 2]);      // (not value-initialised: no zero fill)
-    std::unique_ptr<int32_t[]> rep_s(new int32_t[(size_t)rep_cap + 1]), rep_e(new int32_t[(size_t)rep_cap + 1]);
-    std::unique_ptr<int32_t[]> fb(new int32_t[(size_t)frag_cap + 1]), fe(new int32_t[(size_t)frag_cap + 1]);
     std::vector<int64_t> exc_i;
     std::vector<int32_t> exc_v;
     raft_hip_summary s{};
@@ -221,10 +257,14 @@ int main(int argc, char *argv[])
         ho.rep_offset = rep_off.data(); ho.rep_s = rep_s.get(); ho.rep_e = rep_e.get(); ho.rep_cap = rep_cap;
         ho.frag_offset = frag_off.data(); ho.frag_begin = fb.get(); ho.frag_end = fe.get(); ho.frag_cap = frag_cap;
         // upload, pass and download of consecutive read ranges overlap, on every device named (one piece for small inputs)
-        rc = raft_hip_run_multi(ctxs.data(), (int32_t)ctxs.size(), n_reads, rl, n_rec, raft_host_paf_column(paf, 0),
-                                raft_host_paf_column(paf, 1), raft_host_paf_column(paf, 2), sym ? nullptr : raft_host_paf_column(paf, 3),
-                                sym ? nullptr : raft_host_paf_column(paf, 4), sym ? nullptr : raft_host_paf_column(paf, 5),
-                                chunks_env ? atoi(chunks_env) : 0, &ho, &s);
+        if (n_runs > 0)
+            rc = raft_hip_run_multi_grouped(ctxs.data(), (int32_t)ctxs.size(), n_reads, rl, n_rec, n_runs, rec_off.get(),
+                                            raft_host_paf_column(paf, 1), raft_host_paf_column(paf, 2), chunks_env ? atoi(chunks_env) : 0, &ho, &s);
+        else
+            rc = raft_hip_run_multi(ctxs.data(), (int32_t)ctxs.size(), n_reads, rl, n_rec, raft_host_paf_column(paf, 0),
+                                    raft_host_paf_column(paf, 1), raft_host_paf_column(paf, 2), sym ? nullptr : raft_host_paf_column(paf, 3),
+                                    sym ? nullptr : raft_host_paf_column(paf, 4), sym ? nullptr : raft_host_paf_column(paf, 5),
+                                    chunks_env ? atoi(chunks_env) : 0, &ho, &s);
         n_exc = ho.n_exc;
         if (rc != RAFT_HIP_ERR_TOO_LARGE || attempt == 2 || n_exc <= exc_cap) break;
         // more windows at or above the limit than the list holds (n_exc says how many): two bytes per window when a byte

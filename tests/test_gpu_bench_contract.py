@@ -39,6 +39,14 @@ def test_bench_line_has_every_contract_field():
         assert k in e, k
     assert e["decoded_coverage_equals_device"] is True and e["chunked_equals_one_piece"] is True and e["records_per_s"] > 0 and e["d2h_bytes"] < e["h2d_bytes"] * 3
     assert all(d["self_check"].values()) and len(d["self_check"]) == 3
+    # round 3: grouped input is the headline; the product path (no query column, a byte per window) sits in `roofline`; the
+    # six-column detecting form and the six-column host pipeline are timed beside it
+    assert "grouped" in d["config"]["input"] and "cut_points" in d["config"]
+    for k in ("product_path_kernel_ms", "product_path_frac", "product_path_pass_frac"):
+        assert rf[k] > 0, k
+    assert d["packed_output"]["equals_int32_pass"] is True and "no query column" in d["packed_output"]["input"]
+    assert d["six_column"]["pass_device_ms"] > 0 and d["six_column"]["pass_device_ms_inspect_first"] > 0
+    assert e["six_column_input"]["equals_grouped"] is True and e["six_column_input"]["h2d_bytes"] > e["h2d_bytes"]
     assert cb["cpu_model"] and cb["node_logical_cpus"] >= 1 and "same seed" in cb["sample"]
 
 
@@ -56,6 +64,24 @@ def test_bench_gpus_flag_spawns_the_ranks_itself(extra):
     assert d["n_gpus"] == 2 and d["config"]["records_total"] > d["config"]["records_per_gpu"] > 0
     assert ("pre-split" in d["config"]["sharding"]) == bool(extra)
     assert "cpu_baseline" not in d and "e2e" not in d
+    if extra:                                             # BASELINE configs[3] as written: ONE set, sharded, exchange in the step
+        assert d["scaling"] == "strong" and d["self_check"]["ranks_totals_equal_single_gpu_pass"] is True
+        assert d["config"]["records_total"] > 2 * 0.9 * d["config"]["records_per_gpu"] * 0.5
+    else:                                                 # weak headline + the strong-scaling leg beside it
+        assert d["scaling"] == "weak"
+        st = d["strong"]
+        assert st["scaling"] == "strong" and st["ranks_totals_equal_single_gpu_pass"] is True and st["value"] > 0
+        assert st["records_total"] == d["config"]["records_per_gpu"] and st["rank0_records"] < st["records_total"]
+
+
+def test_bench_strong_flag():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "30000", "--steps", "2",
+                        "--warmup", "1", "--strong"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["self_check"]["ranks_totals_equal_single_gpu_pass"] is True
+    assert "host-routed" in d["config"]["sharding"] and d["config"]["records_per_gpu"] < d["config"]["records_total"]
 
 
 def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
