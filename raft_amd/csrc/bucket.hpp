@@ -123,13 +123,21 @@ __global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const 
 // tile_first[k] = first read whose first window lies in tile k or later (tiles of Q windows).  For grouped input the same
 // threads -- one per read, coalesced -- check the caller's offsets: they must not step back and the runs must chain from
 // record 0 to record n_rec (kErrGroup; every later kernel of the pass then returns at once).
+// It also clears the reads' repeat counters (a fill command of its own before) and, in a pass that was sized by the caller's
+// window count, compares that count with the scan's (kErrHint; a fill command and a one-wave kernel of their own cost
+// ~15 us of a 0.5 ms pass on an eighth of the human-scale set).
 __global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const long long *cov_off, int Q,
                                                          long long n_tiles, int32_t *tile_first, int32_t *err_flags,
-                                                         long long *err_index, GroupedOff grp, int32_t n_runs, long long n_rec)
+                                                         long long *err_index, GroupedOff grp, int32_t n_runs, long long n_rec,
+                                                         int32_t *rep_cnt, const long long *scan_totals, long long hint_bins)
 {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > n_reads) return;
-    if (*(volatile const int32_t *)err_flags & kErrStop) return;   // (n_tiles comes from a window count the device found wrong)
+    if (hint_bins >= 0 && scan_totals[0] != hint_bins) {           // (every thread sees the same: nothing below runs)
+        if (r == 0) atomicOr(err_flags, kErrHint);
+        return;
+    }
+    if (r < n_reads) rep_cnt[r] = 0;
     if (grp.off) {
         bool bad = false;
         if (r < n_reads)

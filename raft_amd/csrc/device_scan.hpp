@@ -149,4 +149,17 @@ inline void exclusive_scan(hipStream_t st, Loader ld, long long n, long long *pa
     if (totals_dev) *totals_dev = totals;
 }
 
+// The same with a loader of its own for each pass: `first` may do work per element (and store what it found); `second`
+// re-reads the values that work left behind.
+template <class LoaderA, class LoaderB, int K>
+inline void exclusive_scan2(hipStream_t st, LoaderA first, LoaderB second, long long n, long long *partials, ScanOut<K> out)
+{
+    int nb = scan_blocks(n);
+    if (nb < 1) nb = 1;
+    long long *totals = partials + (long long)nb * K;
+    hipLaunchKernelGGL((scan_partials_kernel<LoaderA, K>), dim3(nb), dim3(kScanThreads), 0, st, first, n, partials);
+    hipLaunchKernelGGL((scan_partials_scan_kernel<K>), dim3(1), dim3(1024), 0, st, partials, nb, totals);
+    hipLaunchKernelGGL((scan_apply_kernel<LoaderB, K>), dim3(nb), dim3(kScanThreads), 0, st, second, n, partials, totals, out);
+}
+
 } // namespace raft

@@ -51,7 +51,7 @@ void launch_general(hipStream_t st, unsigned grid, const PileupArgs &pa)
     hipLaunchKernelGGL((pileup_kernel<256, CAP, MINW, 3, false>), dim3(grid), dim3(256), 0, st, pa);
 }
 
-template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, bool EXTRA = false, int OW = 4>
+template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, int EXTRA = 0, int OW = 4>
 void launch_fast(hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
     constexpr int S4 = SLOTS % 4 == 0 ? SLOTS : 4;   // four sorted runs need a multiple of four slots
@@ -65,15 +65,15 @@ void launch_fast(hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, 
 }
 
 // the fast kernel's configurations by output width (pileup_fast.hpp OW; the diagnostic build writes int32 only)
-template <bool EXTRA>
+template <int EXTRA>
 void launch_fast_variant(int variant, int ow, hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
     if (variant == 2) {
         if (ow == 1) launch_fast<6144, 5, false, 4, EXTRA, 1>(st, grid, n_seg, cuts, pa);
         else if (ow == 2) launch_fast<6144, 5, false, 4, EXTRA, 2>(st, grid, n_seg, cuts, pa);
         else launch_fast<6144, 5, false, 4, EXTRA, 4>(st, grid, n_seg, cuts, pa);
-    } else if (variant == kDiagVariant && !EXTRA) {
-        launch_fast<7936, 4, true, 6, false, 4>(st, grid, n_seg, cuts, pa);
+    } else if (variant == kDiagVariant && EXTRA == 0) {
+        launch_fast<7936, 4, true, 6, 0, 4>(st, grid, n_seg, cuts, pa);
     } else {
         if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1>(st, grid, n_seg, cuts, pa);
         else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2>(st, grid, n_seg, cuts, pa);
@@ -105,6 +105,7 @@ struct Ctrl {                         // device control block, cleared every pas
     long long out_totals[4];          // rep / cut / frag totals land here via the scan
     GuessOut guess;                   // sorted runs as seen from samples
     unsigned long long n_exc;         // windows at or above the limit of the encoding a pass wrote directly (PileupArgs::n_exc)
+    unsigned totals_done, pad_done;   // workgroups of totals_kernel that are through (the last one publishes this block)
 };
 
 struct DevBuf {
@@ -158,12 +159,9 @@ template <int K> struct CountLoader {
 
 // What the host reads back goes straight into its page-locked block (device-visible host memory): a copy command per
 // few bytes cost ~25 us each on the device timeline (three of them ahead of the pass's host wait).
-__global__ void publish_sizes_kernel(const long long *scan_totals, Ctrl *ctrl, long long *host, long long hint_bins)
+__global__ void publish_sizes_kernel(const long long *scan_totals, const Ctrl *ctrl, long long *host)
 {
     const int t = threadIdx.x;
-    // a pass without a host wait was sized by the caller's window count: if that is not what the lengths give, every later
-    // kernel returns at once (kErrHint) and raft_hip_finish runs the pass again, waiting for the sizes this time
-    if (t == 0 && hint_bins >= 0 && scan_totals[0] != hint_bins) atomicOr(&ctrl->err_flags, kErrHint);
     if (t < 3) host[t] = scan_totals[t];
     const long long *c8 = reinterpret_cast<const long long *>(ctrl);
     if (t < 2) host[4 + t] = c8[t];                                           // err_flags, n_slow, err_index
@@ -180,14 +178,6 @@ __global__ void clear_ctrl_kernel(Ctrl *ctrl)
     if ((int)threadIdx.x < kWords) reinterpret_cast<long long *>(ctrl)[threadIdx.x] = 0;
     __syncthreads();
     if (threadIdx.x == 0) { ctrl->err_index = -1; ctrl->insp.err_index = -1; }
-}
-
-__global__ void publish_ctrl_kernel(const Ctrl *ctrl, long long *host)
-{
-    constexpr int kWords = (int)(sizeof(Ctrl) / 8);
-    static_assert(sizeof(Ctrl) % 8 == 0 && kWords <= 64, "one wave copies the control block");
-    if ((int)threadIdx.x < kWords) host[threadIdx.x] = reinterpret_cast<const long long *>(ctrl)[threadIdx.x];
-    __threadfence_system();
 }
 
 __global__ void selftest_kernel(const int *in, int *out_dpp, int *out_shfl, unsigned long long *ballots)
@@ -554,9 +544,10 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
                                c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
     }
     if (!grouped) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_gjoin, 0));
-    hipLaunchKernelGGL(publish_sizes_kernel, dim3(1), dim3(64), 0, st, scan_totals, ctrl, c->pinned_dev, no_wait ? in.hint_bins : -1LL);
     long long B, RU, CU;
     if (no_wait) {
+        // (the caller's count is compared with the scan's by tile_first_kernel, the next kernel: kErrHint stops the pass there,
+        // and raft_hip_finish runs it again with the host wait)
         // sizes from the caller's window count: B as announced (checked on the device, kErrHint); bounds for the rest --
         // reserved raw-repeat slots sum_r ((w_r + 1) / (minbins + 1) + two per piece of a long read), markers sum_r (len_r / L + 2)
         B = in.hint_bins;
@@ -564,6 +555,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         CU = B / std::max(1, c->prm.interval_length / c->prm.reso) + 2 * N + 2;
         if (c->prm.interval_length < c->prm.reso) CU = B * ((long long)c->prm.reso / c->prm.interval_length + 1) + 2 * N + 2;
     } else {
+        hipLaunchKernelGGL(publish_sizes_kernel, dim3(1), dim3(64), 0, st, scan_totals, ctrl, c->pinned_dev);
         HIP_TRY(c, hipStreamSynchronize(st));                               // the pass's only host wait: sizes + path choice
         B = h[0]; RU = h[1]; CU = h[2];
         const int32_t flags = reinterpret_cast<int32_t *>(h + 4)[0];
@@ -628,11 +620,10 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     HIP_TRY(c, c->rep_off.ensure((size_t)(N + 1) * 8));
     HIP_TRY(c, c->cut_off.ensure((size_t)(N + 1) * 8));
     HIP_TRY(c, c->frag_off.ensure((size_t)(N + 1) * 8));
-    HIP_TRY(c, hipMemsetAsync(c->rep_cnt.p, 0, (size_t)std::max(N, 1LL) * 4, st));
 
     hipLaunchKernelGGL(tile_first_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, st, n_reads,
                        c->cov_off.as<long long>(), Q, n_tiles, c->tile_first.as<int32_t>(), &ctrl->err_flags, &ctrl->err_index, grp,
-                       in.n_runs, (long long)n_rec);
+                       in.n_runs, (long long)n_rec, c->rep_cnt.as<int32_t>(), scan_totals, no_wait ? in.hint_bins : -1LL);
     if (expand)
         hipLaunchKernelGGL(expand_ids_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(((N + 63) / 64 * in.n_runs + 3) / 4, 256 * 16))),
                            dim3(256), 0, st, n_reads, in.n_runs, grp, c->exp_qid.as<int32_t>(), &ctrl->err_flags);
@@ -776,17 +767,23 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         ps.block_sums = pa.block_sums + 2 * (long long)pgrid;
         ps.dbg = nullptr;
         const unsigned sgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * 5));
-        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
-        launch_fast_variant<false>(c->variant, ow, st, pgrid, pa.n_seg, cuts, pa);
-        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-        if (recut) {
-            // the tiles that did not fit as they are, re-cut by tile_desc_kernel: the same kernel, its other instantiation
-            ps.slow_list = nullptr; ps.tile_counter = &ctrl->slow_next; ps.n_extra = &ctrl->n_extra; ps.tile_batch = 1;
-            launch_fast_variant<true>(c->variant, ow, c->side_stream, pgrid, pa.n_seg, cuts, ps);
-        } else launch_general<6144, 5>(c->side_stream, sgrid, ps);
-        HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
-        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
-        n_sum_blocks = pgrid + (recut ? pgrid : sgrid);
+        // (Measured and dropped, round 3: regular tiles, then the re-cut ones, from ONE persistent grid -- pileup_fast.hpp
+        // EXTRA = 2, no second stream and no event hand-over at either end.  Slower on every workload: hg002 pass 2.92
+        // against 2.87 ms, ultralong 3.03 against 2.97, 50 k reads 0.200 against 0.192 -- the extra tiles are better off
+        // running BESIDE the regular ones from the start than behind them.)
+        {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, st));
+            launch_fast_variant<0>(c->variant, ow, st, pgrid, pa.n_seg, cuts, pa);
+            HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+            if (recut) {
+                // the tiles that did not fit as they are, re-cut by tile_desc_kernel: the same kernel, its other instantiation
+                ps.slow_list = nullptr; ps.tile_counter = &ctrl->slow_next; ps.n_extra = &ctrl->n_extra; ps.tile_batch = 1;
+                launch_fast_variant<1>(c->variant, ow, c->side_stream, pgrid, pa.n_seg, cuts, ps);
+            } else launch_general<6144, 5>(c->side_stream, sgrid, ps);
+            HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+            n_sum_blocks = pgrid + (recut ? pgrid : sgrid);
+        }
     } else {
         launch_general<6144, 5>(st, pgrid, pa);
     }
@@ -810,6 +807,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         // reads per thread, and the fill's stores from that shape took 320 us against 65 us; and a single-launch version
         // with decoupled look-back, finalize.hpp.)
         const unsigned rgrid = (unsigned)((N + 255) / 256);
+        // (Measured and dropped, round 3: the per-read count as the loader of the scan's first pass -- finalize.hpp
+        // FinalizeCountLoader, one launch less: that pass walks eight reads per thread, and 32 us replaced 9 + 7 on an eighth
+        // of the human-scale set.)
         hipLaunchKernelGGL(finalize_count_kernel, dim3(rgrid), dim3(256), 0, st, fa);
         CountLoader<3> ld{{c->rep_cnt.as<int32_t>(), c->cut_cnt.as<int32_t>(), c->frag_cnt.as<int32_t>()}};
         ScanOut<3> so{{c->rep_off.as<long long>(), c->cut_off.as<long long>(), c->frag_off.as<long long>()}};
@@ -825,10 +825,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         hipLaunchKernelGGL(totals_kernel, dim3(std::max(g, 1u)), dim3(256), 0, st, (long long)n_sum_blocks, c->block_sums.as<long long>(),
                            n_reads, d_len, ctrl->totals, c->rep_off.as<long long>(), c->cut_off.as<long long>(),
                            c->frag_off.as<long long>(), c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr,
-                           ctrl->out_totals);
+                           ctrl->out_totals, &ctrl->totals_done, reinterpret_cast<const long long *>(ctrl), (int)(sizeof(Ctrl) / 8),
+                           c->pinned_dev + 128);   // everything finish() reports travels in one block (+1024 bytes), written by the last workgroup
     }
-    // everything finish() reports travels in one block, copied while the stream drains
-    hipLaunchKernelGGL(publish_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl, c->pinned_dev + 128);   // (+1024 bytes)
     c->fa = fa; c->cuts_ready = false;
     c->pass_width = ow; c->cov_valid = ow == 4;
     HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
@@ -1798,9 +1797,9 @@ int raft_hip_selftest(int device_id)
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return RAFT_HIP_ERR_DEVICE;
     if (hipSetDevice(device_id) != hipSuccess) return RAFT_HIP_ERR_DEVICE;
     if (getenv("RAFT_PRINT_OCCUPANCY")) {
-        print_occupancy("fast<7936,2,6,4>", pileup_fast_kernel<7936, 2, 6, 4, false, false>);
-        print_occupancy("fast<7936,1,6,4>", pileup_fast_kernel<7936, 1, 6, 4, false, false>);
-        print_occupancy("fast<6144,2,4,5>", pileup_fast_kernel<6144, 2, 4, 5, false, false>);
+        print_occupancy("fast<7936,2,6,4>", pileup_fast_kernel<7936, 2, 6, 4, false, 0>);
+        print_occupancy("fast<7936,1,6,4>", pileup_fast_kernel<7936, 1, 6, 4, false, 0>);
+        print_occupancy("fast<6144,2,4,5>", pileup_fast_kernel<6144, 2, 4, 5, false, 0>);
         print_occupancy("general<256,6144,5,3>", pileup_kernel<256, 6144, 5, 3, false>);
     }
     const int n = 256;

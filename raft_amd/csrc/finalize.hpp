@@ -295,6 +295,21 @@ __device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, int r,
     n_out = n; nF_out = nF; nf_out = nf;
 }
 
+// finalize_count_one as the loader of the output scan's first pass (device_scan.hpp exclusive_scan2): that pass walks the
+// reads one per thread, coalesced, exactly as finalize_count_kernel does, so the count rides in it for free (one launch
+// less; the second pass re-reads the three counts).
+struct FinalizeCountLoader {
+    FinalizeArgs a;
+    __device__ void operator()(long long i, long long (&v)[3]) const
+    {
+        v[0] = v[1] = v[2] = 0;
+        if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
+        int n, nF, nf;
+        finalize_count_one(a, (int)i, n, nF, nf);
+        v[0] = n; v[1] = nF; v[2] = nf;
+    }
+};
+
 __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -385,7 +400,9 @@ __global__ __launch_bounds__(256) void finalize_cuts_kernel(FinalizeArgs a)
 __global__ __launch_bounds__(256) void totals_kernel(long long n_tiles, const long long *tile_sums, int32_t n_reads,
                                                      const int32_t *read_len, unsigned long long *totals,
                                                      const long long *rep_off, const long long *cut_off,
-                                                     const long long *frag_off, const long long *bucket_off, long long *tails)
+                                                     const long long *frag_off, const long long *bucket_off, long long *tails,
+                                                     unsigned *done_blocks, const long long *ctrl_words, int n_ctrl_words,
+                                                     long long *host_block)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {    // output sizes, so that the host reads one block back
         tails[0] = rep_off[n_reads]; tails[1] = cut_off[n_reads]; tails[2] = frag_off[n_reads];
@@ -404,6 +421,20 @@ __global__ __launch_bounds__(256) void totals_kernel(long long n_tiles, const lo
     if (threadIdx.x < 3) {
         const long long v = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
         if (v) atomicAdd(&totals[threadIdx.x], (unsigned long long)v);
+    }
+    // The workgroup that finishes last copies the control block -- everything raft_hip_finish reports -- into the context's
+    // page-locked block (a one-wave kernel of its own before: one launch less at the end of every pass).
+    __shared__ int last;
+    __syncthreads();                                     // (this workgroup's three atomics are issued)
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(done_blocks, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (last && (int)threadIdx.x < 64) {
+        __threadfence();
+        if ((int)threadIdx.x < n_ctrl_words) host_block[threadIdx.x] = reinterpret_cast<const volatile long long *>(ctrl_words)[threadIdx.x];
+        __threadfence_system();
     }
 }
 

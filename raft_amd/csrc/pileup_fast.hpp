@@ -151,17 +151,12 @@ __device__ __forceinline__ void note_exception(const PileupArgs &a, long long wi
 // OW = bytes per window of the coverage written: 4 = cov[] as int32; 1 / 2 = its transfer encoding (PileupArgs::covp) --
 // the consumer of cov[] is a text formatter on the host, four fifths of the kernel's HBM traffic is this array, and real
 // coverage fits a byte.
-template <int CAP, int NSEG, int U, int MINW, bool DIAG, bool EXTRA, int OW = 4>
-__global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *__restrict__ cuts, PileupArgs a)
+template <int CAP, int NSEG, int U, bool DIAG, bool EXTRA, int OW>
+__device__ __forceinline__ void fast_tile_loop(FastSmem<CAP> &sm, const TileCut *__restrict__ cuts, const PileupArgs &a)
 {
     constexpr int THREADS = 256, NW = 4, ITER = U / NSEG;
     static_assert(U % NSEG == 0 && ITER >= 1, "slots are split evenly over the segments");
     using Smem = FastSmem<CAP>;
-    // Measured on MI355X (tools/occ_probe.hip, tools/stamp_probe.py): five 31,744-byte workgroups share a CU, five
-    // 31,856-byte ones do not -- a fifth of the persistent grid then starts only when the first workgroups retire and
-    // the kernel takes a third longer.  Stay at or below the footprint that is known to fit.
-    static_assert(sizeof(Smem) * MINW <= 31328 * 5, "LDS footprint does not allow MINW workgroups per CU");
-    __shared__ __attribute__((aligned(16))) Smem sm;
     const unsigned tid = threadIdx.x;
     const int lane = (int)(tid & 63u);
     const int wid = uni((int)(tid >> 6));
@@ -409,6 +404,10 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
 
             int4 dn = make_int4(0, 0, 0, 0);
             if (row_b < row_e) dn = *reinterpret_cast<const int4 *>(&sm.diff[row_b * 256 + lane * 4]);
+#ifdef RAFT_ABLATE_ROWS
+            for (int row = row_b; row < row_e; ++row) *reinterpret_cast<int4 *>(&sm.diff[row * 256 + lane * 4]) = make_int4(0, 0, 0, 0);
+            if (0)
+#endif
             for (int row = row_b; row < row_e; ++row) {
                 const int base = row * 256, p0 = base + lane * 4;
                 const int4 d = dn;
@@ -479,6 +478,9 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
                     M0 = __ballot(v0 && c0 >= a.high_cov); M1 = __ballot(v1 && c1 >= a.high_cov);
                     M2 = __ballot(v2 && c2 >= a.high_cov); M3 = __ballot(v3 && c3 >= a.high_cov);
                 }
+#ifdef RAFT_ABLATE_SCAN
+                continue;
+#endif
                 if ((M0 | M1 | M2 | M3) == 0ull && !hp) continue;   // the common case: no high window in the row
                 const unsigned long long RS0 = __ballot((ro0 >> 8) == row), RS1 = __ballot((ro1 >> 8) == row); // reads starting here
                 const bool tail = base + 256 > t_end;               // the row holds slots past the end of the tile
@@ -631,6 +633,30 @@ __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *_
     if (tid == 0) {
         a.block_sums[2 * (long long)blockIdx.x] = (long long)sm.acc_cov;
         a.block_sums[2 * (long long)blockIdx.x + 1] = (long long)sm.acc_rep;
+    }
+}
+
+// EXTRA: 0 = the regular tiles; 1 = the extra tiles (a launch of its own, beside the regular one on a second stream:
+// rounds 1-2, kept for A/B and for the diagnostic build); 2 = both from ONE persistent grid -- a workgroup that finds no
+// regular tile left goes on with the extra ones.  (Two launches on two streams cost the pass an event hand-over at either
+// end, ~25 us; on a long-read set, where a fifth of the windows sit in extra tiles, those used to start only when regular
+// workgroups retired.)
+template <int CAP, int NSEG, int U, int MINW, bool DIAG, int EXTRA, int OW = 4>
+__global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *__restrict__ cuts, PileupArgs a)
+{
+    using Smem = FastSmem<CAP>;
+    // Measured on MI355X (tools/occ_probe.hip, tools/stamp_probe.py): five 31,744-byte workgroups share a CU, five
+    // 31,856-byte ones do not -- a fifth of the persistent grid then starts only when the first workgroups retire and
+    // the kernel takes a third longer.  Stay at or below the footprint that is known to fit.
+    static_assert(sizeof(Smem) * MINW <= 31328 * 5, "LDS footprint does not allow MINW workgroups per CU");
+    __shared__ __attribute__((aligned(16))) Smem sm;
+    if (EXTRA != 1) fast_tile_loop<CAP, NSEG, U, DIAG, false, OW>(sm, cuts, a);
+    if (EXTRA == 1) fast_tile_loop<CAP, NSEG, U, DIAG, true, OW>(sm, cuts, a);
+    if (EXTRA == 2) {
+        PileupArgs b = a;                            // the extra tiles: their own hand-out counter, one at a time; sums behind the regular ones'
+        b.tile_counter = a.slow_counter; b.tile_batch = 1; b.block_sums = a.block_sums + 2 * (long long)gridDim.x;
+        lds_barrier();
+        fast_tile_loop<CAP, NSEG, U, DIAG, true, OW>(sm, cuts, b);
     }
 }
 
