@@ -85,6 +85,8 @@ typedef struct raft_hip_summary {
                                    RAFT_HIP_ERR_FRAGMENT; the PAF record index for RAFT_HIP_ERR_READ_ID and, on the
                                    sorted-segment path, RAFT_HIP_ERR_COORD; on the counting-sort path (interval_path
                                    == 1) RAFT_HIP_ERR_COORD reports the index into the BUCKETED interval array */
+    int32_t n_devices_used;     /* host-to-host entry points: contexts that took part in the job (1 for a one-piece pass) */
+    int32_t reserved;
 } raft_hip_summary;
 
 /* Device-resident outputs of the last run (valid until the next run/destroy).

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -1280,6 +1281,7 @@ static int run_monolithic_to_host(raft_hip_ctx *c, int32_t n_reads, const int32_
     raft_hip_summary s{};
     if (rc == RAFT_HIP_OK) rc = raft_hip_finish(c, &s);
     c->out_width = keep_width;
+    s.n_devices_used = 1;
     if (summary) *summary = s;
     if (rc != RAFT_HIP_OK) return rc;
     if (s.n_bins > o->cov8_cap || s.n_repeats > o->rep_cap || s.n_fragments > o->frag_cap) return RAFT_HIP_ERR_TOO_LARGE;
@@ -1339,6 +1341,238 @@ int prepare_lanes(raft_hip_ctx *c)
 
 } // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host-routed jobs for record streams that are NOT a handful of runs sorted by query id (a shuffled PAF, a non-symmetric
+// one, more than four concatenated files): SURVEY.md §8(e)'s host-routed mode in its general form.  create_pileup's
+// bucketing (chop.hpp:155-169: every record into its query's bucket and, while the PAF is not symmetric, into its
+// target's) is done by the host's threads as a counting sort by read id -- counts, offsets, scatter -- which leaves the
+// intervals grouped by read: consecutive read ranges are then contiguous slices, each a sorted run of its own, and go
+// to the contexts (devices) in turn as one-piece passes of the sorted-segment path; a chain of tickets hands each chunk
+// the sizes of the chunks before it.  This is also what lifts the 2^29-records-per-pass limit for such inputs.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+void host_parallel(int n_tasks, const std::function<void(int)> &fn)
+{
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_tasks; ++t) th.emplace_back([&fn, t] { fn(t); });
+    if (n_tasks > 0) fn(0);
+    for (auto &x : th) x.join();
+}
+
+} // namespace
+
+// *fallback = true: nothing was done and the caller should take the one-piece pass (which reports data errors exactly).
+static int run_routed(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                      const int32_t *qid, const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts, const int32_t *te,
+                      int32_t n_chunks, raft_hip_host_outputs *o, raft_hip_summary *summary, bool *fallback)
+{
+    raft_hip_ctx *c = ctxs[0];
+    *fallback = false;
+    const int mode = c->prm.symmetric_mode;
+    if (mode != 1 && (!tid || !ts || !te)) return RAFT_HIP_ERR_PARAM;
+    const bool one_pass_possible = n_rec < (1LL << 29);
+    const int cov_width = o->cov_width == 2 ? 2 : 1;
+    int T = (int)std::min<long long>(std::max(1u, std::thread::hardware_concurrency()), 32);
+    if (n_rec < (1 << 18)) T = 1;
+    // ---- ids in range?  the mirror of record 0 (chop.hpp:171-184) when the caller did not say
+    std::vector<long long> bad((size_t)T, -1);
+    std::vector<int> mirror((size_t)T, 0);
+    host_parallel(T, [&](int t) {
+        const long long lo = n_rec * t / T, hi = n_rec * (t + 1) / T;
+        const bool detect = mode < 0 && n_rec > 0;
+        const int32_t q0 = detect ? qid[0] : 0, t0 = detect ? tid[0] : 0, qs0 = detect ? qs[0] : 0, qe0 = detect ? qe[0] : 0, ts0 = detect ? ts[0] : 0,
+                      te0 = detect ? te[0] : 0;
+        for (long long i = lo; i < hi; ++i) {
+            const bool okq = (uint32_t)qid[i] < (uint32_t)n_reads, okt = mode == 1 || (uint32_t)tid[i] < (uint32_t)n_reads;
+            if (!(okq && okt)) { if (bad[(size_t)t] < 0) bad[(size_t)t] = i; continue; }
+            if (detect && i > 0 && qid[i] == t0 && tid[i] == q0 && ts[i] == qs0 && te[i] == qe0 && qs[i] == ts0 && qe[i] == te0) mirror[(size_t)t] = 1;
+        }
+    });
+    for (int t = 0; t < T; ++t)
+        if (bad[(size_t)t] >= 0) {
+            if (one_pass_possible) { *fallback = true; return RAFT_HIP_OK; }
+            raft_hip_summary s{};
+            s.n_reads = n_reads; s.n_records = n_rec; s.high_cov = c->high_cov; s.error_index = bad[(size_t)t];
+            if (summary) *summary = s;
+            return RAFT_HIP_ERR_READ_ID;
+        }
+    int sym = mode == 1 ? 1 : 0;
+    if (mode < 0) for (int t = 0; t < T; ++t) sym |= mirror[(size_t)t];
+    // ---- counting sort by read id on the host: counts, offsets, scatter (symmetric: query sides; else also target sides of
+    // records whose two reads differ -- bucket.hpp's multiset)
+    std::vector<long long> pre;
+    std::unique_ptr<int32_t[]> cur, b_rid, b_s, b_e;
+    long long total = 0;
+    try {
+        pre.assign((size_t)n_reads + 1, 0);
+        cur.reset(new int32_t[(size_t)n_reads + 1]());
+    } catch (const std::bad_alloc &) { return RAFT_HIP_ERR_NOMEM; }
+    host_parallel(T, [&](int t) {
+        const long long lo = n_rec * t / T, hi = n_rec * (t + 1) / T;
+        for (long long i = lo; i < hi; ++i) {
+            __atomic_fetch_add(&cur[(size_t)qid[i]], 1, __ATOMIC_RELAXED);
+            if (!sym && tid[i] != qid[i]) __atomic_fetch_add(&cur[(size_t)tid[i]], 1, __ATOMIC_RELAXED);
+        }
+    });
+    for (int32_t r = 0; r < n_reads; ++r) {
+        if (cur[(size_t)r] < 0) return RAFT_HIP_ERR_TOO_LARGE;          // (2^31 intervals on one read)
+        pre[(size_t)r + 1] = pre[(size_t)r] + cur[(size_t)r];
+        cur[(size_t)r] = 0;
+    }
+    total = pre[(size_t)n_reads];
+    try {
+        b_rid.reset(new int32_t[(size_t)std::max(total, 1LL)]); b_s.reset(new int32_t[(size_t)std::max(total, 1LL)]);
+        b_e.reset(new int32_t[(size_t)std::max(total, 1LL)]);
+    } catch (const std::bad_alloc &) { return RAFT_HIP_ERR_NOMEM; }
+    host_parallel(T, [&](int t) {
+        const long long lo = n_rec * t / T, hi = n_rec * (t + 1) / T;
+        auto put = [&](int32_t r, int32_t s0, int32_t e0) {
+            const long long d = pre[(size_t)r] + __atomic_fetch_add(&cur[(size_t)r], 1, __ATOMIC_RELAXED);
+            b_rid[(size_t)d] = r; b_s[(size_t)d] = s0; b_e[(size_t)d] = e0;
+        };
+        for (long long i = lo; i < hi; ++i) {
+            put(qid[i], qs[i], qe[i]);
+            if (!sym && tid[i] != qid[i]) put(tid[i], ts[i], te[i]);
+        }
+    });
+    cur.reset();
+    // ---- plan: consecutive read ranges of near-equal interval counts, each far below the per-pass limit
+    const long long per_pass = 1LL << 27;
+    long long want = std::max<long long>(std::max<long long>(n_chunks, n_ctx), (total + per_pass - 1) / per_pass);
+    want = std::max<long long>(1, std::min<long long>(want, std::max(n_reads, 1)));
+    std::vector<int32_t> bound{0};
+    for (long long k = 1; k < want; ++k) {
+        const long long target = total * k / want;
+        const int32_t r = (int32_t)(std::lower_bound(pre.begin(), pre.end(), target) - pre.begin());
+        if (r > bound.back() && r < n_reads) bound.push_back(r);
+    }
+    bound.push_back(n_reads);
+    const int n_ch = (int)bound.size() - 1;
+    for (int k = 0; k < n_ch; ++k)
+        if (pre[(size_t)bound[(size_t)k + 1]] - pre[(size_t)bound[(size_t)k]] >= (1LL << 29)) return RAFT_HIP_ERR_TOO_LARGE;   // (one read's pile alone)
+    const int n_job = std::min(n_ctx, std::max(n_ch, 1));
+    raft_hip_params prm1 = c->prm;
+    prm1.symmetric_mode = 1;                              // the routed intervals ARE the multiset to pile up: query-side records
+    std::vector<raft_hip_params> keep((size_t)n_job);
+    for (int d = 0; d < n_job; ++d) {
+        keep[(size_t)d] = ctxs[d]->prm;
+        const int rc0 = raft_hip_set_params(ctxs[d], &prm1);
+        if (rc0 != RAFT_HIP_OK) return rc0;
+        ctxs[d]->tile_q = c->tile_q; ctxs[d]->variant = c->variant;
+    }
+    // ---- chunk k runs on context k % n_job; a ticket chain publishes the sizes in chunk order
+    std::mutex mu;
+    std::condition_variable cv;
+    int published = 0, err = RAFT_HIP_OK;
+    long long err_index = -1;
+    bool data_error = false;
+    long long base_bins = 0, base_rep = 0, base_frag = 0, base_exc = 0;
+    raft_hip_summary tot{};
+    tot.n_reads = n_reads; tot.symmetric = sym; tot.high_cov = c->high_cov; tot.n_records = n_rec; tot.error_index = -1;
+    tot.interval_path = 0; tot.n_segments = 1; tot.n_devices_used = n_job;
+    std::string err_text;
+    auto job_main = [&](int d) {
+        raft_hip_ctx *jc = ctxs[d];
+        const int keep_width = jc->out_width;
+        jc->out_width = cov_width;
+        auto fail = [&](int code, long long index, bool data) {
+            std::lock_guard<std::mutex> g(mu);
+            if (err == RAFT_HIP_OK) { err = code; err_index = index; data_error = data; err_text = jc->last_error; }
+            cv.notify_all();
+        };
+        for (int k = d; k < n_ch; k += n_job) {
+            { std::lock_guard<std::mutex> g(mu); if (err != RAFT_HIP_OK) break; }
+            const int32_t r0 = bound[(size_t)k], r1 = bound[(size_t)k + 1], nr = r1 - r0;
+            const long long i0 = pre[(size_t)r0], n_iv = pre[(size_t)r1] - i0;
+            int rc = RAFT_HIP_OK;
+            raft_hip_summary s{};
+            hipError_t e = hipSetDevice(jc->device);
+            if (e == hipSuccess) e = jc->in_len.ensure((size_t)std::max(nr, 1) * 4);
+            for (int col = 0; col < 3 && e == hipSuccess; ++col) e = jc->in_col[col].ensure((size_t)std::max<long long>(n_iv, 1) * 4);
+            if (e == hipSuccess && nr) e = hipMemcpyAsync(jc->in_len.p, read_len + r0, (size_t)nr * 4, hipMemcpyHostToDevice, jc->stream);
+            const int32_t *src[3] = {b_rid.get() + i0, b_s.get() + i0, b_e.get() + i0};
+            for (int col = 0; col < 3 && e == hipSuccess && n_iv; ++col)
+                e = hipMemcpyAsync(jc->in_col[col].p, src[col], (size_t)n_iv * 4, hipMemcpyHostToDevice, jc->stream);
+            if (e != hipSuccess) { fail(fail_hip(jc, e, "run_routed: staging"), -1, false); break; }
+            if (n_iv > 0 && r0 != 0)
+                hipLaunchKernelGGL(rebase_ids_kernel, dim3((unsigned)std::min<long long>((n_iv + 255) / 256, 4096)), dim3(256), 0, jc->stream,
+                                   jc->in_col[0].as<int32_t>(), n_iv, r0);
+            rc = raft_hip_run_device(jc, nr, jc->in_len.as<int32_t>(), n_iv, jc->in_col[0].as<int32_t>(), jc->in_col[1].as<int32_t>(),
+                                     jc->in_col[2].as<int32_t>(), nullptr, nullptr, nullptr);
+            if (rc == RAFT_HIP_OK) rc = raft_hip_finish(jc, &s);
+            if (rc != RAFT_HIP_OK) {
+                // (a data error's index counts the routed intervals, not the caller's records: the one-piece pass reports it
+                // properly when the input is small enough for one)
+                fail(rc, -1, rc == RAFT_HIP_ERR_COORD || rc == RAFT_HIP_ERR_FRAGMENT || rc == RAFT_HIP_ERR_PARAM || rc == RAFT_HIP_ERR_READ_ID);
+                break;
+            }
+            long long b_bins, b_rep, b_frag, b_exc;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return published == k || err != RAFT_HIP_OK; });
+                if (err != RAFT_HIP_OK) break;
+                b_bins = base_bins; b_rep = base_rep; b_frag = base_frag; b_exc = base_exc;
+            }
+            // sizes of the encoding's exception list are known only after it has been made (raft_hip_fetch_packed_w's size query)
+            int64_t n_exc = 0;
+            rc = raft_hip_fetch_packed_w(jc, cov_width, nullptr, nullptr, 0, nullptr, nullptr, &n_exc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            const bool fits = rc == RAFT_HIP_OK && b_bins + s.n_bins <= o->cov8_cap && b_rep + s.n_repeats <= o->rep_cap &&
+                              b_frag + s.n_fragments <= o->frag_cap;
+            const bool exc_fits = b_exc + n_exc <= o->exc_cap;
+            if (rc == RAFT_HIP_OK && !fits) { jc->last_error = "host output capacity (coverage / repeats / fragments)"; rc = RAFT_HIP_ERR_TOO_LARGE; }
+            if (rc == RAFT_HIP_OK)
+                rc = raft_hip_fetch_packed_w(jc, cov_width, o->cov_offset + r0, o->cov8 ? o->cov8 + b_bins * cov_width : nullptr, exc_fits ? n_exc : 0,
+                                             (exc_fits && o->exc_index) ? o->exc_index + b_exc : nullptr, (exc_fits && o->exc_value) ? o->exc_value + b_exc : nullptr,
+                                             &n_exc, o->rep_offset + r0, o->rep_s ? o->rep_s + b_rep : nullptr, o->rep_e ? o->rep_e + b_rep : nullptr,
+                                             o->frag_offset + r0, nullptr, o->frag_begin ? o->frag_begin + b_frag : nullptr,
+                                             o->frag_end ? o->frag_end + b_frag : nullptr);
+            if (rc != RAFT_HIP_OK) { fail(rc, -1, false); break; }
+            // (the fetch wrote nr + 1 offsets counting from this chunk's first entry: the closing one is the next chunk's first)
+            for (int32_t r = 0; r < nr + (k == n_ch - 1 ? 1 : 0); ++r) {
+                o->cov_offset[r0 + r] += b_bins; o->rep_offset[r0 + r] += b_rep; o->frag_offset[r0 + r] += b_frag;
+            }
+            if (exc_fits && o->exc_index) for (int64_t i = 0; i < n_exc; ++i) o->exc_index[b_exc + i] += b_bins;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                base_bins += s.n_bins; base_rep += s.n_repeats; base_frag += s.n_fragments; base_exc += n_exc;
+                tot.n_bins += s.n_bins; tot.n_repeats += s.n_repeats; tot.n_fragments += s.n_fragments; tot.n_cuts += s.n_cuts;
+                tot.n_intervals += s.n_intervals; tot.total_coverage += s.total_coverage; tot.total_repeat_length += s.total_repeat_length;
+                tot.total_read_length += s.total_read_length;
+                published = k + 1;
+                cv.notify_all();
+            }
+        }
+        jc->out_width = keep_width;
+        jc->ran = false; jc->finished = false;           // the context holds no pass of the caller's
+    };
+    {
+        std::vector<std::thread> th;
+        for (int d = 1; d < n_job; ++d) th.emplace_back([&, d] { job_main(d); });
+        job_main(0);
+        for (auto &t : th) t.join();
+    }
+    for (int d = 0; d < n_job; ++d) (void)raft_hip_set_params(ctxs[d], &keep[(size_t)d]);
+    (void)hipSetDevice(c->device);
+    if (err != RAFT_HIP_OK) {
+        if (data_error && one_pass_possible) { *fallback = true; return RAFT_HIP_OK; }
+        c->last_error = err_text;
+        tot.error_index = err_index;
+        if (summary) *summary = tot;
+        return err;
+    }
+    // (a chunk that wrote its closing offsets before its successor wrote its first ones: the successor's are the same values)
+    tot.total_windows = tot.n_bins;
+    o->n_exc = base_exc;
+    if (summary) *summary = tot;
+    if (base_exc > o->exc_cap) {
+        c->last_error = "raft_hip_run_multi: more windows at or above the encoding's limit than exc_cap (out->n_exc holds the number)";
+        return RAFT_HIP_ERR_TOO_LARGE;
+    }
+    return RAFT_HIP_OK;
+}
+
 // (n_runs, rec_offset): the grouped form -- the caller's offsets instead of the query column (raft_hip_run_multi_grouped)
 static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
                           const int32_t *qid, const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts,
@@ -1377,7 +1611,18 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             if (seg[g] < 0 || seg[g] > seg[g + 1] || off_at(g, n_reads) != seg[g + 1]) n_seg = -1;   // (the one-piece pass reports it)
         if (seg[0] != 0) n_seg = -1;
     } else if (eligible) n_seg = guess_segments(qid, n_rec, seg);
-    if (n_seg < 1) return one_piece();
+    if (n_seg < 1) {
+        // not a handful of sorted runs (or not symmetric): several contexts, an explicit chunk count or more records than one
+        // pass takes send the job through the host-routed path; anything else is one piece on the first context
+        const bool route = !grouped && n_rec > 0 && n_reads > 0 && !c->force_bucket &&
+                           ((big_enough && (n_ctx > 1 || n_chunks > 1)) || n_rec >= (1LL << 29));
+        if (route) {
+            bool fallback = false;
+            const int rc = run_routed(ctxs, n_ctx, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, n_chunks, o, summary, &fallback);
+            if (!fallback) return rc;
+        }
+        return one_piece();
+    }
 
     int want = n_chunks > 0 ? std::min(n_chunks, n_reads)
                             : (int)std::min<long long>(std::min<long long>(32LL * n_ctx, std::max<long long>(2LL * n_ctx, n_rec / (24LL << 20))),
@@ -1677,6 +1922,7 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
 
     raft_hip_summary s{};
     s.n_reads = n_reads; s.symmetric = 1; s.high_cov = c->high_cov; s.n_segments = n_seg; s.n_records = n_rec; s.error_index = -1;
+    s.n_devices_used = n_job;
     for (const ChunkResult &cr : res) {
         s.n_bins += cr.n_bins; s.n_repeats += cr.n_rep; s.n_fragments += cr.n_frag; s.n_cuts += cr.n_cuts; s.n_intervals += cr.n_iv;
         s.total_coverage += cr.tot_cov; s.total_repeat_length += cr.tot_rep; s.total_read_length += cr.tot_len;

@@ -42,7 +42,7 @@ class _Summary(C.Structure):
                 ("n_repeats", C.c_int64), ("n_cuts", C.c_int64), ("n_fragments", C.c_int64),
                 ("total_coverage", C.c_int64), ("total_windows", C.c_int64),
                 ("total_repeat_length", C.c_int64), ("total_read_length", C.c_int64),
-                ("error_index", C.c_int64)]
+                ("error_index", C.c_int64), ("n_devices_used", C.c_int32), ("reserved", C.c_int32)]
 
 
 class _HostOutputs(C.Structure):
@@ -76,6 +76,8 @@ class Summary:
     total_repeat_length: int
     total_read_length: int
     error_index: int
+    n_devices_used: int = 0
+    reserved: int = 0
 
 
 class RaftError(RuntimeError):

@@ -280,6 +280,7 @@ int main(int argc, char *argv[])
         die(m);
     }
     stage("engine+fetch");
+    if (timing) fprintf(stderr, "TIMING devices_used %d input %s\n", s.n_devices_used, n_runs > 0 ? "grouped" : "columns");
     fprintf(stdout, "INFO, Symmetric overlaps %d \n", s.symmetric);            // chop.hpp:189-190
     fprintf(stdout, "INFO, length of alignments  %d()\n", (int)s.n_records);
     fprintf(stdout, "high_cov %d\n", s.high_cov);                              // repeat.hpp:91

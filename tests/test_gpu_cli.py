@@ -139,3 +139,23 @@ def test_reference_side_binding(tmp_path, name):
     else:
         for f, digest in meta["md5"].items():
             assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, (name, f)
+
+
+@pytest.mark.parametrize("name", ["s300_nonsym_shuffled", "s300_sym_shuffled", "s300_default"])
+def test_cli_spreads_every_input_shape_over_the_contexts(tmp_path, name):
+    """RAFT_DEVICES names two contexts: a hifiasm-shaped PAF is cut into chunks of its sorted runs (grouped input), any
+    other stream -- shuffled, non-symmetric -- is bucketed by the host's threads and routed (engine.hip run_routed).  Both
+    contexts take part (the stage clock on stderr says so) and the four files are the reference's."""
+    p, cols, exp, meta = load_case(name)
+    names = [f"r{i}" for i in range(len(cols[0]))]
+    write_fasta(tmp_path / "reads.fa", names, cols[0])
+    write_paf(tmp_path / "overlaps.paf", names, *cols)
+    r = subprocess.run([RAFT] + meta["args"] + ["reads.fa", "overlaps.paf"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300, env=dict(os.environ, RAFT_DEVICES="0,0", RAFT_CHUNKS="4", RAFT_TIMING="1"))
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
+    assert strip_timing(r.stdout.decode()) == meta["stdout"]
+    for f, digest in meta["md5"].items():
+        assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, (name, f)
+    line = [l for l in r.stderr.decode().splitlines() if l.startswith("TIMING devices_used")]
+    assert line and line[0].split()[2] == "2", r.stderr.decode()
+    assert line[0].split()[4] == ("grouped" if name == "s300_default" else "columns")
