@@ -150,7 +150,8 @@ int  raft_hip_run_host(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_l
 
 /* The same pass over GROUPED input.  hifiasm writes its PAF grouped by query (reference README.md:36-38; the records
  * reach create_pileup in that order, chop.hpp:147-169) and a tokeniser that resolves every name knows where each read's
- * records begin: the record stream is n_runs (1..4) runs, each sorted by query id, and
+ * records begin: the record stream is n_runs (1..RAFT_HIP_MAX_RUNS = 16) runs, each sorted by query id (more than four are merged into
+ * one on the device first, 24 bytes of traffic per record), and
  *     rec_offset[k * (n_reads + 1) + r]  =  index of the first record of read r in run k,
  * entry n_reads of a run closing it: rec_offset[0] = 0, run k + 1 begins where run k ends, the last run ends at n_rec,
  * offsets never step back (raft_host_paf_grouped() builds this from the tokenised columns).  What create_pileup's
@@ -268,6 +269,46 @@ int  raft_hip_run_multi(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_read
 int  raft_hip_run_multi_grouped(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
                                 int32_t n_runs, const int64_t *rec_offset, const int32_t *qs, const int32_t *qe,
                                 int32_t n_chunks, raft_hip_host_outputs *out, raft_hip_summary *summary);
+
+/* ---- pre-split PAF: the exchange step (BASELINE.json configs[3]; SURVEY.md §8e "pre-split" mode) ----------------------
+ * Every rank holds a contiguous slice of the record stream, in its grouped form (see raft_hip_run_device_grouped): per
+ * sorted run of the slice -- a slice of a hifiasm PAF has at most two -- where every read of the WHOLE set begins.  Reads
+ * are owned in contiguous ranges: rank g owns [bounds[g], bounds[g+1]), bounds[0] = 0, bounds[world] = n_reads_total.
+ * A run sorted by read id is sorted by owner too: what a rank has for another is one contiguous piece per run, sent from
+ * where it lies together with the matching slice of the run's offsets; the query ids never travel.  What arrives is
+ * grouped input again -- one run per (peer, run) with records for this rank, at most RAFT_HIP_MAX_RUNS -- held in
+ * buffers of the context until its next exchange:
+ *     raft_hip_run_device_grouped(ctx, got.n_reads, d_read_len_of_my_reads, got.n_rec, got.n_runs, got.d_rec_offset,
+ *                                 NULL, got.d_qs, got.d_qe, n_bins_of_my_reads);
+ * (more than four runs are merged on the device by that pass).  Cross-read state afterwards: the fragment counter
+ * (chop.hpp:195) and the stdout sums (repeat.hpp:93-97) -- one all-gather of five integers per rank, the caller's.
+ *   raft_hip_exchange        one process per GPU: RCCL over xGMI -- piece sizes by ncclAllGather, payload by grouped
+ *                            ncclSend / ncclRecv on the context's stream; returns in stream order (no host wait at the end).
+ *                            `comm`: an ncclComm_t of the caller's, or one made by raft_hip_comm_create from an id that rank 0
+ *                            obtained with raft_hip_comm_unique_id (128 bytes) and handed to the others by its own means.
+ *                            librccl.so.1 is loaded when first used (a single-GPU run never maps it).
+ *   raft_hip_exchange_local  one process, one context per rank (raft_hip_create on each device): peer copies. */
+#define RAFT_HIP_MAX_RUNS 16
+typedef struct raft_hip_slice {
+    int64_t n_rec;              /* records of this rank's slice */
+    int32_t n_runs;             /* sorted runs of the slice, 1..4 */
+    const int64_t *rec_offset;  /* HOST: [n_runs * (n_reads_total + 1)], first record (index into the slice) of every read in every run */
+    const int32_t *d_qs, *d_qe; /* DEVICE: the slice's query coordinates */
+} raft_hip_slice;
+typedef struct raft_hip_received {
+    int32_t n_reads;            /* reads this rank owns */
+    int32_t n_runs;             /* 1..RAFT_HIP_MAX_RUNS */
+    int64_t n_rec;
+    const int64_t *d_rec_offset;/* DEVICE: [n_runs * (n_reads + 1)] */
+    const int32_t *d_qs, *d_qe; /* DEVICE */
+} raft_hip_received;
+int  raft_hip_comm_unique_id(void *id128);
+int  raft_hip_comm_create(int device_id, const void *id128, int32_t rank, int32_t world, void **comm);
+void raft_hip_comm_destroy(void *comm);
+int  raft_hip_exchange(raft_hip_ctx *ctx, void *comm, int32_t rank, int32_t world, int32_t n_reads_total, const int64_t *bounds,
+                       const raft_hip_slice *mine, raft_hip_received *out);
+int  raft_hip_exchange_local(raft_hip_ctx *const *ctxs, int32_t world, int32_t n_reads_total, const int64_t *bounds,
+                             const raft_hip_slice *slices, raft_hip_received *outs);
 
 /* Page-locks / releases a range of the caller's host memory (hipHostRegister, every device of the node).  Arrays handed to
  * the host-to-host entry points move at the link's rate (53 GB/s each way on MI355X) only from page-locked memory; pages

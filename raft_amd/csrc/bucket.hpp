@@ -157,6 +157,83 @@ __global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const 
     for (long long k = t_p + 1; k <= t_r; ++k) tile_first[k] = (int32_t)r;
 }
 
+// ---- grouped input of more runs than the pileup kernels take (kMaxSeg): merged into ONE run first ----------------------
+// (a PAF concatenated from many files; the intervals a rank of a pre-split job receives from its peers, two runs each).
+// With the offsets at hand this needs no histogram and no atomics: read r's records of run j go behind its records of the
+// runs before, at sum_j' (off_j'[r] - off_j'[0]) + sum_{j' < j} count_j'(r).  24 bytes of traffic per record.
+constexpr int kMaxRuns = 16;
+
+__global__ __launch_bounds__(256) void check_offsets_kernel(int32_t n_reads, int32_t n_runs, const long long *off, long long stride,
+                                                            long long n_rec, int32_t *err_flags, long long *err_index)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_reads) return;
+    bool bad = false;
+    if (r < n_reads)
+        for (int s = 0; s < n_runs; ++s) bad |= off[s * stride + r] > off[s * stride + r + 1];
+    if (r == 0) {
+        long long at = 0;
+        for (int s = 0; s < n_runs; ++s) { bad |= off[s * stride] != at; at = off[s * stride + n_reads]; }
+        bad |= at != n_rec;
+    }
+    if (bad) {
+        atomicOr(err_flags, kErrGroup);
+        atomicMin((unsigned long long *)err_index, (unsigned long long)r);
+    }
+}
+
+__global__ __launch_bounds__(256) void merge_runs_kernel(int32_t n_reads, int32_t n_runs, const long long *off, long long stride,
+                                                         const int32_t *qs, const int32_t *qe, long long *m_off, int32_t *b_rid,
+                                                         int32_t *b_s, int32_t *b_e, const int32_t *err_flags)
+{
+    if (*(volatile const int32_t *)err_flags & kErrStop) return;   // (offsets that step back or leave [0, n_rec]: check_offsets_kernel)
+    const int lane = threadIdx.x & 63;
+    const long long n_groups = ((long long)n_reads + 1 + 63) >> 6;          // (entry n_reads closes the merged run)
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long w = wave0; w < n_groups; w += n_waves) {
+        const long long r0 = w << 6, r = r0 + lane;
+        long long lo[kMaxRuns];
+        int cnt[kMaxRuns];
+        long long mo = 0;
+        int tot = 0;
+#pragma unroll
+        for (int j = 0; j < kMaxRuns; ++j) {
+            lo[j] = 0; cnt[j] = 0;
+            if (j < n_runs && r <= n_reads) {
+                const long long a = off[j * stride + r];
+                mo += a - off[j * stride];
+                if (r < n_reads) { lo[j] = a; cnt[j] = (int)(off[j * stride + r + 1] - a); tot += cnt[j]; }
+            }
+        }
+        if (r <= n_reads) m_off[r] = mo;
+        const int n_in = (int)min(64LL, (long long)n_reads - r0);
+        for (int l = 0; l < n_in; ++l) {
+            const int T = __builtin_amdgcn_readlane(tot, l);
+            if (T == 0) continue;
+            const long long base = ((long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned long long)mo, l)) |
+                                   ((long long)__builtin_amdgcn_readlane((int)((unsigned long long)mo >> 32), l) << 32);
+            for (int i0 = 0; i0 < T; i0 += 64) {
+                const int i = i0 + lane;
+                int k = i < T ? i : -1;                       // index inside the read; negative once placed (or idle)
+                long long src = -1;
+#pragma unroll
+                for (int j = 0; j < kMaxRuns; ++j) {
+                    const int c = __builtin_amdgcn_readlane(cnt[j], l);
+                    const long long s = ((long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned long long)lo[j], l)) |
+                                        ((long long)__builtin_amdgcn_readlane((int)((unsigned long long)lo[j] >> 32), l) << 32);
+                    if (k >= 0 && k < c) { src = s + k; k = -1; }
+                    else if (k >= 0) k -= c;
+                }
+                if (src >= 0) {
+                    b_rid[base + i] = (int32_t)(r0 + l);
+                    b_s[base + i] = qs[src];
+                    b_e[base + i] = qe[src];
+                }
+            }
+        }
+    }
+}
+
 // Grouped input without a query column: the ids are what the offsets say.  One wave per 64 consecutive reads and run: the
 // lanes hold their reads' ranges, and the wave writes each read's id over its range (a read has ~45 records in a run:
 // one store instruction per read, two for a read inside a repeat).

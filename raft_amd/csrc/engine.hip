@@ -10,6 +10,9 @@
 #include "pileup.hpp"
 #include "pileup_fast.hpp"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -243,6 +246,8 @@ struct raft_hip_ctx {
     bool grouped = false;              // the last pass was built on the caller's offsets (verified in its kernels)
     bool no_wait = false;              // ... and sized by the caller's window count: nothing was read back on the way
     DevBuf exp_qid, in_off;            // grouped input without a query column: the ids rebuilt from the offsets; staged offsets
+    DevBuf m_off;                      // grouped input of more than kMaxSeg runs: offsets of the merged run
+    DevBuf x_qs, x_qe, x_off, x_raw, x_send_off, x_cnt;   // pre-split exchange (raft_hip_exchange*): what this rank received / staged
 
     // state of the last pass
     bool ran = false, finished = false;
@@ -375,7 +380,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -458,14 +463,22 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     const bool grouped = in.rec_off != nullptr;
     if (n_reads < 0 || n_rec < 0) return RAFT_HIP_ERR_PARAM;
     if (n_reads > 0 && !d_len) return RAFT_HIP_ERR_PARAM;
-    if (grouped && (in.n_runs < 1 || in.n_runs > kMaxSeg || c->prm.symmetric_mode != 1)) return RAFT_HIP_ERR_PARAM;
+    if (grouped && (in.n_runs < 1 || in.n_runs > kMaxRuns || c->prm.symmetric_mode != 1)) return RAFT_HIP_ERR_PARAM;
+    // more runs than the pileup kernels take: merged into one on the device first (bucket.hpp merge_runs_kernel)
+    const bool merge = grouped && in.n_runs > kMaxSeg && n_rec > 0;
+    const int32_t eff_runs = grouped ? (in.n_runs > kMaxSeg ? 1 : in.n_runs) : 0;
     if (n_rec > 0 && ((!d_qid && !grouped) || !d_qs || !d_qe)) return RAFT_HIP_ERR_PARAM;
     if (n_reads == INT32_MAX) return RAFT_HIP_ERR_TOO_LARGE;
     if (n_rec >= (1LL << 29)) return RAFT_HIP_ERR_TOO_LARGE;   // interval byte offsets are 32-bit (2 sides per record at most)
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     bool expand = false;
-    if (n_rec > 0 && grouped && !d_qid) {                      // no query column: the ids are rebuilt from the offsets
+    if (merge) {
+        HIP_TRY(c, c->b_rid.ensure((size_t)n_rec * 4));
+        HIP_TRY(c, c->b_s.ensure((size_t)n_rec * 4));
+        HIP_TRY(c, c->b_e.ensure((size_t)n_rec * 4));
+        HIP_TRY(c, c->m_off.ensure((size_t)(n_reads + 1LL) * 8));
+    } else if (n_rec > 0 && grouped && !d_qid) {               // no query column: the ids are rebuilt from the offsets
         HIP_TRY(c, c->exp_qid.ensure((size_t)n_rec * 4));
         d_qid = c->exp_qid.as<int32_t>();
         expand = true;
@@ -501,6 +514,17 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     HIP_TRY(c, c->ctrl.ensure(sizeof(Ctrl)));
     Ctrl *ctrl = c->ctrl.as<Ctrl>();
     hipLaunchKernelGGL(clear_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl);      // (three fill commands before: ~5 us each on the device)
+    const long long *eff_off = in.rec_off;
+    if (merge) {
+        const long long stride = (long long)n_reads + 1;
+        hipLaunchKernelGGL(check_offsets_kernel, dim3((unsigned)((n_reads + 1LL + 255) / 256)), dim3(256), 0, st, n_reads, in.n_runs, in.rec_off, stride,
+                           (long long)n_rec, &ctrl->err_flags, &ctrl->err_index);
+        hipLaunchKernelGGL(merge_runs_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(((n_reads + 64LL) / 64 + 3) / 4, 256 * 16))), dim3(256), 0, st,
+                           n_reads, in.n_runs, in.rec_off, stride, d_qs, d_qe, c->m_off.as<long long>(), c->b_rid.as<int32_t>(), c->b_s.as<int32_t>(),
+                           c->b_e.as<int32_t>(), &ctrl->err_flags);
+        d_qid = d_tid = c->b_rid.as<int32_t>(); d_qs = d_ts = c->b_s.as<int32_t>(); d_qe = d_te = c->b_e.as<int32_t>();
+        eff_off = c->m_off.as<long long>();
+    }
 
     // ---- two things have to be known before the host can size and launch the rest, and they run side by side:
     //  (main stream) what the record stream looks like -- sorted runs sampled by guess_runs_kernel and, unless the pass
@@ -520,8 +544,8 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     if (want_guess) HIP_TRY(c, c->samples.ensure((size_t)(kSamples + 2) * 4));
     GroupedOff grp{};
     if (grouped) {
-        grp.off = in.rec_off; grp.stride = N + 1;
-        for (int s2 = 0; s2 < kMaxSeg; ++s2) grp.adj[s2] = in.adj[s2];
+        grp.off = eff_off; grp.stride = N + 1;
+        for (int s2 = 0; s2 < kMaxSeg; ++s2) grp.adj[s2] = merge ? 0 : in.adj[s2];
     }
     long long *scan_totals = nullptr;
     {
@@ -624,10 +648,10 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
 
     hipLaunchKernelGGL(tile_first_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, st, n_reads,
                        c->cov_off.as<long long>(), Q, n_tiles, c->tile_first.as<int32_t>(), &ctrl->err_flags, &ctrl->err_index, grp,
-                       in.n_runs, (long long)n_rec, c->rep_cnt.as<int32_t>(), scan_totals, no_wait ? in.hint_bins : -1LL);
+                       eff_runs, (long long)n_rec, c->rep_cnt.as<int32_t>(), scan_totals, no_wait ? in.hint_bins : -1LL);
     if (expand)
-        hipLaunchKernelGGL(expand_ids_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(((N + 63) / 64 * in.n_runs + 3) / 4, 256 * 16))),
-                           dim3(256), 0, st, n_reads, in.n_runs, grp, c->exp_qid.as<int32_t>(), &ctrl->err_flags);
+        hipLaunchKernelGGL(expand_ids_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(((N + 63) / 64 * eff_runs + 3) / 4, 256 * 16))),
+                           dim3(256), 0, st, n_reads, eff_runs, grp, c->exp_qid.as<int32_t>(), &ctrl->err_flags);
 
     int symmetric = c->prm.symmetric_mode == 1 ? 1 : 0;
     int n_desc = 0;
@@ -635,7 +659,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     bool table_ok = false;
     if (grouped) {
         symmetric = 1;
-        n_desc = in.n_runs - 1;
+        n_desc = eff_runs - 1;
     } else if (spec) {
         symmetric = 1;
         n_desc = hg->n_desc;
@@ -695,9 +719,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         pa.n_seg = 0;
         c->sum.interval_path = 0; c->sum.n_segments = 0; c->sum.n_intervals = 0;
     } else if (grouped) {
-        sb.n_seg = in.n_runs;                         // (where the runs begin is in the offsets, on the device)
+        sb.n_seg = eff_runs;                          // (where the runs begin is in the offsets, on the device)
         pa.iv_rid = d_qid; pa.iv_s = d_qs; pa.iv_e = d_qe; pa.n_seg = sb.n_seg;
-        c->sum.interval_path = 0; c->sum.n_segments = sb.n_seg; c->sum.n_intervals = n_rec;
+        c->sum.interval_path = 0; c->sum.n_segments = in.n_runs; c->sum.n_intervals = n_rec;   // (more than kMaxSeg runs: merged into one first)
     } else if (fast) {
         std::sort(desc, desc + n_desc);
         sb.n_seg = n_desc + 1;
@@ -1248,7 +1272,7 @@ int raft_hip_run_host_grouped(raft_hip_ctx *c, int32_t n_reads, const int32_t *r
                               const int64_t *rec_offset, const int32_t *qs, const int32_t *qe, int64_t n_bins)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
-    if (n_reads < 0 || n_rec < 0 || n_runs < 1 || n_runs > kMaxSeg || !rec_offset) return RAFT_HIP_ERR_PARAM;
+    if (n_reads < 0 || n_rec < 0 || n_runs < 1 || n_runs > kMaxRuns || !rec_offset) return RAFT_HIP_ERR_PARAM;
     if (n_reads > 0 && !read_len) return RAFT_HIP_ERR_PARAM;
     if (n_rec > 0 && (!qs || !qe)) return RAFT_HIP_ERR_PARAM;
     if (c->prm.symmetric_mode != 1) return RAFT_HIP_ERR_PARAM;
@@ -2015,6 +2039,242 @@ int raft_hip_host_unregister(void *ptr)
     if (hipHostUnregister(ptr) == hipSuccess) return RAFT_HIP_OK;
     (void)hipGetLastError();
     return RAFT_HIP_ERR_DEVICE;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pre-split PAF (BASELINE configs[3]): every rank holds a contiguous slice of the record stream -- in its
+// grouped form: per sorted run of the slice, where every read's records begin -- and the reads are owned by ranks in
+// contiguous ranges bounds[g] .. bounds[g+1].  A run sorted by read id is sorted by OWNER too, so what rank p has for rank g
+// is one contiguous piece per run: nothing is bucketed, copied or sorted before it leaves -- the pieces of the two
+// coordinate columns go out from where they lie, with the matching slice of the run's offsets (rebased by the receiver),
+// and what arrives is grouped input again: one run per (peer, run) with records for this rank.  More than kMaxSeg of
+// them are merged on the device by the pass itself (bucket.hpp merge_runs_kernel).  The query ids never travel.
+//   raft_hip_exchange        one process per GPU: RCCL -- counts by ncclAllGather, payload by grouped ncclSend / ncclRecv
+//                            over xGMI (librccl is loaded when first used: half a gigabyte that a single-GPU run never maps)
+//   raft_hip_exchange_local  one process, several contexts: peer copies (hipMemcpyPeerAsync over xGMI)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct RcclApi {
+    bool ok = false;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);      // (a process that has PyTorch-ROCm loaded gets that one: same soname)
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        bool ok = true;
+        auto sym = [&](const char *n) { void *p = dlsym(h, n); ok = ok && p; return p; };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+        api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        api.ok = ok;
+    });
+    return api.ok ? &api : nullptr;
+}
+
+struct RunBases { long long base[kMaxRuns]; };
+
+// off[k][r] = base[k] + raw[k][r] - raw[k][0]: a received slice of a peer's offsets counts from that peer's stream
+__global__ __launch_bounds__(256) void rebase_offsets_kernel(int32_t n_runs, long long n1, const long long *raw, RunBases b, long long *off)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1 * n_runs) return;
+    const int k = (int)(i / n1);
+    off[i] = b.base[k] + raw[i] - raw[(long long)k * n1];
+}
+
+struct XRun { int peer, run; long long lo, n; };            // a run this rank receives: records [lo, lo + n) of peer's run
+
+bool slice_ok(const raft_hip_slice &sl, int32_t n_reads_total)
+{
+    return sl.n_rec >= 0 && sl.n_runs >= 1 && sl.n_runs <= kMaxSeg && sl.rec_offset && (sl.n_rec == 0 || (sl.d_qs && sl.d_qe)) && n_reads_total >= 0;
+}
+
+} // namespace
+
+int raft_hip_comm_unique_id(void *id128)
+{
+    RcclApi *r = rccl_api();
+    if (!r || !id128) return RAFT_HIP_ERR_DEVICE;
+    static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
+    return r->GetUniqueId(reinterpret_cast<ncclUniqueId *>(id128)) == ncclSuccess ? RAFT_HIP_OK : RAFT_HIP_ERR_DEVICE;
+}
+
+int raft_hip_comm_create(int device_id, const void *id128, int32_t rank, int32_t world, void **comm)
+{
+    RcclApi *r = rccl_api();
+    if (!r || !id128 || !comm || world < 1 || rank < 0 || rank >= world) return RAFT_HIP_ERR_PARAM;
+    if (hipSetDevice(device_id) != hipSuccess) return RAFT_HIP_ERR_DEVICE;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t c = nullptr;
+    if (r->CommInitRank(&c, world, id, rank) != ncclSuccess) return RAFT_HIP_ERR_DEVICE;
+    *comm = c;
+    return RAFT_HIP_OK;
+}
+
+void raft_hip_comm_destroy(void *comm)
+{
+    RcclApi *r = rccl_api();
+    if (r && comm) (void)r->CommDestroy(reinterpret_cast<ncclComm_t>(comm));
+}
+
+int raft_hip_exchange_local(raft_hip_ctx *const *ctxs, int32_t world, int32_t n_reads_total, const int64_t *bounds,
+                            const raft_hip_slice *slices, raft_hip_received *outs)
+{
+    if (!ctxs || world < 1 || !bounds || !slices || !outs) return RAFT_HIP_ERR_PARAM;
+    const long long N1 = (long long)n_reads_total + 1;
+    for (int p = 0; p < world; ++p) {
+        if (!ctxs[p] || !slice_ok(slices[p], n_reads_total)) return RAFT_HIP_ERR_PARAM;
+        if (bounds[p] < 0 || bounds[p] > bounds[p + 1] || bounds[p + 1] > n_reads_total) return RAFT_HIP_ERR_PARAM;
+    }
+    if (bounds[0] != 0 || bounds[world] != n_reads_total) return RAFT_HIP_ERR_PARAM;
+    for (int g = 0; g < world; ++g) {
+        raft_hip_ctx *c = ctxs[g];
+        const long long b0 = bounds[g], b1 = bounds[g + 1], n1 = b1 - b0 + 1;
+        std::vector<XRun> runs;
+        long long n_rec = 0;
+        for (int p = 0; p < world; ++p)
+            for (int j = 0; j < slices[p].n_runs; ++j) {
+                const long long lo = slices[p].rec_offset[j * N1 + b0], hi = slices[p].rec_offset[j * N1 + b1];
+                if (lo < 0 || hi < lo || hi > slices[p].n_rec) return RAFT_HIP_ERR_PARAM;       // (offsets that leave the slice)
+                if (hi > lo) { runs.push_back(XRun{p, j, lo, hi - lo}); n_rec += hi - lo; }
+            }
+        if ((int)runs.size() > kMaxRuns) { c->last_error = "raft_hip_exchange: more than 16 runs arrive at one rank"; return RAFT_HIP_ERR_TOO_LARGE; }
+        const int K = std::max<int>(1, (int)runs.size());
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, c->x_qs.ensure((size_t)std::max(n_rec, 1LL) * 4));
+        HIP_TRY(c, c->x_qe.ensure((size_t)std::max(n_rec, 1LL) * 4));
+        HIP_TRY(c, c->x_off.ensure((size_t)K * (size_t)n1 * 8));
+        std::vector<long long> off((size_t)K * (size_t)n1, 0);
+        long long base = 0;
+        for (size_t k = 0; k < runs.size(); ++k) {
+            const XRun &x = runs[k];
+            const int64_t *src = slices[x.peer].rec_offset + x.run * N1 + b0;
+            for (long long r = 0; r < n1; ++r) off[k * (size_t)n1 + (size_t)r] = base + (src[r] - src[0]);
+            const int pd = ctxs[x.peer]->device;
+            if (pd == c->device) {
+                HIP_TRY(c, hipMemcpyAsync(c->x_qs.as<int32_t>() + base, slices[x.peer].d_qs + x.lo, (size_t)x.n * 4, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(c->x_qe.as<int32_t>() + base, slices[x.peer].d_qe + x.lo, (size_t)x.n * 4, hipMemcpyDeviceToDevice, c->stream));
+            } else {
+                HIP_TRY(c, hipMemcpyPeerAsync(c->x_qs.as<int32_t>() + base, c->device, slices[x.peer].d_qs + x.lo, pd, (size_t)x.n * 4, c->stream));
+                HIP_TRY(c, hipMemcpyPeerAsync(c->x_qe.as<int32_t>() + base, c->device, slices[x.peer].d_qe + x.lo, pd, (size_t)x.n * 4, c->stream));
+            }
+            base += x.n;
+        }
+        if (runs.empty()) for (long long r = 0; r < n1; ++r) off[(size_t)r] = 0;
+        HIP_TRY(c, hipMemcpyAsync(c->x_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));                         // (`off` leaves scope; the peers' columns may be reused)
+        outs[g] = raft_hip_received{(int32_t)(b1 - b0), K, n_rec, c->x_off.as<int64_t>(), c->x_qs.as<int32_t>(), c->x_qe.as<int32_t>()};
+    }
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world, int32_t n_reads_total, const int64_t *bounds,
+                      const raft_hip_slice *mine, raft_hip_received *out)
+{
+    RcclApi *r = rccl_api();
+    if (!c || !comm_v || !bounds || !mine || !out || world < 1 || rank < 0 || rank >= world) return RAFT_HIP_ERR_PARAM;
+    if (!r) { c->last_error = "librccl.so.1 could not be loaded"; return RAFT_HIP_ERR_DEVICE; }
+    if (!slice_ok(*mine, n_reads_total) || bounds[0] != 0 || bounds[world] != n_reads_total) return RAFT_HIP_ERR_PARAM;
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(comm_v);
+    const long long N1 = (long long)n_reads_total + 1;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+#define NCCL_TRY(expr)                                                                                     \
+    do {                                                                                                   \
+        const ncclResult_t e_ = (expr);                                                                    \
+        if (e_ != ncclSuccess) { c->last_error = std::string(#expr ": ") + r->GetErrorString(e_); return RAFT_HIP_ERR_DEVICE; } \
+    } while (0)
+    // ---- who sends how much to whom: every rank's row of piece sizes, gathered (world * world * kMaxSeg numbers)
+    const size_t row = (size_t)world * kMaxSeg;
+    std::vector<long long> cnt(row * (size_t)world, 0);
+    for (int g = 0; g < world; ++g) {
+        if (bounds[g] < 0 || bounds[g] > bounds[g + 1] || bounds[g + 1] > n_reads_total) return RAFT_HIP_ERR_PARAM;
+        for (int j = 0; j < kMaxSeg; ++j) {
+            long long n = -1;                                                // (-1: the slice has no such run)
+            if (j < mine->n_runs) {
+                const long long lo = mine->rec_offset[j * N1 + bounds[g]], hi = mine->rec_offset[j * N1 + bounds[g + 1]];
+                if (lo < 0 || hi < lo || hi > mine->n_rec) return RAFT_HIP_ERR_PARAM;
+                n = hi - lo;
+            }
+            cnt[(size_t)rank * row + (size_t)g * kMaxSeg + (size_t)j] = n;
+        }
+    }
+    HIP_TRY(c, c->x_cnt.ensure(cnt.size() * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->x_cnt.as<long long>() + (size_t)rank * row, cnt.data() + (size_t)rank * row, row * 8, hipMemcpyHostToDevice, st));
+    NCCL_TRY(r->AllGather(c->x_cnt.as<long long>() + (size_t)rank * row, c->x_cnt.p, row, ncclInt64, comm, st));
+    HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->x_cnt.p, cnt.size() * 8, hipMemcpyDeviceToHost, st));
+    // (meanwhile: this rank's offsets go to the device, from where their slices are sent)
+    HIP_TRY(c, c->x_send_off.ensure((size_t)mine->n_runs * (size_t)N1 * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->x_send_off.p, mine->rec_offset, (size_t)mine->n_runs * (size_t)N1 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    // ---- what arrives here: one run per (peer, run) with records for this rank
+    const long long b0 = bounds[rank], n1 = bounds[rank + 1] - b0 + 1;
+    std::vector<XRun> runs;
+    long long n_rec = 0;
+    for (int p = 0; p < world; ++p)
+        for (int j = 0; j < kMaxSeg; ++j) {
+            const long long n = cnt[(size_t)p * row + (size_t)rank * kMaxSeg + (size_t)j];
+            if (n > 0) { runs.push_back(XRun{p, j, 0, n}); n_rec += n; }
+        }
+    if ((int)runs.size() > kMaxRuns) { c->last_error = "raft_hip_exchange: more than 16 runs arrive at one rank"; return RAFT_HIP_ERR_TOO_LARGE; }
+    const int K = std::max<int>(1, (int)runs.size());
+    HIP_TRY(c, c->x_qs.ensure((size_t)std::max(n_rec, 1LL) * 4));
+    HIP_TRY(c, c->x_qe.ensure((size_t)std::max(n_rec, 1LL) * 4));
+    HIP_TRY(c, c->x_off.ensure((size_t)K * (size_t)n1 * 8));
+    HIP_TRY(c, c->x_raw.ensure((size_t)K * (size_t)n1 * 8));
+    RunBases rb{};
+    {
+        long long base = 0;
+        for (size_t k = 0; k < runs.size(); ++k) { rb.base[k] = base; base += runs[k].n; }
+    }
+    // ---- the exchange: per ordered pair of ranks the sends and the receives are issued in the same order (run by run:
+    // qs, qe, offsets), all inside one group -- xGMI is point-to-point, every pair has its own link
+    NCCL_TRY(r->GroupStart());
+    for (int g = 0; g < world; ++g)
+        for (int j = 0; j < mine->n_runs; ++j) {
+            const long long lo = mine->rec_offset[j * N1 + bounds[g]], n = mine->rec_offset[j * N1 + bounds[g + 1]] - lo;
+            if (n <= 0) continue;
+            NCCL_TRY(r->Send(mine->d_qs + lo, (size_t)n, ncclInt32, g, comm, st));
+            NCCL_TRY(r->Send(mine->d_qe + lo, (size_t)n, ncclInt32, g, comm, st));
+            NCCL_TRY(r->Send(c->x_send_off.as<long long>() + j * N1 + bounds[g], (size_t)(bounds[g + 1] - bounds[g] + 1), ncclInt64, g, comm, st));
+        }
+    for (size_t k = 0; k < runs.size(); ++k) {
+        NCCL_TRY(r->Recv(c->x_qs.as<int32_t>() + rb.base[k], (size_t)runs[k].n, ncclInt32, runs[k].peer, comm, st));
+        NCCL_TRY(r->Recv(c->x_qe.as<int32_t>() + rb.base[k], (size_t)runs[k].n, ncclInt32, runs[k].peer, comm, st));
+        NCCL_TRY(r->Recv(c->x_raw.as<long long>() + (long long)k * n1, (size_t)n1, ncclInt64, runs[k].peer, comm, st));
+    }
+    NCCL_TRY(r->GroupEnd());
+#undef NCCL_TRY
+    if (runs.empty()) HIP_TRY(c, hipMemsetAsync(c->x_off.p, 0, (size_t)n1 * 8, st));
+    else
+        hipLaunchKernelGGL(rebase_offsets_kernel, dim3((unsigned)((n1 * K + 255) / 256)), dim3(256), 0, st, K, n1, c->x_raw.as<long long>(), rb,
+                           c->x_off.as<long long>());
+    HIP_TRY(c, hipGetLastError());
+    *out = raft_hip_received{(int32_t)(n1 - 1), K, n_rec, c->x_off.as<int64_t>(), c->x_qs.as<int32_t>(), c->x_qe.as<int32_t>()};
+    return RAFT_HIP_OK;                                      // (in stream order: a pass on this context's stream may follow at once)
 }
 
 int raft_hip_last_timing(raft_hip_ctx *c, double *pileup_seconds, double *pass_seconds)

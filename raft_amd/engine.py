@@ -25,7 +25,8 @@ EXPORTS = (
     "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
     "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed", "raft_hip_fetch_packed_w", "raft_hip_run_pipelined", "raft_hip_run_multi",
     "raft_hip_set_output_width", "raft_hip_packed_device", "raft_hip_run_device_grouped", "raft_hip_run_host_grouped",
-    "raft_hip_run_multi_grouped", "raft_hip_host_register", "raft_hip_host_unregister",
+    "raft_hip_run_multi_grouped", "raft_hip_host_register", "raft_hip_host_unregister", "raft_hip_comm_unique_id",
+    "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local",
 )
 
 
@@ -51,6 +52,15 @@ class _HostOutputs(C.Structure):
                 ("rep_offset", C.c_void_p), ("rep_s", C.c_void_p), ("rep_e", C.c_void_p), ("rep_cap", C.c_int64),
                 ("frag_offset", C.c_void_p), ("frag_begin", C.c_void_p), ("frag_end", C.c_void_p), ("frag_cap", C.c_int64),
                 ("cov_width", C.c_int32)]
+
+
+class _Slice(C.Structure):
+    _fields_ = [("n_rec", C.c_int64), ("n_runs", C.c_int32), ("rec_offset", C.c_void_p), ("d_qs", C.c_void_p), ("d_qe", C.c_void_p)]
+
+
+class _Received(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_runs", C.c_int32), ("n_rec", C.c_int64), ("d_rec_offset", C.c_void_p), ("d_qs", C.c_void_p),
+                ("d_qe", C.c_void_p)]
 
 
 class _Outputs(C.Structure):
@@ -132,6 +142,12 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_run_device_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, vp, i64]
     lib.raft_hip_run_host_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, i64]
     lib.raft_hip_run_multi_grouped.argtypes = [C.POINTER(vp), i32, i32, vp, i64, i32, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
+    lib.raft_hip_comm_unique_id.argtypes = [vp]
+    lib.raft_hip_comm_create.argtypes = [C.c_int, vp, i32, i32, C.POINTER(vp)]
+    lib.raft_hip_comm_destroy.argtypes = [vp]
+    lib.raft_hip_comm_destroy.restype = None
+    lib.raft_hip_exchange.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(_Slice), C.POINTER(_Received)]
+    lib.raft_hip_exchange_local.argtypes = [C.POINTER(vp), i32, i32, vp, C.POINTER(_Slice), C.POINTER(_Received)]
     lib.raft_hip_host_register.argtypes = [vp, C.c_uint64]
     lib.raft_hip_host_unregister.argtypes = [vp]
     lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -487,6 +503,92 @@ class Engine:
         return {"width": w.value,
                 "cov8": view(codes, self.summary.n_bins, "|u1" if w.value == 1 else "<i2", torch.uint8 if w.value == 1 else torch.int16),
                 "exc_index": view(ei, n.value, "<i8", torch.int64), "exc_value": view(ev, n.value, "<i4", torch.int32)}
+
+
+class Slice:
+    """One rank's part of a pre-split PAF (raft_hip_slice): the slice's query coordinates on the device and, on the host, its
+    grouped form -- int64 [n_runs, n_reads_total + 1], where every read of the whole set begins in every sorted run of the slice
+    (raft_amd.hostio.group_offsets on the slice's query column)."""
+
+    def __init__(self, rec_offset, qs, qe):
+        import torch
+        self.off = np.ascontiguousarray(np.asarray(rec_offset), dtype=np.int64)
+        if self.off.ndim != 2 or not (1 <= self.off.shape[0] <= 4):
+            raise ValueError("Slice: rec_offset must be [n_runs (1..4), n_reads_total + 1]")
+        for t in (qs, qe):
+            if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+                raise TypeError("Slice needs contiguous int32 CUDA tensors")
+        self.qs, self.qe = qs, qe
+
+    def c(self) -> "_Slice":
+        return _Slice(int(self.qs.numel()), int(self.off.shape[0]), self.off.ctypes.data, self.qs.data_ptr() if self.qs.numel() else 0,
+                      self.qe.data_ptr() if self.qe.numel() else 0)
+
+
+def _received_views(eng, r: "_Received") -> dict:
+    """Zero-copy torch views of what a context received (valid until its next exchange)."""
+    import torch
+    dev = f"cuda:{eng.device}"
+
+    def view(ptr, n, ts, dt):
+        if n == 0:
+            return torch.empty(0, dtype=dt, device=dev)
+        return torch.as_tensor(_DevArray(ptr, n, ts, eng), device=dev)
+    off = view(r.d_rec_offset, r.n_runs * (r.n_reads + 1), "<i8", torch.int64).reshape(r.n_runs, r.n_reads + 1)
+    return {"n_reads": int(r.n_reads), "n_rec": int(r.n_rec), "n_runs": int(r.n_runs), "rec_offset": off,
+            "qs": view(r.d_qs, r.n_rec, "<i4", torch.int32), "qe": view(r.d_qe, r.n_rec, "<i4", torch.int32)}
+
+
+def exchange_local(engines, bounds, slices) -> list:
+    """raft_hip_exchange_local: one process, one Engine per rank; ``bounds`` = int64 [world + 1] read ranges, ``slices`` one
+    Slice per rank (on that rank's device).  Returns, per rank, the grouped input it received (torch views)."""
+    import torch
+    lib = load_library()
+    w = len(engines)
+    b = np.ascontiguousarray(np.asarray(bounds), dtype=np.int64)
+    torch.cuda.synchronize()
+    ctxs = (C.c_void_p * w)(*[e._ctx for e in engines])
+    sl = (_Slice * w)(*[s.c() for s in slices])
+    out = (_Received * w)()
+    rc = lib.raft_hip_exchange_local(ctxs, w, int(slices[0].off.shape[1] - 1), C.c_void_p(b.ctypes.data), sl, out)
+    engines[0]._check(rc)
+    return [_received_views(e, out[i]) for i, e in enumerate(engines)]
+
+
+class Comm:
+    """An RCCL communicator for raft_hip_exchange (one process per GPU).  ``unique_id()`` on rank 0, handed to the other ranks
+    by the caller (e.g. a torch.distributed broadcast of its 128 bytes), then ``Comm(device, id, rank, world)`` everywhere."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = load_library().raft_hip_comm_unique_id(buf)
+        if rc != OK:
+            raise RaftError(rc, "ncclGetUniqueId (is librccl.so.1 loadable?)")
+        return buf.raw
+
+    def __init__(self, device: int, uid: bytes, rank: int, world: int):
+        self._lib = load_library()
+        self._comm = C.c_void_p()
+        self.rank, self.world = rank, world
+        rc = self._lib.raft_hip_comm_create(device, C.c_char_p(uid), rank, world, C.byref(self._comm))
+        if rc != OK:
+            raise RaftError(rc, "ncclCommInitRank")
+
+    def exchange(self, eng, bounds, sl: Slice) -> dict:
+        """raft_hip_exchange on the engine's stream; returns the grouped input this rank received (torch views)."""
+        b = np.ascontiguousarray(np.asarray(bounds), dtype=np.int64)
+        eng.use_torch_stream()
+        cs, out = sl.c(), _Received()
+        rc = self._lib.raft_hip_exchange(eng._ctx, self._comm, self.rank, self.world, int(sl.off.shape[1] - 1), C.c_void_p(b.ctypes.data),
+                                         C.byref(cs), C.byref(out))
+        eng._check(rc)
+        return _received_views(eng, out)
+
+    def close(self):
+        if self._comm.value:
+            self._lib.raft_hip_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
 
 
 def selftest(device: int = 0) -> int:
