@@ -392,15 +392,35 @@ def main():
             e = engine.Engine(p_sym, device=local)
             e.set_tuning(args.tile_bins, args.force_bucket, args.variant)
             e.use_torch_stream()
+            if not shared:
+                # every rank has a GPU of its own: the native exchange (raft_hip_exchange -- RCCL all-gather of the piece sizes,
+                # grouped send / receive of the two coordinate columns and the offset slices; the query ids never travel) feeding
+                # the grouped pass.  The communicator's id goes from rank 0 to the others through torch.distributed.
+                uid = [engine.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                comm = engine.Comm(local, uid[0], rank, world)
+                sl = engine.Slice(grouped_form(torch, hostio, full.n_reads, cols[0]), cols[1], cols[2])   # (the tokeniser's by-product)
+                my_bins = windows_of(my_len, p.reso)
+                bnp = bounds.numpy()
 
-            def step():
-                cl = [c if not shared else c.cpu() for c in cols]
-                sym = rdist.global_symmetric_flag(cl)                         # broadcast of record 0 + MAX all-reduce
-                iv = rdist.exchange_intervals(cl, bounds, sym)                # ONE all-to-all-v (RCCL over xGMI)
-                iv = tuple(t.to(dev) for t in iv)
-                s = rdist.run_shard(e, my_len, iv)
-                combine(s)
-                return s
+                def step():
+                    sym = rdist.global_symmetric_flag(cols)                   # broadcast of record 0 + MAX all-reduce
+                    assert sym
+                    got = comm.exchange(e, bnp, sl)                           # ONE exchange step over xGMI
+                    e.run_device_grouped(my_len, got["rec_offset"], None, got["qs"], got["qe"], n_bins=my_bins)
+                    s = e.finish()
+                    combine(s)
+                    return s
+            else:
+                # ranks share a GPU (a one-GPU box: RCCL cannot put two ranks on one device): the exchange in torch over gloo
+                def step():
+                    cl = [c.cpu() for c in cols]
+                    sym = rdist.global_symmetric_flag(cl)                     # broadcast of record 0 + MAX all-reduce
+                    iv = rdist.exchange_intervals(cl, bounds, sym)            # one all-to-all-v per column
+                    iv = tuple(t.to(dev) for t in iv)
+                    s = rdist.run_shard(e, my_len, iv)
+                    combine(s)
+                    return s
         else:
             sh = Shard(my_len, cols, grouped_in)
             e = make_engine(sh, args.cov_width)

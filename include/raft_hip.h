@@ -317,6 +317,16 @@ int  raft_hip_exchange_local(raft_hip_ctx *const *ctxs, int32_t world, int32_t n
 int  raft_hip_host_register(void *ptr, uint64_t bytes);
 int  raft_hip_host_unregister(void *ptr);
 
+/* Optional: pays now what the context's first host-to-host job would pay inside its own clock -- the engine's code going
+ * to the device at its first launch, the pipeline's lanes (sub-contexts, streams, page-locked blocks): 70-80 ms on the
+ * MI355X box.  The CLI calls it on a helper thread while it tokenises its inputs. */
+int  raft_hip_warm_up(raft_hip_ctx *ctx);
+/* Optional: allocates the device buffers of a coming host-to-host job from what its caller knows early -- the reads' lengths
+ * and an estimate of the record count (the CLI: from the size of the overlaps file) -- for a job shared by n_ctx contexts
+ * in coverage width cov_width.  Buffers only grow: a short estimate costs what no estimate would have cost. */
+int  raft_hip_reserve(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec_estimate, int32_t n_ctx,
+                      int32_t cov_width);
+
 /* Device seconds spent in the dominant kernel (coverage pileup + run scan) and
  * in all kernels of the last finished pass, from HIP events recorded on the
  * context's stream around them. */

@@ -1896,12 +1896,14 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
                     {o->frag_begin ? o->frag_begin + b_frag : nullptr, l->frag_begin.p, (size_t)cr.n_frag * 4},
                     {o->frag_end ? o->frag_end + b_frag : nullptr, l->frag_end.p, (size_t)cr.n_frag * 4}};
                 // the download stream takes over once the lane's last kernel is done; the lane waits for its own copies only
+                stamp(k, "bases known");
                 LANE_TRY(hipEventRecord(jc->lane_down_ev[(size_t)li], st));
                 {
                     std::lock_guard<std::mutex> g(sh.down_mu);       // one chunk's copies stay together on the stream
                     LANE_TRY(hipStreamWaitEvent(jc->down_stream, jc->lane_down_ev[(size_t)li], 0));
+                    stamp(k, "d2h wait set");
                     for (auto &j : job)
-                        if (j.dst && j.bytes) LANE_TRY(hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, jc->down_stream));
+                        if (j.dst && j.bytes) { LANE_TRY(hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, jc->down_stream)); if (trace) stamp(k, "d2h copy"); }
                     LANE_TRY(hipEventRecord(jc->lane_down_ev[(size_t)li], jc->down_stream));
                 }
                 stamp(k, "d2h queued");
@@ -1992,6 +1994,97 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             for (int32_t r = ra; r < r_hi; ++r) { o->rep_offset[r] += rep_at; o->frag_offset[r] += frag_at; }
             rep_at += J.n_rep; frag_at += J.n_frag;
         }
+    }
+    return RAFT_HIP_OK;
+}
+
+// What the first job of a fresh process pays once -- the engine's code object going to the device at the first launch, the
+// four lanes (sub-contexts with their streams, events and page-locked blocks), the small per-context buffers -- is 70-80 ms
+// on the MI355X box: five times the work of a 4.4e7-record job.  The CLI calls this beside the tokenising of its inputs.
+int raft_hip_warm_up(raft_hip_ctx *c)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    int rc = prepare_lanes(c);
+    if (rc != RAFT_HIP_OK) return rc;
+    {   // the copy engines behind the pipeline's two copy streams come up at their first large copy (measured: the first
+        // 40 MB download of a process sat 10 ms in hipMemcpyAsync)
+        HIP_TRY(c, hipSetDevice(c->device));
+        void *h = nullptr, *d = nullptr;
+        const size_t n = 4u << 20;
+        if (hipHostMalloc(&h, n, hipHostMallocDefault) == hipSuccess && hipMalloc(&d, n) == hipSuccess) {
+            (void)hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->up_stream);
+            (void)hipStreamSynchronize(c->up_stream);
+            (void)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->down_stream);
+            (void)hipStreamSynchronize(c->down_stream);
+        }
+        if (d) (void)hipFree(d);
+        if (h) (void)hipHostFree(h);
+        (void)hipGetLastError();
+    }
+    const int32_t len[2] = {400, 300}, qs[2] = {0, 10}, qe[2] = {120, 200};
+    const int64_t off[3] = {0, 1, 2};
+    std::vector<raft_hip_ctx *> all(c->lanes);
+    all.push_back(c);
+    for (raft_hip_ctx *l : all) {
+        const raft_hip_params keep = l->prm;
+        const raft_hip_params p1{50, 30, 1.5, 10000, 10000, 20000, 500, 1000, 1};   // (the reference's defaults: the two reads stay whole)
+        apply_params(l, &p1);
+        const int keep_width = l->out_width;
+        for (int w = 1; w <= 2 && rc == RAFT_HIP_OK; ++w) {           // (both widths of the transfer encoding: their own kernels)
+            l->out_width = w;
+            rc = raft_hip_run_host_grouped(l, 2, len, 2, 1, off, qs, qe, -1);
+            raft_hip_summary s{};
+            if (rc == RAFT_HIP_OK) rc = raft_hip_finish(l, &s);
+        }
+        l->out_width = keep_width;
+        apply_params(l, &keep);
+        l->ran = false; l->finished = false;
+        if (rc != RAFT_HIP_OK) { c->last_error = l->last_error; break; }
+    }
+    return rc;
+}
+
+// The device buffers of a job, allocated ahead of it: ~35 allocations per lane (5 ms), the staging of a chunk's columns
+// (hundreds of MB: 2 ms each) -- inside the first job's clock unless somebody knows its shape earlier.  The CLI does, after
+// loading the reads: their lengths, and the record count to within a few per cent from the size of the overlaps file.  A
+// pass over the expected chunk's reads WITHOUT records sizes everything that follows the reads; the record-sized buffers
+// are sized directly.  Buffers only grow, so an estimate that falls short costs what it would have cost anyway.
+int raft_hip_reserve(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec_estimate, int32_t n_ctx, int32_t cov_width)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && !read_len) || n_rec_estimate < 0 || n_ctx < 1) return RAFT_HIP_ERR_PARAM;
+    if (n_reads == 0) return RAFT_HIP_OK;
+    const bool chunked = n_rec_estimate >= (1 << 24) && n_reads >= 4096;        // (run_multi_impl's own rule)
+    long long chunks = 1;
+    if (chunked) chunks = std::max<long long>(1, std::min<long long>(std::min<long long>(32LL * n_ctx, std::max<long long>(2LL * n_ctx, n_rec_estimate / (24LL << 20))), n_reads / 1024));
+    const int32_t nr = (int32_t)std::min<long long>(n_reads, n_reads / chunks + n_reads / chunks / 4 + 64);
+    const long long nrec = n_rec_estimate / chunks + n_rec_estimate / chunks / 4 + 1024;
+    int rc = RAFT_HIP_OK;
+    std::vector<raft_hip_ctx *> who;
+    if (chunked) {
+        rc = prepare_lanes(c);
+        if (rc != RAFT_HIP_OK) return rc;
+        const long long per_ctx = (chunks + n_ctx - 1) / n_ctx;
+        for (int li = 0; li < std::min<long long>(kLanes, per_ctx); ++li) who.push_back(c->lanes[(size_t)li]);
+    } else who.push_back(c);
+    std::vector<int64_t> zeros((size_t)nr + 1, 0);
+    for (raft_hip_ctx *l : who) {
+        HIP_TRY(l, hipSetDevice(l->device));
+        for (int col = 1; col < 3; ++col) HIP_TRY(l, l->in_col[col].ensure((size_t)nrec * 4));
+        HIP_TRY(l, l->exp_qid.ensure((size_t)nrec * 4));
+        HIP_TRY(l, l->in_off.ensure((size_t)kMaxSeg * ((size_t)nr + 1) * 8));
+        const raft_hip_params keep = l->prm;
+        raft_hip_params p1 = c->prm;
+        p1.symmetric_mode = 1;
+        apply_params(l, &p1);
+        const int keep_width = l->out_width;
+        l->out_width = cov_width == 2 ? 2 : 1;
+        rc = raft_hip_run_host_grouped(l, nr, read_len, 0, 1, zeros.data(), nullptr, nullptr, -1);
+        raft_hip_summary s{};
+        if (rc == RAFT_HIP_OK) rc = raft_hip_finish(l, &s);
+        l->out_width = keep_width;
+        apply_params(l, &keep);
+        l->ran = false; l->finished = false;
+        if (rc == RAFT_HIP_ERR_NOMEM || rc == RAFT_HIP_ERR_DEVICE) { c->last_error = l->last_error; return rc; }   // (data errors are the job's to report)
     }
     return RAFT_HIP_OK;
 }

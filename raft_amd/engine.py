@@ -26,7 +26,7 @@ EXPORTS = (
     "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed", "raft_hip_fetch_packed_w", "raft_hip_run_pipelined", "raft_hip_run_multi",
     "raft_hip_set_output_width", "raft_hip_packed_device", "raft_hip_run_device_grouped", "raft_hip_run_host_grouped",
     "raft_hip_run_multi_grouped", "raft_hip_host_register", "raft_hip_host_unregister", "raft_hip_comm_unique_id",
-    "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local",
+    "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local", "raft_hip_warm_up", "raft_hip_reserve",
 )
 
 
@@ -148,6 +148,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_comm_destroy.restype = None
     lib.raft_hip_exchange.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(_Slice), C.POINTER(_Received)]
     lib.raft_hip_exchange_local.argtypes = [C.POINTER(vp), i32, i32, vp, C.POINTER(_Slice), C.POINTER(_Received)]
+    lib.raft_hip_warm_up.argtypes = [vp]
+    lib.raft_hip_reserve.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.raft_hip_host_register.argtypes = [vp, C.c_uint64]
     lib.raft_hip_host_unregister.argtypes = [vp]
     lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -144,8 +144,14 @@ int main(int argc, char *argv[])
     std::shared_future<void> devices_up = devices_up_p.get_future().share();
     std::thread bring_up([&] {
         std::vector<std::thread> th;
-        for (size_t d = 1; d < devices.size(); ++d) th.emplace_back([&, d] { create_rc[d] = raft_hip_create(devices[d], &hp, &ctxs[d]); });
-        create_rc[0] = raft_hip_create(devices[0], &hp, &ctxs[0]);
+        // (created and warmed up: the engine's code goes to the device, the pipeline's lanes come up -- 70-80 ms that would
+        // otherwise sit inside the first job)
+        auto up = [&](size_t d) {
+            create_rc[d] = raft_hip_create(devices[d], &hp, &ctxs[d]);
+            if (create_rc[d] == RAFT_HIP_OK && !getenv("RAFT_NO_WARM_UP")) create_rc[d] = raft_hip_warm_up(ctxs[d]);
+        };
+        for (size_t d = 1; d < devices.size(); ++d) th.emplace_back([&, d] { up(d); });
+        up(0);
         for (auto &t : th) t.join();
         devices_up_p.set_value();
     });
@@ -155,7 +161,7 @@ int main(int argc, char *argv[])
     // error: the copy then takes the pageable path.
     const bool no_pin = getenv("RAFT_NO_PIN") != nullptr;
     auto pin = [&](const void *ptr, size_t bytes) {
-        if (!no_pin && ptr && bytes >= (size_t)(8u << 20)) (void)raft_hip_host_register(const_cast<void *>(ptr), bytes);
+        if (!no_pin && ptr && bytes >= (size_t)(64u << 10)) (void)raft_hip_host_register(const_cast<void *>(ptr), bytes);
     };
 
     // The overlaps file's bytes need nothing of the reads: they are read -- inflated, for a .gz -- beside the loading of
@@ -183,6 +189,9 @@ int main(int argc, char *argv[])
     std::vector<int64_t> cov_off((size_t)n_reads + 1), rep_off((size_t)n_reads + 1), frag_off((size_t)n_reads + 1);
     std::unique_ptr<uint8_t[]> cov8;
     std::unique_ptr<int32_t[]> rep_s, rep_e, fb, fe;
+    std::vector<int64_t> exc_i;
+    std::vector<int32_t> exc_v;
+    int64_t exc_cap0 = 0;
     std::thread out_prep([&] {
         const int64_t minw = std::max<int64_t>(((int64_t)p.repeat_length + p.reso - 1) / p.reso, 1);
         int64_t sum_len = 0;
@@ -192,12 +201,26 @@ int main(int argc, char *argv[])
         cov8.reset(new uint8_t[((size_t)n_win + 1) * 2]);                         // (not value-initialised: no zero fill)
         rep_s.reset(new int32_t[(size_t)rep_cap + 1]); rep_e.reset(new int32_t[(size_t)rep_cap + 1]);
         fb.reset(new int32_t[(size_t)frag_cap + 1]); fe.reset(new int32_t[(size_t)frag_cap + 1]);
+        exc_cap0 = std::max<int64_t>(1 << 16, n_win / 64);
+        exc_i.resize((size_t)exc_cap0); exc_v.resize((size_t)exc_cap0);
         devices_up.wait();
-        if (create_rc[0] != RAFT_HIP_OK) return;
+        for (size_t d = 0; d < devices.size(); ++d) if (create_rc[d] != RAFT_HIP_OK) return;
+        pin(exc_i.data(), exc_i.size() * 8); pin(exc_v.data(), exc_v.size() * 4);
         pin(cov8.get(), ((size_t)n_win + 1) * (p.est_cov >= 40 ? 2 : 1));
         pin(fb.get(), ((size_t)frag_cap + 1) * 4); pin(fe.get(), ((size_t)frag_cap + 1) * 4);
+        pin(rep_s.get(), ((size_t)rep_cap + 1) * 4); pin(rep_e.get(), ((size_t)rep_cap + 1) * 4);
         pin(cov_off.data(), cov_off.size() * 8); pin(frag_off.data(), frag_off.size() * 8); pin(rep_off.data(), rep_off.size() * 8);
         pin(rl, (size_t)n_reads * 4);
+        // the job's device buffers, sized from what is known by now: the reads' lengths, and the record count to within a few
+        // per cent from the size of the overlaps file (a PAF line of hifiasm's has ~63 bytes; .gz: ~4x that when inflated)
+        if (!getenv("RAFT_NO_WARM_UP")) {
+            std::ifstream pf(paf_fn, std::ios::binary | std::ios::ate);
+            const std::string pn(paf_fn);
+            const bool gz = pn.size() > 3 && pn.compare(pn.size() - 3, 3, ".gz") == 0;
+            const int64_t est = pf ? (int64_t)pf.tellg() * (gz ? 4 : 1) / 60 : 0;
+            for (size_t d = 0; d < devices.size(); ++d)
+                (void)raft_hip_reserve(ctxs[d], n_reads, rl, est, (int32_t)devices.size(), p.est_cov >= 40 ? 2 : 1);
+        }
     });
     g_background[3] = &out_prep;
 
@@ -244,13 +267,15 @@ int main(int argc, char *argv[])
     // one byte per window unless the expected coverage lets repeats pile up beyond it (from 40x on: two), and two in any
     // case when the first attempt meets more windows at or above 255 than the exception list holds
     int cov_width = p.est_cov >= 40 ? 2 : 1;
-    std::vector<int64_t> exc_i;
-    std::vector<int32_t> exc_v;
     raft_hip_summary s{};
     int64_t n_exc = 0;
     const char *chunks_env = getenv("RAFT_CHUNKS");   // 0 / unset: the engine decides (one piece for small inputs)
-    for (int64_t exc_cap = std::max<int64_t>(1 << 16, n_win / 64), attempt = 0; attempt < 3; ++attempt) {
-        exc_i.resize((size_t)exc_cap); exc_v.resize((size_t)exc_cap);
+    for (int64_t exc_cap = exc_cap0, attempt = 0; attempt < 3; ++attempt) {
+        if ((int64_t)exc_i.size() != exc_cap) {          // (a retry with more room: the first size was made and page-locked beside the tokenising)
+            if (!no_pin) { (void)raft_hip_host_unregister(exc_i.data()); (void)raft_hip_host_unregister(exc_v.data()); }
+            exc_i.resize((size_t)exc_cap); exc_v.resize((size_t)exc_cap);
+            pin(exc_i.data(), exc_i.size() * 8); pin(exc_v.data(), exc_v.size() * 4);
+        }
         raft_hip_host_outputs ho{};
         ho.cov_offset = cov_off.data(); ho.cov8 = cov8.get(); ho.cov8_cap = n_win; ho.cov_width = cov_width;
         ho.exc_index = exc_i.data(); ho.exc_value = exc_v.data(); ho.exc_cap = exc_cap;

@@ -555,3 +555,54 @@ def test_groups_of_reads_without_windows_are_still_checked(mode, monkeypatch):
         eng.run_host(rl, qid, s_, bad, None, None, None); eng.finish()
     assert err.value.code == engine.ERR_COORD
     eng.close()
+
+
+def test_config4_two_shards_of_the_full_size_set():
+    """BASELINE configs[3] at its own size on the one GPU of the box: the ONE 3.3 M-read set of configs[2] cut into two
+    contiguous read ranges (raft_amd.dist.partition_reads), every shard handed the records of its reads in grouped form
+    (what a rank of `bench.py --strong` runs).  The shards' totals add up to the single pass's; coverage, repeats and
+    fragments of a 20 k-read window inside each shard equal the oracle's."""
+    import torch
+    from raft_amd import dist as rdist
+    from raft_amd import engine, hostio
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(3_300_000, mean_len=30000.0, coverage=32.0, seed=20241008, device="cuda:0")
+    p = RaftParams(est_cov=32)
+    e0 = engine.Engine(p, device=0)
+    e0.run_device(o.read_len, *o.columns())
+    s0 = e0.finish()
+    e0.close()
+    ipr = torch.bincount(o.qid.long(), minlength=o.n_reads)
+    bounds = rdist.partition_reads(o.read_len, p.reso, 2, intervals_per_read=ipr)
+    tot = {k: 0 for k in ("n_bins", "n_repeats", "n_fragments", "total_coverage", "total_repeat_length", "total_read_length", "n_intervals")}
+    eng = engine.Engine(RaftParams(est_cov=32, symmetric_mode=1), device=0)
+    for g in range(2):
+        b0, b1 = int(bounds[g]), int(bounds[g + 1])
+        sel = (o.qid >= b0) & (o.qid < b1)
+        q, qs, qe = (o.qid[sel] - b0).contiguous(), o.qs[sel].contiguous(), o.qe[sel].contiguous()
+        rl = o.read_len[b0:b1].contiguous()
+        off = hostio.group_offsets(b1 - b0, q.cpu().numpy())
+        assert off is not None and off.shape[0] == 2
+        B = int(((rl.long() + p.reso - 1) // p.reso).sum())
+        eng.run_device_grouped(rl, torch.as_tensor(off).to("cuda:0"), q, qs, qe, n_bins=B)
+        s = eng.finish()
+        assert 0.4 < s.n_records / o.n_rec < 0.6 and s.interval_path == 0
+        for k in tot:
+            tot[k] += getattr(s, k)
+        out = eng.outputs_device()
+        host = {k: v.cpu().numpy() for k, v in out.items() if k != "cov"}
+        a = b0 + (b1 - b0) // 2                           # a window in the middle of the shard (global read indices)
+        rlw, cols = window_subproblem(o, a, a + 20_000)
+        want = oracle_run(p, rlw, *cols)
+        la, n = a - b0, 20_000
+        c0, c1 = int(host["cov_offset"][la]), int(host["cov_offset"][la + n])
+        assert np.array_equal(out["cov"][c0:c1].cpu().numpy(), want["cov"][: int(want["cov_offset"][n])]), g
+        for key, arrs in (("rep", ("rep_s", "rep_e")), ("frag", ("frag_begin", "frag_end"))):
+            offk = host[key + "_offset"]
+            assert np.array_equal(offk[la:la + n + 1] - offk[la], want[key + "_offset"][: n + 1]), (g, key)
+            for k in arrs:
+                assert np.array_equal(host[k][offk[la]:offk[la + n]], want[k][: int(want[key + "_offset"][n])]), (g, k)
+        del out, host
+    eng.close()
+    for k in tot:
+        assert tot[k] == getattr(s0, k), k

@@ -27,6 +27,12 @@ for rep in range(2):
     print(f"hipHostMalloc {GB:.1f} GB: {dt * 1e3:8.1f} ms  ({GB / dt:.2f} GB/s)")
     dt, _ = t(lambda: dev.copy_(pinned, non_blocking=True))
     print(f"  H2D from it:        {dt * 1e3:8.1f} ms  ({GB / dt:.1f} GB/s)")
+    t0 = time.perf_counter()
+    pinned.copy_(dev, non_blocking=True)
+    t_call = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"  D2H to hipHostMalloc: call returns after {t_call * 1e3:8.2f} ms, done after {t_all * 1e3:8.1f} ms  ({GB / t_all:.1f} GB/s)")
     del pinned
     a = np.empty(n, np.uint8)
     dt, _ = t(lambda: a.fill(1))
@@ -38,6 +44,12 @@ for rep in range(2):
     print(f"hipHostRegister (touched pages): {dt * 1e3:8.1f} ms  ({GB / dt:.2f} GB/s) rc={rc}")
     dt, _ = t(lambda: dev.copy_(ta, non_blocking=True))
     print(f"  H2D registered:     {dt * 1e3:8.1f} ms  ({GB / dt:.1f} GB/s)")
+    t0 = time.perf_counter()
+    ta.copy_(dev, non_blocking=True)
+    t_call = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"  D2H to registered:  call returns after {t_call * 1e3:8.2f} ms, done after {t_all * 1e3:8.1f} ms  ({GB / t_all:.1f} GB/s)")
     dt, _ = t(lambda: rt.cudaHostUnregister(a.ctypes.data))
     print(f"hipHostUnregister:    {dt * 1e3:8.1f} ms")
     b = np.empty(n, np.uint8)

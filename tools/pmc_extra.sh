@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmcx
 run() { name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmcx/$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-detect-leg --no-packed-leg > gpurun_out/pmcx/$name.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmcx/$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg > gpurun_out/pmcx/$name.log 2>&1
   echo "pass $name rc=$?"; }
 run a SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 run b SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_ACTIVE_INST_VMEM
