@@ -623,7 +623,9 @@ def main():
             line["strong"] = strong_info
         if args.cov_width != 4:
             line["config"]["cov_width"] = args.cov_width
-        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic_file = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")   # (per workload; the headline workload's: pmc_traffic.json)
+        if not os.path.exists(traffic_file):
+            traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tj = json.load(open(traffic_file))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's DESIGN.md numbers come from, in one GPU call; summaries land in gpurun_out/<tag>/ (copy the
 # ones to be judged into profiles/).  usage: tools/evidence_round.sh <tag>
-TAG=${1:-r02_m}
+TAG=${1:-r03_a}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/$TAG
 tools/profile_round.sh $TAG > gpurun_out/$TAG/profile_round.log 2>&1
 tools/pmc_probe.sh -1 3300000 > gpurun_out/$TAG/sq_counters.txt 2>&1
@@ -10,6 +10,12 @@ python tools/stamp_probe.py 3300000 > gpurun_out/$TAG/stamp_probe.txt 2>&1
 [ -x tools/membench ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/membench.hip -o tools/membench > /dev/null 2>&1
 tools/membench > gpurun_out/$TAG/membench.txt 2>&1
 for w in ultralong s50k; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/$TAG/bench_$w.json 2> gpurun_out/$TAG/bench_$w.err; done
+# an eighth of the human-scale set (what one of eight GPUs holds in BASELINE configs[3]); the full-size pass on the counting-sort path
+python bench.py --reads 412500 --no-cpu-baseline --steps 20 --warmup 3 > gpurun_out/$TAG/bench_slice412k.json 2> gpurun_out/$TAG/bench_slice412k.err
+python bench.py --input columns --handover --force-bucket --no-cpu-baseline --no-e2e --no-packed-leg > gpurun_out/$TAG/bench_counting_sort.json 2> gpurun_out/$TAG/bench_counting_sort.err
+tools/pass_timeline.sh ${TAG}_tl412 --reads 412500 > gpurun_out/$TAG/pass_timeline_slice412k.txt 2>&1
+tools/pass_timeline.sh ${TAG}_tlul --workload ultralong > gpurun_out/$TAG/pass_timeline_ultralong.txt 2>&1
+tools/profile_round.sh ${TAG}_ul --workload ultralong > gpurun_out/$TAG/profile_round_ultralong.log 2>&1
 python tools/pipe_trace.py 2> gpurun_out/$TAG/pipeline_trace.txt
 python tools/pcie_duplex.py > gpurun_out/$TAG/pcie_duplex.txt 2>&1
 tail -3 gpurun_out/$TAG/profile_round.log; grep -E "SQ_INSTS|SQ_WAIT_ANY|SQ_WAVE_CYCLES|BANK_CONFLICT|IDX_ACTIVE" gpurun_out/$TAG/sq_counters.txt | head -20
