@@ -43,6 +43,7 @@ constexpr PileVariant kVariants[] = {
     {0, 6144, 5, 2048},   // 1: general kernel only
     {1, 6144, 5, 1536},   // 2: fast kernel, 29.2 KB LDS, 5 workgroups/CU, 4 prefetch slots per lane, Q = 4608
     {1, 7936, 4, 1664},   // 3: variant 0 with s_memtime stamps in the fast kernel (diagnostic; raft_hip_debug_stamps)
+    {1, 7936, 4, 1664},   // 4: variant 0 with lane-serial rows (pileup_fast.hpp LS)
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kDefaultVariant = 0;
@@ -55,23 +56,29 @@ void launch_general(hipStream_t st, unsigned grid, const PileupArgs &pa)
     hipLaunchKernelGGL((pileup_kernel<256, CAP, MINW, 3, false>), dim3(grid), dim3(256), 0, st, pa);
 }
 
-template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, int EXTRA = 0, int OW = 4>
+template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, int EXTRA = 0, int OW = 4, bool LS = false>
 void launch_fast(hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
     constexpr int S4 = SLOTS % 4 == 0 ? SLOTS : 4;   // four sorted runs need a multiple of four slots
     const size_t dyn = 0;
     if (n_seg <= 1)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG, EXTRA, OW>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG, EXTRA, OW, LS>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else if (n_seg == 2)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG, EXTRA, OW>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG, EXTRA, OW, LS>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG, EXTRA, OW>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG, EXTRA, OW, LS>), dim3(grid), dim3(256), dyn, st, cuts, pa);
 }
 
 // the fast kernel's configurations by output width (pileup_fast.hpp OW; the diagnostic build writes int32 only)
 template <int EXTRA>
-void launch_fast_variant(int variant, int ow, hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
+void launch_fast_variant(int variant, int ow, bool ls, hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
+    if (ls && variant != 2 && variant != kDiagVariant) {      // the lane-serial rows (pileup_fast.hpp LS)
+        if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1, true>(st, grid, n_seg, cuts, pa);
+        else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2, true>(st, grid, n_seg, cuts, pa);
+        else launch_fast<7936, 4, false, 6, EXTRA, 4, true>(st, grid, n_seg, cuts, pa);
+        return;
+    }
     if (variant == 2) {
         if (ow == 1) launch_fast<6144, 5, false, 4, EXTRA, 1>(st, grid, n_seg, cuts, pa);
         else if (ow == 2) launch_fast<6144, 5, false, 4, EXTRA, 2>(st, grid, n_seg, cuts, pa);
@@ -781,6 +788,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     const unsigned pgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * bpc));
     unsigned n_sum_blocks = pgrid;
     pa.tile_batch = n_tiles >= 64LL * pgrid ? 8 : (n_tiles >= 16LL * pgrid ? 2 : 1);
+    // lane-serial rows: variant 4, or RAFT_LANE_SERIAL=1 for every fast configuration of the process (A/B, test sweeps); they
+    // take slots outside the tile for not-high, which a threshold below 1 would not give them
+    const bool ls_rows = (c->variant == 4 || getenv("RAFT_LANE_SERIAL") != nullptr) && c->high_cov >= 1;
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
     if (pv.fast) {
         const TileCut *cuts = c->tile_cuts.as<TileCut>();
@@ -798,12 +808,12 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         // running BESIDE the regular ones from the start than behind them.)
         {
             HIP_TRY(c, hipEventRecord(c->ev_fork, st));
-            launch_fast_variant<0>(c->variant, ow, st, pgrid, pa.n_seg, cuts, pa);
+            launch_fast_variant<0>(c->variant, ow, ls_rows, st, pgrid, pa.n_seg, cuts, pa);
             HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
             if (recut) {
                 // the tiles that did not fit as they are, re-cut by tile_desc_kernel: the same kernel, its other instantiation
                 ps.slow_list = nullptr; ps.tile_counter = &ctrl->slow_next; ps.n_extra = &ctrl->n_extra; ps.tile_batch = 1;
-                launch_fast_variant<1>(c->variant, ow, c->side_stream, pgrid, pa.n_seg, cuts, ps);
+                launch_fast_variant<1>(c->variant, ow, ls_rows, c->side_stream, pgrid, pa.n_seg, cuts, ps);
             } else launch_general<6144, 5>(c->side_stream, sgrid, ps);
             HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
             HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));

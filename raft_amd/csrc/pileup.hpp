@@ -254,7 +254,14 @@ template <class Smem>
 __device__ __forceinline__ void emit_run(const PileupArgs &a, Smem &sm, int nr, int sS, int sT)
 {
     if ((long long)(sT - sS) * a.reso < (long long)a.repeat_length) return;
-    emit_run_of(a, sm, owner_slot(sm, nr, sS), sS, sT);
+    // (a run handed over in the concatenated windows may span a read boundary -- pileup_fast.hpp LS: it is one run per read,
+    // repeat.hpp:111-112, each judged by its own length)
+    int j = owner_slot(sm, nr, sS);
+    while (sS < sT) {
+        const int e = min(sT, sm.roff[j + 1]);
+        if (e > sS) emit_run_of(a, sm, j, sS, e);
+        sS = max(sS, e); ++j;
+    }
 }
 
 // lower bound of read id `r` in iv_rid[lo, hi); per-lane and wave-uniform forms

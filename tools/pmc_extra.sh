@@ -19,7 +19,7 @@ for name in "abc":
             kn = r["Kernel_Name"]
             if "pileup_fast" in kn:
                 targs = kn.split("<", 1)[1].split(">", 1)[0].split(",")
-                tag = "extra" if len(targs) > 5 and targs[5].strip() == "true" else "regular"
+                tag = "extra" if len(targs) > 5 and targs[5].strip() in ("true", "1") else "regular"
                 agg[(tag, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for k, v in sorted(agg.items()):
         print(f"{name} {k[0]:8s} {k[1]:28s} n={len(v)} mean={sum(v)/len(v):.4g}")
