@@ -310,6 +310,9 @@ struct FinalizeCountLoader {
     }
 };
 
+// (Measured and dropped, round 3: a long read's raw runs ordered and joined by its whole wave -- a lane per run, rank by 64
+// compare steps, joined through ballots -- instead of its thread's loops in global memory.  The long reads of a wave then
+// take their turns, where the threads' loops had run side by side: finalize_count 0.11 -> 0.21 ms on the ultralong set.)
 __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
