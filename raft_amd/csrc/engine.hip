@@ -1616,7 +1616,7 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
     if (!ctxs || n_ctx < 1 || !ctxs[0] || !o) return RAFT_HIP_ERR_PARAM;
     raft_hip_ctx *c = ctxs[0];
     const bool grouped = rec_offset != nullptr;
-    if (grouped && (n_runs < 1 || n_runs > kMaxSeg || ctxs[0]->prm.symmetric_mode != 1)) return RAFT_HIP_ERR_PARAM;
+    if (grouped && (n_runs < 1 || n_runs > kMaxRuns || ctxs[0]->prm.symmetric_mode != 1)) return RAFT_HIP_ERR_PARAM;
     const long long ostride = (long long)n_reads + 1;
     auto off_at = [&](int g, long long r) -> long long { return rec_offset[(long long)g * ostride + r]; };
     for (int d = 1; d < n_ctx; ++d) {
@@ -1629,6 +1629,8 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
     if (!o->cov_offset || !o->rep_offset || !o->frag_offset) return RAFT_HIP_ERR_PARAM;
     o->n_exc = 0;
     auto one_piece = [&]() { return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary, n_runs, rec_offset); };
+    // (more runs than the chunk plan keeps pieces for -- a PAF concatenated from many files: one piece, merged on the device)
+    if (grouped && n_runs > kMaxSeg) return n_rec < (1LL << 29) ? one_piece() : RAFT_HIP_ERR_TOO_LARGE;
     if (o->cov_width != 0 && o->cov_width != 1 && o->cov_width != 2) return RAFT_HIP_ERR_PARAM;
     const int cov_width = o->cov_width == 2 ? 2 : 1;   // bytes per window of the coverage's transfer encoding
     long long seg[kMaxSeg + 1];

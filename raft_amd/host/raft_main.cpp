@@ -258,6 +258,12 @@ int main(int argc, char *argv[])
     if (sym && n_rec > 0 && !getenv("RAFT_NO_GROUPED")) {
         rec_off.reset(new int64_t[(size_t)4 * ((size_t)n_reads + 1)]);
         if (raft_host_group_offsets(n_reads, n_rec, raft_host_paf_column(paf, 0), 4, &n_runs, rec_off.get()) != RAFT_HOST_OK) n_runs = 0;
+        if (n_runs == 0 && devices.size() == 1 && n_rec < ((int64_t)1 << 29)) {
+            // more than four runs (a PAF concatenated from more than two pairs of files): up to sixteen are still grouped input
+            // for one device -- merged into one run on the device instead of falling to the counting sort
+            rec_off.reset(new int64_t[(size_t)16 * ((size_t)n_reads + 1)]);
+            if (raft_host_group_offsets(n_reads, n_rec, raft_host_paf_column(paf, 0), 16, &n_runs, rec_off.get()) != RAFT_HOST_OK) n_runs = 0;
+        }
     }
     stage("group_offsets");
     if (n_runs > 0) pin(rec_off.get(), (size_t)n_runs * ((size_t)n_reads + 1) * 8);

@@ -159,3 +159,24 @@ def test_cli_spreads_every_input_shape_over_the_contexts(tmp_path, name):
     line = [l for l in r.stderr.decode().splitlines() if l.startswith("TIMING devices_used")]
     assert line and line[0].split()[2] == "2", r.stderr.decode()
     assert line[0].split()[4] == ("grouped" if name == "s300_default" else "columns")
+
+
+def test_cli_many_concatenated_files(tmp_path):
+    """Six PAFs concatenated (each grouped by query): more sorted runs than the pileup kernels take.  The CLI still hands the
+    stream over in grouped form -- the engine merges the runs on the device -- and the files equal those of the same records
+    in one sorted file, which the golden case pins to the reference."""
+    import numpy as np
+    p, cols, exp, meta = load_case("s300_default")
+    names = [f"r{i}" for i in range(len(cols[0]))]
+    write_fasta(tmp_path / "reads.fa", names, cols[0])
+    n = len(cols[1])
+    # the same multiset of records as six runs: record i goes to file i % 6, every file keeps the stream's order
+    order = np.concatenate([np.arange(k, n, 6) for k in range(6)])
+    # (record 0 stays first: it decides the symmetric flag, chop.hpp:171-184)
+    write_paf(tmp_path / "overlaps.paf", names, cols[0], *[c[order] for c in cols[1:]])
+    r = subprocess.run([RAFT] + meta["args"] + ["reads.fa", "overlaps.paf"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300, env=dict(os.environ, RAFT_TIMING="1"))
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
+    assert "input grouped" in r.stderr.decode()
+    for f, digest in meta["md5"].items():
+        assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, f

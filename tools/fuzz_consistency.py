@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from raft_amd import engine
+from raft_amd import engine, hostio
 from raft_amd.params import RaftParams
 from raft_amd.synth import make_overlaps
 
@@ -46,14 +46,26 @@ while time.time() < t_end:
     # 1 = the general kernel alone (independent code path); 0 / 2 = fast kernel, tiles that do not fit re-cut for it;
     # 10 = configuration 0 with the symmetric flag handed over; 20 / 30 = configuration 0 writing the one- / two-byte
     # encoding of cov[] (decoded on the device for the comparison)
-    for variant in (1, 0, 2, 20, 30) + ((10,) if sym_set else ()):
+    # round 3: 4 = lane-serial rows; 40 / 41 / 42 = grouped input (per-read record offsets) with the query column and the
+    # window count announced / without the query column / without either, writing the one-byte encoding
+    off = None
+    if sym_set and not kw.get("shuffle"):
+        off = hostio.group_offsets(o.n_reads, o.qid.cpu().numpy(), max_runs=16)
+        if off is not None:
+            off = torch.as_tensor(off).to("cuda:0")
+            n_bins = int(((o.read_len.long() + reso - 1) // reso).sum())
+    for variant in (1, 0, 2, 4, 20, 30) + ((10,) if sym_set else ()) + ((40, 41, 42) if off is not None else ()):
         print("  variant", variant, flush=True)
-        eng = engine.Engine(RaftParams(**dict(p.__dict__, symmetric_mode=1)) if variant == 10 else p, device=0)
+        eng = engine.Engine(RaftParams(**dict(p.__dict__, symmetric_mode=1)) if variant in (10, 40, 41, 42) else p, device=0)
         eng.set_tuning(0, False, 0 if variant >= 10 else variant)
-        if variant in (20, 30):
-            eng.set_output_width(1 if variant == 20 else 2)
+        if variant in (20, 30, 42):
+            eng.set_output_width(2 if variant == 30 else 1)
         try:
-            eng.run_device(*cols); s = eng.finish()
+            if variant >= 40:
+                eng.run_device_grouped(o.read_len, off, o.qid if variant == 40 else None, o.qs, o.qe, n_bins=n_bins if variant != 42 else -1)
+                s = eng.finish()
+            else:
+                eng.run_device(*cols); s = eng.finish()
         except engine.RaftError as e:
             if e.code in (5, 8):     # out of memory / beyond the per-pass limits: not what this hunt is about
                 eng.close(); ref = "skip"; break
@@ -72,4 +84,5 @@ while time.time() < t_end:
     seed += 1
     del o, out, ref
     torch.cuda.empty_cache()
-print(f"{n_ok} random sets agree across configurations 1, 0, 2, 0 with the symmetric flag handed over and 0 writing the one- and two-byte encodings (seeds up to {seed - 1})")
+print(f"{n_ok} random sets agree across configurations 1, 0, 2, 4 (lane-serial rows), 0 with the symmetric flag handed over, 0 writing the one- and two-byte "
+      f"encodings, and the grouped entry in three forms (seeds up to {seed - 1})")
