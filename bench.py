@@ -170,6 +170,27 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
         ptimes.append(time.perf_counter() - t0)
     psum = (ps.n_bins, ps.n_repeats, ps.n_fragments, ps.total_coverage, ps.total_repeat_length)
     pcopy = {k: pres[k].copy() for k in ("cov8", "rep_s", "rep_e", "frag_begin", "frag_end", "cov_offset", "rep_offset", "frag_offset")}
+    # (a') the same with window records: one word per record goes up instead of two (raft_hip_run_multi_windows).  The
+    # packing is the tokeniser's (two divisions per record where the coordinates are parsed) and outside the clock like it.
+    wrec = None
+    if not args.no_windows_leg and p.reso <= 32767:
+        wbuf = torch.empty(o.n_rec, dtype=torch.int32, pin_memory=True).numpy().view(np.uint32)
+        t0 = time.perf_counter()
+        win = hostio.pack_windows(host[2], host[3], p.reso, out=wbuf)
+        t_pack = time.perf_counter() - t0
+        if win is not None:
+            wtimes = []
+            for it in range(n_iter + 1):
+                t0 = time.perf_counter()
+                wres, ws = eng.run_pipelined_windows(host[0], off, win, out=out)
+                wtimes.append(time.perf_counter() - t0)
+            same_w = psum == (ws.n_bins, ws.n_repeats, ws.n_fragments, ws.total_coverage, ws.total_repeat_length) and \
+                all(np.array_equal(pcopy[k], wres[k]) for k in pcopy)
+            wsec = sorted(wtimes[1:])[len(wtimes[1:]) // 2]
+            wrec = {"records_per_s": o.n_rec / wsec, "fragments_per_s": ws.n_fragments / wsec, "seconds": wsec,
+                    "h2d_bytes": host[0].nbytes + off.nbytes + win.nbytes, "equals_coordinate_columns": bool(same_w),
+                    "pack_seconds_outside_clock": t_pack,
+                    "mode": "raft_hip_run_multi_windows: 4 bytes per record cross PCIe (first window | one past the last << 16, raft_host_pack_windows)"}
     # (b) chunked, six-column input (query column uploaded, runs guessed from samples, cuts searched)
     ctimes = []
     for it in range(n_iter):
@@ -203,7 +224,7 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
     eng.close()
     med = lambda v: sorted(v)[len(v) // 2]
     steady, six, one_piece = med(ptimes[1:]), med(ctimes[1:]) if len(ctimes) > 1 else ctimes[0], med(times[1:]) if len(times) > 1 else times[0]
-    return {"records_per_s": o.n_rec / steady, "fragments_per_s": s.n_fragments / steady, "seconds": steady,
+    res = {"records_per_s": o.n_rec / steady, "fragments_per_s": s.n_fragments / steady, "seconds": steady,
             "first_pass_s": ptimes[0],
             "mode": "chunked, grouped input: H2D / pass / D2H of consecutive read ranges overlapped (raft_hip_run_multi_grouped); "
                     "no query column crosses PCIe",
@@ -215,6 +236,12 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
             "h2d_bytes": in_bytes, "d2h_bytes": out_bytes, "coverage_encoding": f"uint{8 * width} per window + (index, value) for windows >= {limit}",
             "exceptions": int(got["exc_index"].size), "symmetric_mode": "asserted by the tokeniser: query sides only",
             "decoded_coverage_equals_device": ok, "passes": n_iter}
+    if wrec is not None:
+        # the headline of this object is the form the CLI uses (window records); the coordinate-column form stays beside it
+        res["coordinate_columns"] = {k: res[k] for k in ("records_per_s", "fragments_per_s", "seconds", "mode", "h2d_bytes")}
+        res.update(records_per_s=wrec["records_per_s"], fragments_per_s=wrec["fragments_per_s"], seconds=wrec["seconds"], mode=wrec["mode"],
+                   h2d_bytes=wrec["h2d_bytes"], window_records=wrec)
+    return res
 
 
 def spawn_ranks(n: int) -> int:
@@ -250,6 +277,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-windows-leg", action="store_true", help="skip the window-record legs (device pass and host-to-host)")
     ap.add_argument("--cov-width", type=int, default=4, choices=[1, 2, 4], help="bytes per window the timed pass writes (4 = int32 cov[]; 1 / 2 = its transfer encoding)")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the extra passes that time the pass writing the transfer encoding")
     ap.add_argument("--handover", action="store_true", help="--input columns with symmetric_mode = 1: the symmetric flag is handed over")
@@ -500,44 +528,67 @@ def main():
     # ---- the pass exactly as the CLI and the host pipelines run it: grouped input WITHOUT the query column (it never crosses
     # PCIe: rebuilt from the offsets on the device), the pileup kernel writing the transfer encoding of cov[] (one byte per
     # window, two from -e 40 on, + the windows at or above the limit).  Checked against the int32 pass (outside the clock).
-    packed = None
+    packed = windows_leg = None
     if n_gpus == 1 and not args.no_packed_leg and args.cov_width == 4:
         w = 2 if p.est_cov >= 40 else 1
         shp = sh if sh.off is not None else Shard(o.read_len, o.columns(), True)
-        e3 = engine.Engine(p_sym, device=local)
-        e3.set_tuning(args.tile_bins, args.force_bucket, args.variant)
-        e3.set_output_width(w)
-        e3.use_torch_stream()
-        kt, pt, wall = [], [], []
-        for it in range(6):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            s3 = pass_of(e3, shp, qid=False)
-            torch.cuda.synchronize()
-            if it:
-                wall.append(time.perf_counter() - t1)
-                a, b = e3.timing(); kt.append(a); pt.append(b)
-        pk = e3.packed_device()
-        assert pk is not None and pk["width"] == w
         ref_cov = eng.outputs_device()["cov"]
         lim = 255 if w == 1 else 65535
-        codes = pk["cov8"] if w == 1 else pk["cov8"].to(torch.int32) & 0xFFFF
-        ok = bool((codes == ref_cov.clamp(max=lim)).all())
         big = (ref_cov >= lim).nonzero().flatten()
-        order = pk["exc_index"].argsort()
-        ok = ok and bool(torch.equal(pk["exc_index"][order], big)) and bool(torch.equal(pk["exc_value"][order], ref_cov[big]))
-        ok = ok and (s3.n_fragments, s3.n_repeats, s3.total_coverage, s3.total_repeat_length) == (s.n_fragments, s.n_repeats, s.total_coverage, s.total_repeat_length)
-        if not ok:
-            raise SystemExit("bench.py: the packed-output pass differs from the int32 pass")
-        # algorithmic bytes of this form: 8 B per record read (qs, qe; the id comes from 8 B per read and run), w per window written
-        bytes_p = 8 * s3.n_intervals + 16 * s3.n_reads * shp.off.shape[0] + w * s3.n_bins + 12 * int(pk["exc_index"].numel()) + 4 * s3.n_reads + 8 * s3.n_repeats
-        k_s, p_s, w_s = sum(kt) / len(kt), sum(pt) / len(pt), sum(wall) / len(wall)
-        packed = {"cov_width": w, "input": "grouped, no query column (ids rebuilt from the offsets on the device)", "value": my_rec / w_s, "unit": "PAF records/s",
-                  "ms_per_step": w_s * 1e3, "kernel_ms": k_s * 1e3, "pass_device_ms": p_s * 1e3, "bytes_algorithmic": bytes_p,
-                  "kernel_frac": bytes_p / k_s / 1e9 / HBM_PEAK_GBS, "pass_frac": bytes_p / p_s / 1e9 / HBM_PEAK_GBS,
-                  "n_exceptions": int(pk["exc_index"].numel()), "equals_int32_pass": ok}
-        del ref_cov, codes, big, order, pk
-        e3.close()
+
+        def encoded_pass(form):
+            d_win = None
+            if form == "windows":
+                win = hostio.pack_windows(shp.cols[1].cpu().numpy(), shp.cols[2].cpu().numpy(), p.reso)   # (the tokeniser's, outside every clock)
+                if win is None:
+                    return None
+                d_win = torch.as_tensor(win.view("int32")).to(dev)
+            e3 = engine.Engine(p_sym, device=local)
+            e3.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+            e3.set_output_width(w)
+            e3.use_torch_stream()
+            kt, pt, wall = [], [], []
+            for it in range(6):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                if d_win is None:
+                    s3 = pass_of(e3, shp, qid=False)
+                else:
+                    e3.run_device_windows(shp.read_len, shp.off, d_win, n_bins=shp.n_bins)
+                    s3 = e3.finish()
+                torch.cuda.synchronize()
+                if it:
+                    wall.append(time.perf_counter() - t1)
+                    a, b = e3.timing(); kt.append(a); pt.append(b)
+            pk = e3.packed_device()
+            assert pk is not None and pk["width"] == w
+            codes = pk["cov8"] if w == 1 else pk["cov8"].to(torch.int32) & 0xFFFF
+            ok = bool((codes == ref_cov.clamp(max=lim)).all())
+            order = pk["exc_index"].argsort()
+            ok = ok and bool(torch.equal(pk["exc_index"][order], big)) and bool(torch.equal(pk["exc_value"][order], ref_cov[big]))
+            ok = ok and (s3.n_fragments, s3.n_repeats, s3.total_coverage, s3.total_repeat_length) == (s.n_fragments, s.n_repeats, s.total_coverage, s.total_repeat_length)
+            if not ok:
+                raise SystemExit(f"bench.py: the packed-output pass ({form}) differs from the int32 pass")
+            n_runs = shp.off.shape[0]
+            if d_win is None:    # 8 B per record read (qs, qe; the id comes from 8 B per read and run, read twice: expanded, then by the cuts), w per window written
+                bytes_p = 8 * s3.n_intervals + 16 * s3.n_reads * n_runs
+                text = "grouped, no query column (ids rebuilt from the offsets on the device)"
+            else:                # 4 B per record read; 8 B per read and run (the tile's slice of the offsets)
+                bytes_p = 4 * s3.n_intervals + 8 * s3.n_reads * n_runs
+                text = "grouped, window records (one word per record: first window | one past the last << 16; raft_hip_run_device_windows)"
+            bytes_p += w * s3.n_bins + 12 * int(pk["exc_index"].numel()) + 4 * s3.n_reads + 8 * s3.n_repeats
+            k_s, p_s, w_s = sum(kt) / len(kt), sum(pt) / len(pt), sum(wall) / len(wall)
+            res = {"cov_width": w, "input": text, "value": my_rec / w_s, "unit": "PAF records/s",
+                   "ms_per_step": w_s * 1e3, "kernel_ms": k_s * 1e3, "pass_device_ms": p_s * 1e3, "bytes_algorithmic": bytes_p,
+                   "kernel_frac": bytes_p / k_s / 1e9 / HBM_PEAK_GBS, "pass_frac": bytes_p / p_s / 1e9 / HBM_PEAK_GBS,
+                   "n_exceptions": int(pk["exc_index"].numel()), "equals_int32_pass": ok}
+            del codes, order, pk, d_win
+            e3.close()
+            return res
+        packed = encoded_pass("columns")
+        if not args.no_windows_leg and args.variant < 0 and p.reso <= 32767:
+            windows_leg = encoded_pass("windows")
+        del ref_cov, big
 
     # ---- the six plain columns into a detecting context (rounds 1-2's headline form), and its inspect-first form
     six = None
@@ -617,6 +668,12 @@ def main():
                                     product_path_pass_device_ms=packed["pass_device_ms"], product_path_pass_frac=packed["pass_frac"],
                                     product_path_bytes_algorithmic=packed["bytes_algorithmic"])
             line["packed_output"] = packed
+        if windows_leg is not None:
+            # ... and with the records as the tokeniser can hand them over: one word each (the CLI's form)
+            line["roofline"].update(product_path_kernel_ms=windows_leg["kernel_ms"], product_path_frac=windows_leg["kernel_frac"],
+                                    product_path_pass_device_ms=windows_leg["pass_device_ms"], product_path_pass_frac=windows_leg["pass_frac"],
+                                    product_path_bytes_algorithmic=windows_leg["bytes_algorithmic"], product_path_input="window records")
+            line["window_records"] = windows_leg
         if six is not None:
             line["six_column"] = six
         if strong_info is not None:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_ABI_VERSION 5
+#define RAFT_HIP_ABI_VERSION 6
 
 /* error codes (0..5 are shared with oracle/raft_oracle.h) */
 enum {
@@ -173,6 +173,21 @@ int  raft_hip_run_device_grouped(raft_hip_ctx *ctx, int32_t n_reads, const int32
 int  raft_hip_run_host_grouped(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec, int32_t n_runs,
                                const int64_t *rec_offset, const int32_t *qs, const int32_t *qe, int64_t n_bins);
 
+/* Grouped input as WINDOW RECORDS: one 32-bit word per record instead of (qs, qe) --
+ *     win[i] = first | last1 << 16,   first = qs / reso,   last1 = qe > 0 ? (qe - 1) / reso + 1 : 0   (repeat.hpp:69-72: the
+ *     windows first .. last1 - 1 of the query get +1; an interval without windows is stored as 0)
+ * -- cut from the coordinates where they are tokenised (raft_host_pack_windows; possible while every window index fits 16
+ * bits, i.e. reads below 65,535 * reso bases, 3.2 Mbp at the default).  The pileup reads nothing else of a record: its read
+ * is where rec_offset says.  4 bytes per record cross PCIe and are read by the pileup kernel instead of 8 + the 4 of the
+ * rebuilt ids.  Same outputs; a record reaching past the last window of its read is RAFT_HIP_ERR_COORD with its index as
+ * before (negative coordinates cannot be expressed: raft_host_pack_windows reports them).  Requires symmetric_mode = 1 and
+ * reso <= 32767.  n_runs > 2, non-default tuning variants and the fallbacks of the pass are served by unpacking the
+ * records into coordinate columns on the device first. */
+int  raft_hip_run_device_windows(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *d_read_len, int64_t n_rec, int32_t n_runs,
+                                 const int64_t *d_rec_offset, const uint32_t *d_win, int64_t n_bins);
+int  raft_hip_run_host_windows(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec, int32_t n_runs,
+                               const int64_t *rec_offset, const uint32_t *win, int64_t n_bins);
+
 /* Waits for the pass, reads back its scalars and reports data errors found on
  * the device (RAFT_HIP_ERR_READ_ID / _COORD / _FRAGMENT). */
 int  raft_hip_finish(raft_hip_ctx *ctx, raft_hip_summary *summary);
@@ -270,6 +285,11 @@ int  raft_hip_run_multi_grouped(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_
                                 int32_t n_runs, const int64_t *rec_offset, const int32_t *qs, const int32_t *qe,
                                 int32_t n_chunks, raft_hip_host_outputs *out, raft_hip_summary *summary);
 
+/* ... over window records (see raft_hip_run_device_windows): half the upload again. */
+int  raft_hip_run_multi_windows(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                                int32_t n_runs, const int64_t *rec_offset, const uint32_t *win,
+                                int32_t n_chunks, raft_hip_host_outputs *out, raft_hip_summary *summary);
+
 /* ---- pre-split PAF: the exchange step (BASELINE.json configs[3]; SURVEY.md §8e "pre-split" mode) ----------------------
  * Every rank holds a contiguous slice of the record stream, in its grouped form (see raft_hip_run_device_grouped): per
  * sorted run of the slice -- a slice of a hifiasm PAF has at most two -- where every read of the WHOLE set begins.  Reads
@@ -287,7 +307,9 @@ int  raft_hip_run_multi_grouped(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_
  *                            `comm`: an ncclComm_t of the caller's, or one made by raft_hip_comm_create from an id that rank 0
  *                            obtained with raft_hip_comm_unique_id (128 bytes) and handed to the others by its own means.
  *                            librccl.so.1 is loaded when first used (a single-GPU run never maps it).
- *   raft_hip_exchange_local  one process, one context per rank (raft_hip_create on each device): peer copies. */
+ *   raft_hip_exchange_local  one process, one context per rank (raft_hip_create on each device): peer copies.
+ * The slices' device columns must be complete when the call is made (raft_hip_exchange: on the context's stream, or
+ * their producers synchronised; raft_hip_exchange_local: synchronised), and stay untouched until the exchange is done. */
 #define RAFT_HIP_MAX_RUNS 16
 typedef struct raft_hip_slice {
     int64_t n_rec;              /* records of this rank's slice */

@@ -30,7 +30,9 @@ enum {
     RAFT_HOST_ERR_DUP_NAME = 2,   /* two reads share a name (ids would be ambiguous, chop.hpp:108) */
     RAFT_HOST_ERR_UNKNOWN_NAME = 3,/* PAF names a read that is not in the reads file (chop.hpp:162-165 OOB) */
     RAFT_HOST_ERR_IO = 4,         /* write failed */
-    RAFT_HOST_ERR_ARG = 5
+    RAFT_HOST_ERR_ARG = 5,
+    RAFT_HOST_ERR_COORD = 6,      /* raft_host_pack_windows: a negative coordinate (the engine's RAFT_HIP_ERR_COORD) */
+    RAFT_HOST_ERR_RANGE = 7       /* raft_host_pack_windows: a window index beyond 16 bits -- stay with the coordinate columns */
 };
 
 typedef struct raft_host_reads raft_host_reads;
@@ -79,6 +81,17 @@ int            raft_host_paf_symmetric(const raft_host_paf *p);
  * rec_offset holds max_runs * (n_reads + 1) entries (page-locked when it is to be uploaded at the link's rate). */
 int raft_host_group_offsets(int32_t n_reads, int64_t n_rec, const int32_t *qid, int32_t max_runs, int32_t *n_runs,
                             int64_t *rec_offset);
+
+/* Window records for raft_hip_run_*_windows (include/raft_hip.h): win[i] = first | last1 << 16 with first = qs / reso and
+ * last1 = (qe - 1) / reso + 1 -- the windows profileCoverage adds the interval to (repeat.hpp:69-72) -- or 0 for an
+ * interval without windows (qe == 0, or last1 <= first).  The integer divisions of the pileup, done where the
+ * coordinates are tokenised; 4 bytes per record instead of 8.
+ *   RAFT_HOST_ERR_COORD  a coordinate is negative (*bad_index = the first such record): what the engine reports as
+ *                        RAFT_HIP_ERR_COORD with that index;
+ *   RAFT_HOST_ERR_RANGE  some interval ends beyond window 65,535 (*bad_index = the first such record): not expressible --
+ *                        the caller keeps the coordinate columns (raft_hip_run_*_grouped);
+ * win[] is undefined after either.  reso must be in [1, 32767]. */
+int raft_host_pack_windows(int64_t n_rec, const int32_t *qs, const int32_t *qe, int32_t reso, uint32_t *win, int64_t *bad_index);
 
 /* Coverage in the engine's transfer encoding (raft_hip_fetch_packed: one byte per window, 255 = look up the ascending
  * exception list): back to int32, and straight to coverage.txt (repeat.hpp:105-108) without the int32 detour. */

@@ -56,23 +56,30 @@ void launch_general(hipStream_t st, unsigned grid, const PileupArgs &pa)
     hipLaunchKernelGGL((pileup_kernel<256, CAP, MINW, 3, false>), dim3(grid), dim3(256), 0, st, pa);
 }
 
-template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, int EXTRA = 0, int OW = 4, bool LS = false>
+template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, int EXTRA = 0, int OW = 4, bool LS = false, int IN = 0>
 void launch_fast(hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
     constexpr int S4 = SLOTS % 4 == 0 ? SLOTS : 4;   // four sorted runs need a multiple of four slots
     const size_t dyn = 0;
     if (n_seg <= 1)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG, EXTRA, OW, LS>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG, EXTRA, OW, LS, IN>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else if (n_seg == 2)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG, EXTRA, OW, LS>), dim3(grid), dim3(256), dyn, st, cuts, pa);
-    else
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG, EXTRA, OW, LS>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG, EXTRA, OW, LS, IN>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+    else if constexpr (IN == 0)                       // (window records: one or two runs, see kWinMaxRuns)
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG, EXTRA, OW, LS, IN>), dim3(grid), dim3(256), dyn, st, cuts, pa);
 }
+constexpr int kWinMaxRuns = 2;    // runs the window-record instantiations take (their per-run tables share the LDS budget); more: unpacked first
 
 // the fast kernel's configurations by output width (pileup_fast.hpp OW; the diagnostic build writes int32 only)
 template <int EXTRA>
-void launch_fast_variant(int variant, int ow, bool ls, hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
+void launch_fast_variant(int variant, int ow, bool ls, bool win, hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
+    if (win) {                                                // window records (pileup_fast.hpp IN = 1): the default configuration only
+        if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1, false, 1>(st, grid, n_seg, cuts, pa);
+        else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2, false, 1>(st, grid, n_seg, cuts, pa);
+        else launch_fast<7936, 4, false, 6, EXTRA, 4, false, 1>(st, grid, n_seg, cuts, pa);
+        return;
+    }
     if (ls && variant != 2 && variant != kDiagVariant) {      // the lane-serial rows (pileup_fast.hpp LS)
         if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1, true>(st, grid, n_seg, cuts, pa);
         else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2, true>(st, grid, n_seg, cuts, pa);
@@ -249,11 +256,13 @@ struct raft_hip_ctx {
     struct PassArgs {
         int32_t n_reads; const int32_t *len; int64_t n_rec; const int32_t *col[6];
         int32_t n_runs; const long long *rec_off; long long adj[kMaxSeg]; long long hint_bins;
+        const uint32_t *win;           // window records instead of col[1..2] (raft_hip_run_device_windows); grouped only
     } args{};
     bool grouped = false;              // the last pass was built on the caller's offsets (verified in its kernels)
     bool no_wait = false;              // ... and sized by the caller's window count: nothing was read back on the way
     DevBuf exp_qid, in_off;            // grouped input without a query column: the ids rebuilt from the offsets; staged offsets
     DevBuf m_off;                      // grouped input of more than kMaxSeg runs: offsets of the merged run
+    DevBuf u_s, u_e;                   // window records unpacked for the passes that need coordinate columns
     DevBuf x_qs, x_qe, x_off, x_raw, x_send_off, x_cnt;   // pre-split exchange (raft_hip_exchange*): what this rank received / staged
 
     // state of the last pass
@@ -387,7 +396,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -468,24 +477,42 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     const int32_t *d_len = in.len, *d_qid = in.col[0], *d_qs = in.col[1], *d_qe = in.col[2], *d_tid = in.col[3], *d_ts = in.col[4],
                   *d_te = in.col[5];
     const bool grouped = in.rec_off != nullptr;
+    const uint32_t *d_win = in.win;
     if (n_reads < 0 || n_rec < 0) return RAFT_HIP_ERR_PARAM;
     if (n_reads > 0 && !d_len) return RAFT_HIP_ERR_PARAM;
     if (grouped && (in.n_runs < 1 || in.n_runs > kMaxRuns || c->prm.symmetric_mode != 1)) return RAFT_HIP_ERR_PARAM;
+    if (d_win && (!grouped || c->prm.reso > 32767)) return RAFT_HIP_ERR_PARAM;   // (65535 windows * reso stays inside int32 where they are unpacked)
     // more runs than the pileup kernels take: merged into one on the device first (bucket.hpp merge_runs_kernel)
     const bool merge = grouped && in.n_runs > kMaxSeg && n_rec > 0;
     const int32_t eff_runs = grouped ? (in.n_runs > kMaxSeg ? 1 : in.n_runs) : 0;
-    if (n_rec > 0 && ((!d_qid && !grouped) || !d_qs || !d_qe)) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && ((!d_qid && !grouped) || ((!d_qs || !d_qe) && !d_win))) return RAFT_HIP_ERR_PARAM;
     if (n_reads == INT32_MAX) return RAFT_HIP_ERR_TOO_LARGE;
     if (n_rec >= (1LL << 29)) return RAFT_HIP_ERR_TOO_LARGE;   // interval byte offsets are 32-bit (2 sides per record at most)
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     bool expand = false;
+    const PileVariant &pv = kVariants[c->variant];
+    // tiles that do not fit the fast kernel are re-cut for it (pileup.hpp tile_desc_kernel) unless told otherwise
+    const bool recut = pv.fast && !c->no_recut && getenv("RAFT_NO_RECUT") == nullptr;
+    // lane-serial rows: variant 4, or RAFT_LANE_SERIAL=1 for every fast configuration of the process (A/B, test sweeps); they
+    // take slots outside the tile for not-high, which a threshold below 1 would not give them
+    const bool ls_rows = (c->variant == 4 || getenv("RAFT_LANE_SERIAL") != nullptr) && c->high_cov >= 1;
+    // window records go to the fast kernel's own instantiation (pileup_fast.hpp IN = 1) where every tile is the fast kernel's
+    // in its default configuration and the runs are few; anything else gets coordinate columns that fall into the same
+    // windows (bucket.hpp unpack_windows_kernel) and takes the paths those have
+    const bool lean = d_win && n_rec > 0 && !merge && eff_runs <= kWinMaxRuns && recut && c->variant == kDefaultVariant && !ls_rows &&
+                      !c->force_bucket && getenv("RAFT_NO_WINDOW_KERNEL") == nullptr;
+    if (d_win && !lean && n_rec > 0) {
+        HIP_TRY(c, c->u_s.ensure((size_t)n_rec * 4));
+        HIP_TRY(c, c->u_e.ensure((size_t)n_rec * 4));
+        d_qs = c->u_s.as<int32_t>(); d_qe = c->u_e.as<int32_t>();
+    }
     if (merge) {
         HIP_TRY(c, c->b_rid.ensure((size_t)n_rec * 4));
         HIP_TRY(c, c->b_s.ensure((size_t)n_rec * 4));
         HIP_TRY(c, c->b_e.ensure((size_t)n_rec * 4));
         HIP_TRY(c, c->m_off.ensure((size_t)(n_reads + 1LL) * 8));
-    } else if (n_rec > 0 && grouped && !d_qid) {               // no query column: the ids are rebuilt from the offsets
+    } else if (n_rec > 0 && grouped && !d_qid && !lean) {      // no query column: the ids are rebuilt from the offsets
         HIP_TRY(c, c->exp_qid.ensure((size_t)n_rec * 4));
         d_qid = c->exp_qid.as<int32_t>();
         expand = true;
@@ -508,9 +535,6 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     c->sum.n_reads = n_reads; c->sum.n_records = n_rec; c->sum.high_cov = c->high_cov; c->sum.error_index = -1;
     const long long N = n_reads;
 
-    const PileVariant &pv = kVariants[c->variant];
-    // tiles that do not fit the fast kernel are re-cut for it (pileup.hpp tile_desc_kernel) unless told otherwise
-    const bool recut = pv.fast && !c->no_recut && getenv("RAFT_NO_RECUT") == nullptr;
     // the encoding of cov[] is written directly when every tile goes through the fast kernel (pileup_fast.hpp OW); a pass
     // the general kernel takes part in writes int32 and raft_hip_fetch_packed_w encodes it afterwards, as it always did
     const int ow = (c->out_width != 4 && recut && c->variant != kDiagVariant) ? c->out_width : 4;
@@ -521,6 +545,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     HIP_TRY(c, c->ctrl.ensure(sizeof(Ctrl)));
     Ctrl *ctrl = c->ctrl.as<Ctrl>();
     hipLaunchKernelGGL(clear_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl);      // (three fill commands before: ~5 us each on the device)
+    if (d_win && !lean && n_rec > 0)
+        hipLaunchKernelGGL(unpack_windows_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>((n_rec + 255) / 256, 256 * 16))), dim3(256), 0, st,
+                           (long long)n_rec, d_win, c->prm.reso, c->u_s.as<int32_t>(), c->u_e.as<int32_t>());
     const long long *eff_off = in.rec_off;
     if (merge) {
         const long long stride = (long long)n_reads + 1;
@@ -728,6 +755,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     } else if (grouped) {
         sb.n_seg = eff_runs;                          // (where the runs begin is in the offsets, on the device)
         pa.iv_rid = d_qid; pa.iv_s = d_qs; pa.iv_e = d_qe; pa.n_seg = sb.n_seg;
+        pa.iv_w = lean ? d_win : nullptr; pa.grp = grp;
         c->sum.interval_path = 0; c->sum.n_segments = in.n_runs; c->sum.n_intervals = n_rec;   // (more than kMaxSeg runs: merged into one first)
     } else if (fast) {
         std::sort(desc, desc + n_desc);
@@ -788,9 +816,6 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     const unsigned pgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * bpc));
     unsigned n_sum_blocks = pgrid;
     pa.tile_batch = n_tiles >= 64LL * pgrid ? 8 : (n_tiles >= 16LL * pgrid ? 2 : 1);
-    // lane-serial rows: variant 4, or RAFT_LANE_SERIAL=1 for every fast configuration of the process (A/B, test sweeps); they
-    // take slots outside the tile for not-high, which a threshold below 1 would not give them
-    const bool ls_rows = (c->variant == 4 || getenv("RAFT_LANE_SERIAL") != nullptr) && c->high_cov >= 1;
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
     if (pv.fast) {
         const TileCut *cuts = c->tile_cuts.as<TileCut>();
@@ -808,12 +833,12 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         // running BESIDE the regular ones from the start than behind them.)
         {
             HIP_TRY(c, hipEventRecord(c->ev_fork, st));
-            launch_fast_variant<0>(c->variant, ow, ls_rows, st, pgrid, pa.n_seg, cuts, pa);
+            launch_fast_variant<0>(c->variant, ow, ls_rows, lean, st, pgrid, pa.n_seg, cuts, pa);
             HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
             if (recut) {
                 // the tiles that did not fit as they are, re-cut by tile_desc_kernel: the same kernel, its other instantiation
                 ps.slow_list = nullptr; ps.tile_counter = &ctrl->slow_next; ps.n_extra = &ctrl->n_extra; ps.tile_batch = 1;
-                launch_fast_variant<1>(c->variant, ow, ls_rows, c->side_stream, pgrid, pa.n_seg, cuts, ps);
+                launch_fast_variant<1>(c->variant, ow, ls_rows, lean, c->side_stream, pgrid, pa.n_seg, cuts, ps);
             } else launch_general<6144, 5>(c->side_stream, sgrid, ps);
             HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
             HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
@@ -883,14 +908,15 @@ int raft_hip_run_device(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, 
 }
 
 static int run_grouped(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int64_t n_rec, int32_t n_runs, const int64_t *d_rec_offset,
-                       const long long *adj, const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe, int64_t n_bins)
+                       const long long *adj, const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe, int64_t n_bins,
+                       const uint32_t *d_win = nullptr)
 {
     if (!c || !d_rec_offset) return RAFT_HIP_ERR_PARAM;
     if (c->force_bucket && d_qid && c->prm.symmetric_mode == 1)          // (tests, A/B: the counting-sort path needs no offsets)
         return raft_hip_run_device(c, n_reads, d_len, n_rec, d_qid, d_qs, d_qe, nullptr, nullptr, nullptr);
     raft_hip_ctx::PassArgs in{};
     in.n_reads = n_reads; in.len = d_len; in.n_rec = n_rec;
-    in.col[0] = d_qid; in.col[1] = d_qs; in.col[2] = d_qe;
+    in.col[0] = d_qid; in.col[1] = d_qs; in.col[2] = d_qe; in.win = d_win;
     in.n_runs = n_runs; in.rec_off = reinterpret_cast<const long long *>(d_rec_offset);
     for (int s = 0; s < kMaxSeg; ++s) in.adj[s] = adj ? adj[s] : 0;
     in.hint_bins = n_bins >= 0 ? n_bins : -1;
@@ -902,6 +928,14 @@ int raft_hip_run_device_grouped(raft_hip_ctx *c, int32_t n_reads, const int32_t 
                                 int64_t n_bins)
 {
     return run_grouped(c, n_reads, d_len, n_rec, n_runs, d_rec_offset, nullptr, d_qid, d_qs, d_qe, n_bins);
+}
+
+int raft_hip_run_device_windows(raft_hip_ctx *c, int32_t n_reads, const int32_t *d_len, int64_t n_rec, int32_t n_runs,
+                                const int64_t *d_rec_offset, const uint32_t *d_win, int64_t n_bins)
+{
+    if (n_rec > 0 && !d_win) return RAFT_HIP_ERR_PARAM;
+    static const uint32_t none = 0;                       // (no records: the column is never read, but says which form this is)
+    return run_grouped(c, n_reads, d_len, n_rec, n_runs, d_rec_offset, nullptr, nullptr, nullptr, nullptr, n_bins, d_win ? d_win : &none);
 }
 
 int raft_hip_run_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
@@ -1278,13 +1312,13 @@ static long long count_windows(const int32_t *len, long long n, int32_t reso_i)
     return any_neg < 0 ? -1 : w;
 }
 
-int raft_hip_run_host_grouped(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, int32_t n_runs,
-                              const int64_t *rec_offset, const int32_t *qs, const int32_t *qe, int64_t n_bins)
+static int run_host_grouped_impl(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, int32_t n_runs,
+                                 const int64_t *rec_offset, const int32_t *qs, const int32_t *qe, const uint32_t *win, int64_t n_bins)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
     if (n_reads < 0 || n_rec < 0 || n_runs < 1 || n_runs > kMaxRuns || !rec_offset) return RAFT_HIP_ERR_PARAM;
     if (n_reads > 0 && !read_len) return RAFT_HIP_ERR_PARAM;
-    if (n_rec > 0 && (!qs || !qe)) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && (!qs || !qe) && !win) return RAFT_HIP_ERR_PARAM;
     if (c->prm.symmetric_mode != 1) return RAFT_HIP_ERR_PARAM;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
@@ -1293,24 +1327,41 @@ int raft_hip_run_host_grouped(raft_hip_ctx *c, int32_t n_reads, const int32_t *r
     HIP_TRY(c, c->in_off.ensure(n_off * 8));
     if (n_reads) HIP_TRY(c, hipMemcpyAsync(c->in_len.p, read_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->in_off.p, rec_offset, n_off * 8, hipMemcpyHostToDevice, st));
-    const int32_t *src[3] = {nullptr, qs, qe};
-    for (int k = 1; k < 3; ++k) {
+    const void *src[3] = {nullptr, win ? (const void *)win : (const void *)qs, qe};
+    for (int k = 1; k < (win ? 2 : 3); ++k) {
         HIP_TRY(c, c->in_col[k].ensure((size_t)std::max<long long>(n_rec, 1) * 4));
         if (n_rec) HIP_TRY(c, hipMemcpyAsync(c->in_col[k].p, src[k], (size_t)n_rec * 4, hipMemcpyHostToDevice, st));
     }
     if (n_bins < 0) n_bins = count_windows(read_len, n_reads, c->prm.reso);      // (while the copies run)
+    if (win)
+        return run_grouped(c, n_reads, c->in_len.as<int32_t>(), n_rec, n_runs, c->in_off.as<int64_t>(), nullptr, nullptr, nullptr, nullptr, n_bins,
+                           c->in_col[1].as<uint32_t>());
     return run_grouped(c, n_reads, c->in_len.as<int32_t>(), n_rec, n_runs, c->in_off.as<int64_t>(), nullptr, nullptr,
                        c->in_col[1].as<int32_t>(), c->in_col[2].as<int32_t>(), n_bins);
+}
+
+int raft_hip_run_host_grouped(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, int32_t n_runs,
+                              const int64_t *rec_offset, const int32_t *qs, const int32_t *qe, int64_t n_bins)
+{
+    return run_host_grouped_impl(c, n_reads, read_len, n_rec, n_runs, rec_offset, qs, qe, nullptr, n_bins);
+}
+
+int raft_hip_run_host_windows(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, int32_t n_runs,
+                              const int64_t *rec_offset, const uint32_t *win, int64_t n_bins)
+{
+    if (n_rec > 0 && !win) return RAFT_HIP_ERR_PARAM;
+    static const uint32_t none = 0;
+    return run_host_grouped_impl(c, n_reads, read_len, n_rec, n_runs, rec_offset, nullptr, nullptr, win ? win : &none, n_bins);
 }
 
 static int run_monolithic_to_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, const int32_t *qid,
                                   const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts, const int32_t *te,
                                   raft_hip_host_outputs *o, raft_hip_summary *summary, int32_t n_runs = 0,
-                                  const int64_t *rec_offset = nullptr)
+                                  const int64_t *rec_offset = nullptr, const uint32_t *win = nullptr)
 {
     const int keep_width = c->out_width;
     c->out_width = o->cov_width == 2 ? 2 : 1;             // the pass writes the encoding the caller takes
-    int rc = rec_offset ? raft_hip_run_host_grouped(c, n_reads, read_len, n_rec, n_runs, rec_offset, qs, qe, -1)
+    int rc = rec_offset ? run_host_grouped_impl(c, n_reads, read_len, n_rec, n_runs, rec_offset, qs, qe, win, -1)
                         : raft_hip_run_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te);
     raft_hip_summary s{};
     if (rc == RAFT_HIP_OK) rc = raft_hip_finish(c, &s);
@@ -1493,7 +1544,10 @@ static int run_routed(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads,
     for (int d = 0; d < n_job; ++d) {
         keep[(size_t)d] = ctxs[d]->prm;
         const int rc0 = raft_hip_set_params(ctxs[d], &prm1);
-        if (rc0 != RAFT_HIP_OK) return rc0;
+        if (rc0 != RAFT_HIP_OK) {
+            for (int e = 0; e < d; ++e) (void)raft_hip_set_params(ctxs[e], &keep[(size_t)e]);
+            return rc0;
+        }
         ctxs[d]->tile_q = c->tile_q; ctxs[d]->variant = c->variant;
     }
     // ---- chunk k runs on context k % n_job; a ticket chain publishes the sizes in chunk order
@@ -1611,11 +1665,12 @@ static int run_routed(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads,
 static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
                           const int32_t *qid, const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts,
                           const int32_t *te, int32_t n_runs, const int64_t *rec_offset, int32_t n_chunks, raft_hip_host_outputs *o,
-                          raft_hip_summary *summary)
+                          raft_hip_summary *summary, const uint32_t *win = nullptr)
 {
     if (!ctxs || n_ctx < 1 || !ctxs[0] || !o) return RAFT_HIP_ERR_PARAM;
     raft_hip_ctx *c = ctxs[0];
     const bool grouped = rec_offset != nullptr;
+    if (win && (!grouped || c->prm.reso > 32767)) return RAFT_HIP_ERR_PARAM;
     if (grouped && (n_runs < 1 || n_runs > kMaxRuns || ctxs[0]->prm.symmetric_mode != 1)) return RAFT_HIP_ERR_PARAM;
     const long long ostride = (long long)n_reads + 1;
     auto off_at = [&](int g, long long r) -> long long { return rec_offset[(long long)g * ostride + r]; };
@@ -1625,10 +1680,10 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
     }
     if (n_reads < 0 || n_rec < 0 || n_chunks < 0) return RAFT_HIP_ERR_PARAM;
     if (n_reads > 0 && !read_len) return RAFT_HIP_ERR_PARAM;
-    if (n_rec > 0 && ((!qid && !grouped) || !qs || !qe)) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && ((!qid && !grouped) || ((!qs || !qe) && !win))) return RAFT_HIP_ERR_PARAM;
     if (!o->cov_offset || !o->rep_offset || !o->frag_offset) return RAFT_HIP_ERR_PARAM;
     o->n_exc = 0;
-    auto one_piece = [&]() { return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary, n_runs, rec_offset); };
+    auto one_piece = [&]() { return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary, n_runs, rec_offset, win); };
     // (more runs than the chunk plan keeps pieces for -- a PAF concatenated from many files: one piece, merged on the device)
     if (grouped && n_runs > kMaxSeg) return n_rec < (1LL << 29) ? one_piece() : RAFT_HIP_ERR_TOO_LARGE;
     if (o->cov_width != 0 && o->cov_width != 1 && o->cov_width != 2) return RAFT_HIP_ERR_PARAM;
@@ -1797,7 +1852,8 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             hipStream_t st = l->stream;
             // -- upload, in chunk order on the one upload stream (the link is the bottleneck: first come, first served)
             LANE_TRY(l->in_len.ensure((size_t)std::max(nr, 1) * 4));
-            for (int col = grouped ? 1 : 0; col < 3; ++col) LANE_TRY(l->in_col[col].ensure((size_t)std::max<long long>(cp.n_rec, 1) * 4));
+            const int col_end = win ? 2 : 3;         // (window records: one column)
+            for (int col = grouped ? 1 : 0; col < col_end; ++col) LANE_TRY(l->in_col[col].ensure((size_t)std::max<long long>(cp.n_rec, 1) * 4));
             if (grouped) LANE_TRY(l->in_off.ensure((size_t)n_seg * ((size_t)nr + 1) * 8));
             {
                 std::unique_lock<std::mutex> g(sh.mu);
@@ -1806,12 +1862,12 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             }
             {
                 hipError_t e = hipMemcpyAsync(l->in_len.p, read_len + cp.r0, (size_t)nr * 4, hipMemcpyHostToDevice, jc->up_stream);
-                const int32_t *src[3] = {qid, qs, qe};
+                const int32_t *src[3] = {qid, win ? reinterpret_cast<const int32_t *>(win) : qs, qe};
                 // (grouped: a slice of every run's offsets instead of the query column -- 8 bytes per read and run, not 4 per record)
                 for (int g = 0; grouped && g < n_seg && e == hipSuccess; ++g)
                     e = hipMemcpyAsync(l->in_off.as<long long>() + (long long)g * (nr + 1), rec_offset + (long long)g * ostride + cp.r0,
                                        (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, jc->up_stream);
-                for (int col = grouped ? 1 : 0; col < 3 && e == hipSuccess; ++col) {
+                for (int col = grouped ? 1 : 0; col < col_end && e == hipSuccess; ++col) {
                     long long at = 0;
                     for (int g = 0; g < n_seg && e == hipSuccess; ++g) {
                         const long long n = cp.piece[g].hi - cp.piece[g].lo;
@@ -1847,8 +1903,11 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
                     // stream and is moved by adj[g] to where the piece went
                     long long adj[kMaxSeg] = {0, 0, 0, 0}, at = 0;
                     for (int g = 0; g < n_seg; ++g) { adj[g] = at - cp.piece[g].lo; at += cp.piece[g].hi - cp.piece[g].lo; }
-                    rc = run_grouped(l, nr, l->in_len.as<int32_t>(), cp.n_rec, n_seg, l->in_off.as<int64_t>(), adj, nullptr,
-                                     l->in_col[1].as<int32_t>(), l->in_col[2].as<int32_t>(), count_windows(read_len + cp.r0, nr, c->prm.reso));
+                    const long long hint = count_windows(read_len + cp.r0, nr, c->prm.reso);
+                    if (win) rc = run_grouped(l, nr, l->in_len.as<int32_t>(), cp.n_rec, n_seg, l->in_off.as<int64_t>(), adj, nullptr, nullptr, nullptr, hint,
+                                              l->in_col[1].as<uint32_t>());
+                    else rc = run_grouped(l, nr, l->in_len.as<int32_t>(), cp.n_rec, n_seg, l->in_off.as<int64_t>(), adj, nullptr,
+                                          l->in_col[1].as<int32_t>(), l->in_col[2].as<int32_t>(), hint);
                 } else
                     rc = raft_hip_run_device(l, nr, l->in_len.as<int32_t>(), cp.n_rec, l->in_col[0].as<int32_t>(),
                                              l->in_col[1].as<int32_t>(), l->in_col[2].as<int32_t>(), nullptr, nullptr, nullptr);
@@ -2115,6 +2174,16 @@ int raft_hip_run_multi_grouped(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t
     if (!rec_offset) return RAFT_HIP_ERR_PARAM;
     return run_multi_impl(ctxs, n_ctx, n_reads, read_len, n_rec, nullptr, qs, qe, nullptr, nullptr, nullptr, n_runs, rec_offset, n_chunks, o,
                           summary);
+}
+
+int raft_hip_run_multi_windows(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                               int32_t n_runs, const int64_t *rec_offset, const uint32_t *win, int32_t n_chunks,
+                               raft_hip_host_outputs *o, raft_hip_summary *summary)
+{
+    if (!rec_offset || (n_rec > 0 && !win)) return RAFT_HIP_ERR_PARAM;
+    static const uint32_t none = 0;
+    return run_multi_impl(ctxs, n_ctx, n_reads, read_len, n_rec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n_runs, rec_offset, n_chunks, o,
+                          summary, win ? win : &none);
 }
 
 int raft_hip_run_pipelined(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, int64_t n_rec, const int32_t *qid,

@@ -94,6 +94,10 @@ static_assert(sizeof(TileDesc) == 72, "descriptor is fetched as 18 dwords, one p
 struct PileupArgs {
     // intervals: sorted by read id inside each of n_seg segments
     const int32_t *iv_rid, *iv_s, *iv_e;
+    // ... or "window records" (pileup_fast.hpp IN = 1): one word per record, first window | one past the last << 16, no read
+    // ids -- the reads' records are where the caller's offsets (grp) say
+    const uint32_t *iv_w;
+    GroupedOff grp;
     int32_t n_seg;
     // tiles and reads
     const TileDesc *td;

@@ -31,6 +31,7 @@ struct FastRegs {
 };
 struct FastReadRegs {           // per read of a tile (thread j <-> read r_a + j, j <= nr)
     int cv, rr, rl;             // low dwords of cov_off / rep_res_off, read length
+    int so[kMaxSeg];            // IN = 1: the read's first record in each run, relative to the tile's first (GroupedOff)
 };
 
 struct FastTile {               // scalars of one tile
@@ -42,7 +43,7 @@ struct FastTile {               // scalars of one tile
 
 constexpr int kFastMaxReads = 86;    // reads per fast tile (their tables live in LDS, double-buffered)
 
-template <int CAP>
+template <int CAP, int NSO = 0>
 struct FastSmem {
     static constexpr int NW = 4;
     static constexpr int SLOTS = CAP + 256;  // window slots: 3 alignment + CAP + 1 sentinel, rounded to rows
@@ -53,6 +54,7 @@ struct FastSmem {
     int32_t rlen[2][TAB];
     int32_t rcnt[2][TAB];                    // raw repeats emitted for the read
     int32_t rres[2][TAB];                    // its first reserved raw-repeat slot (rep_res_off, < 2^31 checked by the host)
+    int32_t soff[2][NSO > 0 ? NSO : 1][NSO > 0 ? TAB : 2];   // IN = 1: first record of read r_a+j in run s, relative to the tile's first
     unsigned long long acc_cov, acc_rep;
     __attribute__((aligned(16))) int32_t wsum[NW];
     int32_t next_tile;                       // tile index wave 0 drew for the workgroup (dynamic tile hand-out)
@@ -96,7 +98,7 @@ __device__ __forceinline__ T at(const T *base, unsigned byte_off)
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-template <int NSEG, int U>
+template <int NSEG, int U, int IN>
 __device__ __forceinline__ void fast_issue(const PileupArgs &a, unsigned tid, const FastTile &t, const int (&lo)[NSEG],
                                            const int (&n)[NSEG], FastRegs<U> &g, FastReadRegs &rd)
 {
@@ -106,6 +108,13 @@ __device__ __forceinline__ void fast_issue(const PileupArgs &a, unsigned tid, co
     if ((int)tid <= t.nr) {
         rd.cv = at(reinterpret_cast<const int32_t *>(a.cov_off + t.r_a), b8);
         rd.rr = at(reinterpret_cast<const int32_t *>(a.rep_res_off + t.r_a), b8);
+        if (IN == 1) {
+            // where the read's records begin in each run, counted from the tile's first record there: low dwords suffice
+            // (record indices of a pass stay below 2^31, and 32-bit wrap-around keeps the difference exact)
+#pragma unroll
+            for (int s = 0; s < NSEG; ++s)
+                rd.so[s] = at(reinterpret_cast<const int32_t *>(a.grp.off + s * a.grp.stride + t.r_a), b8) + (int)a.grp.adj[s] - lo[s];
+        }
     }
     if ((int)tid < t.nr) rd.rl = at(a.read_len + t.r_a, b4);
     // (Measured and dropped, round 3: segment s taken by the threads rotated by s waves, so that not always wave 0 gets the
@@ -113,12 +122,17 @@ __device__ __forceinline__ void fast_issue(const PileupArgs &a, unsigned tid, co
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int s = u % NSEG, first = (u / NSEG) * 256;
-        g.rid[u] = t.r_a; g.st[u] = 0; g.en[u] = 0;   // an empty slot is an empty interval of the tile's first read: no effect
-        if ((int)tid < n[s] - first) {
-            const long long base = (long long)lo[s] + first;
-            g.rid[u] = at(a.iv_rid + base, b4);
-            g.st[u] = at(a.iv_s + base, b4);
-            g.en[u] = at(a.iv_e + base, b4);
+        if (IN == 1) {
+            g.st[u] = 0;                                  // an empty slot is an empty interval (windows [0, 0))
+            if ((int)tid < n[s] - first) g.st[u] = (int)at(a.iv_w + ((long long)lo[s] + first), b4);
+        } else {
+            g.rid[u] = t.r_a; g.st[u] = 0; g.en[u] = 0;   // an empty slot is an empty interval of the tile's first read: no effect
+            if ((int)tid < n[s] - first) {
+                const long long base = (long long)lo[s] + first;
+                g.rid[u] = at(a.iv_rid + base, b4);
+                g.st[u] = at(a.iv_s + base, b4);
+                g.en[u] = at(a.iv_e + base, b4);
+            }
         }
     }
 }
@@ -159,12 +173,19 @@ __device__ __forceinline__ void note_exception(const PileupArgs &a, long long wi
 // vector work only where a run starts or ends; the values go back to LDS and are read row-wise for the coalesced 1 KiB
 // stores.  The ablations showed the rows bound by their dependent chain -- LDS read, six DPP steps,
 // carry through a scalar register, 27 times per tile -- not by their instruction count; this removes the chain.
-template <int CAP, int NSEG, int U, bool DIAG, bool EXTRA, int OW, bool LS>
-__device__ __forceinline__ void fast_tile_loop(FastSmem<CAP> &sm, const TileCut *__restrict__ cuts, const PileupArgs &a)
+//
+// IN = 1 ("window records", round 3): a record is ONE 32-bit word -- its first window and one past its last, 16 bits each,
+// cut from the coordinates by the tokeniser (raft_host_pack_windows) -- and carries no read id: the caller's offsets say
+// where each read's records begin (GroupedOff), the tile's slice of them sits in LDS beside the other per-read tables, and
+// a wave finds the reads of its 64 consecutive records with two ballots and a short loop over the boundaries between.
+// 4 bytes per record cross the link and are read by this kernel instead of 12.
+template <int CAP, int NSEG, int U, bool DIAG, bool EXTRA, int OW, bool LS, int IN>
+__device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm, const TileCut *__restrict__ cuts, const PileupArgs &a)
 {
     constexpr int THREADS = 256, NW = 4, ITER = U / NSEG;
     static_assert(U % NSEG == 0 && ITER >= 1, "slots are split evenly over the segments");
-    using Smem = FastSmem<CAP>;
+    static_assert(!(IN == 1 && LS), "window records come with the row-wise scan only");
+    using Smem = FastSmem<CAP, IN ? NSEG : 0>;
     const unsigned tid = threadIdx.x;
     const int lane = (int)(tid & 63u);
     const int wid = uni((int)(tid >> 6));
@@ -195,6 +216,10 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP> &sm, const TileCut 
         if ((int)tid <= t.nr) {
             sm.roff[set][tid] = rd.cv - (int)(t.g_lo & ~3LL);       // 32-bit wrap-around is exact
             sm.rlen[set][tid] = rd.rl; sm.rres[set][tid] = rd.rr; sm.rcnt[set][tid] = 0;
+            if (IN == 1) {
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) sm.soff[set][s][tid] = rd.so[s];
+            }
         }
     };
     // repeat counts of a finished tile (rep_cnt[] was zeroed by the host)
@@ -251,7 +276,7 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP> &sm, const TileCut 
         cut_unpack<NSEG, ITER>(cut_word(cut_of(k)), cur, lo, n);
         if (cur.fast) {
             FastReadRegs rd;
-            fast_issue<NSEG, U>(a, tid, cur, lo, n, g, rd);
+            fast_issue<NSEG, U, IN>(a, tid, cur, lo, n, g, rd);
             wait_all_loads();
             stage_reads(0, cur, rd);
         }
@@ -273,7 +298,7 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP> &sm, const TileCut 
             raw_nn = cut_word(cut_of(min(knn, last_cut)));
             drew = want_draw;
             if (want_draw) { draw(); want_draw = false; }
-            if (nxt.fast) fast_issue<NSEG, U>(a, tid, nxt, lo, n, gn, rdn);
+            if (nxt.fast) fast_issue<NSEG, U, IN>(a, tid, nxt, lo, n, gn, rdn);
         }
         if (DIAG && tid == 0 && a.dbg) { sm.stamps[8] = (unsigned long long)cur.nwin; sm.stamps[12] = (unsigned long long)cur.more; sm.stamps[14] = blockIdx.x; }
         RAFT_STAMP(1);
@@ -293,61 +318,134 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP> &sm, const TileCut 
             //    look-ups of all slots first and predicating only the two LDS adds -- more live state, more spills.)
             int covsum = 0;
             bool bad_any = false, bad_order = false;
-            auto win = [&](unsigned n) -> int { return (int)(((n & win_m1) | __umulhi(n, a.div_magic)) >> win_sh); };
-            auto one = [&](int rid, int st, int en) {
-                const unsigned jr = (unsigned)(rid - r_a);
-                const unsigned j = min(jr, (unsigned)nr);                         // (an empty slot would read entry nr)
-                const int b0 = tb.roff[j], nb_r = tb.roff[j + 1] - b0;
-                const int first = win((unsigned)st);
-                const int last1 = win((unsigned)(en - 1)) + 1;                    // meaningful for en >= 1
-                // valid: a record of one of the tile's reads.  Anything else refutes the sampled guess of the sorted runs
-                // this pass may be built on (engine.hip run_pass): it is flagged, must not reach the tables, and the pass
-                // is run again
-                const bool valid = jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
-                const bool over = last1 > first && last1 > nb_r;                   // repeat.hpp:69-72 writes past its vector
-                // (clipped to the tile's slots: a no-op for tiles of whole reads, the cut for a piece of a long read)
-                const int pf = EXTRA ? max(b0 + first, off0) : b0 + first, pl1 = EXTRA ? min(b0 + min(last1, nb_r), t_end) : b0 + min(last1, nb_r);
-                bad_any |= valid && (!sign_ok || (pos && over));
-                bad_order |= !valid;             // a record of a read outside this tile (see kErrOrder in pileup.hpp)
-                if (valid && sign_ok && pos && pf < pl1) {
-                    __hip_atomic_fetch_add(&sm.diff[pf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&sm.diff[pl1], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    covsum += pl1 - pf;          // sum of coverage over the window == windows touched by its intervals
-                }
-            };
-            // (slots behind the first of a segment are mostly empty for three waves in four -- a segment of a HiFi tile
-            // holds ~520 intervals, the third slot's lanes begin at 512 -- and an empty slot still costs its ~30 vector
-            // instructions: a wave skips the slots none of its lanes holds a record in)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (u < NSEG || cur.cnt[u % NSEG] > (u / NSEG) * 256 + wid * 64) one(g.rid[u], g.st[u], g.en[u]);
-            }
-            if (cur.more) {                      // intervals beyond the prefetched slots (dense tiles): synchronous loads
-                const TileCut d0 = cuts[cut_of(k)], d1 = cuts[cut_of(k) + 1];
-#pragma unroll
-                for (int s = 0; s < NSEG; ++s) {
-                    const int n_s = d1.iv_lo[s] - d0.iv_lo[s];
-                    const long long base = (long long)d0.iv_lo[s];
-                    for (int i = ITER * 256 + (int)tid; i < n_s; i += 256)
-                        one((a.iv_rid + base)[i], (a.iv_s + base)[i], (a.iv_e + base)[i]);
-                }
-            }
-            if (__ballot(bad_order) != 0ull && lane == 0) atomicOr(a.err_flags, kErrOrder);   // (every wave for itself)
-            if (__ballot(bad_any) != 0ull) {     // rare: find the offending records again and report the first index
-                const TileCut d0 = cuts[cut_of(k)], d1 = cuts[cut_of(k) + 1];
-                auto is_bad = [&](int rid, int st, int en) -> bool {
-                    if ((unsigned)(rid - r_a) >= (unsigned)nr) return false;
-                    const int j = rid - r_a;
-                    const int nb_r = tb.roff[j + 1] - tb.roff[j];
-                    const int first = (int)win_of(a, (unsigned)st), last1 = (int)win_of(a, (unsigned)(en - 1)) + 1;
-                    return (st | en) < 0 || (en > 0 && last1 > first && last1 > nb_r);
+            if constexpr (IN == 0) {
+                auto win = [&](unsigned n) -> int { return (int)(((n & win_m1) | __umulhi(n, a.div_magic)) >> win_sh); };
+                auto one = [&](int rid, int st, int en) {
+                    const unsigned jr = (unsigned)(rid - r_a);
+                    const unsigned j = min(jr, (unsigned)nr);                         // (an empty slot would read entry nr)
+                    const int b0 = tb.roff[j], nb_r = tb.roff[j + 1] - b0;
+                    const int first = win((unsigned)st);
+                    const int last1 = win((unsigned)(en - 1)) + 1;                    // meaningful for en >= 1
+                    // valid: a record of one of the tile's reads.  Anything else refutes the sampled guess of the sorted runs
+                    // this pass may be built on (engine.hip run_pass): it is flagged, must not reach the tables, and the pass
+                    // is run again
+                    const bool valid = jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
+                    const bool over = last1 > first && last1 > nb_r;                   // repeat.hpp:69-72 writes past its vector
+                    // (clipped to the tile's slots: a no-op for tiles of whole reads, the cut for a piece of a long read)
+                    const int pf = EXTRA ? max(b0 + first, off0) : b0 + first, pl1 = EXTRA ? min(b0 + min(last1, nb_r), t_end) : b0 + min(last1, nb_r);
+                    bad_any |= valid && (!sign_ok || (pos && over));
+                    bad_order |= !valid;             // a record of a read outside this tile (see kErrOrder in pileup.hpp)
+                    if (valid && sign_ok && pos && pf < pl1) {
+                        __hip_atomic_fetch_add(&sm.diff[pf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&sm.diff[pl1], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        covsum += pl1 - pf;          // sum of coverage over the window == windows touched by its intervals
+                    }
                 };
+                // (slots behind the first of a segment are mostly empty for three waves in four -- a segment of a HiFi tile
+                // holds ~520 intervals, the third slot's lanes begin at 512 -- and an empty slot still costs its ~30 vector
+                // instructions: a wave skips the slots none of its lanes holds a record in)
+    #pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (u < NSEG || cur.cnt[u % NSEG] > (u / NSEG) * 256 + wid * 64) one(g.rid[u], g.st[u], g.en[u]);
+                }
+                if (cur.more) {                      // intervals beyond the prefetched slots (dense tiles): synchronous loads
+                    const TileCut d0 = cuts[cut_of(k)], d1 = cuts[cut_of(k) + 1];
+    #pragma unroll
+                    for (int s = 0; s < NSEG; ++s) {
+                        const int n_s = d1.iv_lo[s] - d0.iv_lo[s];
+                        const long long base = (long long)d0.iv_lo[s];
+                        for (int i = ITER * 256 + (int)tid; i < n_s; i += 256)
+                            one((a.iv_rid + base)[i], (a.iv_s + base)[i], (a.iv_e + base)[i]);
+                    }
+                }
+                if (__ballot(bad_order) != 0ull && lane == 0) atomicOr(a.err_flags, kErrOrder);   // (every wave for itself)
+                if (__ballot(bad_any) != 0ull) {     // rare: find the offending records again and report the first index
+                    const TileCut d0 = cuts[cut_of(k)], d1 = cuts[cut_of(k) + 1];
+                    auto is_bad = [&](int rid, int st, int en) -> bool {
+                        if ((unsigned)(rid - r_a) >= (unsigned)nr) return false;
+                        const int j = rid - r_a;
+                        const int nb_r = tb.roff[j + 1] - tb.roff[j];
+                        const int first = (int)win_of(a, (unsigned)st), last1 = (int)win_of(a, (unsigned)(en - 1)) + 1;
+                        return (st | en) < 0 || (en > 0 && last1 > first && last1 > nb_r);
+                    };
+    #pragma unroll
+                    for (int s = 0; s < NSEG; ++s) {
+                        const int n_s = d1.iv_lo[s] - d0.iv_lo[s];
+                        const long long base = (long long)d0.iv_lo[s];
+                        for (int i = (int)tid; i < n_s; i += 256)
+                            if (is_bad((a.iv_rid + base)[i], (a.iv_s + base)[i], (a.iv_e + base)[i])) raise_error(a, kErrCoord, base + i);
+                    }
+                }
+            } else {
+                // ---- window records: (first window, one past the last) in one word, the read from the caller's offsets
+                const int32_t *const so_base = &sm.soff[p][0][0];
+                constexpr int TABW = Smem::TAB;
+                // generic look-up (tiles of more than 64 reads, records beyond the prefetched slots, the error path): the
+                // last read of the tile whose records begin at or before record i of run s
+                auto find_j = [&](int s, int i) -> int {
+                    int x = 1, y = nr;                     // first t in [1, nr) with soff[t] > i
+                    while (x < y) {
+                        const int m = (x + y) >> 1;
+                        if (so_base[s * TABW + m] <= i) x = m + 1; else y = m;
+                    }
+                    return x - 1;
+                };
+                auto one_w = [&](int j, unsigned w) {
+                    const int b0 = tb.roff[j], nb_r = tb.roff[j + 1] - b0;
+                    const int first = (int)(w & 0xffffu), last1 = (int)(w >> 16);
+                    const bool over = last1 > first && last1 > nb_r;                  // repeat.hpp:69-72 writes past its vector
+                    const int pf = EXTRA ? max(b0 + first, off0) : b0 + first, pl1 = EXTRA ? min(b0 + min(last1, nb_r), t_end) : b0 + min(last1, nb_r);
+                    bad_any |= over;
+                    if (pf < pl1) {
+                        __hip_atomic_fetch_add(&sm.diff[pf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&sm.diff[pl1], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        covsum += pl1 - pf;
+                    }
+                };
+                // boundary lane + 1 of every run: where the records of read r_a + lane + 1 begin (entry nr closes the run)
+                int bnd[NSEG];
 #pragma unroll
-                for (int s = 0; s < NSEG; ++s) {
-                    const int n_s = d1.iv_lo[s] - d0.iv_lo[s];
-                    const long long base = (long long)d0.iv_lo[s];
-                    for (int i = (int)tid; i < n_s; i += 256)
-                        if (is_bad((a.iv_rid + base)[i], (a.iv_s + base)[i], (a.iv_e + base)[i])) raise_error(a, kErrCoord, base + i);
+                for (int s = 0; s < NSEG; ++s) bnd[s] = (lane < nr) ? so_base[s * TABW + lane + 1] : 0x7fffffff;
+                const bool wide = nr > 64;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int s = u % NSEG;
+                    const int i0 = (u / NSEG) * 256 + wid * 64;       // the wave's first record of this slot (in run s, from the tile's first)
+                    if (cur.cnt[s] > i0) {
+                        int j;
+                        if (wide) j = find_j(s, min(i0 + lane, cur.cnt[s] - 1));
+                        else {
+                            // reads of the wave's first and last record: boundaries at or before them, counted by ballot
+                            const int i_last = min(i0 + 63, cur.cnt[s] - 1);
+                            const int jf = (int)__popcll(__ballot(bnd[s] <= i0)), jl = (int)__popcll(__ballot(bnd[s] <= i_last));
+                            j = jf;
+                            for (int t = jf; t < jl; ++t) j += (i0 + lane >= __builtin_amdgcn_readlane(bnd[s], t)) ? 1 : 0;
+                        }
+                        one_w(j, (unsigned)g.st[u]);
+                    }
+                }
+                if (cur.more) {                      // records beyond the prefetched slots (dense tiles): synchronous loads
+                    const TileCut d0 = cuts[cut_of(k)], d1 = cuts[cut_of(k) + 1];
+#pragma unroll
+                    for (int s = 0; s < NSEG; ++s) {
+                        const int n_s = d1.iv_lo[s] - d0.iv_lo[s];
+                        const long long base = (long long)d0.iv_lo[s];
+                        for (int i = ITER * 256 + (int)tid; i < n_s; i += 256) one_w(find_j(s, i), (a.iv_w + base)[i]);
+                    }
+                }
+                if (__ballot(bad_any) != 0ull) {     // rare: find the offending records again and report the first index
+                    const TileCut d0 = cuts[cut_of(k)], d1 = cuts[cut_of(k) + 1];
+#pragma unroll
+                    for (int s = 0; s < NSEG; ++s) {
+                        const int n_s = d1.iv_lo[s] - d0.iv_lo[s];
+                        const long long base = (long long)d0.iv_lo[s];
+                        for (int i = (int)tid; i < n_s; i += 256) {
+                            const int j = find_j(s, i);
+                            const unsigned w = (a.iv_w + base)[i];
+                            const int first = (int)(w & 0xffffu), last1 = (int)(w >> 16);
+                            if (last1 > first && last1 > tb.roff[j + 1] - tb.roff[j]) raise_error(a, kErrCoord, base + i);
+                        }
+                    }
                 }
             }
             lane_cov += covsum;
@@ -814,22 +912,22 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP> &sm, const TileCut 
 // regular tile left goes on with the extra ones.  (Two launches on two streams cost the pass an event hand-over at either
 // end, ~25 us; on a long-read set, where a fifth of the windows sit in extra tiles, those used to start only when regular
 // workgroups retired.)
-template <int CAP, int NSEG, int U, int MINW, bool DIAG, int EXTRA, int OW = 4, bool LS = false>
+template <int CAP, int NSEG, int U, int MINW, bool DIAG, int EXTRA, int OW = 4, bool LS = false, int IN = 0>
 __global__ __launch_bounds__(256, MINW) void pileup_fast_kernel(const TileCut *__restrict__ cuts, PileupArgs a)
 {
-    using Smem = FastSmem<CAP>;
+    using Smem = FastSmem<CAP, IN ? NSEG : 0>;
     // Measured on MI355X (tools/occ_probe.hip, tools/stamp_probe.py): five 31,744-byte workgroups share a CU, five
     // 31,856-byte ones do not -- a fifth of the persistent grid then starts only when the first workgroups retire and
     // the kernel takes a third longer.  Stay at or below the footprint that is known to fit.
     static_assert(sizeof(Smem) * MINW <= 31328 * 5, "LDS footprint does not allow MINW workgroups per CU");
     __shared__ __attribute__((aligned(16))) Smem sm;
-    if (EXTRA != 1) fast_tile_loop<CAP, NSEG, U, DIAG, false, OW, LS>(sm, cuts, a);
-    if (EXTRA == 1) fast_tile_loop<CAP, NSEG, U, DIAG, true, OW, LS>(sm, cuts, a);
+    if (EXTRA != 1) fast_tile_loop<CAP, NSEG, U, DIAG, false, OW, LS, IN>(sm, cuts, a);
+    if (EXTRA == 1) fast_tile_loop<CAP, NSEG, U, DIAG, true, OW, LS, IN>(sm, cuts, a);
     if (EXTRA == 2) {
         PileupArgs b = a;                            // the extra tiles: their own hand-out counter, one at a time; sums behind the regular ones'
         b.tile_counter = a.slow_counter; b.tile_batch = 1; b.block_sums = a.block_sums + 2 * (long long)gridDim.x;
         lds_barrier();
-        fast_tile_loop<CAP, NSEG, U, DIAG, true, OW, LS>(sm, cuts, b);
+        fast_tile_loop<CAP, NSEG, U, DIAG, true, OW, LS, IN>(sm, cuts, b);
     }
 }
 

@@ -27,6 +27,7 @@ EXPORTS = (
     "raft_hip_set_output_width", "raft_hip_packed_device", "raft_hip_run_device_grouped", "raft_hip_run_host_grouped",
     "raft_hip_run_multi_grouped", "raft_hip_host_register", "raft_hip_host_unregister", "raft_hip_comm_unique_id",
     "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local", "raft_hip_warm_up", "raft_hip_reserve",
+    "raft_hip_run_device_windows", "raft_hip_run_host_windows", "raft_hip_run_multi_windows",
 )
 
 
@@ -142,6 +143,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_run_device_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, vp, i64]
     lib.raft_hip_run_host_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, i64]
     lib.raft_hip_run_multi_grouped.argtypes = [C.POINTER(vp), i32, i32, vp, i64, i32, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
+    lib.raft_hip_run_device_windows.argtypes = [vp, i32, vp, i64, i32, vp, vp, i64]
+    lib.raft_hip_run_host_windows.argtypes = [vp, i32, vp, i64, i32, vp, vp, i64]
+    lib.raft_hip_run_multi_windows.argtypes = [C.POINTER(vp), i32, i32, vp, i64, i32, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_comm_unique_id.argtypes = [vp]
     lib.raft_hip_comm_create.argtypes = [C.c_int, vp, i32, i32, C.POINTER(vp)]
     lib.raft_hip_comm_destroy.argtypes = [vp]
@@ -263,6 +267,34 @@ class Engine:
         self._check(self._lib.raft_hip_run_device_grouped(self._ctx, n_reads, P(read_len), n_rec, int(rec_offset.shape[0]), P(rec_offset),
                                                           P(qid), P(qs), P(qe), int(n_bins)))
 
+    def run_device_windows(self, read_len, rec_offset, win, n_bins: int = -1):
+        """raft_hip_run_device_windows: grouped input whose records are ONE word each -- first window | one past the last << 16
+        (``hostio.pack_windows``); ``win`` an int32 or uint32-viewed CUDA tensor of 32-bit words.  symmetric_mode must be 1."""
+        import torch
+        n_reads = int(read_len.numel())
+        if rec_offset.dtype != torch.int64 or not rec_offset.is_cuda or not rec_offset.is_contiguous() or rec_offset.dim() != 2 \
+                or rec_offset.shape[1] != n_reads + 1:
+            raise TypeError("run_device_windows needs rec_offset as a contiguous int64 CUDA tensor [n_runs, n_reads + 1]")
+        for t in (read_len, win):
+            if t.element_size() != 4 or t.is_floating_point() or not t.is_cuda or not t.is_contiguous():
+                raise TypeError("run_device_windows needs contiguous 32-bit integer CUDA tensors")
+        self._keep = (read_len, win, rec_offset)
+        self.use_torch_stream()
+        P = lambda t: C.c_void_p(t.data_ptr() if (t is not None and t.numel()) else 0)
+        self._check(self._lib.raft_hip_run_device_windows(self._ctx, n_reads, P(read_len), int(win.numel()), int(rec_offset.shape[0]), P(rec_offset),
+                                                          P(win), int(n_bins)))
+
+    def run_host_windows(self, read_len, rec_offset, win, n_bins: int = -1):
+        """raft_hip_run_host_windows: numpy arrays; ``win`` uint32 window records."""
+        rl = np.ascontiguousarray(np.asarray(read_len), dtype=np.int32)
+        w = np.ascontiguousarray(np.asarray(win), dtype=np.uint32)
+        off = np.ascontiguousarray(np.asarray(rec_offset), dtype=np.int64)
+        if off.ndim != 2 or off.shape[1] != rl.size + 1:
+            raise ValueError("run_host_windows: rec_offset must be [n_runs, n_reads + 1]")
+        self._keep = (rl, w, off)
+        P = lambda x: C.c_void_p(x.ctypes.data if x.size else 0)
+        self._check(self._lib.raft_hip_run_host_windows(self._ctx, rl.size, P(rl), w.size, off.shape[0], P(off), P(w), int(n_bins)))
+
     def run_host_grouped(self, read_len, rec_offset, qs, qe, n_bins: int = -1):
         """raft_hip_run_host_grouped: numpy arrays; ``rec_offset`` int64 [n_runs, n_reads + 1]."""
         rl, a, b = (np.ascontiguousarray(np.asarray(x), dtype=np.int32) for x in (read_len, qs, qe))
@@ -374,6 +406,24 @@ class Engine:
         s = _Summary()
         ctxs = (C.c_void_p * (1 + len(others or [])))(self._ctx, *[e._ctx for e in (others or [])])
         rc = self._lib.raft_hip_run_multi_grouped(ctxs, len(ctxs), rl.size, P(rl), a.size, off.shape[0], P(off), P(a), P(b), int(n_chunks),
+                                                  C.byref(ho), C.byref(s))
+        return self._pipelined_result(rc, s, ho, out)
+
+    def run_pipelined_windows(self, read_len, rec_offset, win, n_chunks: int = 0, out: dict | None = None, others: list | None = None):
+        """raft_hip_run_multi_windows: as ``run_pipelined_grouped`` with window records (uint32, ``hostio.pack_windows``) in place
+        of the two coordinate columns."""
+        rl = np.ascontiguousarray(np.asarray(read_len), dtype=np.int32)
+        w = np.ascontiguousarray(np.asarray(win), dtype=np.uint32)
+        off = np.ascontiguousarray(np.asarray(rec_offset), dtype=np.int64)
+        if off.ndim != 2 or off.shape[1] != rl.size + 1:
+            raise ValueError("run_pipelined_windows: rec_offset must be [n_runs, n_reads + 1]")
+        if out is None:
+            out = self.host_output_buffers(rl, pinned=False)
+        ho = self._host_outputs(out)
+        P = lambda x: C.c_void_p(x.ctypes.data if x.size else 0)
+        s = _Summary()
+        ctxs = (C.c_void_p * (1 + len(others or [])))(self._ctx, *[e._ctx for e in (others or [])])
+        rc = self._lib.raft_hip_run_multi_windows(ctxs, len(ctxs), rl.size, P(rl), w.size, off.shape[0], P(off), P(w), int(n_chunks),
                                                   C.byref(ho), C.byref(s))
         return self._pipelined_result(rc, s, ho, out)
 

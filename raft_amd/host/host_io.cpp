@@ -890,6 +890,37 @@ int raft_host_group_offsets(int32_t n_reads, int64_t n_rec, const int32_t *qid, 
     return RAFT_HOST_OK;
 }
 
+int raft_host_pack_windows(int64_t n_rec, const int32_t *qs, const int32_t *qe, int32_t reso, uint32_t *win, int64_t *bad_index)
+{
+    if (bad_index) *bad_index = -1;
+    if (n_rec < 0 || reso < 1 || reso > 32767 || (n_rec > 0 && (!qs || !qe || !win))) return RAFT_HOST_ERR_ARG;
+    int T = host_threads();
+    if (n_rec < (1 << 18)) T = 1;
+    std::vector<int64_t> neg((size_t)T, INT64_MAX), far((size_t)T, INT64_MAX);
+    const uint32_t d = (uint32_t)reso;
+    parallel_for(T, [&](int t) {
+        const int64_t lo = n_rec * t / T, hi = n_rec * (t + 1) / T;
+        int64_t first_neg = INT64_MAX, first_far = INT64_MAX;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int32_t s = qs[i], e = qe[i];
+            if ((s | e) < 0) { first_neg = std::min(first_neg, i); win[i] = 0; continue; }
+            const uint32_t first = (uint32_t)s / d, last1 = e > 0 ? (uint32_t)(e - 1) / d + 1u : 0u;
+            uint32_t w = 0;
+            if (last1 > first) {
+                if (last1 > 65535u) first_far = std::min(first_far, i);
+                w = first | (last1 << 16);
+            }
+            win[i] = w;
+        }
+        neg[(size_t)t] = first_neg; far[(size_t)t] = first_far;
+    });
+    int64_t n0 = INT64_MAX, f0 = INT64_MAX;
+    for (int t = 0; t < T; ++t) { n0 = std::min(n0, neg[(size_t)t]); f0 = std::min(f0, far[(size_t)t]); }
+    if (n0 != INT64_MAX) { if (bad_index) *bad_index = n0; return RAFT_HOST_ERR_COORD; }
+    if (f0 != INT64_MAX) { if (bad_index) *bad_index = f0; return RAFT_HOST_ERR_RANGE; }
+    return RAFT_HOST_OK;
+}
+
 void raft_host_paf_free(raft_host_paf *p) { delete p; }
 int64_t raft_host_paf_count(const raft_host_paf *p) { return p ? (int64_t)p->n : 0; }
 const int32_t *raft_host_paf_column(const raft_host_paf *p, int k) { return (p && k >= 0 && k < 6) ? p->col[k].get() : nullptr; }

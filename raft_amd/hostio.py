@@ -15,7 +15,7 @@ EXPORTS = ("raft_host_reads_load", "raft_host_reads_free", "raft_host_reads_coun
            "raft_host_write_fasta", "raft_host_set_threads", "raft_host_get_threads", "raft_host_split_naive",
            "raft_host_paf_symmetric", "raft_host_unpack_coverage", "raft_host_write_coverage_packed",
            "raft_host_unpack_coverage_w", "raft_host_write_coverage_packed_w", "raft_host_text_read", "raft_host_text_free",
-           "raft_host_paf_parse", "raft_host_group_offsets")
+           "raft_host_paf_parse", "raft_host_group_offsets", "raft_host_pack_windows")
 
 
 class HostError(RuntimeError):
@@ -62,6 +62,7 @@ def load_library():
         lib.raft_host_write_coverage_packed_w.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp]
         lib.raft_host_get_threads.argtypes = []
         lib.raft_host_group_offsets.argtypes = [C.c_int32, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32), vp]
+        lib.raft_host_pack_windows.argtypes = [C.c_int64, vp, vp, C.c_int32, vp, C.POINTER(C.c_int64)]
         _lib = lib
     return _lib
 
@@ -90,6 +91,33 @@ def group_offsets(n_reads: int, qid, max_runs: int = 4, out=None):
     if n_runs.value == 0:
         return None
     return buf[: n_runs.value * (n_reads + 1)].reshape(n_runs.value, n_reads + 1)
+
+
+ERR_COORD, ERR_RANGE = 6, 7
+
+
+def pack_windows(qs, qe, reso: int, out=None):
+    """raft_host_pack_windows: window records (uint32: first window | one past the last << 16) of the coordinate columns, for
+    the engine's ``*_windows`` entries.  Returns the array, or None when some interval ends beyond window 65,535 (the caller
+    keeps the coordinate columns).  A negative coordinate raises HostError(ERR_COORD) whose ``index`` names the record.
+    ``out``: a caller-owned uint32 array of at least len(qs) entries (e.g. page-locked) to fill."""
+    a = np.ascontiguousarray(np.asarray(qs), dtype=np.int32)
+    b = np.ascontiguousarray(np.asarray(qe), dtype=np.int32)
+    if a.size != b.size:
+        raise ValueError("pack_windows: qs / qe differ in length")
+    buf = out if out is not None else np.empty(a.size, np.uint32)
+    if buf.dtype != np.uint32 or buf.size < a.size or not buf.flags["C_CONTIGUOUS"]:
+        raise ValueError("pack_windows: out must be a contiguous uint32 array of len(qs) entries")
+    bad = C.c_int64(-1)
+    P = lambda x: C.c_void_p(x.ctypes.data if x.size else 0)
+    rc = load_library().raft_host_pack_windows(int(a.size), P(a), P(b), int(reso), P(buf), C.byref(bad))
+    if rc == ERR_RANGE:
+        return None
+    if rc != OK:
+        e = HostError(rc, f"pack_windows (record {bad.value})")
+        e.index = int(bad.value)
+        raise e
+    return buf[: a.size]
 
 
 def split_naive(in_path: str, out_path: str, split_len: int) -> int:

@@ -390,3 +390,52 @@ def test_group_offsets(threads):
         assert hostio.group_offsets(100, bad) is None
     finally:
         hostio.set_threads(0)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_pack_windows(threads):
+    """raft_host_pack_windows against the window arithmetic of profileCoverage (repeat.hpp:69-72) in numpy: the windows an
+    interval touches, 0 for one that touches none; negative coordinates and windows beyond 16 bits are reported."""
+    hostio.set_threads(threads)
+    try:
+        rng = np.random.default_rng(9)
+        for n, reso in ((0, 50), (1, 50), (1000, 1), (400000, 50), (400000, 7), (300000, 32767)):
+            top = min(65535 * reso, 2**31 - 1)
+            a = rng.integers(0, top, n).astype(np.int32)
+            b = np.minimum(a.astype(np.int64) + rng.integers(-3 * reso, 20 * reso, n), top).clip(0).astype(np.int32)
+            if n > 10:
+                b[:5] = 0
+                a[5:8] = 0; b[5:8] = 1
+            w = hostio.pack_windows(a, b, reso)
+            first = a // reso
+            last1 = np.where(b > 0, (b.astype(np.int64) - 1) // reso + 1, 0)
+            live = last1 > first
+            want = np.where(live, first | (last1 << 16), 0).astype(np.uint32)
+            assert w is not None and w.dtype == np.uint32 and np.array_equal(w, want), (n, reso)
+        a = rng.integers(0, 10**6, 300000).astype(np.int32)
+        b = a + 500
+        for idx in ([299999], [12, 270000], [150000, 150001]):
+            x = a.copy(); x[idx] = -1
+            with pytest.raises(hostio.HostError) as e:
+                hostio.pack_windows(x, b, 50)
+            assert e.value.code == hostio.ERR_COORD and e.value.index == idx[0]
+            y = b.copy(); y[idx] = -7
+            with pytest.raises(hostio.HostError) as e:
+                hostio.pack_windows(a, y, 50)
+            assert e.value.code == hostio.ERR_COORD and e.value.index == idx[0]
+        far = b.copy(); far[77777] = 65535 * 50 + 1
+        assert hostio.pack_windows(a, far, 50) is None
+        far[77777] = 65535 * 50
+        assert hostio.pack_windows(a, far, 50)[77777] == (int(a[77777]) // 50) | (65535 << 16)
+        far[3] = -1                                     # both kinds: the negative coordinate is the error
+        with pytest.raises(hostio.HostError):
+            hostio.pack_windows(a, far, 50)
+        for reso in (0, -1, 32768):
+            with pytest.raises(hostio.HostError) as e:
+                hostio.pack_windows(a, b, reso)
+            assert e.value.code == hostio.ERR_ARG
+        out = np.empty(a.size + 10, np.uint32)
+        w = hostio.pack_windows(a, b, 50, out=out)
+        assert w.base is out or w.ctypes.data == out.ctypes.data
+    finally:
+        hostio.set_threads(0)
