@@ -271,8 +271,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="hg002")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's own size); with --strong / --presplit: reads of the ONE set")
     ap.add_argument("--seed", type=int, default=20241008)
-    ap.add_argument("--input", choices=["grouped", "columns"], default="grouped",
-                    help="grouped: columns + per-read record offsets + window count (what the CLI hands over); columns: six plain columns, detecting context")
+    ap.add_argument("--input", choices=["grouped", "columns", "windows"], default="grouped",
+                    help="grouped: columns + per-read record offsets + window count; windows: the same with one word per record (window records, what "
+                         "the CLI hands over); columns: six plain columns, detecting context")
     ap.add_argument("--no-qid", action="store_true", help="grouped input without the query column (rebuilt from the offsets on the device)")
     ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -333,7 +334,8 @@ def main():
     n_reads = args.reads or DEFAULT_READS[args.workload]
     p = RaftParams(est_cov=est_cov)
     p_sym = RaftParams(**dict(p.__dict__, symmetric_mode=1))
-    grouped_in = args.input == "grouped" and not args.force_bucket
+    grouped_in = args.input in ("grouped", "windows") and not args.force_bucket
+    windows_in = args.input == "windows" and grouped_in
 
     def fence():
         if dist is not None:
@@ -346,10 +348,15 @@ def main():
         def __init__(self, read_len, cols, want_grouped):
             self.read_len, self.cols = read_len.contiguous(), tuple(c.contiguous() for c in cols)
             self.n_reads, self.n_rec = int(read_len.numel()), int(cols[0].numel())
-            self.off = self.n_bins = None
+            self.off = self.n_bins = self.win = None
             if want_grouped:
                 self.off = torch.as_tensor(grouped_form(torch, hostio, self.n_reads, self.cols[0])).to(dev)
                 self.n_bins = windows_of(self.read_len, p.reso)
+                if windows_in:
+                    w = hostio.pack_windows(self.cols[1].cpu().numpy(), self.cols[2].cpu().numpy(), p.reso)
+                    if w is None:
+                        raise SystemExit("bench.py: --input windows needs reads below 65,535 windows")
+                    self.win = torch.as_tensor(w.view("int32")).to(dev)
 
     def make_engine(sh: Shard, width: int):
         e = engine.Engine(p_sym if (sh.off is not None or args.handover) else p, device=local)
@@ -359,7 +366,9 @@ def main():
         return e
 
     def pass_of(e, sh: Shard, qid=True):
-        if sh.off is not None:
+        if sh.win is not None:
+            e.run_device_windows(sh.read_len, sh.off, sh.win, n_bins=sh.n_bins)
+        elif sh.off is not None:
             e.run_device_grouped(sh.read_len, sh.off, sh.cols[0] if qid else None, sh.cols[1], sh.cols[2], n_bins=sh.n_bins)
         else:
             e.run_device(sh.read_len, *sh.cols)
@@ -627,11 +636,13 @@ def main():
         # dominant kernel: pileup + prefix scan + coverage store + run scan (pileup_fast.hpp).
         # algorithmic bytes per launch (this rank): 12 B per interval read once, 4 B per window written once,
         # 4 B per read (length) and 8 B per repeat emitted
-        bytes_alg = 12 * s.n_intervals + args.cov_width * s.n_bins + 4 * s.n_reads + 8 * s.n_repeats
+        bytes_alg = (4 if windows_in else 12) * s.n_intervals + args.cov_width * s.n_bins + 4 * s.n_reads + 8 * s.n_repeats
         achieved = bytes_alg / pile / 1e9
         strong_line = args.strong and world > 1
         if args.presplit and world > 1:
             input_text = "records pre-split across ranks; the received intervals enter as query-side records (raft_hip_run_device, symmetric_mode = 1)"
+        elif windows_in:
+            input_text = "grouped, window records (raft_hip_run_device_windows): one word per record, read ids from the per-read record offsets"
         elif grouped_in:
             input_text = ("grouped (raft_hip_run_device_grouped): columns + per-read record offsets of every sorted run + window count, as the CLI hands them over"
                           + ("; no query column" if args.no_qid else "; every record checked against its tile's reads"))
@@ -680,9 +691,11 @@ def main():
             line["strong"] = strong_info
         if args.cov_width != 4:
             line["config"]["cov_width"] = args.cov_width
-        traffic_file = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")   # (per workload; the headline workload's: pmc_traffic.json)
+        # (per workload and input form; the headline workload's: pmc_traffic.json, with window records in / a byte per window out: pmc_traffic_windows_w1.json)
+        form = (f"_windows_w{args.cov_width}" if windows_in else ("" if args.cov_width == 4 else f"_w{args.cov_width}"))
+        traffic_file = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}{form}.json")
         if not os.path.exists(traffic_file):
-            traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            traffic_file = os.path.join(ROOT, "profiles", f"pmc_traffic{form}.json")
         if os.path.exists(traffic_file):
             try:
                 tj = json.load(open(traffic_file))

@@ -74,8 +74,9 @@ constexpr int kWinMaxRuns = 2;    // runs the window-record instantiations take 
 template <int EXTRA>
 void launch_fast_variant(int variant, int ow, bool ls, bool win, hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
-    if (win) {                                                // window records (pileup_fast.hpp IN = 1): the default configuration only
-        if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1, false, 1>(st, grid, n_seg, cuts, pa);
+    if (win) {                                                // window records (pileup_fast.hpp IN = 1): the default configuration (and its diagnostic build)
+        if (variant == kDiagVariant && EXTRA == 0) launch_fast<7936, 4, true, 6, 0, 4, false, 1>(st, grid, n_seg, cuts, pa);
+        else if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1, false, 1>(st, grid, n_seg, cuts, pa);
         else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2, false, 1>(st, grid, n_seg, cuts, pa);
         else launch_fast<7936, 4, false, 6, EXTRA, 4, false, 1>(st, grid, n_seg, cuts, pa);
         return;
@@ -500,7 +501,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     // window records go to the fast kernel's own instantiation (pileup_fast.hpp IN = 1) where every tile is the fast kernel's
     // in its default configuration and the runs are few; anything else gets coordinate columns that fall into the same
     // windows (bucket.hpp unpack_windows_kernel) and takes the paths those have
-    const bool lean = d_win && n_rec > 0 && !merge && eff_runs <= kWinMaxRuns && recut && c->variant == kDefaultVariant && !ls_rows &&
+    const bool lean = d_win && n_rec > 0 && !merge && eff_runs <= kWinMaxRuns && recut && (c->variant == kDefaultVariant || c->variant == kDiagVariant) && !ls_rows &&
                       !c->force_bucket && getenv("RAFT_NO_WINDOW_KERNEL") == nullptr;
     if (d_win && !lean && n_rec > 0) {
         HIP_TRY(c, c->u_s.ensure((size_t)n_rec * 4));

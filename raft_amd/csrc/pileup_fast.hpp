@@ -31,7 +31,7 @@ struct FastRegs {
 };
 struct FastReadRegs {           // per read of a tile (thread j <-> read r_a + j, j <= nr)
     int cv, rr, rl;             // low dwords of cov_off / rep_res_off, read length
-    int so[kMaxSeg];            // IN = 1: the read's first record in each run, relative to the tile's first (GroupedOff)
+    int so[kMaxSeg];            // IN = 1: low dword of the read's first record in each run (GroupedOff::off)
 };
 
 struct FastTile {               // scalars of one tile
@@ -54,7 +54,7 @@ struct FastSmem {
     int32_t rlen[2][TAB];
     int32_t rcnt[2][TAB];                    // raw repeats emitted for the read
     int32_t rres[2][TAB];                    // its first reserved raw-repeat slot (rep_res_off, < 2^31 checked by the host)
-    int32_t soff[2][NSO > 0 ? NSO : 1][NSO > 0 ? TAB : 2];   // IN = 1: first record of read r_a+j in run s, relative to the tile's first
+    int32_t soff[2][NSO > 0 ? NSO : 1][NSO > 0 ? TAB : 2];   // IN = 1: first record of read r_a+j in run s (low dword of the caller's offset)
     unsigned long long acc_cov, acc_rep;
     __attribute__((aligned(16))) int32_t wsum[NW];
     int32_t next_tile;                       // tile index wave 0 drew for the workgroup (dynamic tile hand-out)
@@ -105,15 +105,19 @@ __device__ __forceinline__ void fast_issue(const PileupArgs &a, unsigned tid, co
     unsigned b4 = tid * 4u, b8 = tid * 8u;
     asm volatile("" : "+v"(b4), "+v"(b8));
     rd.cv = 0; rd.rr = 0; rd.rl = 0;
+    // (IN = 1: the zeroes are pinned ahead of the loads.  Left to itself the compiler sank "rl = 0" for the lanes without a read
+    // BEHIND the other lanes' load of the same register and put a wait for every outstanding load -- and store -- before it:
+    // 2.7 k of a tile's 16 k cycles in the issue phase, tools/stamp_probe.py)
+    if (IN == 1) asm volatile("" : "+v"(rd.cv), "+v"(rd.rr), "+v"(rd.rl));
     if ((int)tid <= t.nr) {
         rd.cv = at(reinterpret_cast<const int32_t *>(a.cov_off + t.r_a), b8);
         rd.rr = at(reinterpret_cast<const int32_t *>(a.rep_res_off + t.r_a), b8);
         if (IN == 1) {
-            // where the read's records begin in each run, counted from the tile's first record there: low dwords suffice
-            // (record indices of a pass stay below 2^31, and 32-bit wrap-around keeps the difference exact)
+            // where the read's records begin in each run: the low dword as it is -- relative to the tile's first read when it is
+            // used (32-bit wrap-around keeps that difference exact).  (No arithmetic on the loaded value here: the first version
+            // rebased it on the spot, which put a wait for the load into the issue phase -- 2.7 k of a tile's 16 k cycles.)
 #pragma unroll
-            for (int s = 0; s < NSEG; ++s)
-                rd.so[s] = at(reinterpret_cast<const int32_t *>(a.grp.off + s * a.grp.stride + t.r_a), b8) + (int)a.grp.adj[s] - lo[s];
+            for (int s = 0; s < NSEG; ++s) rd.so[s] = at(reinterpret_cast<const int32_t *>(a.grp.off + s * a.grp.stride + t.r_a), b8);
         }
     }
     if ((int)tid < t.nr) rd.rl = at(a.read_len + t.r_a, b4);
@@ -383,10 +387,11 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                 // generic look-up (tiles of more than 64 reads, records beyond the prefetched slots, the error path): the
                 // last read of the tile whose records begin at or before record i of run s
                 auto find_j = [&](int s, int i) -> int {
-                    int x = 1, y = nr;                     // first t in [1, nr) with soff[t] > i
+                    const int o0 = so_base[s * TABW];     // (the tile's first record in run s is the first of its first read)
+                    int x = 1, y = nr;                     // first t in [1, nr) with soff[t] - soff[0] > i
                     while (x < y) {
                         const int m = (x + y) >> 1;
-                        if (so_base[s * TABW + m] <= i) x = m + 1; else y = m;
+                        if (so_base[s * TABW + m] - o0 <= i) x = m + 1; else y = m;
                     }
                     return x - 1;
                 };
@@ -405,7 +410,7 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                 // boundary lane + 1 of every run: where the records of read r_a + lane + 1 begin (entry nr closes the run)
                 int bnd[NSEG];
 #pragma unroll
-                for (int s = 0; s < NSEG; ++s) bnd[s] = (lane < nr) ? so_base[s * TABW + lane + 1] : 0x7fffffff;
+                for (int s = 0; s < NSEG; ++s) bnd[s] = (lane < nr) ? so_base[s * TABW + lane + 1] - so_base[s * TABW] : 0x7fffffff;
                 const bool wide = nr > 64;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {

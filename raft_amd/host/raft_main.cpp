@@ -266,8 +266,20 @@ int main(int argc, char *argv[])
         }
     }
     stage("group_offsets");
+    // ... and its records as window records: what profileCoverage uses of an interval is the windows it touches
+    // (repeat.hpp:69-72), two 16-bit indices where reads stay below 65,535 windows -- one word per record goes up instead
+    // of two.  They are written over the query column, which grouped input no longer needs.
+    const uint32_t *win = nullptr;
+    if (n_runs > 0 && p.reso <= 32767 && !getenv("RAFT_NO_WINDOWS")) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(const_cast<int32_t *>(raft_host_paf_column(paf, 0)));
+        int64_t bad = -1;
+        if (raft_host_pack_windows(n_rec, raft_host_paf_column(paf, 1), raft_host_paf_column(paf, 2), p.reso, w, &bad) == RAFT_HOST_OK) win = w;
+        // (a negative coordinate or a window index beyond 16 bits: the coordinate columns go up, and the engine reports the former)
+    }
+    stage("pack_windows");
     if (n_runs > 0) pin(rec_off.get(), (size_t)n_runs * ((size_t)n_reads + 1) * 8);
-    for (int k = n_runs > 0 ? 1 : 0; k < (sym ? 3 : 6); ++k) pin(raft_host_paf_column(paf, k), (size_t)n_rec * 4);
+    if (win) pin(const_cast<uint32_t *>(win), (size_t)n_rec * 4);
+    else for (int k = n_runs > 0 ? 1 : 0; k < (sym ? 3 : 6); ++k) pin(raft_host_paf_column(paf, k), (size_t)n_rec * 4);
     out_prep.join();
     stage("page-lock");
     // one byte per window unless the expected coverage lets repeats pile up beyond it (from 40x on: two), and two in any
@@ -288,7 +300,10 @@ int main(int argc, char *argv[])
         ho.rep_offset = rep_off.data(); ho.rep_s = rep_s.get(); ho.rep_e = rep_e.get(); ho.rep_cap = rep_cap;
         ho.frag_offset = frag_off.data(); ho.frag_begin = fb.get(); ho.frag_end = fe.get(); ho.frag_cap = frag_cap;
         // upload, pass and download of consecutive read ranges overlap, on every device named (one piece for small inputs)
-        if (n_runs > 0)
+        if (win)
+            rc = raft_hip_run_multi_windows(ctxs.data(), (int32_t)ctxs.size(), n_reads, rl, n_rec, n_runs, rec_off.get(), win,
+                                            chunks_env ? atoi(chunks_env) : 0, &ho, &s);
+        else if (n_runs > 0)
             rc = raft_hip_run_multi_grouped(ctxs.data(), (int32_t)ctxs.size(), n_reads, rl, n_rec, n_runs, rec_off.get(),
                                             raft_host_paf_column(paf, 1), raft_host_paf_column(paf, 2), chunks_env ? atoi(chunks_env) : 0, &ho, &s);
         else
@@ -311,7 +326,7 @@ int main(int argc, char *argv[])
         die(m);
     }
     stage("engine+fetch");
-    if (timing) fprintf(stderr, "TIMING devices_used %d input %s\n", s.n_devices_used, n_runs > 0 ? "grouped" : "columns");
+    if (timing) fprintf(stderr, "TIMING devices_used %d input %s\n", s.n_devices_used, win ? "windows" : (n_runs > 0 ? "grouped" : "columns"));
     fprintf(stdout, "INFO, Symmetric overlaps %d \n", s.symmetric);            // chop.hpp:189-190
     fprintf(stdout, "INFO, length of alignments  %d()\n", (int)s.n_records);
     fprintf(stdout, "high_cov %d\n", s.high_cov);                              // repeat.hpp:91

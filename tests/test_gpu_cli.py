@@ -158,7 +158,7 @@ def test_cli_spreads_every_input_shape_over_the_contexts(tmp_path, name):
         assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, (name, f)
     line = [l for l in r.stderr.decode().splitlines() if l.startswith("TIMING devices_used")]
     assert line and line[0].split()[2] == "2", r.stderr.decode()
-    assert line[0].split()[4] == ("grouped" if name == "s300_default" else "columns")
+    assert line[0].split()[4] == ("windows" if name == "s300_default" else "columns")
 
 
 def test_cli_many_concatenated_files(tmp_path):
@@ -177,6 +177,29 @@ def test_cli_many_concatenated_files(tmp_path):
     r = subprocess.run([RAFT] + meta["args"] + ["reads.fa", "overlaps.paf"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        timeout=300, env=dict(os.environ, RAFT_TIMING="1"))
     assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
-    assert "input grouped" in r.stderr.decode()
+    assert "input windows" in r.stderr.decode()
     for f, digest in meta["md5"].items():
         assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, f
+
+
+@pytest.mark.parametrize("knob,form", [("RAFT_NO_WINDOWS", "grouped"), ("RAFT_NO_GROUPED", "columns"), (None, "windows")])
+@pytest.mark.parametrize("name", ["s300_default", "s60_ultralong"])
+def test_cli_input_forms(tmp_path, name, knob, form):
+    """The three forms the CLI hands a symmetric hifiasm-shaped PAF over in -- window records (default), coordinate columns
+    with the per-read offsets, the plain columns -- give the reference's files.  s60_ultralong runs at -r 10 with reads of
+    more than 65,535 windows: window records cannot say that, and the CLI stays with the coordinate columns by itself."""
+    p, cols, exp, meta = load_case(name)
+    names = [f"r{i}" for i in range(len(cols[0]))]
+    write_fasta(tmp_path / "reads.fa", names, cols[0])
+    write_paf(tmp_path / "overlaps.paf", names, *cols)
+    env = dict(os.environ, RAFT_TIMING="1")
+    if knob:
+        env[knob] = "1"
+    r = subprocess.run([RAFT] + meta["args"] + ["reads.fa", "overlaps.paf"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
+    assert strip_timing(r.stdout.decode()) == meta["stdout"]
+    for f, digest in meta["md5"].items():
+        assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, (name, f)
+    if name == "s60_ultralong" and form == "windows":
+        form = "grouped"
+    assert f"input {form}" in r.stderr.decode(), r.stderr.decode()

@@ -16,6 +16,12 @@ python bench.py --input columns --handover --force-bucket --no-cpu-baseline --no
 tools/pass_timeline.sh ${TAG}_tl412 --reads 412500 > gpurun_out/$TAG/pass_timeline_slice412k.txt 2>&1
 tools/pass_timeline.sh ${TAG}_tlul --workload ultralong > gpurun_out/$TAG/pass_timeline_ultralong.txt 2>&1
 tools/profile_round.sh ${TAG}_ul --workload ultralong > gpurun_out/$TAG/profile_round_ultralong.log 2>&1
-python tools/pipe_trace.py 2> gpurun_out/$TAG/pipeline_trace.txt
+python tools/pipe_trace.py 3300000 0 grouped 2> gpurun_out/$TAG/pipeline_trace.txt
+# window records (one word per record, read ids derived in the pileup kernel): the pass as a headline of its own, stamps, counters, pipeline
+python bench.py --input windows --cov-width 1 --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg > gpurun_out/$TAG/bench_windows_w1.json 2> gpurun_out/$TAG/bench_windows_w1.err
+python bench.py --input windows --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg > gpurun_out/$TAG/bench_windows_w4.json 2> gpurun_out/$TAG/bench_windows_w4.err
+python tools/stamp_probe.py 3300000 windows > gpurun_out/$TAG/stamp_probe_windows.txt 2>&1
+tools/profile_round.sh ${TAG}_win --input windows --cov-width 1 > gpurun_out/$TAG/profile_round_windows.log 2>&1
+python tools/pipe_trace.py 3300000 0 windows 2> gpurun_out/$TAG/pipeline_trace_windows.txt
 python tools/pcie_duplex.py > gpurun_out/$TAG/pcie_duplex.txt 2>&1
 tail -3 gpurun_out/$TAG/profile_round.log; grep -E "SQ_INSTS|SQ_WAIT_ANY|SQ_WAVE_CYCLES|BANK_CONFLICT|IDX_ACTIVE" gpurun_out/$TAG/sq_counters.txt | head -20

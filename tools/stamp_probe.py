@@ -17,10 +17,19 @@ from raft_amd.synth import make_overlaps
 
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 o = make_overlaps(reads, mean_len=30000.0, coverage=32.0, seed=7, device="cuda:0")
-eng = engine.Engine(RaftParams(est_cov=32))
+mode = sys.argv[2] if len(sys.argv) > 2 else "columns"       # columns | windows (window records: pileup_fast.hpp IN = 1)
+eng = engine.Engine(RaftParams(est_cov=32, symmetric_mode=1 if mode == "windows" else -1))
 eng.set_tuning(0, False, 3)
+if mode == "windows":
+    from raft_amd import hostio
+    off = torch.as_tensor(hostio.group_offsets(reads, o.qid.cpu().numpy())).to("cuda:0")
+    win = torch.as_tensor(hostio.pack_windows(o.qs.cpu().numpy(), o.qe.cpu().numpy(), 50).view(np.int32)).to("cuda:0")
 for _ in range(2):
-    eng.run_device(o.read_len, *o.columns()); s = eng.finish()
+    if mode == "windows":
+        eng.run_device_windows(o.read_len, off, win)
+    else:
+        eng.run_device(o.read_len, *o.columns())
+    s = eng.finish()
 st = eng.debug_stamps().astype(np.int64)
 pile, tot = eng.timing()
 ok = (st[:, 7] > 0) & (np.diff(st[:, :8], axis=1) >= 0).all(axis=1)   # tiles the regular instantiation processed in full
