@@ -411,22 +411,29 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                 int bnd[NSEG];
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) bnd[s] = (lane < nr) ? so_base[s * TABW + lane + 1] - so_base[s * TABW] : 0x7fffffff;
-                const bool wide = nr > 64;
+                if (nr > 64) {                       // more reads than a wave has lanes for their boundaries: the table
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int s = u % NSEG;
-                    const int i0 = (u / NSEG) * 256 + wid * 64;       // the wave's first record of this slot (in run s, from the tile's first)
-                    if (cur.cnt[s] > i0) {
-                        int j;
-                        if (wide) j = find_j(s, min(i0 + lane, cur.cnt[s] - 1));
-                        else {
-                            // reads of the wave's first and last record: boundaries at or before them, counted by ballot
+                    for (int u = 0; u < U; ++u) {
+                        const int s = u % NSEG, i0 = (u / NSEG) * 256 + wid * 64;
+                        if (cur.cnt[s] > i0) one_w(find_j(s, min(i0 + lane, cur.cnt[s] - 1)), (unsigned)g.st[u]);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int s = u % NSEG;
+                        const int i0 = (u / NSEG) * 256 + wid * 64;   // the wave's first record of this slot (in run s, from the tile's first)
+                        if (cur.cnt[s] > i0) {
+                            // reads of the wave's first and last record: boundaries at or before them, counted by ballot; the
+                            // boundaries between decide the lanes (the first two without a loop: 64 records rarely span more than
+                            // three reads.  One ballot and a loop that ends at the first boundary past the wave's last record
+                            // instead of the second ballot: measured the same)
                             const int i_last = min(i0 + 63, cur.cnt[s] - 1);
-                            const int jf = (int)__popcll(__ballot(bnd[s] <= i0)), jl = (int)__popcll(__ballot(bnd[s] <= i_last));
-                            j = jf;
-                            for (int t = jf; t < jl; ++t) j += (i0 + lane >= __builtin_amdgcn_readlane(bnd[s], t)) ? 1 : 0;
+                            const unsigned jf = (unsigned)__popcll(__ballot(bnd[s] <= i0)), jl = (unsigned)__popcll(__ballot(bnd[s] <= i_last));
+                            const int b1 = __builtin_amdgcn_readlane(bnd[s], (int)min(jf, 63u)), b2 = __builtin_amdgcn_readlane(bnd[s], (int)min(jf + 1u, 63u));
+                            int j = (int)jf + ((jf < jl && i0 + lane >= b1) ? 1 : 0) + ((jf + 1u < jl && i0 + lane >= b2) ? 1 : 0);
+                            for (unsigned t = jf + 2u; t < jl; ++t) j += (i0 + lane >= __builtin_amdgcn_readlane(bnd[s], (int)t)) ? 1 : 0;
+                            one_w(j, (unsigned)g.st[u]);
                         }
-                        one_w(j, (unsigned)g.st[u]);
                     }
                 }
                 if (cur.more) {                      // records beyond the prefetched slots (dense tiles): synchronous loads
