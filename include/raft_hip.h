@@ -220,19 +220,39 @@ int  raft_hip_fetch_packed_w(raft_hip_ctx *ctx, int32_t width, int64_t *cov_offs
                              int64_t *exc_index, int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s,
                              int32_t *rep_e, int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end);
 
+/* "delta4": four bits per window.  Once the records cross PCIe as one word each (raft_hip_run_*_windows), the coverage
+ * array is two thirds of a job's bytes, and it barely moves from one window to the next -- the step cov[w] - cov[w-1] is
+ * the pileup's own difference array, within +-7 for 99.8 % of the windows of a 32x set.  Over the concatenated array
+ * cov[0 .. n_bins) (cov[-1] = 0):
+ *     cov_nib[w >> 1], low nibble = even w:  step + 8 for a step in [-7, 7], 0 = escape
+ *     (exc_index, exc_value), ascending:      every escaped window with its ABSOLUTE value (large steps -- mostly where one
+ *                                             read ends and the next begins -- and each pileup tile's first window)
+ *     cov_anchor[k] = cov[1024 k - 1]:        a decoder starts at any multiple of 1024 windows (cov_anchor[0] = 0; where
+ *                                             window 1024 k itself is escaped the entry is not needed and may be 0)
+ * cov_nib holds (n_bins + 1) / 2 bytes, cov_anchor (n_bins + 1023) / 1024 entries.  raft_host_unpack_coverage_d4 /
+ * raft_host_write_coverage_d4 decode it; exceptions and the size query behave as in raft_hip_fetch_packed. */
+#define RAFT_HIP_COV_DELTA4 8
+int  raft_hip_fetch_delta4(raft_hip_ctx *ctx, int64_t *cov_offset, uint8_t *cov_nib, int32_t *cov_anchor, int64_t exc_cap,
+                           int64_t *exc_index, int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s,
+                           int32_t *rep_e, int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end);
+
 /* Output width of the context's later passes: 4 (the default) -- cov[] is written as int32; 1 or 2 -- the pileup kernel
  * writes the transfer encoding above directly (four fifths of a pass's HBM traffic is this array, and its consumer,
  * repeat.hpp:105-108, is a text formatter) and the int32 array exists only if somebody asks for it: raft_hip_fetch() and
  * raft_hip_outputs_device() decode it on the device at their first call, raft_hip_fetch_packed_w() of the same width is a
  * plain copy, raft_hip_packed_device() hands out the device arrays.  Results are the same in every width; a width whose
  * limit most windows reach (width 1 on a 60x set) costs a second pass, because the list of exceptions is sized for the
- * usual case first.  The host pipelines below set the width their caller's buffers ask for by themselves. */
+ * usual case first.  The host pipelines below set the width their caller's buffers ask for by themselves.
+ * width = RAFT_HIP_COV_DELTA4: the pileup kernel writes the four-bit step encoding above (raft_hip_fetch_delta4 is then a
+ * plain copy). */
 int  raft_hip_set_output_width(raft_hip_ctx *ctx, int32_t width);
 
 /* Device arrays of the encoding the finished pass holds (width 0: none -- the pass wrote int32; call
  * raft_hip_fetch_packed_w once to have it encoded).  The exceptions are in no particular order. */
 int  raft_hip_packed_device(raft_hip_ctx *ctx, int32_t *width, const void **cov_packed, const int64_t **exc_index,
                             const int32_t **exc_value, int64_t *n_exc);
+/* ... and the block anchors when that encoding is delta4 (width RAFT_HIP_COV_DELTA4; NULL / 0 otherwise). */
+int  raft_hip_packed_anchor_device(raft_hip_ctx *ctx, const int32_t **cov_anchor, int64_t *n_anchor);
 
 /* Caller-owned host arrays (page-locked for full PCIe rate) that receive the outputs of raft_hip_run_pipelined, with
  * their capacities in elements.  Upper bounds the caller can compute from read_len alone, with W = sum ceil(len/reso)

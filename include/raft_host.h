@@ -82,6 +82,14 @@ int            raft_host_paf_symmetric(const raft_host_paf *p);
 int raft_host_group_offsets(int32_t n_reads, int64_t n_rec, const int32_t *qid, int32_t max_runs, int32_t *n_runs,
                             int64_t *rec_offset);
 
+/* ... and in the four-bit step encoding (include/raft_hip.h, cov_width = RAFT_HIP_COV_DELTA4): nib[] holds a step + 8 per
+ * window (low nibble = even window) or 0 for a window listed with its value, anchor[k] = cov[1024 k - 1].  exc_index must
+ * be ascending (as the engine hands it out). */
+int raft_host_unpack_coverage_d4(int64_t n_bins, const uint8_t *nib, const int32_t *anchor, int64_t n_exc, const int64_t *exc_index,
+                                 const int32_t *exc_value, int32_t *cov);
+int raft_host_write_coverage_d4(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset, const uint8_t *nib,
+                                const int32_t *anchor, int64_t n_exc, const int64_t *exc_index, const int32_t *exc_value);
+
 /* Window records for raft_hip_run_*_windows (include/raft_hip.h): win[i] = first | last1 << 16 with first = qs / reso and
  * last1 = (qe - 1) / reso + 1 -- the windows profileCoverage adds the interval to (repeat.hpp:69-72) -- or 0 for an
  * interval without windows (qe == 0, or last1 <= first).  The integer divisions of the pileup, done where the

@@ -76,6 +76,7 @@ void launch_fast_variant(int variant, int ow, bool ls, bool win, hipStream_t st,
 {
     if (win) {                                                // window records (pileup_fast.hpp IN = 1): the default configuration (and its diagnostic build)
         if (variant == kDiagVariant && EXTRA == 0) launch_fast<7936, 4, true, 6, 0, 4, false, 1>(st, grid, n_seg, cuts, pa);
+        else if (ow == kCovDelta4) launch_fast<7936, 4, false, 6, EXTRA, kCovDelta4, false, 1>(st, grid, n_seg, cuts, pa);
         else if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1, false, 1>(st, grid, n_seg, cuts, pa);
         else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2, false, 1>(st, grid, n_seg, cuts, pa);
         else launch_fast<7936, 4, false, 6, EXTRA, 4, false, 1>(st, grid, n_seg, cuts, pa);
@@ -94,7 +95,8 @@ void launch_fast_variant(int variant, int ow, bool ls, bool win, hipStream_t st,
     } else if (variant == kDiagVariant && EXTRA == 0) {
         launch_fast<7936, 4, true, 6, 0, 4>(st, grid, n_seg, cuts, pa);
     } else {
-        if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1>(st, grid, n_seg, cuts, pa);
+        if (ow == kCovDelta4) launch_fast<7936, 4, false, 6, EXTRA, kCovDelta4>(st, grid, n_seg, cuts, pa);
+        else if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1>(st, grid, n_seg, cuts, pa);
         else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2>(st, grid, n_seg, cuts, pa);
         else launch_fast<7936, 4, false, 6, EXTRA, 4>(st, grid, n_seg, cuts, pa);
     }
@@ -264,6 +266,7 @@ struct raft_hip_ctx {
     DevBuf exp_qid, in_off;            // grouped input without a query column: the ids rebuilt from the offsets; staged offsets
     DevBuf m_off;                      // grouped input of more than kMaxSeg runs: offsets of the merged run
     DevBuf u_s, u_e;                   // window records unpacked for the passes that need coordinate columns
+    DevBuf cov_anchor, abs_bits;       // delta4 encoding of cov[] (pack.hpp): block anchors; escape flags of the device-side decoder
     DevBuf x_qs, x_qe, x_off, x_raw, x_send_off, x_cnt;   // pre-split exchange (raft_hip_exchange*): what this rank received / staged
 
     // state of the last pass
@@ -361,7 +364,7 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     apply_params(c, params);
     if (const char *w = getenv("RAFT_COV_WIDTH")) {           // (test sweeps: every context of the process in that width)
         const int v = atoi(w);
-        if (v == 1 || v == 2 || v == 4) c->out_width = v;
+        if (v == 1 || v == 2 || v == 4 || v == kCovDelta4) c->out_width = v;
     }
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -397,7 +400,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -538,7 +541,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
 
     // the encoding of cov[] is written directly when every tile goes through the fast kernel (pileup_fast.hpp OW); a pass
     // the general kernel takes part in writes int32 and raft_hip_fetch_packed_w encodes it afterwards, as it always did
-    const int ow = (c->out_width != 4 && recut && c->variant != kDiagVariant) ? c->out_width : 4;
+    // (delta4: the default configuration's instantiations only; elsewhere the pass writes int32 and is encoded afterwards)
+    const bool d4_ok = c->variant == kDefaultVariant && !ls_rows;
+    const int ow = (c->out_width != 4 && recut && c->variant != kDiagVariant && (c->out_width != kCovDelta4 || d4_ok)) ? c->out_width : 4;
     // a grouped pass whose caller announced the window count needs nothing back from the device on the way
     const bool no_wait = grouped && in.hint_bins >= 0 && getenv("RAFT_NO_HINT") == nullptr;
     c->no_wait = no_wait;
@@ -645,6 +650,10 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
 
     if (ow == 4) HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
     else {
+        if (ow == kCovDelta4) {
+            HIP_TRY(c, c->cov8.ensure((size_t)std::max(B, 1LL) / 2 + 16));
+            HIP_TRY(c, c->cov_anchor.ensure(((size_t)std::max(B, 1LL) / kD4Block + 2) * 4));
+        } else
         HIP_TRY(c, c->cov8.ensure((size_t)std::max(B, 1LL) * (size_t)ow + 16));
         const long long cap = std::max<long long>(c->exc_cap, std::max<long long>(4096, B / 64));
         HIP_TRY(c, c->exc_idx.ensure((size_t)cap * 8));
@@ -730,6 +739,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     pa.reso = c->prm.reso; pa.high_cov = c->high_cov; pa.repeat_length = c->prm.repeat_length; pa.flank = c->prm.flanking_length;
     pa.cov = ow == 4 ? c->cov.as<int32_t>() : nullptr;
     pa.covp = ow == 4 ? nullptr : c->cov8.p; pa.n_exc = &ctrl->n_exc; pa.exc_cap = c->exc_cap;
+    pa.cov_anchor = ow == kCovDelta4 ? c->cov_anchor.as<int32_t>() : nullptr;
     pa.exc_idx = c->exc_idx.as<long long>(); pa.exc_val = c->exc_val.as<int32_t>();
     pa.rep_res_off = c->rep_res_off.as<long long>(); pa.rep_cnt = c->rep_cnt.as<int32_t>();
     pa.raw_key = c->raw_key.as<int32_t>(); pa.raw_s = c->raw_s.as<int32_t>(); pa.raw_e = c->raw_e.as<int32_t>();
@@ -1075,6 +1085,20 @@ static int materialise_cov(raft_hip_ctx *c)
     HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
     if (B > 0) {
         const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((B / 4 + 255) / 256, 256 * 16));
+        if (c->pass_width == kCovDelta4) {
+            HIP_TRY(c, c->abs_bits.ensure(((size_t)B / 32 + 2) * 4));
+            hipLaunchKernelGGL(delta4_expand_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>((B / 32 + 255) / 256, 256 * 16))), dim3(256), 0, c->stream,
+                               c->cov8.as<uint8_t>(), B, c->cov.as<int32_t>(), c->abs_bits.as<unsigned>());
+            if (c->n_exc > 0)
+                hipLaunchKernelGGL(scatter_exceptions_kernel, dim3((unsigned)std::min<long long>((c->n_exc + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                                   c->exc_idx.as<long long>(), c->exc_val.as<int32_t>(), c->n_exc, c->cov.as<int32_t>());
+            hipLaunchKernelGGL(delta4_walk_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>((B / kD4Block + 255) / 256, 256 * 16))), dim3(256), 0, c->stream,
+                               B, c->cov_anchor.as<int32_t>(), c->abs_bits.as<unsigned>(), c->cov.as<int32_t>());
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->cov_valid = true;
+            return RAFT_HIP_OK;
+        }
         if (c->pass_width == 1) hipLaunchKernelGGL(unpack_cov_kernel<uint8_t>, dim3(grid), dim3(256), 0, c->stream, c->cov8.as<uint8_t>(), B, c->cov.as<int32_t>());
         else hipLaunchKernelGGL(unpack_cov_kernel<uint16_t>, dim3(grid), dim3(256), 0, c->stream, c->cov8.as<uint16_t>(), B, c->cov.as<int32_t>());
         if (c->n_exc > 0)
@@ -1089,7 +1113,7 @@ static int materialise_cov(raft_hip_ctx *c)
 
 int raft_hip_set_output_width(raft_hip_ctx *c, int32_t width)
 {
-    if (!c || (width != 1 && width != 2 && width != 4)) return RAFT_HIP_ERR_PARAM;
+    if (!c || (width != 1 && width != 2 && width != 4 && width != kCovDelta4)) return RAFT_HIP_ERR_PARAM;
     c->out_width = width;
     return RAFT_HIP_OK;
 }
@@ -1105,6 +1129,16 @@ int raft_hip_packed_device(raft_hip_ctx *c, int32_t *width, const void **cov_pac
     if (exc_index) *exc_index = have ? c->exc_idx.as<int64_t>() : nullptr;
     if (exc_value) *exc_value = have ? c->exc_val.as<int32_t>() : nullptr;
     if (n_exc) *n_exc = have ? c->n_exc : 0;
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_packed_anchor_device(raft_hip_ctx *c, const int32_t **cov_anchor, int64_t *n_anchor)
+{
+    if (!c || !cov_anchor) return RAFT_HIP_ERR_PARAM;
+    if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
+    const bool have = c->packed_width == kCovDelta4;
+    *cov_anchor = have ? c->cov_anchor.as<int32_t>() : nullptr;
+    if (n_anchor) *n_anchor = have ? (c->sum.n_bins + kD4Block - 1) / kD4Block : 0;
     return RAFT_HIP_OK;
 }
 
@@ -1152,9 +1186,11 @@ static int pack_coverage(raft_hip_ctx *c, int width)
     HIP_TRY(c, hipSetDevice(c->device));
     { const int rc = materialise_cov(c); if (rc != RAFT_HIP_OK) return rc; }   // (a pass that wrote the other width)
     const long long B = c->sum.n_bins;
-    HIP_TRY(c, c->cov8.ensure((size_t)std::max(B, 1LL) * (size_t)width + 16));
+    const bool d4 = width == kCovDelta4;
+    HIP_TRY(c, c->cov8.ensure(d4 ? (size_t)std::max(B, 1LL) / 2 + 16 : (size_t)std::max(B, 1LL) * (size_t)width + 16));
+    if (d4) HIP_TRY(c, c->cov_anchor.ensure(((size_t)std::max(B, 1LL) / kD4Block + 2) * 4));
     HIP_TRY(c, c->exc_cnt.ensure(8));
-    long long cap = std::max<long long>(c->exc_cap, std::max<long long>(4096, B / 512));
+    long long cap = std::max<long long>(c->exc_cap, std::max<long long>(4096, d4 ? B / 64 : B / 512));
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIP_TRY(c, c->exc_idx.ensure((size_t)cap * 8));
         HIP_TRY(c, c->exc_val.ensure((size_t)cap * 4));
@@ -1162,7 +1198,10 @@ static int pack_coverage(raft_hip_ctx *c, int width)
         HIP_TRY(c, hipMemsetAsync(c->exc_cnt.p, 0, 8, c->stream));
         if (B > 0) {
             const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((B / 4 + 1023) / 1024, 256 * 16));
-            if (width == 1) {
+            if (d4) {
+                Delta4Out po{c->cov8.as<uint8_t>(), c->cov_anchor.as<int32_t>(), c->exc_cnt.as<unsigned long long>(), cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>()};
+                hipLaunchKernelGGL(pack_delta4_kernel, dim3(grid), dim3(256), 0, c->stream, c->cov.as<int32_t>(), B, po);
+            } else if (width == 1) {
                 PackOut<uint8_t> po{c->cov8.as<uint8_t>(), c->exc_cnt.as<unsigned long long>(), cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>()};
                 hipLaunchKernelGGL(pack_cov_kernel<uint8_t>, dim3(grid), dim3(256), 0, c->stream, c->cov.as<int32_t>(), B, po);
             } else {
@@ -1182,19 +1221,21 @@ static int pack_coverage(raft_hip_ctx *c, int width)
     return RAFT_HIP_OK;
 }
 
-int raft_hip_fetch_packed_w(raft_hip_ctx *c, int32_t width, int64_t *cov_offset, void *cov_packed, int64_t exc_cap, int64_t *exc_index,
-                            int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
-                            int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end)
+static int fetch_packed_impl(raft_hip_ctx *c, int32_t width, int64_t *cov_offset, void *cov_packed, int32_t *cov_anchor, int64_t exc_cap, int64_t *exc_index,
+                             int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
+                             int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end)
 {
-    if (!c || !n_exc || (width != 1 && width != 2)) return RAFT_HIP_ERR_PARAM;
+    if (!c || !n_exc || (width != 1 && width != 2 && width != kCovDelta4)) return RAFT_HIP_ERR_PARAM;
     if (!c->finished || c->pending_err) return RAFT_HIP_ERR_STATE;
     { const int rc = pack_coverage(c, width); if (rc != RAFT_HIP_OK) return rc; }
     *n_exc = c->n_exc;
     // (*n_exc tells the caller what to provide; the size query -- every pointer NULL -- always succeeds)
     if (c->n_exc > exc_cap && (cov_packed || exc_index || exc_value)) return RAFT_HIP_ERR_TOO_LARGE;
     const size_t N1 = (size_t)c->sum.n_reads + 1;
+    const bool d4 = width == kCovDelta4;
     struct { void *dst; const void *src; size_t bytes; } job[] = {
-        {cov_packed, c->cov8.p, (size_t)c->sum.n_bins * (size_t)width}, {cov_offset, c->cov_off.p, N1 * 8},
+        {cov_packed, c->cov8.p, d4 ? ((size_t)c->sum.n_bins + 1) / 2 : (size_t)c->sum.n_bins * (size_t)width}, {cov_offset, c->cov_off.p, N1 * 8},
+        {d4 ? cov_anchor : nullptr, c->cov_anchor.p, (((size_t)c->sum.n_bins + kD4Block - 1) / kD4Block) * 4},
         {exc_index, c->exc_idx.p, (size_t)c->n_exc * 8}, {exc_value, c->exc_val.p, (size_t)c->n_exc * 4},
         {rep_offset, c->rep_off.p, N1 * 8}, {rep_s, c->rep_s.p, (size_t)c->sum.n_repeats * 4},
         {rep_e, c->rep_e.p, (size_t)c->sum.n_repeats * 4}, {frag_offset, c->frag_off.p, N1 * 8},
@@ -1211,6 +1252,24 @@ int raft_hip_fetch_packed_w(raft_hip_ctx *c, int32_t width, int64_t *cov_offset,
         for (size_t i = 0; i < ex.size(); ++i) { exc_index[i] = ex[i].first; exc_value[i] = ex[i].second; }
     }
     return RAFT_HIP_OK;
+}
+
+int raft_hip_fetch_packed_w(raft_hip_ctx *c, int32_t width, int64_t *cov_offset, void *cov_packed, int64_t exc_cap, int64_t *exc_index,
+                            int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
+                            int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end)
+{
+    if (width != 1 && width != 2) return RAFT_HIP_ERR_PARAM;
+    return fetch_packed_impl(c, width, cov_offset, cov_packed, nullptr, exc_cap, exc_index, exc_value, n_exc, rep_offset, rep_s, rep_e, frag_offset,
+                             frag_read, frag_begin, frag_end);
+}
+
+int raft_hip_fetch_delta4(raft_hip_ctx *c, int64_t *cov_offset, uint8_t *cov_nib, int32_t *cov_anchor, int64_t exc_cap, int64_t *exc_index,
+                          int32_t *exc_value, int64_t *n_exc, int64_t *rep_offset, int32_t *rep_s, int32_t *rep_e,
+                          int64_t *frag_offset, int32_t *frag_read, int32_t *frag_begin, int32_t *frag_end)
+{
+    if ((cov_nib != nullptr) != (cov_anchor != nullptr)) return RAFT_HIP_ERR_PARAM;
+    return fetch_packed_impl(c, kCovDelta4, cov_offset, cov_nib, cov_anchor, exc_cap, exc_index, exc_value, n_exc, rep_offset, rep_s, rep_e, frag_offset,
+                             frag_read, frag_begin, frag_end);
 }
 
 int raft_hip_fetch_packed(raft_hip_ctx *c, int64_t *cov_offset, uint8_t *cov8, int64_t exc_cap, int64_t *exc_index,

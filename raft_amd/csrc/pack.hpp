@@ -103,6 +103,96 @@ __global__ __launch_bounds__(256) void scatter_exceptions_kernel(const long long
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) cov[idx[i]] = val[i];
 }
 
+// ---- "delta4": four bits per window -----------------------------------------------------------------------------------
+// Once the records cross PCIe as one word each, the coverage array is two thirds of a job's bytes -- and it barely moves
+// from one window to the next (the difference array the pileup builds IS the step; 99.8 % of the steps of a 32x set lie
+// within +-7).  Encoding, over the concatenated array cov[0 .. B):
+//     nib[w]  (byte w >> 1, low nibble = even w)   step + 8 for a step cov[w] - cov[w-1] in [-7, 7] (cov[-1] = 0), 0 = escape
+//     exceptions (w, cov[w])                        the ABSOLUTE value of every escaped window, ascending when handed out
+//     anchor[k] = cov[1024 k - 1]  (anchor[0] = 0)  where a decoder may start: blocks of 1024 windows decode independently
+// The pileup kernel writes it directly (pileup_fast.hpp OW = kCovDelta4): a step is the LDS difference array's own value,
+// except at a tile's first window, whose predecessor another workgroup holds -- that window is always escaped.
+// Decoding (raft_host_unpack_coverage_d4 / unpack_delta4_kernel): v = anchor[k]; per window v = escape ? listed value : v + step.
+constexpr int kCovDelta4 = 8;     // width code of the encoding (raft_hip_set_output_width, raft_hip_host_outputs::cov_width)
+constexpr int kD4Block = 1024;
+
+struct Delta4Out {
+    uint8_t *nib;                 // ceil(B / 2) bytes (+ padding to a dword)
+    int32_t *anchor;              // ceil(B / 1024) entries
+    unsigned long long *n_exc;
+    long long exc_cap;
+    long long *exc_idx;
+    int32_t *exc_val;
+};
+
+__device__ __forceinline__ unsigned delta4_code(int step, int value, long long w, bool force, const Delta4Out &o)
+{
+    if (!force && (unsigned)(step + 7) <= 14u) return (unsigned)(step + 8);
+    const unsigned long long slot = atomicAdd(o.n_exc, 1ull);
+    if ((long long)slot < o.exc_cap) { o.exc_idx[slot] = w; o.exc_val[slot] = value; }
+    return 0u;
+}
+
+// int32 cov[] -> delta4 (after a pass that wrote int32: the general kernel took part, or the caller asked late)
+__global__ __launch_bounds__(256) void pack_delta4_kernel(const int32_t *__restrict__ cov, long long n_bins, Delta4Out o)
+{
+    const long long n4 = (n_bins + 3) >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
+        const long long w0 = g << 2;
+        int prev = w0 > 0 ? cov[w0 - 1] : 0;
+        if ((w0 & (kD4Block - 1)) == 0) o.anchor[w0 >> 10] = prev;
+        unsigned code = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (w0 + k < n_bins) {
+                const int v = cov[w0 + k];
+                code |= delta4_code(v - prev, v, w0 + k, false, o) << (4 * k);
+                prev = v;
+            }
+        }
+        reinterpret_cast<uint16_t *>(o.nib)[g] = (uint16_t)code;
+    }
+}
+
+// delta4 -> int32 cov[] on the device (tests, raft_hip_outputs_device after a pass that wrote the encoding): steps
+// widened, the listed windows overwritten with their values and flagged, then one thread per block of 1024 windows walks it.
+// Not a fast path: nothing in the product decodes on the device.
+__global__ __launch_bounds__(256) void delta4_expand_kernel(const uint8_t *__restrict__ nib, long long n_bins, int32_t *__restrict__ cov,
+                                                            unsigned *__restrict__ is_abs)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n32 = (n_bins + 31) >> 5;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n32; g += stride) {
+        unsigned esc = 0;
+        for (int k = 0; k < 32; ++k) {
+            const long long w = (g << 5) + k;
+            if (w < n_bins) {
+                const unsigned c = (nib[w >> 1] >> (4 * (w & 1))) & 15u;
+                cov[w] = c ? (int)c - 8 : 0;
+                if (!c) esc |= 1u << k;
+            }
+        }
+        is_abs[g] = esc;
+    }
+}
+
+__global__ __launch_bounds__(256) void delta4_walk_kernel(long long n_bins, const int32_t *__restrict__ anchor, const unsigned *__restrict__ is_abs,
+                                                          int32_t *__restrict__ cov)
+{
+    const long long n_blocks = (n_bins + kD4Block - 1) / kD4Block;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += stride) {
+        int v = anchor[b];
+        const long long w0 = b * kD4Block, w1 = min(n_bins, w0 + kD4Block);
+        for (long long w = w0; w < w1; ++w) {
+            const bool abs_v = (is_abs[w >> 5] >> (w & 31)) & 1u;    // (the listed value was scattered into cov[w] before this kernel)
+            v = abs_v ? cov[w] : v + cov[w];
+            cov[w] = v;
+        }
+    }
+}
+
 // chunked pipeline: read ids of a chunk's records are rebased to the chunk's first read
 __global__ __launch_bounds__(256) void rebase_ids_kernel(int32_t *ids, long long n, int32_t base)
 {

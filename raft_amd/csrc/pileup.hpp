@@ -114,6 +114,7 @@ struct PileupArgs {
     // pileup_fast_kernel instantiated with OW = 1 or 2 writes the transfer encoding of cov[] instead (pack.hpp: OW bytes per
     // window, min(cov, 255 / 65535), plus the list of the windows at or above that limit) and leaves `cov` alone
     void *covp;
+    int32_t *cov_anchor;          // OW = 8 (pack.hpp kCovDelta4, four bits per window): cov[1024 k - 1] per block of 1024 windows
     unsigned long long *n_exc;    // windows at or above the limit (counted even when the list is full)
     long long exc_cap;
     long long *exc_idx;

@@ -314,7 +314,24 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
             const int t_end = off0 + cur.nwin;           // one past the last valid slot (the sentinel slot)
             const int rows = (t_end + 1 + 255) >> 8;
             int32_t *const cov0 = OW == 4 ? a.cov + a0 : nullptr;
-            char *const covp0 = OW == 4 ? nullptr : reinterpret_cast<char *>(a.covp) + a0 * OW;   // slot p -> covp0 + p * OW
+            constexpr bool D4 = OW == 8;           // the four-bit step encoding (pack.hpp kCovDelta4): slot p -> nibble a0 + p
+            static_assert(!(D4 && LS), "the step encoding comes with the row-wise scan only");
+            char *const covp0 = OW == 4 ? nullptr : reinterpret_cast<char *>(a.covp) + (D4 ? a0 / 2 : a0 * OW);   // slot p -> covp0 + p * OW (D4: + p / 2)
+            // D4: a step is the difference array's own value -- except at the tile's first window, whose predecessor another
+            // workgroup holds: that window is always listed with its value.  A lane's four steps are one aligned ushort; the
+            // ushort a tile shares with its neighbour is updated with an and / or pair of atomics on its own nibbles.
+            auto d4_codes = [&](const int4 d, int c0, int c1, int c2, int c3, int p0, unsigned valid) -> unsigned {
+                unsigned code = 0;
+                const int dd[4] = {d.x, d.y, d.z, d.w}, cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((valid >> q) & 1u) {
+                        if (p0 + q != off0 && (unsigned)(dd[q] + 7) <= 14u) code |= (unsigned)(dd[q] + 8) << (4 * q);
+                        else note_exception(a, a0 + p0 + q, cc[q]);
+                    }
+                }
+                return code;
+            };
             constexpr unsigned kLimit = OW == 1 ? 255u : 65535u;
             FastTables tb{sm.roff[p], sm.rlen[p], sm.rcnt[p], sm.rres[p], sm.acc_rep};
 
@@ -704,8 +721,12 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                     // scalar base + this lane's 32-bit byte offset (the LDS address of the row): no 64-bit address arithmetic
                     if (OW == 4) *reinterpret_cast<int4 *>(reinterpret_cast<char *>(cov0) + (unsigned)p0 * 4u) = make_int4(c0, c1, c2, c3);
                     else if (OW == 1) *reinterpret_cast<unsigned *>(covp0 + (unsigned)p0) = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);
+                    else if (D4) {
+                        *reinterpret_cast<uint16_t *>(covp0 + ((unsigned)p0 >> 1)) = (uint16_t)d4_codes(d, c0, c1, c2, c3, p0, 15u);
+                        if ((((unsigned)a0 + (unsigned)p0) & 1023u) == 0u) a.cov_anchor[(a0 + p0) >> 10] = excl;
+                    }
                     else *reinterpret_cast<uint2 *>(covp0 + (unsigned)p0 * 2u) = make_uint2(k0 | (k1 << 16), k2 | (k3 << 16));
-                    if (big) {
+                    if (big && !D4) {
                         if ((unsigned)c0 >= kLimit) note_exception(a, a0 + p0, c0);
                         if ((unsigned)c1 >= kLimit) note_exception(a, a0 + p0 + 1, c1);
                         if ((unsigned)c2 >= kLimit) note_exception(a, a0 + p0 + 2, c2);
@@ -723,6 +744,22 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                             if (v1) cov0[p0 + 1] = c1;
                             if (v2) cov0[p0 + 2] = c2;
                             if (v3) cov0[p0 + 3] = c3;
+                        }
+                    } else if (D4) {
+                        const unsigned valid = (v0 ? 1u : 0u) | (v1 ? 2u : 0u) | (v2 ? 4u : 0u) | (v3 ? 8u : 0u);
+                        if (valid) {
+                            const unsigned code = d4_codes(d, c0, c1, c2, c3, p0, valid);
+                            char *const o = covp0 + ((unsigned)p0 >> 1);
+                            if (valid == 15u) *reinterpret_cast<uint16_t *>(o) = (uint16_t)code;
+                            else {      // the neighbouring tile owns the other nibbles of this ushort: clear mine, then set them
+                                const unsigned mask = (v0 ? 0xFu : 0u) | (v1 ? 0xF0u : 0u) | (v2 ? 0xF00u : 0u) | (v3 ? 0xF000u : 0u);
+                                const unsigned long long addr = reinterpret_cast<unsigned long long>(o);
+                                unsigned *const word = reinterpret_cast<unsigned *>(addr & ~3ull);
+                                const unsigned sh = (unsigned)(addr & 2ull) * 8u;
+                                atomicAnd(word, ~(mask << sh));
+                                atomicOr(word, (code & mask) << sh);
+                            }
+                            if (v0 && (((unsigned)a0 + (unsigned)p0) & 1023u) == 0u) a.cov_anchor[(a0 + p0) >> 10] = excl;
                         }
                     } else if (OW == 1) {
                         uint8_t *const o = reinterpret_cast<uint8_t *>(covp0) + p0;
@@ -743,7 +780,7 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                             if (v3) o[3] = (uint16_t)k3;
                         }
                     }
-                    if (big) {
+                    if (big && !D4) {
                         if (v0 && (unsigned)c0 >= kLimit) note_exception(a, a0 + p0, c0);
                         if (v1 && (unsigned)c1 >= kLimit) note_exception(a, a0 + p0 + 1, c1);
                         if (v2 && (unsigned)c2 >= kLimit) note_exception(a, a0 + p0 + 2, c2);

@@ -28,6 +28,7 @@ EXPORTS = (
     "raft_hip_run_multi_grouped", "raft_hip_host_register", "raft_hip_host_unregister", "raft_hip_comm_unique_id",
     "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local", "raft_hip_warm_up", "raft_hip_reserve",
     "raft_hip_run_device_windows", "raft_hip_run_host_windows", "raft_hip_run_multi_windows",
+    "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device",
 )
 
 
@@ -143,6 +144,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_run_device_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, vp, i64]
     lib.raft_hip_run_host_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, i64]
     lib.raft_hip_run_multi_grouped.argtypes = [C.POINTER(vp), i32, i32, vp, i64, i32, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
+    lib.raft_hip_fetch_delta4.argtypes = [vp, vp, vp, vp, i64, vp, vp, C.POINTER(i64)] + [vp] * 7
+    lib.raft_hip_packed_anchor_device.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     lib.raft_hip_run_device_windows.argtypes = [vp, i32, vp, i64, i32, vp, vp, i64]
     lib.raft_hip_run_host_windows.argtypes = [vp, i32, vp, i64, i32, vp, vp, i64]
     lib.raft_hip_run_multi_windows.argtypes = [C.POINTER(vp), i32, i32, vp, i64, i32, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
@@ -229,20 +232,21 @@ class Engine:
         self._check(self._lib.raft_hip_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     # -- passes -----------------------------------------------------------------
-    def run_device(self, read_len, qid, qs, qe, tid, ts, te):
-        """Inputs: int32 torch tensors on this engine's device (kept alive until the next pass)."""
+    def run_device(self, read_len, qid, qs, qe, tid=None, ts=None, te=None):
+        """Inputs: int32 torch tensors on this engine's device (kept alive until the next pass); tid / ts / te may be None when
+        the params assert symmetric_mode = 1."""
         import torch
         cols = (read_len, qid, qs, qe, tid, ts, te)
         for t in cols:
-            if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+            if t is not None and (t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous()):
                 raise TypeError("run_device needs contiguous int32 CUDA tensors")
         n_rec = int(qid.numel())
         for t in cols[2:]:
-            if int(t.numel()) != n_rec:
+            if t is not None and int(t.numel()) != n_rec:
                 raise ValueError("PAF columns differ in length")
         self._keep = cols
         self.use_torch_stream()     # the tensors were produced on torch's current stream: order after it
-        ptr = [C.c_void_p(t.data_ptr() if t.numel() else 0) for t in cols]
+        ptr = [C.c_void_p(t.data_ptr() if (t is not None and t.numel()) else 0) for t in cols]
         self._check(self._lib.raft_hip_run_device(self._ctx, int(read_len.numel()), ptr[0], n_rec, *ptr[1:]))
 
     def run_device_grouped(self, read_len, rec_offset, qid, qs, qe, n_bins: int = -1):
@@ -508,6 +512,37 @@ class Engine:
                                                       ptr["frag_offset"], ptr["frag_read"], ptr["frag_begin"], ptr["frag_end"]))
         return res
 
+    def fetch_delta4(self, pinned: bool = False, out: dict | None = None) -> dict:
+        """Host copies with the coverage array in the four-bit step encoding (raft_hip_fetch_delta4): ``cov_nib`` (uint8,
+        two windows per byte), ``cov_anchor`` (int32 per 1024 windows), ``exc_index`` / ``exc_value`` (ascending; ABSOLUTE values
+        of the escaped windows), and the repeat / fragment tables.  ``hostio.unpack_coverage_d4`` restores the int32 array."""
+        s = self.summary
+        n1 = s.n_reads + 1
+        n_exc = C.c_int64(0)
+        none = [C.c_void_p(0)] * 7
+        self._check(self._lib.raft_hip_fetch_delta4(self._ctx, None, None, None, 0, None, None, C.byref(n_exc), *none))
+        spec = {"cov_offset": (n1, np.int64), "cov_nib": ((s.n_bins + 1) // 2, np.uint8), "cov_anchor": ((s.n_bins + 1023) // 1024, np.int32),
+                "exc_index": (n_exc.value, np.int64), "exc_value": (n_exc.value, np.int32), "rep_offset": (n1, np.int64),
+                "rep_s": (s.n_repeats, np.int32), "rep_e": (s.n_repeats, np.int32), "frag_offset": (n1, np.int64),
+                "frag_read": (s.n_fragments, np.int32), "frag_begin": (s.n_fragments, np.int32), "frag_end": (s.n_fragments, np.int32)}
+
+        def alloc(n, dt):
+            if pinned and n:
+                import torch
+                tdt = {np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8}[dt]
+                return torch.empty(int(n), dtype=tdt, pin_memory=True).numpy()
+            return np.empty(n, dt)
+
+        res = {}
+        for key, (n, dt) in spec.items():
+            have = out.get(key) if out else None
+            res[key] = have[:n] if (have is not None and have.dtype == dt and have.size >= n and have.flags["C_CONTIGUOUS"]) else alloc(n, dt)
+        ptr = {k: C.c_void_p(res[k].ctypes.data if res[k].size else 0) for k in res}
+        self._check(self._lib.raft_hip_fetch_delta4(self._ctx, ptr["cov_offset"], ptr["cov_nib"], ptr["cov_anchor"], n_exc.value, ptr["exc_index"],
+                                                    ptr["exc_value"], C.byref(n_exc), ptr["rep_offset"], ptr["rep_s"], ptr["rep_e"],
+                                                    ptr["frag_offset"], ptr["frag_read"], ptr["frag_begin"], ptr["frag_end"]))
+        return res
+
     def debug_stamps(self, max_tiles: int = 1 << 20) -> np.ndarray:
         """Diagnostic kernel variant 3: per-tile s_memtime stamps [n, 16] of the last pass."""
         n = C.c_int64()
@@ -552,6 +587,12 @@ class Engine:
             if count == 0:
                 return torch.empty(0, dtype=dt, device=dev)
             return torch.as_tensor(_DevArray(ptr.value, count, ts, self), device=dev)
+        if w.value == 8:                      # delta4: two windows per byte + block anchors
+            an, na = C.c_void_p(), C.c_int64(0)
+            self._check(self._lib.raft_hip_packed_anchor_device(self._ctx, C.byref(an), C.byref(na)))
+            return {"width": 8, "cov_nib": view(codes, (self.summary.n_bins + 1) // 2, "|u1", torch.uint8),
+                    "cov_anchor": view(an, na.value, "<i4", torch.int32),
+                    "exc_index": view(ei, n.value, "<i8", torch.int64), "exc_value": view(ev, n.value, "<i4", torch.int32)}
         return {"width": w.value,
                 "cov8": view(codes, self.summary.n_bins, "|u1" if w.value == 1 else "<i2", torch.uint8 if w.value == 1 else torch.int16),
                 "exc_index": view(ei, n.value, "<i8", torch.int64), "exc_value": view(ev, n.value, "<i4", torch.int32)}

@@ -926,6 +926,71 @@ int64_t raft_host_paf_count(const raft_host_paf *p) { return p ? (int64_t)p->n :
 const int32_t *raft_host_paf_column(const raft_host_paf *p, int k) { return (p && k >= 0 && k < 6) ? p->col[k].get() : nullptr; }
 int raft_host_paf_symmetric(const raft_host_paf *p) { return p ? p->symmetric : 0; }
 
+// ---- the four-bit step encoding of the coverage array (include/raft_hip.h "delta4") ----
+namespace {
+struct D4Cursor {                 // walks the encoding forward from a block anchor
+    const uint8_t *nib; const int32_t *anchor; const int64_t *exc_index; const int32_t *exc_value; int64_t n_exc;
+    int64_t w = 0, x = 0;         // next window; next exception
+    long long v = 0;
+    void seek(int64_t to)         // position before window `to`: v = cov[to - 1]
+    {
+        const int64_t k = to >> 10;
+        w = k << 10; v = anchor[k];
+        x = n_exc ? std::lower_bound(exc_index, exc_index + n_exc, w) - exc_index : 0;
+        while (w < to) next();
+    }
+    inline long long next()
+    {
+        const unsigned c = (nib[w >> 1] >> (4 * (w & 1))) & 15u;
+        if (c) v += (long long)c - 8;
+        else { v = (x < n_exc && exc_index[x] == w) ? exc_value[x] : -1; ++x; }     // (-1: an escape without its entry -- checked by the unpacker)
+        ++w;
+        return v;
+    }
+};
+}
+
+int raft_host_unpack_coverage_d4(int64_t n_bins, const uint8_t *nib, const int32_t *anchor, int64_t n_exc, const int64_t *exc_index,
+                                 const int32_t *exc_value, int32_t *cov)
+{
+    if (n_bins < 0 || n_exc < 0 || (n_bins && (!nib || !anchor || !cov)) || (n_exc && (!exc_index || !exc_value))) return RAFT_HOST_ERR_ARG;
+    for (int64_t k = 0; k < n_exc; ++k)
+        if (exc_index[k] < 0 || exc_index[k] >= n_bins || (k && exc_index[k] <= exc_index[k - 1]) ||
+            ((nib[exc_index[k] >> 1] >> (4 * (exc_index[k] & 1))) & 15u) != 0u) return RAFT_HOST_ERR_ARG;
+    const int64_t n_blocks = (n_bins + 1023) >> 10;
+    const int T_ = n_bins < (1 << 22) ? 1 : host_threads();
+    std::vector<int> bad((size_t)T_, 0);
+    parallel_for(T_, [&](int t) {
+        const int64_t b0 = n_blocks * t / T_, b1 = n_blocks * (t + 1) / T_;
+        D4Cursor c{nib, anchor, exc_index, exc_value, n_exc};
+        for (int64_t b = b0; b < b1; ++b) {
+            c.seek(b << 10);
+            const int64_t hi = std::min<int64_t>(n_bins, (b + 1) << 10);
+            while (c.w < hi) { const int64_t at = c.w; const long long v = c.next(); if (v < 0) bad[(size_t)t] = 1; cov[at] = (int32_t)v; }
+        }
+    });
+    for (int b : bad) if (b) return RAFT_HOST_ERR_ARG;
+    return RAFT_HOST_OK;
+}
+
+int raft_host_write_coverage_d4(const char *path, int32_t n_reads, int32_t reso, const int64_t *cov_offset, const uint8_t *nib,
+                                const int32_t *anchor, int64_t n_exc, const int64_t *exc_index, const int32_t *exc_value)
+{
+    return write_ordered(path, n_reads, 1 << 20,
+                         [&](long long i) { return (long long)(cov_offset[i + 1] - cov_offset[i]) + 4; },
+                         [&](long long i, std::string &o) {
+                             o.append("read ", 5); put_num(o, i); o.push_back(' ');
+                             const int64_t b = cov_offset[i], e = cov_offset[i + 1];
+                             D4Cursor c{nib, anchor, exc_index, exc_value, n_exc};
+                             if (e > b) c.seek(b);
+                             for (int64_t j = b; j < e; ++j) {
+                                 const long long v = c.next();
+                                 put_num(o, (long long)(j - b) * reso); o.push_back(','); put_num(o, v); o.push_back(' ');
+                             }
+                             o.push_back('\n');
+                         });
+}
+
 int raft_host_unpack_coverage_w(int32_t width, int64_t n_bins, const void *cov_packed, int64_t n_exc, const int64_t *exc_index,
                                 const int32_t *exc_value, int32_t *cov)
 {

@@ -15,7 +15,8 @@ EXPORTS = ("raft_host_reads_load", "raft_host_reads_free", "raft_host_reads_coun
            "raft_host_write_fasta", "raft_host_set_threads", "raft_host_get_threads", "raft_host_split_naive",
            "raft_host_paf_symmetric", "raft_host_unpack_coverage", "raft_host_write_coverage_packed",
            "raft_host_unpack_coverage_w", "raft_host_write_coverage_packed_w", "raft_host_text_read", "raft_host_text_free",
-           "raft_host_paf_parse", "raft_host_group_offsets", "raft_host_pack_windows")
+           "raft_host_paf_parse", "raft_host_group_offsets", "raft_host_pack_windows", "raft_host_unpack_coverage_d4",
+           "raft_host_write_coverage_d4")
 
 
 class HostError(RuntimeError):
@@ -62,6 +63,8 @@ def load_library():
         lib.raft_host_write_coverage_packed_w.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp]
         lib.raft_host_get_threads.argtypes = []
         lib.raft_host_group_offsets.argtypes = [C.c_int32, C.c_int64, vp, C.c_int32, C.POINTER(C.c_int32), vp]
+        lib.raft_host_unpack_coverage_d4.argtypes = [C.c_int64, vp, vp, C.c_int64, vp, vp, vp]
+        lib.raft_host_write_coverage_d4.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp, vp, vp, C.c_int64, vp, vp]
         lib.raft_host_pack_windows.argtypes = [C.c_int64, vp, vp, C.c_int32, vp, C.POINTER(C.c_int64)]
         _lib = lib
     return _lib
@@ -211,6 +214,31 @@ def unpack_coverage(code, exc_index, exc_value):
     if rc != OK:
         raise HostError(rc, "unpack_coverage")
     return out
+
+
+def unpack_coverage_d4(n_bins: int, cov_nib, cov_anchor, exc_index, exc_value):
+    """raft_host_unpack_coverage_d4: the int32 coverage array from the four-bit step encoding."""
+    nib = np.ascontiguousarray(cov_nib, np.uint8)
+    an = np.ascontiguousarray(cov_anchor, np.int32)
+    xi, xv = np.ascontiguousarray(exc_index, np.int64), np.ascontiguousarray(exc_value, np.int32)
+    if nib.size < (n_bins + 1) // 2 or an.size < (n_bins + 1023) // 1024:
+        raise ValueError("unpack_coverage_d4: cov_nib / cov_anchor too short")
+    out = np.empty(n_bins, np.int32)
+    p = lambda x: C.c_void_p(x.ctypes.data if x.size else 0)
+    rc = load_library().raft_host_unpack_coverage_d4(int(n_bins), p(nib), p(an), xi.size, p(xi), p(xv), p(out))
+    if rc != OK:
+        raise HostError(rc, "unpack_coverage_d4")
+    return out
+
+
+def write_coverage_d4(path: str, n_reads: int, reso: int, cov_offset, cov_nib, cov_anchor, exc_index, exc_value):
+    co = np.ascontiguousarray(cov_offset, np.int64)
+    nib, an = np.ascontiguousarray(cov_nib, np.uint8), np.ascontiguousarray(cov_anchor, np.int32)
+    xi, xv = np.ascontiguousarray(exc_index, np.int64), np.ascontiguousarray(exc_value, np.int32)
+    p = lambda x: C.c_void_p(x.ctypes.data if x.size else 0)
+    rc = load_library().raft_host_write_coverage_d4(path.encode(), n_reads, reso, p(co), p(nib), p(an), xi.size, p(xi), p(xv))
+    if rc != OK:
+        raise HostError(rc, path)
 
 
 def write_coverage_packed(path: str, n_reads: int, reso: int, cov_offset, code, exc_index, exc_value):

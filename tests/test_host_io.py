@@ -439,3 +439,52 @@ def test_pack_windows(threads):
         assert w.base is out or w.ctypes.data == out.ctypes.data
     finally:
         hostio.set_threads(0)
+
+
+def encode_d4(cov, forced=()):
+    """numpy restatement of the four-bit step encoding (include/raft_hip.h "delta4"); `forced`: windows escaped regardless."""
+    cov = np.asarray(cov, np.int64)
+    step = np.diff(np.concatenate([[0], cov]))
+    code = np.where(np.abs(step) <= 7, step + 8, 0).astype(np.uint8)
+    code[list(forced)] = 0
+    exc = np.flatnonzero(code == 0)
+    pad = np.concatenate([code, np.zeros(len(code) & 1, np.uint8)])
+    nib = (pad[0::2] | (pad[1::2] << 4)).astype(np.uint8)
+    anchor = np.concatenate([[0], cov[1023::1024]])[: (len(cov) + 1023) // 1024].astype(np.int32)
+    return nib, anchor, exc.astype(np.int64), cov[exc].astype(np.int32)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_delta4_decoder_and_writer(tmp_path, threads):
+    """raft_host_unpack_coverage_d4 / raft_host_write_coverage_d4 against a numpy encoder: steps, escapes (large steps and
+    forced ones), anchors at block starts, odd lengths; the text equals the int32 writer's."""
+    hostio.set_threads(threads)
+    try:
+        rng = np.random.default_rng(31)
+        for n in (0, 1, 2, 1023, 1024, 1025, 5000, 5_000_001):
+            walk = rng.integers(-2, 3, n)
+            jumps = rng.random(n) < 0.002
+            walk[jumps] = rng.integers(-300, 300, int(jumps.sum()))
+            cov = np.abs(np.cumsum(walk)).astype(np.int32)
+            forced = rng.integers(0, n, min(n, 50)) if n else []
+            nib, anchor, xi, xv = encode_d4(cov, forced)
+            got = hostio.unpack_coverage_d4(n, nib, anchor, xi, xv)
+            assert np.array_equal(got, cov), n
+            if 0 < n <= 5000:
+                lens = rng.multinomial(n, np.ones(7) / 7)
+                off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+                hostio.write_coverage_d4(str(tmp_path / "d4.txt"), 7, 50, off, nib, anchor, xi, xv)
+                code, ei, ev = hostio.pack_coverage(cov, 2)
+                hostio.write_coverage_packed(str(tmp_path / "ref.txt"), 7, 50, off, code, ei, ev)
+                assert open(tmp_path / "d4.txt", "rb").read() == open(tmp_path / "ref.txt", "rb").read()
+        # an escape without its entry, an entry on a window that is not escaped: rejected
+        cov = np.arange(3000, dtype=np.int32) * 9
+        nib, anchor, xi, xv = encode_d4(cov)
+        with pytest.raises(hostio.HostError):
+            hostio.unpack_coverage_d4(3000, nib, anchor, xi[:-1], xv[:-1])
+        cov2 = np.zeros(3000, np.int32)
+        nib, anchor, _, _ = encode_d4(cov2)
+        with pytest.raises(hostio.HostError):
+            hostio.unpack_coverage_d4(3000, nib, anchor, np.array([5], np.int64), np.array([1], np.int32))
+    finally:
+        hostio.set_threads(0)
