@@ -12,7 +12,7 @@ from raft_amd.params import RaftParams
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "raft_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(raft_hip_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(raft_hip_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():

@@ -20,7 +20,7 @@ from test_oracle_golden import MAN, _micro_columns, _params_from_args, load_case
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "raft_host.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(raft_host_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(raft_host_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_host_library_exports_every_symbol():
