@@ -268,7 +268,11 @@ typedef struct raft_hip_host_outputs {
     int64_t *rep_offset;  int32_t *rep_s, *rep_e;               int64_t rep_cap;
     int64_t *frag_offset; int32_t *frag_begin, *frag_end;       int64_t frag_cap;
     int32_t cov_width;    /* bytes per window of the coverage encoding: 0 or 1 = one (cov8 as declared), 2 = cov8 points
-                             at cov8_cap uint16 codes (limit 65535; see raft_hip_fetch_packed_w) */
+                             at cov8_cap uint16 codes (limit 65535; see raft_hip_fetch_packed_w);
+                             RAFT_HIP_COV_DELTA4 = four-bit steps (see raft_hip_fetch_delta4): cov8 holds (cov8_cap + 1) / 2
+                             bytes, cov_anchor anchor_cap >= (W + 1023) / 1024 entries; exc_value are absolute values */
+    int32_t reserved;
+    int32_t *cov_anchor;  int64_t anchor_cap;
 } raft_hip_host_outputs;
 
 /* One end-to-end pass, host memory to host memory: raft_hip_run_host + raft_hip_finish + raft_hip_fetch_packed in one

@@ -7,6 +7,7 @@
 #include "device_scan.hpp"
 #include "finalize.hpp"
 #include "pack.hpp"
+#include <rocprim/device/device_radix_sort.hpp>   // (the exception list's order: a library sort of a few 1e5 pairs, off the hot path)
 #include "pileup.hpp"
 #include "pileup_fast.hpp"
 
@@ -267,6 +268,9 @@ struct raft_hip_ctx {
     DevBuf m_off;                      // grouped input of more than kMaxSeg runs: offsets of the merged run
     DevBuf u_s, u_e;                   // window records unpacked for the passes that need coordinate columns
     DevBuf cov_anchor, abs_bits;       // delta4 encoding of cov[] (pack.hpp): block anchors; escape flags of the device-side decoder
+    DevBuf exc_idx2, exc_val2, sort_tmp;   // the exception list in ascending order (sort_exceptions)
+    DevBuf exc_pidx, exc_pval;             // delta4: the windows each tile lists, kExcPerTile slots per tile (compact_exceptions_kernel)
+    bool exc_sorted = false;
     DevBuf x_qs, x_qe, x_off, x_raw, x_send_off, x_cnt;   // pre-split exchange (raft_hip_exchange*): what this rank received / staged
 
     // state of the last pass
@@ -400,7 +404,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->exc_idx2, &c->exc_val2, &c->sort_tmp, &c->exc_pidx, &c->exc_pval, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -527,7 +531,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         d_tid = d_qid; d_ts = d_qs; d_te = d_qe;
     }
     c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1; c->packed_width = 0;
-    c->cov_valid = false; c->pass_width = 4; c->n_exc = 0;
+    c->cov_valid = false; c->pass_width = 4; c->n_exc = 0; c->exc_sorted = false;
     c->args = in;
     const bool no_verify_env = getenv("RAFT_ALWAYS_INSPECT") != nullptr;   // (A/B measurements; bench.py times both forms)
     // (a detecting context assumes a symmetric PAF -- hifiasm's shape -- until a pass of its own has found otherwise)
@@ -740,6 +744,13 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     pa.cov = ow == 4 ? c->cov.as<int32_t>() : nullptr;
     pa.covp = ow == 4 ? nullptr : c->cov8.p; pa.n_exc = &ctrl->n_exc; pa.exc_cap = c->exc_cap;
     pa.cov_anchor = ow == kCovDelta4 ? c->cov_anchor.as<int32_t>() : nullptr;
+    const long long d4_tiles = n_tiles + extra_cap;          // (regular tiles, then the extra ones)
+    if (ow == kCovDelta4) {
+        HIP_TRY(c, c->exc_pidx.ensure((size_t)d4_tiles * kExcPerTile * 8));
+        HIP_TRY(c, c->exc_pval.ensure((size_t)d4_tiles * kExcPerTile * 4));
+        HIP_TRY(c, hipMemsetAsync(c->exc_pidx.p, 0xFF, (size_t)d4_tiles * kExcPerTile * 8, st));
+        pa.exc_pidx = c->exc_pidx.as<long long>(); pa.exc_pval = c->exc_pval.as<int32_t>();
+    }
     pa.exc_idx = c->exc_idx.as<long long>(); pa.exc_val = c->exc_val.as<int32_t>();
     pa.rep_res_off = c->rep_res_off.as<long long>(); pa.rep_cnt = c->rep_cnt.as<int32_t>();
     pa.raw_key = c->raw_key.as<int32_t>(); pa.raw_s = c->raw_s.as<int32_t>(); pa.raw_e = c->raw_e.as<int32_t>();
@@ -859,6 +870,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         launch_general<6144, 5>(st, pgrid, pa);
     }
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
+    if (ow == kCovDelta4)      // the windows the tiles listed, gathered into the shared list (whose counter the control block carries)
+        hipLaunchKernelGGL(compact_exceptions_kernel, dim3((unsigned)((d4_tiles + 255) / 256)), dim3(256), 0, st, d4_tiles, kExcPerTile,
+                           c->exc_pidx.as<long long>(), c->exc_pval.as<int32_t>(), &ctrl->n_exc, c->exc_cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>());
 
     // ---- per-read tail: order repeats, mask markers, fragments
     FinalizeArgs fa{};
@@ -1043,7 +1057,7 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
         if (c->pending_err == RAFT_HIP_OK) {
             Ctrl hc;
             memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));   // copied at the end of the pass
-            if (c->pass_width != 4) { c->n_exc = (long long)hc.n_exc; c->packed_width = c->pass_width; }
+            if (c->pass_width != 4) { c->n_exc = (long long)hc.n_exc; c->packed_width = c->pass_width; c->exc_sorted = false; }
             c->sum.n_repeats = hc.out_totals[0]; c->sum.n_cuts = hc.out_totals[1]; c->sum.n_fragments = hc.out_totals[2];
             if (c->sum.interval_path == 1) c->sum.n_intervals = hc.out_totals[3];
             c->sum.total_coverage = (long long)hc.totals[0];
@@ -1213,11 +1227,35 @@ static int pack_coverage(raft_hip_ctx *c, int width)
         long long *h = reinterpret_cast<long long *>(c->pinned) + 16;
         HIP_TRY(c, hipMemcpyAsync(h, c->exc_cnt.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->n_exc = *h;
+        c->n_exc = *h; c->exc_sorted = false;
         if (c->n_exc <= cap) break;
         cap = c->n_exc;                              // (rare) more windows at or above the limit than the list held: once more
     }
     c->packed_width = width;
+    return RAFT_HIP_OK;
+}
+
+// The kernels append exceptions in no particular order; callers get them ascending by window.  With a byte per window there
+// are none on a 32x set; the four-bit encoding lists 0.2-0.3 % of the windows (3.7e6 at human scale) and the host's
+// std::sort of a chunk's 3.4e5 pairs held its lane for 25 ms: sorted on the device (radix sort on the index bits in use).
+static int sort_exceptions(raft_hip_ctx *c)
+{
+    if (c->exc_sorted || c->n_exc < 2) { c->exc_sorted = true; return RAFT_HIP_OK; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->n_exc;
+    HIP_TRY(c, c->exc_idx2.ensure(std::max(n * 8, c->exc_idx.cap)));
+    HIP_TRY(c, c->exc_val2.ensure(std::max(n * 4, c->exc_val.cap)));
+    int bits = 1;
+    while (bits < 63 && (1LL << bits) <= std::max<long long>(c->sum.n_bins, 1)) ++bits;
+    size_t tmp = 0;
+    using Key = unsigned long long;           // (window indices are non-negative)
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, c->exc_idx.as<Key>(), c->exc_idx2.as<Key>(), c->exc_val.as<int32_t>(), c->exc_val2.as<int32_t>(), n, 0,
+                                         (unsigned)bits, c->stream));
+    HIP_TRY(c, c->sort_tmp.ensure(tmp));
+    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, c->exc_idx.as<Key>(), c->exc_idx2.as<Key>(), c->exc_val.as<int32_t>(), c->exc_val2.as<int32_t>(), n, 0,
+                                         (unsigned)bits, c->stream));
+    std::swap(c->exc_idx, c->exc_idx2); std::swap(c->exc_val, c->exc_val2);
+    c->exc_sorted = true;
     return RAFT_HIP_OK;
 }
 
@@ -1231,6 +1269,7 @@ static int fetch_packed_impl(raft_hip_ctx *c, int32_t width, int64_t *cov_offset
     *n_exc = c->n_exc;
     // (*n_exc tells the caller what to provide; the size query -- every pointer NULL -- always succeeds)
     if (c->n_exc > exc_cap && (cov_packed || exc_index || exc_value)) return RAFT_HIP_ERR_TOO_LARGE;
+    if (exc_index || exc_value) { const int rc = sort_exceptions(c); if (rc != RAFT_HIP_OK) return rc; }   // handed out ascending by window
     const size_t N1 = (size_t)c->sum.n_reads + 1;
     const bool d4 = width == kCovDelta4;
     struct { void *dst; const void *src; size_t bytes; } job[] = {
@@ -1244,13 +1283,6 @@ static int fetch_packed_impl(raft_hip_ctx *c, int32_t width, int64_t *cov_offset
     for (auto &j : job)
         if (j.dst && j.bytes) HIP_TRY(c, hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // the kernel appends exceptions in no particular order: hand them out ascending by window
-    if (exc_index && exc_value && c->n_exc > 1) {
-        std::vector<std::pair<int64_t, int32_t>> ex((size_t)c->n_exc);
-        for (size_t i = 0; i < ex.size(); ++i) ex[i] = {exc_index[i], exc_value[i]};
-        std::sort(ex.begin(), ex.end());
-        for (size_t i = 0; i < ex.size(); ++i) { exc_index[i] = ex[i].first; exc_value[i] = ex[i].second; }
-    }
     return RAFT_HIP_OK;
 }
 
@@ -1420,7 +1452,8 @@ static int run_monolithic_to_host(raft_hip_ctx *c, int32_t n_reads, const int32_
                                   const int64_t *rec_offset = nullptr, const uint32_t *win = nullptr)
 {
     const int keep_width = c->out_width;
-    c->out_width = o->cov_width == 2 ? 2 : 1;             // the pass writes the encoding the caller takes
+    const int width = o->cov_width == kCovDelta4 ? kCovDelta4 : (o->cov_width == 2 ? 2 : 1);
+    c->out_width = width;                                 // the pass writes the encoding the caller takes
     int rc = rec_offset ? run_host_grouped_impl(c, n_reads, read_len, n_rec, n_runs, rec_offset, qs, qe, win, -1)
                         : raft_hip_run_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te);
     raft_hip_summary s{};
@@ -1431,8 +1464,9 @@ static int run_monolithic_to_host(raft_hip_ctx *c, int32_t n_reads, const int32_
     if (rc != RAFT_HIP_OK) return rc;
     if (s.n_bins > o->cov8_cap || s.n_repeats > o->rep_cap || s.n_fragments > o->frag_cap) return RAFT_HIP_ERR_TOO_LARGE;
     int64_t n_exc = 0;
-    rc = raft_hip_fetch_packed_w(c, o->cov_width == 2 ? 2 : 1, o->cov_offset, o->cov8, o->exc_cap, o->exc_index, o->exc_value, &n_exc,
-                                 o->rep_offset, o->rep_s, o->rep_e, o->frag_offset, nullptr, o->frag_begin, o->frag_end);
+    if (width == kCovDelta4 && (s.n_bins + kD4Block - 1) / kD4Block > o->anchor_cap) return RAFT_HIP_ERR_TOO_LARGE;
+    rc = fetch_packed_impl(c, width, o->cov_offset, o->cov8, width == kCovDelta4 ? o->cov_anchor : nullptr, o->exc_cap, o->exc_index, o->exc_value, &n_exc,
+                           o->rep_offset, o->rep_s, o->rep_e, o->frag_offset, nullptr, o->frag_begin, o->frag_end);
     o->n_exc = n_exc;
     return rc;
 }
@@ -1746,8 +1780,10 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
     auto one_piece = [&]() { return run_monolithic_to_host(c, n_reads, read_len, n_rec, qid, qs, qe, tid, ts, te, o, summary, n_runs, rec_offset, win); };
     // (more runs than the chunk plan keeps pieces for -- a PAF concatenated from many files: one piece, merged on the device)
     if (grouped && n_runs > kMaxSeg) return n_rec < (1LL << 29) ? one_piece() : RAFT_HIP_ERR_TOO_LARGE;
-    if (o->cov_width != 0 && o->cov_width != 1 && o->cov_width != 2) return RAFT_HIP_ERR_PARAM;
-    const int cov_width = o->cov_width == 2 ? 2 : 1;   // bytes per window of the coverage's transfer encoding
+    if (o->cov_width != 0 && o->cov_width != 1 && o->cov_width != 2 && o->cov_width != kCovDelta4) return RAFT_HIP_ERR_PARAM;
+    const bool d4 = o->cov_width == kCovDelta4;        // four-bit steps (pack.hpp): chunks must begin on multiples of 1024 windows
+    if (d4 && (!o->cov_anchor || !o->cov8)) return RAFT_HIP_ERR_PARAM;
+    const int cov_width = d4 ? kCovDelta4 : (o->cov_width == 2 ? 2 : 1);   // bytes per window of the coverage's transfer encoding (or the delta4 code)
     long long seg[kMaxSeg + 1];
     int n_seg = -1;
     // chunking needs: the symmetric flag asserted, enough work to split, a record stream of at most kMaxSeg sorted runs
@@ -1765,7 +1801,8 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
     if (n_seg < 1) {
         // not a handful of sorted runs (or not symmetric): several contexts, an explicit chunk count or more records than one
         // pass takes send the job through the host-routed path; anything else is one piece on the first context
-        const bool route = !grouped && n_rec > 0 && n_reads > 0 && !c->force_bucket &&
+        // (the routed path cuts its chunks where the host's buckets end: no multiples of 1024 windows -- delta4 stays in one piece)
+        const bool route = !grouped && !d4 && n_rec > 0 && n_reads > 0 && !c->force_bucket &&
                            ((big_enough && (n_ctx > 1 || n_chunks > 1)) || n_rec >= (1LL << 29));
         if (route) {
             bool fallback = false;
@@ -1801,6 +1838,33 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             if (lo > bound.back() && lo < n_reads) bound.push_back(lo);
         }
         bound.push_back(n_reads);
+        if (d4 && bound.size() > 2) {
+            // delta4: a chunk's windows must begin on a multiple of 1024 (whole anchor blocks, whole bytes): every inner boundary
+            // moves forward to the next read that does -- on average 1024 reads further, of ~3e5 in a chunk.  The windows before
+            // the boundaries are counted by one thread per chunk.
+            const size_t nb = bound.size() - 1;
+            std::vector<long long> wsum(nb, 0);
+            host_parallel((int)nb, [&](int k) { wsum[(size_t)k] = count_windows(read_len + bound[(size_t)k], bound[(size_t)k + 1] - bound[(size_t)k], c->prm.reso); });
+            std::vector<int32_t> moved{0};
+            long long before = 0;                       // windows before the ORIGINAL boundary k
+            bool ok = true;
+            for (size_t k = 1; k < nb && ok; ++k) {
+                ok = wsum[k - 1] >= 0;
+                before += wsum[k - 1];
+                int32_t r = bound[k];
+                long long w = before;
+                if (r < moved.back()) { r = moved.back(); w = -1; }     // (an earlier boundary moved past this one: drop it)
+                while (ok && w >= 0 && (w & (kD4Block - 1)) != 0 && r < n_reads) {
+                    const long long one = count_windows(read_len + r, 1, c->prm.reso);
+                    if (one < 0) ok = false;
+                    w += one; ++r;
+                }
+                if (w >= 0 && r > moved.back() && r < n_reads && (w & (kD4Block - 1)) == 0) moved.push_back(r);
+            }
+            if (!ok) return one_piece();                 // (a negative read length: reported by the one-piece pass)
+            moved.push_back(n_reads);
+            bound.swap(moved);
+        }
         std::vector<long long> cur(seg, seg + n_seg);
         for (size_t k = 0; k + 1 < bound.size(); ++k) {
             ChunkPlan cp{};
@@ -1864,7 +1928,7 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
         }
         if (n_job == 1) {                            // one context: the caller's capacities are the only limits
             jobs[0].rep_room = o->rep_cap; jobs[0].frag_room = o->frag_cap;
-        } else if (rep_cap > o->rep_cap || frag_cap > o->frag_cap || (o->cov8 && bins > o->cov8_cap)) {
+        } else if (rep_cap > o->rep_cap || frag_cap > o->frag_cap || (o->cov8 && bins > o->cov8_cap) || (d4 && (bins + kD4Block - 1) / kD4Block > o->anchor_cap)) {
             c->last_error = "raft_hip_run_multi: cov8_cap / rep_cap / frag_cap below the bounds stated in raft_hip.h";
             return RAFT_HIP_ERR_TOO_LARGE;
         }
@@ -1981,6 +2045,7 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
                 }
                 if (rc != RAFT_HIP_OK) { fail(rc, l->last_error); goto out; }
                 rc = pack_coverage(l, cov_width);
+                if (rc == RAFT_HIP_OK) rc = sort_exceptions(l);          // (ascending by window, like raft_hip_fetch_packed)
                 if (rc != RAFT_HIP_OK) { fail(rc, l->last_error); goto out; }
                 stamp(k, "packed");
             }
@@ -1999,7 +2064,8 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
                 sh.base_bins += cr.n_bins; sh.base_rep += cr.n_rep; sh.base_frag += cr.n_frag;
                 sh.published = kk + 1;
                 if (sh.base_rep > J.rep_room || sh.base_frag > J.frag_room ||
-                    (o->cov8 && J.bins0 + sh.base_bins > o->cov8_cap)) {
+                    (o->cov8 && J.bins0 + sh.base_bins > o->cov8_cap) ||
+                    (d4 && (J.bins0 + sh.base_bins + kD4Block - 1) / kD4Block > o->anchor_cap)) {
                     if (sh.error == RAFT_HIP_OK) { sh.error = RAFT_HIP_ERR_TOO_LARGE; sh.error_text = "host output capacity (coverage / repeats / fragments)"; }
                 }
                 sh.cv.notify_all();
@@ -2016,7 +2082,9 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
                 add_base(l->cov_off, n1, b_bins); add_base(l->rep_off, n1, b_rep - J.rep0); add_base(l->frag_off, n1, b_frag - J.frag0);
                 add_base(l->exc_idx, cr.n_exc, b_bins);
                 struct { void *dst; const void *src; size_t bytes; } job[] = {
-                    {o->cov8 ? o->cov8 + b_bins * cov_width : nullptr, l->cov8.p, (size_t)cr.n_bins * (size_t)cov_width},
+                    {o->cov8 ? o->cov8 + (d4 ? b_bins / 2 : b_bins * cov_width) : nullptr, l->cov8.p,
+                     d4 ? ((size_t)cr.n_bins + 1) / 2 : (size_t)cr.n_bins * (size_t)cov_width},
+                    {d4 ? o->cov_anchor + b_bins / kD4Block : nullptr, l->cov_anchor.p, (((size_t)cr.n_bins + kD4Block - 1) / kD4Block) * 4},
                     {o->cov_offset + cp.r0, l->cov_off.p, (size_t)n1 * 8},
                     {(o->exc_index && exc_fits) ? o->exc_index + b_exc : nullptr, l->exc_idx.p, (size_t)cr.n_exc * 8},
                     {(o->exc_value && exc_fits) ? o->exc_value + b_exc : nullptr, l->exc_val.p, (size_t)cr.n_exc * 4},
@@ -2040,12 +2108,6 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
                 stamp(k, "d2h queued");
                 LANE_TRY(hipEventSynchronize(jc->lane_down_ev[(size_t)li]));
                 stamp(k, "d2h done");
-                if (o->exc_index && o->exc_value && cr.n_exc > 1 && exc_fits) {    // ascending by window, like raft_hip_fetch_packed
-                    std::vector<std::pair<int64_t, int32_t>> ex((size_t)cr.n_exc);
-                    for (size_t i = 0; i < ex.size(); ++i) ex[i] = {o->exc_index[b_exc + (long long)i], o->exc_value[b_exc + (long long)i]};
-                    std::sort(ex.begin(), ex.end());
-                    for (size_t i = 0; i < ex.size(); ++i) { o->exc_index[b_exc + (long long)i] = ex[i].first; o->exc_value[b_exc + (long long)i] = ex[i].second; }
-                }
             }
         }
     out:
@@ -2208,7 +2270,7 @@ int raft_hip_reserve(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, 
         p1.symmetric_mode = 1;
         apply_params(l, &p1);
         const int keep_width = l->out_width;
-        l->out_width = cov_width == 2 ? 2 : 1;
+        l->out_width = cov_width == kCovDelta4 ? kCovDelta4 : (cov_width == 2 ? 2 : 1);
         rc = raft_hip_run_host_grouped(l, nr, read_len, 0, 1, zeros.data(), nullptr, nullptr, -1);
         raft_hip_summary s{};
         if (rc == RAFT_HIP_OK) rc = raft_hip_finish(l, &s);

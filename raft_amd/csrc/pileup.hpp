@@ -66,6 +66,8 @@ struct GroupedOff {
     __device__ __forceinline__ long long at(int s, long long r) const { return off[s * stride + r] + adj[s]; }
 };
 
+constexpr int kExcPerTile = 16;   // delta4: listed windows a tile keeps in slots of its own (a HiFi tile lists ~12: its first window, large steps at read boundaries)
+
 struct SegStarts { long long start[kMaxSeg + 1]; int32_t n_seg; };
 
 struct TileDesc {              // written by tile_desc_kernel; 18 dwords
@@ -115,6 +117,8 @@ struct PileupArgs {
     // window, min(cov, 255 / 65535), plus the list of the windows at or above that limit) and leaves `cov` alone
     void *covp;
     int32_t *cov_anchor;          // OW = 8 (pack.hpp kCovDelta4, four bits per window): cov[1024 k - 1] per block of 1024 windows
+    long long *exc_pidx;          // ... and the windows it lists, kExcPerTile slots per tile (regular tiles, then the extra ones);
+    int32_t *exc_pval;            //     unused slots hold index -1 (filled before the pass)
     unsigned long long *n_exc;    // windows at or above the limit (counted even when the list is full)
     long long exc_cap;
     long long *exc_idx;

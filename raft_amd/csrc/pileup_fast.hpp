@@ -58,6 +58,7 @@ struct FastSmem {
     unsigned long long acc_cov, acc_rep;
     __attribute__((aligned(16))) int32_t wsum[NW];
     int32_t next_tile;                       // tile index wave 0 drew for the workgroup (dynamic tile hand-out)
+    int32_t exc_n;                           // OW = 8: windows of the current tile listed so far (PileupArgs::exc_pidx)
     int32_t wst[NW * 8];                     // per wave: rows, pclose, sfinal, hpfinal, hpin
     unsigned long long stamps[16];           // diagnostic build
     int32_t runq[NW * 2 * kRunQ];            // per wave: closed runs parked for emission (slots relative to a0)
@@ -211,7 +212,7 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
 
     // LDS starts clean: the difference array is zero between tiles
     for (int i = (int)tid * 4; i < Smem::SLOTS; i += THREADS * 4) *reinterpret_cast<int4 *>(&sm.diff[i]) = make_int4(0, 0, 0, 0);
-    if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; }
+    if (tid == 0) { sm.acc_cov = 0ull; sm.acc_rep = 0ull; sm.exc_n = 0; }
     lds_barrier();
     long long lane_cov = 0;                      // this lane's share of the coverage total (reduced once, at the end)
 
@@ -327,7 +328,17 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                 for (int q = 0; q < 4; ++q) {
                     if ((valid >> q) & 1u) {
                         if (p0 + q != off0 && (unsigned)(dd[q] + 7) <= 14u) code |= (unsigned)(dd[q] + 8) << (4 * q);
-                        else note_exception(a, a0 + p0 + q, cc[q]);
+                        else {
+                            // listed windows: a dozen per tile.  They go to the tile's own kExcPerTile slots (an LDS counter per
+                            // tile, plain stores; compact_exceptions_kernel gathers them afterwards) -- a returning atomic per
+                            // window on the one shared counter took 12 ms for the 3.4e5 of a 36 ms chunk; what does not fit
+                            // the tile's slots goes there
+                            const int slot = __hip_atomic_fetch_add(&sm.exc_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (slot < kExcPerTile) {
+                                const long long at = (long long)(EXTRA ? n_reg + k : k) * kExcPerTile + slot;
+                                a.exc_pidx[at] = a0 + p0 + q; a.exc_pval[at] = cc[q];
+                            } else note_exception(a, a0 + p0 + q, cc[q]);
+                        }
                     }
                 }
                 return code;
@@ -874,6 +885,7 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
             RAFT_STAMP(5);
             lds_barrier();
             RAFT_STAMP(6);
+            if (D4 && tid == 0) sm.exc_n = 0;        // (the next tile lists its windows two barriers from here)
 
             // 5. seams, resolved by every wave for itself: a run inherited from earlier waves starts at the run start of
             //    the nearest earlier wave that saw one; the wave holding the last valid slot closes the run that

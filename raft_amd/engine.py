@@ -53,7 +53,7 @@ class _HostOutputs(C.Structure):
                 ("exc_index", C.c_void_p), ("exc_value", C.c_void_p), ("exc_cap", C.c_int64), ("n_exc", C.c_int64),
                 ("rep_offset", C.c_void_p), ("rep_s", C.c_void_p), ("rep_e", C.c_void_p), ("rep_cap", C.c_int64),
                 ("frag_offset", C.c_void_p), ("frag_begin", C.c_void_p), ("frag_end", C.c_void_p), ("frag_cap", C.c_int64),
-                ("cov_width", C.c_int32)]
+                ("cov_width", C.c_int32), ("reserved", C.c_int32), ("cov_anchor", C.c_void_p), ("anchor_cap", C.c_int64)]
 
 
 class _Slice(C.Structure):
@@ -389,6 +389,12 @@ class Engine:
                 tdt = {np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8}[dt]
                 return torch.empty(n, dtype=tdt, pin_memory=True).numpy()
             return np.empty(n, dt)
+        if width == 8:       # delta4: two windows per byte + an anchor per 1024 windows ("cov_nib" / "cov_anchor" name the encoding)
+            caps["exc"] = max(caps["exc"], caps["cov8"] // 128)      # (every tile's first window and the large steps: 0.2-0.3 % of a 32x set)
+            return {"cov_offset": alloc(n1, np.int64), "cov_nib": alloc((caps["cov8"] + 1) // 2, np.uint8), "cov_anchor": alloc((caps["cov8"] + 1023) // 1024, np.int32),
+                    "exc_index": alloc(caps["exc"], np.int64), "exc_value": alloc(caps["exc"], np.int32), "rep_offset": alloc(n1, np.int64),
+                    "rep_s": alloc(caps["rep"], np.int32), "rep_e": alloc(caps["rep"], np.int32), "frag_offset": alloc(n1, np.int64),
+                    "frag_begin": alloc(caps["frag"], np.int32), "frag_end": alloc(caps["frag"], np.int32)}
         return {"cov_offset": alloc(n1, np.int64), "cov8": alloc(caps["cov8"], np.uint16 if width == 2 else np.uint8),
                 "exc_index": alloc(caps["exc"], np.int64),
                 "exc_value": alloc(caps["exc"], np.int32), "rep_offset": alloc(n1, np.int64), "rep_s": alloc(caps["rep"], np.int32),
@@ -433,10 +439,16 @@ class Engine:
 
     def _host_outputs(self, out: dict) -> "_HostOutputs":
         ho = _HostOutputs()
-        for k in ("cov_offset", "cov8", "exc_index", "exc_value", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
+        for k in ("cov_offset", "exc_index", "exc_value", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
             setattr(ho, k, out[k].ctypes.data)
-        ho.cov8_cap, ho.exc_cap, ho.rep_cap, ho.frag_cap = out["cov8"].size, out["exc_index"].size, out["rep_s"].size, out["frag_begin"].size
-        ho.cov_width = 2 if out["cov8"].dtype == np.uint16 else 1          # the buffer's dtype chooses the encoding's width
+        ho.exc_cap, ho.rep_cap, ho.frag_cap = out["exc_index"].size, out["rep_s"].size, out["frag_begin"].size
+        if "cov_nib" in out:                                               # delta4 (host_output_buffers(width=8))
+            ho.cov8, ho.cov8_cap = out["cov_nib"].ctypes.data, 2 * out["cov_nib"].size
+            ho.cov_anchor, ho.anchor_cap = out["cov_anchor"].ctypes.data, out["cov_anchor"].size
+            ho.cov_width = 8
+        else:
+            ho.cov8, ho.cov8_cap = out["cov8"].ctypes.data, out["cov8"].size
+            ho.cov_width = 2 if out["cov8"].dtype == np.uint16 else 1      # the buffer's dtype chooses the encoding's width
         return ho
 
     def _pipelined_result(self, rc, s, ho, out):
@@ -445,7 +457,9 @@ class Engine:
         self.last_n_exc = int(ho.n_exc)
         self._check(rc, summ.error_index)
         n1 = summ.n_reads + 1
-        res = {"cov_offset": out["cov_offset"][:n1], "cov8": out["cov8"][:summ.n_bins], "exc_index": out["exc_index"][:ho.n_exc],
+        cov = ({"cov_nib": out["cov_nib"][:(summ.n_bins + 1) // 2], "cov_anchor": out["cov_anchor"][:(summ.n_bins + 1023) // 1024]} if "cov_nib" in out
+               else {"cov8": out["cov8"][:summ.n_bins]})
+        res = {"cov_offset": out["cov_offset"][:n1], **cov, "exc_index": out["exc_index"][:ho.n_exc],
                "exc_value": out["exc_value"][:ho.n_exc], "rep_offset": out["rep_offset"][:n1], "rep_s": out["rep_s"][:summ.n_repeats],
                "rep_e": out["rep_e"][:summ.n_repeats], "frag_offset": out["frag_offset"][:n1],
                "frag_begin": out["frag_begin"][:summ.n_fragments], "frag_end": out["frag_end"][:summ.n_fragments]}

@@ -208,3 +208,78 @@ def test_delta4_on_the_bench_workload_slice():
         for f in ("n_bins", "n_repeats", "n_cuts", "n_fragments", "total_coverage", "total_repeat_length", "total_read_length"):
             assert getattr(s0, f) == getattr(s1, f), f
     e0.close(); e1.close()
+
+
+def check_pipelined_d4(res, s, want, what):
+    from raft_amd import hostio
+    n = want["cov"].size
+    got = hostio.unpack_coverage_d4(n, res["cov_nib"], res["cov_anchor"], res["exc_index"], res["exc_value"])
+    assert np.array_equal(got, want["cov"]), what
+    assert np.all(np.diff(res["exc_index"]) > 0) and np.array_equal(res["exc_value"], want["cov"][res["exc_index"]]), what
+    for k in ("cov_offset", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
+        assert np.array_equal(res[k], want[k]), (what, k)
+    assert (s.symmetric, s.high_cov, s.total_coverage, s.total_windows, s.total_repeat_length, s.total_read_length) == \
+        tuple(want[k] for k in ("symmetric", "high_cov", "total_coverage", "total_windows", "total_repeat_length", "total_read_length")), what
+    assert s.n_fragments == len(want["frag_read"]) and s.n_repeats == len(want["rep_s"]), what
+
+
+@pytest.mark.parametrize("n_ctx", [1, 2, 3])
+@pytest.mark.parametrize("kw,n_chunks", [(dict(n_reads=4000, seed=81), 5), (dict(n_reads=4000, seed=81), 2), (dict(n_reads=9000, seed=83, mean_len=6000.0), 23),
+                                         (dict(n_reads=1500, seed=82, mean_len=90000, sigma=0.9, max_len=1_200_000, coverage=25), 4),
+                                         (dict(n_reads=50000, seed=2), 0), (dict(n_reads=300, seed=84), 3)])
+@pytest.mark.parametrize("form", ["columns", "grouped", "windows"])
+def test_pipelined_delta4_equals_oracle(kw, n_chunks, n_ctx, form):
+    """The host pipelines handing the coverage back as four-bit steps: chunk boundaries move to reads that begin on a multiple
+    of 1024 windows (whole anchor blocks, whole bytes), several contexts write disjoint ranges of the caller's arrays; a set
+    too small to be cut goes through in one piece."""
+    from raft_amd import engine, hostio
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(**kw)
+    cols = [c.numpy() for c in (o.read_len,) + o.columns()]
+    p = RaftParams(est_cov=int(kw.get("coverage", 30)))
+    want = oracle_run(p, *cols)
+    off = hostio.group_offsets(o.n_reads, cols[1])
+    win = hostio.pack_windows(cols[2], cols[3], p.reso)
+    eng = engine.Engine(sym_params(p), device=0)
+    others = [engine.Engine(RaftParams(est_cov=3, reso=7, symmetric_mode=1), device=0) for _ in range(n_ctx - 1)]
+    out = eng.host_output_buffers(cols[0], pinned=True, width=8)
+    for rep in range(2):
+        out["cov_nib"][:] = 0xA5; out["cov_anchor"][:] = -7           # (stale bytes of the pass before must not survive)
+        if form == "columns":
+            res, s = eng.run_pipelined(cols[0], cols[1], cols[2], cols[3], n_chunks=n_chunks, out=out, others=others)
+        elif form == "grouped":
+            res, s = eng.run_pipelined_grouped(cols[0], off, cols[2], cols[3], n_chunks=n_chunks, out=out, others=others)
+        else:
+            res, s = eng.run_pipelined_windows(cols[0], off, win, n_chunks=n_chunks, out=out, others=others)
+        check_pipelined_d4(res, s, want, f"{kw} chunks {n_chunks} contexts {n_ctx} {form} pass {rep}")
+    for e2 in [eng] + others:
+        e2.close()
+
+
+def test_pipelined_delta4_errors_and_shuffled_input():
+    """A data error comes back as from the byte encodings; a shuffled stream (no chunk plan; with several contexts the
+    host-routed path, which cannot align its chunks) is served in one piece."""
+    from raft_amd import engine, hostio
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(n_reads=4000, seed=81)
+    cols = [c.numpy() for c in (o.read_len,) + o.columns()]
+    p = RaftParams(est_cov=30)
+    want = oracle_run(p, *cols)
+    off = hostio.group_offsets(o.n_reads, cols[1])
+    eng = engine.Engine(sym_params(p), device=0)
+    other = engine.Engine(sym_params(p), device=0)
+    out = eng.host_output_buffers(cols[0], pinned=False, width=8)
+    be = cols[3].copy(); be[4321] = cols[0][cols[1][4321]] + 7000
+    with pytest.raises(engine.RaftError) as e:
+        eng.run_pipelined_grouped(cols[0], off, cols[2], be, n_chunks=5, out=out)
+    assert e.value.code == engine.ERR_COORD and e.value.index == 4321
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(len(cols[1])); perm = np.concatenate([[0], perm[perm != 0]])
+    sh = [c[perm] for c in cols[1:4]]
+    res, s = eng.run_pipelined(cols[0], sh[0], sh[1], sh[2], n_chunks=4, out=out, others=[other])
+    check_pipelined_d4(res, s, want, "shuffled stream, two contexts")
+    small = {k: v[: max(1, v.size // 8)] for k, v in out.items()}
+    with pytest.raises(engine.RaftError) as e:
+        eng.run_pipelined_grouped(cols[0], off, cols[2], cols[3], n_chunks=5, out=small)
+    assert e.value.code == engine.ERR_TOO_LARGE
+    eng.close(); other.close()

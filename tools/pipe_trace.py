@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One chunked end-to-end pass of the bench workload with RAFT_PIPE_TRACE=1 (stage clock per chunk on stderr).
-usage: pipe_trace.py [reads] [chunks] [columns|grouped|windows]"""
+usage: pipe_trace.py [reads] [chunks] [columns|grouped|windows|windows_d4]   (windows_d4: coverage back as four-bit steps)"""
 import os, sys, time
 os.environ["RAFT_PIPE_TRACE"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ mode = sys.argv[3] if len(sys.argv) > 3 else "columns"
 o = make_overlaps(reads, mean_len=30000.0, coverage=32.0, seed=20241008, device="cuda:0")
 host = [c.cpu().pin_memory().numpy() for c in (o.read_len, o.qid, o.qs, o.qe)]
 eng = engine.Engine(RaftParams(est_cov=32, symmetric_mode=1))
-out = eng.host_output_buffers(host[0], pinned=True)
+out = eng.host_output_buffers(host[0], pinned=True, width=8 if mode.endswith("_d4") else 1)
 if mode != "columns":
     off = hostio.group_offsets(reads, host[1], out=torch.empty(4 * (reads + 1), dtype=torch.int64, pin_memory=True).numpy())
     win = hostio.pack_windows(host[2], host[3], 50, out=torch.empty(o.n_rec, dtype=torch.int32, pin_memory=True).numpy().view(np.uint32))
@@ -30,5 +30,7 @@ for it in range(3):
         res, s = eng.run_pipelined_grouped(host[0], off, host[2], host[3], n_chunks=chunks, out=out)
     else:
         res, s = eng.run_pipelined_windows(host[0], off, win, n_chunks=chunks, out=out)
+        if it == 2:
+            sys.stderr.write(f"exceptions {res['exc_index'].size} of {s.n_bins} windows\n")
     dt = time.perf_counter() - t
     sys.stderr.write(f"pass {it}: {dt*1e3:.1f} ms -> {o.n_rec/dt:.3e} records/s\n")
