@@ -191,6 +191,27 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
                     "h2d_bytes": host[0].nbytes + off.nbytes + win.nbytes, "equals_coordinate_columns": bool(same_w),
                     "pack_seconds_outside_clock": t_pack,
                     "mode": "raft_hip_run_multi_windows: 4 bytes per record cross PCIe (first window | one past the last << 16, raft_host_pack_windows)"}
+            # (a'') ... and the coverage back as four-bit steps (delta4: the pileup's own difference array, large steps and each
+            # tile's first window listed with their values, an anchor per 1024 windows): half the download again
+            out4 = eng.host_output_buffers(host[0], pinned=True, width=8)
+            dtimes = []
+            for it in range(n_iter + 1):
+                t0 = time.perf_counter()
+                dres, ds = eng.run_pipelined_windows(host[0], off, win, out=out4)
+                dtimes.append(time.perf_counter() - t0)
+            dsec = sorted(dtimes[1:])[len(dtimes[1:]) // 2]
+            same_d = psum == (ds.n_bins, ds.n_repeats, ds.n_fragments, ds.total_coverage, ds.total_repeat_length) and \
+                all(np.array_equal(pcopy[k], dres[k]) for k in pcopy if k != "cov8")
+            # decoded on the host (raft_host_unpack_coverage_d4) and compared with the byte encoding of the same windows, outside the clock
+            dec = hostio.unpack_coverage_d4(ds.n_bins, dres["cov_nib"], dres["cov_anchor"], dres["exc_index"], dres["exc_value"])
+            lim8 = 255 if width == 1 else 65535
+            same_d = same_d and bool(np.array_equal(np.minimum(dec, lim8).astype(pcopy["cov8"].dtype), pcopy["cov8"]))
+            del dec
+            wrec["delta4"] = {"records_per_s": o.n_rec / dsec, "fragments_per_s": ds.n_fragments / dsec, "seconds": dsec, "first_pass_s": dtimes[0],
+                              "d2h_bytes": int(sum(dres[k].nbytes for k in dres)), "listed_windows": int(dres["exc_index"].size),
+                              "decoded_equals_byte_encoding": bool(same_d),
+                              "mode": "raft_hip_run_multi_windows, cov_width = RAFT_HIP_COV_DELTA4: coverage comes back as four bits per window"}
+            del out4, dres
     # (b) chunked, six-column input (query column uploaded, runs guessed from samples, cuts searched)
     ctimes = []
     for it in range(n_iter):
@@ -239,8 +260,10 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
     if wrec is not None:
         # the headline of this object is the form the CLI uses (window records); the coordinate-column form stays beside it
         res["coordinate_columns"] = {k: res[k] for k in ("records_per_s", "fragments_per_s", "seconds", "mode", "h2d_bytes")}
-        res.update(records_per_s=wrec["records_per_s"], fragments_per_s=wrec["fragments_per_s"], seconds=wrec["seconds"], mode=wrec["mode"],
-                   h2d_bytes=wrec["h2d_bytes"], window_records=wrec)
+        top = wrec["delta4"] if wrec.get("delta4", {}).get("decoded_equals_byte_encoding") else wrec
+        res["byte_per_window_d2h_bytes"] = res["d2h_bytes"]
+        res.update(records_per_s=top["records_per_s"], fragments_per_s=top["fragments_per_s"], seconds=top["seconds"], mode=top["mode"],
+                   h2d_bytes=wrec["h2d_bytes"], d2h_bytes=top.get("d2h_bytes", res["d2h_bytes"]), window_records=wrec)
     return res
 
 
@@ -279,7 +302,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-windows-leg", action="store_true", help="skip the window-record legs (device pass and host-to-host)")
-    ap.add_argument("--cov-width", type=int, default=4, choices=[1, 2, 4], help="bytes per window the timed pass writes (4 = int32 cov[]; 1 / 2 = its transfer encoding)")
+    ap.add_argument("--cov-width", type=int, default=4, choices=[1, 2, 4, 8],
+                    help="bytes per window the timed pass writes (4 = int32 cov[]; 1 / 2 = its transfer encoding; 8 = four-bit steps, delta4)")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the extra passes that time the pass writing the transfer encoding")
     ap.add_argument("--handover", action="store_true", help="--input columns with symmetric_mode = 1: the symmetric flag is handed over")
     ap.add_argument("--no-six-column-leg", action="store_true", help="skip the extra passes that time the six-column detecting form")
@@ -537,7 +561,7 @@ def main():
     # ---- the pass exactly as the CLI and the host pipelines run it: grouped input WITHOUT the query column (it never crosses
     # PCIe: rebuilt from the offsets on the device), the pileup kernel writing the transfer encoding of cov[] (one byte per
     # window, two from -e 40 on, + the windows at or above the limit).  Checked against the int32 pass (outside the clock).
-    packed = windows_leg = None
+    packed = windows_leg = windows_d4_leg = None
     if n_gpus == 1 and not args.no_packed_leg and args.cov_width == 4:
         w = 2 if p.est_cov >= 40 else 1
         shp = sh if sh.off is not None else Shard(o.read_len, o.columns(), True)
@@ -547,14 +571,15 @@ def main():
 
         def encoded_pass(form):
             d_win = None
-            if form == "windows":
+            d4 = form == "windows_d4"
+            if form in ("windows", "windows_d4"):
                 win = hostio.pack_windows(shp.cols[1].cpu().numpy(), shp.cols[2].cpu().numpy(), p.reso)   # (the tokeniser's, outside every clock)
                 if win is None:
                     return None
                 d_win = torch.as_tensor(win.view("int32")).to(dev)
             e3 = engine.Engine(p_sym, device=local)
             e3.set_tuning(args.tile_bins, args.force_bucket, args.variant)
-            e3.set_output_width(w)
+            e3.set_output_width(8 if d4 else w)
             e3.use_torch_stream()
             kt, pt, wall = [], [], []
             for it in range(6):
@@ -570,11 +595,18 @@ def main():
                     wall.append(time.perf_counter() - t1)
                     a, b = e3.timing(); kt.append(a); pt.append(b)
             pk = e3.packed_device()
-            assert pk is not None and pk["width"] == w
-            codes = pk["cov8"] if w == 1 else pk["cov8"].to(torch.int32) & 0xFFFF
-            ok = bool((codes == ref_cov.clamp(max=lim)).all())
-            order = pk["exc_index"].argsort()
-            ok = ok and bool(torch.equal(pk["exc_index"][order], big)) and bool(torch.equal(pk["exc_value"][order], ref_cov[big]))
+            assert pk is not None and pk["width"] == (8 if d4 else w)
+            if d4:       # decoded on the device (outputs_device) against the int32 pass; the listed windows carry their values
+                n_listed = int(pk["exc_index"].numel())
+                ok = bool(torch.equal(pk["exc_value"], ref_cov[pk["exc_index"]]))
+                ok = ok and bool(torch.equal(e3.outputs_device()["cov"], ref_cov))
+                codes = order = None
+            else:
+                codes = pk["cov8"] if w == 1 else pk["cov8"].to(torch.int32) & 0xFFFF
+                ok = bool((codes == ref_cov.clamp(max=lim)).all())
+                order = pk["exc_index"].argsort()
+                ok = ok and bool(torch.equal(pk["exc_index"][order], big)) and bool(torch.equal(pk["exc_value"][order], ref_cov[big]))
+                n_listed = int(pk["exc_index"].numel())
             ok = ok and (s3.n_fragments, s3.n_repeats, s3.total_coverage, s3.total_repeat_length) == (s.n_fragments, s.n_repeats, s.total_coverage, s.total_repeat_length)
             if not ok:
                 raise SystemExit(f"bench.py: the packed-output pass ({form}) differs from the int32 pass")
@@ -585,18 +617,24 @@ def main():
             else:                # 4 B per record read; 8 B per read and run (the tile's slice of the offsets)
                 bytes_p = 4 * s3.n_intervals + 8 * s3.n_reads * n_runs
                 text = "grouped, window records (one word per record: first window | one past the last << 16; raft_hip_run_device_windows)"
-            bytes_p += w * s3.n_bins + 12 * int(pk["exc_index"].numel()) + 4 * s3.n_reads + 8 * s3.n_repeats
+            if d4:
+                text = text.replace("raft_hip_run_device_windows)", "raft_hip_run_device_windows), coverage written as four-bit steps (delta4)")
+                bytes_p += s3.n_bins // 2 + 4 * (s3.n_bins // 1024) + 12 * n_listed + 4 * s3.n_reads + 8 * s3.n_repeats
+            else:
+                bytes_p += w * s3.n_bins + 12 * n_listed + 4 * s3.n_reads + 8 * s3.n_repeats
             k_s, p_s, w_s = sum(kt) / len(kt), sum(pt) / len(pt), sum(wall) / len(wall)
-            res = {"cov_width": w, "input": text, "value": my_rec / w_s, "unit": "PAF records/s",
+            res = {"cov_width": 8 if d4 else w, "input": text, "value": my_rec / w_s, "unit": "PAF records/s",
                    "ms_per_step": w_s * 1e3, "kernel_ms": k_s * 1e3, "pass_device_ms": p_s * 1e3, "bytes_algorithmic": bytes_p,
                    "kernel_frac": bytes_p / k_s / 1e9 / HBM_PEAK_GBS, "pass_frac": bytes_p / p_s / 1e9 / HBM_PEAK_GBS,
-                   "n_exceptions": int(pk["exc_index"].numel()), "equals_int32_pass": ok}
+                   "n_exceptions": n_listed, "equals_int32_pass": ok}
             del codes, order, pk, d_win
             e3.close()
             return res
         packed = encoded_pass("columns")
         if not args.no_windows_leg and args.variant < 0 and p.reso <= 32767:
             windows_leg = encoded_pass("windows")
+            if windows_leg is not None:
+                windows_d4_leg = encoded_pass("windows_d4")
         del ref_cov, big
 
     # ---- the six plain columns into a detecting context (rounds 1-2's headline form), and its inspect-first form
@@ -636,7 +674,8 @@ def main():
         # dominant kernel: pileup + prefix scan + coverage store + run scan (pileup_fast.hpp).
         # algorithmic bytes per launch (this rank): 12 B per interval read once, 4 B per window written once,
         # 4 B per read (length) and 8 B per repeat emitted
-        bytes_alg = (4 if windows_in else 12) * s.n_intervals + args.cov_width * s.n_bins + 4 * s.n_reads + 8 * s.n_repeats
+        cov_bytes = s.n_bins // 2 + 4 * (s.n_bins // 1024) if args.cov_width == 8 else args.cov_width * s.n_bins
+        bytes_alg = (4 if windows_in else 12) * s.n_intervals + cov_bytes + 4 * s.n_reads + 8 * s.n_repeats
         achieved = bytes_alg / pile / 1e9
         strong_line = args.strong and world > 1
         if args.presplit and world > 1:
@@ -685,6 +724,8 @@ def main():
                                     product_path_pass_device_ms=windows_leg["pass_device_ms"], product_path_pass_frac=windows_leg["pass_frac"],
                                     product_path_bytes_algorithmic=windows_leg["bytes_algorithmic"], product_path_input="window records")
             line["window_records"] = windows_leg
+            if windows_d4_leg is not None:
+                line["window_records_delta4"] = windows_d4_leg
         if six is not None:
             line["six_column"] = six
         if strong_info is not None:

@@ -269,8 +269,9 @@ struct raft_hip_ctx {
     DevBuf u_s, u_e;                   // window records unpacked for the passes that need coordinate columns
     DevBuf cov_anchor, abs_bits;       // delta4 encoding of cov[] (pack.hpp): block anchors; escape flags of the device-side decoder
     DevBuf exc_idx2, exc_val2, sort_tmp;   // the exception list in ascending order (sort_exceptions)
-    DevBuf exc_pidx, exc_pval;             // delta4: the windows each tile lists, kExcPerTile slots per tile (compact_exceptions_kernel)
+    DevBuf exc_pidx, exc_pval, exc_tile_n; // delta4: the windows each tile lists, kExcPerTile slots per tile (compact_exceptions_kernel)
     bool exc_sorted = false;
+    int d4_shift = 0;                  // delta4 on a chunk of a larger array (the host pipelines' lanes): windows of the block its first window lies in that precede it
     DevBuf x_qs, x_qe, x_off, x_raw, x_send_off, x_cnt;   // pre-split exchange (raft_hip_exchange*): what this rank received / staged
 
     // state of the last pass
@@ -404,7 +405,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
-                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->exc_idx2, &c->exc_val2, &c->sort_tmp, &c->exc_pidx, &c->exc_pval, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->exc_idx2, &c->exc_val2, &c->sort_tmp, &c->exc_pidx, &c->exc_pval, &c->exc_tile_n, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -656,7 +657,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     else {
         if (ow == kCovDelta4) {
             HIP_TRY(c, c->cov8.ensure((size_t)std::max(B, 1LL) / 2 + 16));
-            HIP_TRY(c, c->cov_anchor.ensure(((size_t)std::max(B, 1LL) / kD4Block + 2) * 4));
+            HIP_TRY(c, c->cov_anchor.ensure(((size_t)std::max(B, 1LL) / kD4Block + 3) * 4));
         } else
         HIP_TRY(c, c->cov8.ensure((size_t)std::max(B, 1LL) * (size_t)ow + 16));
         const long long cap = std::max<long long>(c->exc_cap, std::max<long long>(4096, B / 64));
@@ -743,13 +744,14 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     pa.reso = c->prm.reso; pa.high_cov = c->high_cov; pa.repeat_length = c->prm.repeat_length; pa.flank = c->prm.flanking_length;
     pa.cov = ow == 4 ? c->cov.as<int32_t>() : nullptr;
     pa.covp = ow == 4 ? nullptr : c->cov8.p; pa.n_exc = &ctrl->n_exc; pa.exc_cap = c->exc_cap;
-    pa.cov_anchor = ow == kCovDelta4 ? c->cov_anchor.as<int32_t>() : nullptr;
+    pa.cov_anchor = ow == kCovDelta4 ? c->cov_anchor.as<int32_t>() : nullptr; pa.d4_shift = c->d4_shift;
     const long long d4_tiles = n_tiles + extra_cap;          // (regular tiles, then the extra ones)
     if (ow == kCovDelta4) {
         HIP_TRY(c, c->exc_pidx.ensure((size_t)d4_tiles * kExcPerTile * 8));
         HIP_TRY(c, c->exc_pval.ensure((size_t)d4_tiles * kExcPerTile * 4));
-        HIP_TRY(c, hipMemsetAsync(c->exc_pidx.p, 0xFF, (size_t)d4_tiles * kExcPerTile * 8, st));
-        pa.exc_pidx = c->exc_pidx.as<long long>(); pa.exc_pval = c->exc_pval.as<int32_t>();
+        HIP_TRY(c, c->exc_tile_n.ensure((size_t)d4_tiles * 4));
+        HIP_TRY(c, hipMemsetAsync(c->exc_tile_n.p, 0, (size_t)d4_tiles * 4, st));
+        pa.exc_pidx = c->exc_pidx.as<long long>(); pa.exc_pval = c->exc_pval.as<int32_t>(); pa.exc_tile_n = c->exc_tile_n.as<int32_t>();
     }
     pa.exc_idx = c->exc_idx.as<long long>(); pa.exc_val = c->exc_val.as<int32_t>();
     pa.rep_res_off = c->rep_res_off.as<long long>(); pa.rep_cnt = c->rep_cnt.as<int32_t>();
@@ -872,7 +874,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
     if (ow == kCovDelta4)      // the windows the tiles listed, gathered into the shared list (whose counter the control block carries)
         hipLaunchKernelGGL(compact_exceptions_kernel, dim3((unsigned)((d4_tiles + 255) / 256)), dim3(256), 0, st, d4_tiles, kExcPerTile,
-                           c->exc_pidx.as<long long>(), c->exc_pval.as<int32_t>(), &ctrl->n_exc, c->exc_cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>());
+                           c->exc_tile_n.as<int32_t>(), c->exc_pidx.as<long long>(), c->exc_pval.as<int32_t>(), &ctrl->n_exc, c->exc_cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>());
 
     // ---- per-read tail: order repeats, mask markers, fragments
     FinalizeArgs fa{};
@@ -1100,6 +1102,7 @@ static int materialise_cov(raft_hip_ctx *c)
     if (B > 0) {
         const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((B / 4 + 255) / 256, 256 * 16));
         if (c->pass_width == kCovDelta4) {
+            if (c->d4_shift != 0) return RAFT_HIP_ERR_STATE;      // (a pipeline lane's chunk: its blocks do not begin at its first window)
             HIP_TRY(c, c->abs_bits.ensure(((size_t)B / 32 + 2) * 4));
             hipLaunchKernelGGL(delta4_expand_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>((B / 32 + 255) / 256, 256 * 16))), dim3(256), 0, c->stream,
                                c->cov8.as<uint8_t>(), B, c->cov.as<int32_t>(), c->abs_bits.as<unsigned>());
@@ -1202,7 +1205,7 @@ static int pack_coverage(raft_hip_ctx *c, int width)
     const long long B = c->sum.n_bins;
     const bool d4 = width == kCovDelta4;
     HIP_TRY(c, c->cov8.ensure(d4 ? (size_t)std::max(B, 1LL) / 2 + 16 : (size_t)std::max(B, 1LL) * (size_t)width + 16));
-    if (d4) HIP_TRY(c, c->cov_anchor.ensure(((size_t)std::max(B, 1LL) / kD4Block + 2) * 4));
+    if (d4) HIP_TRY(c, c->cov_anchor.ensure(((size_t)std::max(B, 1LL) / kD4Block + 3) * 4));
     HIP_TRY(c, c->exc_cnt.ensure(8));
     long long cap = std::max<long long>(c->exc_cap, std::max<long long>(4096, d4 ? B / 64 : B / 512));
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1214,7 +1217,7 @@ static int pack_coverage(raft_hip_ctx *c, int width)
             const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((B / 4 + 1023) / 1024, 256 * 16));
             if (d4) {
                 Delta4Out po{c->cov8.as<uint8_t>(), c->cov_anchor.as<int32_t>(), c->exc_cnt.as<unsigned long long>(), cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>()};
-                hipLaunchKernelGGL(pack_delta4_kernel, dim3(grid), dim3(256), 0, c->stream, c->cov.as<int32_t>(), B, po);
+                hipLaunchKernelGGL(pack_delta4_kernel, dim3(grid), dim3(256), 0, c->stream, c->cov.as<int32_t>(), B, po, c->d4_shift);
             } else if (width == 1) {
                 PackOut<uint8_t> po{c->cov8.as<uint8_t>(), c->exc_cnt.as<unsigned long long>(), cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>()};
                 hipLaunchKernelGGL(pack_cov_kernel<uint8_t>, dim3(grid), dim3(256), 0, c->stream, c->cov.as<int32_t>(), B, po);
@@ -1365,6 +1368,7 @@ struct ChunkPlan {
     int32_t r0, r1;
     Piece piece[kMaxSeg];
     long long n_rec;
+    long long win_lo;            // delta4: windows of the reads before r0 (where the chunk's coverage begins in the caller's array)
 };
 
 struct ChunkResult {
@@ -1838,14 +1842,16 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             if (lo > bound.back() && lo < n_reads) bound.push_back(lo);
         }
         bound.push_back(n_reads);
-        if (d4 && bound.size() > 2) {
-            // delta4: a chunk's windows must begin on a multiple of 1024 (whole anchor blocks, whole bytes): every inner boundary
-            // moves forward to the next read that does -- on average 1024 reads further, of ~3e5 in a chunk.  The windows before
-            // the boundaries are counted by one thread per chunk.
+        std::vector<long long> win_before;           // delta4: windows before every boundary
+        if (d4) {
+            // delta4: a chunk's windows must begin on a multiple of 4 (its nibbles fill whole ushorts of the caller's array;
+            // the anchors' blocks may begin anywhere, see PileupArgs::d4_shift): every inner boundary moves forward to the
+            // next read that does -- a few reads on.  The windows before the boundaries are counted by one thread per chunk.
             const size_t nb = bound.size() - 1;
             std::vector<long long> wsum(nb, 0);
             host_parallel((int)nb, [&](int k) { wsum[(size_t)k] = count_windows(read_len + bound[(size_t)k], bound[(size_t)k + 1] - bound[(size_t)k], c->prm.reso); });
             std::vector<int32_t> moved{0};
+            win_before.push_back(0);
             long long before = 0;                       // windows before the ORIGINAL boundary k
             bool ok = true;
             for (size_t k = 1; k < nb && ok; ++k) {
@@ -1853,15 +1859,18 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
                 before += wsum[k - 1];
                 int32_t r = bound[k];
                 long long w = before;
-                if (r < moved.back()) { r = moved.back(); w = -1; }     // (an earlier boundary moved past this one: drop it)
-                while (ok && w >= 0 && (w & (kD4Block - 1)) != 0 && r < n_reads) {
+                if (r <= moved.back()) continue;        // (an earlier boundary moved past this one: dropped)
+                while (ok && (w & 3) != 0 && r < n_reads) {
                     const long long one = count_windows(read_len + r, 1, c->prm.reso);
                     if (one < 0) ok = false;
                     w += one; ++r;
                 }
-                if (w >= 0 && r > moved.back() && r < n_reads && (w & (kD4Block - 1)) == 0) moved.push_back(r);
+                if (ok && r < n_reads && (w & 3) == 0) {
+                    // (boundaries after this one still count from their ORIGINAL place: `before` is not touched)
+                    moved.push_back(r); win_before.push_back(w);
+                }
             }
-            if (!ok) return one_piece();                 // (a negative read length: reported by the one-piece pass)
+            if (!ok || wsum[nb - 1] < 0) return one_piece();   // (a negative read length: reported by the one-piece pass)
             moved.push_back(n_reads);
             bound.swap(moved);
         }
@@ -1869,6 +1878,7 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
         for (size_t k = 0; k + 1 < bound.size(); ++k) {
             ChunkPlan cp{};
             cp.r0 = bound[k]; cp.r1 = bound[k + 1]; cp.n_rec = 0;
+            cp.win_lo = d4 ? win_before[k] : 0;
             for (int g = 0; g < n_seg; ++g) {
                 const long long hi = (k + 2 == bound.size()) ? seg[g + 1] : first_of(g, cur[g], cp.r1);
                 cp.piece[g] = Piece{cur[g], hi};
@@ -2021,6 +2031,7 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             // -- the pass on this chunk
             {
                 l->out_width = cov_width;            // the pass writes the encoding that travels
+                l->d4_shift = d4 ? (int)(cp.win_lo & (kD4Block - 1)) : 0;
                 int rc;
                 if (grouped) {
                     // the chunk's pieces lie back to back on the device: run g's slice of offsets counts from the caller's
@@ -2081,10 +2092,14 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
                 // offsets count from the job's first entry (rep / frag of later jobs are moved down afterwards)
                 add_base(l->cov_off, n1, b_bins); add_base(l->rep_off, n1, b_rep - J.rep0); add_base(l->frag_off, n1, b_frag - J.frag0);
                 add_base(l->exc_idx, cr.n_exc, b_bins);
+                const int d4_sh = l->d4_shift, d4_j0 = d4_sh ? 1 : 0;
+                if (d4 && b_bins != cp.win_lo) { fail(RAFT_HIP_ERR_DEVICE, "delta4: a chunk's windows do not begin where the plan put them"); goto out; }
                 struct { void *dst; const void *src; size_t bytes; } job[] = {
                     {o->cov8 ? o->cov8 + (d4 ? b_bins / 2 : b_bins * cov_width) : nullptr, l->cov8.p,
                      d4 ? ((size_t)cr.n_bins + 1) / 2 : (size_t)cr.n_bins * (size_t)cov_width},
-                    {d4 ? o->cov_anchor + b_bins / kD4Block : nullptr, l->cov_anchor.p, (((size_t)cr.n_bins + kD4Block - 1) / kD4Block) * 4},
+                    // (anchors: the block the chunk begins in belongs to the chunk before unless it begins with it)
+                    {d4 ? o->cov_anchor + (b_bins - d4_sh) / kD4Block + d4_j0 : nullptr, l->cov_anchor.as<int32_t>() + d4_j0,
+                     d4 ? (size_t)(((long long)d4_sh + cr.n_bins + kD4Block - 1) / kD4Block - d4_j0) * 4 : 0},
                     {o->cov_offset + cp.r0, l->cov_off.p, (size_t)n1 * 8},
                     {(o->exc_index && exc_fits) ? o->exc_index + b_exc : nullptr, l->exc_idx.p, (size_t)cr.n_exc * 8},
                     {(o->exc_value && exc_fits) ? o->exc_value + b_exc : nullptr, l->exc_val.p, (size_t)cr.n_exc * 4},

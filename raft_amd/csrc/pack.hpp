@@ -133,37 +133,36 @@ __device__ __forceinline__ unsigned delta4_code(int step, int value, long long w
     return 0u;
 }
 
-// The windows the pileup listed tile by tile (PileupArgs::exc_pidx, 16 slots per tile, -1 = unused) appended to the shared
-// list: one thread per tile, one atomic per wave.
-__global__ __launch_bounds__(256) void compact_exceptions_kernel(long long n_tiles, int per_tile, const long long *__restrict__ pidx,
-                                                                 const int32_t *__restrict__ pval, unsigned long long *n_exc, long long exc_cap,
-                                                                 long long *__restrict__ exc_idx, int32_t *__restrict__ exc_val)
+// The windows the pileup listed tile by tile (PileupArgs::exc_pidx: kExcPerTile slots per tile, exc_tile_n of them used) appended
+// to the shared list: one thread per tile, one atomic per wave.
+__global__ __launch_bounds__(256) void compact_exceptions_kernel(long long n_tiles, int per_tile, const int32_t *__restrict__ tile_n,
+                                                                 const long long *__restrict__ pidx, const int32_t *__restrict__ pval,
+                                                                 unsigned long long *n_exc, long long exc_cap, long long *__restrict__ exc_idx,
+                                                                 int32_t *__restrict__ exc_val)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    int cnt = 0;
-    if (t < n_tiles)
-        while (cnt < per_tile && pidx[t * per_tile + cnt] >= 0) ++cnt;
+    const int cnt = t < n_tiles ? tile_n[t] : 0;
     const int incl = wave_incl_scan_add(cnt);
     const int total = __builtin_amdgcn_readlane(incl, 63);
     if (total == 0) return;
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(n_exc, (unsigned long long)total);
-    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
     const long long at = (long long)base + incl - cnt;
     for (int q = 0; q < cnt; ++q)
         if (at + q < exc_cap) { exc_idx[at + q] = pidx[t * per_tile + q]; exc_val[at + q] = pval[t * per_tile + q]; }
 }
 
 // int32 cov[] -> delta4 (after a pass that wrote int32: the general kernel took part, or the caller asked late)
-__global__ __launch_bounds__(256) void pack_delta4_kernel(const int32_t *__restrict__ cov, long long n_bins, Delta4Out o)
+__global__ __launch_bounds__(256) void pack_delta4_kernel(const int32_t *__restrict__ cov, long long n_bins, Delta4Out o, int shift)
 {
     const long long n4 = (n_bins + 3) >> 2;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
         const long long w0 = g << 2;
         int prev = w0 > 0 ? cov[w0 - 1] : 0;
-        if ((w0 & (kD4Block - 1)) == 0) o.anchor[w0 >> 10] = prev;
+        if (((w0 + shift) & (kD4Block - 1)) == 0) o.anchor[(w0 + shift) >> 10] = prev;   // (shift: see PileupArgs::d4_shift)
         unsigned code = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -117,8 +117,10 @@ struct PileupArgs {
     // window, min(cov, 255 / 65535), plus the list of the windows at or above that limit) and leaves `cov` alone
     void *covp;
     int32_t *cov_anchor;          // OW = 8 (pack.hpp kCovDelta4, four bits per window): cov[1024 k - 1] per block of 1024 windows
-    long long *exc_pidx;          // ... and the windows it lists, kExcPerTile slots per tile (regular tiles, then the extra ones);
-    int32_t *exc_pval;            //     unused slots hold index -1 (filled before the pass)
+    int32_t d4_shift;             //     ... blocks counted from d4_shift windows before this pass's first (a chunk of a larger array: multiple of 4, < 1024)
+    long long *exc_pidx;          // ... and the windows it lists, kExcPerTile slots per tile (regular tiles, then the extra ones)
+    int32_t *exc_pval;
+    int32_t *exc_tile_n;          //     how many of its slots a tile used (zeroed before the pass)
     unsigned long long *n_exc;    // windows at or above the limit (counted even when the list is full)
     long long exc_cap;
     long long *exc_idx;

@@ -321,23 +321,43 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
             // D4: a step is the difference array's own value -- except at the tile's first window, whose predecessor another
             // workgroup holds: that window is always listed with its value.  A lane's four steps are one aligned ushort; the
             // ushort a tile shares with its neighbour is updated with an and / or pair of atomics on its own nibbles.
+            int pend_p = -1, pend_c = 0;           // D4: this lane's listed window waiting for the end of the rows (slot, value)
+            auto d4_list = [&](int p, int v, int slot) {      // slot: the window's place among the tile's listed ones
+                if (slot < kExcPerTile) {
+                    const long long at = (long long)(EXTRA ? n_reg + k : k) * kExcPerTile + slot;
+                    a.exc_pidx[at] = a0 + p; a.exc_pval[at] = v;
+                } else note_exception(a, a0 + p, v);
+            };
             auto d4_codes = [&](const int4 d, int c0, int c1, int c2, int c3, int p0, unsigned valid) -> unsigned {
-                unsigned code = 0;
-                const int dd[4] = {d.x, d.y, d.z, d.w}, cc[4] = {c0, c1, c2, c3};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if ((valid >> q) & 1u) {
-                        if (p0 + q != off0 && (unsigned)(dd[q] + 7) <= 14u) code |= (unsigned)(dd[q] + 8) << (4 * q);
-                        else {
-                            // listed windows: a dozen per tile.  They go to the tile's own kExcPerTile slots (an LDS counter per
-                            // tile, plain stores; compact_exceptions_kernel gathers them afterwards) -- a returning atomic per
-                            // window on the one shared counter took 12 ms for the 3.4e5 of a 36 ms chunk; what does not fit
-                            // the tile's slots goes there
-                            const int slot = __hip_atomic_fetch_add(&sm.exc_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (slot < kExcPerTile) {
-                                const long long at = (long long)(EXTRA ? n_reg + k : k) * kExcPerTile + slot;
-                                a.exc_pidx[at] = a0 + p0 + q; a.exc_pval[at] = cc[q];
-                            } else note_exception(a, a0 + p0 + q, cc[q]);
+                // the common case first: four steps within [-7, 7], none of them the tile's first window
+                const unsigned ux = (unsigned)(d.x + 7), uy = (unsigned)(d.y + 7), uz = (unsigned)(d.z + 7), uw = (unsigned)(d.w + 7);
+                const bool plain = max(max(ux, uy), max(uz, uw)) <= 14u && (unsigned)(off0 - p0) >= 4u;
+                if (plain) return ((ux + 1u) | ((uy + 1u) << 4) | ((uz + 1u) << 8) | ((uw + 1u) << 12)) & (valid == 15u ? 0xFFFFu : (((valid & 1u) ? 0xFu : 0u) | ((valid & 2u) ? 0xF0u : 0u) | ((valid & 4u) ? 0xF00u : 0u) | ((valid & 8u) ? 0xF000u : 0u)));
+                // some window of this lane is listed -- half of all rows have such a lane (a large step at a read boundary) and the
+                // whole wave walks this path with it, so it is kept short: the steps of the other windows as above, and the
+                // listed window parked in two registers until the rows are done (one LDS atomic per wave and tile then places
+                // all of them: in the tile's own kExcPerTile slots, plain stores, gathered by compact_exceptions_kernel -- a
+                // returning atomic per window on the one shared counter took 12 ms for the 3.4e5 of a 36 ms chunk, an LDS atomic
+                // with its wait inside the rows 0.4 ms of the kernel's 2.7).  A lane that lists a second window before that,
+                // or two at once, places them at once.
+                const unsigned f = (unsigned)(off0 - p0);                     // < 4: the tile's first window is this lane's slot f
+                unsigned esc = ((ux > 14u || f == 0u) ? 1u : 0u) | ((uy > 14u || f == 1u) ? 2u : 0u) | ((uz > 14u || f == 2u) ? 4u : 0u) |
+                               ((uw > 14u || f == 3u) ? 8u : 0u);
+                esc &= valid;
+                const unsigned keep = valid & ~esc;
+                // (a listed window's step does not fit four bits: every term is cut to its nibble before they are joined)
+                const unsigned code = (((ux + 1u) & 15u) | (((uy + 1u) & 15u) << 4) | (((uz + 1u) & 15u) << 8) | (((uw + 1u) & 15u) << 12)) &
+                                      (((keep & 1u) ? 0xFu : 0u) | ((keep & 2u) ? 0xF0u : 0u) | ((keep & 4u) ? 0xF00u : 0u) | ((keep & 8u) ? 0xF000u : 0u));
+                if (esc) {
+                    if (pend_p < 0 && (esc & (esc - 1u)) == 0u) {
+                        const int q = __ffs((int)esc) - 1;
+                        pend_p = p0 + q; pend_c = q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3;
+                    } else {
+                        int slot = __hip_atomic_fetch_add(&sm.exc_n, (int)__popc(esc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        while (esc) {
+                            const int q = __ffs((int)esc) - 1;
+                            esc &= esc - 1u;
+                            d4_list(p0 + q, q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3, slot++);
                         }
                     }
                 }
@@ -734,7 +754,7 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                     else if (OW == 1) *reinterpret_cast<unsigned *>(covp0 + (unsigned)p0) = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);
                     else if (D4) {
                         *reinterpret_cast<uint16_t *>(covp0 + ((unsigned)p0 >> 1)) = (uint16_t)d4_codes(d, c0, c1, c2, c3, p0, 15u);
-                        if ((((unsigned)a0 + (unsigned)p0) & 1023u) == 0u) a.cov_anchor[(a0 + p0) >> 10] = excl;
+                        if ((((unsigned)a0 + (unsigned)p0 + (unsigned)a.d4_shift) & 1023u) == 0u) a.cov_anchor[(a0 + p0 + a.d4_shift) >> 10] = excl;
                     }
                     else *reinterpret_cast<uint2 *>(covp0 + (unsigned)p0 * 2u) = make_uint2(k0 | (k1 << 16), k2 | (k3 << 16));
                     if (big && !D4) {
@@ -770,7 +790,7 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                                 atomicAnd(word, ~(mask << sh));
                                 atomicOr(word, (code & mask) << sh);
                             }
-                            if (v0 && (((unsigned)a0 + (unsigned)p0) & 1023u) == 0u) a.cov_anchor[(a0 + p0) >> 10] = excl;
+                            if (v0 && (((unsigned)a0 + (unsigned)p0 + (unsigned)a.d4_shift) & 1023u) == 0u) a.cov_anchor[(a0 + p0 + a.d4_shift) >> 10] = excl;
                         }
                     } else if (OW == 1) {
                         uint8_t *const o = reinterpret_cast<uint8_t *>(covp0) + p0;
@@ -877,6 +897,15 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                 }
             }
 
+            if (D4) {                            // the windows the lanes parked: one place in the tile's list each
+                const unsigned long long pm = __ballot(pend_p >= 0);
+                if (pm) {
+                    int base = 0;
+                    if (lane == 0) base = __hip_atomic_fetch_add(&sm.exc_n, (int)__popcll(pm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (pend_p >= 0) d4_list(pend_p, pend_c, base + (int)__popcll(pm & ((1ull << lane) - 1ull)));
+                }
+            }
             // 4. publish the wave's seam state
             if (lane == 0) {
                 *reinterpret_cast<int4 *>(&sm.wst[wid * 8]) = make_int4(row_e > row_b ? 1 : 0, pclose, S, hp ? 1 : 0);
@@ -885,7 +914,10 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
             RAFT_STAMP(5);
             lds_barrier();
             RAFT_STAMP(6);
-            if (D4 && tid == 0) sm.exc_n = 0;        // (the next tile lists its windows two barriers from here)
+            if (D4 && tid == 0) {                    // (the next tile lists its windows two barriers from here)
+                const int n_listed = sm.exc_n;
+                if (n_listed) { a.exc_tile_n[EXTRA ? n_reg + k : k] = min(n_listed, kExcPerTile); sm.exc_n = 0; }
+            }
 
             // 5. seams, resolved by every wave for itself: a run inherited from earlier waves starts at the run start of
             //    the nearest earlier wave that saw one; the wave holding the last valid slot closes the run that

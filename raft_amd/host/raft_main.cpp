@@ -191,6 +191,7 @@ int main(int argc, char *argv[])
     std::unique_ptr<int32_t[]> rep_s, rep_e, fb, fe;
     std::vector<int64_t> exc_i;
     std::vector<int32_t> exc_v;
+    std::vector<int32_t> cov_anchor;          // the four-bit step encoding's block anchors (cov_width = RAFT_HIP_COV_DELTA4)
     int64_t exc_cap0 = 0;
     std::thread out_prep([&] {
         const int64_t minw = std::max<int64_t>(((int64_t)p.repeat_length + p.reso - 1) / p.reso, 1);
@@ -203,9 +204,11 @@ int main(int argc, char *argv[])
         fb.reset(new int32_t[(size_t)frag_cap + 1]); fe.reset(new int32_t[(size_t)frag_cap + 1]);
         exc_cap0 = std::max<int64_t>(1 << 16, n_win / 64);
         exc_i.resize((size_t)exc_cap0); exc_v.resize((size_t)exc_cap0);
+        cov_anchor.resize((size_t)n_win / 1024 + 2);
         devices_up.wait();
         for (size_t d = 0; d < devices.size(); ++d) if (create_rc[d] != RAFT_HIP_OK) return;
         pin(exc_i.data(), exc_i.size() * 8); pin(exc_v.data(), exc_v.size() * 4);
+        pin(cov_anchor.data(), cov_anchor.size() * 4);
         pin(cov8.get(), ((size_t)n_win + 1) * (p.est_cov >= 40 ? 2 : 1));
         pin(fb.get(), ((size_t)frag_cap + 1) * 4); pin(fe.get(), ((size_t)frag_cap + 1) * 4);
         pin(rep_s.get(), ((size_t)rep_cap + 1) * 4); pin(rep_e.get(), ((size_t)rep_cap + 1) * 4);
@@ -219,7 +222,8 @@ int main(int argc, char *argv[])
             const bool gz = pn.size() > 3 && pn.compare(pn.size() - 3, 3, ".gz") == 0;
             const int64_t est = pf ? (int64_t)pf.tellg() * (gz ? 4 : 1) / 60 : 0;
             for (size_t d = 0; d < devices.size(); ++d)
-                (void)raft_hip_reserve(ctxs[d], n_reads, rl, est, (int32_t)devices.size(), p.est_cov >= 40 ? 2 : 1);
+                (void)raft_hip_reserve(ctxs[d], n_reads, rl, est, (int32_t)devices.size(),
+                                       getenv("RAFT_NO_DELTA4") ? (p.est_cov >= 40 ? 2 : 1) : RAFT_HIP_COV_DELTA4);   // (what a hifiasm-shaped PAF will use)
         }
     });
     g_background[3] = &out_prep;
@@ -284,7 +288,10 @@ int main(int argc, char *argv[])
     stage("page-lock");
     // one byte per window unless the expected coverage lets repeats pile up beyond it (from 40x on: two), and two in any
     // case when the first attempt meets more windows at or above 255 than the exception list holds
-    int cov_width = p.est_cov >= 40 ? 2 : 1;
+    // ... but grouped input (whose chunks the pipelines can cut where they like) brings the coverage back as four-bit steps: the
+    // step from one window to the next is the pileup's own difference array, within +-7 for all but a few windows in a
+    // thousand whatever the depth -- half of a byte per window, a quarter of two
+    int cov_width = (n_runs > 0 && !getenv("RAFT_NO_DELTA4")) ? RAFT_HIP_COV_DELTA4 : (p.est_cov >= 40 ? 2 : 1);
     raft_hip_summary s{};
     int64_t n_exc = 0;
     const char *chunks_env = getenv("RAFT_CHUNKS");   // 0 / unset: the engine decides (one piece for small inputs)
@@ -296,6 +303,7 @@ int main(int argc, char *argv[])
         }
         raft_hip_host_outputs ho{};
         ho.cov_offset = cov_off.data(); ho.cov8 = cov8.get(); ho.cov8_cap = n_win; ho.cov_width = cov_width;
+        ho.cov_anchor = cov_anchor.data(); ho.anchor_cap = (int64_t)cov_anchor.size();
         ho.exc_index = exc_i.data(); ho.exc_value = exc_v.data(); ho.exc_cap = exc_cap;
         ho.rep_offset = rep_off.data(); ho.rep_s = rep_s.get(); ho.rep_e = rep_e.get(); ho.rep_cap = rep_cap;
         ho.frag_offset = frag_off.data(); ho.frag_begin = fb.get(); ho.frag_end = fe.get(); ho.frag_cap = frag_cap;
@@ -315,7 +323,8 @@ int main(int argc, char *argv[])
         if (rc != RAFT_HIP_ERR_TOO_LARGE || attempt == 2 || n_exc <= exc_cap) break;
         // more windows at or above the limit than the list holds (n_exc says how many): two bytes per window when a byte
         // leaves more than one window in 16 on the list, else room for exactly those
-        if (cov_width == 1 && n_exc > n_win / 16) cov_width = 2;
+        if (cov_width == RAFT_HIP_COV_DELTA4 && n_exc > n_win / 8) cov_width = 2;      // (steps that mostly do not fit: not a coverage profile)
+        else if (cov_width == 1 && n_exc > n_win / 16) cov_width = 2;
         else exc_cap = n_exc;
     }
     if (rc != RAFT_HIP_OK) {
@@ -327,6 +336,7 @@ int main(int argc, char *argv[])
     }
     stage("engine+fetch");
     if (timing) fprintf(stderr, "TIMING devices_used %d input %s\n", s.n_devices_used, win ? "windows" : (n_runs > 0 ? "grouped" : "columns"));
+    if (timing) fprintf(stderr, "TIMING coverage_encoding %s\n", cov_width == RAFT_HIP_COV_DELTA4 ? "delta4" : (cov_width == 2 ? "uint16" : "uint8"));
     fprintf(stdout, "INFO, Symmetric overlaps %d \n", s.symmetric);            // chop.hpp:189-190
     fprintf(stdout, "INFO, length of alignments  %d()\n", (int)s.n_records);
     fprintf(stdout, "high_cov %d\n", s.high_cov);                              // repeat.hpp:91
@@ -335,8 +345,12 @@ int main(int argc, char *argv[])
     int fasta_rc = RAFT_HOST_OK;
     std::thread fasta_writer([&] { fasta_rc = raft_host_write_fasta(fasta_out.c_str(), reads, frag_off.data(), fb.get(), fe.get()); });
     g_background[1] = &fasta_writer;
-    if (raft_host_write_coverage_packed_w(cov_width, (p.prefix + ".coverage.txt").c_str(), n_reads, p.reso, cov_off.data(), cov8.get(), n_exc,
-                                          exc_i.data(), exc_v.data()) != RAFT_HOST_OK ||
+    const int cov_rc = cov_width == RAFT_HIP_COV_DELTA4
+        ? raft_host_write_coverage_d4((p.prefix + ".coverage.txt").c_str(), n_reads, p.reso, cov_off.data(), cov8.get(), cov_anchor.data(), n_exc,
+                                      exc_i.data(), exc_v.data())
+        : raft_host_write_coverage_packed_w(cov_width, (p.prefix + ".coverage.txt").c_str(), n_reads, p.reso, cov_off.data(), cov8.get(), n_exc,
+                                            exc_i.data(), exc_v.data());
+    if (cov_rc != RAFT_HOST_OK ||
         raft_host_write_repeats((p.prefix + ".long_repeats.txt").c_str(), (p.prefix + ".long_repeats.bed").c_str(), reads,
                                 rep_off.data(), rep_s.get(), rep_e.get()) != RAFT_HOST_OK) {
         die("ERROR, repeat_annotate(), cannot write output files");

@@ -182,7 +182,7 @@ def test_cli_many_concatenated_files(tmp_path):
         assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, f
 
 
-@pytest.mark.parametrize("knob,form", [("RAFT_NO_WINDOWS", "grouped"), ("RAFT_NO_GROUPED", "columns"), (None, "windows")])
+@pytest.mark.parametrize("knob,form", [("RAFT_NO_WINDOWS", "grouped"), ("RAFT_NO_GROUPED", "columns"), (None, "windows"), ("RAFT_NO_DELTA4", "windows")])
 @pytest.mark.parametrize("name", ["s300_default", "s60_ultralong"])
 def test_cli_input_forms(tmp_path, name, knob, form):
     """The three forms the CLI hands a symmetric hifiasm-shaped PAF over in -- window records (default), coordinate columns
@@ -203,3 +203,6 @@ def test_cli_input_forms(tmp_path, name, knob, form):
     if name == "s60_ultralong" and form == "windows":
         form = "grouped"
     assert f"input {form}" in r.stderr.decode(), r.stderr.decode()
+    # grouped input brings the coverage back as four-bit steps unless told otherwise; the plain columns keep the byte encodings
+    enc = "delta4" if (form != "columns" and knob != "RAFT_NO_DELTA4") else ("uint16" if p.est_cov >= 40 else "uint8")
+    assert f"coverage_encoding {enc}" in r.stderr.decode(), r.stderr.decode()
