@@ -48,6 +48,14 @@ def test_bench_line_has_every_contract_field():
     assert d["six_column"]["pass_device_ms"] > 0 and d["six_column"]["pass_device_ms_inspect_first"] > 0
     assert e["six_column_input"]["equals_grouped"] is True and e["six_column_input"]["h2d_bytes"] > e["h2d_bytes"]
     assert cb["cpu_model"] and cb["node_logical_cpus"] >= 1 and "same seed" in cb["sample"]
+    # ... window records and the four-bit step encoding of the coverage: the CLI's forms, each checked against the int32 pass
+    assert rf["product_path_input"] == "window records"
+    assert d["window_records"]["equals_int32_pass"] is True and d["window_records_delta4"]["equals_int32_pass"] is True
+    assert d["window_records_delta4"]["n_exceptions"] > 0 and d["window_records_delta4"]["cov_width"] == 8
+    w = e["window_records"]
+    assert w["equals_coordinate_columns"] is True and w["delta4"]["decoded_equals_byte_encoding"] is True
+    assert w["delta4"]["d2h_bytes"] < e["byte_per_window_d2h_bytes"] and e["coordinate_columns"]["h2d_bytes"] > e["h2d_bytes"]
+    assert e["records_per_s"] == w["delta4"]["records_per_s"]
 
 
 @pytest.mark.parametrize("extra", [[], ["--presplit"]])

@@ -23,5 +23,9 @@ python bench.py --input windows --no-cpu-baseline --no-e2e --no-six-column-leg -
 python tools/stamp_probe.py 3300000 windows > gpurun_out/$TAG/stamp_probe_windows.txt 2>&1
 tools/profile_round.sh ${TAG}_win --input windows --cov-width 1 > gpurun_out/$TAG/profile_round_windows.log 2>&1
 python tools/pipe_trace.py 3300000 0 windows 2> gpurun_out/$TAG/pipeline_trace_windows.txt
+# ... and the coverage back as four-bit steps (delta4): the device pass as a headline of its own, the pipeline
+python bench.py --input windows --cov-width 8 --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg > gpurun_out/$TAG/bench_windows_w8.json 2> gpurun_out/$TAG/bench_windows_w8.err
+python tools/pipe_trace.py 3300000 0 windows_d4 2> gpurun_out/$TAG/pipeline_trace_windows_d4.txt
+tools/pass_timeline.sh ${TAG}_tl8 --input windows --cov-width 8 > gpurun_out/$TAG/pass_timeline_windows_w8.txt 2>&1
 python tools/pcie_duplex.py > gpurun_out/$TAG/pcie_duplex.txt 2>&1
 tail -3 gpurun_out/$TAG/profile_round.log; grep -E "SQ_INSTS|SQ_WAIT_ANY|SQ_WAVE_CYCLES|BANK_CONFLICT|IDX_ACTIVE" gpurun_out/$TAG/sq_counters.txt | head -20

@@ -48,6 +48,7 @@ while time.time() < t_end:
     # encoding of cov[] (decoded on the device for the comparison)
     # round 3: 4 = lane-serial rows; 40 / 41 / 42 = grouped input (per-read record offsets) with the query column and the
     # window count announced / without the query column / without either, writing the one-byte encoding
+    # 60 / 61 = the coverage written as four-bit steps (delta4) from the columns / from window records, decoded on the device
     # 50 / 51 / 52 = window records (one word per record, read ids derived in the kernel): int32 out with the window count
     # announced / one-byte encoding / without the count, two-byte encoding
     off = win = None
@@ -60,17 +61,17 @@ while time.time() < t_end:
                 win = hostio.pack_windows(o.qs.cpu().numpy(), o.qe.cpu().numpy(), reso)
                 if win is not None:
                     win = torch.as_tensor(win.view("int32")).to("cuda:0")
-    for variant in (1, 0, 2, 4, 20, 30) + ((10,) if sym_set else ()) + ((40, 41, 42) if off is not None else ()) + ((50, 51, 52) if win is not None else ()):
+    for variant in (1, 0, 2, 4, 20, 30) + ((10,) if sym_set else ()) + ((40, 41, 42) if off is not None else ()) + ((50, 51, 52, 61) if win is not None else ()) + (60,):
         print("  variant", variant, flush=True)
-        eng = engine.Engine(RaftParams(**dict(p.__dict__, symmetric_mode=1)) if variant in (10, 40, 41, 42, 50, 51, 52) else p, device=0)
-        eng.set_tuning(0, False, 0 if variant >= 10 else variant)
-        if variant in (20, 30, 42, 51, 52):
-            eng.set_output_width(2 if variant in (30, 52) else 1)
+        eng = engine.Engine(RaftParams(**dict(p.__dict__, symmetric_mode=1)) if variant in (10, 40, 41, 42, 50, 51, 52, 61) else p, device=0)
+        eng.set_tuning(0, False, 0 if variant >= 10 else variant)   # (60: the columns into configuration 0, four-bit steps out)
+        if variant in (20, 30, 42, 51, 52, 60, 61):
+            eng.set_output_width(8 if variant >= 60 else (2 if variant in (30, 52) else 1))
         try:
-            if variant >= 50:
+            if variant in (50, 51, 52, 61):
                 eng.run_device_windows(o.read_len, off, win, n_bins=n_bins if variant != 52 else -1)
                 s = eng.finish()
-            elif variant >= 40:
+            elif 40 <= variant < 50:
                 eng.run_device_grouped(o.read_len, off, o.qid if variant == 40 else None, o.qs, o.qe, n_bins=n_bins if variant != 42 else -1)
                 s = eng.finish()
             else:
@@ -94,4 +95,4 @@ while time.time() < t_end:
     del o, out, ref
     torch.cuda.empty_cache()
 print(f"{n_ok} random sets agree across configurations 1, 0, 2, 4 (lane-serial rows), 0 with the symmetric flag handed over, 0 writing the one- and two-byte "
-      f"encodings, the grouped entry in three forms and window records in three (seeds up to {seed - 1})")
+      f"encodings, the grouped entry in three forms, window records in three and the four-bit step encoding in two (seeds up to {seed - 1})")
