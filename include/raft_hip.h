@@ -270,7 +270,10 @@ typedef struct raft_hip_host_outputs {
     int32_t cov_width;    /* bytes per window of the coverage encoding: 0 or 1 = one (cov8 as declared), 2 = cov8 points
                              at cov8_cap uint16 codes (limit 65535; see raft_hip_fetch_packed_w);
                              RAFT_HIP_COV_DELTA4 = four-bit steps (see raft_hip_fetch_delta4): cov8 holds (cov8_cap + 1) / 2
-                             bytes, cov_anchor anchor_cap >= (W + 1023) / 1024 entries; exc_value are absolute values */
+                             bytes, cov_anchor anchor_cap >= (W + 1023) / 1024 entries; exc_value are absolute values, and
+                             exc_cap should allow for W / 128 of them (0.2-0.3 % of the windows of a 32x set).  Chunks are cut
+                             at reads that begin on a multiple of four windows; a job that would take the host-routed path
+                             (a stream that is not a handful of sorted runs) is served in one piece in this encoding */
     int32_t reserved;
     int32_t *cov_anchor;  int64_t anchor_cap;
 } raft_hip_host_outputs;
