@@ -61,6 +61,7 @@ while time.time() < t_end:
                 win = hostio.pack_windows(o.qs.cpu().numpy(), o.qe.cpu().numpy(), reso)
                 if win is not None:
                     win = torch.as_tensor(win.view("int32")).to("cuda:0")
+    out = None
     for variant in (1, 0, 2, 4, 20, 30) + ((10,) if sym_set else ()) + ((40, 41, 42) if off is not None else ()) + ((50, 51, 52, 61) if win is not None else ()) + (60,):
         print("  variant", variant, flush=True)
         eng = engine.Engine(RaftParams(**dict(p.__dict__, symmetric_mode=1)) if variant in (10, 40, 41, 42, 50, 51, 52, 61) else p, device=0)
