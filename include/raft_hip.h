@@ -335,6 +335,10 @@ int  raft_hip_run_multi_windows(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_
  *                            obtained with raft_hip_comm_unique_id (128 bytes) and handed to the others by its own means.
  *                            librccl.so.1 is loaded when first used (a single-GPU run never maps it).
  *   raft_hip_exchange_local  one process, one context per rank (raft_hip_create on each device): peer copies.
+ * Window records travel the same way: a slice with d_qe = NULL carries them in d_qs (one 32-bit word per record,
+ * raft_host_pack_windows -- every rank of an exchange in the same form); what arrives then has d_qe = NULL and goes to
+ * raft_hip_run_device_windows(ctx, got.n_reads, ..., got.n_runs, got.d_rec_offset, (const uint32_t *)got.d_qs, n_bins): half the
+ * bytes over xGMI.
  * The slices' device columns must be complete when the call is made (raft_hip_exchange: on the context's stream, or
  * their producers synchronised; raft_hip_exchange_local: synchronised), and stay untouched until the exchange is done. */
 #define RAFT_HIP_MAX_RUNS 16

@@ -2419,7 +2419,8 @@ struct XRun { int peer, run; long long lo, n; };            // a run this rank r
 
 bool slice_ok(const raft_hip_slice &sl, int32_t n_reads_total)
 {
-    return sl.n_rec >= 0 && sl.n_runs >= 1 && sl.n_runs <= kMaxSeg && sl.rec_offset && (sl.n_rec == 0 || (sl.d_qs && sl.d_qe)) && n_reads_total >= 0;
+    // (d_qe == NULL: d_qs holds window records, one word per record -- raft_hip_run_device_windows' form; the same on every rank)
+    return sl.n_rec >= 0 && sl.n_runs >= 1 && sl.n_runs <= kMaxSeg && sl.rec_offset && (sl.n_rec == 0 || sl.d_qs) && n_reads_total >= 0;
 }
 
 } // namespace
@@ -2461,6 +2462,8 @@ int raft_hip_exchange_local(raft_hip_ctx *const *ctxs, int32_t world, int32_t n_
         if (bounds[p] < 0 || bounds[p] > bounds[p + 1] || bounds[p + 1] > n_reads_total) return RAFT_HIP_ERR_PARAM;
     }
     if (bounds[0] != 0 || bounds[world] != n_reads_total) return RAFT_HIP_ERR_PARAM;
+    const bool one_col = slices[0].d_qe == nullptr;       // window records: one column travels
+    for (int p = 1; p < world; ++p) if ((slices[p].d_qe == nullptr) != one_col && slices[p].n_rec > 0 && slices[0].n_rec > 0) return RAFT_HIP_ERR_PARAM;
     for (int g = 0; g < world; ++g) {
         raft_hip_ctx *c = ctxs[g];
         const long long b0 = bounds[g], b1 = bounds[g + 1], n1 = b1 - b0 + 1;
@@ -2476,7 +2479,7 @@ int raft_hip_exchange_local(raft_hip_ctx *const *ctxs, int32_t world, int32_t n_
         const int K = std::max<int>(1, (int)runs.size());
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, c->x_qs.ensure((size_t)std::max(n_rec, 1LL) * 4));
-        HIP_TRY(c, c->x_qe.ensure((size_t)std::max(n_rec, 1LL) * 4));
+        if (!one_col) HIP_TRY(c, c->x_qe.ensure((size_t)std::max(n_rec, 1LL) * 4));
         HIP_TRY(c, c->x_off.ensure((size_t)K * (size_t)n1 * 8));
         std::vector<long long> off((size_t)K * (size_t)n1, 0);
         long long base = 0;
@@ -2487,17 +2490,17 @@ int raft_hip_exchange_local(raft_hip_ctx *const *ctxs, int32_t world, int32_t n_
             const int pd = ctxs[x.peer]->device;
             if (pd == c->device) {
                 HIP_TRY(c, hipMemcpyAsync(c->x_qs.as<int32_t>() + base, slices[x.peer].d_qs + x.lo, (size_t)x.n * 4, hipMemcpyDeviceToDevice, c->stream));
-                HIP_TRY(c, hipMemcpyAsync(c->x_qe.as<int32_t>() + base, slices[x.peer].d_qe + x.lo, (size_t)x.n * 4, hipMemcpyDeviceToDevice, c->stream));
+                if (!one_col) HIP_TRY(c, hipMemcpyAsync(c->x_qe.as<int32_t>() + base, slices[x.peer].d_qe + x.lo, (size_t)x.n * 4, hipMemcpyDeviceToDevice, c->stream));
             } else {
                 HIP_TRY(c, hipMemcpyPeerAsync(c->x_qs.as<int32_t>() + base, c->device, slices[x.peer].d_qs + x.lo, pd, (size_t)x.n * 4, c->stream));
-                HIP_TRY(c, hipMemcpyPeerAsync(c->x_qe.as<int32_t>() + base, c->device, slices[x.peer].d_qe + x.lo, pd, (size_t)x.n * 4, c->stream));
+                if (!one_col) HIP_TRY(c, hipMemcpyPeerAsync(c->x_qe.as<int32_t>() + base, c->device, slices[x.peer].d_qe + x.lo, pd, (size_t)x.n * 4, c->stream));
             }
             base += x.n;
         }
         if (runs.empty()) for (long long r = 0; r < n1; ++r) off[(size_t)r] = 0;
         HIP_TRY(c, hipMemcpyAsync(c->x_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));                         // (`off` leaves scope; the peers' columns may be reused)
-        outs[g] = raft_hip_received{(int32_t)(b1 - b0), K, n_rec, c->x_off.as<int64_t>(), c->x_qs.as<int32_t>(), c->x_qe.as<int32_t>()};
+        outs[g] = raft_hip_received{(int32_t)(b1 - b0), K, n_rec, c->x_off.as<int64_t>(), c->x_qs.as<int32_t>(), one_col ? nullptr : c->x_qe.as<int32_t>()};
     }
     return RAFT_HIP_OK;
 }
@@ -2552,8 +2555,9 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
         }
     if ((int)runs.size() > kMaxRuns) { c->last_error = "raft_hip_exchange: more than 16 runs arrive at one rank"; return RAFT_HIP_ERR_TOO_LARGE; }
     const int K = std::max<int>(1, (int)runs.size());
+    const bool one_col = mine->d_qe == nullptr;           // window records: one column travels (the same on every rank: the caller's protocol)
     HIP_TRY(c, c->x_qs.ensure((size_t)std::max(n_rec, 1LL) * 4));
-    HIP_TRY(c, c->x_qe.ensure((size_t)std::max(n_rec, 1LL) * 4));
+    if (!one_col) HIP_TRY(c, c->x_qe.ensure((size_t)std::max(n_rec, 1LL) * 4));
     HIP_TRY(c, c->x_off.ensure((size_t)K * (size_t)n1 * 8));
     HIP_TRY(c, c->x_raw.ensure((size_t)K * (size_t)n1 * 8));
     RunBases rb{};
@@ -2569,12 +2573,12 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
             const long long lo = mine->rec_offset[j * N1 + bounds[g]], n = mine->rec_offset[j * N1 + bounds[g + 1]] - lo;
             if (n <= 0) continue;
             NCCL_TRY(r->Send(mine->d_qs + lo, (size_t)n, ncclInt32, g, comm, st));
-            NCCL_TRY(r->Send(mine->d_qe + lo, (size_t)n, ncclInt32, g, comm, st));
+            if (!one_col) NCCL_TRY(r->Send(mine->d_qe + lo, (size_t)n, ncclInt32, g, comm, st));
             NCCL_TRY(r->Send(c->x_send_off.as<long long>() + j * N1 + bounds[g], (size_t)(bounds[g + 1] - bounds[g] + 1), ncclInt64, g, comm, st));
         }
     for (size_t k = 0; k < runs.size(); ++k) {
         NCCL_TRY(r->Recv(c->x_qs.as<int32_t>() + rb.base[k], (size_t)runs[k].n, ncclInt32, runs[k].peer, comm, st));
-        NCCL_TRY(r->Recv(c->x_qe.as<int32_t>() + rb.base[k], (size_t)runs[k].n, ncclInt32, runs[k].peer, comm, st));
+        if (!one_col) NCCL_TRY(r->Recv(c->x_qe.as<int32_t>() + rb.base[k], (size_t)runs[k].n, ncclInt32, runs[k].peer, comm, st));
         NCCL_TRY(r->Recv(c->x_raw.as<long long>() + (long long)k * n1, (size_t)n1, ncclInt64, runs[k].peer, comm, st));
     }
     NCCL_TRY(r->GroupEnd());
@@ -2584,7 +2588,7 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
         hipLaunchKernelGGL(rebase_offsets_kernel, dim3((unsigned)((n1 * K + 255) / 256)), dim3(256), 0, st, K, n1, c->x_raw.as<long long>(), rb,
                            c->x_off.as<long long>());
     HIP_TRY(c, hipGetLastError());
-    *out = raft_hip_received{(int32_t)(n1 - 1), K, n_rec, c->x_off.as<int64_t>(), c->x_qs.as<int32_t>(), c->x_qe.as<int32_t>()};
+    *out = raft_hip_received{(int32_t)(n1 - 1), K, n_rec, c->x_off.as<int64_t>(), c->x_qs.as<int32_t>(), one_col ? nullptr : c->x_qe.as<int32_t>()};
     return RAFT_HIP_OK;                                      // (in stream order: a pass on this context's stream may follow at once)
 }
 

@@ -617,19 +617,20 @@ class Slice:
     grouped form -- int64 [n_runs, n_reads_total + 1], where every read of the whole set begins in every sorted run of the slice
     (raft_amd.hostio.group_offsets on the slice's query column)."""
 
-    def __init__(self, rec_offset, qs, qe):
+    def __init__(self, rec_offset, qs, qe=None):
+        """``qe=None``: ``qs`` holds window records (one int32-viewed word per record, hostio.pack_windows) -- one column travels."""
         import torch
         self.off = np.ascontiguousarray(np.asarray(rec_offset), dtype=np.int64)
         if self.off.ndim != 2 or not (1 <= self.off.shape[0] <= 4):
             raise ValueError("Slice: rec_offset must be [n_runs (1..4), n_reads_total + 1]")
         for t in (qs, qe):
-            if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+            if t is not None and (t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous()):
                 raise TypeError("Slice needs contiguous int32 CUDA tensors")
         self.qs, self.qe = qs, qe
 
     def c(self) -> "_Slice":
         return _Slice(int(self.qs.numel()), int(self.off.shape[0]), self.off.ctypes.data, self.qs.data_ptr() if self.qs.numel() else 0,
-                      self.qe.data_ptr() if self.qe.numel() else 0)
+                      self.qe.data_ptr() if (self.qe is not None and self.qe.numel()) else 0)
 
 
 def _received_views(eng, r: "_Received") -> dict:
@@ -643,7 +644,8 @@ def _received_views(eng, r: "_Received") -> dict:
         return torch.as_tensor(_DevArray(ptr, n, ts, eng), device=dev)
     off = view(r.d_rec_offset, r.n_runs * (r.n_reads + 1), "<i8", torch.int64).reshape(r.n_runs, r.n_reads + 1)
     return {"n_reads": int(r.n_reads), "n_rec": int(r.n_rec), "n_runs": int(r.n_runs), "rec_offset": off,
-            "qs": view(r.d_qs, r.n_rec, "<i4", torch.int32), "qe": view(r.d_qe, r.n_rec, "<i4", torch.int32)}
+            "qs": view(r.d_qs, r.n_rec, "<i4", torch.int32),      # (window records when the slices carried them: then "qe" is None)
+            "qe": view(r.d_qe, r.n_rec, "<i4", torch.int32) if (r.d_qe or r.n_rec == 0) else None}
 
 
 def exchange_local(engines, bounds, slices) -> list:

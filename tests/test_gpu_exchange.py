@@ -24,15 +24,20 @@ def rank_slice_of(want, b0, b1):
     return out
 
 
-def make_slices(torch, hostio, engine, o, world):
-    """The record stream cut into `world` contiguous slices (what each rank's tokeniser would hold), each in grouped form."""
+def make_slices(torch, hostio, engine, o, world, windows=False):
+    """The record stream cut into `world` contiguous slices (what each rank's tokeniser would hold), each in grouped form;
+    `windows`: the records as window records (one word each) instead of the two coordinate columns."""
     n_rec = o.n_rec
     slices = []
     for g in range(world):
         lo, hi = n_rec * g // world, n_rec * (g + 1) // world
         off = hostio.group_offsets(o.n_reads, o.qid[lo:hi].numpy(), max_runs=4)
         assert off is not None and off.shape[0] <= 2
-        slices.append(engine.Slice(off, o.qs[lo:hi].to("cuda:0").contiguous(), o.qe[lo:hi].to("cuda:0").contiguous()))
+        if windows:
+            w = hostio.pack_windows(o.qs[lo:hi].numpy(), o.qe[lo:hi].numpy(), 50)
+            slices.append(engine.Slice(off, torch.as_tensor(w.view(np.int32)).to("cuda:0")))
+        else:
+            slices.append(engine.Slice(off, o.qs[lo:hi].to("cuda:0").contiguous(), o.qe[lo:hi].to("cuda:0").contiguous()))
     return slices
 
 
@@ -40,7 +45,10 @@ def check_rank(torch, eng, p, got, read_len, b0, b1, want, what):
     rl = read_len[b0:b1]
     d_rl = torch.as_tensor(np.ascontiguousarray(rl)).to("cuda:0")
     B = int(((rl.astype(np.int64) + p.reso - 1) // p.reso).sum())
-    eng.run_device_grouped(d_rl, got["rec_offset"], None, got["qs"], got["qe"], n_bins=B)
+    if got["qe"] is None:            # window records arrived
+        eng.run_device_windows(d_rl, got["rec_offset"], got["qs"], n_bins=B)
+    else:
+        eng.run_device_grouped(d_rl, got["rec_offset"], None, got["qs"], got["qe"], n_bins=B)
     s = eng.finish()
     res = eng.fetch()
     exp = rank_slice_of(want, b0, b1)
@@ -50,8 +58,9 @@ def check_rank(torch, eng, p, got, read_len, b0, b1, want, what):
     return s
 
 
+@pytest.mark.parametrize("windows", [False, True])
 @pytest.mark.parametrize("world", [1, 2, 3, 5, 8])
-def test_exchange_local_then_pass_equals_oracle(world):
+def test_exchange_local_then_pass_equals_oracle(world, windows):
     import torch
     from raft_amd import dist as rdist
     from raft_amd import engine, hostio
@@ -61,7 +70,7 @@ def test_exchange_local_then_pass_equals_oracle(world):
     p = RaftParams(est_cov=30)
     want = oracle_run(p, *cols)
     engs = [engine.Engine(RaftParams(est_cov=30, symmetric_mode=1), device=0) for _ in range(world)]
-    slices = make_slices(torch, hostio, engine, o, world)
+    slices = make_slices(torch, hostio, engine, o, world, windows)
     ipr = torch.bincount(o.qid.long(), minlength=o.n_reads)
     bounds = rdist.partition_reads(o.read_len, p.reso, world, intervals_per_read=ipr).numpy()
     for rep in range(2):                                  # a second exchange reuses the contexts' buffers
@@ -77,7 +86,8 @@ def test_exchange_local_then_pass_equals_oracle(world):
         e.close()
 
 
-def test_exchange_rccl_one_rank_communicator():
+@pytest.mark.parametrize("windows", [False, True])
+def test_exchange_rccl_one_rank_communicator(windows):
     """RCCL itself: communicator from a unique id, the all-gather of the piece sizes, grouped send / receive (to itself) on the
     context's stream, the rebasing kernel -- with the one rank this box can hold."""
     import torch
@@ -91,7 +101,7 @@ def test_exchange_rccl_one_rank_communicator():
     uid = engine.Comm.unique_id()
     assert len(uid) == 128
     comm = engine.Comm(0, uid, 0, 1)
-    sl = make_slices(torch, hostio, engine, o, 1)[0]
+    sl = make_slices(torch, hostio, engine, o, 1, windows)[0]
     bounds = np.array([0, o.n_reads], np.int64)
     for rep in range(2):
         got = comm.exchange(eng, bounds, sl)
