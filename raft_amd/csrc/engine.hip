@@ -271,6 +271,8 @@ struct raft_hip_ctx {
     DevBuf exc_idx2, exc_val2, sort_tmp;   // the exception list in ascending order (sort_exceptions)
     DevBuf exc_pidx, exc_pval, exc_tile_n; // delta4: the windows each tile lists, kExcPerTile slots per tile (compact_exceptions_kernel)
     bool exc_sorted = false;
+    long long pass_seq = 0;            // number of the pass whose totals_kernel is queued (written behind the control block when it is through)
+    bool seq_armed = false;
     int d4_shift = 0;                  // delta4 on a chunk of a larger array (the host pipelines' lanes): windows of the block its first window lies in that precede it
     DevBuf x_qs, x_qe, x_off, x_raw, x_send_off, x_cnt;   // pre-split exchange (raft_hip_exchange*): what this rank received / staged
 
@@ -385,6 +387,7 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
         return RAFT_HIP_ERR_DEVICE;
     }
     c->stream = c->own_stream;
+    memset(c->pinned, 0, 4096);                            // (the pass numbers raft_hip_finish looks for start at 1)
     *out = c;
     return RAFT_HIP_OK;
 }
@@ -531,7 +534,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         if (c->prm.symmetric_mode != 1) return RAFT_HIP_ERR_PARAM;
         d_tid = d_qid; d_ts = d_qs; d_te = d_qe;
     }
-    c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1; c->packed_width = 0;
+    c->ran = false; c->finished = false; c->pending_err = RAFT_HIP_OK; c->pending_err_index = -1; c->packed_width = 0; c->seq_armed = false;
     c->cov_valid = false; c->pass_width = 4; c->n_exc = 0; c->exc_sorted = false;
     c->args = in;
     const bool no_verify_env = getenv("RAFT_ALWAYS_INSPECT") != nullptr;   // (A/B measurements; bench.py times both forms)
@@ -913,7 +916,8 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
                            n_reads, d_len, ctrl->totals, c->rep_off.as<long long>(), c->cut_off.as<long long>(),
                            c->frag_off.as<long long>(), c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr,
                            ctrl->out_totals, &ctrl->totals_done, reinterpret_cast<const long long *>(ctrl), (int)(sizeof(Ctrl) / 8),
-                           c->pinned_dev + 128);   // everything finish() reports travels in one block (+1024 bytes), written by the last workgroup
+                           c->pinned_dev + 128, ++c->pass_seq);   // everything finish() reports travels in one block (+1024 bytes), written by the last workgroup
+        c->seq_armed = true;
     }
     c->fa = fa; c->cuts_ready = false;
     c->pass_width = ow; c->cov_valid = ow == 4;
@@ -997,7 +1001,18 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
     if (!c->ran) return RAFT_HIP_ERR_STATE;
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->finished) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        // The pass's last workgroup writes the pass's number behind the control block: seen there, everything is done.  The host
+        // looks for it itself for a while (a pass is 0.2-3 ms; the runtime's wait sleeps, and waking up costs 20-30 us) and
+        // falls back to the runtime's wait -- which is also what reports a device fault.
+        bool seen = false;
+        if (c->seq_armed && getenv("RAFT_NO_SPIN") == nullptr) {
+            const volatile long long *seq = reinterpret_cast<const volatile long long *>(c->pinned) + 128 + kSeqWord;
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+            for (int it = 0; !(seen = *seq == c->pass_seq); ++it)
+                if ((it & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) HIP_TRY(c, hipStreamSynchronize(c->stream));
         auto ctrl_block = [&]() { Ctrl hc; memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl)); return hc; };
         auto again = [&](const raft_hip_ctx::PassArgs &a) -> int {       // the pass once more, this time nothing assumed
             const int rc = run_pass(c, a, false);
@@ -2596,6 +2611,7 @@ int raft_hip_last_timing(raft_hip_ctx *c, double *pileup_seconds, double *pass_s
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
     if (!c->finished) return RAFT_HIP_ERR_STATE;
+    HIP_TRY(c, hipEventSynchronize(c->ev_pass1));          // (finish may have seen the pass's number before the runtime saw its last event)
     float ms = 0.f;
     if (pileup_seconds) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pile0, c->ev_pile1)); *pileup_seconds = ms * 1e-3; }
     if (pass_seconds) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pass0, c->ev_pass1)); *pass_seconds = ms * 1e-3; }

@@ -400,12 +400,13 @@ __global__ __launch_bounds__(256) void finalize_cuts_kernel(FinalizeArgs a)
 // totals[0] = sum coverage, [1] = sum unclamped repeat bp, [2] = sum read length.  One atomic per workgroup and
 // total (a few hundred per launch): with one per wave the three counters saw 12 k serialised atomics and the kernel
 // took 56 us for 13 MB of input.
+constexpr int kSeqWord = 256;     // (in 8-byte words behind the control block's copy in the page-locked block)
 __global__ __launch_bounds__(256) void totals_kernel(long long n_tiles, const long long *tile_sums, int32_t n_reads,
                                                      const int32_t *read_len, unsigned long long *totals,
                                                      const long long *rep_off, const long long *cut_off,
                                                      const long long *frag_off, const long long *bucket_off, long long *tails,
                                                      unsigned *done_blocks, const long long *ctrl_words, int n_ctrl_words,
-                                                     long long *host_block)
+                                                     long long *host_block, long long pass_seq)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {    // output sizes, so that the host reads one block back
         tails[0] = rep_off[n_reads]; tails[1] = cut_off[n_reads]; tails[2] = frag_off[n_reads];
@@ -438,6 +439,9 @@ __global__ __launch_bounds__(256) void totals_kernel(long long n_tiles, const lo
         __threadfence();
         if ((int)threadIdx.x < n_ctrl_words) host_block[threadIdx.x] = reinterpret_cast<const volatile long long *>(ctrl_words)[threadIdx.x];
         __threadfence_system();
+        // ... and then the pass's number, behind the block: raft_hip_finish spins on it instead of sleeping in the runtime's wait
+        // (whose wake-up is 20-30 us of a pass that may take 200)
+        if (threadIdx.x == 0) { host_block[kSeqWord] = pass_seq; __threadfence_system(); }
     }
 }
 
