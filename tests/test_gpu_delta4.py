@@ -283,3 +283,24 @@ def test_pipelined_delta4_errors_and_shuffled_input():
         eng.run_pipelined_grouped(cols[0], off, cols[2], cols[3], n_chunks=5, out=small)
     assert e.value.code == engine.ERR_TOO_LARGE
     eng.close(); other.close()
+
+
+def test_delta4_when_the_general_kernel_has_to_take_part(monkeypatch):
+    """The re-cut list overflows (RAFT_EXTRA_CAP=1): the pass is run again with the general kernel, which writes int32 -- the
+    four-bit steps are then made from that array (pack_delta4_kernel) and are the same array."""
+    from raft_amd import engine
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(n_reads=1200, seed=13, mean_len=90000, sigma=0.9, max_len=1_200_000, coverage=25)
+    cols = [c.numpy() for c in (o.read_len,) + o.columns()]
+    p = RaftParams(est_cov=25)
+    want = oracle_run(p, *cols)
+    monkeypatch.setenv("RAFT_EXTRA_CAP", "1")
+    eng = engine.Engine(sym_params(p), device=0)
+    eng.set_output_width(8)
+    eng.run_host(cols[0], cols[1], cols[2], cols[3], None, None, None)
+    s = eng.finish()
+    check_encoding(eng.fetch_delta4(), want, "extra-tile overflow")
+    assert_same_result(result_of(eng, s), want, "extra-tile overflow, int32")
+    res, s2 = eng.run_pipelined(cols[0], cols[1], cols[2], cols[3], n_chunks=3, out=eng.host_output_buffers(cols[0], pinned=False, width=8))
+    check_pipelined_d4(res, s2, want, "extra-tile overflow, pipelined")
+    eng.close()
