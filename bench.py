@@ -398,10 +398,28 @@ def main():
             e.run_device(sh.read_len, *sh.cols)
         return e.finish()
 
+    comb = {"work": None, "mine": None, "all": None, "stage": None}
+
     def combine(s):
-        # global read_num base of this shard's fragments + the stdout sums (chop.hpp:195, repeat.hpp:93-97)
-        if dist is not None:
-            rdist.combine_totals(s.n_fragments, s.total_coverage, s.total_windows, s.total_repeat_length, s.total_read_length, device=coll_dev)
+        # global read_num base of this shard's fragments + the stdout sums (chop.hpp:195, repeat.hpp:93-97): one all-gather of five
+        # integers per rank and step.  It is queued behind the pass and waited for at the next step's (the ranks' passes are
+        # independent: nothing of step k+1 needs step k's bases), the last one inside the timed region's closing fence.
+        if dist is None:
+            return
+        if comb["mine"] is None:
+            comb["stage"] = torch.zeros(5, dtype=torch.int64).pin_memory() if str(coll_dev) != "cpu" else torch.zeros(5, dtype=torch.int64)
+            comb["mine"] = torch.zeros((1, 5), dtype=torch.int64, device=coll_dev)
+            comb["all"] = torch.zeros((dist.get_world_size(), 5), dtype=torch.int64, device=coll_dev)
+        if comb["work"] is not None:
+            comb["work"].wait()
+        comb["stage"].copy_(torch.tensor([s.n_fragments, s.total_coverage, s.total_windows, s.total_repeat_length, s.total_read_length], dtype=torch.int64))
+        comb["mine"].copy_(comb["stage"].unsqueeze(0))        # (five numbers; the stream is idle behind raft_hip_finish)
+        comb["work"] = dist.all_gather_into_tensor(comb["all"], comb["mine"], async_op=True)
+
+    def combine_done():
+        if comb["work"] is not None:
+            comb["work"].wait()
+            comb["work"] = None
 
     def timed(step_fn, e, warmup, steps):
         for _ in range(warmup):
@@ -413,6 +431,7 @@ def main():
             s = step_fn()
             a, b = e.timing()
             pile_t.append(a); pass_t.append(b)
+        combine_done()
         fence()
         elapsed = time.perf_counter() - t0
         if dist is not None:
