@@ -876,7 +876,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     }
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
     if (ow == kCovDelta4)      // the windows the tiles listed, gathered into the shared list (whose counter the control block carries)
-        hipLaunchKernelGGL(compact_exceptions_kernel, dim3((unsigned)((d4_tiles + 255) / 256)), dim3(256), 0, st, d4_tiles, kExcPerTile,
+        hipLaunchKernelGGL(compact_exceptions_kernel, dim3((unsigned)((d4_tiles + kCompactTiles - 1) / kCompactTiles)), dim3(256), 0, st, d4_tiles, kExcPerTile,
                            c->exc_tile_n.as<int32_t>(), c->exc_pidx.as<long long>(), c->exc_pval.as<int32_t>(), &ctrl->n_exc, c->exc_cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>());
 
     // ---- per-read tail: order repeats, mask markers, fragments

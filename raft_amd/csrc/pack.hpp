@@ -134,24 +134,52 @@ __device__ __forceinline__ unsigned delta4_code(int step, int value, long long w
 }
 
 // The windows the pileup listed tile by tile (PileupArgs::exc_pidx: kExcPerTile slots per tile, exc_tile_n of them used) appended
-// to the shared list: one thread per tile, one atomic per wave.
+// to the shared list.  One workgroup per 1024 tiles: the tiles' counts are scanned in the workgroup, ONE atomic reserves the
+// room of all of them, and the slots are copied with a thread per slot -- a tile's entries lie together, consecutive tiles'
+// entries land behind one another.  (First version: a thread per tile copying its own slots one by one, an atomic per wave:
+// 0.21 ms at human scale, its 8-byte stores scattered at a tile's stride.)
+constexpr int kCompactTiles = 1024;
 __global__ __launch_bounds__(256) void compact_exceptions_kernel(long long n_tiles, int per_tile, const int32_t *__restrict__ tile_n,
                                                                  const long long *__restrict__ pidx, const int32_t *__restrict__ pval,
                                                                  unsigned long long *n_exc, long long exc_cap, long long *__restrict__ exc_idx,
                                                                  int32_t *__restrict__ exc_val)
 {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int cnt = t < n_tiles ? tile_n[t] : 0;
-    const int incl = wave_incl_scan_add(cnt);
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    if (total == 0) return;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(n_exc, (unsigned long long)total);
-    base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    const long long at = (long long)base + incl - cnt;
-    for (int q = 0; q < cnt; ++q)
-        if (at + q < exc_cap) { exc_idx[at + q] = pidx[t * per_tile + q]; exc_val[at + q] = pval[t * per_tile + q]; }
+    __shared__ int pre[kCompactTiles + 1];
+    __shared__ int wsum[4];
+    __shared__ long long base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const long long t0 = (long long)blockIdx.x * kCompactTiles;
+    int c[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long t = t0 + tid * 4 + j;
+        c[j] = t < n_tiles ? tile_n[t] : 0;
+        sum += c[j];
+    }
+    const int incl = wave_incl_scan_add(sum);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int x = wsum[w]; if (w < wid) before += x; total += x; }
+    if (total == 0) return;                              // (uniform: most workgroups of the extra tiles' range)
+    int run = before + incl - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { pre[tid * 4 + j] = run; run += c[j]; }
+    if (tid == 255) pre[kCompactTiles] = run;
+    if (tid == 0) base_s = (long long)atomicAdd(n_exc, (unsigned long long)total);
+    __syncthreads();
+    const long long base = base_s;
+    const int slot = tid % per_tile, tile_in_group = tid / per_tile, tiles_per_group = 256 / per_tile;   // (per_tile divides 256)
+    for (int g = 0; g < kCompactTiles; g += tiles_per_group) {
+        if (pre[g + tiles_per_group] == pre[g]) continue;   // (uniform: none of these tiles listed a window)
+        const int tl = g + tile_in_group;
+        const int first = pre[tl], cnt = pre[tl + 1] - first;
+        if (slot < cnt) {
+            const long long at = base + first + slot, from = (t0 + tl) * per_tile + slot;
+            if (at < exc_cap) { exc_idx[at] = pidx[from]; exc_val[at] = pval[from]; }
+        }
+    }
 }
 
 // int32 cov[] -> delta4 (after a pass that wrote int32: the general kernel took part, or the caller asked late)

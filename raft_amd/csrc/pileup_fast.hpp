@@ -329,33 +329,32 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                 } else note_exception(a, a0 + p, v);
             };
             auto d4_codes = [&](const int4 d, int c0, int c1, int c2, int c3, int p0, unsigned valid) -> unsigned {
-                // the common case first: four steps within [-7, 7], none of them the tile's first window
+                // four steps -> four nibbles, step + 8 where it lies within [-7, 7], else 0; the tile's first window and the
+                // slots outside the tile are cleared as well.  Straight-line: half of all rows have ONE lane with a listed
+                // window (a large step at a read boundary), and whatever that lane does the whole wave walks through -- so
+                // the lane only finds its zero nibble and parks the window in two registers until the rows are done (one LDS
+                // atomic per wave and tile then places all of them in the tile's own kExcPerTile slots, plain stores,
+                // gathered by compact_exceptions_kernel).  History: a returning atomic per window on the one shared counter
+                // took 12 ms for the 3.4e5 of a 36 ms chunk; an LDS atomic with its wait inside the rows 0.15 ms of the
+                // kernel; a second path that recomputed the steps for the wave whenever one lane listed a window 0.2 ms.
                 const unsigned ux = (unsigned)(d.x + 7), uy = (unsigned)(d.y + 7), uz = (unsigned)(d.z + 7), uw = (unsigned)(d.w + 7);
-                const bool plain = max(max(ux, uy), max(uz, uw)) <= 14u && (unsigned)(off0 - p0) >= 4u;
-                if (plain) return ((ux + 1u) | ((uy + 1u) << 4) | ((uz + 1u) << 8) | ((uw + 1u) << 12)) & (valid == 15u ? 0xFFFFu : (((valid & 1u) ? 0xFu : 0u) | ((valid & 2u) ? 0xF0u : 0u) | ((valid & 4u) ? 0xF00u : 0u) | ((valid & 8u) ? 0xF000u : 0u)));
-                // some window of this lane is listed -- half of all rows have such a lane (a large step at a read boundary) and the
-                // whole wave walks this path with it, so it is kept short: the steps of the other windows as above, and the
-                // listed window parked in two registers until the rows are done (one LDS atomic per wave and tile then places
-                // all of them: in the tile's own kExcPerTile slots, plain stores, gathered by compact_exceptions_kernel -- a
-                // returning atomic per window on the one shared counter took 12 ms for the 3.4e5 of a 36 ms chunk, an LDS atomic
-                // with its wait inside the rows 0.4 ms of the kernel's 2.7).  A lane that lists a second window before that,
-                // or two at once, places them at once.
+                unsigned code = (ux <= 14u ? ux + 1u : 0u) | ((uy <= 14u ? uy + 1u : 0u) << 4) | ((uz <= 14u ? uz + 1u : 0u) << 8) |
+                                ((uw <= 14u ? uw + 1u : 0u) << 12);
                 const unsigned f = (unsigned)(off0 - p0);                     // < 4: the tile's first window is this lane's slot f
-                unsigned esc = ((ux > 14u || f == 0u) ? 1u : 0u) | ((uy > 14u || f == 1u) ? 2u : 0u) | ((uz > 14u || f == 2u) ? 4u : 0u) |
-                               ((uw > 14u || f == 3u) ? 8u : 0u);
-                esc &= valid;
-                const unsigned keep = valid & ~esc;
-                // (a listed window's step does not fit four bits: every term is cut to its nibble before they are joined)
-                const unsigned code = (((ux + 1u) & 15u) | (((uy + 1u) & 15u) << 4) | (((uz + 1u) & 15u) << 8) | (((uw + 1u) & 15u) << 12)) &
-                                      (((keep & 1u) ? 0xFu : 0u) | ((keep & 2u) ? 0xF0u : 0u) | ((keep & 4u) ? 0xF00u : 0u) | ((keep & 8u) ? 0xF000u : 0u));
+                if (f < 4u) code &= ~(0xFu << (4u * f));
+                const unsigned vmask = valid == 15u ? 0xFFFFu : (((valid & 1u) ? 0xFu : 0u) | ((valid & 2u) ? 0xF0u : 0u) | ((valid & 4u) ? 0xF00u : 0u) | ((valid & 8u) ? 0xF000u : 0u));
+                code &= vmask;
+                unsigned t = code | (code >> 1);
+                t |= t >> 2;                                                  // bit 4q: nibble q is not zero
+                unsigned esc = ~t & 0x1111u & vmask;                          // bit 4q: window q of this lane is listed
                 if (esc) {
                     if (pend_p < 0 && (esc & (esc - 1u)) == 0u) {
-                        const int q = __ffs((int)esc) - 1;
+                        const int q = (__ffs((int)esc) - 1) >> 2;
                         pend_p = p0 + q; pend_c = q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3;
                     } else {
                         int slot = __hip_atomic_fetch_add(&sm.exc_n, (int)__popc(esc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         while (esc) {
-                            const int q = __ffs((int)esc) - 1;
+                            const int q = (__ffs((int)esc) - 1) >> 2;
                             esc &= esc - 1u;
                             d4_list(p0 + q, q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3, slot++);
                         }
