@@ -203,10 +203,16 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
             same_d = psum == (ds.n_bins, ds.n_repeats, ds.n_fragments, ds.total_coverage, ds.total_repeat_length) and \
                 all(np.array_equal(pcopy[k], dres[k]) for k in pcopy if k != "cov8")
             # decoded on the host (raft_host_unpack_coverage_d4) and compared with the byte encoding of the same windows, outside the clock
-            dec = hostio.unpack_coverage_d4(ds.n_bins, dres["cov_nib"], dres["cov_anchor"], dres["exc_index"], dres["exc_value"])
+            # (in slices of 2^28 windows -- blocks of 1024 decode independently -- so that the check needs 1 GB, not the 8 of the int32 array)
             lim8 = 255 if width == 1 else 65535
-            same_d = same_d and bool(np.array_equal(np.minimum(dec, lim8).astype(pcopy["cov8"].dtype), pcopy["cov8"]))
-            del dec
+            xi = dres["exc_index"]
+            for a in range(0, ds.n_bins, 1 << 28):
+                b = min(ds.n_bins, a + (1 << 28))
+                x0, x1 = np.searchsorted(xi, [a, b])
+                dec = hostio.unpack_coverage_d4(b - a, dres["cov_nib"][a // 2:(b + 1) // 2], dres["cov_anchor"][a // 1024:(b + 1023) // 1024],
+                                                xi[x0:x1] - a, dres["exc_value"][x0:x1])
+                same_d = same_d and bool(np.array_equal(np.minimum(dec, lim8).astype(pcopy["cov8"].dtype), pcopy["cov8"][a:b]))
+                del dec
             wrec["delta4"] = {"records_per_s": o.n_rec / dsec, "fragments_per_s": ds.n_fragments / dsec, "seconds": dsec, "first_pass_s": dtimes[0],
                               "d2h_bytes": int(sum(dres[k].nbytes for k in dres)), "listed_windows": int(dres["exc_index"].size),
                               "decoded_equals_byte_encoding": bool(same_d),
