@@ -127,10 +127,10 @@ def test_long_reads_and_pieces_in_every_width(width, seed):
         check_against(res, want, width, f"long reads seed {seed} width {width} reso {p.reso}")
 
 
-@pytest.mark.parametrize("width", [1, 2])
+@pytest.mark.parametrize("width", [1, 2, 8])
 def test_existing_suites_with_every_context_in_that_width(width):
-    """RAFT_COV_WIDTH puts every context of a process into the width: the parity and consistency suites, whose checks all go
-    through the int32 array, must not notice."""
+    """RAFT_COV_WIDTH puts every context of a process into the width (8: the four-bit step encoding): the parity and
+    consistency suites, whose checks all go through the int32 array, must not notice."""
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_consistency.py")],
                        cwd=ROOT, env=dict(os.environ, RAFT_COV_WIDTH=str(width)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
