@@ -2,17 +2,15 @@
 """bench.py -- RAFT hot path (PAF overlaps -> coverage -> repeat mask -> fragments) on MI355X.
 
 One "step" = one full pass of the engine over one synthetic all-vs-all overlap set that is already resident in HBM when the
-clock starts: tile cuts, the pileup / prefix-sum / run-scan kernel, repeat ordering, cut-point counts, fragment table and
-the stdout statistics.  Outputs stay in HBM.  (The cut points themselves -- chop.hpp's final_stars, 4 B per kept marker --
-are materialised by the first caller that asks for them and are not part of a pass; the fragments are derived without
-them.)
+clock starts: stream inspection (sorted runs, symmetric detection), tile cuts, the pileup / prefix-sum / run-scan kernel,
+repeat ordering, cut points (chop.hpp's final_stars), fragment table and the stdout statistics.  Outputs stay in HBM.
 
-Input form (`--input`): `grouped` (default) -- what the `raft` CLI hands the engine: the tokeniser's columns plus, per
-sorted run of the stream, where every read's records begin (raft_hip_run_device_grouped; hifiasm writes its PAF grouped by
-query, reference README.md:36-38) and the window count the loader of the reads knows; the pass then needs no look at the
-stream, no searches, no host wait, and still checks every record against the reads of the tile that processes it.
-`columns` -- the six plain columns into a detecting context (symmetric_mode = -1), the form of rounds 1-2; at N = 1 it is
-timed beside the headline as `six_column`.
+Input form (`--input`): `columns` (default, the headline `value`) -- the six plain int32 columns of SURVEY.md §8(b)'s C-ABI
+into a detecting context (symmetric_mode = -1): everything create_pileup has to find out about the stream (sorted runs, the
+mirror of record 0, which records belong to which read) is found out INSIDE the timed step.  `grouped` / `windows` -- what a
+tokeniser that resolves every name can hand over beside the columns (per sorted run, where every read's records begin; the
+window count; one word per record): those passes are reported as extra legs (`grouped`, `window_records`) and are never the
+headline, because part of create_pileup's bucketing then happens outside the step.
 
 Workload (config.workload), default `hg002`: BASELINE.json configs[2] restated synthetically:
 HG002-like 32x set, 3.3 M reads of 30 kb mean length, ~2.9e8 symmetric PAF records written as a cis file followed by a
@@ -30,7 +28,10 @@ contiguous slice of the record stream and one all-to-all-v (RCCL over xGMI) per 
 The line also carries (N = 1): `packed_output` -- the pass exactly as the CLI and the host pipelines run it (grouped, no
 query column, coverage written as one byte per window by the pileup kernel itself); `e2e` -- the same workload from
 page-locked host columns to every output back on the host (SURVEY.md §8d `t_e2e`; never the headline `value`);
-`roofline.pass_frac` -- algorithmic bytes over the device time of the WHOLE pass; `cpu_baseline`.
+`roofline.pass_frac` -- algorithmic bytes over the device time of the WHOLE pass (cut points included: the pass writes
+chop.hpp's final_stars itself; `pass_device_ms_without_cuts` is the same pass with them left to the first fetch);
+`cpu_baseline`.  `e2e.records_per_s` starts at SURVEY.md §8(d)'s boundary -- page-locked int32 columns in, every output back
+on the host -- with everything the engine's host side derives from the columns inside the clock.
 
 `python bench.py --gpus N` without a launcher starts the N ranks itself (child processes, before any GPU call); under
 `python -m torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE.
@@ -217,7 +218,32 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
                               "d2h_bytes": int(sum(dres[k].nbytes for k in dres)), "listed_windows": int(dres["exc_index"].size),
                               "decoded_equals_byte_encoding": bool(same_d),
                               "mode": "raft_hip_run_multi_windows, cov_width = RAFT_HIP_COV_DELTA4: coverage comes back as four bits per window"}
-            del out4, dres
+            # (a3) SURVEY.md §8(d)'s boundary, nothing prepared: the clock starts with the page-locked int32 columns (read_len, qid, qs, qe)
+            # and the tokeniser's symmetric flag, and ends with every output on the host.  The grouped form (raft_host_group_offsets)
+            # and the window records (raft_host_pack_windows) are derived INSIDE the clock, into page-locked buffers the caller keeps
+            # from job to job (allocated before the clock, like the output buffers).
+            off_buf = torch.empty(4 * (o.n_reads + 1), dtype=torch.int64, pin_memory=True).numpy()
+            stimes, prep = [], []
+            for it in range(n_iter + 1):
+                t0 = time.perf_counter()
+                off_s = hostio.group_offsets(o.n_reads, host[1], max_runs=4, out=off_buf)
+                t1 = time.perf_counter()
+                win_s = hostio.pack_windows(host[2], host[3], p.reso, out=wbuf)
+                t2 = time.perf_counter()
+                sres, ss = eng.run_pipelined_windows(host[0], off_s, win_s, out=out4)
+                t3 = time.perf_counter()
+                stimes.append(t3 - t0); prep.append((t1 - t0, t2 - t1, t3 - t2))
+            ssec = sorted(stimes[1:])[len(stimes[1:]) // 2]
+            pm = prep[1 + stimes[1:].index(ssec)]
+            same_s = (ss.n_bins, ss.n_repeats, ss.n_fragments, ss.total_coverage, ss.total_repeat_length) == psum and \
+                all(np.array_equal(pcopy[k], sres[k]) for k in pcopy if k != "cov8") and np.array_equal(sres["exc_index"], dres["exc_index"]) and \
+                np.array_equal(sres["cov_nib"], dres["cov_nib"])
+            wrec["from_soa"] = {"records_per_s": o.n_rec / ssec, "fragments_per_s": ss.n_fragments / ssec, "seconds": ssec, "first_pass_s": stimes[0],
+                                "group_offsets_s": pm[0], "pack_windows_s": pm[1], "engine_s": pm[2], "equals_prepared_input": bool(same_s),
+                                "boundary": "page-locked int32 columns (read_len, qid, qs, qe) + the tokeniser's symmetric flag in; repeats, fragments and "
+                                            "coverage (four-bit steps) in page-locked host memory out; raft_host_group_offsets and raft_host_pack_windows "
+                                            "inside the clock, writing page-locked buffers allocated before it"}
+            del out4, dres, sres
     # (b) chunked, six-column input (query column uploaded, runs guessed from samples, cuts searched)
     ctimes = []
     for it in range(n_iter):
@@ -266,7 +292,13 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
     if wrec is not None:
         # the headline of this object is the form the CLI uses (window records); the coordinate-column form stays beside it
         res["coordinate_columns"] = {k: res[k] for k in ("records_per_s", "fragments_per_s", "seconds", "mode", "h2d_bytes")}
+        # headline of the object: the contract boundary (from_soa); the prepared-input figures stay beside it
         top = wrec["delta4"] if wrec.get("delta4", {}).get("decoded_equals_byte_encoding") else wrec
+        if wrec.get("from_soa", {}).get("equals_prepared_input"):
+            res["prepared_input"] = {k: top[k] for k in ("records_per_s", "fragments_per_s", "seconds")}
+            res["prepared_input"]["note"] = "offsets and window records built outside the clock (round 3's e2e headline)"
+            top = dict(top, **{k: wrec["from_soa"][k] for k in ("records_per_s", "fragments_per_s", "seconds")})
+            top["mode"] = "SoA boundary: " + wrec["from_soa"]["boundary"]
         res["byte_per_window_d2h_bytes"] = res["d2h_bytes"]
         res.update(records_per_s=top["records_per_s"], fragments_per_s=top["fragments_per_s"], seconds=top["seconds"], mode=top["mode"],
                    h2d_bytes=wrec["h2d_bytes"], d2h_bytes=top.get("d2h_bytes", res["d2h_bytes"]), window_records=wrec)
@@ -300,9 +332,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="hg002")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's own size); with --strong / --presplit: reads of the ONE set")
     ap.add_argument("--seed", type=int, default=20241008)
-    ap.add_argument("--input", choices=["grouped", "columns", "windows"], default="grouped",
-                    help="grouped: columns + per-read record offsets + window count; windows: the same with one word per record (window records, what "
-                         "the CLI hands over); columns: six plain columns, detecting context")
+    ap.add_argument("--input", choices=["grouped", "columns", "windows"], default="columns",
+                    help="columns (headline): six plain columns, detecting context -- the self-contained pass; grouped: columns + per-read record "
+                         "offsets + window count; windows: the same with one word per record (window records, what the CLI hands over)")
     ap.add_argument("--no-qid", action="store_true", help="grouped input without the query column (rebuilt from the offsets on the device)")
     ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -312,7 +344,7 @@ def main():
                     help="bytes per window the timed pass writes (4 = int32 cov[]; 1 / 2 = its transfer encoding; 8 = four-bit steps, delta4)")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the extra passes that time the pass writing the transfer encoding")
     ap.add_argument("--handover", action="store_true", help="--input columns with symmetric_mode = 1: the symmetric flag is handed over")
-    ap.add_argument("--no-six-column-leg", action="store_true", help="skip the extra passes that time the six-column detecting form")
+    ap.add_argument("--no-six-column-leg", action="store_true", help="skip the extra passes that time the other input form (six-column / grouped)")
     ap.add_argument("--strong", action="store_true", help="ONE set cut into --gpus contiguous read ranges (BASELINE configs[3] without the exchange)")
     ap.add_argument("--presplit", action="store_true", help="BASELINE configs[3]: --strong with the records pre-split across ranks, all-to-all-v in the step")
     ap.add_argument("--no-strong-leg", action="store_true", help="weak multi-GPU runs: skip the strong-scaling leg")
@@ -388,8 +420,9 @@ def main():
                         raise SystemExit("bench.py: --input windows needs reads below 65,535 windows")
                     self.win = torch.as_tensor(w.view("int32")).to(dev)
 
-    def make_engine(sh: Shard, width: int):
-        e = engine.Engine(p_sym if (sh.off is not None or args.handover) else p, device=local)
+    def make_engine(sh: Shard, width: int, routed: bool = False):
+        # (routed: the records a rank of a host-routed job is handed ARE the query-side multiset of its reads, engine.hip run_routed)
+        e = engine.Engine(p_sym if (sh.off is not None or args.handover or routed) else p, device=local)
         e.set_tuning(args.tile_bins, args.force_bucket, args.variant)
         e.set_output_width(width)
         e.use_torch_stream()
@@ -508,8 +541,8 @@ def main():
                     combine(s)
                     return s
         else:
-            sh = Shard(my_len, cols, grouped_in)
-            e = make_engine(sh, args.cov_width)
+            sh = Shard(my_len, cols[:3], grouped_in)
+            e = make_engine(sh, args.cov_width, routed=True)
 
             def step():
                 s = pass_of(e, sh, qid=not args.no_qid)
@@ -563,7 +596,11 @@ def main():
         check = {"sum_cov_equals_windows_touched": int(out["cov"].sum(dtype=torch.int64)) == int(touched.sum()) == s.total_coverage,
                  "fragments_tile_reads": bool((fb[fo[:-1]] == 0).all()) and bool((fe[fo[1:] - 1] == o.read_len).all())
                  and bool(((fe[:-1] - fb[1:])[same] == p.overlap_length).all()),
-                 "windows": s.n_bins == int(((o.read_len.long() + p.reso - 1) // p.reso).sum())}
+                 "windows": s.n_bins == int(((o.read_len.long() + p.reso - 1) // p.reso).sum()),
+                 # cut points (written by the pass): every read's first is 0 and its last its length, ascending in between, and every
+                 # fragment boundary is one of them (chop.hpp:225-246, :280-321)
+                 "cut_points_span_reads": bool((out["cuts"][out["cut_offset"][:-1]] == 0).all()) and bool((out["cuts"][out["cut_offset"][1:] - 1] == o.read_len).all())
+                 and int(out["cut_offset"][-1]) == s.n_cuts}
         del touched, out
         if not all(check.values()) and "RAFT_BENCH_ABLATION" not in os.environ:      # (ablation builds of tools/ab.sh compute nonsense on purpose)
             raise SystemExit(f"bench.py: self-check failed: {check}")
@@ -662,37 +699,65 @@ def main():
                 windows_d4_leg = encoded_pass("windows_d4")
         del ref_cov, big
 
-    # ---- the six plain columns into a detecting context (rounds 1-2's headline form), and its inspect-first form
-    six = None
-    if n_gpus == 1 and not args.no_six_column_leg and grouped_in:
-        def six_passes(env=None):
-            if env:
-                os.environ[env] = "1"
-            try:
-                e2 = engine.Engine(p, device=local)
-                e2.set_tuning(args.tile_bins, args.force_bucket, args.variant)
-                e2.use_torch_stream()
-                kt, pt, wall = [], [], []
-                for it in range(5):
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
+    # ---- the other input form beside the headline: the six plain columns into a detecting context (with its inspect-first
+    # form) when the headline is a grouped form; the grouped form (offsets + window count handed over) when the headline is
+    # the six-column pass.  Same set, same checks, five passes each.
+    six = grouped_leg = no_cuts = None
+
+    def extra_passes(form, env=None, cuts=True):
+        if env:
+            os.environ[env] = "1"
+        try:
+            if form == "grouped":
+                shg = sh if sh.off is not None else Shard(o.read_len, o.columns(), True)
+                e2 = engine.Engine(p_sym, device=local)
+            else:
+                shg = None
+                e2 = engine.Engine(p_sym if form == "handover" else p, device=local)
+            e2.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+            e2.set_emit_cuts(cuts)
+            e2.use_torch_stream()
+            kt, pt, wall = [], [], []
+            for it in range(5):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                if shg is not None:
+                    e2.run_device_grouped(shg.read_len, shg.off, shg.cols[0], shg.cols[1], shg.cols[2], n_bins=shg.n_bins)
+                elif form == "handover":
+                    e2.run_device(o.read_len, o.qid, o.qs, o.qe)
+                else:
                     e2.run_device(o.read_len, *o.columns())
-                    s2 = e2.finish()
-                    torch.cuda.synchronize()
-                    if it:
-                        wall.append(time.perf_counter() - t1)
-                        a, b = e2.timing(); kt.append(a); pt.append(b)
-                assert (s2.n_fragments, s2.n_repeats, s2.total_coverage, s2.symmetric) == (s.n_fragments, s.n_repeats, s.total_coverage, 1)
-                e2.close()
-                return sum(kt) / len(kt), sum(pt) / len(pt), sum(wall) / len(wall)
-            finally:
-                if env:
-                    del os.environ[env]
-        k2, p2, w2 = six_passes()
-        _, p2i, _ = six_passes("RAFT_ALWAYS_INSPECT")
-        six = {"value": my_rec / w2, "unit": "PAF records/s", "ms_per_step": w2 * 1e3, "kernel_ms": k2 * 1e3, "pass_device_ms": p2 * 1e3,
-               "pass_device_ms_inspect_first": p2i * 1e3,
-               "form": "raft_hip_run_device, symmetric_mode = -1: sorted runs guessed from samples, tile cuts searched, mirror of record 0 found beside the pileup, one host wait"}
+                s2 = e2.finish()
+                torch.cuda.synchronize()
+                if it:
+                    wall.append(time.perf_counter() - t1)
+                    a, b = e2.timing(); kt.append(a); pt.append(b)
+            assert (s2.n_fragments, s2.n_repeats, s2.total_coverage, s2.symmetric) == (s.n_fragments, s.n_repeats, s.total_coverage, 1)
+            e2.close()
+            return sum(kt) / len(kt), sum(pt) / len(pt), sum(wall) / len(wall)
+        finally:
+            if env:
+                del os.environ[env]
+    if n_gpus == 1 and not args.no_six_column_leg and eng is not None and args.cov_width == 4 and not args.force_bucket:
+        if grouped_in:
+            k2, p2, w2 = extra_passes("columns")
+            _, p2i, _ = extra_passes("columns", "RAFT_ALWAYS_INSPECT")
+            six = {"value": my_rec / w2, "unit": "PAF records/s", "ms_per_step": w2 * 1e3, "kernel_ms": k2 * 1e3, "pass_device_ms": p2 * 1e3,
+                   "pass_device_ms_inspect_first": p2i * 1e3,
+                   "form": "raft_hip_run_device, symmetric_mode = -1: sorted runs guessed from samples, tile cuts searched, mirror of record 0 found beside the pileup, one host wait"}
+        else:
+            k2, p2, w2 = extra_passes("grouped")
+            grouped_leg = {"value": my_rec / w2, "unit": "PAF records/s", "ms_per_step": w2 * 1e3, "kernel_ms": k2 * 1e3, "pass_device_ms": p2 * 1e3,
+                           "form": "raft_hip_run_device_grouped, symmetric_mode = 1: the caller hands over the symmetric flag, per sorted run where every read's records "
+                                   "begin (raft_host_group_offsets, built OUTSIDE this clock) and the window count: no guess, no searches, no host wait",
+                           "note": "part of create_pileup's bucketing is done by the caller here: never the headline"}
+            _, p2i, _ = extra_passes("columns", "RAFT_ALWAYS_INSPECT")
+            grouped_leg["six_column_pass_device_ms_inspect_first"] = p2i * 1e3
+        # the headline's form with the cut points left to the first fetch (what rounds 1-3 timed)
+        form0 = "grouped" if grouped_in else ("handover" if args.handover else "columns")
+        if not windows_in:
+            _, p0, w0 = extra_passes(form0, cuts=False)
+            no_cuts = {"pass_device_ms": p0 * 1e3, "ms_per_step": w0 * 1e3}
 
     if rank == 0:
         per_step = elapsed / args.steps
@@ -724,8 +789,8 @@ def main():
                        "repeats_rank0": s.n_repeats, "mean_read_len": gen_kw["mean_len"], "coverage": gen_kw["coverage"],
                        "interval_path": "sorted-segments" if s.interval_path == 0 else "counting-sort",
                        "segments": s.n_segments,
-                       "cut_points": "materialised on demand by the first fetch that asks for them (finalize_cuts_kernel), outside the pass and the clock; "
-                                     "fragment bounds are derived without them",
+                       "cut_points": "written by the pass (chop.hpp:225-246 final_stars; finalize_fill_kernel<true>), inside the step and the clock",
+                       "cut_points_total_rank0": s.n_cuts,
                        "sharding": (f"the ONE set of {o.n_reads} reads in {n_gpus} contiguous read ranges, "
                                     + ("records pre-split, one all-to-all-v per step" if args.presplit else "host-routed, no data-path collective") if strong_line
                                     else f"reads x{n_gpus}, independent shards, no data-path collective") + (", ranks share GPUs (gloo check run)" if shared else "")},
@@ -734,7 +799,10 @@ def main():
                                    + ("" if args.variant < 0 else f" variant {args.variant}"),
                          "kernel_ms": pile * 1e3, "bytes_algorithmic": bytes_alg,
                          "pass_device_ms": pass_dev * 1e3, "pass_achieved": bytes_alg / pass_dev / 1e9,
-                         "pass_frac": bytes_alg / pass_dev / 1e9 / HBM_PEAK_GBS, "kernel_source_hash": kernel_source_hash()},
+                         "pass_frac": bytes_alg / pass_dev / 1e9 / HBM_PEAK_GBS, "pass_includes_cut_points": True,
+                         "pass_note": "pass_frac divides the pileup kernel's algorithmic bytes (12 I + 4 B + 4 N + 8 R) by the device time of the whole pass, "
+                                      "cut points (4 M more bytes, not counted) included",
+                         "kernel_source_hash": kernel_source_hash()},
             "self_check": check,
         }
         if packed is not None:
@@ -753,6 +821,11 @@ def main():
                 line["window_records_delta4"] = windows_d4_leg
         if six is not None:
             line["six_column"] = six
+        if grouped_leg is not None:
+            line["grouped"] = grouped_leg
+        if no_cuts is not None:
+            line["roofline"]["pass_device_ms_without_cuts"] = no_cuts["pass_device_ms"]
+            line["roofline"]["ms_per_step_without_cuts"] = no_cuts["ms_per_step"]
         if strong_info is not None:
             line["strong"] = strong_info
         if args.cov_width != 4:

@@ -247,6 +247,12 @@ int  raft_hip_fetch_delta4(raft_hip_ctx *ctx, int64_t *cov_offset, uint8_t *cov_
  * plain copy). */
 int  raft_hip_set_output_width(raft_hip_ctx *ctx, int32_t width);
 
+/* Cut points (chop.hpp:225-246 final_stars; `cuts` / `cut_offset` of raft_hip_outputs and raft_hip_fetch): on = 1 (the
+ * default) -- every later pass of the context writes them itself, in the kernel that also writes the fragment table;
+ * on = 0 -- they are left out of the pass and written by the first raft_hip_fetch / raft_hip_outputs_device that asks for
+ * them (the fragment bounds are derived without them; the host pipelines, whose outputs hold no cut points, run this way). */
+int  raft_hip_set_emit_cuts(raft_hip_ctx *ctx, int32_t on);
+
 /* Device arrays of the encoding the finished pass holds (width 0: none -- the pass wrote int32; call
  * raft_hip_fetch_packed_w once to have it encoded).  The exceptions are in no particular order. */
 int  raft_hip_packed_device(raft_hip_ctx *ctx, int32_t *width, const void **cov_packed, const int64_t **exc_index,

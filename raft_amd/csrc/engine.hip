@@ -10,6 +10,12 @@
 #include <rocprim/device/device_radix_sort.hpp>   // (the exception list's order: a library sort of a few 1e5 pairs, off the hot path)
 #include "pileup.hpp"
 #include "pileup_fast.hpp"
+#include "pileup_wave.hpp"
+#include "wave_launch.hpp"
+
+#ifndef RAFT_DEFAULT_VARIANT
+#define RAFT_DEFAULT_VARIANT 0
+#endif
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -45,10 +51,20 @@ constexpr PileVariant kVariants[] = {
     {1, 6144, 5, 1536},   // 2: fast kernel, 29.2 KB LDS, 5 workgroups/CU, 4 prefetch slots per lane, Q = 4608
     {1, 7936, 4, 1664},   // 3: variant 0 with s_memtime stamps in the fast kernel (diagnostic; raft_hip_debug_stamps)
     {1, 7936, 4, 1664},   // 4: variant 0 with lane-serial rows (pileup_fast.hpp LS)
+    {2, kWaveSlots - 4, 4, 0},   // 5: one wave per tile, 16-bit difference array (pileup_wave.hpp); every tile cut by tile_desc_kernel's walk
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
-constexpr int kDefaultVariant = 0;
+constexpr int kDefaultVariant = RAFT_DEFAULT_VARIANT;
 constexpr int kDiagVariant = 3;
+// the variant a context starts with and raft_hip_set_tuning(variant = -1) returns to: RAFT_VARIANT=<n> (test sweeps, A/B) or the build's default
+int default_variant()
+{
+    static const int v = [] {
+        if (const char *e = getenv("RAFT_VARIANT")) { const int x = atoi(e); if (x >= 0 && x < kNumVariants) return x; }
+        return kDefaultVariant;
+    }();
+    return v;
+}
 constexpr int kFastSlots = 4;     // default number of prefetched intervals per lane and tile in the fast kernel
 
 template <int CAP, int MINW>
@@ -222,7 +238,7 @@ struct raft_hip_ctx {
     raft_hip_params prm{};
     int32_t high_cov = 0, div = 0, minbins = 1;
     int32_t tile_q = 0;               // 0 = variant default
-    int32_t variant = kDefaultVariant;
+    int32_t variant = default_variant();
     int32_t force_bucket = 0;
     bool no_recut = false;            // leave tiles that do not fit the fast kernel to the general kernel (fallback, A/B)
     std::string last_error;
@@ -284,6 +300,8 @@ struct raft_hip_ctx {
     long long cap_rep = 0, cap_cut = 0;
     FinalizeArgs fa{};                // of the last pass (the cut points are materialised on demand)
     bool cuts_ready = false;
+    bool is_lane = false;              // a sub-context of a host pipeline (prepare_lanes)
+    bool emit_cuts = true;             // the pass writes the cut points (final_stars) itself; false: on demand (raft_hip_set_emit_cuts)
 };
 
 namespace {
@@ -326,7 +344,7 @@ int code_from_flags(int flags)
     if (flags & kErrReadId) return RAFT_HIP_ERR_READ_ID;
     if (flags & kErrCoord) return RAFT_HIP_ERR_COORD;
     if (flags & kErrFragment) return RAFT_HIP_ERR_FRAGMENT;
-    if (flags & (kErrInternal | kErrOrder | kErrExtra | kErrHint)) return RAFT_HIP_ERR_DEVICE;   // (kErrOrder / kErrHint never outlive raft_hip_finish's second run)
+    if (flags & (kErrInternal | kErrOrder | kErrExtra | kErrHint | kErrDeep)) return RAFT_HIP_ERR_DEVICE;   // (kErrOrder / kErrHint never outlive raft_hip_finish's second run)
     return RAFT_HIP_OK;
 }
 
@@ -453,8 +471,8 @@ int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
     if (variant < -1 || variant >= kNumVariants) return RAFT_HIP_ERR_PARAM;
-    const int v = variant < 0 ? kDefaultVariant : variant;
-    if (tile_bins < 0 || tile_bins > kVariants[v].cap) return RAFT_HIP_ERR_PARAM;
+    const int v = variant < 0 ? default_variant() : variant;
+    if (tile_bins < 0 || tile_bins > (kVariants[v].fast == 2 ? (1 << 20) : kVariants[v].cap)) return RAFT_HIP_ERR_PARAM;   // (wave tiles: the quantum is the walkers' share, not a tile)
     c->variant = v;
     c->tile_q = tile_bins;
     c->force_bucket = force_bucket_path ? 1 : 0;
@@ -505,14 +523,15 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     bool expand = false;
     const PileVariant &pv = kVariants[c->variant];
     // tiles that do not fit the fast kernel are re-cut for it (pileup.hpp tile_desc_kernel) unless told otherwise
-    const bool recut = pv.fast && !c->no_recut && getenv("RAFT_NO_RECUT") == nullptr;
+    const bool wave = pv.fast == 2;                      // one wave per tile (pileup_wave.hpp): every tile is cut by tile_desc_kernel's walk
+    const bool recut = wave || (pv.fast && !c->no_recut && getenv("RAFT_NO_RECUT") == nullptr);
     // lane-serial rows: variant 4, or RAFT_LANE_SERIAL=1 for every fast configuration of the process (A/B, test sweeps); they
     // take slots outside the tile for not-high, which a threshold below 1 would not give them
     const bool ls_rows = (c->variant == 4 || getenv("RAFT_LANE_SERIAL") != nullptr) && c->high_cov >= 1;
     // window records go to the fast kernel's own instantiation (pileup_fast.hpp IN = 1) where every tile is the fast kernel's
     // in its default configuration and the runs are few; anything else gets coordinate columns that fall into the same
     // windows (bucket.hpp unpack_windows_kernel) and takes the paths those have
-    const bool lean = d_win && n_rec > 0 && !merge && eff_runs <= kWinMaxRuns && recut && (c->variant == kDefaultVariant || c->variant == kDiagVariant) && !ls_rows &&
+    const bool lean = d_win && n_rec > 0 && !merge && eff_runs <= kWinMaxRuns && recut && (c->variant == 0 || c->variant == kDiagVariant || wave) && !ls_rows &&
                       !c->force_bucket && getenv("RAFT_NO_WINDOW_KERNEL") == nullptr;
     if (d_win && !lean && n_rec > 0) {
         HIP_TRY(c, c->u_s.ensure((size_t)n_rec * 4));
@@ -550,7 +569,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     // the encoding of cov[] is written directly when every tile goes through the fast kernel (pileup_fast.hpp OW); a pass
     // the general kernel takes part in writes int32 and raft_hip_fetch_packed_w encodes it afterwards, as it always did
     // (delta4: the default configuration's instantiations only; elsewhere the pass writes int32 and is encoded afterwards)
-    const bool d4_ok = c->variant == kDefaultVariant && !ls_rows;
+    const bool d4_ok = (c->variant == 0 || wave) && !ls_rows;
     const int ow = (c->out_width != 4 && recut && c->variant != kDiagVariant && (c->out_width != kCovDelta4 || d4_ok)) ? c->out_width : 4;
     // a grouped pass whose caller announced the window count needs nothing back from the device on the way
     const bool no_wait = grouped && in.hint_bins >= 0 && getenv("RAFT_NO_HINT") == nullptr;
@@ -648,7 +667,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     // the room left above Q has to follow the read lengths or most tiles of a long-read set overflow the LDS window
     // (measured optima, mean windows per read -> room: 600 -> 1.7 k, 1200 -> 2.7 k, 3000 -> 3.9 k of a 7936-window tile).
     int Q = c->tile_q ? std::min(c->tile_q, pv.cap) : pv.cap - pv.short_max;
-    if (!c->tile_q && pv.fast && N > 0) {
+    // (wave tiles: the quantum only says which thread of tile_desc_kernel walks which reads -- four tiles' worth each)
+    if (wave) Q = c->tile_q ? std::max(256, c->tile_q) : 4 * (pv.cap / 128) * 128;
+    if (!c->tile_q && pv.fast == 1 && N > 0) {
         const double mean_w = (double)B / (double)N;
         const int room = (int)std::min<double>(pv.cap / 2, std::max<double>(1408.0, 600.0 + 1.75 * mean_w));
         Q = std::max(256, ((pv.cap - room) / 128) * 128);
@@ -674,6 +695,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     long long extra_cap = 0;
     if (recut) {
         extra_cap = n_tiles + B / pv.cap + N / 8 + 1024;
+        if (wave) extra_cap = 2 * n_tiles + 2 * (B / pv.cap) + N / 32 + 1024;   // (a group is closed by a full window, 63 reads, a long read or the walker's last read)
         if (const char *ec = getenv("RAFT_EXTRA_CAP")) extra_cap = std::max(0, atoi(ec));   // (tests: force the overflow fallback)
         if ((n_tiles + 1 + 2 * extra_cap) * 8 >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;   // cut words are indexed with 32 bits
     }
@@ -681,7 +703,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         HIP_TRY(c, c->tile_cuts.ensure((size_t)(n_tiles + 1 + 2 * extra_cap) * sizeof(TileCut)));
         HIP_TRY(c, c->slow_list.ensure((size_t)n_tiles * 4));
     }
-    HIP_TRY(c, c->block_sums.ensure((size_t)256 * 8 * 16 * 2));
+    HIP_TRY(c, c->block_sums.ensure((size_t)256 * 8 * 16 * 2 * 4));
     HIP_TRY(c, c->rep_cnt.ensure((size_t)std::max(N, 1LL) * 4));
     HIP_TRY(c, c->cut_cnt.ensure((size_t)std::max(N, 1LL) * 4));
     HIP_TRY(c, c->frag_cnt.ensure((size_t)std::max(N, 1LL) * 4));
@@ -822,11 +844,11 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     if (spec && c->prm.symmetric_mode < 0 && fast) mir = {d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp.sym_found};
     hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 2 + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
                        pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>(),
-                       pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, pv.cap, kFastMaxReads,
+                       pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, wave ? -1 : pv.cap, wave ? kWaveMaxReads : kFastMaxReads,
                        pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow,
                        (fast && table_ok) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
                        c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags,
-                       recut ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp);
+                       recut ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp, pv.cap);
     pa.n_extra = recut ? &ctrl->n_extra : nullptr;
     pa.piece_w = pv.cap;
 
@@ -844,7 +866,17 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     unsigned n_sum_blocks = pgrid;
     pa.tile_batch = n_tiles >= 64LL * pgrid ? 8 : (n_tiles >= 16LL * pgrid ? 2 : 1);
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
-    if (pv.fast) {
+    if (wave) {
+        // ONE launch, no second stream: a persistent grid of single-wave workers, each drawing wave tiles from the list
+        // tile_desc_kernel cut (its length is known on the device only: workers without a tile leave at once)
+        const int n_waves = wave_grid_waves();
+        const long long est_tiles = B / std::max(1, (pv.cap * 3) / 4) + 1;
+        pa.tile_batch = est_tiles >= 64LL * n_waves ? 4 : (est_tiles >= 16LL * n_waves ? 2 : 1);
+        if (const char *e = getenv("RAFT_WAVE_BATCH")) pa.tile_batch = std::max(1, atoi(e));
+        pa.n_extra = &ctrl->n_extra;
+        launch_wave_variant(ow, lean, st, pa.n_seg, c->tile_cuts.p, &pa);
+        n_sum_blocks = (unsigned)n_waves;
+    } else if (pv.fast) {
         const TileCut *cuts = c->tile_cuts.as<TileCut>();
         // The tiles the fast kernel does not take (reads longer than the LDS window, very many reads) go to the general
         // kernel on a second stream: the two kernels touch disjoint reads, and the general kernel's workgroups move in
@@ -904,7 +936,8 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         CountLoader<3> ld{{c->rep_cnt.as<int32_t>(), c->cut_cnt.as<int32_t>(), c->frag_cnt.as<int32_t>()}};
         ScanOut<3> so{{c->rep_off.as<long long>(), c->cut_off.as<long long>(), c->frag_off.as<long long>()}};
         exclusive_scan<CountLoader<3>, 3>(st, ld, N, c->scan_tmp.as<long long>(), so);
-        hipLaunchKernelGGL(finalize_fill_kernel, dim3(rgrid), dim3(256), 0, st, fa);
+        if (c->emit_cuts) hipLaunchKernelGGL(finalize_fill_kernel<true>, dim3(rgrid), dim3(256), 0, st, fa);
+        else hipLaunchKernelGGL(finalize_fill_kernel<false>, dim3(rgrid), dim3(256), 0, st, fa);
     } else {
         HIP_TRY(c, hipMemsetAsync(c->rep_off.p, 0, 8, st));
         HIP_TRY(c, hipMemsetAsync(c->cut_off.p, 0, 8, st));
@@ -919,7 +952,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
                            c->pinned_dev + 128, ++c->pass_seq);   // everything finish() reports travels in one block (+1024 bytes), written by the last workgroup
         c->seq_armed = true;
     }
-    c->fa = fa; c->cuts_ready = false;
+    c->fa = fa; c->cuts_ready = c->emit_cuts;
     c->pass_width = ow; c->cov_valid = ow == 4;
     HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
     HIP_TRY(c, hipGetLastError());
@@ -1005,14 +1038,20 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
         // looks for it itself for a while (a pass is 0.2-3 ms; the runtime's wait sleeps, and waking up costs 20-30 us) and
         // falls back to the runtime's wait -- which is also what reports a device fault.
         bool seen = false;
-        if (c->seq_armed && getenv("RAFT_NO_SPIN") == nullptr) {
+        // (bounded by what a pass takes: 4 ms; a pipeline lane does not spin at all -- its thread shares the host's cores with
+        // the other lanes, the tokeniser's and the formatter's workers, and its pass is a tenth of its transfers)
+        if (c->seq_armed && !c->is_lane && getenv("RAFT_NO_SPIN") == nullptr) {
             const volatile long long *seq = reinterpret_cast<const volatile long long *>(c->pinned) + 128 + kSeqWord;
-            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(4);
             for (int it = 0; !(seen = *seq == c->pass_seq); ++it)
                 if ((it & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
             std::atomic_thread_fence(std::memory_order_acquire);
         }
         if (!seen) HIP_TRY(c, hipStreamSynchronize(c->stream));
+        else {                                           // (the number was seen without the runtime: a fault of this pass still surfaces here)
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail_hip(c, q, "hipStreamQuery after the pass");
+        }
         auto ctrl_block = [&]() { Ctrl hc; memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl)); return hc; };
         auto again = [&](const raft_hip_ctx::PassArgs &a) -> int {       // the pass once more, this time nothing assumed
             const int rc = run_pass(c, a, false);
@@ -1057,14 +1096,29 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
             const Ctrl hc = ctrl_block();
             if ((hc.err_flags & kErrExtra) && !(hc.err_flags & kErrStop)) {   // more extra tiles than room: this pass with the general kernel
                 c->no_recut = true;
+                const int keep = c->variant;
+                if (kVariants[c->variant].fast == 2) c->variant = 0;      // (the wave kernel has no other tiles than the list's)
                 const int rc = again(c->args);
+                c->variant = keep;
                 c->no_recut = false;
+                if (rc != RAFT_HIP_OK) return rc;
+            }
+        }
+        if (c->pending_err == RAFT_HIP_OK) {
+            const Ctrl hc = ctrl_block();
+            if ((hc.err_flags & kErrDeep) && !(hc.err_flags & kErrStop)) {
+                // a wave tile with 2^15 or more intervals (a pile-up that deep does not fit the 16-bit difference array of
+                // pileup_wave.hpp): this pass once more with the int32 kernels
+                const int keep = c->variant;
+                c->variant = 0;
+                const int rc = again(c->args);
+                c->variant = keep;
                 if (rc != RAFT_HIP_OK) return rc;
             }
         }
         if (c->pending_err == RAFT_HIP_OK && c->pass_width != 4) {
             const Ctrl hc = ctrl_block();
-            if ((long long)hc.n_exc > c->exc_cap && !(hc.err_flags & ~(kErrOrder | kErrExtra))) {
+            if ((long long)hc.n_exc > c->exc_cap && !(hc.err_flags & ~(kErrOrder | kErrExtra | kErrDeep))) {
                 // more windows at or above the encoding's limit than the list held: once more with room for all of them
                 c->exc_cap = (long long)hc.n_exc;
                 const int rc = again(c->args);
@@ -1147,6 +1201,13 @@ int raft_hip_set_output_width(raft_hip_ctx *c, int32_t width)
 {
     if (!c || (width != 1 && width != 2 && width != 4 && width != kCovDelta4)) return RAFT_HIP_ERR_PARAM;
     c->out_width = width;
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_set_emit_cuts(raft_hip_ctx *c, int32_t on)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    c->emit_cuts = on != 0;
     return RAFT_HIP_OK;
 }
 
@@ -1533,6 +1594,8 @@ int prepare_lanes(raft_hip_ctx *c)
     for (raft_hip_ctx *l : c->lanes) {
         apply_params(l, &c->prm);
         l->tile_q = c->tile_q; l->variant = c->variant; l->force_bucket = 0;
+        l->is_lane = true;
+        l->emit_cuts = false;                         // (raft_hip_host_outputs holds no cut points)
     }
     return RAFT_HIP_OK;
 }
@@ -1724,7 +1787,8 @@ static int run_routed(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads,
             const bool exc_fits = b_exc + n_exc <= o->exc_cap;
             if (rc == RAFT_HIP_OK && !fits) { jc->last_error = "host output capacity (coverage / repeats / fragments)"; rc = RAFT_HIP_ERR_TOO_LARGE; }
             if (rc == RAFT_HIP_OK)
-                rc = raft_hip_fetch_packed_w(jc, cov_width, o->cov_offset + r0, o->cov8 ? o->cov8 + b_bins * cov_width : nullptr, exc_fits ? n_exc : 0,
+                rc = raft_hip_fetch_packed_w(jc, cov_width, o->cov_offset + r0, o->cov8 ? o->cov8 + b_bins * cov_width : nullptr, n_exc,   // (a list that no longer fits is counted, not fetched: the call ends with TOO_LARGE and the job's total)
+                                            
                                              (exc_fits && o->exc_index) ? o->exc_index + b_exc : nullptr, (exc_fits && o->exc_value) ? o->exc_value + b_exc : nullptr,
                                              &n_exc, o->rep_offset + r0, o->rep_s ? o->rep_s + b_rep : nullptr, o->rep_e ? o->rep_e + b_rep : nullptr,
                                              o->frag_offset + r0, nullptr, o->frag_begin ? o->frag_begin + b_frag : nullptr,
@@ -2536,29 +2600,50 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
         const ncclResult_t e_ = (expr);                                                                    \
         if (e_ != ncclSuccess) { c->last_error = std::string(#expr ": ") + r->GetErrorString(e_); return RAFT_HIP_ERR_DEVICE; } \
     } while (0)
-    // ---- who sends how much to whom: every rank's row of piece sizes, gathered (world * world * kMaxSeg numbers)
+    // ---- who sends how much to whom: every rank's row of piece sizes, gathered (world * world * kMaxSeg numbers).
+    // Every rank must reach every collective, so nothing a single rank finds wrong with its own arguments ends the call
+    // before the all-gather: such a rank announces a row of kBadRow instead, and ALL ranks return the same error once the
+    // rows are in (the matrix is complete on every rank) -- before any send or receive is posted.
+    constexpr long long kBadRow = -2;
     const size_t row = (size_t)world * kMaxSeg;
     std::vector<long long> cnt(row * (size_t)world, 0);
-    for (int g = 0; g < world; ++g) {
-        if (bounds[g] < 0 || bounds[g] > bounds[g + 1] || bounds[g + 1] > n_reads_total) return RAFT_HIP_ERR_PARAM;
+    bool mine_ok = true;
+    for (int g = 0; g < world && mine_ok; ++g) {
+        if (bounds[g] < 0 || bounds[g] > bounds[g + 1] || bounds[g + 1] > n_reads_total) { mine_ok = false; break; }
         for (int j = 0; j < kMaxSeg; ++j) {
             long long n = -1;                                                // (-1: the slice has no such run)
             if (j < mine->n_runs) {
                 const long long lo = mine->rec_offset[j * N1 + bounds[g]], hi = mine->rec_offset[j * N1 + bounds[g + 1]];
-                if (lo < 0 || hi < lo || hi > mine->n_rec) return RAFT_HIP_ERR_PARAM;
+                if (lo < 0 || hi < lo || hi > mine->n_rec) { mine_ok = false; break; }
                 n = hi - lo;
             }
             cnt[(size_t)rank * row + (size_t)g * kMaxSeg + (size_t)j] = n;
         }
     }
+    if (!mine_ok) for (size_t i = 0; i < row; ++i) cnt[(size_t)rank * row + i] = kBadRow;
     HIP_TRY(c, c->x_cnt.ensure(cnt.size() * 8));
     HIP_TRY(c, hipMemcpyAsync(c->x_cnt.as<long long>() + (size_t)rank * row, cnt.data() + (size_t)rank * row, row * 8, hipMemcpyHostToDevice, st));
     NCCL_TRY(r->AllGather(c->x_cnt.as<long long>() + (size_t)rank * row, c->x_cnt.p, row, ncclInt64, comm, st));
     HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->x_cnt.p, cnt.size() * 8, hipMemcpyDeviceToHost, st));
     // (meanwhile: this rank's offsets go to the device, from where their slices are sent)
     HIP_TRY(c, c->x_send_off.ensure((size_t)mine->n_runs * (size_t)N1 * 8));
-    HIP_TRY(c, hipMemcpyAsync(c->x_send_off.p, mine->rec_offset, (size_t)mine->n_runs * (size_t)N1 * 8, hipMemcpyHostToDevice, st));
+    if (mine_ok) HIP_TRY(c, hipMemcpyAsync(c->x_send_off.p, mine->rec_offset, (size_t)mine->n_runs * (size_t)N1 * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    // ---- the same verdict on every rank: a rank with invalid arguments; more runs arriving at SOME rank than a pass takes
+    for (int p = 0; p < world; ++p)
+        if (cnt[(size_t)p * row] == kBadRow) {
+            c->last_error = "raft_hip_exchange: rank " + std::to_string(p) + " was handed bounds or offsets that do not fit its slice";
+            return RAFT_HIP_ERR_PARAM;
+        }
+    for (int g = 0; g < world; ++g) {
+        int arriving = 0;
+        for (int p = 0; p < world; ++p)
+            for (int j = 0; j < kMaxSeg; ++j) arriving += cnt[(size_t)p * row + (size_t)g * kMaxSeg + (size_t)j] > 0 ? 1 : 0;
+        if (arriving > kMaxRuns) {
+            c->last_error = "raft_hip_exchange: more than 16 runs arrive at rank " + std::to_string(g);
+            return RAFT_HIP_ERR_TOO_LARGE;
+        }
+    }
     // ---- what arrives here: one run per (peer, run) with records for this rank
     const long long b0 = bounds[rank], n1 = bounds[rank + 1] - b0 + 1;
     std::vector<XRun> runs;
@@ -2568,7 +2653,6 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
             const long long n = cnt[(size_t)p * row + (size_t)rank * kMaxSeg + (size_t)j];
             if (n > 0) { runs.push_back(XRun{p, j, 0, n}); n_rec += n; }
         }
-    if ((int)runs.size() > kMaxRuns) { c->last_error = "raft_hip_exchange: more than 16 runs arrive at one rank"; return RAFT_HIP_ERR_TOO_LARGE; }
     const int K = std::max<int>(1, (int)runs.size());
     const bool one_col = mine->d_qe == nullptr;           // window records: one column travels (the same on every rank: the caller's protocol)
     HIP_TRY(c, c->x_qs.ensure((size_t)std::max(n_rec, 1LL) * 4));
@@ -2583,20 +2667,28 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
     // ---- the exchange: per ordered pair of ranks the sends and the receives are issued in the same order (run by run:
     // qs, qe, offsets), all inside one group -- xGMI is point-to-point, every pair has its own link
     NCCL_TRY(r->GroupStart());
-    for (int g = 0; g < world; ++g)
-        for (int j = 0; j < mine->n_runs; ++j) {
-            const long long lo = mine->rec_offset[j * N1 + bounds[g]], n = mine->rec_offset[j * N1 + bounds[g + 1]] - lo;
-            if (n <= 0) continue;
-            NCCL_TRY(r->Send(mine->d_qs + lo, (size_t)n, ncclInt32, g, comm, st));
-            if (!one_col) NCCL_TRY(r->Send(mine->d_qe + lo, (size_t)n, ncclInt32, g, comm, st));
-            NCCL_TRY(r->Send(c->x_send_off.as<long long>() + j * N1 + bounds[g], (size_t)(bounds[g + 1] - bounds[g] + 1), ncclInt64, g, comm, st));
+    {
+        // (a failed post must not leave the group open: the first error is kept, the group is closed, then the call returns)
+        ncclResult_t first = ncclSuccess;
+        const char *what = "";
+        auto post = [&](ncclResult_t e, const char *w) { if (e != ncclSuccess && first == ncclSuccess) { first = e; what = w; } return first == ncclSuccess; };
+        for (int g = 0; g < world && first == ncclSuccess; ++g)
+            for (int j = 0; j < mine->n_runs && first == ncclSuccess; ++j) {
+                const long long lo = mine->rec_offset[j * N1 + bounds[g]], n = mine->rec_offset[j * N1 + bounds[g + 1]] - lo;
+                if (n <= 0) continue;
+                if (!post(r->Send(mine->d_qs + lo, (size_t)n, ncclInt32, g, comm, st), "ncclSend(qs)")) break;
+                if (!one_col && !post(r->Send(mine->d_qe + lo, (size_t)n, ncclInt32, g, comm, st), "ncclSend(qe)")) break;
+                post(r->Send(c->x_send_off.as<long long>() + j * N1 + bounds[g], (size_t)(bounds[g + 1] - bounds[g] + 1), ncclInt64, g, comm, st), "ncclSend(offsets)");
+            }
+        for (size_t k = 0; k < runs.size() && first == ncclSuccess; ++k) {
+            if (!post(r->Recv(c->x_qs.as<int32_t>() + rb.base[k], (size_t)runs[k].n, ncclInt32, runs[k].peer, comm, st), "ncclRecv(qs)")) break;
+            if (!one_col && !post(r->Recv(c->x_qe.as<int32_t>() + rb.base[k], (size_t)runs[k].n, ncclInt32, runs[k].peer, comm, st), "ncclRecv(qe)")) break;
+            post(r->Recv(c->x_raw.as<long long>() + (long long)k * n1, (size_t)n1, ncclInt64, runs[k].peer, comm, st), "ncclRecv(offsets)");
         }
-    for (size_t k = 0; k < runs.size(); ++k) {
-        NCCL_TRY(r->Recv(c->x_qs.as<int32_t>() + rb.base[k], (size_t)runs[k].n, ncclInt32, runs[k].peer, comm, st));
-        if (!one_col) NCCL_TRY(r->Recv(c->x_qe.as<int32_t>() + rb.base[k], (size_t)runs[k].n, ncclInt32, runs[k].peer, comm, st));
-        NCCL_TRY(r->Recv(c->x_raw.as<long long>() + (long long)k * n1, (size_t)n1, ncclInt64, runs[k].peer, comm, st));
+        const ncclResult_t ge = r->GroupEnd();
+        if (first != ncclSuccess) { c->last_error = std::string(what) + ": " + r->GetErrorString(first); return RAFT_HIP_ERR_DEVICE; }
+        if (ge != ncclSuccess) { c->last_error = std::string("ncclGroupEnd: ") + r->GetErrorString(ge); return RAFT_HIP_ERR_DEVICE; }
     }
-    NCCL_TRY(r->GroupEnd());
 #undef NCCL_TRY
     if (runs.empty()) HIP_TRY(c, hipMemsetAsync(c->x_off.p, 0, (size_t)n1 * 8, st));
     else

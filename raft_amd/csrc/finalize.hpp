@@ -372,12 +372,21 @@ __device__ __forceinline__ void finalize_fill_one(const FinalizeArgs &a, int r, 
     a.frag_end[fo + nf - 1] = len;                // the last kept marker is the read's end
 }
 
+// CUTS: the pass also writes the cut points themselves (chop.hpp:225-246 final_stars) -- the default of a
+// context (raft_hip_set_emit_cuts); the host pipelines, whose outputs hold no cut points, leave them to finalize_cuts_kernel.
+template <bool CUTS>
 __global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_reads) return;
     if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
-    finalize_fill_one(a, r, a.rep_off[r], a.frag_off[r], a.rep_cnt[r], a.cut_cnt[r]);
+    const int n = a.rep_cnt[r];
+    finalize_fill_one(a, r, a.rep_off[r], a.frag_off[r], n, a.cut_cnt[r]);
+    if (CUTS) {
+        int32_t *F = a.cuts + a.cut_off[r];
+        int w = 0;
+        (void)walk_cuts(a.read_len[r], a.interval_length, a.raw_s + a.rep_res_off[r], a.raw_e + a.rep_res_off[r], n, [&](int m) { F[w++] = m; });
+    }
 }
 
 // (Measured and dropped: count, offsets and fill in ONE launch -- a single-pass scan with decoupled look-back over

@@ -854,8 +854,10 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                                                         int32_t *n_slow, const int32_t *samples, long long n_rec,
                                                         const long long *bucket_off, int32_t *err_flags, TileCut *extra,
                                                         int32_t *n_extra, int32_t extra_cap, int32_t piece_w, MirrorArgs mir,
-                                                        GroupedOff grp)
+                                                        GroupedOff grp, int recut_cap)
 {
+    // fast_cap < 0: no tile is taken as it is -- every tile with reads is re-cut into entries of at most recut_cap windows and
+    // fast_max_reads reads (pileup_wave.hpp: one wave per entry); otherwise recut_cap == fast_cap
     if (*(volatile int32_t *)err_flags & kErrStop) return;   // (sizes or offsets the device found wrong: nothing here is safe)
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -1033,7 +1035,7 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
             while (r < d.r_hi) {
                 const long long g_n = (r + 1 == d.r_hi) ? d.g_hi : cov_off[r + 1];
                 const long long nb = g_n - g_r;
-                if (nb > fast_cap) {                       // pieces of one long read
+                if (nb > recut_cap) {                      // pieces of one long read
                     const int P = (int)((nb + piece_w - 1) / piece_w);
                     if (write) {
                         bounds_of(r + 1, ie);
@@ -1049,7 +1051,7 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                     long long g2 = g_n;
                     while (r2 < d.r_hi && r2 - r < fast_max_reads) {
                         const long long g3 = (r2 + 1 == d.r_hi) ? d.g_hi : cov_off[r2 + 1];
-                        if (g3 - g2 > fast_cap || g3 - g_r > fast_cap) break;   // a long read ends the group; so does a full window
+                        if (g3 - g2 > recut_cap || g3 - g_r > recut_cap) break;   // a long read ends the group; so does a full window
                         ++r2; g2 = g3;
                     }
                     // (also a group of reads without windows: its records still have to be looked at)

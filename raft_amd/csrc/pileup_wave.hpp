@@ -1,0 +1,621 @@
+// pileup_wave.hpp -- the pileup kernel of round 4: one WAVE per tile, a 16-bit difference array, eight windows per lane.
+//
+// What pileup_fast.hpp's counters and stamps said: its time does not follow its bytes -- 53 % of
+// the wave cycles are waits, the vector pipe is a quarter busy, and what a tile costs is its dependent chains (LDS read ->
+// adds -> six DPP steps -> carry; three workgroup barriers; a pass over the array just to hand every wave its start value)
+// executed by four waves per SIMD.  This kernel removes the chains' causes instead of shortening them:
+//   * a tile belongs to ONE wave.  No barrier, no pass A (the carry is a scalar that runs along the wave's rows), no seams
+//     between waves, no double-buffered tables; waves of a SIMD are in unrelated phases of unrelated tiles, so there is
+//     always one that can issue.  Tiles are the groups of whole reads (and the pieces of reads longer than a tile) that
+//     tile_desc_kernel already cuts for windows that do not fit (pileup.hpp `extra`): here EVERY tile is cut that way.
+//   * the difference array holds 16 bits per window, two windows per LDS dword.  +1 / -1 land as ds_add_u32 of
+//     +-1 or +-65536 on the window's dword; the low halves carry a bias of 0x8000 so that they never borrow from the high
+//     ones.  A tile's LDS footprint is a quarter of the int32 window's, which is what lets up to eight waves share a SIMD.
+//   * a lane owns eight windows of every 512-window row -- four in each half-row, so that both of the wave's stores are
+//     contiguous -- and the prefix sum is packed arithmetic: with P = (L, H) the dword without its bias, P + (P << 16) has
+//     L in its low and L + H in its high half; two more packed adds give the lane's prefix, the lanes' totals of BOTH
+//     half-rows travel through ONE DPP scan as one 32-bit word, and one packed add per dword puts the start value in.
+//     ~22 vector instructions per 512 windows where the int32 rows took 2 x 20 per 512, half the scans, no carry hand-over.
+//   * bound: every intermediate is exact modulo 2^16 and every coverage value must be below 32768.  A tile holds fewer
+//     intervals than that or it refutes the pass (kErrDeep: raft_hip_finish runs the pass again with the int32 kernels).
+// Reference semantics: repeat.hpp:28-79 (profileCoverage), repeat.hpp:111-168 (run scan) -- see pileup.hpp; the run scan
+// of a half-row is pileup_fast.hpp's per-lane scan (one wave shift + one max-scan).
+#pragma once
+#include "pileup.hpp"
+
+namespace raft {
+
+constexpr int kErrDeep = 1 << 9;     // a wave tile with 32768 or more intervals: 16-bit coverage is not safe for it
+
+// The empty difference array: the LOW half of every dword is biased by 0x8000, so that a -1 landing on an even slot never
+// borrows from the odd slot above it (the ds_add is a 32-bit add); one xor per dword takes the bias off again.
+constexpr uint32_t kZero = 0x00008000u;
+constexpr int kWaveMaxReads = 63;    // reads per wave tile: lane j <-> read r_a + j, entry nr closes the table (nr + 1 <= 64)
+
+template <int SLOTS>
+struct WaveSmem {                    // ONE wave's LDS
+    static_assert(SLOTS % 512 == 0, "rows of 512 slots");
+    uint32_t diff[SLOTS / 2];        // two 16-bit slots per dword, slot order; all kZero between tiles
+    int32_t roff[64];                // first slot of read r_a + j relative to a0 (j <= nr)
+    int32_t rcnt[64];                // raw repeats emitted for the read in this tile
+    int32_t runq[2 * kRunQ];         // closed runs parked for emission
+};
+
+struct WaveTile {                    // scalars of one tile (SGPRs)
+    int r_a, nr, nwin, piece, more, n_total;
+    int lo[kMaxSeg], cnt[kMaxSeg];
+    long long g_lo;
+};
+
+// v_pk_add_u16 with one half of `b` added to BOTH halves of `a` (VOP3P op_sel: free).  HI: b's high half, else its low half.
+template <bool HI>
+__device__ __forceinline__ unsigned pk_add_bcast(unsigned a, unsigned b)
+{
+    unsigned r;
+    if (HI) asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    else    asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int wave_shl1(int v, int last)      // lane l takes lane l + 1's value, lane 63 keeps `last`
+{
+    return __builtin_amdgcn_update_dpp(last, v, 0x130, 0xf, 0xf, false);         // wave_shl:1 (GFX9 family)
+}
+
+template <int U>
+struct WaveRegs { int rid[U], st[U], en[U]; };
+struct WaveReadRegs { int cv, rr, rl; int so[2]; };
+
+// NSEG sorted runs, U prefetch slots per lane (slot u: record (u / NSEG) * 64 + lane of run u % NSEG), OW bytes per window
+// written (4: int32 cov[]; 1 / 2: the transfer encoding; 8: four-bit steps, pack.hpp), IN = 1: window records.
+template <int SLOTS, int NSEG, int U, int OW, int IN>
+__device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCut *__restrict__ cuts, const PileupArgs &a, int wave_id, int n_waves)
+{
+    constexpr int ITER = U / NSEG;
+    static_assert(U % NSEG == 0 && ITER >= 1, "slots are split evenly over the runs");
+    static_assert(IN == 0 || NSEG <= 2, "window records: one or two runs");
+    constexpr bool D4 = OW == 8;
+    const int lane = (int)(threadIdx.x & 63u);
+    // (every worker owns two words of the sums totals_kernel adds up: also the ones that leave without a tile)
+    auto leave_empty = [&]() { if (lane == 0) { a.block_sums[2 * (long long)wave_id] = 0; a.block_sums[2 * (long long)wave_id + 1] = 0; } };
+    if (uni(*(volatile int32_t *)a.err_flags) & (kErrExtra | kErrStop)) { leave_empty(); return; }
+    const int n_reg = (int)a.n_tiles;
+    const int n_tiles = uni(*a.n_extra);
+    const unsigned win_m1 = a.div_shift < 0 ? ~0u : 0u;
+    const int win_sh = a.div_shift < 0 ? 0 : a.div_shift;
+    constexpr unsigned kLimit = OW == 1 ? 255u : 65535u;
+    // threshold test on packed halves: c + (0x8000 - high_cov) has bit 15 set <=> c >= high_cov (0 <= c < 32768; a threshold
+    // above 32767 can never be reached by a 16-bit tile, one below 1 is reached by every window: both clamp)
+    const unsigned hc16 = (unsigned)min(max(a.high_cov, 0), 0x8000);
+    const unsigned kthr = ((0x8000u - hc16) & 0xffffu) * 0x10001u;
+
+    for (int i = lane; i < SLOTS / 2; i += 64) sm.diff[i] = kZero;
+    long long lane_cov = 0, lane_rep = 0;
+
+    const int32_t *cut_words = reinterpret_cast<const int32_t *>(cuts);
+    auto cut_word = [&](int t) -> int {          // dword `lane` of the tile's (begin, end) pair
+        const unsigned idx = (unsigned)(n_reg + 1 + 2 * t) * 8u + (unsigned)lane;
+        return lane < 16 ? cut_words[idx] : 0;
+    };
+    auto unpack = [&](int raw, WaveTile &t) {
+        auto d = [&](int i) -> int { return __builtin_amdgcn_readlane(raw, i); };
+        t.r_a = d(0); t.nr = d(8) - t.r_a; t.piece = d(1) & kCutPiece;
+        t.g_lo = (long long)(((unsigned long long)(unsigned)d(7) << 32) | (unsigned)d(6));
+        t.nwin = d(14) - d(6);
+        t.more = 0; t.n_total = 0;
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+            t.lo[s] = d(2 + s); t.cnt[s] = d(10 + s) - t.lo[s];
+            t.n_total += t.cnt[s];
+            if (t.cnt[s] > ITER * 64) t.more = 1;
+        }
+    };
+    // loads of one tile: three (+ NSEG for window records) per read, lanes 0 .. nr; U interval slots
+    auto issue = [&](const WaveTile &t, WaveRegs<U> &g, WaveReadRegs &rd) {
+        rd.cv = 0; rd.rr = 0; rd.rl = 0; rd.so[0] = 0; rd.so[1] = 0;
+        if (lane <= t.nr) {
+            rd.cv = reinterpret_cast<const int32_t *>(a.cov_off + t.r_a)[2 * lane];
+            rd.rr = reinterpret_cast<const int32_t *>(a.rep_res_off + t.r_a)[2 * lane];
+            if (IN == 1) {
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) rd.so[s] = reinterpret_cast<const int32_t *>(a.grp.off + s * a.grp.stride + t.r_a)[2 * lane];
+            }
+        }
+        if (lane < t.nr) rd.rl = a.read_len[t.r_a + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = u % NSEG, first = (u / NSEG) * 64;
+            if (IN == 1) {
+                g.st[u] = 0;
+                if (lane < t.cnt[s] - first) g.st[u] = (int)a.iv_w[(long long)t.lo[s] + first + lane];
+            } else {
+                g.rid[u] = t.r_a; g.st[u] = 0; g.en[u] = 0;       // an empty slot is an empty interval of the tile's first read
+                if (lane < t.cnt[s] - first) {
+                    const long long at = (long long)t.lo[s] + first + lane;
+                    g.rid[u] = a.iv_rid[at]; g.st[u] = a.iv_s[at]; g.en[u] = a.iv_e[at];
+                }
+            }
+        }
+    };
+
+    // tiles are drawn in batches from a device counter (tile costs differ by what the tile holds; CUs are not equally fast)
+    const int kBatch = max(1, a.tile_batch);
+    typedef __attribute__((address_space(1))) int32_t *global_i32_ptr;
+    global_i32_ptr draw_from = (global_i32_ptr)a.tile_counter;
+    asm volatile("" : "+v"(draw_from));
+    int drawn = 0;
+    auto draw = [&]() { if (lane == 0) drawn = __hip_atomic_fetch_add(draw_from, kBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // the first batch is the wave's own: tiles [wave_id * kBatch, + kBatch); later ones come from the counter, which starts at 0
+    // and stands for "batches handed out beyond the waves' first ones".  Three tiles are known at any time: the current one,
+    // the next (its cuts have landed, its loads go out behind the current tile's interval phase) and the one after (its cuts
+    // are in flight); a draw is issued in the iteration after the one that used up the batch drawn before and has landed
+    // by that iteration's end, which is where the next tile index is taken.
+    int bn = wave_id * kBatch, be = bn + kBatch;
+    int next_base = 0;
+    bool want_draw = false;
+    auto hand_out = [&]() -> int {
+        if (bn == be) { bn = next_base; be = bn + kBatch; want_draw = true; }
+        return bn++;
+    };
+    auto draw_now = [&]() { draw(); wait_all_loads(); next_base = n_waves * kBatch + uni(drawn); want_draw = false; };
+    int k = bn++;
+    if (k >= n_tiles) { leave_empty(); return; }
+    WaveTile cur, nxt;
+    WaveRegs<U> g;
+    WaveReadRegs rd, rdn;
+    unpack(cut_word(k), cur);
+    issue(cur, g, rd);
+    draw_now();
+    int kn = hand_out();
+    if (want_draw) draw_now();
+    int knn = hand_out();
+    int raw_n = cut_word(min(kn, n_tiles - 1));
+    wait_all_loads();
+
+    while (true) {
+        const int nr = cur.nr, r_a = cur.r_a;
+        const long long a0 = cur.g_lo & ~3LL;
+        const int off0 = (int)(cur.g_lo - a0);
+        const int t_end = off0 + cur.nwin;
+        const int rows = (t_end + 1 + 511) >> 9;
+        const int piece = cur.piece;
+        if (cur.n_total >= 32768) { if (lane == 0) atomicOr(a.err_flags, kErrDeep); }
+        // ---- per-read table of this tile
+        const int ro = rd.cv - (int)a0;                     // 32-bit wrap-around is exact
+        if (lane <= nr) sm.roff[lane] = ro;
+        sm.rcnt[lane] = 0;
+        const int ro_s = (lane < nr) ? ro : 0x7fffffff;     // first slots of the tile's reads, for the run scan and the owner search
+
+        // ---- 1. intervals -> +1 / -1 on 16-bit slots
+        int covsum = 0;
+        bool bad_any = false, bad_order = false;
+        auto add_pm = [&](int pf, int pl1) {
+            const unsigned vp = 1u << ((pf & 1) << 4), vm = 0u - (1u << ((pl1 & 1) << 4));
+            __hip_atomic_fetch_add(&sm.diff[pf >> 1], vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sm.diff[pl1 >> 1], vm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            covsum += pl1 - pf;
+        };
+        if constexpr (IN == 0) {
+            auto win = [&](unsigned n) -> int { return (int)(((n & win_m1) | __umulhi(n, a.div_magic)) >> win_sh); };
+            auto one = [&](int rid, int st, int en) {
+                const unsigned jr = (unsigned)(rid - r_a);
+                const unsigned j = min(jr, (unsigned)nr);
+                const int b0 = sm.roff[j], nb_r = sm.roff[(j + 1u) & 63u] - b0;
+                const int first = win((unsigned)st);
+                const int last1 = win((unsigned)(en - 1)) + 1;
+                const bool valid = jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
+                const bool over = last1 > first && last1 > nb_r;
+                const int pf = max(b0 + first, off0), pl1 = min(b0 + min(last1, nb_r), t_end);
+                bad_any |= valid && (!sign_ok || (pos && over));
+                bad_order |= !valid;
+                if (valid && sign_ok && pos && pf < pl1) add_pm(pf, pl1);
+            };
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (u < NSEG || cur.cnt[u % NSEG] > (u / NSEG) * 64) one(g.rid[u], g.st[u], g.en[u]);
+            }
+            if (cur.more) {
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) {
+                    const long long base = (long long)cur.lo[s];
+                    for (int i = ITER * 64 + lane; i < cur.cnt[s]; i += 64) one((a.iv_rid + base)[i], (a.iv_s + base)[i], (a.iv_e + base)[i]);
+                }
+            }
+            if (__ballot(bad_order) != 0ull && lane == 0) atomicOr(a.err_flags, kErrOrder);
+            if (__ballot(bad_any) != 0ull) {         // rare: find the offending records again and report the first index
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) {
+                    const long long base = (long long)cur.lo[s];
+                    for (int i = lane; i < cur.cnt[s]; i += 64) {
+                        const int rid = (a.iv_rid + base)[i], st = (a.iv_s + base)[i], en = (a.iv_e + base)[i];
+                        if ((unsigned)(rid - r_a) >= (unsigned)nr) continue;
+                        const int j = rid - r_a;
+                        const int nb_r = sm.roff[j + 1] - sm.roff[j];
+                        const int first = (int)win_of(a, (unsigned)st), last1 = (int)win_of(a, (unsigned)(en - 1)) + 1;
+                        if ((st | en) < 0 || (en > 0 && last1 > first && last1 > nb_r)) raise_error(a, kErrCoord, base + i);
+                    }
+                }
+            }
+        } else {
+            // window records: (first window, one past the last) in one word; the read from the caller's offsets.  Boundary
+            // lane + 1 of a run: where the records of read r_a + lane + 1 begin (relative to the tile's first record of the run)
+            int bnd[NSEG];
+#pragma unroll
+            for (int s = 0; s < NSEG; ++s) {
+                const int nx = wave_shl1(rd.so[s], 0) - uni(rd.so[s]);
+                bnd[s] = (lane < nr) ? nx : 0x7fffffff;
+            }
+            auto one_w = [&](int j, unsigned w) {
+                const int b0 = sm.roff[j], nb_r = sm.roff[j + 1] - b0;
+                const int first = (int)(w & 0xffffu), last1 = (int)(w >> 16);
+                const bool over = last1 > first && last1 > nb_r;
+                const int pf = max(b0 + first, off0), pl1 = min(b0 + min(last1, nb_r), t_end);
+                bad_any |= over;
+                if (pf < pl1) add_pm(pf, pl1);
+            };
+            auto read_of = [&](int s, int i0, int i) -> int {   // read of record i of run s; the wave's records are [i0, i0 + 64)
+                const int i_last = min(i0 + 63, cur.cnt[s] - 1);
+                const unsigned jf = (unsigned)__popcll(__ballot(bnd[s] <= i0)), jl = (unsigned)__popcll(__ballot(bnd[s] <= i_last));
+                int j = (int)jf;
+                for (unsigned t = jf; t < jl; ++t) j += (i >= __builtin_amdgcn_readlane(bnd[s], (int)t)) ? 1 : 0;
+                return min(j, max(nr - 1, 0));
+            };
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = u % NSEG, i0 = (u / NSEG) * 64;
+                if (cur.cnt[s] > i0) one_w(read_of(s, i0, i0 + lane), (unsigned)g.st[u]);
+            }
+            if (cur.more) {
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) {
+                    const long long base = (long long)cur.lo[s];
+                    for (int i0 = ITER * 64; i0 < cur.cnt[s]; i0 += 64) {
+                        const int i = i0 + lane;
+                        const int j = read_of(s, i0, i);
+                        if (i < cur.cnt[s]) one_w(j, (a.iv_w + base)[i]);
+                    }
+                }
+            }
+            if (__ballot(bad_any) != 0ull) {
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) {
+                    const long long base = (long long)cur.lo[s];
+                    for (int i0 = 0; i0 < cur.cnt[s]; i0 += 64) {
+                        const int i = i0 + lane;
+                        const int j = read_of(s, i0, i);
+                        if (i < cur.cnt[s]) {
+                            const unsigned w = (a.iv_w + base)[i];
+                            const int first = (int)(w & 0xffffu), last1 = (int)(w >> 16);
+                            if (last1 > first && last1 > sm.roff[j + 1] - sm.roff[j]) raise_error(a, kErrCoord, base + i);
+                        }
+                    }
+                }
+            }
+        }
+        lane_cov += covsum;
+
+        // ---- the next tile's loads go out now: the interval registers are free, and the rows below hide their latency
+        const bool have_next = kn < n_tiles;
+        const bool drew = want_draw;
+        unpack(raw_n, nxt);
+        const int raw_nn = cut_word(min(knn, n_tiles - 1));
+        if (want_draw) { draw(); want_draw = false; }
+        if (have_next) issue(nxt, g, rdn);
+
+        // ---- 2. rows: prefix sum, store, run detection; every row is zeroed once it is read
+        int carry = 0;
+        bool hp = false;                 // the slot before the next one is high
+        int S = kNone;                   // start slot of the run currently open
+        int nq = 0;
+        int32_t *const cov0 = OW == 4 ? a.cov + a0 : nullptr;
+        char *const covp0 = OW == 4 ? nullptr : reinterpret_cast<char *>(a.covp) + (D4 ? a0 / 2 : a0 * OW);
+        int pend_p = -1, pend_c = 0;     // D4: this lane's listed window waiting for the end of the rows
+        int d4_n = 0;                    // D4: windows of this tile listed so far (wave-uniform)
+        auto d4_list = [&](int p, int v, int slot) {
+            if (slot < kExcPerTile) {
+                const long long at = (long long)(n_reg + k) * kExcPerTile + slot;
+                a.exc_pidx[at] = a0 + p; a.exc_pval[at] = v;
+            } else note_exception(a, a0 + p, v);
+        };
+        // a run found while the queue is full (a tile of very many short repeats): emitted at once by the lane that found it,
+        // from global memory (no shuffles inside divergent code)
+        auto emit_overflow = [&](int sS, int sT) {
+            if (piece) {
+                const int r0 = reinterpret_cast<const int32_t *>(a.rep_res_off + r_a)[0], r1 = reinterpret_cast<const int32_t *>(a.rep_res_off + r_a)[2];
+                const int slot = atomicAdd(&a.rep_cnt[r_a], 1);
+                if (slot >= r1 - r0) { raise_error(a, kErrInternal, r_a); return; }
+                const int start = (sS - sm.roff[0]) * a.reso;
+                const long long ix = (long long)r0 + slot;
+                a.raw_key[ix] = start; a.raw_s[ix] = start; a.raw_e[ix] = start + (sT - sS) * a.reso;
+                return;
+            }
+            int jo = 0;                          // owner: the last read that begins at or before the run's first slot
+            for (int q = 1; q < nr; ++q) if (sm.roff[q] <= sS) jo = q;
+            const int nwin_r = sT - sS;
+            if ((long long)nwin_r * a.reso < (long long)a.repeat_length) return;
+            const int len = a.read_len[r_a + jo];
+            const int r0 = reinterpret_cast<const int32_t *>(a.rep_res_off + r_a + jo)[0], r1 = reinterpret_cast<const int32_t *>(a.rep_res_off + r_a + jo)[2];
+            const int slot = atomicAdd(&sm.rcnt[jo], 1);
+            const int start = (sS - sm.roff[jo]) * a.reso, end = start + nwin_r * a.reso;
+            int s2 = start - a.flank, e2 = end + a.flank;
+            if (s2 <= 0) s2 = 0;
+            if (e2 >= len) e2 = len;
+            if (slot >= r1 - r0) { raise_error(a, kErrInternal, r_a + jo); return; }
+            const long long idx = (long long)r0 + slot;
+            a.raw_key[idx] = start; a.raw_s[idx] = s2; a.raw_e[idx] = e2;
+            lane_rep += end - start;
+        };
+
+        const uint64_t *drow = reinterpret_cast<const uint64_t *>(sm.diff);      // dword pairs: 4 slots
+        uint64_t dA = drow[lane], dB = drow[64 + lane];
+        for (int row = 0; row < rows; ++row) {
+            const int base = row * 512;
+            const uint64_t cA = dA, cB = dB;
+            // the next row, unconditionally (behind the last row: row 0 again, never used)
+            const int nrow = row + 1 < rows ? row + 1 : 0;
+            dA = drow[nrow * 128 + lane];
+            dB = drow[nrow * 128 + 64 + lane];
+            constexpr uint64_t kZero2 = ((uint64_t)kZero << 32) | kZero;
+            reinterpret_cast<uint64_t *>(sm.diff)[row * 128 + lane] = kZero2;
+            reinterpret_cast<uint64_t *>(sm.diff)[row * 128 + 64 + lane] = kZero2;
+            // (bias off: two independent 16-bit steps per dword from here on)
+            const unsigned dA0 = (unsigned)cA ^ kZero, dA1 = (unsigned)(cA >> 32) ^ kZero, dB0 = (unsigned)cB ^ kZero, dB1 = (unsigned)(cB >> 32) ^ kZero;
+            // in-lane prefix of each half-row's four slots (packed, modulo 2^16 per half)
+            const unsigned qA0 = dA0 + (dA0 << 16), qB0 = dB0 + (dB0 << 16);
+            const unsigned qA1 = pk_add_bcast<true>(dA1 + (dA1 << 16), qA0), qB1 = pk_add_bcast<true>(dB1 + (dB1 << 16), qB0);
+            // the lanes' totals of both half-rows through ONE scan: V = totA + 65536 totB as a 32-bit integer (exact: |tot| < 32768)
+            const int V = ((int)qA1 >> 16) + (int)(qB1 & 0xffff0000u);
+            const int incl = wave_incl_scan_add(V);
+            const int tot = __builtin_amdgcn_readlane(incl, 63);
+            const int totA = (int)(short)tot, totB = (tot - totA) >> 16;
+            // start values: low half = carry + lanes before in half-row A; high half = carry + all of A + lanes before in B
+            const unsigned E = (unsigned)(incl - V) + (unsigned)carry * 0x10001u + ((unsigned)totA << 16);
+            carry += totA + totB;
+            const unsigned rA0 = pk_add_bcast<false>(qA0, E), rA1 = pk_add_bcast<false>(qA1, E);
+            const unsigned rB0 = pk_add_bcast<true>(qB0, E), rB1 = pk_add_bcast<true>(qB1, E);
+            const int pA = base + lane * 4, pB = base + 256 + lane * 4;        // this lane's first slot in each half-row
+            const unsigned mx = pk_max_u16(pk_max_u16(rA0, rA1), pk_max_u16(rB0, rB1));
+            const bool full = base >= off0 && base + 512 <= t_end;              // every slot of the row is a window of the tile
+            // ---- store
+            auto store_half = [&](unsigned r0, unsigned r1, int p0, unsigned d0, unsigned d1) {
+                const unsigned c0 = r0 & 0xffffu, c1 = r0 >> 16, c2 = r1 & 0xffffu, c3 = r1 >> 16;
+                if (OW == 4) {
+                    int32_t *o = cov0 + p0;
+                    if (full) *reinterpret_cast<int4 *>(o) = make_int4((int)c0, (int)c1, (int)c2, (int)c3);
+                    else {
+                        const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
+                        const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
+                        if (v0 && v3) *reinterpret_cast<int4 *>(o) = make_int4((int)c0, (int)c1, (int)c2, (int)c3);
+                        else { if (v0) o[0] = (int)c0; if (v1) o[1] = (int)c1; if (v2) o[2] = (int)c2; if (v3) o[3] = (int)c3; }
+                    }
+                } else if (OW == 1 || OW == 2) {
+                    const unsigned m0 = pk_min_u16(r0, kLimit * 0x10001u), m1 = pk_min_u16(r1, kLimit * 0x10001u);
+                    const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
+                    const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
+                    if (OW == 1) {
+                        uint8_t *o = reinterpret_cast<uint8_t *>(covp0) + p0;
+                        const unsigned pk4 = __builtin_amdgcn_perm(m1, m0, 0x06040200u);
+                        if (full || (v0 && v3)) *reinterpret_cast<unsigned *>(o) = pk4;
+                        else { if (v0) o[0] = (uint8_t)pk4; if (v1) o[1] = (uint8_t)(pk4 >> 8); if (v2) o[2] = (uint8_t)(pk4 >> 16); if (v3) o[3] = (uint8_t)(pk4 >> 24); }
+                    } else {
+                        uint16_t *o = reinterpret_cast<uint16_t *>(covp0) + p0;
+                        if (full || (v0 && v3)) *reinterpret_cast<uint2 *>(o) = make_uint2(m0, m1);
+                        else { if (v0) o[0] = (uint16_t)m0; if (v1) o[1] = (uint16_t)(m0 >> 16); if (v2) o[2] = (uint16_t)m1; if (v3) o[3] = (uint16_t)(m1 >> 16); }
+                    }
+                    if ((c0 | c1 | c2 | c3) >= kLimit) {       // rare by the choice of the width
+                        if ((full || v0) && c0 >= kLimit) note_exception(a, a0 + p0, (int)c0);
+                        if ((full || v1) && c1 >= kLimit) note_exception(a, a0 + p0 + 1, (int)c1);
+                        if ((full || v2) && c2 >= kLimit) note_exception(a, a0 + p0 + 2, (int)c2);
+                        if ((full || v3) && c3 >= kLimit) note_exception(a, a0 + p0 + 3, (int)c3);
+                    }
+                } else {
+                    // four-bit steps: a step IS the difference array's value; the lane's four steps are one aligned ushort
+                    const int s0 = (int)(short)d0, s1 = (int)d0 >> 16, s2 = (int)(short)d1, s3 = (int)d1 >> 16;
+                    const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
+                    const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
+                    const unsigned valid = full ? 15u : ((v0 ? 1u : 0u) | (v1 ? 2u : 0u) | (v2 ? 4u : 0u) | (v3 ? 8u : 0u));
+                    unsigned esc = 0u;
+                    if (valid) {
+                        const unsigned ux = (unsigned)(s0 + 7), uy = (unsigned)(s1 + 7), uz = (unsigned)(s2 + 7), uw = (unsigned)(s3 + 7);
+                        unsigned code = (ux <= 14u ? ux + 1u : 0u) | ((uy <= 14u ? uy + 1u : 0u) << 4) | ((uz <= 14u ? uz + 1u : 0u) << 8) | ((uw <= 14u ? uw + 1u : 0u) << 12);
+                        const unsigned f = (unsigned)(off0 - p0);                     // < 4: the tile's first window is this lane's slot f
+                        if (f < 4u) code &= ~(0xFu << (4u * f));
+                        const unsigned vmask = ((valid & 1u) ? 0xFu : 0u) | ((valid & 2u) ? 0xF0u : 0u) | ((valid & 4u) ? 0xF00u : 0u) | ((valid & 8u) ? 0xF000u : 0u);
+                        code &= vmask;
+                        unsigned t = code | (code >> 1);
+                        t |= t >> 2;
+                        esc = ~t & 0x1111u & vmask;                                   // bit 4q: window q of this lane is listed
+                        char *const o = covp0 + ((unsigned)p0 >> 1);
+                        if (valid == 15u) *reinterpret_cast<uint16_t *>(o) = (uint16_t)code;
+                        else {      // the neighbouring tile owns the other nibbles of this ushort: clear mine, then set them
+                            const unsigned long long addr = reinterpret_cast<unsigned long long>(o);
+                            unsigned *const word = reinterpret_cast<unsigned *>(addr & ~3ull);
+                            const unsigned sh = (unsigned)(addr & 2ull) * 8u;
+                            atomicAnd(word, ~(vmask << sh));
+                            atomicOr(word, (code & vmask) << sh);
+                        }
+                        // the lane whose first window opens a block of 1024 stores the prefix before it as the anchor
+                        if ((valid & 1u) && (((unsigned)a0 + (unsigned)p0 + (unsigned)a.d4_shift) & 1023u) == 0u)
+                            a.cov_anchor[(a0 + p0 + a.d4_shift) >> 10] = (int)c0 - s0;
+                        // a lane parks its first listed window until the rows are done
+                        if (esc && pend_p < 0) {
+                            const int q = (__ffs((int)esc) - 1) >> 2;
+                            esc &= esc - 1u;
+                            pend_p = p0 + q; pend_c = q == 0 ? (int)c0 : q == 1 ? (int)c1 : q == 2 ? (int)c2 : (int)c3;
+                        }
+                    }
+                    // (rare) further listed windows of a lane: placed at once, in the tile's own slots, ranked by ballot
+                    unsigned long long em = __ballot(esc != 0u);
+                    while (em) {
+                        if (esc) {
+                            const int q = (__ffs((int)esc) - 1) >> 2;
+                            esc &= esc - 1u;
+                            d4_list(p0 + q, q == 0 ? (int)c0 : q == 1 ? (int)c1 : q == 2 ? (int)c2 : (int)c3, d4_n + (int)__popcll(em & ((1ull << lane) - 1ull)));
+                        }
+                        d4_n += (int)__popcll(em);
+                        em = __ballot(esc != 0u);
+                    }
+                }
+            };
+            store_half(rA0, rA1, pA, dA0, dA1);
+            store_half(rB0, rB1, pB, dB0, dB1);
+
+            // ---- run scan: only rows that hold a high window or inherit an open run
+            const unsigned xh = (mx + kthr) & 0x80008000u;
+            if (__ballot(xh != 0u) == 0ull && !hp) continue;
+            // per half-row: pileup_fast.hpp's per-lane scan of four slots
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                const int hb = base + h * 256;                         // first slot of the half-row
+                if (hb > t_end) break;
+                const unsigned x0 = (h ? rB0 : rA0) + kthr, x1 = (h ? rB1 : rA1) + kthr;
+                const int p0 = hb + lane * 4;
+                int hvn = (int)(((x0 >> 15) & 1u) | ((x0 >> 30) & 2u) | ((x1 >> 13) & 4u) | ((x1 >> 28) & 8u));
+                // slots outside the tile are not windows
+                int inside = 15;
+                if (hb < off0 || hb + 256 > t_end) {
+                    const int lo_k = min(max(off0 - p0, 0), 4), hi_k = min(max(t_end - p0, 0), 4);
+                    inside = ((1 << hi_k) - 1) & ~((1 << lo_k) - 1);
+                }
+                hvn &= inside;
+                const unsigned long long HV = __ballot(hvn != 0);
+                if (HV == 0ull && !hp) continue;
+                const unsigned long long RS = __ballot((ro_s >> 8) == (hb >> 8) && ro_s >= hb);   // reads that begin in this half-row
+                const bool tail = hb + 256 > t_end;
+                if (hp && !tail && RS == 0ull && __ballot(hvn == 15) == ~0ull) continue;            // a run passes through the half-row
+                int sbm = 0;
+                {
+                    unsigned long long rs = RS;
+                    while (rs) {
+                        const int pos = __builtin_amdgcn_readlane(ro_s, (int)__builtin_ctzll(rs)) - hb;
+                        rs &= rs - 1ull;
+                        if ((pos >> 2) == lane) sbm |= 1 << (pos & 3);
+                    }
+                }
+                const int hk = (hb < off0 + 1 && hb + 256 > off0) ? (off0 - hb) : 0;   // the carried-in bit belongs to the first valid slot
+                int prvn = ((hvn << 1) & 15) | wave_shr1(hvn >> 3, 0);
+                if (hp && lane == (hk >> 2)) prvn |= 1 << (hk & 3);
+                int inside_e = 15;                                   // slots at which a run may END: t_end itself included (the sentinel)
+                if (tail) inside_e = (1 << min(max(t_end - p0 + 1, 0), 4)) - 1;
+                const int starts = hvn & ((prvn ^ 15) | sbm);
+                int ends = prvn & ((hvn ^ 15) | sbm) & inside_e;
+                const int ls = starts ? p0 + (31 - __clz(starts)) : -0x40000000;
+                const int incl2 = wave_incl_scan_max(ls, -0x40000000);
+                const int carried = max(S, wave_shr1(incl2, -0x40000000));
+                while (__ballot(ends != 0) != 0ull) {
+                    const bool has = ends != 0;
+                    const int kq = has ? __builtin_ctz(ends) : 0;
+                    const int below = starts & ((1 << kq) - 1);
+                    const int best = max(carried, below ? p0 + (31 - __clz(below)) : -0x40000000);
+                    const int t = p0 + kq;
+                    ends &= ends - 1;
+                    const bool keep = has && best >= 0 &&
+                                      ((long long)(t - best) * a.reso >= (long long)a.repeat_length || (piece && (best == off0 || t == t_end)));
+                    const unsigned long long km = __ballot(keep);
+                    if (km) {
+                        const int idx = nq + (int)__popcll(km & ((1ull << lane) - 1ull));
+                        if (keep) {
+                            if (idx < kRunQ) { sm.runq[idx * 2] = best; sm.runq[idx * 2 + 1] = t; }
+                            else emit_overflow(best, t);
+                        }
+                        nq = min(kRunQ, nq + (int)__popcll(km));
+                    }
+                }
+                S = max(S, __builtin_amdgcn_readlane(incl2, 63));
+                // what the next half-row inherits: is its predecessor slot high?
+                if (!tail) hp = (__builtin_amdgcn_readlane(hvn, 63) & 8) != 0;
+                else hp = false;        // (the run that reaches t_end was closed at the sentinel slot)
+            }
+        }
+
+        if (D4) {                            // the windows the lanes parked: one place in the tile's list each
+            const unsigned long long pm = __ballot(pend_p >= 0);
+            if (pm) {
+                if (pend_p >= 0) d4_list(pend_p, pend_c, d4_n + (int)__popcll(pm & ((1ull << lane) - 1ull)));
+                d4_n += (int)__popcll(pm);
+            }
+            if (d4_n && lane == 0) a.exc_tile_n[n_reg + k] = min(d4_n, kExcPerTile);
+        }
+        // ---- 3. every parked run becomes a raw repeat record, one lane per run
+        if (nq > 0) {
+            int sS = 0, sT = 0, j = 0;
+            if (lane < nq) { sS = sm.runq[lane * 2]; sT = sm.runq[lane * 2 + 1]; }
+#pragma unroll 1
+            for (int q = 0; q < nq; ++q) {
+                const int s0 = __builtin_amdgcn_readlane(sS, q);
+                const int jq = __popcll(__ballot(ro_s <= s0)) - 1;
+                if (lane == q) j = jq;
+            }
+            if (piece) {
+                const int r0 = __builtin_amdgcn_readlane(rd.rr, 0), r1 = __builtin_amdgcn_readlane(rd.rr, 1);
+                if (lane < nq) {
+                    const int slot = atomicAdd(&a.rep_cnt[r_a], 1);
+                    if (slot >= r1 - r0) raise_error(a, kErrInternal, r_a);
+                    else {
+                        const int start = (sS - sm.roff[0]) * a.reso;
+                        const long long ix = (long long)r0 + slot;
+                        a.raw_key[ix] = start; a.raw_s[ix] = start; a.raw_e[ix] = start + (sT - sS) * a.reso;
+                    }
+                }
+            } else {
+                // (shuffles below need every lane: lanes without a run carry an empty one)
+                const int jj = lane < nq ? max(j, 0) : 0;
+                const int nwin_r = sT - sS;
+                const bool live = lane < nq && (long long)nwin_r * a.reso >= (long long)a.repeat_length;
+                const int len = __shfl(rd.rl, jj), r0 = __shfl(rd.rr, jj), r1 = __shfl(rd.rr, jj + 1);
+                if (live) {
+                    const int off = sm.roff[jj];
+                    const int slot = atomicAdd(&sm.rcnt[jj], 1);
+                    const int start = (sS - off) * a.reso, end = start + nwin_r * a.reso;
+                    int s = start - a.flank, e = end + a.flank;
+                    if (s <= 0) s = 0;
+                    if (e >= len) e = len;
+                    if (slot >= r1 - r0) raise_error(a, kErrInternal, r_a + jj);
+                    else {
+                        const long long idx = (long long)r0 + slot;
+                        a.raw_key[idx] = start; a.raw_s[idx] = s; a.raw_e[idx] = e;
+                        lane_rep += end - start;
+                    }
+                }
+            }
+            if (!piece && lane < nr) {
+                const int c = sm.rcnt[lane];
+                if (c) a.rep_cnt[r_a + lane] = c;
+            }
+        }
+
+        // ---- hand over to the next tile
+        if (!have_next) break;
+        wait_all_loads();
+        if (drew) next_base = n_waves * kBatch + uni(drawn);
+        k = kn; kn = knn; knn = hand_out(); raw_n = raw_nn;
+        cur = nxt; rd = rdn;
+    }
+    {
+        const long long cs = wave_reduce_add64(lane_cov), rs = wave_reduce_add64(lane_rep);
+        if (lane == 0) { a.block_sums[2 * (long long)wave_id] = cs; a.block_sums[2 * (long long)wave_id + 1] = rs; }
+    }
+}
+
+// WPB waves per workgroup, each with a tile stream and an LDS slice of its own (no barrier anywhere); WPS waves per SIMD asked
+// of the register allocator.
+template <int SLOTS, int NSEG, int U, int OW, int IN, int WPB, int WPS>
+__global__ __launch_bounds__(64 * WPB, WPS) void pileup_wave_kernel(const TileCut *__restrict__ cuts, PileupArgs a)
+{
+    __shared__ __attribute__((aligned(16))) WaveSmem<SLOTS> sm[WPB];
+    const int wid = WPB == 1 ? 0 : uni((int)(threadIdx.x >> 6));
+    wave_tile_loop<SLOTS, NSEG, U, OW, IN>(sm[wid], cuts, a, (int)blockIdx.x * WPB + wid, (int)gridDim.x * WPB);
+}
+
+} // namespace raft

@@ -28,7 +28,7 @@ EXPORTS = (
     "raft_hip_run_multi_grouped", "raft_hip_host_register", "raft_hip_host_unregister", "raft_hip_comm_unique_id",
     "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local", "raft_hip_warm_up", "raft_hip_reserve",
     "raft_hip_run_device_windows", "raft_hip_run_host_windows", "raft_hip_run_multi_windows",
-    "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device",
+    "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device", "raft_hip_set_emit_cuts",
 )
 
 
@@ -162,6 +162,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.raft_hip_set_tuning.argtypes = [vp, i32, i32, i32]
     lib.raft_hip_set_output_width.argtypes = [vp, i32]
+    lib.raft_hip_set_emit_cuts.argtypes = [vp, i32]
     lib.raft_hip_packed_device.argtypes = [vp, C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
     lib.raft_hip_selftest.argtypes = [C.c_int]
     lib.raft_hip_debug_stamps.argtypes = [vp, vp, i64, C.POINTER(i64)]
@@ -226,6 +227,10 @@ class Engine:
     def set_output_width(self, width: int):
         """4: cov[] as int32 (default); 1 / 2: later passes write the transfer encoding directly (raft_hip_set_output_width)."""
         self._check(self._lib.raft_hip_set_output_width(self._ctx, width))
+
+    def set_emit_cuts(self, on: bool):
+        """True (default): every pass writes the cut points itself; False: the first fetch that asks for them does."""
+        self._check(self._lib.raft_hip_set_emit_cuts(self._ctx, 1 if on else 0))
 
     def use_torch_stream(self):
         import torch

@@ -250,6 +250,7 @@ int main(int argc, char *argv[])
     // registers): the engine is told, so it neither scans for the mirror of record 0 nor -- for a symmetric PAF -- is
     // handed the target columns at all (half of the upload).
     hp.symmetric_mode = raft_host_paf_symmetric(paf) ? 1 : 0;
+    out_prep.join();                                  // (its raft_hip_reserve reads the contexts' parameters: done before they change)
     rc = raft_hip_set_params(ctx, &hp);
     if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_set_params(), ") + raft_hip_strerror(rc));
     const bool sym = hp.symmetric_mode == 1;
@@ -284,7 +285,6 @@ int main(int argc, char *argv[])
     if (n_runs > 0) pin(rec_off.get(), (size_t)n_runs * ((size_t)n_reads + 1) * 8);
     if (win) pin(const_cast<uint32_t *>(win), (size_t)n_rec * 4);
     else for (int k = n_runs > 0 ? 1 : 0; k < (sym ? 3 : 6); ++k) pin(raft_host_paf_column(paf, k), (size_t)n_rec * 4);
-    out_prep.join();
     stage("page-lock");
     // one byte per window unless the expected coverage lets repeats pile up beyond it (from 40x on: two), and two in any
     // case when the first attempt meets more windows at or above 255 than the exception list holds

@@ -38,14 +38,17 @@ def test_bench_line_has_every_contract_field():
     for k in ("records_per_s", "fragments_per_s", "seconds", "first_pass_s", "h2d_bytes", "d2h_bytes", "host_memory"):
         assert k in e, k
     assert e["decoded_coverage_equals_device"] is True and e["chunked_equals_one_piece"] is True and e["records_per_s"] > 0 and e["d2h_bytes"] < e["h2d_bytes"] * 3
-    assert all(d["self_check"].values()) and len(d["self_check"]) == 3
-    # round 3: grouped input is the headline; the product path (no query column, a byte per window) sits in `roofline`; the
-    # six-column detecting form and the six-column host pipeline are timed beside it
-    assert "grouped" in d["config"]["input"] and "cut_points" in d["config"]
+    assert all(d["self_check"].values()) and len(d["self_check"]) == 4
+    # round 4: the headline is the self-contained six-column pass into a detecting context again (the grouped form -- part of
+    # create_pileup's bucketing handed over by the caller -- is a leg beside it), and the pass writes the cut points itself
+    assert "six plain columns" in d["config"]["input"] and "detecting" in d["config"]["input"] and "inside the step" in d["config"]["cut_points"]
+    assert d["config"]["cut_points_total_rank0"] >= d["config"]["reads_per_gpu"] and rf["pass_includes_cut_points"] is True
+    assert 0 < rf["pass_device_ms_without_cuts"] < rf["pass_device_ms"] * 1.2
+    # the product path (no query column, a byte per window) sits in `roofline`; the grouped form and the six-column host pipeline are timed beside it
     for k in ("product_path_kernel_ms", "product_path_frac", "product_path_pass_frac"):
         assert rf[k] > 0, k
     assert d["packed_output"]["equals_int32_pass"] is True and "no query column" in d["packed_output"]["input"]
-    assert d["six_column"]["pass_device_ms"] > 0 and d["six_column"]["pass_device_ms_inspect_first"] > 0
+    assert "six_column" not in d and d["grouped"]["pass_device_ms"] > 0 and d["grouped"]["six_column_pass_device_ms_inspect_first"] > 0
     assert e["six_column_input"]["equals_grouped"] is True and e["six_column_input"]["h2d_bytes"] > e["h2d_bytes"]
     assert cb["cpu_model"] and cb["node_logical_cpus"] >= 1 and "same seed" in cb["sample"]
     # ... window records and the four-bit step encoding of the coverage: the CLI's forms, each checked against the int32 pass
@@ -55,7 +58,10 @@ def test_bench_line_has_every_contract_field():
     w = e["window_records"]
     assert w["equals_coordinate_columns"] is True and w["delta4"]["decoded_equals_byte_encoding"] is True
     assert w["delta4"]["d2h_bytes"] < e["byte_per_window_d2h_bytes"] and e["coordinate_columns"]["h2d_bytes"] > e["h2d_bytes"]
-    assert e["records_per_s"] == w["delta4"]["records_per_s"]
+    # the object's headline starts at SURVEY.md §8(d)'s boundary: the grouped form and the window records are derived inside the clock
+    fs = w["from_soa"]
+    assert fs["equals_prepared_input"] is True and e["records_per_s"] == fs["records_per_s"] and e["seconds"] == fs["seconds"]
+    assert e["prepared_input"]["records_per_s"] == w["delta4"]["records_per_s"] and "SoA boundary" in e["mode"]
 
 
 @pytest.mark.parametrize("extra", [[], ["--presplit"]])

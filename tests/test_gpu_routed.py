@@ -67,6 +67,35 @@ def test_routed_errors():
     eng.close(); other.close()
 
 
+def test_routed_exception_list_too_small_reports_the_job_total():
+    """A shuffled, non-symmetric stream whose windows at or above the byte limit outnumber exc_cap: raft_hip_run_multi returns
+    RAFT_HIP_ERR_TOO_LARGE with the JOB's exception count in out->n_exc (include/raft_hip.h: one retry suffices), and the
+    retry with that much room gives the oracle's arrays."""
+    from raft_amd import engine, hostio
+    rng = np.random.default_rng(11)
+    rl = rng.integers(3000, 20000, 600).astype(np.int32)
+    n = 400000                                          # ~600 intervals per read on ~230 windows: most windows are above 255
+    qid = rng.integers(0, len(rl), n).astype(np.int32); tid = rng.integers(0, len(rl), n).astype(np.int32)
+    a = (rng.random(n) * rl[qid] * 0.5).astype(np.int32); b = np.minimum(rl[qid], a + 1 + (rng.random(n) * rl[qid] * 0.5).astype(np.int32)).astype(np.int32)
+    ta = (rng.random(n) * rl[tid] * 0.5).astype(np.int32); tb = np.minimum(rl[tid], ta + 1 + (rng.random(n) * rl[tid] * 0.5).astype(np.int32)).astype(np.int32)
+    p = RaftParams(est_cov=400, symmetric_mode=-1)
+    want = oracle_run(p, rl, qid, a, b, tid, ta, tb)
+    n_big = int((want["cov"] >= 255).sum())
+    assert n_big > 5000
+    eng = engine.Engine(p, device=0)
+    other = engine.Engine(p, device=0)
+    out = eng.host_output_buffers(rl, pinned=False, width=1, exc_cap=64)
+    with pytest.raises(engine.RaftError) as e:
+        eng.run_pipelined(rl, qid, a, b, tid, ta, tb, n_chunks=5, out=out, others=[other])
+    assert e.value.code == engine.ERR_TOO_LARGE and eng.last_n_exc == n_big, (e.value.code, eng.last_n_exc, n_big)
+    out = eng.host_output_buffers(rl, pinned=False, width=1, exc_cap=eng.last_n_exc)
+    res, s = eng.run_pipelined(rl, qid, a, b, tid, ta, tb, n_chunks=5, out=out, others=[other])
+    assert s.n_devices_used == 2 and res["exc_index"].size == n_big
+    assert np.array_equal(hostio.unpack_coverage(res["cov8"], res["exc_index"], res["exc_value"]), want["cov"])
+    check_pipelined(res, s, want, "routed, exception list grown after TOO_LARGE")
+    eng.close(); other.close()
+
+
 def test_more_records_than_one_pass_takes():
     """5.5e8 non-symmetric records (> 2^29, the limit of a one-piece pass): refused as RAFT_HIP_ERR_TOO_LARGE before; now
     routed in read ranges.  Checked by invariants (the oracle does not finish at this size)."""
