@@ -14,7 +14,7 @@
 #include "wave_launch.hpp"
 
 #ifndef RAFT_DEFAULT_VARIANT
-#define RAFT_DEFAULT_VARIANT 0
+#define RAFT_DEFAULT_VARIANT 5
 #endif
 
 #include <dlfcn.h>
@@ -842,13 +842,19 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     // the detection of a pass that assumes a symmetric PAF: one more boundary search of this kernel (pileup.hpp MirrorArgs)
     MirrorArgs mir{};
     if (spec && c->prm.symmetric_mode < 0 && fast) mir = {d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp.sym_found};
+    // (every tile re-cut and the bounds to be searched in the record stream itself: the searches get threads of their own)
+    const bool defer_bounds = wave && n_rec > 0 && !grouped && c->sum.interval_path == 0;
     hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 2 + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
                        pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>(),
                        pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, wave ? -1 : pv.cap, wave ? kWaveMaxReads : kFastMaxReads,
                        pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow,
                        (fast && table_ok) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
                        c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags,
-                       recut ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp, pv.cap);
+                       recut ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp, pv.cap,
+                       defer_bounds ? 1 : 0);
+    if (defer_bounds)
+        hipLaunchKernelGGL(cut_bounds_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>((extra_cap / 2 + 255) / 256, 256 * 16))), dim3(256), 0, st,
+                           &ctrl->n_extra, c->tile_cuts.as<TileCut>() + (n_tiles + 1), c->tile_cuts.as<TileCut>(), pa.iv_rid, pa.n_seg, &ctrl->err_flags);
     pa.n_extra = recut ? &ctrl->n_extra : nullptr;
     pa.piece_w = pv.cap;
 
@@ -870,8 +876,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         // ONE launch, no second stream: a persistent grid of single-wave workers, each drawing wave tiles from the list
         // tile_desc_kernel cut (its length is known on the device only: workers without a tile leave at once)
         const int n_waves = wave_grid_waves();
+        // (a quarter of the tiles is handed out dynamically, in batches of up to eight: pileup_wave.hpp)
         const long long est_tiles = B / std::max(1, (pv.cap * 3) / 4) + 1;
-        pa.tile_batch = est_tiles >= 64LL * n_waves ? 4 : (est_tiles >= 16LL * n_waves ? 2 : 1);
+        pa.tile_batch = (int32_t)std::max<long long>(1, std::min<long long>(8, est_tiles / (16LL * n_waves)));
         if (const char *e = getenv("RAFT_WAVE_BATCH")) pa.tile_batch = std::max(1, atoi(e));
         pa.n_extra = &ctrl->n_extra;
         launch_wave_variant(ow, lean, st, pa.n_seg, c->tile_cuts.p, &pa);

@@ -237,7 +237,9 @@ __device__ __forceinline__ int walk_cuts(int len, int L, const int32_t *s, const
 }
 
 // one read: order (and, for a long read, join) its repeats; count its kept markers and fragments
-__device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, int r, int &n_out, int &nF_out, int &nf_out)
+// (rep_bp_out: unclamped repeat bases of a read joined from pieces -- repeat.hpp:127,152 -- for the caller to add to the total:
+// one atomic per READ on the one word serialised to 0.4 ms once a human-scale set had 1e4 such reads)
+__device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, int r, int &n_out, int &nF_out, int &nf_out, long long &rep_bp_out)
 {
     int n = a.rep_cnt[r];
     const long long base = a.rep_res_off[r];
@@ -268,7 +270,7 @@ __device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, int r,
             }
             n = m;
             a.rep_cnt_rw[r] = m;
-            if (rep_bp) atomicAdd(a.total_repeat, (unsigned long long)rep_bp);
+            rep_bp_out += rep_bp;
         }
     }
     if (n > 16 && a.raw_s[base + 1] == 0) rep_std_sort(a.raw_s + base, a.raw_e + base, n);   // tied starts: repeat.hpp:170
@@ -305,7 +307,9 @@ struct FinalizeCountLoader {
         v[0] = v[1] = v[2] = 0;
         if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
         int n, nF, nf;
-        finalize_count_one(a, (int)i, n, nF, nf);
+        long long bp = 0;
+        finalize_count_one(a, (int)i, n, nF, nf, bp);
+        if (bp) atomicAdd(a.total_repeat, (unsigned long long)bp);
         v[0] = n; v[1] = nF; v[2] = nf;
     }
 };
@@ -316,10 +320,17 @@ struct FinalizeCountLoader {
 __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_reads) return;
     if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
-    int n, nF, nf;
-    finalize_count_one(a, r, n, nF, nf);
+    long long bp = 0;
+    if (r < a.n_reads) {
+        int n, nF, nf;
+        finalize_count_one(a, r, n, nF, nf, bp);
+    }
+    // one atomic per wave that has anything to add
+    if (__ballot(bp != 0) != 0ull) {
+        const long long s = wave_reduce_add64(bp);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.total_repeat, (unsigned long long)s);
+    }
 }
 
 // Compact repeats and the fragments of every read.  The cut points themselves (chop.hpp's final_stars, 4 B per

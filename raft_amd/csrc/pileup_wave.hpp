@@ -73,6 +73,14 @@ __device__ __forceinline__ int wave_shl1(int v, int last)      // lane l takes l
     return __builtin_amdgcn_update_dpp(last, v, 0x130, 0xf, 0xf, false);         // wave_shl:1 (GFX9 family)
 }
 
+// The wave's coverage stores as the instructions they are meant to be: raw buffer stores (a per-tile descriptor, the lane's
+// 32-bit byte offset).  (Left to the compiler, the 16-byte store of a row's lanes and the element stores of a tile's edge
+// lanes were merged into a 12-byte plus a 4-byte store per half-row: twice the store instructions, none of them a whole
+// 16 bytes -- the int32 pass took 3.2 ms where the byte pass took 1.9.  Inline asm stores are not an option either: the
+// compiler does not pad the wait states behind them and overwrote their data registers.)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
 template <int U>
 struct WaveRegs { int rid[U], st[U], en[U]; };
 struct WaveReadRegs { int cv, rr, rl; int so[2]; };
@@ -156,27 +164,32 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
     asm volatile("" : "+v"(draw_from));
     int drawn = 0;
     auto draw = [&]() { if (lane == 0) drawn = __hip_atomic_fetch_add(draw_from, kBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    // the first batch is the wave's own: tiles [wave_id * kBatch, + kBatch); later ones come from the counter, which starts at 0
-    // and stands for "batches handed out beyond the waves' first ones".  Three tiles are known at any time: the current one,
-    // the next (its cuts have landed, its loads go out behind the current tile's interval phase) and the one after (its cuts
-    // are in flight); a draw is issued in the iteration after the one that used up the batch drawn before and has landed
-    // by that iteration's end, which is where the next tile index is taken.
-    int bn = wave_id * kBatch, be = bn + kBatch;
+    // Three quarters of the tiles are dealt out in advance -- wave w takes tiles [w S, (w + 1) S), neighbours in cov[] -- and the
+    // rest comes from a device counter in batches: tile costs differ by what a tile holds and CUs are not equally fast, so
+    // the end of the kernel needs a queue, but returning atomics on ONE word serialise at ~12 ns each (a draw per four
+    // tiles, 2.9e5 of them at human scale, WAS the kernel's duration: 3.7 ms whatever the waves did in between).
+    // Three tiles are known at any time: the current one, the next (its cuts have landed, its loads go out behind the
+    // current tile's interval phase) and the one after (its cuts are in flight); a draw is issued in the iteration after the
+    // one that used up the batch before and has landed by that iteration's end, which is where the next tile index is taken.
+    const int n_static = (int)((long long)n_tiles * 3 / 4 / n_waves);
+    const int dyn0 = n_static * n_waves;
+    int bn = wave_id * n_static, be = bn + n_static;
     int next_base = 0;
     bool want_draw = false;
     auto hand_out = [&]() -> int {
         if (bn == be) { bn = next_base; be = bn + kBatch; want_draw = true; }
         return bn++;
     };
-    auto draw_now = [&]() { draw(); wait_all_loads(); next_base = n_waves * kBatch + uni(drawn); want_draw = false; };
+    auto draw_now = [&]() { draw(); wait_all_loads(); next_base = dyn0 + uni(drawn); want_draw = false; };
+    draw_now();
+    if (bn == be) { bn = next_base; be = bn + kBatch; draw_now(); }
     int k = bn++;
     if (k >= n_tiles) { leave_empty(); return; }
     WaveTile cur, nxt;
-    WaveRegs<U> g;
+    WaveRegs<U> g, gn;
     WaveReadRegs rd, rdn;
     unpack(cut_word(k), cur);
     issue(cur, g, rd);
-    draw_now();
     int kn = hand_out();
     if (want_draw) draw_now();
     int knn = hand_out();
@@ -184,6 +197,14 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
     wait_all_loads();
 
     while (true) {
+        // ---- the next tile's loads go out first: the interval phase below hides their latency
+        const bool have_next = kn < n_tiles;
+        const bool drew = want_draw;
+        unpack(raw_n, nxt);
+        const int raw_nn = cut_word(min(knn, n_tiles - 1));
+        if (want_draw) { draw(); want_draw = false; }
+        if (have_next) issue(nxt, gn, rdn);
+
         const int nr = cur.nr, r_a = cur.r_a;
         const long long a0 = cur.g_lo & ~3LL;
         const int off0 = (int)(cur.g_lo - a0);
@@ -305,13 +326,11 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         }
         lane_cov += covsum;
 
-        // ---- the next tile's loads go out now: the interval registers are free, and the rows below hide their latency
-        const bool have_next = kn < n_tiles;
-        const bool drew = want_draw;
-        unpack(raw_n, nxt);
-        const int raw_nn = cut_word(min(knn, n_tiles - 1));
-        if (want_draw) { draw(); want_draw = false; }
-        if (have_next) issue(nxt, g, rdn);
+        // ---- every load issued so far -- the NEXT tile's among them -- must have landed before this tile's first coverage
+        // store: vmcnt counts loads and stores in one in-order queue, so a wait placed behind the stores would wait for the
+        // stores too (measured: a wave that waited for its loads at the end of the tile spent a third of its time there)
+        wait_all_loads();
+        if (drew) next_base = dyn0 + uni(drawn);
 
         // ---- 2. rows: prefix sum, store, run detection; every row is zeroed once it is read
         int carry = 0;
@@ -320,6 +339,8 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         int nq = 0;
         int32_t *const cov0 = OW == 4 ? a.cov + a0 : nullptr;
         char *const covp0 = OW == 4 ? nullptr : reinterpret_cast<char *>(a.covp) + (D4 ? a0 / 2 : a0 * OW);
+        // (descriptor of this tile's piece of the coverage array: base = the tile's first aligned window, no stride, raw 32-bit data)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(OW == 4 ? (void *)cov0 : (void *)covp0, 0, SLOTS * 4, 0x00020000);
         int pend_p = -1, pend_c = 0;     // D4: this lane's listed window waiting for the end of the rows
         int d4_n = 0;                    // D4: windows of this tile listed so far (wave-uniform)
         auto d4_list = [&](int p, int v, int slot) {
@@ -392,11 +413,11 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 const unsigned c0 = r0 & 0xffffu, c1 = r0 >> 16, c2 = r1 & 0xffffu, c3 = r1 >> 16;
                 if (OW == 4) {
                     int32_t *o = cov0 + p0;
-                    if (full) *reinterpret_cast<int4 *>(o) = make_int4((int)c0, (int)c1, (int)c2, (int)c3);
+                    if (full) __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)c0, (int)c1, (int)c2, (int)c3}, rsrc, p0 * 4, 0, 0);
                     else {
                         const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
                         const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
-                        if (v0 && v3) *reinterpret_cast<int4 *>(o) = make_int4((int)c0, (int)c1, (int)c2, (int)c3);
+                        if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)c0, (int)c1, (int)c2, (int)c3}, rsrc, p0 * 4, 0, 0);
                         else { if (v0) o[0] = (int)c0; if (v1) o[1] = (int)c1; if (v2) o[2] = (int)c2; if (v3) o[3] = (int)c3; }
                     }
                 } else if (OW == 1 || OW == 2) {
@@ -406,11 +427,11 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                     if (OW == 1) {
                         uint8_t *o = reinterpret_cast<uint8_t *>(covp0) + p0;
                         const unsigned pk4 = __builtin_amdgcn_perm(m1, m0, 0x06040200u);
-                        if (full || (v0 && v3)) *reinterpret_cast<unsigned *>(o) = pk4;
+                        if (full || (v0 && v3)) __builtin_amdgcn_raw_buffer_store_b32((int)pk4, rsrc, p0, 0, 0);
                         else { if (v0) o[0] = (uint8_t)pk4; if (v1) o[1] = (uint8_t)(pk4 >> 8); if (v2) o[2] = (uint8_t)(pk4 >> 16); if (v3) o[3] = (uint8_t)(pk4 >> 24); }
                     } else {
                         uint16_t *o = reinterpret_cast<uint16_t *>(covp0) + p0;
-                        if (full || (v0 && v3)) *reinterpret_cast<uint2 *>(o) = make_uint2(m0, m1);
+                        if (full || (v0 && v3)) __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, p0 * 2, 0, 0);
                         else { if (v0) o[0] = (uint16_t)m0; if (v1) o[1] = (uint16_t)(m0 >> 16); if (v2) o[2] = (uint16_t)m1; if (v3) o[3] = (uint16_t)(m1 >> 16); }
                     }
                     if ((c0 | c1 | c2 | c3) >= kLimit) {       // rare by the choice of the width
@@ -468,8 +489,12 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                     }
                 }
             };
+#ifndef RAFT_ABLATE_WAVE_STORE
             store_half(rA0, rA1, pA, dA0, dA1);
             store_half(rB0, rB1, pB, dB0, dB1);
+#else
+            (void)store_half; (void)pA; (void)pB;
+#endif
 
             // ---- run scan: only rows that hold a high window or inherit an open run
             const unsigned xh = (mx + kthr) & 0x80008000u;
@@ -597,10 +622,8 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
 
         // ---- hand over to the next tile
         if (!have_next) break;
-        wait_all_loads();
-        if (drew) next_base = n_waves * kBatch + uni(drawn);
         k = kn; kn = knn; knn = hand_out(); raw_n = raw_nn;
-        cur = nxt; rd = rdn;
+        cur = nxt; rd = rdn; g = gn;
     }
     {
         const long long cs = wave_reduce_add64(lane_cov), rs = wave_reduce_add64(lane_rep);

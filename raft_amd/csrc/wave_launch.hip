@@ -13,13 +13,20 @@ using namespace raft_wave_tu;
 namespace {
 constexpr int kWps = RAFT_WAVE_WPS, kWpb = RAFT_WAVE_WPB;
 // prefetch slots per lane (64 records each) by the number of sorted runs: a HiFi wave tile of ~1700 windows holds ~250 records
-constexpr int kIter = RAFT_WAVE_SLOTS >= 4096 ? 5 : 3;
+constexpr int kIterWin = RAFT_WAVE_SLOTS / 1024 + 1;
+// (coordinate columns: three registers per slot, held twice -- the current tile's and the next one's; what does not fit the
+// slots is fetched synchronously)
+#ifndef RAFT_WAVE_COLS_ITER
+#define RAFT_WAVE_COLS_ITER 3
+#endif
+constexpr int kIterCols = RAFT_WAVE_COLS_ITER < kIterWin ? RAFT_WAVE_COLS_ITER : kIterWin;
 constexpr int kWaveSlots = RAFT_WAVE_SLOTS;
 
 template <int OW, int IN>
 void launch_ow(hipStream_t st, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
     const unsigned grid = (unsigned)(wave_grid_waves() / kWpb);
+    constexpr int kIter = IN == 1 ? kIterWin : kIterCols;
     if (n_seg <= 1)
         hipLaunchKernelGGL((pileup_wave_kernel<kWaveSlots, 1, kIter + 1, OW, IN, kWpb, kWps>), dim3(grid), dim3(64 * kWpb), 0, st, cuts, pa);
     else if (n_seg == 2)

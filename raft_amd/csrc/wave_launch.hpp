@@ -4,10 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #ifndef RAFT_WAVE_SLOTS
-#define RAFT_WAVE_SLOTS 2048      // 16-bit window slots of one wave's LDS array (a multiple of 512)
+#define RAFT_WAVE_SLOTS 4096      // 16-bit window slots of one wave's LDS array (a multiple of 512)
 #endif
 #ifndef RAFT_WAVE_WPS
-#define RAFT_WAVE_WPS 6           // waves per SIMD asked of the register allocator (64 VGPRs at 8)
+#define RAFT_WAVE_WPS 4           // waves per SIMD asked of the register allocator (64 VGPRs at 8)
 #endif
 #ifndef RAFT_WAVE_WPB
 #define RAFT_WAVE_WPB 1           // waves per workgroup (independent of each other: no barrier anywhere)

@@ -1,54 +1,82 @@
-// tools/membench.hip -- what the chip sustains for the pileup kernel's memory shape (diagnostic, not product code):
-//   fill:   persistent 256-thread workgroups, each wave stores rows of 1 KiB (int4 per lane), tile after tile
-//   mixed:  same stores + per tile a coalesced read of 30 % as many bytes (the interval columns)
-// usage: membench <GiB of stores> ; prints GB/s for several workgroups-per-CU counts
+// tools/membench.hip -- what the chip sustains for the pileup pass's memory shape (diagnostic, not product code).
+//
+// Round 4 rewrite (the old tool issued its reads as a dependent chain with a 64-bit modulo per load in front of
+// its stores, and its 10 % swing with the grid shape was never explained).  Now:
+//   * every wave streams its own contiguous piece: per step it STORES `rows` x 1 KiB (int4 per lane, what a pileup wave writes
+//     per row) and LOADS `reads` x 256 B (one dword per lane: the interval columns), the loads of step i+1 issued before the
+//     stores of step i and consumed one step later (prefetched: no load is waited for right after its issue);
+//   * addresses advance by constants (no division, no modulo);
+//   * workgroups of 64 .. 256 threads, 1 .. 8 waves per SIMD, three mixes: store-only, load-only, the int32 pass's mix
+//     (12 B read per 0.147 windows + 4 B per window written: 0.44 B read per B written), the byte pass's mix (1 B per window).
+// usage: membench [GiB of stores]; prints GB/s per configuration (best of 4 launches).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 
-__global__ __launch_bounds__(256) void fill_kernel(int4 *out, long long n_tiles, int rows_per_wave, int mode,
-                                                   const int4 *in, long long in_vec, int *sink)
+template <int RD_PER_ROW_X16>      // loads per 16 stored rows (0: store-only)
+__global__ __launch_bounds__(256) void stream_kernel(int4 *out, const int *in, long long rows_per_wave, long long in_per_wave, int *sink, int do_store)
 {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int4 *o = out + wave * rows_per_wave * 64 + lane;
+    const int *p = in + wave * in_per_wave + lane;
     int acc = 0;
-    for (long long k = blockIdx.x; k < n_tiles; k += gridDim.x) {
-        const long long base = (k * 4 + wid) * rows_per_wave * 64;
-        if (mode == 1) { // read 0.3x the bytes first (3 x int4 per 10 stored), like the interval columns
-            const long long ib = (k * 4 + wid) * (long long)((rows_per_wave * 3 + 9) / 10) * 64;
-            for (int r = 0; r < (rows_per_wave * 3 + 9) / 10; ++r) {
-                const int4 v = in[(ib + r * 64 + lane) % in_vec];
-                acc += v.x + v.y + v.z + v.w;
-            }
+    int nxt[RD_PER_ROW_X16 > 0 ? RD_PER_ROW_X16 : 1];
+#pragma unroll
+    for (int r = 0; r < RD_PER_ROW_X16; ++r) nxt[r] = p[r * 64];
+    p += RD_PER_ROW_X16 * 64;
+    for (long long row = 0; row + 16 <= rows_per_wave; row += 16) {
+        int cur[RD_PER_ROW_X16 > 0 ? RD_PER_ROW_X16 : 1];
+#pragma unroll
+        for (int r = 0; r < RD_PER_ROW_X16; ++r) { cur[r] = nxt[r]; nxt[r] = p[r * 64]; }
+        p += RD_PER_ROW_X16 * 64;
+#pragma unroll
+        for (int r = 0; r < RD_PER_ROW_X16; ++r) acc += cur[r];
+        if (do_store) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(row + r) * 64] = make_int4(acc, r, lane, (int)row);
         }
-        for (int r = 0; r < rows_per_wave; ++r) out[base + r * 64 + lane] = make_int4(acc, r, lane, wid);
     }
     if (acc == 0x7fffffff) *sink = acc;
 }
 
-int main(int argc, char **argv)
+template <int RD>
+static void run(const char *name, int4 *out, int *in, double gib, int *sink, int do_store, double bytes_per_row_read)
 {
-    const double gib = argc > 1 ? atof(argv[1]) : 8.0;
-    const int rows_per_wave = 5;
-    const long long tile_bytes = 4LL * rows_per_wave * 1024;
-    const long long n_tiles = (long long)(gib * (1LL << 30)) / tile_bytes;
-    int4 *out, *in; int *sink;
-    hipMalloc(&out, n_tiles * tile_bytes);
-    const long long in_vec = (3LL << 30) / 16;
-    hipMalloc(&in, in_vec * 16); hipMemset(in, 1, in_vec * 16);
-    hipMalloc(&sink, 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 2; ++mode)
-        for (int bpc : {1, 2, 4, 5, 8}) {
+    for (int threads : {64, 256})
+        for (int wps : {1, 2, 4, 6, 8}) {
+            const long long waves = 256LL * 4 * wps;
+            const long long total_rows = (long long)(gib * (1LL << 30)) / 1024;
+            const long long rows_per_wave = (total_rows / waves) / 16 * 16;
+            const long long in_per_wave = (rows_per_wave / 16 + 1) * (RD > 0 ? RD : 0) * 64;
+            const unsigned grid = (unsigned)(waves / (threads / 64));
             float best = 1e9f;
             for (int it = 0; it < 4; ++it) {
                 hipEventRecord(e0);
-                hipLaunchKernelGGL(fill_kernel, dim3(256 * bpc), dim3(256), 0, 0, out, n_tiles, rows_per_wave, mode, in, in_vec, sink);
+                hipLaunchKernelGGL((stream_kernel<RD>), dim3(grid), dim3(threads), 0, 0, out, in, rows_per_wave, in_per_wave, sink, do_store);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (ms < best) best = ms;
             }
-            const double bytes = (double)n_tiles * tile_bytes * (mode ? 1.3 : 1.0);
-            printf("mode %s  wg/CU %d  %.3f ms  %.0f GB/s\n", mode ? "store+0.3read" : "store", bpc, best, bytes / best / 1e6);
+            const double wr = do_store ? (double)rows_per_wave * waves * 1024 : 0.0;
+            const double rd = (double)(rows_per_wave / 16) * waves * RD * 256;
+            printf("%-28s wg %3d thr  waves/SIMD %d  %.3f ms  written %.2f GB read %.2f GB  %.0f GB/s\n", name, threads, wps, best, wr / 1e9, rd / 1e9,
+                   (wr + rd) / best / 1e6);
         }
+    (void)bytes_per_row_read;
+}
+
+int main(int argc, char **argv)
+{
+    const double gib = argc > 1 ? atof(argv[1]) : 7.4;     // (the int32 pass of the bench set writes 7.9 GB)
+    int4 *out; int *in; int *sink;
+    hipMalloc(&out, (size_t)(gib * (1LL << 30)) + (1 << 20));
+    const size_t in_bytes = (size_t)(gib * (1LL << 30)) / 2 + (64 << 20);
+    hipMalloc(&in, in_bytes); hipMemset(in, 1, in_bytes);
+    hipMalloc(&sink, 4);
+    run<0>("store only (1 KiB rows)", out, in, gib, sink, 1, 0);
+    run<28>("int32 pass mix (0.44 rd/wr)", out, in, gib, sink, 1, 0);      // 28 x 256 B read per 16 KiB written
+    run<16>("load only (256 B rows)", out, in, gib, sink, 0, 0);
     return 0;
 }
