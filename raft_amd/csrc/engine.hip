@@ -523,7 +523,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     bool expand = false;
     const PileVariant &pv = kVariants[c->variant];
     // tiles that do not fit the fast kernel are re-cut for it (pileup.hpp tile_desc_kernel) unless told otherwise
-    const bool wave = pv.fast == 2;                      // one wave per tile (pileup_wave.hpp): every tile is cut by tile_desc_kernel's walk
+    // one wave per tile (pileup_wave.hpp): the workers cut their tiles themselves -- reads longer than a tile in pieces, which is
+    // what `recut` says to the geometry scan and to finalize -- from the boundaries of quantum tiles four times a tile's size
+    const bool wave = pv.fast == 2;
     const bool recut = wave || (pv.fast && !c->no_recut && getenv("RAFT_NO_RECUT") == nullptr);
     // lane-serial rows: variant 4, or RAFT_LANE_SERIAL=1 for every fast configuration of the process (A/B, test sweeps); they
     // take slots outside the tile for not-high, which a threshold below 1 would not give them
@@ -668,7 +670,11 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     // (measured optima, mean windows per read -> room: 600 -> 1.7 k, 1200 -> 2.7 k, 3000 -> 3.9 k of a 7936-window tile).
     int Q = c->tile_q ? std::min(c->tile_q, pv.cap) : pv.cap - pv.short_max;
     // (wave tiles: the quantum only says which thread of tile_desc_kernel walks which reads -- four tiles' worth each)
-    if (wave) Q = c->tile_q ? std::max(256, c->tile_q) : 4 * (pv.cap / 128) * 128;
+    if (wave) {
+        // four tiles' worth, but never so few quantum tiles that workers stay without one (a 50 k-read set)
+        const long long q4 = 4LL * (pv.cap / 128) * 128, q1 = (pv.cap / 128) * 128;
+        Q = c->tile_q ? std::max(256, c->tile_q) : (int)std::max(q1, std::min(q4, (B / (4LL * wave_grid_waves(true))) / 128 * 128));
+    }
     if (!c->tile_q && pv.fast == 1 && N > 0) {
         const double mean_w = (double)B / (double)N;
         const int room = (int)std::min<double>(pv.cap / 2, std::max<double>(1408.0, 600.0 + 1.75 * mean_w));
@@ -693,9 +699,12 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     HIP_TRY(c, c->tile_desc.ensure((size_t)n_tiles * sizeof(TileDesc)));
     // extra tiles (tiles re-cut for the fast kernel: groups of whole reads, pieces of long reads) follow the regular cuts
     long long extra_cap = 0;
+    const bool ow_is_d4 = ow == kCovDelta4;
     if (recut) {
         extra_cap = n_tiles + B / pv.cap + N / 8 + 1024;
-        if (wave) extra_cap = 2 * n_tiles + 2 * (B / pv.cap) + N / 32 + 1024;   // (a group is closed by a full window, 63 reads, a long read or the walker's last read)
+        // (wave tiles are cut by the workers: no list; the number only bounds the tile ids under which a delta4 pass lists windows --
+        // a tile is closed by a full array, 63 reads, a long read or the end of a range; ids are drawn 32 at a time)
+        if (wave) extra_cap = ow_is_d4 ? 2 * n_tiles + 2 * (B / pv.cap) + N / 32 + 32LL * wave_grid_waves(true) + 1024 : 0;
         if (const char *ec = getenv("RAFT_EXTRA_CAP")) extra_cap = std::max(0, atoi(ec));   // (tests: force the overflow fallback)
         if ((n_tiles + 1 + 2 * extra_cap) * 8 >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;   // cut words are indexed with 32 bits
     }
@@ -842,19 +851,13 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     // the detection of a pass that assumes a symmetric PAF: one more boundary search of this kernel (pileup.hpp MirrorArgs)
     MirrorArgs mir{};
     if (spec && c->prm.symmetric_mode < 0 && fast) mir = {d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp.sym_found};
-    // (every tile re-cut and the bounds to be searched in the record stream itself: the searches get threads of their own)
-    const bool defer_bounds = wave && n_rec > 0 && !grouped && c->sum.interval_path == 0;
     hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 2 + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
                        pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>(),
-                       pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, wave ? -1 : pv.cap, wave ? kWaveMaxReads : kFastMaxReads,
+                       pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, wave ? INT32_MAX : pv.cap, wave ? INT32_MAX : kFastMaxReads,
                        pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow,
                        (fast && table_ok) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
                        c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags,
-                       recut ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp, pv.cap,
-                       defer_bounds ? 1 : 0);
-    if (defer_bounds)
-        hipLaunchKernelGGL(cut_bounds_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>((extra_cap / 2 + 255) / 256, 256 * 16))), dim3(256), 0, st,
-                           &ctrl->n_extra, c->tile_cuts.as<TileCut>() + (n_tiles + 1), c->tile_cuts.as<TileCut>(), pa.iv_rid, pa.n_seg, &ctrl->err_flags);
+                       (recut && !wave) ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp, pv.cap, 0);
     pa.n_extra = recut ? &ctrl->n_extra : nullptr;
     pa.piece_w = pv.cap;
 
@@ -875,13 +878,13 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     if (wave) {
         // ONE launch, no second stream: a persistent grid of single-wave workers, each drawing wave tiles from the list
         // tile_desc_kernel cut (its length is known on the device only: workers without a tile leave at once)
-        const int n_waves = wave_grid_waves();
-        // (a quarter of the tiles is handed out dynamically, in batches of up to eight: pileup_wave.hpp)
-        const long long est_tiles = B / std::max(1, (pv.cap * 3) / 4) + 1;
-        pa.tile_batch = (int32_t)std::max<long long>(1, std::min<long long>(8, est_tiles / (16LL * n_waves)));
+        const int n_waves = (int)std::max<long long>(1, std::min<long long>(wave_grid_waves(lean), n_tiles));
+        // (a quarter of the quantum tiles -- four wave tiles each -- is handed out dynamically, up to two per draw: pileup_wave.hpp)
+        pa.tile_batch = (int32_t)std::max<long long>(1, std::min<long long>(2, n_tiles / (16LL * n_waves)));
         if (const char *e = getenv("RAFT_WAVE_BATCH")) pa.tile_batch = std::max(1, atoi(e));
-        pa.n_extra = &ctrl->n_extra;
-        launch_wave_variant(ow, lean, st, pa.n_seg, c->tile_cuts.p, &pa);
+        pa.n_extra = nullptr;
+        pa.piece_w = (int32_t)std::min<long long>(extra_cap, INT32_MAX);    // (delta4: tile ids below this have slots of their own)
+        launch_wave_variant(ow, lean, st, pa.n_seg, c->tile_cuts.p, &pa, n_waves);
         n_sum_blocks = (unsigned)n_waves;
     } else if (pv.fast) {
         const TileCut *cuts = c->tile_cuts.as<TileCut>();

@@ -98,8 +98,8 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
     // (every worker owns two words of the sums totals_kernel adds up: also the ones that leave without a tile)
     auto leave_empty = [&]() { if (lane == 0) { a.block_sums[2 * (long long)wave_id] = 0; a.block_sums[2 * (long long)wave_id + 1] = 0; } };
     if (uni(*(volatile int32_t *)a.err_flags) & (kErrExtra | kErrStop)) { leave_empty(); return; }
-    const int n_reg = (int)a.n_tiles;
-    const int n_tiles = uni(*a.n_extra);
+    const int n_seg_tiles = (int)a.n_tiles;      // segments (quantum tiles) tile_desc_kernel cut: boundaries cuts[0 .. n_seg_tiles]
+    constexpr int CAP = SLOTS - 4;               // windows of a tile: 3 alignment slots + CAP + 1 sentinel
     const unsigned win_m1 = a.div_shift < 0 ? ~0u : 0u;
     const int win_sh = a.div_shift < 0 ? 0 : a.div_shift;
     constexpr unsigned kLimit = OW == 1 ? 255u : 65535u;
@@ -111,106 +111,229 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
     for (int i = lane; i < SLOTS / 2; i += 64) sm.diff[i] = kZero;
     long long lane_cov = 0, lane_rep = 0;
 
+    // ---- A worker STREAMS through contiguous ranges of reads and cuts its tiles itself (round 4, second version).
+    // The first version walked a list of tiles tile_desc_kernel had cut in advance -- a sequential walk per quantum tile plus,
+    // for six-column input, four bisections of the record stream per tile: 0.3 ms at human scale, and 80 MB of cut records
+    // written and read back.  None of that is needed: a range begins at a boundary tile_desc_kernel found anyway (first read,
+    // first record of every run, first window); from there the NEXT tile is the longest run of whole reads whose windows fit the
+    // LDS array (a ballot over the reads' offsets, which the worker loads for its per-read table in any case) and its records
+    // are the ones whose read id is below the tile's last read -- a ballot over the record slots that have already landed,
+    // since they are what the tile's interval phase is about to consume.  A read longer than the array is taken in pieces;
+    // a tile with more records than slots finds its end with two 64-way probes of the id column.
     const int32_t *cut_words = reinterpret_cast<const int32_t *>(cuts);
-    auto cut_word = [&](int t) -> int {          // dword `lane` of the tile's (begin, end) pair
-        const unsigned idx = (unsigned)(n_reg + 1 + 2 * t) * 8u + (unsigned)lane;
-        return lane < 16 ? cut_words[idx] : 0;
-    };
-    auto unpack = [&](int raw, WaveTile &t) {
-        auto d = [&](int i) -> int { return __builtin_amdgcn_readlane(raw, i); };
-        t.r_a = d(0); t.nr = d(8) - t.r_a; t.piece = d(1) & kCutPiece;
-        t.g_lo = (long long)(((unsigned long long)(unsigned)d(7) << 32) | (unsigned)d(6));
-        t.nwin = d(14) - d(6);
-        t.more = 0; t.n_total = 0;
+    struct Start { int r, q; int pos[NSEG]; long long g; };   // a tile's first read, piece index, first record of every run, first window of the READ
+    int R_end = 0, pend[NSEG];                    // the current range: one past its last read, one past its last record of every run
 #pragma unroll
-        for (int s = 0; s < NSEG; ++s) {
-            t.lo[s] = d(2 + s); t.cnt[s] = d(10 + s) - t.lo[s];
-            t.n_total += t.cnt[s];
-            if (t.cnt[s] > ITER * 64) t.more = 1;
-        }
+    for (int s = 0; s < NSEG; ++s) pend[s] = 0;
+    auto load_range = [&](int k0, int k1, Start &t) {   // synchronous: once per range
+        const int w0 = lane < 8 ? cut_words[(unsigned)k0 * 8u + (unsigned)lane] : 0;
+        const int w1 = lane < 8 ? cut_words[(unsigned)k1 * 8u + (unsigned)lane] : 0;
+        wait_all_loads();
+        t.r = __builtin_amdgcn_readlane(w0, 0); t.q = 0;
+        t.g = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(w0, 7) << 32) | (unsigned)__builtin_amdgcn_readlane(w0, 6));
+        R_end = __builtin_amdgcn_readlane(w1, 0);
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) { t.pos[s] = __builtin_amdgcn_readlane(w0, 2 + s); pend[s] = __builtin_amdgcn_readlane(w1, 2 + s); }
     };
-    // loads of one tile: three (+ NSEG for window records) per read, lanes 0 .. nr; U interval slots
-    auto issue = [&](const WaveTile &t, WaveRegs<U> &g, WaveReadRegs &rd) {
+    // loads of the tile that begins at `t`: the per-read table (64 reads from t.r on) and U record slots from t.pos on
+    auto issue = [&](const Start &t, WaveRegs<U> &g, WaveReadRegs &rd) {
         rd.cv = 0; rd.rr = 0; rd.rl = 0; rd.so[0] = 0; rd.so[1] = 0;
-        if (lane <= t.nr) {
-            rd.cv = reinterpret_cast<const int32_t *>(a.cov_off + t.r_a)[2 * lane];
-            rd.rr = reinterpret_cast<const int32_t *>(a.rep_res_off + t.r_a)[2 * lane];
+        const int idx = t.r + lane;
+        if (idx <= a.n_reads) {
+            rd.cv = reinterpret_cast<const int32_t *>(a.cov_off + t.r)[2 * lane];
+            rd.rr = reinterpret_cast<const int32_t *>(a.rep_res_off + t.r)[2 * lane];
             if (IN == 1) {
 #pragma unroll
-                for (int s = 0; s < NSEG; ++s) rd.so[s] = reinterpret_cast<const int32_t *>(a.grp.off + s * a.grp.stride + t.r_a)[2 * lane];
+                for (int s = 0; s < NSEG; ++s) rd.so[s] = reinterpret_cast<const int32_t *>(a.grp.off + s * a.grp.stride + t.r)[2 * lane];
             }
         }
-        if (lane < t.nr) rd.rl = a.read_len[t.r_a + lane];
+        if (idx < a.n_reads) rd.rl = a.read_len[idx];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int s = u % NSEG, first = (u / NSEG) * 64;
+            const long long at = (long long)t.pos[s] + first + lane;
             if (IN == 1) {
                 g.st[u] = 0;
-                if (lane < t.cnt[s] - first) g.st[u] = (int)a.iv_w[(long long)t.lo[s] + first + lane];
+                if (at < pend[s]) g.st[u] = (int)a.iv_w[at];
             } else {
-                g.rid[u] = t.r_a; g.st[u] = 0; g.en[u] = 0;       // an empty slot is an empty interval of the tile's first read
-                if (lane < t.cnt[s] - first) {
-                    const long long at = (long long)t.lo[s] + first + lane;
-                    g.rid[u] = a.iv_rid[at]; g.st[u] = a.iv_s[at]; g.en[u] = a.iv_e[at];
-                }
+                g.rid[u] = 0x7fffffff; g.st[u] = 0; g.en[u] = 0;
+                if (at < pend[s]) { g.rid[u] = a.iv_rid[at]; g.st[u] = a.iv_s[at]; g.en[u] = a.iv_e[at]; }
             }
         }
     };
 
-    // tiles are drawn in batches from a device counter (tile costs differ by what the tile holds; CUs are not equally fast)
+    // Ranges: three quarters of the segments are dealt out in advance -- worker w takes segments [w S, (w + 1) S) as ONE range,
+    // neighbours in cov[] -- and the rest comes from a device counter, kBatch segments per draw (tile costs differ by what a
+    // tile holds and CUs are not equally fast, so the end of the kernel needs a queue; but returning atomics on ONE word
+    // serialise at ~12 ns each: a draw per four tiles, 2.9e5 of them at human scale, WAS the first version's duration).
     const int kBatch = max(1, a.tile_batch);
     typedef __attribute__((address_space(1))) int32_t *global_i32_ptr;
     global_i32_ptr draw_from = (global_i32_ptr)a.tile_counter;
     asm volatile("" : "+v"(draw_from));
-    int drawn = 0;
-    auto draw = [&]() { if (lane == 0) drawn = __hip_atomic_fetch_add(draw_from, kBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    // Three quarters of the tiles are dealt out in advance -- wave w takes tiles [w S, (w + 1) S), neighbours in cov[] -- and the
-    // rest comes from a device counter in batches: tile costs differ by what a tile holds and CUs are not equally fast, so
-    // the end of the kernel needs a queue, but returning atomics on ONE word serialise at ~12 ns each (a draw per four
-    // tiles, 2.9e5 of them at human scale, WAS the kernel's duration: 3.7 ms whatever the waves did in between).
-    // Three tiles are known at any time: the current one, the next (its cuts have landed, its loads go out behind the
-    // current tile's interval phase) and the one after (its cuts are in flight); a draw is issued in the iteration after the
-    // one that used up the batch before and has landed by that iteration's end, which is where the next tile index is taken.
-    const int n_static = (int)((long long)n_tiles * 3 / 4 / n_waves);
-    const int dyn0 = n_static * n_waves;
-    int bn = wave_id * n_static, be = bn + n_static;
-    int next_base = 0;
-    bool want_draw = false;
-    auto hand_out = [&]() -> int {
-        if (bn == be) { bn = next_base; be = bn + kBatch; want_draw = true; }
-        return bn++;
+    // (few segments: one each, the rest from the counter)
+    int n_static = (int)((long long)n_seg_tiles * 3 / 4 / n_waves);
+    int dyn0 = n_static * n_waves;
+    if (n_static == 0) { dyn0 = min(n_waves, n_seg_tiles); n_static = wave_id < n_seg_tiles ? 1 : 0; }
+    bool static_left = n_static > 0;
+    auto next_range = [&](Start &t) -> bool {     // synchronous (a draw, two boundary records): a few times per worker
+        for (;;) {
+            int k0, k1;
+            if (static_left) { static_left = false; k0 = wave_id * n_static; k1 = k0 + n_static; }
+            else {
+                int drawn = 0;
+                if (lane == 0) drawn = __hip_atomic_fetch_add(draw_from, kBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wait_all_loads();
+                k0 = dyn0 + uni(drawn);
+                if (k0 >= n_seg_tiles) return false;
+                k1 = min(k0 + kBatch, n_seg_tiles);
+            }
+            load_range(k0, k1, t);
+            bool left = false;                   // (a range without reads must not own records: they would be walked by nobody)
+#pragma unroll
+            for (int s = 0; s < NSEG; ++s) left |= t.pos[s] != pend[s];
+            if (t.r < R_end) return true;
+            if (left && lane == 0) atomicOr(a.err_flags, kErrOrder);
+        }
     };
-    auto draw_now = [&]() { draw(); wait_all_loads(); next_base = dyn0 + uni(drawn); want_draw = false; };
-    draw_now();
-    if (bn == be) { bn = next_base; be = bn + kBatch; draw_now(); }
-    int k = bn++;
-    if (k >= n_tiles) { leave_empty(); return; }
-    WaveTile cur, nxt;
+    // delta4: a tile's listed windows go to slots of its own, named by a tile id; ids come in blocks of 32 from a second counter
+    int d4_id = 0, d4_id_end = 0;
+    auto next_d4_id = [&]() -> int {
+        if (d4_id == d4_id_end) {
+            int drawn = 0;
+            if (lane == 0) drawn = atomicAdd(a.slow_counter, 32);
+            d4_id = uni(drawn); d4_id_end = d4_id + 32;
+        }
+        return d4_id++;
+    };
+    (void)next_d4_id;
+
+    Start ts, nts;
+    if (!next_range(ts)) { leave_empty(); return; }
+    WaveTile cur;
     WaveRegs<U> g, gn;
     WaveReadRegs rd, rdn;
-    unpack(cut_word(k), cur);
-    issue(cur, g, rd);
-    int kn = hand_out();
-    if (want_draw) draw_now();
-    int knn = hand_out();
-    int raw_n = cut_word(min(kn, n_tiles - 1));
+    issue(ts, g, rd);
     wait_all_loads();
 
     while (true) {
+        // ---- the current tile: its loads have landed.  Which reads fit?  (the reads' first windows are non-decreasing and so is
+        // "belongs to this range": the ballot is a prefix of the lanes, lane 0 -- the tile's first read -- always in it)
+        const int cv0 = uni(rd.cv);
+        const int rel = rd.cv - cv0;
+        const unsigned long long okm = __ballot(ts.r + lane <= R_end && (unsigned)rel <= (unsigned)CAP);
+        int nr = (int)__popcll(okm) - 1;
+        int piece = 0, n_pieces = 1, nb_read = 0;
+        cur.r_a = ts.r;
+        if (nr <= 0) {                           // the first read alone is longer than the array: this tile is piece ts.q of it
+            nb_read = __builtin_amdgcn_readlane(rel, 1);
+            n_pieces = (nb_read + CAP - 1) / CAP;
+            piece = kCutPiece; nr = 1;
+            cur.nwin = min(nb_read - ts.q * CAP, CAP);
+            cur.g_lo = ts.g + (long long)ts.q * CAP;
+        } else {
+            cur.nwin = __builtin_amdgcn_readlane(rel, nr);
+            cur.g_lo = ts.g;
+        }
+        // ... and which records are theirs?  The ids are sorted inside a run, so "id below the tile's last read" is a prefix of
+        // the slots' lanes; a slot that is full and all of the tile's passes the question on to the next one.  A run whose
+        // slots are ALL the tile's (the tile has more records than slots) shrinks the tile to the reads that are complete in the
+        // slots -- dense stretches get smaller tiles instead of a wait for more records -- unless that leaves no read at all:
+        // then the end is found with two 64-way probes of the id column and the records behind the slots are streamed.
+        int r_b = ts.r + nr;
+        bool open_run[NSEG];
+        auto count_run = [&](int s2, int rb) -> int {      // records of run s2 in the slots whose id is below rb; open_run: all of them and more to come
+            const int avail = pend[s2] - ts.pos[s2];
+            int c = 0;
+            bool open = true;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int L = min(max(avail - 64 * it, 0), 64);
+                if (open) {
+                    const int n = (int)__popcll(__ballot(lane < L && g.rid[it * NSEG + s2] < rb));
+                    c += n;
+                    if (n < 64) open = false;
+                }
+            }
+            open_run[s2] = open && avail > 64 * ITER;
+            return c;
+        };
+        cur.more = 0; cur.n_total = 0;
+        if constexpr (IN == 0) {
+            int rb_fit = r_b;
+#pragma unroll
+            for (int s = 0; s < NSEG; ++s) {
+                cur.cnt[s] = count_run(s, r_b);
+                if (open_run[s]) rb_fit = min(rb_fit, __builtin_amdgcn_readlane(g.rid[(ITER - 1) * NSEG + s], 63));
+            }
+            if (rb_fit < r_b && rb_fit > ts.r && !piece) {   // fewer reads, all of whose records are in the slots
+                nr = rb_fit - ts.r; r_b = rb_fit;
+                cur.nwin = __builtin_amdgcn_readlane(rel, nr);
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) cur.cnt[s] = count_run(s, r_b);
+            }
+        }
+        cur.nr = nr; cur.piece = piece;
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+            cur.lo[s] = ts.pos[s];
+            const int avail = pend[s] - ts.pos[s];
+            int c = 0;
+            if constexpr (IN == 1) {
+                c = __builtin_amdgcn_readlane(rd.so[s], nr) - __builtin_amdgcn_readlane(rd.so[s], 0);
+                c = min(max(c, 0), avail);       // (offsets that disagree with the range: the order check below refutes the pass)
+            } else {
+                c = cur.cnt[s];
+                if (open_run[s]) {
+                    // every slot is the tile's and the run goes on: the end lies further on
+                    int base = ts.pos[s] + 64 * ITER;                         // (ids before `base` are below r_b)
+                    for (;;) {
+                        const long long pj = (long long)base + 64LL * lane;
+                        const int v = pj < pend[s] ? a.iv_rid[pj] : 0x7fffffff;
+                        const int t = (int)__popcll(__ballot(v < r_b));
+                        if (t == 64) { base += 64 * 63 + 1; continue; }       // (the last probe, too, is the tile's)
+                        int e = base;
+                        if (t > 0) {
+                            const long long p2 = (long long)base + 64LL * (t - 1) + 1 + lane;
+                            const int v2 = p2 < pend[s] ? a.iv_rid[p2] : 0x7fffffff;
+                            e = base + 64 * (t - 1) + 1 + (int)__popcll(__ballot(v2 < r_b));
+                        }
+                        c = e - ts.pos[s];
+                        break;
+                    }
+                }
+            }
+            cur.cnt[s] = c;
+            cur.n_total += c;
+            if (c > 64 * ITER) cur.more = 1;
+        }
+        // ---- where the next tile begins; the end of the range
+        const bool last_piece = !piece || ts.q + 1 == n_pieces;
+        bool have_next = true;
+        if (!last_piece) { nts = ts; nts.q = ts.q + 1; }
+        else {
+            nts.r = r_b; nts.q = 0; nts.g = ts.g + (piece ? nb_read : cur.nwin);
+#pragma unroll
+            for (int s = 0; s < NSEG; ++s) nts.pos[s] = ts.pos[s] + cur.cnt[s];
+            if (r_b == R_end) {
+                // the range is done: every record of it has been handed to a tile, or the stream is not what the pass assumed
+                bool left = false;
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) left |= nts.pos[s] != pend[s];
+                if (left && lane == 0) atomicOr(a.err_flags, kErrOrder);
+                have_next = next_range(nts);
+            }
+        }
         // ---- the next tile's loads go out first: the interval phase below hides their latency
-        const bool have_next = kn < n_tiles;
-        const bool drew = want_draw;
-        unpack(raw_n, nxt);
-        const int raw_nn = cut_word(min(knn, n_tiles - 1));
-        if (want_draw) { draw(); want_draw = false; }
-        if (have_next) issue(nxt, gn, rdn);
+        if (have_next) issue(nts, gn, rdn);
+        int tile_id = 0;
+        if (D4) tile_id = next_d4_id();
+        (void)tile_id;
 
-        const int nr = cur.nr, r_a = cur.r_a;
+        const int r_a = cur.r_a;
         const long long a0 = cur.g_lo & ~3LL;
         const int off0 = (int)(cur.g_lo - a0);
         const int t_end = off0 + cur.nwin;
         const int rows = (t_end + 1 + 511) >> 9;
-        const int piece = cur.piece;
         if (cur.n_total >= 32768) { if (lane == 0) atomicOr(a.err_flags, kErrDeep); }
         // ---- per-read table of this tile
         const int ro = rd.cv - (int)a0;                     // 32-bit wrap-around is exact
@@ -229,28 +352,39 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         };
         if constexpr (IN == 0) {
             auto win = [&](unsigned n) -> int { return (int)(((n & win_m1) | __umulhi(n, a.div_magic)) >> win_sh); };
-            auto one = [&](int rid, int st, int en) {
+            // (`mine`: the slot's lane holds a record of this tile -- the lanes behind the tile's count hold the next tile's)
+            auto one = [&](int rid, int st, int en, bool mine) {
                 const unsigned jr = (unsigned)(rid - r_a);
                 const unsigned j = min(jr, (unsigned)nr);
                 const int b0 = sm.roff[j], nb_r = sm.roff[(j + 1u) & 63u] - b0;
                 const int first = win((unsigned)st);
                 const int last1 = win((unsigned)(en - 1)) + 1;
-                const bool valid = jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
+                const bool valid = mine && jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
                 const bool over = last1 > first && last1 > nb_r;
                 const int pf = max(b0 + first, off0), pl1 = min(b0 + min(last1, nb_r), t_end);
                 bad_any |= valid && (!sign_ok || (pos && over));
-                bad_order |= !valid;
+                bad_order |= mine && !valid;
                 if (valid && sign_ok && pos && pf < pl1) add_pm(pf, pl1);
             };
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (u < NSEG || cur.cnt[u % NSEG] > (u / NSEG) * 64) one(g.rid[u], g.st[u], g.en[u]);
+                const int left = cur.cnt[u % NSEG] - (u / NSEG) * 64;
+                if (left > 0) one(g.rid[u], g.st[u], g.en[u], lane < left);
             }
-            if (cur.more) {
+            if (cur.more) {                      // records beyond the slots: streamed, the next 64 in flight while these are piled up
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) {
                     const long long base = (long long)cur.lo[s];
-                    for (int i = ITER * 64 + lane; i < cur.cnt[s]; i += 64) one((a.iv_rid + base)[i], (a.iv_s + base)[i], (a.iv_e + base)[i]);
+                    int i0 = ITER * 64;
+                    int rA = 0, sA = 0, eA = 0;
+                    if (i0 + lane < cur.cnt[s]) { rA = (a.iv_rid + base)[i0 + lane]; sA = (a.iv_s + base)[i0 + lane]; eA = (a.iv_e + base)[i0 + lane]; }
+                    while (i0 < cur.cnt[s]) {
+                        const int i1 = i0 + 64;
+                        int rB = 0, sB = 0, eB = 0;
+                        if (i1 + lane < cur.cnt[s]) { rB = (a.iv_rid + base)[i1 + lane]; sB = (a.iv_s + base)[i1 + lane]; eB = (a.iv_e + base)[i1 + lane]; }
+                        one(rA, sA, eA, i0 + lane < cur.cnt[s]);
+                        rA = rB; sA = sB; eA = eB; i0 = i1;
+                    }
                 }
             }
             if (__ballot(bad_order) != 0ull && lane == 0) atomicOr(a.err_flags, kErrOrder);
@@ -295,16 +429,20 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int s = u % NSEG, i0 = (u / NSEG) * 64;
-                if (cur.cnt[s] > i0) one_w(read_of(s, i0, i0 + lane), (unsigned)g.st[u]);
+                // (the lanes behind the tile's count hold the next tile's records: an empty word piles nothing up)
+                if (cur.cnt[s] > i0) one_w(read_of(s, i0, i0 + lane), i0 + lane < cur.cnt[s] ? (unsigned)g.st[u] : 0u);
             }
-            if (cur.more) {
+            if (cur.more) {                      // records beyond the slots: streamed, the next 64 in flight while these are piled up
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) {
                     const long long base = (long long)cur.lo[s];
-                    for (int i0 = ITER * 64; i0 < cur.cnt[s]; i0 += 64) {
-                        const int i = i0 + lane;
-                        const int j = read_of(s, i0, i);
-                        if (i < cur.cnt[s]) one_w(j, (a.iv_w + base)[i]);
+                    int i0 = ITER * 64;
+                    unsigned wA = i0 + lane < cur.cnt[s] ? (a.iv_w + base)[i0 + lane] : 0u;
+                    while (i0 < cur.cnt[s]) {
+                        const int i1 = i0 + 64;
+                        const unsigned wB = i1 + lane < cur.cnt[s] ? (a.iv_w + base)[i1 + lane] : 0u;
+                        one_w(read_of(s, i0, i0 + lane), wA);
+                        wA = wB; i0 = i1;
                     }
                 }
             }
@@ -330,7 +468,6 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         // store: vmcnt counts loads and stores in one in-order queue, so a wait placed behind the stores would wait for the
         // stores too (measured: a wave that waited for its loads at the end of the tile spent a third of its time there)
         wait_all_loads();
-        if (drew) next_base = dyn0 + uni(drawn);
 
         // ---- 2. rows: prefix sum, store, run detection; every row is zeroed once it is read
         int carry = 0;
@@ -344,8 +481,8 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         int pend_p = -1, pend_c = 0;     // D4: this lane's listed window waiting for the end of the rows
         int d4_n = 0;                    // D4: windows of this tile listed so far (wave-uniform)
         auto d4_list = [&](int p, int v, int slot) {
-            if (slot < kExcPerTile) {
-                const long long at = (long long)(n_reg + k) * kExcPerTile + slot;
+            if (slot < kExcPerTile && tile_id < a.piece_w) {
+                const long long at = (long long)tile_id * kExcPerTile + slot;
                 a.exc_pidx[at] = a0 + p; a.exc_pval[at] = v;
             } else note_exception(a, a0 + p, v);
         };
@@ -570,7 +707,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 if (pend_p >= 0) d4_list(pend_p, pend_c, d4_n + (int)__popcll(pm & ((1ull << lane) - 1ull)));
                 d4_n += (int)__popcll(pm);
             }
-            if (d4_n && lane == 0) a.exc_tile_n[n_reg + k] = min(d4_n, kExcPerTile);
+            if (d4_n && lane == 0 && tile_id < a.piece_w) a.exc_tile_n[tile_id] = min(d4_n, kExcPerTile);
         }
         // ---- 3. every parked run becomes a raw repeat record, one lane per run
         if (nq > 0) {
@@ -622,8 +759,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
 
         // ---- hand over to the next tile
         if (!have_next) break;
-        k = kn; kn = knn; knn = hand_out(); raw_n = raw_nn;
-        cur = nxt; rd = rdn; g = gn;
+        ts = nts; rd = rdn; g = gn;
     }
     {
         const long long cs = wave_reduce_add64(lane_cov), rs = wave_reduce_add64(lane_rep);
