@@ -206,50 +206,66 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
             # decoded on the host (raft_host_unpack_coverage_d4) and compared with the byte encoding of the same windows, outside the clock
             # (in slices of 2^28 windows -- blocks of 1024 decode independently -- so that the check needs 1 GB, not the 8 of the int32 array)
             lim8 = 255 if width == 1 else 65535
-            xi = dres["exc_index"]
-            for a in range(0, ds.n_bins, 1 << 28):
-                b = min(ds.n_bins, a + (1 << 28))
-                x0, x1 = np.searchsorted(xi, [a, b])
-                dec = hostio.unpack_coverage_d4(b - a, dres["cov_nib"][a // 2:(b + 1) // 2], dres["cov_anchor"][a // 1024:(b + 1023) // 1024],
-                                                xi[x0:x1] - a, dres["exc_value"][x0:x1])
-                same_d = same_d and bool(np.array_equal(np.minimum(dec, lim8).astype(pcopy["cov8"].dtype), pcopy["cov8"][a:b]))
-                del dec
+
+            def d4_equals_bytes(r4, n_bins):
+                ok, xi = True, r4["exc_index"]
+                for a in range(0, n_bins, 1 << 28):
+                    b = min(n_bins, a + (1 << 28))
+                    x0, x1 = np.searchsorted(xi, [a, b])
+                    dec = hostio.unpack_coverage_d4(b - a, r4["cov_nib"][a // 2:(b + 1) // 2], r4["cov_anchor"][a // 1024:(b + 1023) // 1024],
+                                                    xi[x0:x1] - a, r4["exc_value"][x0:x1])
+                    ok = ok and bool(np.array_equal(np.minimum(dec, lim8).astype(pcopy["cov8"].dtype), pcopy["cov8"][a:b]))
+                    del dec
+                return ok
+            same_d = same_d and d4_equals_bytes(dres, ds.n_bins)
             wrec["delta4"] = {"records_per_s": o.n_rec / dsec, "fragments_per_s": ds.n_fragments / dsec, "seconds": dsec, "first_pass_s": dtimes[0],
                               "d2h_bytes": int(sum(dres[k].nbytes for k in dres)), "listed_windows": int(dres["exc_index"].size),
                               "decoded_equals_byte_encoding": bool(same_d),
                               "mode": "raft_hip_run_multi_windows, cov_width = RAFT_HIP_COV_DELTA4: coverage comes back as four bits per window"}
             # (a3) SURVEY.md §8(d)'s boundary, nothing prepared: the clock starts with the page-locked int32 columns (read_len, qid, qs, qe)
-            # and the tokeniser's symmetric flag, and ends with every output on the host.  The grouped form (raft_host_group_offsets)
-            # and the window records (raft_host_pack_windows) are derived INSIDE the clock, into page-locked buffers the caller keeps
-            # from job to job (allocated before the clock, like the output buffers).
+            # and the tokeniser's symmetric flag, and ends with every output on the host -- ONE call, raft_hip_run_pipelined on the
+            # plain columns: the engine's lanes derive every chunk's offsets and window records themselves (engine.hip derive_piece:
+            # host threads, into page-locked staging the context keeps) while earlier chunks travel, so 4 bytes per record cross the
+            # link and nothing about the stream has to be handed over.
+            stimes = []
+            for it in range(n_iter + 2):
+                t0 = time.perf_counter()
+                sres, ss = eng.run_pipelined(host[0], host[1], host[2], host[3], out=out4)
+                stimes.append(time.perf_counter() - t0)
+            ssec = sorted(stimes[2:])[len(stimes[2:]) // 2]
+            # (its chunks are cut elsewhere, so the encoding differs from the prepared-input one where chunks begin: compared decoded)
+            same_s = (ss.n_bins, ss.n_repeats, ss.n_fragments, ss.total_coverage, ss.total_repeat_length) == psum and \
+                all(np.array_equal(pcopy[k], sres[k]) for k in pcopy if k != "cov8") and d4_equals_bytes(sres, ss.n_bins)
+            # ... and the same boundary with the two derivations as calls of the host library in front of the engine (round 4's first form)
             off_buf = torch.empty(4 * (o.n_reads + 1), dtype=torch.int64, pin_memory=True).numpy()
-            stimes, prep = [], []
-            for it in range(n_iter + 1):
+            xt = []
+            for it in range(2):
                 t0 = time.perf_counter()
                 off_s = hostio.group_offsets(o.n_reads, host[1], max_runs=4, out=off_buf)
                 t1 = time.perf_counter()
                 win_s = hostio.pack_windows(host[2], host[3], p.reso, out=wbuf)
                 t2 = time.perf_counter()
-                sres, ss = eng.run_pipelined_windows(host[0], off_s, win_s, out=out4)
+                eng.run_pipelined_windows(host[0], off_s, win_s, out=out4)
                 t3 = time.perf_counter()
-                stimes.append(t3 - t0); prep.append((t1 - t0, t2 - t1, t3 - t2))
-            ssec = sorted(stimes[1:])[len(stimes[1:]) // 2]
-            pm = prep[1 + stimes[1:].index(ssec)]
-            same_s = (ss.n_bins, ss.n_repeats, ss.n_fragments, ss.total_coverage, ss.total_repeat_length) == psum and \
-                all(np.array_equal(pcopy[k], sres[k]) for k in pcopy if k != "cov8") and np.array_equal(sres["exc_index"], dres["exc_index"]) and \
-                np.array_equal(sres["cov_nib"], dres["cov_nib"])
+                xt.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+            xm = min(xt)
             wrec["from_soa"] = {"records_per_s": o.n_rec / ssec, "fragments_per_s": ss.n_fragments / ssec, "seconds": ssec, "first_pass_s": stimes[0],
-                                "group_offsets_s": pm[0], "pack_windows_s": pm[1], "engine_s": pm[2], "equals_prepared_input": bool(same_s),
+                                "equals_prepared_input": bool(same_s), "h2d_bytes": host[0].nbytes + 8 * 2 * (o.n_reads + 1) + 4 * o.n_rec,
+                                "explicit_host_calls": {"seconds": xm[0], "group_offsets_s": xm[1], "pack_windows_s": xm[2], "engine_s": xm[3]},
                                 "boundary": "page-locked int32 columns (read_len, qid, qs, qe) + the tokeniser's symmetric flag in; repeats, fragments and "
-                                            "coverage (four-bit steps) in page-locked host memory out; raft_host_group_offsets and raft_host_pack_windows "
-                                            "inside the clock, writing page-locked buffers allocated before it"}
+                                            "coverage (four-bit steps) in page-locked host memory out; ONE call (raft_hip_run_pipelined): per-read record "
+                                            "offsets and window records are derived by the engine's lanes chunk by chunk, inside the clock"}
             del out4, dres, sres
     # (b) chunked, six-column input (query column uploaded, runs guessed from samples, cuts searched)
     ctimes = []
-    for it in range(n_iter):
-        t0 = time.perf_counter()
-        cres, cs = eng.run_pipelined(host[0], host[1], host[2], host[3], out=out)
-        ctimes.append(time.perf_counter() - t0)
+    os.environ["RAFT_NO_DERIVE"] = "1"         # (the columns as they are: what rounds 1-3 uploaded; the derived form is `from_soa` above)
+    try:
+        for it in range(n_iter):
+            t0 = time.perf_counter()
+            cres, cs = eng.run_pipelined(host[0], host[1], host[2], host[3], out=out)
+            ctimes.append(time.perf_counter() - t0)
+    finally:
+        del os.environ["RAFT_NO_DERIVE"]
     same_c = psum == (cs.n_bins, cs.n_repeats, cs.n_fragments, cs.total_coverage, cs.total_repeat_length) and \
         all(np.array_equal(pcopy[k], cres[k]) for k in pcopy)
     # (c) one piece: H2D, pass, D2H one after the other (raft_hip_run_host_grouped + raft_hip_fetch_packed)
@@ -282,7 +298,7 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
             "mode": "chunked, grouped input: H2D / pass / D2H of consecutive read ranges overlapped (raft_hip_run_multi_grouped); "
                     "no query column crosses PCIe",
             "six_column_input": {"records_per_s": o.n_rec / six, "seconds": six, "h2d_bytes": sum(a.nbytes for a in host),
-                                 "mode": "raft_hip_run_pipelined (query column uploaded)", "equals_grouped": bool(same_c)},
+                                 "mode": "raft_hip_run_pipelined with RAFT_NO_DERIVE=1 (the three columns uploaded as they are, 12 bytes per record)", "equals_grouped": bool(same_c)},
             "one_piece": {"records_per_s": o.n_rec / one_piece, "seconds": one_piece, "h2d_plus_pass_s": split[0], "pack_plus_d2h_s": split[1]},
             "chunked_equals_one_piece": bool(same),
             "host_memory": "page-locked, allocated before the clock, caller-owned and reused" if reused else "page-locked (grown inside the clock)",

@@ -46,12 +46,13 @@ namespace {
 // short_max windows always fits one LDS window.
 struct PileVariant { int fast, cap, wg_per_cu, short_max; };
 constexpr PileVariant kVariants[] = {
-    {1, 7936, 4, 1664},   // 0: default: fast kernel, 36.4 KB LDS, 4 workgroups/CU, 6 prefetch slots per lane, Q = 6272
-    {0, 6144, 5, 2048},   // 1: general kernel only
-    {1, 6144, 5, 1536},   // 2: fast kernel, 29.2 KB LDS, 5 workgroups/CU, 4 prefetch slots per lane, Q = 4608
+    {1, 7936, 4, 1664},   // 0: round 1-3's pileup: workgroup tiles, int32 LDS window (pileup_fast.hpp), 36.4 KB LDS, 4 workgroups/CU, Q = 6272;
+                          //    the pass a wave tile too deep for 16 bits falls back to (kErrDeep), and the A/B partner of variant 5
+    {0, 6144, 5, 2048},   // 1: general kernel only (the first design: the independent cross-check of tests/test_gpu_consistency.py)
+    {1, 7936, 4, 1664},   // 2: (retired: the 5-workgroup configuration; same as 0)
     {1, 7936, 4, 1664},   // 3: variant 0 with s_memtime stamps in the fast kernel (diagnostic; raft_hip_debug_stamps)
-    {1, 7936, 4, 1664},   // 4: variant 0 with lane-serial rows (pileup_fast.hpp LS)
-    {2, kWaveSlots - 4, 4, 0},   // 5: one wave per tile, 16-bit difference array (pileup_wave.hpp); every tile cut by tile_desc_kernel's walk
+    {1, 7936, 4, 1664},   // 4: (retired: lane-serial rows; same as 0)
+    {2, kWaveSlots - 4, 4, 0},   // 5: one wave per tile, 16-bit difference array, workers cut their own tiles (pileup_wave.hpp): the default
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kDefaultVariant = RAFT_DEFAULT_VARIANT;
@@ -73,50 +74,31 @@ void launch_general(hipStream_t st, unsigned grid, const PileupArgs &pa)
     hipLaunchKernelGGL((pileup_kernel<256, CAP, MINW, 3, false>), dim3(grid), dim3(256), 0, st, pa);
 }
 
-template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, int EXTRA = 0, int OW = 4, bool LS = false, int IN = 0>
+template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, int EXTRA = 0, int OW = 4>
 void launch_fast(hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
     constexpr int S4 = SLOTS % 4 == 0 ? SLOTS : 4;   // four sorted runs need a multiple of four slots
     const size_t dyn = 0;
     if (n_seg <= 1)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG, EXTRA, OW, LS, IN>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG, EXTRA, OW, false, 0>), dim3(grid), dim3(256), dyn, st, cuts, pa);
     else if (n_seg == 2)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG, EXTRA, OW, LS, IN>), dim3(grid), dim3(256), dyn, st, cuts, pa);
-    else if constexpr (IN == 0)                       // (window records: one or two runs, see kWinMaxRuns)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG, EXTRA, OW, LS, IN>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG, EXTRA, OW, false, 0>), dim3(grid), dim3(256), dyn, st, cuts, pa);
+    else
+        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG, EXTRA, OW, false, 0>), dim3(grid), dim3(256), dyn, st, cuts, pa);
 }
-constexpr int kWinMaxRuns = 2;    // runs the window-record instantiations take (their per-run tables share the LDS budget); more: unpacked first
+constexpr int kWinMaxRuns = 2;    // runs the window-record instantiations (pileup_wave.hpp IN = 1) take; more: unpacked to coordinate columns first
 
-// the fast kernel's configurations by output width (pileup_fast.hpp OW; the diagnostic build writes int32 only)
+// the workgroup-tile kernel's configurations by output width (pileup_fast.hpp OW; the diagnostic build writes int32 only).  Round 4
+// pruned its instantiations to what a fallback needs: coordinate columns in; int32, one or two bytes per window out (window
+// records are unpacked for it, the four-bit encoding is made from its int32 array afterwards); the lane-serial rows and the
+// 5-workgroup configuration are gone.
 template <int EXTRA>
-void launch_fast_variant(int variant, int ow, bool ls, bool win, hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
+void launch_fast_variant(int variant, int ow, hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
 {
-    if (win) {                                                // window records (pileup_fast.hpp IN = 1): the default configuration (and its diagnostic build)
-        if (variant == kDiagVariant && EXTRA == 0) launch_fast<7936, 4, true, 6, 0, 4, false, 1>(st, grid, n_seg, cuts, pa);
-        else if (ow == kCovDelta4) launch_fast<7936, 4, false, 6, EXTRA, kCovDelta4, false, 1>(st, grid, n_seg, cuts, pa);
-        else if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1, false, 1>(st, grid, n_seg, cuts, pa);
-        else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2, false, 1>(st, grid, n_seg, cuts, pa);
-        else launch_fast<7936, 4, false, 6, EXTRA, 4, false, 1>(st, grid, n_seg, cuts, pa);
-        return;
-    }
-    if (ls && variant != 2 && variant != kDiagVariant) {      // the lane-serial rows (pileup_fast.hpp LS)
-        if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1, true>(st, grid, n_seg, cuts, pa);
-        else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2, true>(st, grid, n_seg, cuts, pa);
-        else launch_fast<7936, 4, false, 6, EXTRA, 4, true>(st, grid, n_seg, cuts, pa);
-        return;
-    }
-    if (variant == 2) {
-        if (ow == 1) launch_fast<6144, 5, false, 4, EXTRA, 1>(st, grid, n_seg, cuts, pa);
-        else if (ow == 2) launch_fast<6144, 5, false, 4, EXTRA, 2>(st, grid, n_seg, cuts, pa);
-        else launch_fast<6144, 5, false, 4, EXTRA, 4>(st, grid, n_seg, cuts, pa);
-    } else if (variant == kDiagVariant && EXTRA == 0) {
-        launch_fast<7936, 4, true, 6, 0, 4>(st, grid, n_seg, cuts, pa);
-    } else {
-        if (ow == kCovDelta4) launch_fast<7936, 4, false, 6, EXTRA, kCovDelta4>(st, grid, n_seg, cuts, pa);
-        else if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1>(st, grid, n_seg, cuts, pa);
-        else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2>(st, grid, n_seg, cuts, pa);
-        else launch_fast<7936, 4, false, 6, EXTRA, 4>(st, grid, n_seg, cuts, pa);
-    }
+    if (variant == kDiagVariant && EXTRA == 0) launch_fast<7936, 4, true, 6, 0, 4>(st, grid, n_seg, cuts, pa);
+    else if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1>(st, grid, n_seg, cuts, pa);
+    else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2>(st, grid, n_seg, cuts, pa);
+    else launch_fast<7936, 4, false, 6, EXTRA, 4>(st, grid, n_seg, cuts, pa);
 }
 
 // RAFT_PRINT_OCCUPANCY=1: what the runtime thinks of the pileup kernels (registers, LDS, resident workgroups per CU)
@@ -301,6 +283,8 @@ struct raft_hip_ctx {
     FinalizeArgs fa{};                // of the last pass (the cut points are materialised on demand)
     bool cuts_ready = false;
     bool is_lane = false;              // a sub-context of a host pipeline (prepare_lanes)
+    void *h_stage = nullptr;           // page-locked staging of a lane: what the host derives from a chunk's columns (window records, offsets)
+    size_t h_stage_cap = 0;
     bool emit_cuts = true;             // the pass writes the cut points (final_stars) itself; false: on demand (raft_hip_set_emit_cuts)
 };
 
@@ -429,6 +413,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
                      &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->exc_idx2, &c->exc_val2, &c->sort_tmp, &c->exc_pidx, &c->exc_pval, &c->exc_tile_n, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
     if (c->ev_pass1) (void)hipEventDestroy(c->ev_pass1);
     if (c->ev_pile0) (void)hipEventDestroy(c->ev_pile0);
@@ -527,14 +512,10 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     // what `recut` says to the geometry scan and to finalize -- from the boundaries of quantum tiles four times a tile's size
     const bool wave = pv.fast == 2;
     const bool recut = wave || (pv.fast && !c->no_recut && getenv("RAFT_NO_RECUT") == nullptr);
-    // lane-serial rows: variant 4, or RAFT_LANE_SERIAL=1 for every fast configuration of the process (A/B, test sweeps); they
-    // take slots outside the tile for not-high, which a threshold below 1 would not give them
-    const bool ls_rows = (c->variant == 4 || getenv("RAFT_LANE_SERIAL") != nullptr) && c->high_cov >= 1;
     // window records go to the fast kernel's own instantiation (pileup_fast.hpp IN = 1) where every tile is the fast kernel's
     // in its default configuration and the runs are few; anything else gets coordinate columns that fall into the same
     // windows (bucket.hpp unpack_windows_kernel) and takes the paths those have
-    const bool lean = d_win && n_rec > 0 && !merge && eff_runs <= kWinMaxRuns && recut && (c->variant == 0 || c->variant == kDiagVariant || wave) && !ls_rows &&
-                      !c->force_bucket && getenv("RAFT_NO_WINDOW_KERNEL") == nullptr;
+    const bool lean = d_win && n_rec > 0 && !merge && eff_runs <= kWinMaxRuns && wave && !c->force_bucket && getenv("RAFT_NO_WINDOW_KERNEL") == nullptr;
     if (d_win && !lean && n_rec > 0) {
         HIP_TRY(c, c->u_s.ensure((size_t)n_rec * 4));
         HIP_TRY(c, c->u_e.ensure((size_t)n_rec * 4));
@@ -571,7 +552,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     // the encoding of cov[] is written directly when every tile goes through the fast kernel (pileup_fast.hpp OW); a pass
     // the general kernel takes part in writes int32 and raft_hip_fetch_packed_w encodes it afterwards, as it always did
     // (delta4: the default configuration's instantiations only; elsewhere the pass writes int32 and is encoded afterwards)
-    const bool d4_ok = (c->variant == 0 || wave) && !ls_rows;
+    const bool d4_ok = wave;
     const int ow = (c->out_width != 4 && recut && c->variant != kDiagVariant && (c->out_width != kCovDelta4 || d4_ok)) ? c->out_width : 4;
     // a grouped pass whose caller announced the window count needs nothing back from the device on the way
     const bool no_wait = grouped && in.hint_bins >= 0 && getenv("RAFT_NO_HINT") == nullptr;
@@ -902,12 +883,12 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         // running BESIDE the regular ones from the start than behind them.)
         {
             HIP_TRY(c, hipEventRecord(c->ev_fork, st));
-            launch_fast_variant<0>(c->variant, ow, ls_rows, lean, st, pgrid, pa.n_seg, cuts, pa);
+            launch_fast_variant<0>(c->variant, ow, st, pgrid, pa.n_seg, cuts, pa);
             HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
             if (recut) {
                 // the tiles that did not fit as they are, re-cut by tile_desc_kernel: the same kernel, its other instantiation
                 ps.slow_list = nullptr; ps.tile_counter = &ctrl->slow_next; ps.n_extra = &ctrl->n_extra; ps.tile_batch = 1;
-                launch_fast_variant<1>(c->variant, ow, ls_rows, lean, c->side_stream, pgrid, pa.n_seg, cuts, ps);
+                launch_fast_variant<1>(c->variant, ow, c->side_stream, pgrid, pa.n_seg, cuts, ps);
             } else launch_general<6144, 5>(c->side_stream, sgrid, ps);
             HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
             HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
@@ -1848,6 +1829,90 @@ static int run_routed(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads,
     return RAFT_HIP_OK;
 }
 
+// What the engine's host side derives from the plain columns of a symmetric, sorted stream before they cross the link (SURVEY.md
+// §8(d): the clock of a host-to-host job starts at the int32 columns): per piece of a chunk -- records [lo, hi) of one sorted run,
+// reads [r0, r1) -- where every read's records begin (the grouped form of raft_hip_run_device_grouped) and the records as
+// window records (one word: first window | one past the last << 16; repeat.hpp:69-72 uses nothing else of an interval).  4 bytes
+// per record go up instead of 12, and the pass needs no look at the stream.  The ids are checked on the way (inside the
+// chunk's reads, never stepping back): anything else, a negative coordinate or a window beyond 16 bits sends the job to the
+// one-piece pass over the columns, which reports or handles it.  T threads share the piece.
+// (Two loops, the first branch-free so that the compiler vectorises it: the window indices by multiply-high -- n / reso ==
+// (n * m) >> (31 + L) for 0 <= n < 2^31, the identity the kernels use; a hardware division per coordinate made the derivation
+// compute-bound at 10 cycles per record -- with the error conditions collected, not branched on; then the id column for the places
+// where the read changes.)
+static inline __attribute__((always_inline)) bool derive_body(int t, int T, const int32_t *qid, const int32_t *qs, const int32_t *qe, long long lo, long long hi,
+                                                              int32_t r0, int32_t r1, int32_t reso, long long at, long long *off, uint32_t *win)
+{
+    const long long n = hi - lo;
+    const int32_t nr = r1 - r0;
+    if (n <= 0) { if (t == 0) for (int32_t j = 0; j <= nr; ++j) off[j] = at; return true; }
+    const long long a = lo + n * t / T, b = lo + n * (t + 1) / T;
+    if (a >= b) return true;
+    int L = 0;
+    while ((1u << L) < (uint32_t)reso) ++L;
+    const uint64_t m = reso > 1 ? ((1ull << (31 + L)) / (uint32_t)reso + 1ull) : 1ull;
+    const int sh = reso > 1 ? 31 + L : 0;
+    {
+        const int32_t *ps = qs + a, *pe = qe + a;
+        uint32_t *pw = win + (a - lo);
+        const long long cnt = b - a;
+        uint32_t neg = 0, far = 0;
+        for (long long i = 0; i < cnt; ++i) {
+            const int32_t s0 = ps[i], e0 = pe[i];
+            neg |= (uint32_t)(s0 | e0);
+            const uint32_t first = (uint32_t)(((uint64_t)(uint32_t)s0 * m) >> sh);
+            const uint32_t em = (uint32_t)(e0 > 0 ? e0 - 1 : 0);
+            const uint32_t last1 = e0 > 0 ? (uint32_t)(((uint64_t)em * m) >> sh) + 1u : 0u;
+            const uint32_t w = last1 > first ? (first | (last1 << 16)) : 0u;
+            far |= last1 > first ? last1 : 0u;
+            pw[i] = w;
+        }
+        if ((neg >> 31) || (far >> 16)) return false;      // a negative coordinate; a window index beyond 16 bits
+    }
+    int32_t prev = a == lo ? r0 - 1 : qid[a - 1];
+    if (prev < r0 - 1 || prev >= r1) return false;
+    for (long long i = a; i < b; ++i) {
+        const int32_t q = qid[i];
+        if (q != prev) {
+            if (q < prev || q >= r1) return false;
+            for (int32_t r = prev + 1; r <= q; ++r) off[r - r0] = at + (i - lo);      // (reads without records begin where the next one does)
+            prev = q;
+        }
+    }
+    if (b == hi) for (int32_t r = prev + 1; r <= r1; ++r) off[r - r0] = at + n;           // closing entries
+    return true;
+}
+__attribute__((target("avx2"))) static bool derive_slice_avx2(int t, int T, const int32_t *qid, const int32_t *qs, const int32_t *qe, long long lo, long long hi,
+                                                              int32_t r0, int32_t r1, int32_t reso, long long at, long long *off, uint32_t *win)
+{
+    return derive_body(t, T, qid, qs, qe, lo, hi, r0, r1, reso, at, off, win);
+}
+static bool derive_slice(int t, int T, const int32_t *qid, const int32_t *qs, const int32_t *qe, long long lo, long long hi, int32_t r0, int32_t r1,
+                         int32_t reso, long long at, long long *off, uint32_t *win)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return derive_slice_avx2(t, T, qid, qs, qe, lo, hi, r0, r1, reso, at, off, win);
+    return derive_body(t, T, qid, qs, qe, lo, hi, r0, r1, reso, at, off, win);
+}
+
+// The chunks of one context's job are derived in order by T workers that stay for the whole job -- worker t takes the t-th slice
+// of every piece -- into a ring of page-locked staging slots; a lane uploads chunk k when all workers are through with it and
+// hands its slot back when the upload is done.  (The first version had every lane derive its own chunk with threads made for
+// the purpose: four derivations at a time, each behind its lane's previous chunk, left the link idle a third of the time.)
+struct DeriveRing {
+    static constexpr int R = 3;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> done;            // workers through with chunk k
+    std::vector<char> released, bad;
+    bool stop = false;
+    int T = 1;
+    size_t slot_bytes = 0, off_bytes = 0;
+    char *base = nullptr;
+    long long *off_of(int kk) const { return reinterpret_cast<long long *>(base + (size_t)(kk % R) * slot_bytes); }
+    uint32_t *win_of(int kk) const { return reinterpret_cast<uint32_t *>(base + (size_t)(kk % R) * slot_bytes + off_bytes); }
+};
+
 // (n_runs, rec_offset): the grouped form -- the caller's offsets instead of the query column (raft_hip_run_multi_grouped)
 static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
                           const int32_t *qid, const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts,
@@ -1905,6 +1970,20 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
         return one_piece();
     }
 
+    // plain columns of a symmetric stream in a few sorted runs: the lanes derive offsets and window records chunk by chunk (above)
+    bool derive = !grouped && !win && c->prm.symmetric_mode == 1 && c->prm.reso <= 32767 && n_seg <= kWinMaxRuns && getenv("RAFT_NO_DERIVE") == nullptr;
+    if (derive) {
+        const long long max_len = 65535LL * c->prm.reso;      // (reads of more windows than a record's 16 bits hold keep their coordinate columns)
+        std::atomic<bool> fits{true};
+        const int Tl = (int)std::min<long long>(16, std::max<long long>(1, n_reads / (1 << 18)));
+        host_parallel(Tl, [&](int t) {
+            const long long a = (long long)n_reads * t / Tl, b = (long long)n_reads * (t + 1) / Tl;
+            bool f = true;
+            for (long long i = a; i < b; ++i) f = f && read_len[i] <= max_len;
+            if (!f) fits.store(false);
+        });
+        derive = fits.load();
+    }
     int want = n_chunks > 0 ? std::min(n_chunks, n_reads)
                             : (int)std::min<long long>(std::min<long long>(32LL * n_ctx, std::max<long long>(2LL * n_ctx, n_rec / (24LL << 20))),
                                                        n_reads / 1024);
@@ -1921,8 +2000,11 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             return n;
         };
         std::vector<int32_t> bound{0};
+        // (derived input: the first chunk's derivation and the last chunk's pass and download are not hidden behind anything --
+        // those two chunks are half the others' size)
+        const bool ramp = derive && n_chunks == 0 && want >= 6;
         for (int k = 1; k < want; ++k) {
-            const long long target = n_rec * k / want;
+            const long long target = ramp ? (long long)((double)n_rec * (k - 0.5) / (want - 1.0)) : n_rec * k / want;
             int32_t lo = bound.back(), hi = n_reads;
             while (lo < hi) {
                 const int32_t mid = lo + (hi - lo) / 2;
@@ -1979,6 +2061,12 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
     }
     const int n_ch = (int)plan.size();
     if (n_ch < 2) return one_piece();
+    int derive_threads = 1;
+    if (derive) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        derive_threads = (int)std::max(1u, std::min(16u, hw / 4u));
+        if (const char *e = getenv("RAFT_DERIVE_THREADS")) derive_threads = std::max(1, atoi(e));
+    }
 
     // ---- contexts: consecutive chunks each (the plan balances records per chunk), parameters of the first
     const int n_job = std::min(n_ctx, n_ch);
@@ -2033,6 +2121,60 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
         }
     }
 
+    std::vector<std::unique_ptr<DeriveRing>> rings((size_t)n_job);
+    if (derive) {
+        for (int d = 0; d < n_job; ++d) {
+            DeviceJob &J = jobs[(size_t)d];
+            auto ring = std::make_unique<DeriveRing>();
+            size_t off_b = 0, win_b = 0;
+            for (int kk = 0; kk < J.n_chunks; ++kk) {
+                const ChunkPlan &cp = plan[(size_t)(J.first_chunk + kk)];
+                off_b = std::max(off_b, (size_t)n_seg * ((size_t)(cp.r1 - cp.r0) + 1) * 8);
+                win_b = std::max(win_b, (size_t)std::max<long long>(cp.n_rec, 1) * 4);
+            }
+            ring->off_bytes = (off_b + 255) & ~(size_t)255;
+            ring->slot_bytes = (ring->off_bytes + win_b + 255) & ~(size_t)255;
+            const size_t need = ring->slot_bytes * DeriveRing::R;
+            raft_hip_ctx *jc = J.c;
+            if (need > jc->h_stage_cap) {
+                HIP_TRY(jc, hipSetDevice(jc->device));
+                if (jc->h_stage) (void)hipHostFree(jc->h_stage);
+                jc->h_stage = nullptr; jc->h_stage_cap = 0;
+                HIP_TRY(jc, hipHostMalloc(&jc->h_stage, need + need / 8, hipHostMallocDefault));
+                jc->h_stage_cap = need + need / 8;
+            }
+            ring->base = reinterpret_cast<char *>(jc->h_stage);
+            ring->T = derive_threads;
+            ring->done.assign((size_t)J.n_chunks, 0); ring->released.assign((size_t)J.n_chunks, 0); ring->bad.assign((size_t)J.n_chunks, 0);
+            rings[(size_t)d] = std::move(ring);
+        }
+        (void)hipSetDevice(c->device);
+    }
+    auto derive_worker = [&](int d, int t) {
+        DeviceJob &J = jobs[(size_t)d];
+        DeriveRing &R = *rings[(size_t)d];
+        for (int kk = 0; kk < J.n_chunks; ++kk) {
+            {
+                std::unique_lock<std::mutex> g(R.mu);
+                R.cv.wait(g, [&] { return R.stop || kk < DeriveRing::R || R.released[(size_t)(kk - DeriveRing::R)]; });
+                if (R.stop) return;
+            }
+            const ChunkPlan &cp = plan[(size_t)(J.first_chunk + kk)];
+            const int32_t nr = cp.r1 - cp.r0;
+            long long at = 0;
+            bool good = true;
+            for (int g2 = 0; g2 < n_seg; ++g2) {
+                good = derive_slice(t, R.T, qid, qs, qe, cp.piece[g2].lo, cp.piece[g2].hi, cp.r0, cp.r1, c->prm.reso, at, R.off_of(kk) + (long long)g2 * (nr + 1),
+                                    R.win_of(kk) + at) && good;
+                at += cp.piece[g2].hi - cp.piece[g2].lo;
+            }
+            {
+                std::lock_guard<std::mutex> g(R.mu);
+                if (!good) R.bad[(size_t)kk] = 1;
+                if (++R.done[(size_t)kk] == R.T) R.cv.notify_all();
+            }
+        }
+    };
     std::vector<ChunkResult> res((size_t)n_ch);
     // Exceptions (windows at or above the encoding's limit) have no useful bound per device -- one device may hold all the
     // repeat-rich reads -- so every chunk takes its room from ONE cursor over the caller's list; chunks of different
@@ -2075,9 +2217,25 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             hipStream_t st = l->stream;
             // -- upload, in chunk order on the one upload stream (the link is the bottleneck: first come, first served)
             LANE_TRY(l->in_len.ensure((size_t)std::max(nr, 1) * 4));
-            const int col_end = win ? 2 : 3;         // (window records: one column)
-            for (int col = grouped ? 1 : 0; col < col_end; ++col) LANE_TRY(l->in_col[col].ensure((size_t)std::max<long long>(cp.n_rec, 1) * 4));
-            if (grouped) LANE_TRY(l->in_off.ensure((size_t)n_seg * ((size_t)nr + 1) * 8));
+            const int col_end = (win || derive) ? 2 : 3;         // (window records: one column)
+            for (int col = (grouped || derive) ? 1 : 0; col < col_end; ++col) LANE_TRY(l->in_col[col].ensure((size_t)std::max<long long>(cp.n_rec, 1) * 4));
+            if (grouped || derive) LANE_TRY(l->in_off.ensure((size_t)n_seg * ((size_t)nr + 1) * 8));
+            long long *st_off = nullptr;
+            uint32_t *st_win = nullptr;
+            if (derive) {
+                // the chunk's offsets and window records: derived by the job's workers while earlier chunks travel
+                DeriveRing &R = *rings[(size_t)(&J - &jobs[0])];
+                bool bad_chunk = false, stopped = false;
+                {
+                    std::unique_lock<std::mutex> g(R.mu);
+                    R.cv.wait(g, [&] { return R.stop || R.done[(size_t)kk] == R.T; });
+                    stopped = R.stop; bad_chunk = R.bad[(size_t)kk] != 0;
+                }
+                stamp(k, "derived");
+                if (stopped) goto out;
+                if (bad_chunk) { redo.store(true); goto out; }      // (the one-piece pass over the columns reports or handles it)
+                st_off = R.off_of(kk); st_win = R.win_of(kk);
+            }
             {
                 std::unique_lock<std::mutex> g(sh.mu);
                 sh.cv.wait(g, [&] { return sh.uploaded == kk || stop(); });
@@ -2085,12 +2243,16 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             }
             {
                 hipError_t e = hipMemcpyAsync(l->in_len.p, read_len + cp.r0, (size_t)nr * 4, hipMemcpyHostToDevice, jc->up_stream);
+                if (derive) {
+                    if (e == hipSuccess) e = hipMemcpyAsync(l->in_off.p, st_off, (size_t)n_seg * ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, jc->up_stream);
+                    if (e == hipSuccess && cp.n_rec > 0) e = hipMemcpyAsync(l->in_col[1].p, st_win, (size_t)cp.n_rec * 4, hipMemcpyHostToDevice, jc->up_stream);
+                }
                 const int32_t *src[3] = {qid, win ? reinterpret_cast<const int32_t *>(win) : qs, qe};
                 // (grouped: a slice of every run's offsets instead of the query column -- 8 bytes per read and run, not 4 per record)
-                for (int g = 0; grouped && g < n_seg && e == hipSuccess; ++g)
+                for (int g = 0; grouped && !derive && g < n_seg && e == hipSuccess; ++g)
                     e = hipMemcpyAsync(l->in_off.as<long long>() + (long long)g * (nr + 1), rec_offset + (long long)g * ostride + cp.r0,
                                        (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, jc->up_stream);
-                for (int col = grouped ? 1 : 0; col < col_end && e == hipSuccess; ++col) {
+                for (int col = grouped ? 1 : 0; !derive && col < col_end && e == hipSuccess; ++col) {
                     long long at = 0;
                     for (int g = 0; g < n_seg && e == hipSuccess; ++g) {
                         const long long n = cp.piece[g].hi - cp.piece[g].lo;
@@ -2113,7 +2275,13 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             // (measured: chunks whose pass was queued at 12 ms ran at 24 ms).
             LANE_TRY(hipEventSynchronize(jc->lane_up_ev[(size_t)li]));
             stamp(k, "h2d done");
-            if (cp.n_rec > 0 && cp.r0 != 0 && !grouped) {
+            if (derive) {
+                DeriveRing &R = *rings[(size_t)(&J - &jobs[0])];
+                std::lock_guard<std::mutex> g(R.mu);
+                R.released[(size_t)kk] = 1;
+                R.cv.notify_all();
+            }
+            if (cp.n_rec > 0 && cp.r0 != 0 && !grouped && !derive) {
                 const unsigned grid = (unsigned)std::min<long long>((cp.n_rec + 255) / 256, 4096);
                 hipLaunchKernelGGL(rebase_ids_kernel, dim3(grid), dim3(256), 0, st, l->in_col[0].as<int32_t>(), cp.n_rec, cp.r0);
             }
@@ -2122,7 +2290,12 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
                 l->out_width = cov_width;            // the pass writes the encoding that travels
                 l->d4_shift = d4 ? (int)(cp.win_lo & (kD4Block - 1)) : 0;
                 int rc;
-                if (grouped) {
+                if (derive) {
+                    // (the staged offsets count from the chunk's own first record: nothing to rebase)
+                    const long long hint = count_windows(read_len + cp.r0, nr, c->prm.reso);
+                    rc = run_grouped(l, nr, l->in_len.as<int32_t>(), cp.n_rec, n_seg, l->in_off.as<int64_t>(), nullptr, nullptr, nullptr, nullptr, hint,
+                                     cp.n_rec > 0 ? l->in_col[1].as<uint32_t>() : nullptr);
+                } else if (grouped) {
                     // the chunk's pieces lie back to back on the device: run g's slice of offsets counts from the caller's
                     // stream and is moved by adj[g] to where the piece went
                     long long adj[kMaxSeg] = {0, 0, 0, 0}, at = 0;
@@ -2220,15 +2393,31 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             std::lock_guard<std::mutex> g(sh.mu);
             sh.cv.notify_all();
         }
+        if (derive && (sh.error != RAFT_HIP_OK || redo.load())) {      // ... nor the workers for its slots
+            DeriveRing &R = *rings[(size_t)(&J - &jobs[0])];
+            std::lock_guard<std::mutex> g(R.mu);
+            R.stop = true;
+            R.cv.notify_all();
+        }
     };
 
     {
-        std::vector<std::thread> th;
+        std::vector<std::thread> th, workers;
+        if (derive)
+            for (int d = 0; d < n_job; ++d)
+                for (int t = 0; t < derive_threads; ++t) workers.emplace_back([&, d, t] { derive_worker(d, t); });
         for (int d = 0; d < n_job; ++d)
             for (int li = 0; li < kLanes; ++li)
                 if (d || li) th.emplace_back([&, d, li] { lane_main(jobs[(size_t)d], li); });
         lane_main(jobs[0], 0);
         for (auto &t : th) t.join();
+        if (derive)
+            for (int d = 0; d < n_job; ++d) {       // (a job that ended early leaves workers waiting for slots)
+                std::lock_guard<std::mutex> g(rings[(size_t)d]->mu);
+                rings[(size_t)d]->stop = true;
+                rings[(size_t)d]->cv.notify_all();
+            }
+        for (auto &t : workers) t.join();
     }
     int err = RAFT_HIP_OK;
     for (DeviceJob &J : jobs) {
@@ -2738,7 +2927,6 @@ int raft_hip_selftest(int device_id)
     if (getenv("RAFT_PRINT_OCCUPANCY")) {
         print_occupancy("fast<7936,2,6,4>", pileup_fast_kernel<7936, 2, 6, 4, false, 0>);
         print_occupancy("fast<7936,1,6,4>", pileup_fast_kernel<7936, 1, 6, 4, false, 0>);
-        print_occupancy("fast<6144,2,4,5>", pileup_fast_kernel<6144, 2, 4, 5, false, 0>);
         print_occupancy("general<256,6144,5,3>", pileup_kernel<256, 6144, 5, 3, false>);
     }
     const int n = 256;

@@ -172,12 +172,8 @@ __device__ __forceinline__ void note_exception(const PileupArgs &a, long long wi
 // OW = bytes per window of the coverage written: 4 = cov[] as int32; 1 / 2 = its transfer encoding (PileupArgs::covp) --
 // the consumer of cov[] is a text formatter on the host, four fifths of the kernel's HBM traffic is this array, and real
 // coverage fits a byte.
-// LS ("lane-serial", round 3): the rows of a wave are prefix-summed with every lane owning a CONTIGUOUS run of windows
-// (4 x rows-of-the-wave of them) instead of four windows of every row: one wave scan per wave and tile (over the lanes'
-// totals) instead of one per row, no carry handed from row to row, the run scan as scalar mask logic per window with
-// vector work only where a run starts or ends; the values go back to LDS and are read row-wise for the coalesced 1 KiB
-// stores.  The ablations showed the rows bound by their dependent chain -- LDS read, six DPP steps,
-// carry through a scalar register, 27 times per tile -- not by their instruction count; this removes the chain.
+// (LS: the lane-serial rows of round 3 -- equal on the byte path, 7-9 % slower with int32 output -- were removed in round 4; the
+// parameter stays false.)
 //
 // IN = 1 ("window records", round 3): a record is ONE 32-bit word -- its first window and one past its last, 16 bits each,
 // cut from the coordinates by the tokeniser (raft_host_pack_windows) -- and carries no read id: the caller's offsets say
@@ -189,7 +185,7 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
 {
     constexpr int THREADS = 256, NW = 4, ITER = U / NSEG;
     static_assert(U % NSEG == 0 && ITER >= 1, "slots are split evenly over the segments");
-    static_assert(!(IN == 1 && LS), "window records come with the row-wise scan only");
+    static_assert(!LS, "the lane-serial rows were removed in round 4");
     using Smem = FastSmem<CAP, IN ? NSEG : 0>;
     const unsigned tid = threadIdx.x;
     const int lane = (int)(tid & 63u);
@@ -316,7 +312,6 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
             const int rows = (t_end + 1 + 255) >> 8;
             int32_t *const cov0 = OW == 4 ? a.cov + a0 : nullptr;
             constexpr bool D4 = OW == 8;           // the four-bit step encoding (pack.hpp kCovDelta4): slot p -> nibble a0 + p
-            static_assert(!(D4 && LS), "the step encoding comes with the row-wise scan only");
             char *const covp0 = OW == 4 ? nullptr : reinterpret_cast<char *>(a.covp) + (D4 ? a0 / 2 : a0 * OW);   // slot p -> covp0 + p * OW (D4: + p / 2)
             // D4: a step is the difference array's own value -- except at the tile's first window, whose predecessor another
             // workgroup holds: that window is always listed with its value.  A lane's four steps are one aligned ushort; the
@@ -516,26 +511,7 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
             const int rpw = (rows + NW - 1) / NW;
             const int row_b = wid * rpw;
             const int row_e = min(rows, row_b + rpw);
-            // LS: the wave's rows as one or two chunks of an ODD number of rows (an even count leaves one row for a chunk of
-            // its own): a lane's run of 4 * rows words then begins 4 (mod 8) words after its neighbour's, and the lanes'
-            // 16-byte LDS accesses fall on all banks evenly (an even number of rows would put 8 to 32 lanes on each bank quad)
-            const int n_r = max(row_e - row_b, 0);
-            const int nA = LS ? ((n_r & 1) ? n_r : max(n_r - 1, 0)) : 0, nB = LS ? n_r - nA : 0;
-            int lexA = 0, lexB = 0, totA = 0, totB = 0;      // LS: sum of the lanes before this one in the chunk; the chunk's total
-            if (LS) {
-                auto lane_sum = [&](int cb, int nrow) -> int {
-                    const int32_t *p = &sm.diff[cb * 256 + lane * (4 * nrow)];
-                    int t = 0;
-                    for (int q = 0; q < nrow; ++q) {
-                        const int4 d = *reinterpret_cast<const int4 *>(p + 4 * q);
-                        t += d.x + d.y + d.z + d.w;
-                    }
-                    return t;
-                };
-                if (nA) { const int t = lane_sum(row_b, nA); const int incl = wave_incl_scan_add(t); lexA = incl - t; totA = __builtin_amdgcn_readlane(incl, 63); }
-                if (nB) { const int t = lane_sum(row_b + nA, nB); const int incl = wave_incl_scan_add(t); lexB = incl - t; totB = __builtin_amdgcn_readlane(incl, 63); }
-                if (lane == 0) sm.wsum[wid] = totA + totB;
-            } else {
+            {
                 int s = 0;
                 for (int row = row_b; row < row_e; ++row) {
                     const int4 d = *reinterpret_cast<const int4 *>(&sm.diff[row * 256 + lane * 4]);
@@ -586,150 +562,13 @@ __device__ __forceinline__ void fast_tile_loop(FastSmem<CAP, IN ? NSEG : 0> &sm,
                 } else if (lane == 0) { if (piece) emit_piece_run(a, tb, r_a, sS, sT); else emit_run(a, tb, nr, sS, sT); }
             };
 
-            if (LS) {
-                constexpr int NEG = -0x40000000;
-                const unsigned long long lt_mask = (1ull << lane) - 1ull;
-                // runs found by a lane or at a lane boundary: kept ones go to the wave's queue by ballot rank
-                auto park_lanes = [&](bool keep, int vS, int vT) {
-                    const unsigned long long km = __ballot(keep);
-                    if (km) {
-                        const int idx = nq + (int)__popcll(km & lt_mask);
-                        if (keep) {
-                            if (idx < kRunQ) { sm.runq[(wid * kRunQ + idx) * 2] = vS; sm.runq[(wid * kRunQ + idx) * 2 + 1] = vT; }
-                            else if (piece) emit_piece_run(a, tb, r_a, vS, vT);
-                            else emit_run(a, tb, nr, vS, vT);
-                        }
-                        nq = min(kRunQ, nq + (int)__popcll(km));
-                    }
-                };
-                // repeat.hpp:125,150 -- except at the edges of a PIECE of a long read (see park())
-                auto long_enough = [&](int vS, int vT) -> bool {
-                    return (long long)(vT - vS) * a.reso >= (long long)a.repeat_length || (piece && (vS == off0 || vT == t_end));
-                };
-                auto chunk = [&](int cb, int nrow, int lex, int tot) {
-                    const int span = 4 * nrow, pos0 = cb * 256 + lane * span;
-                    int32_t *const p = &sm.diff[pos0];
-                    int acc = carry + lex;
-                    int ls = NEG, inh = -1;                       // last run start inside the lane; first run end without one before it
-                    unsigned long long P = 0ull, HF = 0ull;       // high mask of the slot before (per lane); of the lanes' first slots
-                    // one slot of every lane: M = lanes whose slot is high.  Nothing happens unless a run starts or ends in some lane.
-                    auto step = [&](unsigned long long M, int posv) {
-                        const unsigned long long E = P & ~M, St = M & ~P;
-                        if ((E | St) != 0ull) {
-                            const bool st = ((St >> lane) & 1ull) != 0ull, en = ((E >> lane) & 1ull) != 0ull;
-                            if (en && ls == NEG) inh = posv;                     // the run began before this lane: judged at the chunk's end
-                            park_lanes(en && ls >= 0 && long_enough(ls, posv), ls, posv);
-                            if (en) ls = NEG + 1;                                 // (closed: a later end in this lane needs a start of its own)
-                            if (st) ls = posv;
-                        }
-                        P = M;
-                    };
-                    int4 dn = *reinterpret_cast<const int4 *>(p);
-                    for (int q = 0; q < nrow; ++q) {
-                        const int4 d = dn;
-                        if (q + 1 < nrow) dn = *reinterpret_cast<const int4 *>(p + 4 * q + 4);
-                        const int c0 = acc + d.x, c1 = c0 + d.y, c2 = c1 + d.z, c3 = c2 + d.w;
-                        acc = c3;
-                        *reinterpret_cast<int4 *>(p + 4 * q) = make_int4(c0, c1, c2, c3);   // (read back row-wise below)
-                        const unsigned long long M0 = __ballot(c0 >= a.high_cov), M1 = __ballot(c1 >= a.high_cov),
-                                                 M2 = __ballot(c2 >= a.high_cov), M3 = __ballot(c3 >= a.high_cov);
-                        if (q == 0) { HF = M0; P = M0; }          // (a lane's first slot: what lies before it is the neighbour lane's, below)
-#ifndef RAFT_ABLATE_LS_SCAN
-                        step(M0, pos0 + 4 * q); step(M1, pos0 + 4 * q + 1); step(M2, pos0 + 4 * q + 2); step(M3, pos0 + 4 * q + 3);
-#else
-                        P = M0 | M1 | M2 | M3;
-#endif
-                    }
-                    // ---- the lanes' first slots: the slot before is the last slot of the lane before (lane 0: what the wave carried in)
-                    const unsigned long long HL = P, PB = (HL << 1) | (hp ? 1ull : 0ull);
-                    const unsigned long long bE = PB & ~HF, bS = HF & ~PB;
-                    const bool be = ((bE >> lane) & 1ull) != 0ull, bs = ((bS >> lane) & 1ull) != 0ull;
-                    const int lsv = ls >= 0 ? ls : (bs ? pos0 : NEG);                  // the lane's last run start (a closed one is older than any open one)
-                    if (__ballot(lsv > NEG || be || inh >= 0) != 0ull) {
-                        const int incl = wave_incl_scan_max(lsv, NEG);
-                        const int carried = max(S, wave_shr1(incl, NEG));           // start of the run that reaches this lane's first slot
-                        auto deferred = [&](bool has, int vS, int vT) {
-                            const unsigned long long inhm = __ballot(has && vS == kOpen);
-                            if (inhm) pclose = __builtin_amdgcn_readlane(vT, (int)__builtin_ctzll(inhm));   // the wave's inherited run: start known after the barrier
-                            park_lanes(has && vS >= 0 && long_enough(vS, vT), vS, vT);
-                        };
-                        deferred(be, carried, pos0);
-                        deferred(inh >= 0, bs ? pos0 : carried, inh);
-                        S = max(S, __builtin_amdgcn_readlane(incl, 63));
-                    }
-                    hp = (HL >> 63) != 0ull;
-                    carry += tot;
-                };
-                if (nA) chunk(row_b, nA, lexA, totA);
-                if (nB) chunk(row_b + nA, nB, lexB, totB);
-                // ---- the values, row-wise: coalesced stores; the rows are clean for the next tile afterwards
-                for (int row = row_b; row < row_e; ++row) {
-                    const int p0 = row * 256 + lane * 4;
-                    const int4 v = *reinterpret_cast<const int4 *>(&sm.diff[p0]);
-                    *reinterpret_cast<int4 *>(&sm.diff[p0]) = make_int4(0, 0, 0, 0);
-                    const int c0 = v.x, c1 = v.y, c2 = v.z, c3 = v.w;
-                    const unsigned k0 = min((unsigned)c0, kLimit), k1 = min((unsigned)c1, kLimit), k2 = min((unsigned)c2, kLimit), k3 = min((unsigned)c3, kLimit);
-                    const bool big = OW != 4 && ((unsigned)c0 | (unsigned)c1 | (unsigned)c2 | (unsigned)c3) >= kLimit;
-#ifdef RAFT_ABLATE_LS_STORE
-                    if (k0 + k1 + k2 + k3 == 0x7fffffffu) cov0[p0] = 1;          // (keeps the values alive; never true)
-                    continue;
-#endif
-                    if (((partial_rows >> row) & 1u) == 0u) {
-                        if (OW == 4) *reinterpret_cast<int4 *>(reinterpret_cast<char *>(cov0) + (unsigned)p0 * 4u) = make_int4(c0, c1, c2, c3);
-                        else if (OW == 1) *reinterpret_cast<unsigned *>(covp0 + (unsigned)p0) = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);
-                        else *reinterpret_cast<uint2 *>(covp0 + (unsigned)p0 * 2u) = make_uint2(k0 | (k1 << 16), k2 | (k3 << 16));
-                        if (big) {
-                            if ((unsigned)c0 >= kLimit) note_exception(a, a0 + p0, c0);
-                            if ((unsigned)c1 >= kLimit) note_exception(a, a0 + p0 + 1, c1);
-                            if ((unsigned)c2 >= kLimit) note_exception(a, a0 + p0 + 2, c2);
-                            if ((unsigned)c3 >= kLimit) note_exception(a, a0 + p0 + 3, c3);
-                        }
-                    } else {                         // first / last row of the tile: some slots lie outside [off0, t_end)
-                        const unsigned q0 = (unsigned)(p0 - off0), nw_u = (unsigned)cur.nwin;
-                        const bool v0 = q0 < nw_u, v1 = q0 + 1u < nw_u, v2 = q0 + 2u < nw_u, v3 = q0 + 3u < nw_u;
-                        if (OW == 4) {
-                            if (v0 && v3) *reinterpret_cast<int4 *>(&cov0[p0]) = make_int4(c0, c1, c2, c3);
-                            else {
-                                if (v0) cov0[p0 + 0] = c0;
-                                if (v1) cov0[p0 + 1] = c1;
-                                if (v2) cov0[p0 + 2] = c2;
-                                if (v3) cov0[p0 + 3] = c3;
-                            }
-                        } else if (OW == 1) {
-                            uint8_t *const o = reinterpret_cast<uint8_t *>(covp0) + p0;
-                            if (v0 && v3) *reinterpret_cast<unsigned *>(o) = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);
-                            else {
-                                if (v0) o[0] = (uint8_t)k0;
-                                if (v1) o[1] = (uint8_t)k1;
-                                if (v2) o[2] = (uint8_t)k2;
-                                if (v3) o[3] = (uint8_t)k3;
-                            }
-                        } else {
-                            uint16_t *const o = reinterpret_cast<uint16_t *>(covp0) + p0;
-                            if (v0 && v3) *reinterpret_cast<uint2 *>(o) = make_uint2(k0 | (k1 << 16), k2 | (k3 << 16));
-                            else {
-                                if (v0) o[0] = (uint16_t)k0;
-                                if (v1) o[1] = (uint16_t)k1;
-                                if (v2) o[2] = (uint16_t)k2;
-                                if (v3) o[3] = (uint16_t)k3;
-                            }
-                        }
-                        if (big) {
-                            if (v0 && (unsigned)c0 >= kLimit) note_exception(a, a0 + p0, c0);
-                            if (v1 && (unsigned)c1 >= kLimit) note_exception(a, a0 + p0 + 1, c1);
-                            if (v2 && (unsigned)c2 >= kLimit) note_exception(a, a0 + p0 + 2, c2);
-                            if (v3 && (unsigned)c3 >= kLimit) note_exception(a, a0 + p0 + 3, c3);
-                        }
-                    }
-                }
-            }
             int4 dn = make_int4(0, 0, 0, 0);
-            if (!LS && row_b < row_e) dn = *reinterpret_cast<const int4 *>(&sm.diff[row_b * 256 + lane * 4]);
+            if (row_b < row_e) dn = *reinterpret_cast<const int4 *>(&sm.diff[row_b * 256 + lane * 4]);
 #ifdef RAFT_ABLATE_ROWS
             for (int row = row_b; row < row_e; ++row) *reinterpret_cast<int4 *>(&sm.diff[row * 256 + lane * 4]) = make_int4(0, 0, 0, 0);
             if (0)
 #endif
-            for (int row = row_b; !LS && row < row_e; ++row) {
+            for (int row = row_b; row < row_e; ++row) {
                 const int base = row * 256, p0 = base + lane * 4;
                 const int4 d = dn;
                 // the next row, unconditionally: past the wave's last row this reads a row another wave owns (or the

@@ -258,9 +258,14 @@ int main(int argc, char *argv[])
     // hifiasm writes its PAF grouped by query (reference README.md:36-38): a symmetric stream of at most four runs sorted by
     // read id is handed over in its grouped form -- per run, where every read's records begin -- and the query column stays
     // on the host (a third of the upload); any other stream goes up as it is.
+    // Round 4: by default neither is prepared here any more.  The engine's host pipeline derives both from the plain columns of a
+    // symmetric stream itself, chunk by chunk, beside the uploads of the chunks before (raft_hip.h "derived input"): the two
+    // stages below were a second and a third pass over the columns between the parse and the engine (19 ms for 4.4e7 records).
+    // RAFT_CLI_PREPARE=1 keeps them (A/B, and the grouped / window-record entry points through the CLI).
     std::unique_ptr<int64_t[]> rec_off;
     int32_t n_runs = 0;
-    if (sym && n_rec > 0 && !getenv("RAFT_NO_GROUPED")) {
+    const bool prepare = getenv("RAFT_CLI_PREPARE") != nullptr;
+    if (prepare && sym && n_rec > 0 && !getenv("RAFT_NO_GROUPED")) {
         rec_off.reset(new int64_t[(size_t)4 * ((size_t)n_reads + 1)]);
         if (raft_host_group_offsets(n_reads, n_rec, raft_host_paf_column(paf, 0), 4, &n_runs, rec_off.get()) != RAFT_HOST_OK) n_runs = 0;
         if (n_runs == 0 && devices.size() == 1 && n_rec < ((int64_t)1 << 29)) {
@@ -291,7 +296,23 @@ int main(int argc, char *argv[])
     // ... but grouped input (whose chunks the pipelines can cut where they like) brings the coverage back as four-bit steps: the
     // step from one window to the next is the pileup's own difference array, within +-7 for all but a few windows in a
     // thousand whatever the depth -- half of a byte per window, a quarter of two
-    int cov_width = (n_runs > 0 && !getenv("RAFT_NO_DELTA4")) ? RAFT_HIP_COV_DELTA4 : (p.est_cov >= 40 ? 2 : 1);
+    // (handing over the plain columns, the CLI does not know the stream's shape exactly; 8 k samples tell a handful of sorted runs
+    // -- which the engine cuts into chunks wherever it likes -- from a shuffled stream, whose routed chunks end where the host's
+    // buckets do and keep the byte encodings)
+    bool few_runs = false;
+    if (sym && !prepare && n_rec > 0) {
+        const int32_t *q = raft_host_paf_column(paf, 0);
+        const int64_t S = std::min<int64_t>(n_rec, 8192);
+        int descents = 0;
+        int64_t prev = 0;
+        for (int64_t i = 1; i < S; ++i) {
+            const int64_t pos = S > 1 ? i * (n_rec - 1) / (S - 1) : 0;
+            if (q[pos] < q[prev]) ++descents;
+            prev = pos;
+        }
+        few_runs = descents < 4;
+    }
+    int cov_width = ((n_runs > 0 || few_runs) && !getenv("RAFT_NO_DELTA4")) ? RAFT_HIP_COV_DELTA4 : (p.est_cov >= 40 ? 2 : 1);
     raft_hip_summary s{};
     int64_t n_exc = 0;
     const char *chunks_env = getenv("RAFT_CHUNKS");   // 0 / unset: the engine decides (one piece for small inputs)
@@ -335,7 +356,7 @@ int main(int argc, char *argv[])
         die(m);
     }
     stage("engine+fetch");
-    if (timing) fprintf(stderr, "TIMING devices_used %d input %s\n", s.n_devices_used, win ? "windows" : (n_runs > 0 ? "grouped" : "columns"));
+    if (timing) fprintf(stderr, "TIMING devices_used %d input %s\n", s.n_devices_used, win ? "windows" : (n_runs > 0 ? "grouped" : (sym ? "columns (offsets and window records derived by the engine)" : "columns")));
     if (timing) fprintf(stderr, "TIMING coverage_encoding %s\n", cov_width == RAFT_HIP_COV_DELTA4 ? "delta4" : (cov_width == 2 ? "uint16" : "uint8"));
     fprintf(stdout, "INFO, Symmetric overlaps %d \n", s.symmetric);            // chop.hpp:189-190
     fprintf(stdout, "INFO, length of alignments  %d()\n", (int)s.n_records);

@@ -61,6 +61,7 @@ def test_bench_line_has_every_contract_field():
     # the object's headline starts at SURVEY.md §8(d)'s boundary: the grouped form and the window records are derived inside the clock
     fs = w["from_soa"]
     assert fs["equals_prepared_input"] is True and e["records_per_s"] == fs["records_per_s"] and e["seconds"] == fs["seconds"]
+    assert fs["explicit_host_calls"]["seconds"] > 0 and "ONE call" in fs["boundary"]
     assert e["prepared_input"]["records_per_s"] == w["delta4"]["records_per_s"] and "SoA boundary" in e["mode"]
 
 

@@ -158,10 +158,12 @@ def test_cli_spreads_every_input_shape_over_the_contexts(tmp_path, name):
         assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, (name, f)
     line = [l for l in r.stderr.decode().splitlines() if l.startswith("TIMING devices_used")]
     assert line and line[0].split()[2] == "2", r.stderr.decode()
-    assert line[0].split()[4] == ("windows" if name == "s300_default" else "columns")
+    assert line[0].split()[4] == "columns"           # (round 4: the engine derives what a hifiasm-shaped stream allows by itself)
+    assert ("derived by the engine" in line[0]) == (name != "s300_nonsym_shuffled")
 
 
-def test_cli_many_concatenated_files(tmp_path):
+@pytest.mark.parametrize("prepare", [False, True])
+def test_cli_many_concatenated_files(tmp_path, prepare):
     """Six PAFs concatenated (each grouped by query): more sorted runs than the pileup kernels take.  The CLI still hands the
     stream over in grouped form -- the engine merges the runs on the device -- and the files equal those of the same records
     in one sorted file, which the golden case pins to the reference."""
@@ -175,14 +177,15 @@ def test_cli_many_concatenated_files(tmp_path):
     # (record 0 stays first: it decides the symmetric flag, chop.hpp:171-184)
     write_paf(tmp_path / "overlaps.paf", names, cols[0], *[c[order] for c in cols[1:]])
     r = subprocess.run([RAFT] + meta["args"] + ["reads.fa", "overlaps.paf"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       timeout=300, env=dict(os.environ, RAFT_TIMING="1"))
+                       timeout=300, env=dict(os.environ, RAFT_TIMING="1", **({"RAFT_CLI_PREPARE": "1"} if prepare else {})))
     assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
-    assert "input windows" in r.stderr.decode()
+    assert ("input windows" if prepare else "input columns") in r.stderr.decode()
     for f, digest in meta["md5"].items():
         assert md5(open(tmp_path / ("out." + f), "rb").read()) == digest, f
 
 
-@pytest.mark.parametrize("knob,form", [("RAFT_NO_WINDOWS", "grouped"), ("RAFT_NO_GROUPED", "columns"), (None, "windows"), ("RAFT_NO_DELTA4", "windows")])
+@pytest.mark.parametrize("knob,form", [("RAFT_NO_WINDOWS", "grouped"), ("RAFT_NO_GROUPED", "columns"), (None, "windows"), ("RAFT_NO_DELTA4", "windows"),
+                                       ("default", "columns (offsets and window records derived by the engine)")])
 @pytest.mark.parametrize("name", ["s300_default", "s60_ultralong"])
 def test_cli_input_forms(tmp_path, name, knob, form):
     """The three forms the CLI hands a symmetric hifiasm-shaped PAF over in -- window records (default), coordinate columns
@@ -193,8 +196,10 @@ def test_cli_input_forms(tmp_path, name, knob, form):
     write_fasta(tmp_path / "reads.fa", names, cols[0])
     write_paf(tmp_path / "overlaps.paf", names, *cols)
     env = dict(os.environ, RAFT_TIMING="1")
-    if knob:
-        env[knob] = "1"
+    if knob != "default":
+        env["RAFT_CLI_PREPARE"] = "1"                 # (the forms prepared by the host library in front of the engine; the default hands over the plain columns)
+        if knob:
+            env[knob] = "1"
     r = subprocess.run([RAFT] + meta["args"] + ["reads.fa", "overlaps.paf"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
     assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
     assert strip_timing(r.stdout.decode()) == meta["stdout"]

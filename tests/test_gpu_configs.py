@@ -56,7 +56,7 @@ def test_engine_vs_reference_binary_fuzz():
         p, cols, exp = ref_fuzz_case(i)
         eng = engine.Engine(p, device=0)
         try:
-            eng.set_tuning(0, i % 3 == 2, (-1, 1, 2)[i % 3] if i % 3 != 2 else -1)
+            eng.set_tuning(0, i % 3 == 2, (-1, 1, 0)[i % 3] if i % 3 != 2 else -1)
             eng.run_host(*cols)
             s = eng.finish()
             assert_matches_ref_fuzz(engine_result(eng, s), exp, p, f"ref_fuzz case {i}")
@@ -522,7 +522,7 @@ def test_recut_tiles_and_pieces(seed, mode, monkeypatch):
         assert want["rep_s"].size > 20
         eng = engine.Engine(p, device=0)
         try:
-            eng.set_tuning(0, False, 2 if mode == "variant2" else -1)
+            eng.set_tuning(0, False, -1 if mode == "default" else 0)      # (the fallbacks belong to round 3's workgroup-tile kernel; "default": the wave kernel's own pieces)
             eng.run_host(rl, qid, a, b, None, None, None)
             s = eng.finish()
             assert_same_result(engine_result(eng, s), want, f"seed {seed} {mode} reso {p.reso}")

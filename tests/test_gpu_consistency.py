@@ -38,7 +38,7 @@ def test_pileup_configurations_agree(si, pi):
     o = make_overlaps(device="cuda:0", **SHAPES[si])
     cols = (o.read_len,) + o.columns()
     ref = None
-    for variant, bucket in ((1, False), (0, False), (2, False), (0, True), (4, False)):   # (4: lane-serial rows, pileup_fast.hpp LS)
+    for variant, bucket in ((1, False), (0, False), (5, False), (5, True), (0, True)):   # (5: the wave kernel, the default; 0: round 3's workgroup tiles; 1: the general kernel)
         eng = engine.Engine(PARAMS[pi], device=0)
         try:
             eng.set_tuning(0, bucket, variant)

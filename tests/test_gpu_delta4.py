@@ -70,7 +70,7 @@ def all_forms(eng, run, want, what, direct=True):
 
 
 @pytest.mark.parametrize("name", sorted(MAN["synthetic"]))
-@pytest.mark.parametrize("variant", [-1, 1, 2, 4])
+@pytest.mark.parametrize("variant", [-1, 0, 1])
 def test_golden_cases_delta4(name, variant):
     from raft_amd import engine
     z = np.load(os.path.join(GOLDEN, name + ".npz"))

@@ -112,12 +112,12 @@ def random_case(seed, n_lo=1, n_hi=60, len_hi=3000, m_hi=600):
 def test_random_small_vs_oracle(eng_mod, seed):
     p, cols = random_case(seed)
     want = oracle_run(p, *cols)
-    for tile, bucket, variant in ((0, False, -1), (32, False, seed % 5), (0, True, (seed + 2) % 5), (200, False, (seed + 3) % 5)):
+    for tile, bucket, variant in ((0, False, -1), (32, False, (0, 1, 3, 5)[seed % 4]), (0, True, (0, 1, 3, 5)[(seed + 2) % 4]), (200, False, (0, 1, 3, 5)[(seed + 3) % 4])):
         got, s = run_engine(eng_mod, p, cols, tile_bins=tile, force_bucket=bucket, variant=variant)
         assert_same_result(got, want, f"seed {seed} tile {tile} bucket {bucket} variant {variant}")
 
 
-@pytest.mark.parametrize("variant", range(5))
+@pytest.mark.parametrize("variant", [0, 1, 3, 5])
 @pytest.mark.parametrize("name", ["s60_ultralong", "s200_smallparams", "s300_default", "edge_reads"])
 def test_golden_cases_all_kernel_variants(eng_mod, name, variant):
     p, cols, exp, meta = load_case(name)
@@ -277,7 +277,7 @@ def _fast_kernel_cases():
 FAST_CASES = _fast_kernel_cases()
 
 
-@pytest.mark.parametrize("variant", range(5))
+@pytest.mark.parametrize("variant", [0, 1, 3, 5])
 @pytest.mark.parametrize("name", sorted(FAST_CASES))
 def test_fast_kernel_paths(eng_mod, name, variant):
     p, cols = FAST_CASES[name]

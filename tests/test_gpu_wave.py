@@ -1,0 +1,189 @@
+"""GPU: the wave kernel (pileup_wave.hpp: one wave per tile, 16-bit difference array, workers that cut their own tiles) -- what is
+specific to it, beyond the parity, configuration and consistency suites that run with it as the default pileup:
+
+* against the int32 kernels (variants 0 and 1) on shapes that stress its tile cutting: very many short reads (63 per tile),
+  reads longer than a tile (pieces), dense stretches (tiles shrink to the reads whose records are in the slots; records
+  behind the slots are streamed), a stream of four runs (columns only), reads without records or windows;
+* the 16-bit bound: a tile with 2^15 or more intervals refutes the pass (kErrDeep) and the result comes from the int32
+  kernels -- same arrays as the oracle;
+* cut points written by the pass itself (raft_hip_set_emit_cuts) or by the first fetch: the same;
+* the host pipeline deriving offsets and window records from the plain columns chunk by chunk (raft_hip_run_multi,
+  symmetric_mode = 1): the oracle's arrays, and every input the derivation gives up on (ids out of place, a negative
+  coordinate, a read beyond 65,535 windows) still ends as the one-piece pass ends.
+Reference semantics: repeat.hpp:28-79, :111-168; chop.hpp:225-246.
+"""
+import numpy as np
+import pytest
+from raft_testlib import RaftParams, assert_same_result, oracle_run
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_result(eng, cols):
+    eng.run_host(*cols)
+    s = eng.finish()
+    got = eng.fetch()
+    got.update(symmetric=s.symmetric, high_cov=s.high_cov, total_coverage=s.total_coverage, total_windows=s.total_windows,
+               total_repeat_length=s.total_repeat_length, total_read_length=s.total_read_length)
+    return got, s
+
+
+SHAPES = [
+    dict(n_reads=30_000, mean_len=1200.0, coverage=15.0, seed=201, min_len=100, sigma=0.8),        # ~150 reads per 4096 windows: the 63-read limit
+    dict(n_reads=3_000, mean_len=400_000.0, coverage=30.0, seed=202, min_len=50_000, max_len=2_000_000, sigma=0.6),   # pieces
+    dict(n_reads=8_000, mean_len=25_000.0, coverage=300.0, seed=203),                              # dense: records far beyond the slots
+    dict(n_reads=20_000, mean_len=20_000.0, coverage=30.0, seed=204, n_families=2000, copies=5),
+]
+
+
+@pytest.mark.parametrize("si", range(len(SHAPES)))
+@pytest.mark.parametrize("reso", [50, 7])
+def test_wave_kernel_equals_int32_kernels(si, reso):
+    import torch
+    from raft_amd import engine
+    from raft_amd.synth import make_overlaps
+    if reso == 7 and si == 1:
+        pytest.skip("2 Mb reads at reso 7 exceed a window record's 16 bits: covered with columns in test_gpu_configs")
+    o = make_overlaps(device="cuda:0", **SHAPES[si])
+    p = RaftParams(est_cov=int(SHAPES[si]["coverage"]), reso=reso)
+    cols = (o.read_len,) + o.columns()
+    ref = None
+    for variant, bucket in ((0, False), (5, False), (5, True), (1, False)):
+        eng = engine.Engine(p, device=0)
+        try:
+            eng.set_tuning(0, bucket, variant)
+            eng.run_device(*cols)
+            s = eng.finish()
+            out = {k: v.clone() for k, v in eng.outputs_device().items()}
+            tot = (s.symmetric, s.n_bins, s.n_repeats, s.n_cuts, s.n_fragments, s.total_coverage, s.total_repeat_length, s.total_read_length)
+        finally:
+            eng.close()
+        if ref is None:
+            ref = (out, tot)
+            continue
+        assert tot == ref[1], (SHAPES[si], variant, bucket)
+        for k in out:
+            assert torch.equal(out[k], ref[0][k]), (SHAPES[si], variant, bucket, k)
+
+
+def test_wave_kernel_four_runs_and_window_records():
+    """Columns in four sorted runs (a PAF concatenated from two pairs of files), and the same stream as two runs of window records."""
+    from raft_amd import engine, hostio
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(6000, seed=31)
+    cols = [c.numpy() for c in (o.read_len,) + o.columns()]
+    n = len(cols[1])
+    cut = [0, n // 5, o.n_cis, (o.n_cis + n) // 2, n]          # each part stays sorted by query id: four runs
+    p = RaftParams(est_cov=30)
+    want = oracle_run(p, *cols)
+    eng = engine.Engine(p, device=0)
+    eng.set_tuning(0, False, 5)
+    got, s = engine_result(eng, cols)
+    assert_same_result(got, want, "two runs, columns")
+    # four runs: split each file in two and interleave the halves' order inside the files
+    order = np.concatenate([np.arange(cut[1], cut[2]), np.arange(cut[0], cut[1]), np.arange(cut[3], cut[4]), np.arange(cut[2], cut[3])])
+    c4 = [cols[0]] + [c[order] for c in cols[1:]]
+    want4 = oracle_run(p, *c4)
+    got4, s4 = engine_result(eng, c4)
+    assert s4.n_segments in (3, 4) and s4.interval_path == 0      # (more runs than two: the four-run instantiation)
+    assert_same_result(got4, want4, "four runs, columns")
+    eng.close()
+    ps = RaftParams(est_cov=30, symmetric_mode=1)
+    eng = engine.Engine(ps, device=0)
+    eng.set_tuning(0, False, 5)
+    off = hostio.group_offsets(o.n_reads, cols[1])
+    win = hostio.pack_windows(cols[2], cols[3], 50)
+    for width in (4, 1, 8):
+        eng.set_output_width(width)
+        eng.run_host_windows(cols[0], off, win)
+        s = eng.finish()
+        g = eng.fetch()
+        g.update(symmetric=1, high_cov=s.high_cov, total_coverage=s.total_coverage, total_windows=s.total_windows,
+                 total_repeat_length=s.total_repeat_length, total_read_length=s.total_read_length)
+        assert_same_result(g, want, f"window records, width {width}")
+    eng.close()
+
+
+def test_a_tile_too_deep_for_sixteen_bits_falls_back_to_the_int32_kernels():
+    """40,000 intervals on one read: the wave kernel's tile refutes the pass (kErrDeep) and raft_hip_finish runs it again with
+    the int32 kernels -- coverage 40,000 in the middle of the read, as the oracle has it."""
+    from raft_amd import engine
+    rng = np.random.default_rng(9)
+    rl = np.array([30000, 12000, 50000, 8000], np.int32)
+    m = 40000
+    qid = np.concatenate([np.zeros(50, np.int32), np.full(m, 2, np.int32), np.full(30, 3, np.int32)])
+    qs = np.zeros(qid.size, np.int32); qe = np.zeros(qid.size, np.int32)
+    qs[50:50 + m] = rng.integers(0, 20000, m); qe[50:50 + m] = qs[50:50 + m] + rng.integers(20000, 30000, m)
+    qs[:50] = rng.integers(0, 10000, 50); qe[:50] = qs[:50] + 5000
+    qs[50 + m:] = 100; qe[50 + m:] = 7000
+    p = RaftParams(est_cov=30, symmetric_mode=1)
+    want = oracle_run(p, rl, qid, qs, qe, qid, qs, qe)      # (self overlaps: the query sides are all there is, whatever the flag)
+    want["symmetric"] = 1
+    assert want["cov"].max() >= 32768
+    eng = engine.Engine(p, device=0)
+    eng.set_tuning(0, False, 5)
+    for _ in range(2):                                   # (the context is itself again after the fallback)
+        got, s = engine_result(eng, (rl, qid, qs, qe))
+        assert_same_result(got, want, "deep tile")
+    eng.close()
+
+
+def test_cut_points_in_the_pass_or_on_demand():
+    from raft_amd import engine
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(4000, seed=77)
+    cols = [c.numpy() for c in (o.read_len,) + o.columns()]
+    p = RaftParams(est_cov=30)
+    want = oracle_run(p, *cols)
+    for on in (True, False):
+        eng = engine.Engine(p, device=0)
+        eng.set_emit_cuts(on)
+        got, s = engine_result(eng, cols)
+        assert_same_result(got, want, f"emit_cuts={on}")
+        assert s.n_cuts == want["cuts"].size
+        eng.close()
+
+
+def test_pipeline_derives_offsets_and_window_records_from_the_columns():
+    from raft_amd import engine, hostio
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(9000, seed=41)
+    cols = [c.numpy() for c in (o.read_len,) + o.columns()]
+    p = RaftParams(est_cov=30, symmetric_mode=1)
+    want = oracle_run(RaftParams(est_cov=30), *cols)
+    eng = engine.Engine(p, device=0)
+    other = engine.Engine(p, device=0)
+
+    def check(res, s, what):
+        if "cov_nib" in res:
+            cov = hostio.unpack_coverage_d4(s.n_bins, res["cov_nib"], res["cov_anchor"], res["exc_index"], res["exc_value"])
+        else:
+            cov = hostio.unpack_coverage(res["cov8"], res["exc_index"], res["exc_value"])
+        assert np.array_equal(cov, want["cov"]), what
+        for k in ("cov_offset", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
+            assert np.array_equal(res[k], want[k]), (what, k)
+        assert (s.n_fragments, s.total_coverage, s.total_repeat_length) == (want["frag_begin"].size, want["total_coverage"], want["total_repeat_length"])
+    for width in (1, 8):
+        for n_chunks, others in ((3, None), (7, None), (5, [other]), (23, [other])):
+            out = eng.host_output_buffers(cols[0], pinned=False, width=width)
+            res, s = eng.run_pipelined(cols[0], cols[1], cols[2], cols[3], n_chunks=n_chunks, out=out, others=others)
+            check(res, s, f"width {width} chunks {n_chunks} ctx {1 + len(others or [])}")
+    # what the derivation gives up on ends as the one-piece pass ends
+    c2 = [c.copy() for c in cols]
+    for c in c2[1:]:
+        c[[100, 5000]] = c[[5000, 100]]                                            # two records out of place: still the right result
+    res, s = eng.run_pipelined(c2[0], c2[1], c2[2], c2[3], n_chunks=4)
+    one = engine.Engine(p, device=0)
+    one.run_host(c2[0], c2[1], c2[2], c2[3]); s1 = one.finish(); g1 = one.fetch()
+    assert np.array_equal(g1["cov"], want["cov"])
+    assert np.array_equal(hostio.unpack_coverage(res["cov8"], res["exc_index"], res["exc_value"]), g1["cov"]) and s.n_fragments == s1.n_fragments
+    b2 = cols[2].copy(); b2[777] = -5                                              # a negative coordinate: the plain entries' code and index
+    with pytest.raises(engine.RaftError) as e:
+        eng.run_pipelined(cols[0], cols[1], b2, cols[3], n_chunks=4)
+    assert e.value.code == engine.ERR_COORD and e.value.index == 777
+    rl2 = cols[0].copy(); rl2[5] = 65_536 * 50 + 10                                # a read of more windows than a window record's 16 bits hold
+    res, s = eng.run_pipelined(rl2, cols[1], cols[2], cols[3], n_chunks=4)
+    one.run_host(rl2, cols[1], cols[2], cols[3]); s1 = one.finish(); g1 = one.fetch()
+    assert np.array_equal(hostio.unpack_coverage(res["cov8"], res["exc_index"], res["exc_value"]), g1["cov"]) and s.n_bins == s1.n_bins
+    for e_ in (eng, other, one):
+        e_.close()
