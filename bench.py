@@ -364,12 +364,17 @@ def main():
     ap.add_argument("--strong", action="store_true", help="ONE set cut into --gpus contiguous read ranges (BASELINE configs[3] without the exchange)")
     ap.add_argument("--presplit", action="store_true", help="BASELINE configs[3]: --strong with the records pre-split across ranks, all-to-all-v in the step")
     ap.add_argument("--no-strong-leg", action="store_true", help="weak multi-GPU runs: skip the strong-scaling leg")
+    ap.add_argument("--shuffle", action="store_true", help="the records in random order (create_pileup's bucketing in full: the counting-sort path); never the headline")
+    ap.add_argument("--nonsym", action="store_true", help="a non-symmetric PAF (one record per pair: target sides are piled up too, chop.hpp:165-169), shuffled; never the headline")
     ap.add_argument("--tile-bins", type=int, default=0)
     ap.add_argument("--force-bucket", action="store_true")
     ap.add_argument("--variant", type=int, default=-1, help="pileup kernel variant (engine.hip kVariants), -1 = default")
     args = ap.parse_args()
     if args.presplit:
         args.strong = True
+    if args.shuffle or args.nonsym:                   # (general streams: the plain columns only, no grouped / window / host-to-host legs)
+        args.input = "columns"
+        args.no_packed_leg = args.no_six_column_leg = args.no_e2e = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -409,6 +414,9 @@ def main():
     torch.cuda.set_device(local)
 
     gen_kw, est_cov, workload_text = WORKLOADS[args.workload]
+    if args.shuffle or args.nonsym:
+        gen_kw = dict(gen_kw, shuffle=True, symmetric=not args.nonsym)
+        workload_text += "; records SHUFFLED" + (", NON-symmetric (one record per pair)" if args.nonsym else "")
     n_reads = args.reads or DEFAULT_READS[args.workload]
     p = RaftParams(est_cov=est_cov)
     p_sym = RaftParams(**dict(p.__dict__, symmetric_mode=1))
@@ -607,6 +615,8 @@ def main():
         # ---- self-check of the last timed pass (outside the clock): size-independent invariants of the outputs
         out = eng.outputs_device()
         touched = ((o.qe.long() - 1) // p.reso - o.qs.long() // p.reso + 1).clamp(min=0)
+        if args.nonsym:                               # (target sides of records whose two reads differ are piled up as well)
+            touched = torch.cat([touched, (((o.te.long() - 1) // p.reso - o.ts.long() // p.reso + 1).clamp(min=0))[o.tid != o.qid]])
         fo, fb, fe = out["frag_offset"], out["frag_begin"], out["frag_end"]
         same = out["frag_read"][1:] == out["frag_read"][:-1]
         check = {"sum_cov_equals_windows_touched": int(out["cov"].sum(dtype=torch.int64)) == int(touched.sum()) == s.total_coverage,

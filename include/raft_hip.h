@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_ABI_VERSION 6
+#define RAFT_HIP_ABI_VERSION 7
 
 /* error codes (0..5 are shared with oracle/raft_oracle.h) */
 enum {
@@ -291,7 +291,15 @@ typedef struct raft_hip_host_outputs {
  * call falls back for any other input (and for any chunk that reports a data error, so that errors are reported
  * exactly as by raft_hip_run_host).  tid/ts/te may be NULL when symmetric_mode = 1.  RAFT_HIP_ERR_TOO_LARGE: a
  * capacity in `out` was too small (size them by the bounds above).  Device-resident outputs of the context are NOT valid
- * after this call (raft_hip_fetch / raft_hip_outputs_device return RAFT_HIP_ERR_STATE). */
+ * after this call (raft_hip_fetch / raft_hip_outputs_device return RAFT_HIP_ERR_STATE).
+ * Derived input (ABI 7).  With symmetric_mode = 1, a stream of one or two sorted runs and reads below 65,535 windows, the
+ * engine's host side derives -- chunk by chunk, on threads of its own, beside the uploads of the chunks before -- what
+ * raft_hip_run_multi_windows would have to be handed: where every read's records begin (from qid) and the records as
+ * window records (from qs / qe; repeat.hpp:69-72 uses nothing else of an interval).  4 bytes per record cross the link
+ * instead of 12, the pass needs no look at the stream, and the caller prepares nothing: this is the call SURVEY.md §8(d)'s
+ * clock brackets ("int32 SoA in pinned host memory ... to outputs on the host").  The ids are checked on the way; anything
+ * the derivation cannot take (ids out of place, a negative coordinate, a window beyond 16 bits) sends the job to the
+ * one-piece pass over the columns, which reports or handles it as before.  RAFT_NO_DERIVE=1 uploads the columns as they are. */
 int  raft_hip_run_pipelined(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
                             const int32_t *qid, const int32_t *qs, const int32_t *qe,
                             const int32_t *tid, const int32_t *ts, const int32_t *te,
