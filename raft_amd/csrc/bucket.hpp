@@ -40,16 +40,19 @@ struct InspectOut {            // device words written by inspect_kernel
 __device__ __forceinline__ void inspect_one(long long i, int32_t q, int32_t prev, int32_t n_reads, int detect_sym,
                                             const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts,
                                             const int32_t *te, int32_t q0, int32_t t0, int32_t qs0, int32_t qe0,
-                                            int32_t ts0, int32_t te0, InspectOut *out)
+                                            int32_t ts0, int32_t te0, InspectOut *out, bool &many)
 {
     if (q < 0 || q >= n_reads) {
         atomicOr(&out->err_flags, kErrReadId);
         atomicMin((unsigned long long *)&out->err_index, (unsigned long long)i);
     }
     if (i > 0) {
-        if (q < prev) {
+        // (`many`: this thread has seen the count beyond what anybody asks for -- a shuffled stream has a descent at every other
+        // record, and 1.5e8 returning atomics on the one word were 50 ms of a pass)
+        if (q < prev && !many) {
             const int slot = atomicAdd(&out->n_desc, 1);
             if (slot < kMaxSeg) out->desc_pos[slot] = i;
+            else many = true;
         }
         if (detect_sym && q == t0) {
             if (tid[i] == q0 && ts[i] == qs0 && te[i] == qe0 && qs[i] == ts0 && qe[i] == te0) out->sym_found = 1;
@@ -70,19 +73,20 @@ __global__ __launch_bounds__(256) void inspect_kernel(long long n_rec, int32_t n
     const long long tail = head + (n_groups << 2);
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long t0i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool many = *(volatile int32_t *)&out->n_desc > kMaxSeg;
     for (long long g = t0i; g < n_groups; g += stride) {
         const long long i = head + (g << 2);
         const int4 v = *reinterpret_cast<const int4 *>(qid + i);
         const int32_t prev = i > 0 ? qid[i - 1] : 0;
-        inspect_one(i + 0, v.x, prev, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out);
-        inspect_one(i + 1, v.y, v.x, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out);
-        inspect_one(i + 2, v.z, v.y, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out);
-        inspect_one(i + 3, v.w, v.z, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out);
+        inspect_one(i + 0, v.x, prev, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out, many);
+        inspect_one(i + 1, v.y, v.x, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out, many);
+        inspect_one(i + 2, v.z, v.y, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out, many);
+        inspect_one(i + 3, v.w, v.z, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out, many);
     }
     if (blockIdx.x == 0) {
         for (long long i = threadIdx.x; i < head + (n_rec - tail); i += blockDim.x) {
             const long long j = i < head ? i : tail + (i - head);
-            inspect_one(j, qid[j], j > 0 ? qid[j - 1] : 0, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out);
+            inspect_one(j, qid[j], j > 0 ? qid[j - 1] : 0, n_reads, detect_sym, qs, qe, tid, ts, te, q0, t0, qs0, qe0, ts0, te0, out, many);
         }
     }
 }
@@ -361,6 +365,54 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(long long n_rec, in
                 b_rid[d] = t; b_s[d] = ts[i]; b_e[d] = te[i];
             }
         }
+    }
+}
+
+// ---- bucketing by read id for streams of any order: sort, do not scatter (round 4) --------------------------------------------
+// The counting sort above -- one atomic per record on its read's counter, then a 12-byte write per record wherever its read's
+// bucket lies -- is fine where the stream is almost sorted and took 87 ms for 2.9e8 SHUFFLED records (every write a partial
+// line somewhere in 3.5 GB).  For large inputs the intervals are sorted instead: expand_sides_kernel writes (read id,
+// start | end << 32) per side -- query sides, and target sides of records whose two reads differ while the PAF is not
+// symmetric (chop.hpp:165-169); sides that do not exist get the key n_reads and sort behind everything -- a radix sort by
+// the id's bits (engine.hip: rocprim's device radix sort, the library primitive for exactly this), and unzip_sorted_kernel
+// writes the three columns the pileup kernels read plus where every read's intervals begin.
+__global__ __launch_bounds__(256) void expand_sides_kernel(long long n_rec, int32_t n_reads, int symmetric, const int32_t *qid, const int32_t *qs, const int32_t *qe,
+                                                           const int32_t *tid, const int32_t *ts, const int32_t *te, uint32_t *key, unsigned long long *val,
+                                                           int32_t *err_flags, long long *err_index)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (long long)gridDim.x * blockDim.x) {
+        const int q = qid[i];
+        const bool okq = q >= 0 && q < n_reads;
+        bool bad = !okq;
+        key[i] = okq ? (uint32_t)q : (uint32_t)n_reads;
+        val[i] = (unsigned long long)(uint32_t)qs[i] | ((unsigned long long)(uint32_t)qe[i] << 32);
+        if (!symmetric) {
+            const int t = tid[i];
+            const bool okt = t >= 0 && t < n_reads;
+            bad = bad || !okt;
+            key[n_rec + i] = (okt && t != q) ? (uint32_t)t : (uint32_t)n_reads;
+            val[n_rec + i] = (unsigned long long)(uint32_t)ts[i] | ((unsigned long long)(uint32_t)te[i] << 32);
+        }
+        if (bad) {
+            atomicOr(err_flags, kErrReadId);
+            atomicMin((unsigned long long *)err_index, (unsigned long long)i);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void unzip_sorted_kernel(long long n_ent, int32_t n_reads, const uint32_t *__restrict__ key, const unsigned long long *__restrict__ val,
+                                                           int32_t *__restrict__ b_rid, int32_t *__restrict__ b_s, int32_t *__restrict__ b_e, long long *__restrict__ off)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_ent; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t k = key[i];
+        const long long prev = i == 0 ? -1 : (long long)key[i - 1];
+        if ((long long)k != prev)
+            for (long long r = prev + 1; r <= (long long)k; ++r) off[r] = i;       // (reads without intervals begin where the next one does; r == n_reads: the end)
+        if (k < (uint32_t)n_reads) {
+            const unsigned long long v = val[i];
+            b_rid[i] = (int32_t)k; b_s[i] = (int32_t)(uint32_t)v; b_e[i] = (int32_t)(uint32_t)(v >> 32);
+        }
+        if (i == n_ent - 1) for (long long r = (long long)k + 1; r <= (long long)n_reads; ++r) off[r] = n_ent;
     }
 }
 

@@ -230,6 +230,7 @@ struct raft_hip_ctx {
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
+    DevBuf rs_k0, rs_k1, rs_v0, rs_v1;   // general streams, large inputs: (read id, start | end << 32) per side, before and after the radix sort
     DevBuf samples;                   // up to kSamples + 2 read ids at evenly spaced records (guess_runs_kernel): coarse index
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
     DevBuf dbg;                       // diagnostic variant only
@@ -409,7 +410,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
     DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
-                     &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->in_len,
+                     &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1, &c->in_len,
                      &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->exc_idx2, &c->exc_val2, &c->sort_tmp, &c->exc_pidx, &c->exc_pval, &c->exc_tile_n, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -811,6 +812,28 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         HIP_TRY(c, c->b_rid.ensure((size_t)cap_iv * 4));
         HIP_TRY(c, c->b_s.ensure((size_t)cap_iv * 4));
         HIP_TRY(c, c->b_e.ensure((size_t)cap_iv * 4));
+        // large inputs are sorted, not scattered (bucket.hpp): the counting sort's random 12-byte writes took 87 ms for 2.9e8
+        // shuffled records; it stays for small inputs, where its three launches cost less than the sort's
+        // (... and for a symmetric stream of a few sorted runs that is sent here all the same -- force_bucket, A/B: its scatter is local)
+        const bool radix = cap_iv >= (1LL << 20) && (!symmetric || n_desc + 1 > kMaxSeg) && getenv("RAFT_NO_RADIX_SORT") == nullptr;
+        if (radix) {
+            HIP_TRY(c, c->rs_k0.ensure((size_t)cap_iv * 4)); HIP_TRY(c, c->rs_k1.ensure((size_t)cap_iv * 4));
+            HIP_TRY(c, c->rs_v0.ensure((size_t)cap_iv * 8)); HIP_TRY(c, c->rs_v1.ensure((size_t)cap_iv * 8));
+            const unsigned g1 = (unsigned)std::min<long long>((n_rec + 255) / 256, 256 * 32);
+            hipLaunchKernelGGL(expand_sides_kernel, dim3(g1), dim3(256), 0, st, (long long)n_rec, n_reads, symmetric, d_qid, d_qs, d_qe, d_tid, d_ts, d_te,
+                               c->rs_k0.as<uint32_t>(), c->rs_v0.as<unsigned long long>(), &ctrl->err_flags, &ctrl->err_index);
+            int bits = 1;
+            while (bits < 32 && (1LL << bits) <= N) ++bits;               // keys 0 .. n_reads (the sides that do not exist)
+            size_t tmp = 0;
+            HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
+                                                 c->rs_v1.as<unsigned long long>(), (size_t)cap_iv, 0u, (unsigned)bits, st));
+            HIP_TRY(c, c->sort_tmp.ensure(tmp));
+            HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
+                                                 c->rs_v1.as<unsigned long long>(), (size_t)cap_iv, 0u, (unsigned)bits, st));
+            const unsigned g2 = (unsigned)std::min<long long>((cap_iv + 255) / 256, 256 * 32);
+            hipLaunchKernelGGL(unzip_sorted_kernel, dim3(g2), dim3(256), 0, st, cap_iv, n_reads, c->rs_k1.as<uint32_t>(), c->rs_v1.as<unsigned long long>(),
+                               c->b_rid.as<int32_t>(), c->b_s.as<int32_t>(), c->b_e.as<int32_t>(), c->b_off.as<long long>());
+        } else {
         HIP_TRY(c, hipMemsetAsync(c->b_cnt.p, 0, (size_t)std::max(N, 1LL) * 4, st));
         const unsigned grid = (unsigned)std::min<long long>((n_rec + 255) / 256, 8192);
         hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads, symmetric, d_qid,
@@ -824,6 +847,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads, symmetric, d_qid,
                            d_qs, d_qe, d_tid, d_ts, d_te, c->b_off.as<long long>(), c->b_cnt.as<int32_t>(),
                            c->b_rid.as<int32_t>(), c->b_s.as<int32_t>(), c->b_e.as<int32_t>());
+        }
         sb.n_seg = 1; sb.start[0] = 0; sb.start[1] = cap_iv;
         seg_end_dev = c->b_off.as<long long>() + N;   // the true interval count lives at b_off[N]
         pa.iv_rid = c->b_rid.as<int32_t>(); pa.iv_s = c->b_s.as<int32_t>(); pa.iv_e = c->b_e.as<int32_t>(); pa.n_seg = 1;
