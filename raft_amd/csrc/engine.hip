@@ -653,9 +653,10 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     int Q = c->tile_q ? std::min(c->tile_q, pv.cap) : pv.cap - pv.short_max;
     // (wave tiles: the quantum only says which thread of tile_desc_kernel walks which reads -- four tiles' worth each)
     if (wave) {
-        // four tiles' worth, but never so few quantum tiles that workers stay without one (a 50 k-read set)
+        // four tiles' worth, but never so few quantum tiles that workers stay without one (a 50 k-read set) or that the last draws
+        // of the kernel are a fifth of its duration (an eighth of the human-scale set: two tiles' worth)
         const long long q4 = 4LL * (pv.cap / 128) * 128, q1 = (pv.cap / 128) * 128;
-        Q = c->tile_q ? std::max(256, c->tile_q) : (int)std::max(q1, std::min(q4, (B / (4LL * wave_grid_waves(true))) / 128 * 128));
+        Q = c->tile_q ? std::max(256, c->tile_q) : (int)std::max(q1, std::min(q4, (B / (8LL * wave_grid_waves(true))) / 128 * 128));
     }
     if (!c->tile_q && pv.fast == 1 && N > 0) {
         const double mean_w = (double)B / (double)N;
