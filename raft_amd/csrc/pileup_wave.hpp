@@ -258,6 +258,10 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             return c;
         };
         cur.more = 0; cur.n_total = 0;
+        bool defer = false;
+        int avail_s[NSEG];
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) { avail_s[s] = pend[s] - ts.pos[s]; open_run[s] = false; }
         if constexpr (IN == 0) {
             int rb_fit = r_b;
 #pragma unroll
@@ -283,48 +287,37 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 c = min(max(c, 0), avail);       // (offsets that disagree with the range: the order check below refutes the pass)
             } else {
                 c = cur.cnt[s];
-                if (open_run[s]) {
-                    // every slot is the tile's and the run goes on: the end lies further on
-                    int base = ts.pos[s] + 64 * ITER;                         // (ids before `base` are below r_b)
-                    for (;;) {
-                        const long long pj = (long long)base + 64LL * lane;
-                        const int v = pj < pend[s] ? a.iv_rid[pj] : 0x7fffffff;
-                        const int t = (int)__popcll(__ballot(v < r_b));
-                        if (t == 64) { base += 64 * 63 + 1; continue; }       // (the last probe, too, is the tile's)
-                        int e = base;
-                        if (t > 0) {
-                            const long long p2 = (long long)base + 64LL * (t - 1) + 1 + lane;
-                            const int v2 = p2 < pend[s] ? a.iv_rid[p2] : 0x7fffffff;
-                            e = base + 64 * (t - 1) + 1 + (int)__popcll(__ballot(v2 < r_b));
-                        }
-                        c = e - ts.pos[s];
-                        break;
-                    }
-                }
+                // (an open run: every slot is the tile's and the run goes on -- the interval phase streams on until an id says
+                // stop, and only then is the next tile's first record known: its loads go out late, see `defer`)
+                if (open_run[s]) { cur.more = 1; defer = true; }
             }
             cur.cnt[s] = c;
             cur.n_total += c;
             if (c > 64 * ITER) cur.more = 1;
         }
-        // ---- where the next tile begins; the end of the range
+        // ---- where the next tile begins; the end of the range.  Normally planned here, so that the next tile's loads go out ahead
+        // of the interval phase that hides their latency; a tile with an open run plans it behind its interval phase.
         const bool last_piece = !piece || ts.q + 1 == n_pieces;
         bool have_next = true;
-        if (!last_piece) { nts = ts; nts.q = ts.q + 1; }
-        else {
-            nts.r = r_b; nts.q = 0; nts.g = ts.g + (piece ? nb_read : cur.nwin);
+        auto plan_next = [&]() {
+            if (!last_piece) { nts = ts; nts.q = ts.q + 1; }
+            else {
+                nts.r = r_b; nts.q = 0; nts.g = ts.g + (piece ? nb_read : cur.nwin);
 #pragma unroll
-            for (int s = 0; s < NSEG; ++s) nts.pos[s] = ts.pos[s] + cur.cnt[s];
-            if (r_b == R_end) {
-                // the range is done: every record of it has been handed to a tile, or the stream is not what the pass assumed
-                bool left = false;
+                for (int s = 0; s < NSEG; ++s) nts.pos[s] = ts.pos[s] + cur.cnt[s];
+                if (r_b == R_end) {
+                    // the range is done: every record of it has been handed to a tile, or the stream is not what the pass assumed
+                    bool left = false;
 #pragma unroll
-                for (int s = 0; s < NSEG; ++s) left |= nts.pos[s] != pend[s];
-                if (left && lane == 0) atomicOr(a.err_flags, kErrOrder);
-                have_next = next_range(nts);
+                    for (int s = 0; s < NSEG; ++s) left |= nts.pos[s] != pend[s];
+                    if (left && lane == 0) atomicOr(a.err_flags, kErrOrder);
+                    have_next = next_range(nts);
+                }
             }
-        }
-        // ---- the next tile's loads go out first: the interval phase below hides their latency
-        if (have_next) issue(nts, gn, rdn);
+            if (have_next) issue(nts, gn, rdn);
+        };
+        if (!last_piece) defer = false;          // (the next piece begins where this one does: nothing to wait for)
+        if (!defer) plan_next();
         int tile_id = 0;
         if (D4) tile_id = next_d4_id();
         (void)tile_id;
@@ -334,7 +327,6 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         const int off0 = (int)(cur.g_lo - a0);
         const int t_end = off0 + cur.nwin;
         const int rows = (t_end + 1 + 511) >> 9;
-        if (cur.n_total >= 32768) { if (lane == 0) atomicOr(a.err_flags, kErrDeep); }
         // ---- per-read table of this tile
         const int ro = rd.cv - (int)a0;                     // 32-bit wrap-around is exact
         if (lane <= nr) sm.roff[lane] = ro;
@@ -371,21 +363,33 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 const int left = cur.cnt[u % NSEG] - (u / NSEG) * 64;
                 if (left > 0) one(g.rid[u], g.st[u], g.en[u], lane < left);
             }
-            if (cur.more) {                      // records beyond the slots: streamed, the next 64 in flight while these are piled up
+            if (cur.more) {
+                // records behind the slots: streamed until an id at or beyond the tile's last read (or the range's end) says stop,
+                // the next 64 in flight while these are piled up
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) {
+                    if (!open_run[s]) continue;
                     const long long base = (long long)cur.lo[s];
-                    int i0 = ITER * 64;
-                    int rA = 0, sA = 0, eA = 0;
-                    if (i0 + lane < cur.cnt[s]) { rA = (a.iv_rid + base)[i0 + lane]; sA = (a.iv_s + base)[i0 + lane]; eA = (a.iv_e + base)[i0 + lane]; }
-                    while (i0 < cur.cnt[s]) {
+                    const int limit = avail_s[s];
+                    int i0 = ITER * 64, total = cur.cnt[s];
+                    int rA = 0x7fffffff, sA = 0, eA = 0;
+                    if (i0 + lane < limit) { rA = (a.iv_rid + base)[i0 + lane]; sA = (a.iv_s + base)[i0 + lane]; eA = (a.iv_e + base)[i0 + lane]; }
+                    while (i0 < limit) {
                         const int i1 = i0 + 64;
-                        int rB = 0, sB = 0, eB = 0;
-                        if (i1 + lane < cur.cnt[s]) { rB = (a.iv_rid + base)[i1 + lane]; sB = (a.iv_s + base)[i1 + lane]; eB = (a.iv_e + base)[i1 + lane]; }
-                        one(rA, sA, eA, i0 + lane < cur.cnt[s]);
+                        int rB = 0x7fffffff, sB = 0, eB = 0;
+                        if (i1 + lane < limit) { rB = (a.iv_rid + base)[i1 + lane]; sB = (a.iv_s + base)[i1 + lane]; eB = (a.iv_e + base)[i1 + lane]; }
+                        const bool mine = i0 + lane < limit && rA < r_b;           // (sorted: a prefix of the lanes)
+                        const int n = (int)__popcll(__ballot(mine));
+                        one(rA, sA, eA, mine);
+                        total += n;
+                        if (n < 64) break;
                         rA = rB; sA = sB; eA = eB; i0 = i1;
                     }
+                    cur.cnt[s] = total;
                 }
+                cur.n_total = 0;
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) cur.n_total += cur.cnt[s];
             }
             if (__ballot(bad_order) != 0ull && lane == 0) atomicOr(a.err_flags, kErrOrder);
             if (__ballot(bad_any) != 0ull) {         // rare: find the offending records again and report the first index
@@ -463,6 +467,8 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             }
         }
         lane_cov += covsum;
+        if (cur.n_total >= 32768) { if (lane == 0) atomicOr(a.err_flags, kErrDeep); }
+        if (defer) plan_next();                  // (late: these loads are waited for right below, with nothing to hide behind)
 
         // ---- every load issued so far -- the NEXT tile's among them -- must have landed before this tile's first coverage
         // store: vmcnt counts loads and stores in one in-order queue, so a wait placed behind the stores would wait for the
