@@ -74,7 +74,8 @@ DEFAULT_READS = {"hg002": 3_300_000, "ultralong": 400_000, "s50k": 50_000}
 def kernel_source_hash() -> str:
     """Identifies the kernels a counter profile belongs to (profiles/pmc_traffic.json goes stale with them)."""
     h = hashlib.sha1()
-    for f in ("pileup_fast.hpp", "pileup.hpp", "engine.hip", "bucket.hpp", "finalize.hpp", "wave.hpp", "device_scan.hpp"):
+    for f in ("pileup_wave.hpp", "wave_launch.hip", "wave_launch.hpp", "pileup_fast.hpp", "pileup.hpp", "engine.hip", "bucket.hpp", "finalize.hpp", "wave.hpp",
+              "device_scan.hpp", "pack.hpp"):
         with open(os.path.join(ROOT, "raft_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -821,7 +822,7 @@ def main():
                                     + ("records pre-split, one all-to-all-v per step" if args.presplit else "host-routed, no data-path collective") if strong_line
                                     else f"reads x{n_gpus}, independent shards, no data-path collective") + (", ranks share GPUs (gloo check run)" if shared else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": ("pileup_fast_kernel (regular + re-cut tiles)" if args.variant != 1 else "pileup_kernel")
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": ("pileup_wave_kernel" if args.variant in (-1, 5) else ("pileup_fast_kernel (regular + re-cut tiles)" if args.variant != 1 else "pileup_kernel"))
                                    + ("" if args.variant < 0 else f" variant {args.variant}"),
                          "kernel_ms": pile * 1e3, "bytes_algorithmic": bytes_alg,
                          "pass_device_ms": pass_dev * 1e3, "pass_achieved": bytes_alg / pass_dev / 1e9,

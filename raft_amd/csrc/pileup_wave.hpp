@@ -6,8 +6,10 @@
 // executed by four waves per SIMD.  This kernel removes the chains' causes instead of shortening them:
 //   * a tile belongs to ONE wave.  No barrier, no pass A (the carry is a scalar that runs along the wave's rows), no seams
 //     between waves, no double-buffered tables; waves of a SIMD are in unrelated phases of unrelated tiles, so there is
-//     always one that can issue.  Tiles are the groups of whole reads (and the pieces of reads longer than a tile) that
-//     tile_desc_kernel already cuts for windows that do not fit (pileup.hpp `extra`): here EVERY tile is cut that way.
+//     always one that can issue.  A worker streams through a contiguous range of reads and cuts its tiles itself: the longest
+//     run of whole reads whose windows fit the array (a ballot over the reads' offsets), their records by a ballot over the id
+//     slots that have landed; a read longer than the array goes in pieces (joined by finalize_count_kernel).  The only thing
+//     cut in advance are the boundaries of quantum tiles four times a tile's size (tile_desc_kernel): where ranges may begin.
 //   * the difference array holds 16 bits per window, two windows per LDS dword.  +1 / -1 land as ds_add_u32 of
 //     +-1 or +-65536 on the window's dword; the low halves carry a bias of 0x8000 so that they never borrow from the high
 //     ones.  A tile's LDS footprint is a quarter of the int32 window's, which is what lets up to eight waves share a SIMD.
@@ -16,6 +18,10 @@
 //     L in its low and L + H in its high half; two more packed adds give the lane's prefix, the lanes' totals of BOTH
 //     half-rows travel through ONE DPP scan as one 32-bit word, and one packed add per dword puts the start value in.
 //     ~22 vector instructions per 512 windows where the int32 rows took 2 x 20 per 512, half the scans, no carry hand-over.
+//   * loads: the next tile's (per-read table, record slots) go out at the top of an iteration and are waited for once, before
+//     the iteration's first coverage store (vmcnt counts loads and stores in one in-order queue: a wait behind the stores
+//     would wait for the stores); the stores are raw buffer stores of whole 16-byte lanes (the compiler merged plain ones
+//     with the tile edges' element stores into 12 + 4 bytes).
 //   * bound: every intermediate is exact modulo 2^16 and every coverage value must be below 32768.  A tile holds fewer
 //     intervals than that or it refutes the pass (kErrDeep: raft_hip_finish runs the pass again with the int32 kernels).
 // Reference semantics: repeat.hpp:28-79 (profileCoverage), repeat.hpp:111-168 (run scan) -- see pileup.hpp; the run scan
