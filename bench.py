@@ -369,6 +369,8 @@ def main():
     ap.add_argument("--nonsym", action="store_true", help="a non-symmetric PAF (one record per pair: target sides are piled up too, chop.hpp:165-169), shuffled; never the headline")
     ap.add_argument("--tile-bins", type=int, default=0)
     ap.add_argument("--force-bucket", action="store_true")
+    ap.add_argument("--plain-input-memory", action="store_true", help="leave the input columns where torch's allocator (hipMalloc) put them instead of moving them "
+                    "into memory from raft_hip_device_alloc before the clock (see include/raft_hip.h: a pass's time depends on where its buffers lie)")
     ap.add_argument("--variant", type=int, default=-1, help="pileup kernel variant (engine.hip kVariants), -1 = default")
     args = ap.parse_args()
     if args.presplit:
@@ -429,6 +431,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Where the inputs lie.  They are resident in HBM before any clock starts either way; by default they are moved into device
+    # memory from raft_hip_device_alloc first (the engine's placement policy: a virtual range over shuffled 32 MiB chunks) --
+    # with torch's hipMalloc blocks the same binary on the same box measured 2.15 .. 2.6 ms for the pileup kernel depending on
+    # what earlier processes had left behind (tools/variance_probe.sh, tools/membench).
+    mem_ctx = None if args.plain_input_memory else engine.Engine(p, device=local)
+
+    def place(t):
+        return t if mem_ctx is None or t is None or not t.is_cuda or t.numel() == 0 else mem_ctx.device_copy(t.contiguous())
+
+    def place_set(ov):
+        for name in ("read_len", "qid", "qs", "qe", "tid", "ts", "te"):
+            setattr(ov, name, place(getattr(ov, name)))
+        return ov
+
     class Shard:
         """One rank's inputs, resident in HBM: read lengths, the tokeniser's columns and (grouped input) the per-read
         record offsets + the window count."""
@@ -437,13 +453,13 @@ def main():
             self.n_reads, self.n_rec = int(read_len.numel()), int(cols[0].numel())
             self.off = self.n_bins = self.win = None
             if want_grouped:
-                self.off = torch.as_tensor(grouped_form(torch, hostio, self.n_reads, self.cols[0])).to(dev)
+                self.off = place(torch.as_tensor(grouped_form(torch, hostio, self.n_reads, self.cols[0])).to(dev))
                 self.n_bins = windows_of(self.read_len, p.reso)
                 if windows_in:
                     w = hostio.pack_windows(self.cols[1].cpu().numpy(), self.cols[2].cpu().numpy(), p.reso)
                     if w is None:
                         raise SystemExit("bench.py: --input windows needs reads below 65,535 windows")
-                    self.win = torch.as_tensor(w.view("int32")).to(dev)
+                    self.win = place(torch.as_tensor(w.view("int32")).to(dev))
 
     def make_engine(sh: Shard, width: int, routed: bool = False):
         # (routed: the records a rank of a host-routed job is handed ARE the query-side multiset of its reads, engine.hip run_routed)
@@ -586,7 +602,7 @@ def main():
     # ---- the timed region
     strong_info = None
     if args.strong and world > 1:
-        full = make_overlaps(n_reads, seed=args.seed, device=dev, **gen_kw)
+        full = place_set(make_overlaps(n_reads, seed=args.seed, device=dev, **gen_kw))
         torch.cuda.synchronize()
         s, elapsed, pile, pass_dev, tot, ok = strong_run(full, args.presplit, args.warmup, args.steps)
         tot_rec, tot_frag, tot_bins, tot_iv = full.n_rec, tot[0], tot[4], tot[5]
@@ -595,7 +611,7 @@ def main():
             raise SystemExit("bench.py: the ranks' totals differ from the single-GPU pass over the same set")
         o, eng, check = full, None, {"ranks_totals_equal_single_gpu_pass": bool(ok)} if rank == 0 else {}
     else:
-        o = make_overlaps(n_reads, seed=args.seed + rank, device=dev, **gen_kw)
+        o = place_set(make_overlaps(n_reads, seed=args.seed + rank, device=dev, **gen_kw))
         sh = Shard(o.read_len, o.columns(), grouped_in)
         torch.cuda.synchronize()
         eng = make_engine(sh, args.cov_width)
@@ -634,7 +650,7 @@ def main():
 
         # ---- several GPUs, weak headline: BASELINE configs[3]'s setting beside it -- the ONE set of configs[2] in `world` read ranges
         if world > 1 and not args.no_strong_leg:
-            full = make_overlaps(n_reads, seed=args.seed, device=dev, **gen_kw) if rank else o   # (rank 0's weak shard IS that set)
+            full = place_set(make_overlaps(n_reads, seed=args.seed, device=dev, **gen_kw)) if rank else o   # (rank 0's weak shard IS that set)
             torch.cuda.synchronize()
             s2, el2, pile2, pass2, tot2, ok2 = strong_run(full, False, args.warmup, args.steps)
             if rank == 0:
@@ -665,7 +681,7 @@ def main():
                 win = hostio.pack_windows(shp.cols[1].cpu().numpy(), shp.cols[2].cpu().numpy(), p.reso)   # (the tokeniser's, outside every clock)
                 if win is None:
                     return None
-                d_win = torch.as_tensor(win.view("int32")).to(dev)
+                d_win = place(torch.as_tensor(win.view("int32")).to(dev))
             e3 = engine.Engine(p_sym, device=local)
             e3.set_tuning(args.tile_bins, args.force_bucket, args.variant)
             e3.set_output_width(8 if d4 else w)
@@ -811,6 +827,7 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "fragments_per_s": tot_frag / per_step,
             "config": {"workload": workload_text, "workload_name": args.workload, "input": input_text,
+                       "input_memory": "torch allocator (hipMalloc)" if mem_ctx is None else "raft_hip_device_alloc (device memory placed as the engine places its own arrays: shuffled 32 MiB chunks), filled before the clock",
                        "reads_per_gpu": s.n_reads, "records_per_gpu": my_rec, "records_total": tot_rec,
                        "windows_total": tot_bins, "intervals_total": tot_iv, "fragments_total": tot_frag,
                        "repeats_rank0": s.n_repeats, "mean_read_len": gen_kw["mean_len"], "coverage": gen_kw["coverage"],

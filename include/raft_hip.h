@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_ABI_VERSION 7
+#define RAFT_HIP_ABI_VERSION 8
 
 /* error codes (0..5 are shared with oracle/raft_oracle.h) */
 enum {
@@ -252,6 +252,17 @@ int  raft_hip_set_output_width(raft_hip_ctx *ctx, int32_t width);
  * on = 0 -- they are left out of the pass and written by the first raft_hip_fetch / raft_hip_outputs_device that asks for
  * them (the fragment bounds are derived without them; the host pipelines, whose outputs hold no cut points, run this way). */
 int  raft_hip_set_emit_cuts(raft_hip_ctx *ctx, int32_t on);
+
+/* Device memory for the caller's input columns (ABI 8), placed the way the engine places its own large arrays: a virtual
+ * range backed by 32 MiB physical chunks in a shuffled order.  What a stream of loads and stores gets from this part
+ * depends on where its buffers lie (tools/membench: the int32 pass's mix of traffic takes 2.0 ms on such chunks, 2.2-2.3 ms
+ * on one physically contiguous block, and anything in between on hipMalloc memory, depending on what earlier processes left
+ * behind); columns that live in memory from here make a pass's time reproducible.  Plain hipMalloc memory stays valid
+ * input everywhere.  The buffer belongs to the context's device and lives until raft_hip_device_free or
+ * raft_hip_destroy; falls back to hipMalloc where the mapping calls are unavailable.  (Replaces nothing in the
+ * reference: chop.hpp:155-169 fills host vectors.) */
+int  raft_hip_device_alloc(raft_hip_ctx *ctx, int64_t bytes, void **dptr);
+int  raft_hip_device_free(raft_hip_ctx *ctx, void *dptr);
 
 /* Device arrays of the encoding the finished pass holds (width 0: none -- the pass wrote int32; call
  * raft_hip_fetch_packed_w once to have it encoded).  The exceptions are in no particular order. */

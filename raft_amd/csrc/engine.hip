@@ -128,21 +128,95 @@ struct Ctrl {                         // device control block, cleared every pas
     unsigned totals_done, pad_done;   // workgroups of totals_kernel that are through (the last one publishes this block)
 };
 
+// Device buffers.  The large ones the pass streams through (coverage, repeats, cut points, fragments, the pipeline's staging
+// columns: `big`) are virtual ranges over 32 MiB physical chunks (hipMemCreate / hipMemMap) that are SPREAD over a wide
+// physical span: eight times the chunks are created, every eighth is kept (mapped in a shuffled order), the rest go back.
+// Why (tools/membench, profiles/r04_membench_placement.txt; tools/placement_probe2.py): what a stream gets from this part
+// is a property of where its buffer lies.  Plain stores into an 8 GB hipMalloc block: 5.65 TB/s, with few exceptions; into
+// chunks taken one after the other: 5.6 .. 7.1 TB/s from buffer to buffer; into every eighth chunk of a 64 GB span:
+// 7.0 .. 7.1 TB/s, every time.  The pileup kernel followed its coverage array -- contexts of ONE process ran at 2.14 or at
+// 2.6 ms, and swapping their `cov` buffers swapped their times.  Any failure falls back (fewer spare chunks, then
+// hipMalloc); RAFT_NO_VMM=1 switches the mapping off.  Buffers other devices write into (the exchange's receive side)
+// stay with hipMalloc.
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool big = false;                 // may be backed by shuffled chunks
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+    size_t va_bytes = 0;
+    static constexpr size_t kVmmMin = 64u << 20;
+    bool map_chunks(size_t want)
+    {
+        static const bool off = getenv("RAFT_NO_VMM") != nullptr;
+        if (off) return false;
+        static const size_t kChunk = (size_t)(getenv("RAFT_VMM_CHUNK_MB") ? std::max(2, atoi(getenv("RAFT_VMM_CHUNK_MB"))) : 32) << 20;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0 || kChunk % gran) {
+            (void)hipGetLastError(); return false;
+        }
+        const size_t n = (want + kChunk - 1) / kChunk;
+        static const size_t kSpread = (size_t)(getenv("RAFT_VMM_SPREAD") ? std::max(1, atoi(getenv("RAFT_VMM_SPREAD"))) : 8);
+        hipDeviceptr_t va = nullptr;
+        if (hipMemAddressReserve(&va, n * kChunk, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+        bool ok = false;
+        for (size_t k = kSpread; k >= 1 && !ok; k /= 2) {              // (spare chunks the device cannot give: try with fewer)
+            std::vector<hipMemGenericAllocationHandle_t> all(n * k);
+            size_t made = 0;
+            ok = true;
+            for (; ok && made < n * k; ++made) ok = hipMemCreate(&all[made], kChunk, &prop, 0) == hipSuccess;
+            if (!ok) { --made; (void)hipGetLastError(); }
+            for (size_t i = 0; i < made; ++i) if (!ok || i % k) (void)hipMemRelease(all[i]);
+            if (ok) { chunks.resize(n); for (size_t i = 0; i < n; ++i) chunks[i] = all[i * k]; }
+        }
+        if (!ok) { (void)hipMemAddressFree(va, n * kChunk); chunks.clear(); return false; }
+        std::vector<size_t> order(n);
+        for (size_t i = 0; i < n; ++i) order[i] = i;
+        unsigned long long x = 0x9E3779B97F4A7C15ull;                     // (Fisher-Yates with a fixed generator: the same order every run)
+        for (size_t i = n; i > 1; --i) { x = x * 6364136223846793005ull + 1442695040888963407ull; std::swap(order[i - 1], order[(size_t)((x >> 33) % i)]); }
+        size_t mapped = 0;
+        for (; ok && mapped < n; ++mapped) ok = hipMemMap((hipDeviceptr_t)((char *)va + mapped * kChunk), kChunk, 0, chunks[order[mapped]], 0) == hipSuccess;
+        if (!ok) --mapped;
+        if (ok) {
+            hipMemAccessDesc acc{};
+            acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+            ok = hipMemSetAccess(va, n * kChunk, &acc, 1) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            if (mapped) (void)hipMemUnmap(va, mapped * kChunk);
+            for (auto &h : chunks) (void)hipMemRelease(h);
+            chunks.clear();
+            (void)hipMemAddressFree(va, n * kChunk);
+            return false;
+        }
+        p = va; cap = n * kChunk; va_bytes = n * kChunk;
+        return true;
+    }
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap && p) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        release();
         size_t want = (bytes + 255) & ~size_t(255);
         if (want == 0) want = 256;
+        if (big && want >= kVmmMin && map_chunks(want)) return hipSuccess;
         hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
+        if (e == hipSuccess) cap = want; else p = nullptr;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release()
+    {
+        if (p && va_bytes) {
+            (void)hipMemUnmap(p, va_bytes);
+            for (auto &h : chunks) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(p, va_bytes);
+            chunks.clear();
+        } else if (p) (void)hipFree(p);
+        p = nullptr; cap = 0; va_bytes = 0;
+    }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -192,10 +266,12 @@ __global__ void publish_sizes_kernel(const long long *scan_totals, const Ctrl *c
     __threadfence_system();
 }
 
-__global__ void clear_ctrl_kernel(Ctrl *ctrl)
+constexpr int kWaveCounters = 32;      // tile hand-out counters of the wave kernel, 256 bytes apart (pileup_wave.hpp next_range)
+__global__ void clear_ctrl_kernel(Ctrl *ctrl, int32_t *wave_ctr)
 {
     constexpr int kWords = (int)(sizeof(Ctrl) / 8);
     if ((int)threadIdx.x < kWords) reinterpret_cast<long long *>(ctrl)[threadIdx.x] = 0;
+    if ((int)threadIdx.x < kWaveCounters) wave_ctr[threadIdx.x * kCtrStride] = 0;
     __syncthreads();
     if (threadIdx.x == 0) { ctrl->err_index = -1; ctrl->insp.err_index = -1; }
 }
@@ -226,7 +302,7 @@ struct raft_hip_ctx {
     std::string last_error;
 
     // device buffers
-    DevBuf ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_desc, tile_cuts, slow_list, block_sums;
+    DevBuf wave_ctr, ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_desc, tile_cuts, slow_list, block_sums;
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
@@ -286,6 +362,7 @@ struct raft_hip_ctx {
     bool is_lane = false;              // a sub-context of a host pipeline (prepare_lanes)
     void *h_stage = nullptr;           // page-locked staging of a lane: what the host derives from a chunk's columns (window records, offsets)
     size_t h_stage_cap = 0;
+    std::vector<DevBuf *> user_bufs;   // raft_hip_device_alloc
     bool emit_cuts = true;             // the pass writes the cut points (final_stars) itself; false: on demand (raft_hip_set_emit_cuts)
 };
 
@@ -371,6 +448,10 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     raft_hip_ctx *c = new (std::nothrow) raft_hip_ctx();
     if (!c) return RAFT_HIP_ERR_NOMEM;
     c->device = device_id;
+    for (DevBuf *b : {&c->cov, &c->cov8, &c->cuts, &c->frag_read, &c->frag_begin, &c->frag_end, &c->raw_key, &c->raw_s, &c->raw_e, &c->rep_s, &c->rep_e,
+                      &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5], &c->u_s, &c->u_e, &c->exp_qid,
+                      &c->b_rid, &c->b_s, &c->b_e, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1})
+        b->big = true;                                         // (what a pass streams through: see DevBuf)
     apply_params(c, params);
     if (const char *w = getenv("RAFT_COV_WIDTH")) {           // (test sweeps: every context of the process in that width)
         const int v = atoi(w);
@@ -407,12 +488,14 @@ void raft_hip_destroy(raft_hip_ctx *c)
     c->lane_up_ev.clear(); c->lane_down_ev.clear();
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
-    DevBuf *all[] = {&c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
+    DevBuf *all[] = {&c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1, &c->in_len,
                      &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->exc_idx2, &c->exc_val2, &c->sort_tmp, &c->exc_pidx, &c->exc_pval, &c->exc_tile_n, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
+    for (DevBuf *b : c->user_bufs) { b->release(); delete b; }
+    c->user_bufs.clear();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->ev_pass0) (void)hipEventDestroy(c->ev_pass0);
@@ -561,7 +644,8 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     HIP_TRY(c, hipEventRecord(c->ev_pass0, st));
     HIP_TRY(c, c->ctrl.ensure(sizeof(Ctrl)));
     Ctrl *ctrl = c->ctrl.as<Ctrl>();
-    hipLaunchKernelGGL(clear_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl);      // (three fill commands before: ~5 us each on the device)
+    HIP_TRY(c, c->wave_ctr.ensure((size_t)kWaveCounters * kCtrStride * 4));
+    hipLaunchKernelGGL(clear_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl, c->wave_ctr.as<int32_t>());      // (three fill commands before: ~5 us each on the device)
     if (d_win && !lean && n_rec > 0)
         hipLaunchKernelGGL(unpack_windows_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>((n_rec + 255) / 256, 256 * 16))), dim3(256), 0, st,
                            (long long)n_rec, d_win, c->prm.reso, c->u_s.as<int32_t>(), c->u_e.as<int32_t>());
@@ -884,10 +968,16 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     if (wave) {
         // ONE launch, no second stream: a persistent grid of single-wave workers, each drawing wave tiles from the list
         // tile_desc_kernel cut (its length is known on the device only: workers without a tile leave at once)
-        const int n_waves = (int)std::max<long long>(1, std::min<long long>(wave_grid_waves(lean), n_tiles));
-        // (a quarter of the quantum tiles -- four wave tiles each -- is handed out dynamically, up to two per draw: pileup_wave.hpp)
-        pa.tile_batch = (int32_t)std::max<long long>(1, std::min<long long>(2, n_tiles / (16LL * n_waves)));
-        if (const char *e = getenv("RAFT_WAVE_BATCH")) pa.tile_batch = std::max(1, atoi(e));
+        int n_waves = (int)std::max<long long>(1, std::min<long long>(wave_grid_waves(lean), n_tiles));
+        if (const char *e = getenv("RAFT_WAVE_WAVES")) n_waves = std::max(1, std::min(n_waves, atoi(e)));
+        // (segments are handed out one at a time through eight counters: pileup_wave.hpp next_range)
+        pa.tile_batch = 1;
+        if (const char *e = getenv("RAFT_WAVE_MODE")) pa.tile_batch |= std::min(15, std::max(0, atoi(e))) << 20;
+        int n_ctr = 8;
+        if (const char *e = getenv("RAFT_WAVE_COUNTERS")) n_ctr = std::min(kWaveCounters, std::max(1, atoi(e)));
+        pa.tile_batch |= (n_ctr - 1) << 24;
+        if (getenv("RAFT_WAVE_LABEL") && atoi(getenv("RAFT_WAVE_LABEL"))) pa.tile_batch |= 1 << 29;
+        pa.tile_counter = c->wave_ctr.as<int32_t>();
         pa.n_extra = nullptr;
         pa.piece_w = (int32_t)std::min<long long>(extra_cap, INT32_MAX);    // (delta4: tile ids below this have slots of their own)
         launch_wave_variant(ow, lean, st, pa.n_seg, c->tile_cuts.p, &pa, n_waves);
@@ -1225,6 +1315,52 @@ int raft_hip_set_emit_cuts(raft_hip_ctx *c, int32_t on)
     if (!c) return RAFT_HIP_ERR_PARAM;
     c->emit_cuts = on != 0;
     return RAFT_HIP_OK;
+}
+
+#ifdef RAFT_DEBUG_SWAP
+// (investigation only, tools/placement_probe2.py, make DEFS=-DRAFT_DEBUG_SWAP: swaps one scratch buffer between two idle contexts)
+extern "C" int raft_hip_debug_swap(raft_hip_ctx *a, raft_hip_ctx *b, int which)
+{
+    DevBuf raft_hip_ctx::*m[] = {&raft_hip_ctx::wave_ctr, &raft_hip_ctx::ctrl, &raft_hip_ctx::block_sums, &raft_hip_ctx::tile_cuts, &raft_hip_ctx::cov_off,
+                                 &raft_hip_ctx::rep_res_off, &raft_hip_ctx::cutcap_off, &raft_hip_ctx::rep_cnt, &raft_hip_ctx::raw_key, &raft_hip_ctx::raw_s,
+                                 &raft_hip_ctx::raw_e, &raft_hip_ctx::cov, &raft_hip_ctx::tile_first, &raft_hip_ctx::tile_desc, &raft_hip_ctx::scan_tmp,
+                                 &raft_hip_ctx::samples, &raft_hip_ctx::slow_list, &raft_hip_ctx::cut_cnt, &raft_hip_ctx::frag_cnt, &raft_hip_ctx::rep_off,
+                                 &raft_hip_ctx::cut_off, &raft_hip_ctx::frag_off, &raft_hip_ctx::rep_s, &raft_hip_ctx::rep_e, &raft_hip_ctx::cuts,
+                                 &raft_hip_ctx::frag_read, &raft_hip_ctx::frag_begin, &raft_hip_ctx::frag_end};
+    const int n = (int)(sizeof m / sizeof m[0]);
+    if (which < 0 || which >= n) return n;
+    std::swap(a->*m[which], b->*m[which]);
+    return 0;
+}
+#endif
+
+int raft_hip_device_alloc(raft_hip_ctx *c, int64_t bytes, void **dptr)
+{
+    if (!c || !dptr || bytes < 0) return RAFT_HIP_ERR_PARAM;
+    *dptr = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return RAFT_HIP_ERR_DEVICE;
+    DevBuf *b = new (std::nothrow) DevBuf();
+    if (!b) return RAFT_HIP_ERR_NOMEM;
+    b->big = true;
+    if (b->ensure((size_t)std::max<int64_t>(bytes, 1)) != hipSuccess) { (void)hipGetLastError(); delete b; return RAFT_HIP_ERR_NOMEM; }
+    c->user_bufs.push_back(b);
+    *dptr = b->p;
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_device_free(raft_hip_ctx *c, void *dptr)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    if (!dptr) return RAFT_HIP_OK;
+    for (size_t i = 0; i < c->user_bufs.size(); ++i)
+        if (c->user_bufs[i]->p == dptr) {
+            (void)hipSetDevice(c->device);
+            c->user_bufs[i]->release();
+            delete c->user_bufs[i];
+            c->user_bufs.erase(c->user_bufs.begin() + (long)i);
+            return RAFT_HIP_OK;
+        }
+    return RAFT_HIP_ERR_PARAM;
 }
 
 int raft_hip_packed_device(raft_hip_ctx *c, int32_t *width, const void **cov_packed, const int64_t **exc_index,

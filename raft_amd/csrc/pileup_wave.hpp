@@ -36,6 +36,7 @@ constexpr int kErrDeep = 1 << 9;     // a wave tile with 32768 or more intervals
 // The empty difference array: the LOW half of every dword is biased by 0x8000, so that a -1 landing on an even slot never
 // borrows from the odd slot above it (the ds_add is a 32-bit add); one xor per dword takes the bias off again.
 constexpr uint32_t kZero = 0x00008000u;
+constexpr int kCtrStride = (4096 + 256) / 4;   // int32 words between two hand-out counters: another 4 KiB block AND another 256-byte slot of it
 constexpr int kWaveMaxReads = 63;    // reads per wave tile: lane j <-> read r_a + j, entry nr closes the table (nr + 1 <= 64)
 
 template <int SLOTS>
@@ -89,7 +90,7 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 
 template <int U>
 struct WaveRegs { int rid[U], st[U], en[U]; };
-struct WaveReadRegs { int cv, rr, rl; int so[2]; };
+struct WaveReadRegs { int cv, rr, rl; int so[2]; int n; };      // n: lanes whose table entries were asked for (wave-uniform)
 
 // NSEG sorted runs, U prefetch slots per lane (slot u: record (u / NSEG) * 64 + lane of run u % NSEG), OW bytes per window
 // written (4: int32 cov[]; 1 / 2: the transfer encoding; 8: four-bit steps, pack.hpp), IN = 1: window records.
@@ -142,10 +143,13 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         for (int s = 0; s < NSEG; ++s) { t.pos[s] = __builtin_amdgcn_readlane(w0, 2 + s); pend[s] = __builtin_amdgcn_readlane(w1, 2 + s); }
     };
     // loads of the tile that begins at `t`: the per-read table (64 reads from t.r on) and U record slots from t.pos on
-    auto issue = [&](const Start &t, WaveRegs<U> &g, WaveReadRegs &rd) {
-        rd.cv = 0; rd.rr = 0; rd.rl = 0; rd.so[0] = 0; rd.so[1] = 0;
+    // (`tables`: the per-read entries of reads t.r .. t.r + 63 are loaded; not when the tile before holds them already -- a tile
+    // of long reads uses a handful of the 64, and every line a tile asks for comes from HBM again: the coverage stores turn
+    // the L2 over several times per tile.  The next tile then takes the entries by a shift across the lanes, see `reuse`)
+    auto issue = [&](const Start &t, WaveRegs<U> &g, WaveReadRegs &rd, bool tables) {
+        rd.cv = 0; rd.rr = 0; rd.rl = 0; rd.so[0] = 0; rd.so[1] = 0; rd.n = 64;
         const int idx = t.r + lane;
-        if (idx <= a.n_reads) {
+        if (tables && idx <= a.n_reads) {
             rd.cv = reinterpret_cast<const int32_t *>(a.cov_off + t.r)[2 * lane];
             rd.rr = reinterpret_cast<const int32_t *>(a.rep_res_off + t.r)[2 * lane];
             if (IN == 1) {
@@ -153,7 +157,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 for (int s = 0; s < NSEG; ++s) rd.so[s] = reinterpret_cast<const int32_t *>(a.grp.off + s * a.grp.stride + t.r)[2 * lane];
             }
         }
-        if (idx < a.n_reads) rd.rl = a.read_len[idx];
+        if (tables && idx < a.n_reads) rd.rl = a.read_len[idx];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int s = u % NSEG, first = (u / NSEG) * 64;
@@ -168,31 +172,38 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         }
     };
 
-    // Ranges: three quarters of the segments are dealt out in advance -- worker w takes segments [w S, (w + 1) S) as ONE range,
-    // neighbours in cov[] -- and the rest comes from a device counter, kBatch segments per draw (tile costs differ by what a
-    // tile holds and CUs are not equally fast, so the end of the kernel needs a queue; but returning atomics on ONE word
-    // serialise at ~12 ns each: a draw per four tiles, 2.9e5 of them at human scale, WAS the first version's duration).
-    const int kBatch = max(1, a.tile_batch);
+    // Ranges: a worker draws ONE segment at a time (tile costs differ by what a tile holds and CUs are not equally fast), and it
+    // draws it from the counter of its XCD: workgroups go to the XCDs round-robin, so with kCtr a multiple of 8 the workers that
+    // share counter c = wave_id % kCtr share an L2, and each counter hands out a contiguous share of the segments.  Neighbouring
+    // tiles -- the lines of the per-read tables and of the record columns they both touch, the coverage line their common edge
+    // lies in -- then meet in ONE L2 (measured inside one process, tools/mode_probe.py: 2.26 ms against 2.50 with the segments
+    // dealt round-robin to all workers; kernel times of separate processes differ by as much with where their buffers
+    // happen to lie).  Returning atomics on ONE word serialise at ~12 ns each -- a draw per four tiles from one counter WAS
+    // the first version's duration; the counters are 4 KiB + 256 bytes apart (256 bytes apart, the eight of
+    // them shared a memory channel or not depending on where the block lay: contexts of ONE process ran at 2.2 or at 2.6 ms).  A worker whose share is used up helps with the next.
+    const int kCtr = ((a.tile_batch >> 24) & 31) + 1, kMode = (a.tile_batch >> 20) & 15;
     typedef __attribute__((address_space(1))) int32_t *global_i32_ptr;
     global_i32_ptr draw_from = (global_i32_ptr)a.tile_counter;
     asm volatile("" : "+v"(draw_from));
-    // (few segments: one each, the rest from the counter)
-    int n_static = (int)((long long)n_seg_tiles * 3 / 4 / n_waves);
-    int dyn0 = n_static * n_waves;
-    if (n_static == 0) { dyn0 = min(n_waves, n_seg_tiles); n_static = wave_id < n_seg_tiles ? 1 : 0; }
-    bool static_left = n_static > 0;
-    auto next_range = [&](Start &t) -> bool {     // synchronous (a draw, two boundary records): a few times per worker
+    // (which XCD: HW_REG_XCC_ID, id 20, bits 3:0 -- workgroups go to the XCDs round-robin, but which one the first gets is not fixed)
+    const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
+    const int per_xcc = max(1, kCtr / 8);
+    int ctr = (a.tile_batch >> 29) & 1 ? wave_id % kCtr : (kCtr >= 8 ? xcc * per_xcc + (wave_id / 8) % per_xcc : wave_id % kCtr), ctr_tried = 0;
+    auto next_range = [&](Start &t) -> bool {     // synchronous (a draw, two boundary records)
         for (;;) {
-            int k0, k1;
-            if (static_left) { static_left = false; k0 = wave_id * n_static; k1 = k0 + n_static; }
+            if (ctr_tried == kCtr) return false;
+            int drawn = 0;
+            if (lane == 0) drawn = __hip_atomic_fetch_add(draw_from + ctr * kCtrStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wait_all_loads();
+            int k0;
+            if (kMode & 1) k0 = uni(drawn) * kCtr + ctr;          // (A/B: segments dealt round-robin to the counters)
             else {
-                int drawn = 0;
-                if (lane == 0) drawn = __hip_atomic_fetch_add(draw_from, kBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                wait_all_loads();
-                k0 = dyn0 + uni(drawn);
-                if (k0 >= n_seg_tiles) return false;
-                k1 = min(k0 + kBatch, n_seg_tiles);
+                const int d0 = (int)((long long)n_seg_tiles * ctr / kCtr), d1 = (int)((long long)n_seg_tiles * (ctr + 1) / kCtr);
+                k0 = d0 + uni(drawn);
+                if (k0 >= d1) k0 = n_seg_tiles;
             }
+            if (k0 >= n_seg_tiles) { ctr = ctr + 1 == kCtr ? 0 : ctr + 1; ++ctr_tried; continue; }
+            const int k1 = k0 + 1;
             load_range(k0, k1, t);
             bool left = false;                   // (a range without reads must not own records: they would be walked by nobody)
 #pragma unroll
@@ -218,7 +229,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
     WaveTile cur;
     WaveRegs<U> g, gn;
     WaveReadRegs rd, rdn;
-    issue(ts, g, rd);
+    issue(ts, g, rd, true);
     wait_all_loads();
 
     while (true) {
@@ -226,7 +237,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         // "belongs to this range": the ballot is a prefix of the lanes, lane 0 -- the tile's first read -- always in it)
         const int cv0 = uni(rd.cv);
         const int rel = rd.cv - cv0;
-        const unsigned long long okm = __ballot(ts.r + lane <= R_end && (unsigned)rel <= (unsigned)CAP);
+        const unsigned long long okm = __ballot(ts.r + lane <= R_end && (unsigned)rel <= (unsigned)CAP && lane < rd.n);
         int nr = (int)__popcll(okm) - 1;
         int piece = 0, n_pieces = 1, nb_read = 0;
         cur.r_a = ts.r;
@@ -305,9 +316,15 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         // of the interval phase that hides their latency; a tile with an open run plans it behind its interval phase.
         const bool last_piece = !piece || ts.q + 1 == n_pieces;
         bool have_next = true;
+        // the next tile's table entries: the ones this tile holds, `shift` lanes up, when they reach far enough for it (twice this
+        // tile's reads + 8, at least 16 -- a tile that could have held more reads than it has entries for is cut short)
+        bool reuse = false;
+        int shift = 0;
         auto plan_next = [&]() {
-            if (!last_piece) { nts = ts; nts.q = ts.q + 1; }
+            if (!last_piece) { nts = ts; nts.q = ts.q + 1; reuse = true; shift = 0; }
             else {
+                shift = nr;
+                reuse = r_b != R_end && rd.n - nr >= min(64, max(16, 2 * nr + 8));
                 nts.r = r_b; nts.q = 0; nts.g = ts.g + (piece ? nb_read : cur.nwin);
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) nts.pos[s] = ts.pos[s] + cur.cnt[s];
@@ -320,7 +337,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                     have_next = next_range(nts);
                 }
             }
-            if (have_next) issue(nts, gn, rdn);
+            if (have_next) issue(nts, gn, rdn, !reuse);
         };
         if (!last_piece) defer = false;          // (the next piece begins where this one does: nothing to wait for)
         if (!defer) plan_next();
@@ -344,6 +361,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         bool bad_any = false, bad_order = false;
         auto add_pm = [&](int pf, int pl1) {
             const unsigned vp = 1u << ((pf & 1) << 4), vm = 0u - (1u << ((pl1 & 1) << 4));
+            if (kMode & 4) { covsum += pl1 - pf + (int)vp + (int)vm; return; }      // (diagnostic: no scatter)
             __hip_atomic_fetch_add(&sm.diff[pf >> 1], vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&sm.diff[pl1 >> 1], vm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             covsum += pl1 - pf;
@@ -638,15 +656,14 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                     }
                 }
             };
-#ifndef RAFT_ABLATE_WAVE_STORE
-            store_half(rA0, rA1, pA, dA0, dA1);
-            store_half(rB0, rB1, pB, dB0, dB1);
-#else
-            (void)store_half; (void)pA; (void)pB;
-#endif
+            if (!(kMode & 8)) {                  // (diagnostic: no coverage stores)
+                store_half(rA0, rA1, pA, dA0, dA1);
+                store_half(rB0, rB1, pB, dB0, dB1);
+            }
 
             // ---- run scan: only rows that hold a high window or inherit an open run
             const unsigned xh = (mx + kthr) & 0x80008000u;
+            if (kMode & 2) continue;             // (diagnostic, RAFT_WAVE_MODE: no run scan)
             if (__ballot(xh != 0u) == 0ull && !hp) continue;
             // per half-row: pileup_fast.hpp's per-lane scan of four slots
 #pragma unroll 1
@@ -771,7 +788,16 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
 
         // ---- hand over to the next tile
         if (!have_next) break;
-        ts = nts; rd = rdn; g = gn;
+        if (reuse) {
+            const int src = lane + shift;
+            rd.cv = __shfl(rd.cv, src); rd.rr = __shfl(rd.rr, src); rd.rl = __shfl(rd.rl, src);
+            if (IN == 1) {
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s) rd.so[s] = __shfl(rd.so[s], src);
+            }
+            rd.n -= shift;
+        } else rd = rdn;
+        ts = nts; g = gn;
     }
     {
         const long long cs = wave_reduce_add64(lane_cov), rs = wave_reduce_add64(lane_rep);

@@ -28,7 +28,7 @@ EXPORTS = (
     "raft_hip_run_multi_grouped", "raft_hip_host_register", "raft_hip_host_unregister", "raft_hip_comm_unique_id",
     "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local", "raft_hip_warm_up", "raft_hip_reserve",
     "raft_hip_run_device_windows", "raft_hip_run_host_windows", "raft_hip_run_multi_windows",
-    "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device", "raft_hip_set_emit_cuts",
+    "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device", "raft_hip_set_emit_cuts", "raft_hip_device_alloc", "raft_hip_device_free",
 )
 
 
@@ -163,6 +163,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_set_tuning.argtypes = [vp, i32, i32, i32]
     lib.raft_hip_set_output_width.argtypes = [vp, i32]
     lib.raft_hip_set_emit_cuts.argtypes = [vp, i32]
+    lib.raft_hip_device_alloc.argtypes = [vp, i64, C.POINTER(C.c_void_p)]
+    lib.raft_hip_device_free.argtypes = [vp, vp]
     lib.raft_hip_packed_device.argtypes = [vp, C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
     lib.raft_hip_selftest.argtypes = [C.c_int]
     lib.raft_hip_debug_stamps.argtypes = [vp, vp, i64, C.POINTER(i64)]
@@ -231,6 +233,36 @@ class Engine:
     def set_emit_cuts(self, on: bool):
         """True (default): every pass writes the cut points itself; False: the first fetch that asks for them does."""
         self._check(self._lib.raft_hip_set_emit_cuts(self._ctx, 1 if on else 0))
+
+    def device_tensor(self, shape, dtype):
+        """A torch tensor over device memory from raft_hip_device_alloc (the engine's placement: shuffled 32 MiB chunks); it
+        lives until the context is closed or device_free(tensor) is called."""
+        import torch
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        n = 1
+        for x in shape:
+            n *= x
+        item = torch.empty(0, dtype=dtype).element_size()
+        ptr = C.c_void_p()
+        self._check(self._lib.raft_hip_device_alloc(self._ctx, n * item, C.byref(ptr)))
+        typestr = {torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1", torch.int16: "<i2"}[dtype]
+
+        class _Mem:
+            pass
+        m = _Mem()
+        m.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr.value or 0), False), "version": 2}
+        t = torch.as_tensor(m, device=f"cuda:{self.device}")
+        t._raft_ptr = int(ptr.value or 0)
+        return t
+
+    def device_copy(self, t):
+        """`t` copied into memory from device_tensor."""
+        out = self.device_tensor(tuple(t.shape), t.dtype)
+        out.copy_(t)
+        return out
+
+    def device_free(self, t):
+        self._check(self._lib.raft_hip_device_free(self._ctx, C.c_void_p(t._raft_ptr)))
 
     def use_torch_stream(self):
         import torch

@@ -67,14 +67,83 @@ static void run(const char *name, int4 *out, int *in, double gib, int *sink, int
     (void)bytes_per_row_read;
 }
 
+// Allocation modes (argv[2]): 0 hipMalloc; 1 physically contiguous (hipDeviceMallocContiguous); 2 / 3: virtual range backed by
+// 2 MiB (or the device's granularity) physical chunks mapped in shuffled / in creation order (hipMemCreate + hipMemMap) --
+// the pileup kernel's time differs by 10 % between processes with where its buffers lie; does a plain stream's?
+#include <vector>
+#include <chrono>
+#include <algorithm>
+#include <random>
+static size_t g_chunk = 2u << 20;
+static void *alloc_mode(size_t bytes, int mode)
+{
+    void *p = nullptr;
+    if (mode == 0) { hipMalloc(&p, bytes); return p; }
+    if (mode == 1) { if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous) != hipSuccess) { printf("contiguous allocation failed\n"); hipMalloc(&p, bytes); } return p; }
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+    size_t gran = 0;
+    hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+    if (gran < g_chunk) gran = g_chunk;
+    const size_t n = (bytes + gran - 1) / gran;
+    hipDeviceptr_t va;
+    if (hipMemAddressReserve(&va, n * gran, 0, 0, 0) != hipSuccess) { printf("reserve failed\n"); hipMalloc(&p, bytes); return p; }
+    if (mode >= 4) {      // mode 4 + k: create (k + 2) * n chunks, keep every (k + 2)-th, release the rest: a buffer spread over a wide physical span
+        const size_t k = (size_t)mode - 2, big_n = n * k;
+        std::vector<hipMemGenericAllocationHandle_t> all(big_n);
+        for (size_t i = 0; i < big_n; ++i) if (hipMemCreate(&all[i], gran, &prop, 0) != hipSuccess) { printf("create failed at %zu\n", i); exit(1); }
+        std::vector<size_t> order(n);
+        for (size_t i = 0; i < n; ++i) order[i] = i;
+        std::mt19937_64 rng(12345); std::shuffle(order.begin(), order.end(), rng);
+        for (size_t i = 0; i < n; ++i) hipMemMap((hipDeviceptr_t)((char *)va + i * gran), gran, 0, all[order[i] * k], 0);
+        for (size_t i = 0; i < big_n; ++i) if (i % k) hipMemRelease(all[i]);
+        hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+        hipMemSetAccess(va, n * gran, &acc, 1);
+        return (void *)va;
+    }
+    std::vector<hipMemGenericAllocationHandle_t> h(n);
+    hipEvent_t t0, t1; (void)t0; (void)t1;
+    auto w0 = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < n; ++i) if (hipMemCreate(&h[i], gran, &prop, 0) != hipSuccess) { printf("create failed at %zu\n", i); exit(1); }
+    printf("  %zu x hipMemCreate: %.1f ms\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = i;
+    if (mode == 2) { std::mt19937_64 rng(12345); std::shuffle(order.begin(), order.end(), rng); }
+    for (size_t i = 0; i < n; ++i) hipMemMap((hipDeviceptr_t)((char *)va + i * gran), gran, 0, h[order[i]], 0);
+    hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    hipMemSetAccess(va, n * gran, &acc, 1);
+    printf("mode %d: %zu chunks of %zu KiB\n", mode, n, gran >> 10);
+    return (void *)va;
+}
+
 int main(int argc, char **argv)
 {
     const double gib = argc > 1 ? atof(argv[1]) : 7.4;     // (the int32 pass of the bench set writes 7.9 GB)
+    const int mode = argc > 2 ? atoi(argv[2]) : 0;
+    if (argc > 3) g_chunk = (size_t)atoi(argv[3]) << 20;
     int4 *out; int *in; int *sink;
-    hipMalloc(&out, (size_t)(gib * (1LL << 30)) + (1 << 20));
+    out = (int4 *)alloc_mode((size_t)(gib * (1LL << 30)) + (1 << 20), mode);
     const size_t in_bytes = (size_t)(gib * (1LL << 30)) / 2 + (64 << 20);
-    hipMalloc(&in, in_bytes); hipMemset(in, 1, in_bytes);
+    in = (int *)alloc_mode(in_bytes, mode); hipMemset(in, 1, in_bytes);
     hipMalloc(&sink, 4);
+    if (argc > 4) {     // several output buffers, one after the other: is a buffer's rate a property of where it lies?
+        const int nbuf = atoi(argv[4]);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int b = 0; b < nbuf; ++b) {
+            int4 *o2 = b == 0 ? out : (int4 *)alloc_mode((size_t)(gib * (1LL << 30)) + (1 << 20), mode);
+            const long long waves = 4096, total_rows = (long long)(gib * (1LL << 30)) / 1024, rows_per_wave = (total_rows / waves) / 16 * 16;
+            float best = 1e9f;
+            for (int it = 0; it < 5; ++it) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL((stream_kernel<0>), dim3(4096), dim3(64), 0, 0, o2, in, rows_per_wave, 0LL, sink, 1);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) best = ms;
+            }
+            printf("buffer %d at %p: store-only %.3f ms = %.0f GB/s\n", b, (void *)o2, best, (double)rows_per_wave * waves * 1024 / best / 1e6);
+        }
+        return 0;
+    }
     run<0>("store only (1 KiB rows)", out, in, gib, sink, 1, 0);
     run<28>("int32 pass mix (0.44 rd/wr)", out, in, gib, sink, 1, 0);      // 28 x 256 B read per 16 KiB written
     run<16>("load only (256 B rows)", out, in, gib, sink, 0, 0);

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""A/B of run-time modes of the wave kernel inside ONE process and ONE context (same buffers, same physical placement: kernel
+times of separate processes differ by up to 10 % with where their buffers land).  usage: mode_probe.py ENV=v1,v2,... [reps] [bench-set args]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from raft_amd import engine
+from raft_amd.params import RaftParams
+from raft_amd.synth import make_overlaps
+name, vals = sys.argv[1].split("=")
+vals = vals.split(",")
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+width = int(os.environ.get("PROBE_WIDTH", "4"))
+o = make_overlaps(3_300_000, mean_len=30000.0, coverage=32.0, seed=20241008, device="cuda:0")
+eng = engine.Engine(RaftParams(est_cov=32))
+if width != 4:
+    eng.set_output_width(width)
+cols = tuple(eng.device_copy(c) for c in (o.read_len,) + o.columns())      # (inputs where the engine would put them: raft_hip_device_alloc)
+for _ in range(5):
+    eng.run_device(*cols); eng.finish()
+res = {v: [] for v in vals}
+for r in range(reps):
+    for v in vals:
+        if name == "Q":
+            eng.set_tuning(int(v), False, -1)
+        else:
+            os.environ[name] = v
+        k = p = 0.0
+        for _ in range(10):
+            eng.run_device(*cols); s = eng.finish(); a, b = eng.timing(); k += a; p += b
+        res[v].append((k * 100, p * 100))
+for v in vals:
+    print(f"{name}={v}: kernel " + " ".join(f"{a:.3f}" for a, _ in res[v]) + "   pass " + " ".join(f"{b:.3f}" for _, b in res[v]), "frag", s.n_fragments)
