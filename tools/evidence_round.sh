@@ -11,9 +11,14 @@ tools/pmc_probe.sh -1 3300000 > gpurun_out/$TAG/sq_counters.txt 2>&1
 tools/pass_timeline.sh ${TAG}_tl > gpurun_out/$TAG/pass_timeline.txt 2>&1
 tools/pass_timeline.sh ${TAG}_tlg --input grouped > gpurun_out/$TAG/pass_timeline_grouped.txt 2>&1
 tools/pass_timeline.sh ${TAG}_tlw --input windows --cov-width 1 > gpurun_out/$TAG/pass_timeline_windows_w1.txt 2>&1
-# 3. what the memory system gives the pass's shape
+# 3. what the memory system gives the pass's shape, and how much of that is where a buffer lies (hipMalloc / chunks one after the
+#    other / every eighth chunk of a wide span: what the engine does); the same binary in several processes, inputs in torch's
+#    memory or in the engine's; the kernel's parts switched off one at a time inside one process
 [ -x tools/membench ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/membench.hip -o tools/membench > /dev/null 2>&1
-tools/membench > gpurun_out/$TAG/membench.txt 2>&1
+tools/membench 7.4 10 32 > gpurun_out/$TAG/membench.txt 2>&1
+for m in 0 2 10; do echo "== mode $m"; tools/membench 7.4 $m 32 8 2>&1 | grep buffer; done > gpurun_out/$TAG/membench_placement.txt 2>&1
+tools/variance_probe.sh 6 > gpurun_out/$TAG/variance_probe.txt 2>&1
+( python tools/mode_probe.py RAFT_WAVE_MODE=0,1,2,4,8,14 3; PROBE_WIDTH=1 python tools/mode_probe.py RAFT_WAVE_MODE=0,1,2,4,8,14 3 ) 2>&1 | grep RAFT_ > gpurun_out/$TAG/mode_probe.txt
 # 4. other workloads and forms: configs[4] (ultralong), configs[1] (50 k reads), an eighth of configs[2] (one of eight GPUs in configs[3]),
 #    window records in / a byte per window out as a headline of its own (with stats and traffic), general streams (shuffled, non-symmetric)
 for w in ultralong s50k; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/$TAG/bench_$w.json 2> gpurun_out/$TAG/bench_$w.err; done

@@ -8,7 +8,11 @@
 //   * addresses advance by constants (no division, no modulo);
 //   * workgroups of 64 .. 256 threads, 1 .. 8 waves per SIMD, three mixes: store-only, load-only, the int32 pass's mix
 //     (12 B read per 0.147 windows + 4 B per window written: 0.44 B read per B written), the byte pass's mix (1 B per window).
-// usage: membench [GiB of stores]; prints GB/s per configuration (best of 4 launches).
+// usage: membench [GiB of stores] [allocation mode] [chunk MiB] [n buffers]; prints GB/s per configuration (best of 4 launches).
+// Allocation modes -- what a stream gets depends on where its buffers lie (profiles/r04_membench_placement.txt): 0 hipMalloc,
+// 1 hipDeviceMallocContiguous, 2 / 3 hipMemCreate chunks taken one after the other and mapped in shuffled / creation order,
+// 4 + k: (k + 2) times the chunks created, every (k + 2)-th kept (10: every eighth -- engine.hip DevBuf).  With [n buffers] only
+// the store-only stream runs, into n buffers allocated one after the other.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
