@@ -181,7 +181,12 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
     // happen to lie).  Returning atomics on ONE word serialise at ~12 ns each -- a draw per four tiles from one counter WAS
     // the first version's duration; the counters are 4 KiB + 256 bytes apart (256 bytes apart, the eight of
     // them shared a memory channel or not depending on where the block lay: contexts of ONE process ran at 2.2 or at 2.6 ms).  A worker whose share is used up helps with the next.
-    const int kCtr = ((a.tile_batch >> 24) & 31) + 1, kMode = (a.tile_batch >> 20) & 15;
+    const int kCtr = ((a.tile_batch >> 24) & 31) + 1;
+#ifdef RAFT_WAVE_DIAG      // (make DEFS=-DRAFT_WAVE_DIAG, RAFT_WAVE_MODE=<bits>, tools/mode_probe.py: parts of the kernel switched off at run time)
+    const int kMode = (a.tile_batch >> 20) & 15;
+#else
+    constexpr int kMode = 0;
+#endif
     typedef __attribute__((address_space(1))) int32_t *global_i32_ptr;
     global_i32_ptr draw_from = (global_i32_ptr)a.tile_counter;
     asm volatile("" : "+v"(draw_from));
@@ -195,13 +200,9 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             int drawn = 0;
             if (lane == 0) drawn = __hip_atomic_fetch_add(draw_from + ctr * kCtrStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             wait_all_loads();
-            int k0;
-            if (kMode & 1) k0 = uni(drawn) * kCtr + ctr;          // (A/B: segments dealt round-robin to the counters)
-            else {
-                const int d0 = (int)((long long)n_seg_tiles * ctr / kCtr), d1 = (int)((long long)n_seg_tiles * (ctr + 1) / kCtr);
-                k0 = d0 + uni(drawn);
-                if (k0 >= d1) k0 = n_seg_tiles;
-            }
+            const int d0 = (int)((long long)n_seg_tiles * ctr / kCtr), d1 = (int)((long long)n_seg_tiles * (ctr + 1) / kCtr);
+            int k0 = d0 + uni(drawn);
+            if (k0 >= d1) k0 = n_seg_tiles;
             if (k0 >= n_seg_tiles) { ctr = ctr + 1 == kCtr ? 0 : ctr + 1; ++ctr_tried; continue; }
             const int k1 = k0 + 1;
             load_range(k0, k1, t);
@@ -324,7 +325,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             if (!last_piece) { nts = ts; nts.q = ts.q + 1; reuse = true; shift = 0; }
             else {
                 shift = nr;
-                reuse = r_b != R_end && rd.n - nr >= min(64, max(16, 2 * nr + 8));
+                reuse = !(kMode & 1) && r_b != R_end && rd.n - nr >= min(64, max(16, 2 * nr + 8));
                 nts.r = r_b; nts.q = 0; nts.g = ts.g + (piece ? nb_read : cur.nwin);
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) nts.pos[s] = ts.pos[s] + cur.cnt[s];
@@ -588,24 +589,24 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                         else { if (v0) o[0] = (int)c0; if (v1) o[1] = (int)c1; if (v2) o[2] = (int)c2; if (v3) o[3] = (int)c3; }
                     }
                 } else if (OW == 1 || OW == 2) {
+                    // (the windows at or above the limit are listed once per row, below: the common row has none)
                     const unsigned m0 = pk_min_u16(r0, kLimit * 0x10001u), m1 = pk_min_u16(r1, kLimit * 0x10001u);
-                    const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
-                    const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
-                    if (OW == 1) {
-                        uint8_t *o = reinterpret_cast<uint8_t *>(covp0) + p0;
-                        const unsigned pk4 = __builtin_amdgcn_perm(m1, m0, 0x06040200u);
-                        if (full || (v0 && v3)) __builtin_amdgcn_raw_buffer_store_b32((int)pk4, rsrc, p0, 0, 0);
-                        else { if (v0) o[0] = (uint8_t)pk4; if (v1) o[1] = (uint8_t)(pk4 >> 8); if (v2) o[2] = (uint8_t)(pk4 >> 16); if (v3) o[3] = (uint8_t)(pk4 >> 24); }
+                    if (full) {
+                        if (OW == 1) __builtin_amdgcn_raw_buffer_store_b32((int)__builtin_amdgcn_perm(m1, m0, 0x06040200u), rsrc, p0, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, p0 * 2, 0, 0);
                     } else {
-                        uint16_t *o = reinterpret_cast<uint16_t *>(covp0) + p0;
-                        if (full || (v0 && v3)) __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, p0 * 2, 0, 0);
-                        else { if (v0) o[0] = (uint16_t)m0; if (v1) o[1] = (uint16_t)(m0 >> 16); if (v2) o[2] = (uint16_t)m1; if (v3) o[3] = (uint16_t)(m1 >> 16); }
-                    }
-                    if ((c0 | c1 | c2 | c3) >= kLimit) {       // rare by the choice of the width
-                        if ((full || v0) && c0 >= kLimit) note_exception(a, a0 + p0, (int)c0);
-                        if ((full || v1) && c1 >= kLimit) note_exception(a, a0 + p0 + 1, (int)c1);
-                        if ((full || v2) && c2 >= kLimit) note_exception(a, a0 + p0 + 2, (int)c2);
-                        if ((full || v3) && c3 >= kLimit) note_exception(a, a0 + p0 + 3, (int)c3);
+                        const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
+                        const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
+                        if (OW == 1) {
+                            uint8_t *o = reinterpret_cast<uint8_t *>(covp0) + p0;
+                            const unsigned pk4 = __builtin_amdgcn_perm(m1, m0, 0x06040200u);
+                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b32((int)pk4, rsrc, p0, 0, 0);
+                            else { if (v0) o[0] = (uint8_t)pk4; if (v1) o[1] = (uint8_t)(pk4 >> 8); if (v2) o[2] = (uint8_t)(pk4 >> 16); if (v3) o[3] = (uint8_t)(pk4 >> 24); }
+                        } else {
+                            uint16_t *o = reinterpret_cast<uint16_t *>(covp0) + p0;
+                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, p0 * 2, 0, 0);
+                            else { if (v0) o[0] = (uint16_t)m0; if (v1) o[1] = (uint16_t)(m0 >> 16); if (v2) o[2] = (uint16_t)m1; if (v3) o[3] = (uint16_t)(m1 >> 16); }
+                        }
                     }
                 } else {
                     // four-bit steps: a step IS the difference array's value; the lane's four steps are one aligned ushort
@@ -659,6 +660,23 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             if (!(kMode & 8)) {                  // (diagnostic: no coverage stores)
                 store_half(rA0, rA1, pA, dA0, dA1);
                 store_half(rB0, rB1, pB, dB0, dB1);
+            }
+            // windows at or above a byte's limit (a 16-bit tile's values are below 32768: the two-byte encoding's 65535 is never
+            // reached here): ONE test per row on the packed maximum, c + (0x8000 - limit) has bit 15 set <=> c >= limit
+            if (OW == 1) {
+                constexpr unsigned klim = ((0x8000u - kLimit) & 0xffffu) * 0x10001u;
+                if (__ballot(((mx + klim) & 0x80008000u) != 0u) != 0ull) {
+                    auto list_half = [&](unsigned r0, unsigned r1, int p0) {
+                        const unsigned c0 = r0 & 0xffffu, c1 = r0 >> 16, c2 = r1 & 0xffffu, c3 = r1 >> 16;
+                        const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
+                        if (q0 < nw && c0 >= kLimit) note_exception(a, a0 + p0, (int)c0);
+                        if (q0 + 1u < nw && c1 >= kLimit) note_exception(a, a0 + p0 + 1, (int)c1);
+                        if (q0 + 2u < nw && c2 >= kLimit) note_exception(a, a0 + p0 + 2, (int)c2);
+                        if (q0 + 3u < nw && c3 >= kLimit) note_exception(a, a0 + p0 + 3, (int)c3);
+                    };
+                    list_half(rA0, rA1, pA);
+                    list_half(rB0, rB1, pB);
+                }
             }
 
             // ---- run scan: only rows that hold a high window or inherit an open run

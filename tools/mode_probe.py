@@ -17,8 +17,23 @@ eng = engine.Engine(RaftParams(est_cov=32))
 if width != 4:
     eng.set_output_width(width)
 cols = tuple(eng.device_copy(c) for c in (o.read_len,) + o.columns())      # (inputs where the engine would put them: raft_hip_device_alloc)
+form = os.environ.get("PROBE_FORM", "columns")      # columns | windows (per-read offsets + one word per record, symmetric flag handed over)
+if form == "windows":
+    import numpy as np
+    from raft_amd import hostio
+    eng.close()
+    eng = engine.Engine(RaftParams(est_cov=32, symmetric_mode=1))
+    if width != 4:
+        eng.set_output_width(width)
+    off = eng.device_copy(torch.as_tensor(hostio.group_offsets(o.n_reads, o.qid.cpu().numpy())).cuda())
+    win = eng.device_copy(torch.as_tensor(hostio.pack_windows(o.qs.cpu().numpy(), o.qe.cpu().numpy(), 50).view("int32")).cuda())
+    rl = eng.device_copy(o.read_len)
+    n_bins = int(((o.read_len.long() + 49) // 50).sum())
+    run = lambda: eng.run_device_windows(rl, off, win, n_bins=n_bins)
+else:
+    run = lambda: eng.run_device(*cols)
 for _ in range(5):
-    eng.run_device(*cols); eng.finish()
+    run(); eng.finish()
 res = {v: [] for v in vals}
 for r in range(reps):
     for v in vals:
@@ -28,7 +43,7 @@ for r in range(reps):
             os.environ[name] = v
         k = p = 0.0
         for _ in range(10):
-            eng.run_device(*cols); s = eng.finish(); a, b = eng.timing(); k += a; p += b
+            run(); s = eng.finish(); a, b = eng.timing(); k += a; p += b
         res[v].append((k * 100, p * 100))
 for v in vals:
     print(f"{name}={v}: kernel " + " ".join(f"{a:.3f}" for a, _ in res[v]) + "   pass " + " ".join(f"{b:.3f}" for _, b in res[v]), "frag", s.n_fragments)
