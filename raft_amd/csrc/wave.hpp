@@ -30,12 +30,15 @@ __device__ __forceinline__ int wave_incl_scan_add(int v)
 // values).  wave_shr1: lane l takes lane l - 1's value, lane 0 keeps `first`.
 __device__ __forceinline__ int wave_incl_scan_max(int v, int neutral)
 {
-    v = max(v, __builtin_amdgcn_update_dpp(neutral, v, 0x111, 0xf, 0xf, false)); // row_shr:1
-    v = max(v, __builtin_amdgcn_update_dpp(neutral, v, 0x112, 0xf, 0xf, false)); // row_shr:2
-    v = max(v, __builtin_amdgcn_update_dpp(neutral, v, 0x114, 0xf, 0xf, false)); // row_shr:4
-    v = max(v, __builtin_amdgcn_update_dpp(neutral, v, 0x118, 0xf, 0xf, false)); // row_shr:8
-    v = max(v, __builtin_amdgcn_update_dpp(neutral, v, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1,3
-    v = max(v, __builtin_amdgcn_update_dpp(neutral, v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2,3
+    // (a lane without a source keeps its own value -- max(v, v) -- so that each step is ONE v_max_i32_dpp instead of a move of the
+    // neutral element, a dpp move and a max)
+    (void)neutral;
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false)); // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false)); // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false)); // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false)); // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1,3
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2,3
     return v;
 }
 __device__ __forceinline__ int wave_shr1(int v, int first)
