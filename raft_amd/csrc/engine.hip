@@ -149,7 +149,7 @@ struct DevBuf {
     {
         static const bool off = getenv("RAFT_NO_VMM") != nullptr;
         if (off) return false;
-        static const size_t kChunk = (size_t)(getenv("RAFT_VMM_CHUNK_MB") ? std::max(2, atoi(getenv("RAFT_VMM_CHUNK_MB"))) : 32) << 20;
+        constexpr size_t kChunk = 32u << 20;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         hipMemAllocationProp prop{};
@@ -969,14 +969,14 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         // ONE launch, no second stream: a persistent grid of single-wave workers, each drawing wave tiles from the list
         // tile_desc_kernel cut (its length is known on the device only: workers without a tile leave at once)
         int n_waves = (int)std::max<long long>(1, std::min<long long>(wave_grid_waves(lean), n_tiles));
-        if (const char *e = getenv("RAFT_WAVE_WAVES")) n_waves = std::max(1, std::min(n_waves, atoi(e)));
-        // (segments are handed out one at a time through eight counters: pileup_wave.hpp next_range)
         pa.tile_batch = 1;
-        if (const char *e = getenv("RAFT_WAVE_MODE")) pa.tile_batch |= std::min(15, std::max(0, atoi(e))) << 20;
         int n_ctr = 8;
+#ifdef RAFT_WAVE_DIAG   // (make DEFS=-DRAFT_WAVE_DIAG: run-time switches for tools/mode_probe.py -- workers, parts of the kernel, counters)
+        if (const char *e = getenv("RAFT_WAVE_WAVES")) n_waves = std::max(1, std::min(n_waves, atoi(e)));
+        if (const char *e = getenv("RAFT_WAVE_MODE")) pa.tile_batch |= std::min(15, std::max(0, atoi(e))) << 20;
         if (const char *e = getenv("RAFT_WAVE_COUNTERS")) n_ctr = std::min(kWaveCounters, std::max(1, atoi(e)));
+#endif
         pa.tile_batch |= (n_ctr - 1) << 24;
-        if (getenv("RAFT_WAVE_LABEL") && atoi(getenv("RAFT_WAVE_LABEL"))) pa.tile_batch |= 1 << 29;
         pa.tile_counter = c->wave_ctr.as<int32_t>();
         pa.n_extra = nullptr;
         pa.piece_w = (int32_t)std::min<long long>(extra_cap, INT32_MAX);    // (delta4: tile ids below this have slots of their own)

@@ -193,7 +193,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
     // (which XCD: HW_REG_XCC_ID, id 20, bits 3:0 -- workgroups go to the XCDs round-robin, but which one the first gets is not fixed)
     const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
     const int per_xcc = max(1, kCtr / 8);
-    int ctr = (a.tile_batch >> 29) & 1 ? wave_id % kCtr : (kCtr >= 8 ? xcc * per_xcc + (wave_id / 8) % per_xcc : wave_id % kCtr), ctr_tried = 0;
+    int ctr = kCtr >= 8 ? xcc * per_xcc + (wave_id / 8) % per_xcc : wave_id % kCtr, ctr_tried = 0;
     auto next_range = [&](Start &t) -> bool {     // synchronous (a draw, two boundary records)
         for (;;) {
             if (ctr_tried == kCtr) return false;

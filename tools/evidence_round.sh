@@ -18,7 +18,16 @@ tools/pass_timeline.sh ${TAG}_tlw --input windows --cov-width 1 > gpurun_out/$TA
 tools/membench 7.4 10 32 > gpurun_out/$TAG/membench.txt 2>&1
 for m in 0 2 10; do echo "== mode $m"; tools/membench 7.4 $m 32 8 2>&1 | grep buffer; done > gpurun_out/$TAG/membench_placement.txt 2>&1
 tools/variance_probe.sh 6 > gpurun_out/$TAG/variance_probe.txt 2>&1
-( python tools/mode_probe.py RAFT_WAVE_MODE=0,1,2,4,8,14 3; PROBE_WIDTH=1 python tools/mode_probe.py RAFT_WAVE_MODE=0,1,2,4,8,14 3 ) 2>&1 | grep RAFT_ > gpurun_out/$TAG/mode_probe.txt
+# (the run-time switches exist in a diagnostic build only: make -C raft_amd/csrc LIB=libraft_hip_diag.so BUILD=../../build/csrc_diag DEFS="-DRAFT_WAVE_DIAG -DRAFT_DEBUG_SWAP")
+if [ -f raft_amd/lib/libraft_hip_diag.so ]; then
+  export RAFT_HIP_LIB=$PWD/raft_amd/lib/libraft_hip_diag.so
+  ( echo "# six columns, int32 out; mode bits: 1 no reuse of the per-read tables, 2 no run scan, 4 no scatter, 8 no coverage stores"; python tools/mode_probe.py RAFT_WAVE_MODE=0,1,2,4,8,14 3
+    echo "# six columns, a byte per window out"; PROBE_WIDTH=1 python tools/mode_probe.py RAFT_WAVE_MODE=0,1,2,4,8,14 3
+    echo "# window records, a byte per window out"; PROBE_FORM=windows PROBE_WIDTH=1 python tools/mode_probe.py RAFT_WAVE_MODE=0,1,2,4,8,14 3
+    echo "# workers (of 4096)"; python tools/mode_probe.py RAFT_WAVE_WAVES=4096,3072,2048,1024 2 ) 2>&1 | grep -E "RAFT_|^#" > gpurun_out/$TAG/mode_probe.txt
+  RAFT_VMM_SPREAD=1 python tools/placement_probe2.py 2>&1 | grep -v amdgpu > gpurun_out/$TAG/placement_probe2.txt
+  unset RAFT_HIP_LIB
+fi
 # 4. other workloads and forms: configs[4] (ultralong), configs[1] (50 k reads), an eighth of configs[2] (one of eight GPUs in configs[3]),
 #    window records in / a byte per window out as a headline of its own (with stats and traffic), general streams (shuffled, non-symmetric)
 for w in ultralong s50k; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/$TAG/bench_$w.json 2> gpurun_out/$TAG/bench_$w.err; done

@@ -12,7 +12,7 @@ name, vals = sys.argv[1].split("=")
 vals = vals.split(",")
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 width = int(os.environ.get("PROBE_WIDTH", "4"))
-o = make_overlaps(3_300_000, mean_len=30000.0, coverage=32.0, seed=20241008, device="cuda:0")
+o = make_overlaps(int(os.environ.get("PROBE_READS", "3300000")), mean_len=30000.0, coverage=32.0, seed=20241008, device="cuda:0")
 eng = engine.Engine(RaftParams(est_cov=32))
 if width != 4:
     eng.set_output_width(width)
