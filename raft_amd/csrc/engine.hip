@@ -144,7 +144,7 @@ struct DevBuf {
     bool big = false;                 // may be backed by shuffled chunks
     std::vector<hipMemGenericAllocationHandle_t> chunks;
     size_t va_bytes = 0;
-    static constexpr size_t kVmmMin = 64u << 20;
+    static constexpr size_t kVmmMin = 64u << 20, kSpreadMin = size_t(1) << 30;
     bool map_chunks(size_t want)
     {
         static const bool off = getenv("RAFT_NO_VMM") != nullptr;
@@ -163,7 +163,10 @@ struct DevBuf {
         hipDeviceptr_t va = nullptr;
         if (hipMemAddressReserve(&va, n * kChunk, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
         bool ok = false;
-        for (size_t k = kSpread; k >= 1 && !ok; k /= 2) {              // (spare chunks the device cannot give: try with fewer)
+        // (only buffers of 1 GiB and more are spread: making and releasing 56 GB of spare chunks for the bench set's coverage array
+        // takes the driver up to 2 s, once -- which a job of a few hundred MB per buffer would not earn back.  The spares have to be
+        // chunks of their own: with ONE spare block of k - 1 chunks' size behind every kept chunk the effect was gone)
+        for (size_t k = want >= kSpreadMin ? kSpread : 1; k >= 1 && !ok; k /= 2) {
             std::vector<hipMemGenericAllocationHandle_t> all(n * k);
             size_t made = 0;
             ok = true;

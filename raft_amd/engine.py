@@ -262,7 +262,7 @@ class Engine:
         return out
 
     def device_free(self, t):
-        self._check(self._lib.raft_hip_device_free(self._ctx, C.c_void_p(t._raft_ptr)))
+        self._check(self._lib.raft_hip_device_free(self._ctx, C.c_void_p(getattr(t, "_raft_ptr", None) or t.data_ptr())))
 
     def use_torch_stream(self):
         import torch

@@ -187,3 +187,36 @@ def test_pipeline_derives_offsets_and_window_records_from_the_columns():
     assert np.array_equal(hostio.unpack_coverage(res["cov8"], res["exc_index"], res["exc_value"]), g1["cov"]) and s.n_bins == s1.n_bins
     for e_ in (eng, other, one):
         e_.close()
+
+
+def test_input_columns_in_memory_from_the_engine_give_the_same_result():
+    """raft_hip_device_alloc (ABI 8): device memory placed as the engine places its own large arrays (a virtual range over
+    physical chunks spread over the device) -- columns copied there are plain device input; free and reuse work; a buffer
+    below the mapping's threshold comes from hipMalloc and behaves the same."""
+    import torch
+    from raft_amd import engine
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(60_000, seed=91, device="cuda:0")            # (17 M intervals: the columns are above the 64 MiB threshold)
+    p = RaftParams(est_cov=30)
+    cols = (o.read_len,) + o.columns()
+    eng = engine.Engine(p, device=0)
+    eng.run_device(*cols)
+    s0 = eng.finish()
+    ref = {k: v.clone() for k, v in eng.outputs_device().items()}
+    placed = tuple(eng.device_copy(c) for c in cols)
+    assert all(torch.equal(a, b) for a, b in zip(placed, cols))
+    small = eng.device_tensor(1000, torch.int32)                    # (hipMalloc path)
+    small.fill_(7)
+    assert int(small.sum()) == 7000
+    eng.run_device(*placed)
+    s1 = eng.finish()
+    out = eng.outputs_device()
+    assert (s1.n_fragments, s1.n_repeats, s1.total_coverage) == (s0.n_fragments, s0.n_repeats, s0.total_coverage)
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+    eng.device_free(placed[1])
+    again = eng.device_copy(cols[1])                               # (freed chunks are handed out again)
+    assert torch.equal(again, cols[1])
+    with pytest.raises(engine.RaftError):
+        eng.device_free(again[10:])                                # (not a pointer this context handed out)
+    eng.close()
