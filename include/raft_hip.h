@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_ABI_VERSION 8
+#define RAFT_HIP_ABI_VERSION 9
 
 /* error codes (0..5 are shared with oracle/raft_oracle.h) */
 enum {
@@ -387,6 +387,36 @@ int  raft_hip_exchange(raft_hip_ctx *ctx, void *comm, int32_t rank, int32_t worl
                        const raft_hip_slice *mine, raft_hip_received *out);
 int  raft_hip_exchange_local(raft_hip_ctx *const *ctxs, int32_t world, int32_t n_reads_total, const int64_t *bounds,
                              const raft_hip_slice *slices, raft_hip_received *outs);
+
+/* A slice of a NON-symmetric (or not id-sorted) PAF, made ready for the exchange above on the device (ABI 9; replaces
+ * raft_amd/dist.py's torch sort + all-to-all for target sides).  The reference piles up, for every record, its query side on
+ * the query read and -- unless the PAF is symmetric -- its target side on the target read when the two reads differ
+ * (chop.hpp:165-169, repeat.hpp:48-58).  raft_hip_group_sides writes exactly those (read, start, end) intervals of the
+ * slice's records, sorted by read id (the device radix sort the engine's general bucketing uses), and hands them back as
+ * a slice in grouped form with ONE sorted run: `out->rec_offset` (host, n_reads_total + 1 entries: where every read's
+ * intervals begin), `out->d_qs / d_qe` (device), `out->n_rec` = the number of intervals.  A run sorted by read id is
+ * sorted by owner, so raft_hip_exchange / raft_hip_exchange_local route it as they route a symmetric slice -- one
+ * contiguous piece per destination -- and the receiver runs raft_hip_run_device_grouped on what arrives (the sides are
+ * already expanded: a grouped pass piles up what it is given).  symmetric != 0: query sides only.
+ * The arrays belong to the context and live until its next raft_hip_group_sides or pass of the general bucketing path;
+ * the record columns are device arrays, complete when the call is made.  Errors: RAFT_HIP_ERR_READ_ID (an id outside
+ * [0, n_reads_total): error_index via raft_hip_last_error text), RAFT_HIP_ERR_TOO_LARGE (2^31 intervals or more). */
+int  raft_hip_group_sides(raft_hip_ctx *ctx, int32_t n_reads_total, int64_t n_rec, const int32_t *d_qid, const int32_t *d_qs,
+                          const int32_t *d_qe, const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te, int32_t symmetric,
+                          raft_hip_slice *out);
+
+/* ... and the flag such a job needs first: is the pre-split PAF symmetric (chop.hpp:171-184: some record i > 0 is record 0
+ * with query and target swapped)?  Record 0 is rank 0's first record; every rank looks for its mirror in its own slice (one
+ * kernel over the six columns) and the verdict is the OR over the ranks -- two all-gathers of a few words (RCCL), or host
+ * copies between the contexts of one process.  Every rank returns the same *symmetric.  A stream without records is not
+ * symmetric.  (Replaces raft_amd/dist.py global_symmetric_flag: torch broadcast + all-reduce.) */
+typedef struct raft_hip_records {
+    int64_t n_rec;                                       /* records of this rank's slice */
+    const int32_t *d_qid, *d_qs, *d_qe, *d_tid, *d_ts, *d_te;   /* DEVICE */
+} raft_hip_records;
+int  raft_hip_presplit_symmetric(raft_hip_ctx *ctx, void *comm, int32_t rank, int32_t world, const raft_hip_records *mine,
+                                 int32_t *symmetric);
+int  raft_hip_presplit_symmetric_local(raft_hip_ctx *const *ctxs, int32_t world, const raft_hip_records *slices, int32_t *symmetric);
 
 /* Page-locks / releases a range of the caller's host memory (hipHostRegister, every device of the node).  Arrays handed to
  * the host-to-host entry points move at the link's rate (53 GB/s each way on MI355X) only from page-locked memory; pages

@@ -130,27 +130,45 @@ struct Ctrl {                         // device control block, cleared every pas
 
 // Device buffers.  The large ones the pass streams through (coverage, repeats, cut points, fragments, the pipeline's staging
 // columns: `big`) are virtual ranges over 32 MiB physical chunks (hipMemCreate / hipMemMap) that are SPREAD over a wide
-// physical span: eight times the chunks are created, every eighth is kept (mapped in a shuffled order), the rest go back.
+// physical span: for a buffer of 1 GiB or more eight times the chunks are created and every eighth is mapped, in a
+// shuffled order.
 // Why (tools/membench, profiles/r04_membench_placement.txt; tools/placement_probe2.py): what a stream gets from this part
 // is a property of where its buffer lies.  Plain stores into an 8 GB hipMalloc block: 5.65 TB/s, with few exceptions; into
 // chunks taken one after the other: 5.6 .. 7.1 TB/s from buffer to buffer; into every eighth chunk of a 64 GB span:
 // 7.0 .. 7.1 TB/s, every time.  The pileup kernel followed its coverage array -- contexts of ONE process ran at 2.14 or at
-// 2.6 ms, and swapping their `cov` buffers swapped their times.  Any failure falls back (fewer spare chunks, then
-// hipMalloc); RAFT_NO_VMM=1 switches the mapping off.  Buffers other devices write into (the exchange's receive side)
-// stay with hipMalloc.
+// 2.6 ms, and swapping their `cov` buffers swapped their times.
+// Two rules the mapping calls turned out to need on this stack (tools/gpu_tmp.py's sequence: one-byte coverage, then two-byte
+// coverage in the same context -- tests/test_gpu_windows.py):
+//   * a virtual range is reserved once and never given back (hipMemAddressFree) while the process lives.  A range that was
+//     unmapped, freed and handed out again by the next hipMemAddressReserve was served from STALE translations: writes and reads
+//     of the new buffer went to the chunks the old buffer had been mapped to, deterministically from the second chunk on.
+//     (Address space is not scarce: 47 bits.  A range never mapped -- a failed attempt -- may go back.)
+//   * chunks are not handed back to the driver either: the spare ones, and the ones of a buffer that is released or outgrown,
+//     go to a per-device pool that later buffers draw from (random picks: spread again) -- no create / release storm when a
+//     buffer grows, and nothing depends on when the driver wipes released memory.  Cost: the pool keeps up to seven times the
+//     largest spread buffer (56 GB for the bench set's coverage array, of 288).
+// Any failure falls back (fewer spare chunks, then hipMalloc); RAFT_NO_VMM=1 switches the mapping off.  Buffers other devices
+// write into (the exchange's receive side) stay with hipMalloc.
+struct ChunkPool {                    // per device; handles of 32 MiB physical chunks nobody maps at the moment
+    std::mutex mu;
+    std::vector<hipMemGenericAllocationHandle_t> free_chunks;
+    unsigned long long rng = 0x9E3779B97F4A7C15ull;
+    static ChunkPool &of(int dev) { static ChunkPool pools[64]; return pools[dev & 63]; }
+    unsigned long long next() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return rng >> 33; }
+};
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
-    bool big = false;                 // may be backed by shuffled chunks
+    bool big = false;                 // may be backed by pooled chunks
+    int dev = 0;                      // device of the chunks
     std::vector<hipMemGenericAllocationHandle_t> chunks;
     size_t va_bytes = 0;
-    static constexpr size_t kVmmMin = 64u << 20, kSpreadMin = size_t(1) << 30;
+    static constexpr size_t kChunk = 32u << 20, kVmmMin = 64u << 20, kSpreadMin = size_t(1) << 30;
     bool map_chunks(size_t want)
     {
         static const bool off = getenv("RAFT_NO_VMM") != nullptr;
         if (off) return false;
-        constexpr size_t kChunk = 32u << 20;
-        int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         hipMemAllocationProp prop{};
         prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
@@ -162,25 +180,47 @@ struct DevBuf {
         static const size_t kSpread = (size_t)(getenv("RAFT_VMM_SPREAD") ? std::max(1, atoi(getenv("RAFT_VMM_SPREAD"))) : 8);
         hipDeviceptr_t va = nullptr;
         if (hipMemAddressReserve(&va, n * kChunk, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-        bool ok = false;
-        // (only buffers of 1 GiB and more are spread: making and releasing 56 GB of spare chunks for the bench set's coverage array
-        // takes the driver up to 2 s, once -- which a job of a few hundred MB per buffer would not earn back.  The spares have to be
-        // chunks of their own: with ONE spare block of k - 1 chunks' size behind every kept chunk the effect was gone)
-        for (size_t k = want >= kSpreadMin ? kSpread : 1; k >= 1 && !ok; k /= 2) {
-            std::vector<hipMemGenericAllocationHandle_t> all(n * k);
-            size_t made = 0;
-            ok = true;
-            for (; ok && made < n * k; ++made) ok = hipMemCreate(&all[made], kChunk, &prop, 0) == hipSuccess;
-            if (!ok) { --made; (void)hipGetLastError(); }
-            for (size_t i = 0; i < made; ++i) if (!ok || i % k) (void)hipMemRelease(all[i]);
-            if (ok) { chunks.resize(n); for (size_t i = 0; i < n; ++i) chunks[i] = all[i * k]; }
+        ChunkPool &pool = ChunkPool::of(dev);
+        chunks.clear();
+        {
+            std::lock_guard<std::mutex> lk(pool.mu);
+            // (1) from the pool: random picks -- its chunks lie all over the spans earlier buffers were spread over
+            auto draw = [&]() {
+                while (chunks.size() < n && !pool.free_chunks.empty()) {
+                    const size_t j = (size_t)(pool.next() % pool.free_chunks.size());
+                    chunks.push_back(pool.free_chunks[j]);
+                    pool.free_chunks[j] = pool.free_chunks.back();
+                    pool.free_chunks.pop_back();
+                }
+            };
+            draw();
+            // (2) the rest fresh from the driver: k times as many, every k-th for this buffer, the others into the pool; when the
+            // device cannot give that many, what was made goes to the pool, serves first, and the rest is tried with fewer spares
+            for (size_t k = want >= kSpreadMin ? kSpread : 1; chunks.size() < n; k /= 2) {
+                const size_t need = n - chunks.size();
+                std::vector<hipMemGenericAllocationHandle_t> all(need * k);
+                size_t made = 0;
+                bool ok = true;
+                for (; ok && made < need * k; ++made) ok = hipMemCreate(&all[made], kChunk, &prop, 0) == hipSuccess;
+                if (!ok) { --made; (void)hipGetLastError(); }
+                for (size_t i = 0; i < made; ++i) {
+                    if (ok && i % k == 0) chunks.push_back(all[i]);
+                    else pool.free_chunks.push_back(all[i]);
+                }
+                if (!ok) { draw(); if (k == 1) break; }
+            }
+            if (chunks.size() != n) {
+                for (auto &h : chunks) pool.free_chunks.push_back(h);
+                chunks.clear();
+            }
         }
-        if (!ok) { (void)hipMemAddressFree(va, n * kChunk); chunks.clear(); return false; }
+        if (chunks.size() != n) { (void)hipMemAddressFree(va, n * kChunk); return false; }
         std::vector<size_t> order(n);
         for (size_t i = 0; i < n; ++i) order[i] = i;
-        unsigned long long x = 0x9E3779B97F4A7C15ull;                     // (Fisher-Yates with a fixed generator: the same order every run)
+        unsigned long long x = 0x9E3779B97F4A7C15ull;                     // (Fisher-Yates with a fixed generator)
         for (size_t i = n; i > 1; --i) { x = x * 6364136223846793005ull + 1442695040888963407ull; std::swap(order[i - 1], order[(size_t)((x >> 33) % i)]); }
         size_t mapped = 0;
+        bool ok = true;
         for (; ok && mapped < n; ++mapped) ok = hipMemMap((hipDeviceptr_t)((char *)va + mapped * kChunk), kChunk, 0, chunks[order[mapped]], 0) == hipSuccess;
         if (!ok) --mapped;
         if (ok) {
@@ -191,10 +231,9 @@ struct DevBuf {
         if (!ok) {
             (void)hipGetLastError();
             if (mapped) (void)hipMemUnmap(va, mapped * kChunk);
-            for (auto &h : chunks) (void)hipMemRelease(h);
+            { std::lock_guard<std::mutex> lk(pool.mu); for (auto &h : chunks) pool.free_chunks.push_back(h); }
             chunks.clear();
-            (void)hipMemAddressFree(va, n * kChunk);
-            return false;
+            return false;                                  // (a range that was mapped, even in part, stays reserved)
         }
         p = va; cap = n * kChunk; va_bytes = n * kChunk;
         return true;
@@ -213,9 +252,10 @@ struct DevBuf {
     void release()
     {
         if (p && va_bytes) {
+            (void)hipDeviceSynchronize();                  // (nothing in flight may still use the range)
             (void)hipMemUnmap(p, va_bytes);
-            for (auto &h : chunks) (void)hipMemRelease(h);
-            (void)hipMemAddressFree(p, va_bytes);
+            { ChunkPool &pool = ChunkPool::of(dev); std::lock_guard<std::mutex> lk(pool.mu); for (auto &h : chunks) pool.free_chunks.push_back(h); }
+            // (the range stays reserved: see above)
             chunks.clear();
         } else if (p) (void)hipFree(p);
         p = nullptr; cap = 0; va_bytes = 0;
@@ -309,6 +349,8 @@ struct raft_hip_ctx {
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
+    DevBuf gs_s, gs_e, gs_off, gs_err;  // raft_hip_group_sides: the slice it hands back (+ its error word)
+    std::vector<long long> gs_off_host;
     DevBuf rs_k0, rs_k1, rs_v0, rs_v1;   // general streams, large inputs: (read id, start | end << 32) per side, before and after the radix sort
     DevBuf samples;                   // up to kSamples + 2 read ids at evenly spaced records (guess_runs_kernel): coarse index
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
@@ -494,7 +536,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
     DevBuf *all[] = {&c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
-                     &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1, &c->in_len,
+                     &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->gs_s, &c->gs_e, &c->gs_off, &c->gs_err, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1, &c->in_len,
                      &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->exc_idx2, &c->exc_val2, &c->sort_tmp, &c->exc_pidx, &c->exc_pval, &c->exc_tile_n, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     for (DevBuf *b : c->user_bufs) { b->release(); delete b; }
@@ -2866,6 +2908,174 @@ bool slice_ok(const raft_hip_slice &sl, int32_t n_reads_total)
 }
 
 } // namespace
+
+// A slice of a non-symmetric PAF as ONE run sorted by read id, in grouped form (see include/raft_hip.h): the expansion and the
+// sort are the general bucketing path's (bucket.hpp expand_sides_kernel / unzip_sorted_kernel around the device radix sort).
+int raft_hip_group_sides(raft_hip_ctx *c, int32_t n_reads_total, int64_t n_rec, const int32_t *d_qid, const int32_t *d_qs, const int32_t *d_qe,
+                         const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te, int32_t symmetric, raft_hip_slice *out)
+{
+    if (!c || !out || n_reads_total < 0 || n_rec < 0) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && (!d_qid || !d_qs || !d_qe || (!symmetric && (!d_tid || !d_ts || !d_te)))) return RAFT_HIP_ERR_PARAM;
+    const long long n_ent = n_rec * (symmetric ? 1 : 2), N1 = (long long)n_reads_total + 1;
+    if (n_ent >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    c->gs_off_host.assign((size_t)N1, 0);
+    long long n_valid = 0;
+    if (n_ent > 0) {
+        HIP_TRY(c, c->rs_k0.ensure((size_t)n_ent * 4)); HIP_TRY(c, c->rs_k1.ensure((size_t)n_ent * 4));
+        HIP_TRY(c, c->rs_v0.ensure((size_t)n_ent * 8)); HIP_TRY(c, c->rs_v1.ensure((size_t)n_ent * 8));
+        HIP_TRY(c, c->gs_s.ensure((size_t)n_ent * 4)); HIP_TRY(c, c->gs_e.ensure((size_t)n_ent * 4));
+        HIP_TRY(c, c->gs_off.ensure((size_t)N1 * 8));
+        HIP_TRY(c, c->gs_err.ensure(16));
+        HIP_TRY(c, hipMemsetAsync(c->gs_err.p, 0, 8, st));
+        HIP_TRY(c, hipMemsetAsync(c->gs_err.as<char>() + 8, 0xff, 8, st));
+        const unsigned g1 = (unsigned)std::min<long long>((n_rec + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(expand_sides_kernel, dim3(g1), dim3(256), 0, st, (long long)n_rec, n_reads_total, symmetric ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te,
+                           c->rs_k0.as<uint32_t>(), c->rs_v0.as<unsigned long long>(), c->gs_err.as<int32_t>(), reinterpret_cast<long long *>(c->gs_err.as<char>() + 8));
+        int bits = 1;
+        while (bits < 32 && (1LL << bits) <= (long long)n_reads_total) ++bits;      // keys 0 .. n_reads_total (the sides that do not exist)
+        size_t tmp = 0;
+        HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
+                                             c->rs_v1.as<unsigned long long>(), (size_t)n_ent, 0u, (unsigned)bits, st));
+        HIP_TRY(c, c->sort_tmp.ensure(tmp));
+        HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
+                                             c->rs_v1.as<unsigned long long>(), (size_t)n_ent, 0u, (unsigned)bits, st));
+        const unsigned g2 = (unsigned)std::min<long long>((n_ent + 255) / 256, 256 * 32);
+        // (the unsorted keys are done with: their array takes the id column nobody asks for)
+        hipLaunchKernelGGL(unzip_sorted_kernel, dim3(g2), dim3(256), 0, st, n_ent, n_reads_total, c->rs_k1.as<uint32_t>(), c->rs_v1.as<unsigned long long>(),
+                           c->rs_k0.as<int32_t>(), c->gs_s.as<int32_t>(), c->gs_e.as<int32_t>(), c->gs_off.as<long long>());
+        HIP_TRY(c, hipGetLastError());
+        long long err[2] = {0, -1};
+        HIP_TRY(c, hipMemcpyAsync(c->gs_off_host.data(), c->gs_off.p, (size_t)N1 * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(err, c->gs_err.p, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if ((int32_t)err[0] & kErrReadId) {
+            c->last_error = "raft_hip_group_sides: record " + std::to_string(err[1]) + " names a read outside [0, n_reads_total)";
+            return RAFT_HIP_ERR_READ_ID;
+        }
+        n_valid = c->gs_off_host[(size_t)n_reads_total];
+    }
+    *out = raft_hip_slice{n_valid, 1, reinterpret_cast<const int64_t *>(c->gs_off_host.data()), c->gs_s.as<int32_t>(), c->gs_e.as<int32_t>()};
+    return RAFT_HIP_OK;
+}
+
+namespace {
+struct FirstRecord { int32_t v[6]; };
+// hit: a record other than record 0 itself that is record 0 with query and target swapped (chop.hpp:171-184)
+__global__ __launch_bounds__(256) void mirror_search_kernel(long long n_rec, long long first_index, FirstRecord f, const int32_t *qid, const int32_t *qs,
+                                                            const int32_t *qe, const int32_t *tid, const int32_t *ts, const int32_t *te, int32_t *found)
+{
+    bool hit = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (long long)gridDim.x * blockDim.x)
+        hit |= i != first_index && qid[i] == f.v[3] && tid[i] == f.v[0] && ts[i] == f.v[1] && te[i] == f.v[2] && qs[i] == f.v[4] && qe[i] == f.v[5];
+    if (__ballot(hit) != 0ull && (threadIdx.x & 63) == 0) atomicOr(found, 1);
+}
+bool records_ok(const raft_hip_records &r)
+{
+    return r.n_rec >= 0 && (r.n_rec == 0 || (r.d_qid && r.d_qs && r.d_qe && r.d_tid && r.d_ts && r.d_te));
+}
+// the search of one rank's slice, queued on its context's stream; the flag lands in the context's 16-byte error word
+int queue_mirror_search(raft_hip_ctx *c, const raft_hip_records &r, const FirstRecord &f, bool holds_first)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->gs_err.ensure(16));
+    HIP_TRY(c, hipMemsetAsync(c->gs_err.p, 0, 16, c->stream));
+    if (r.n_rec > 0)
+        hipLaunchKernelGGL(mirror_search_kernel, dim3((unsigned)std::min<long long>((r.n_rec + 255) / 256, 256 * 16)), dim3(256), 0, c->stream, (long long)r.n_rec,
+                           holds_first ? 0LL : -1LL, f, r.d_qid, r.d_qs, r.d_qe, r.d_tid, r.d_ts, r.d_te, c->gs_err.as<int32_t>());
+    HIP_TRY(c, hipGetLastError());
+    return RAFT_HIP_OK;
+}
+int read_first_record(raft_hip_ctx *c, const raft_hip_records &r, FirstRecord *f)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int32_t *col[6] = {r.d_qid, r.d_qs, r.d_qe, r.d_tid, r.d_ts, r.d_te};
+    for (int k = 0; k < 6; ++k) HIP_TRY(c, hipMemcpyAsync(&f->v[k], col[k], 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RAFT_HIP_OK;
+}
+} // namespace
+
+int raft_hip_presplit_symmetric_local(raft_hip_ctx *const *ctxs, int32_t world, const raft_hip_records *slices, int32_t *symmetric)
+{
+    if (!ctxs || world < 1 || !slices || !symmetric) return RAFT_HIP_ERR_PARAM;
+    for (int p = 0; p < world; ++p) if (!ctxs[p] || !records_ok(slices[p])) return RAFT_HIP_ERR_PARAM;
+    *symmetric = 0;
+    if (slices[0].n_rec == 0) return RAFT_HIP_OK;          // (record 0 is rank 0's first record: without it nothing can mirror it)
+    FirstRecord f{};
+    { const int rc = read_first_record(ctxs[0], slices[0], &f); if (rc != RAFT_HIP_OK) return rc; }
+    for (int p = 0; p < world; ++p) { const int rc = queue_mirror_search(ctxs[p], slices[p], f, p == 0); if (rc != RAFT_HIP_OK) return rc; }
+    for (int p = 0; p < world; ++p) {
+        raft_hip_ctx *c = ctxs[p];
+        int32_t found = 0;
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipMemcpyAsync(&found, c->gs_err.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (found) *symmetric = 1;
+    }
+    return RAFT_HIP_OK;
+}
+
+int raft_hip_presplit_symmetric(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world, const raft_hip_records *mine, int32_t *symmetric)
+{
+    if (!c || !mine || !symmetric || world < 1 || rank < 0 || rank >= world || (world > 1 && !comm_v)) return RAFT_HIP_ERR_PARAM;
+    RcclApi *r = world > 1 || comm_v ? rccl_api() : nullptr;
+    if ((world > 1 || comm_v) && !r) { c->last_error = "librccl.so.1 could not be loaded"; return RAFT_HIP_ERR_DEVICE; }
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(comm_v);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    // Every rank reaches both collectives whatever it finds wrong with its own arguments: a rank with bad arguments says so in
+    // its row, and all ranks return the same error once the rows are in.
+    const bool ok_mine = records_ok(*mine);
+    constexpr size_t kRow = 8;                              // per rank: six columns of its first record, "has records", "arguments fine"
+    std::vector<long long> rows(kRow * (size_t)world, 0);
+    long long *my = rows.data() + kRow * (size_t)rank;
+    my[7] = ok_mine ? 1 : 0;
+    if (ok_mine && mine->n_rec > 0 && rank == 0) {
+        FirstRecord f{};
+        const int rc = read_first_record(c, *mine, &f);
+        if (rc != RAFT_HIP_OK) my[7] = 0;
+        else { for (int k = 0; k < 6; ++k) my[k] = f.v[k]; my[6] = 1; }
+    }
+    HIP_TRY(c, c->x_cnt.ensure(std::max<size_t>(rows.size() * 8, 64)));
+    auto gather = [&](size_t words) -> int {                // this rank's `words` of rows[] to everybody, everybody's back to the host
+        if (!comm_v) return RAFT_HIP_OK;
+        HIP_TRY(c, hipMemcpyAsync(c->x_cnt.as<long long>() + words * (size_t)rank, rows.data() + words * (size_t)rank, words * 8, hipMemcpyHostToDevice, st));
+        const ncclResult_t e = r->AllGather(c->x_cnt.as<long long>() + words * (size_t)rank, c->x_cnt.p, words, ncclInt64, comm, st);
+        if (e != ncclSuccess) { c->last_error = std::string("ncclAllGather: ") + r->GetErrorString(e); return RAFT_HIP_ERR_DEVICE; }
+        HIP_TRY(c, hipMemcpyAsync(rows.data(), c->x_cnt.p, words * (size_t)world * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        return RAFT_HIP_OK;
+    };
+    { const int rc = gather(kRow); if (rc != RAFT_HIP_OK) return rc; }
+    bool all_ok = true;
+    for (int p = 0; p < world; ++p) all_ok = all_ok && rows[kRow * (size_t)p + 7] == 1;
+    FirstRecord f{};
+    const bool have_first = all_ok && rows[6] == 1;
+    for (int k = 0; k < 6; ++k) f.v[k] = (int32_t)rows[(size_t)k];
+    // second round: one word per rank
+    std::vector<long long> flags((size_t)world, 0);
+    if (have_first) {
+        const int rc = queue_mirror_search(c, *mine, f, rank == 0);
+        int32_t found = 0;
+        if (rc == RAFT_HIP_OK) {
+            HIP_TRY(c, hipMemcpyAsync(&found, c->gs_err.p, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+        }
+        flags[(size_t)rank] = rc == RAFT_HIP_OK ? (found ? 1 : 0) : -1;
+    }
+    rows.assign((size_t)world, 0);
+    rows[(size_t)rank] = flags[(size_t)rank];
+    { const int rc = gather(1); if (rc != RAFT_HIP_OK) return rc; }
+    if (!all_ok) { c->last_error = "raft_hip_presplit_symmetric: a rank was handed columns that do not fit its record count"; return RAFT_HIP_ERR_PARAM; }
+    *symmetric = 0;
+    for (int p = 0; p < world; ++p) {
+        if (rows[(size_t)p] < 0) { c->last_error = "raft_hip_presplit_symmetric: the search failed on rank " + std::to_string(p); return RAFT_HIP_ERR_DEVICE; }
+        if (rows[(size_t)p] > 0) *symmetric = 1;
+    }
+    return RAFT_HIP_OK;
+}
 
 int raft_hip_comm_unique_id(void *id128)
 {

@@ -28,7 +28,7 @@ EXPORTS = (
     "raft_hip_run_multi_grouped", "raft_hip_host_register", "raft_hip_host_unregister", "raft_hip_comm_unique_id",
     "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local", "raft_hip_warm_up", "raft_hip_reserve",
     "raft_hip_run_device_windows", "raft_hip_run_host_windows", "raft_hip_run_multi_windows",
-    "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device", "raft_hip_set_emit_cuts", "raft_hip_device_alloc", "raft_hip_device_free",
+    "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device", "raft_hip_set_emit_cuts", "raft_hip_device_alloc", "raft_hip_device_free", "raft_hip_group_sides", "raft_hip_presplit_symmetric", "raft_hip_presplit_symmetric_local",
 )
 
 
@@ -58,6 +58,10 @@ class _HostOutputs(C.Structure):
 
 class _Slice(C.Structure):
     _fields_ = [("n_rec", C.c_int64), ("n_runs", C.c_int32), ("rec_offset", C.c_void_p), ("d_qs", C.c_void_p), ("d_qe", C.c_void_p)]
+
+
+class _Records(C.Structure):
+    _fields_ = [("n_rec", C.c_int64)] + [(n, C.c_void_p) for n in ("d_qid", "d_qs", "d_qe", "d_tid", "d_ts", "d_te")]
 
 
 class _Received(C.Structure):
@@ -165,6 +169,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_set_emit_cuts.argtypes = [vp, i32]
     lib.raft_hip_device_alloc.argtypes = [vp, i64, C.POINTER(C.c_void_p)]
     lib.raft_hip_device_free.argtypes = [vp, vp]
+    lib.raft_hip_group_sides.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_Slice)]
+    lib.raft_hip_presplit_symmetric.argtypes = [vp, vp, i32, i32, C.POINTER(_Records), C.POINTER(i32)]
+    lib.raft_hip_presplit_symmetric_local.argtypes = [C.POINTER(vp), i32, C.POINTER(_Records), C.POINTER(i32)]
     lib.raft_hip_packed_device.argtypes = [vp, C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
     lib.raft_hip_selftest.argtypes = [C.c_int]
     lib.raft_hip_debug_stamps.argtypes = [vp, vp, i64, C.POINTER(i64)]
@@ -263,6 +270,27 @@ class Engine:
 
     def device_free(self, t):
         self._check(self._lib.raft_hip_device_free(self._ctx, C.c_void_p(getattr(t, "_raft_ptr", None) or t.data_ptr())))
+
+    def group_sides(self, n_reads_total: int, qid, qs, qe, tid=None, ts=None, te=None, symmetric: bool = False) -> "Slice":
+        """raft_hip_group_sides: the (read, start, end) intervals of a slice's records -- query sides, and target sides of records
+        whose two reads differ unless ``symmetric`` -- sorted by read id on the device, as a Slice in grouped form with one run
+        (ready for exchange_local / Comm.exchange).  The arrays are the context's (valid until its next group_sides)."""
+        import torch
+        self.use_torch_stream()
+        cols = [qid, qs, qe] + ([] if symmetric else [tid, ts, te])
+        for t in cols:
+            if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+                raise TypeError("group_sides needs contiguous int32 CUDA tensors")
+        ptr = [C.c_void_p(t.data_ptr() if t.numel() else 0) for t in cols] + ([C.c_void_p(0)] * 3 if symmetric else [])
+        out = _Slice()
+        self._check(self._lib.raft_hip_group_sides(self._ctx, n_reads_total, int(qid.numel()), *ptr, 1 if symmetric else 0, C.byref(out)))
+        n = int(out.n_rec)
+        off = np.ctypeslib.as_array(C.cast(out.rec_offset, C.POINTER(C.c_int64)), shape=(1, n_reads_total + 1)).copy()
+        dev = f"cuda:{self.device}"
+
+        def view(p):
+            return torch.empty(0, dtype=torch.int32, device=dev) if n == 0 else torch.as_tensor(_DevArray(p, n, "<i4", self), device=dev)
+        return Slice(off, view(out.d_qs), view(out.d_qe))
 
     def use_torch_stream(self):
         import torch
@@ -701,6 +729,28 @@ def exchange_local(engines, bounds, slices) -> list:
     return [_received_views(e, out[i]) for i, e in enumerate(engines)]
 
 
+def _records(cols) -> "_Records":
+    import torch
+    for t in cols:
+        if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+            raise TypeError("record columns must be contiguous int32 CUDA tensors")
+    n = int(cols[0].numel())
+    return _Records(n, *[t.data_ptr() if n else 0 for t in cols])
+
+
+def presplit_symmetric_local(engines, slices_cols) -> bool:
+    """raft_hip_presplit_symmetric_local: is the pre-split PAF symmetric?  ``slices_cols``: per rank its six device columns."""
+    import torch
+    lib = load_library()
+    w = len(engines)
+    torch.cuda.synchronize()
+    ctxs = (C.c_void_p * w)(*[e._ctx for e in engines])
+    recs = (_Records * w)(*[_records(c) for c in slices_cols])
+    flag = C.c_int32(-1)
+    engines[0]._check(lib.raft_hip_presplit_symmetric_local(ctxs, w, recs, C.byref(flag)))
+    return bool(flag.value)
+
+
 class Comm:
     """An RCCL communicator for raft_hip_exchange (one process per GPU).  ``unique_id()`` on rank 0, handed to the other ranks
     by the caller (e.g. a torch.distributed broadcast of its 128 bytes), then ``Comm(device, id, rank, world)`` everywhere."""
@@ -730,6 +780,15 @@ class Comm:
                                          C.byref(cs), C.byref(out))
         eng._check(rc)
         return _received_views(eng, out)
+
+    def symmetric(self, eng, cols) -> bool:
+        """raft_hip_presplit_symmetric: the OR over the ranks of "my slice holds the mirror of record 0"."""
+        eng.use_torch_stream()
+        import torch
+        torch.cuda.current_stream(eng.device).synchronize()
+        rec, flag = _records(cols), C.c_int32(-1)
+        eng._check(self._lib.raft_hip_presplit_symmetric(eng._ctx, self._comm, self.rank, self.world, C.byref(rec), C.byref(flag)))
+        return bool(flag.value)
 
     def close(self):
         if self._comm.value:

@@ -149,3 +149,96 @@ def test_more_than_four_runs_are_merged_on_the_device(k_runs):
         eng.run_device_grouped(t(rl), t(bad, torch.int64), None, t(a), t(b), n_bins=B); eng.finish()
     assert e.value.code == engine.ERR_PARAM
     eng.close()
+
+
+@pytest.mark.parametrize("shape", ["nonsym", "shuffled_sym"])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_non_symmetric_presplit_group_sides_then_exchange_equals_oracle(world, shape):
+    """A pre-split PAF that is NOT symmetric (target sides are piled up too, chop.hpp:165-169) or not sorted by query: every
+    rank expands and sorts ITS slice's sides on the device (raft_hip_group_sides, ABI 9) -- one run sorted by read id, hence by
+    owner -- and the exchange routes it like any grouped slice; each rank's grouped pass over what arrives equals the oracle's
+    outputs for its reads.  No torch sort, no torch collective (raft_amd/dist.py's exchange_intervals did both)."""
+    import torch
+    from raft_amd import dist as rdist
+    from raft_amd import engine
+    from raft_amd.synth import make_overlaps
+    sym = shape != "nonsym"
+    o = make_overlaps(n_reads=4000, seed=51 + world, symmetric=sym, shuffle=True)
+    cols = [c.numpy() for c in (o.read_len,) + o.columns()]
+    p = RaftParams(est_cov=30)
+    want = oracle_run(p, *cols)
+    assert want["symmetric"] == (1 if sym else 0)
+    engs = [engine.Engine(RaftParams(est_cov=30, symmetric_mode=1), device=0) for _ in range(world)]
+    weight = torch.bincount(o.qid.long(), minlength=o.n_reads)
+    if not sym:
+        weight = weight + torch.bincount(o.tid.long(), minlength=o.n_reads)
+    bounds = rdist.partition_reads(o.read_len, p.reso, world, intervals_per_read=weight).numpy()
+    slices, n_iv = [], 0
+    for g in range(world):
+        lo, hi = o.n_rec * g // world, o.n_rec * (g + 1) // world
+        dcols = [c[lo:hi].to("cuda:0").contiguous() for c in o.columns()]
+        sl = engs[g].group_sides(o.n_reads, *dcols, symmetric=sym)
+        # the slice is one run sorted by read id: offsets ascend, chain from 0 to the number of intervals
+        assert sl.off.shape == (1, o.n_reads + 1) and sl.off[0, 0] == 0 and (np.diff(sl.off[0]) >= 0).all() and sl.off[0, -1] == sl.qs.numel()
+        expect = (hi - lo) if sym else (hi - lo) + int((o.qid[lo:hi] != o.tid[lo:hi]).sum())
+        assert sl.qs.numel() == expect
+        n_iv += expect
+        slices.append(sl)
+    got = engine.exchange_local(engs, bounds, slices)
+    assert sum(g["n_rec"] for g in got) == n_iv
+    tot = 0
+    for g in range(world):
+        s = check_rank(torch, engs[g], p, got[g], cols[0], int(bounds[g]), int(bounds[g + 1]), want, f"{shape} world {world} rank {g}")
+        tot += s.n_fragments
+    assert tot == len(want["frag_read"])
+    # a read id out of range is reported, not sorted
+    bad = o.qid[:100].clone(); bad[7] = o.n_reads + 3
+    with pytest.raises(engine.RaftError) as e:
+        engs[0].group_sides(o.n_reads, bad.to("cuda:0"), *[c[:100].to("cuda:0").contiguous() for c in o.columns()[1:]], symmetric=sym)
+    assert e.value.code == engine.ERR_READ_ID
+    empty = [torch.empty(0, dtype=torch.int32, device="cuda:0")] * 6
+    sl0 = engs[0].group_sides(o.n_reads, *empty, symmetric=False)
+    assert sl0.qs.numel() == 0 and not sl0.off.any()
+    for e_ in engs:
+        e_.close()
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_presplit_symmetric_flag_is_the_or_over_the_ranks(world):
+    """chop.hpp:171-184 across ranks (raft_hip_presplit_symmetric_local / the RCCL form with one rank): record 0 is rank 0's first
+    record, its mirror may lie in any rank's slice -- or nowhere."""
+    import torch
+    from raft_amd import engine
+    from raft_amd.synth import make_overlaps
+    engs = [engine.Engine(RaftParams(est_cov=30), device=0) for _ in range(world)]
+    for sym in (True, False):
+        o = make_overlaps(n_reads=3000, seed=5 + world, symmetric=sym, shuffle=True)
+        cols = [c.to("cuda:0") for c in o.columns()]
+        want = oracle_run(RaftParams(est_cov=30), *[c.numpy() for c in (o.read_len,) + o.columns()])["symmetric"]
+        assert want == (1 if sym else 0)
+        cut = [o.n_rec * g // world for g in range(world + 1)]
+        parts = [[c[cut[g]:cut[g + 1]].contiguous() for c in cols] for g in range(world)]
+        assert engine.presplit_symmetric_local(engs, parts) == sym
+        if sym and world > 1:
+            # the mirror of record 0 moved to the last rank / removed altogether
+            q0, qs0, qe0, t0, ts0, te0 = (int(c[0]) for c in cols)
+            m = (cols[0] == t0) & (cols[3] == q0) & (cols[4] == qs0) & (cols[5] == qe0) & (cols[1] == ts0) & (cols[2] == te0)
+            m[0] = False
+            keep = ~m
+            rest = [c[keep] for c in cols]
+            mirror = [c[m][:1] for c in cols]
+            cut2 = [rest[0].numel() * g // world for g in range(world + 1)]
+            parts2 = [[c[cut2[g]:cut2[g + 1]].contiguous() for c in rest] for g in range(world)]
+            assert engine.presplit_symmetric_local(engs, parts2) is False
+            parts2[-1] = [torch.cat([a, b]).contiguous() for a, b in zip(parts2[-1], mirror)]
+            assert engine.presplit_symmetric_local(engs, parts2) is True
+    empty = [[torch.empty(0, dtype=torch.int32, device="cuda:0")] * 6 for _ in range(world)]
+    assert engine.presplit_symmetric_local(engs, empty) is False
+    if world == 1:
+        comm = engine.Comm(0, engine.Comm.unique_id(), 0, 1)
+        for sym in (True, False):
+            o = make_overlaps(n_reads=2000, seed=9, symmetric=sym)
+            assert comm.symmetric(engs[0], [c.to("cuda:0") for c in o.columns()]) == sym
+        comm.close()
+    for e in engs:
+        e.close()
