@@ -1,3 +1,6 @@
+"""The sequence that exposed the two rules of DevBuf's mapping (engine.hip): one context, the window-record pass with int32, then one-byte,
+then two-byte coverage -- the two-byte array is allocated right after the one-byte one is released -- each compared with the plain
+int32 pass.  WIDTHS=4,1,2 (default) | 2 | 2,2 ..."""
 import os, sys
 sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
 import numpy as np, torch
