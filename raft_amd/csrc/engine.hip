@@ -992,7 +992,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
                        pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow,
                        (fast && table_ok) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
                        c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags,
-                       (recut && !wave) ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp, pv.cap, 0);
+                       (recut && !wave) ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp, pv.cap);
     pa.n_extra = recut ? &ctrl->n_extra : nullptr;
     pa.piece_w = pv.cap;
 

@@ -90,7 +90,6 @@ static_assert(sizeof(TileCut) == 32, "two adjacent cuts are one 64-byte scalar l
 enum : int {
     kCutFast = 1,              // tile k holds whole reads that fit one LDS window
     kCutPiece = 2,             // (extra entries only) the tile is a piece of ONE read longer than the LDS window
-    kCutDefer = 4              // (extra entries only) the interval bounds are still to be searched (cut_bounds_kernel); iv_lo[0] = the tile walked
 };
 static_assert(sizeof(TileDesc) == 72, "descriptor is fetched as 18 dwords, one per lane");
 
@@ -855,11 +854,8 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                                                         int32_t *n_slow, const int32_t *samples, long long n_rec,
                                                         const long long *bucket_off, int32_t *err_flags, TileCut *extra,
                                                         int32_t *n_extra, int32_t extra_cap, int32_t piece_w, MirrorArgs mir,
-                                                        GroupedOff grp, int recut_cap, int defer_bounds)
+                                                        GroupedOff grp, int recut_cap)
 {
-    // defer_bounds: the walk below writes its entries without their interval bounds (cut_bounds_kernel searches them, one
-    // thread per entry: a walker's entries are one dependent chain of a hundred probes, 0.7 ms at human scale with every
-    // tile re-cut)
     // fast_cap < 0: no tile is taken as it is -- every tile with reads is re-cut into entries of at most recut_cap windows and
     // fast_max_reads reads (pileup_wave.hpp: one wave per entry); otherwise recut_cap == fast_cap
     if (*(volatile int32_t *)err_flags & kErrStop) return;   // (sizes or offsets the device found wrong: nothing here is safe)
@@ -1017,18 +1013,12 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
         // the entry before it ended)
         int32_t ib[kMaxSeg], ie[kMaxSeg];
         auto bounds_of = [&](int r, int32_t (&out)[kMaxSeg]) {
-            if (defer_bounds) {
-#pragma unroll
-                for (int s = 0; s < kMaxSeg; ++s) out[s] = 0;
-                out[0] = (int32_t)k;
-                return;
-            }
 #pragma unroll
             for (int s = 0; s < kMaxSeg; ++s) out[s] = s < sb.n_seg ? (int32_t)bound(s, r) : 0;
         };
         auto emit = [&](int slot, int r_a, int r_b, long long g_a, long long g_b, int flags) {
             TileCut b{}, e{};
-            b.r_lo = r_a; b.flags = flags | (defer_bounds ? kCutDefer : 0); b.g_lo = g_a;
+            b.r_lo = r_a; b.flags = flags; b.g_lo = g_a;
             e.r_lo = r_b; e.flags = 0; e.g_lo = g_b;
 #pragma unroll
             for (int s = 0; s < kMaxSeg; ++s) { b.iv_lo[s] = ib[s]; e.iv_lo[s] = ie[s]; }
@@ -1096,64 +1086,6 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
         if (lane == leader) base = atomicAdd(n_slow, (int)__popcll(sm));
         base = __shfl(base, leader, kWave);
         if (slow) slow_list[base + (int)__popcll(sm & ((1ull << lane) - 1ull))] = (int32_t)k;
-    }
-}
-
-// Interval bounds of the entries tile_desc_kernel's walk wrote without them (kCutDefer): entry [r_a, r_b) of the tile k the walk
-// belonged to begins, in run s, at the first record of read r_a inside the tile's own range and ends at the first of r_b --
-// the tile's own bounds where r_a / r_b are the tile's.  One thread per entry, its 2 n_seg bisections advancing together;
-// neighbouring entries search the same keys in the same range and so meet at the same index (the entries tile the range).
-__global__ __launch_bounds__(256) void cut_bounds_kernel(const int32_t *n_extra, TileCut *extra, const TileCut *cuts, const int32_t *iv_rid,
-                                                         int32_t n_seg, int32_t *err_flags)
-{
-    if (*(volatile int32_t *)err_flags & (kErrStop | kErrExtra)) return;
-    const int n = *n_extra;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        TileCut b = extra[2 * (long long)e], c = extra[2 * (long long)e + 1];
-        if (!(b.flags & kCutDefer)) continue;
-        const int k = b.iv_lo[0];
-        const TileCut t0 = cuts[k], t1 = cuts[k + 1];
-        long long lo[2 * kMaxSeg], hi[2 * kMaxSeg];
-        int key[2 * kMaxSeg];
-#pragma unroll
-        for (int s = 0; s < kMaxSeg; ++s) {
-            lo[s] = hi[s] = lo[kMaxSeg + s] = hi[kMaxSeg + s] = 0;
-            key[s] = b.r_lo; key[kMaxSeg + s] = c.r_lo;
-            if (s < n_seg) {
-                const long long tl = t0.iv_lo[s], th = t1.iv_lo[s];
-                lo[s] = tl; hi[s] = b.r_lo <= t0.r_lo ? tl : th;
-                if (b.r_lo >= t1.r_lo) lo[s] = th;
-                lo[kMaxSeg + s] = tl; hi[kMaxSeg + s] = c.r_lo <= t0.r_lo ? tl : th;
-                if (c.r_lo >= t1.r_lo) lo[kMaxSeg + s] = th;
-            }
-        }
-        for (;;) {
-            int v[2 * kMaxSeg];
-            bool any = false;
-#pragma unroll
-            for (int q = 0; q < 2 * kMaxSeg; ++q) {
-                v[q] = 0;
-                if (lo[q] < hi[q]) { v[q] = iv_rid[(lo[q] + hi[q]) >> 1]; any = true; }
-            }
-            if (!any) break;
-#pragma unroll
-            for (int q = 0; q < 2 * kMaxSeg; ++q) {
-                if (lo[q] < hi[q]) {
-                    const long long mid = (lo[q] + hi[q]) >> 1;
-                    if (v[q] < key[q]) lo[q] = mid + 1; else hi[q] = mid;
-                }
-            }
-        }
-        bool back = false;
-#pragma unroll
-        for (int s = 0; s < kMaxSeg; ++s) {
-            b.iv_lo[s] = (int32_t)lo[s];
-            c.iv_lo[s] = (int32_t)lo[kMaxSeg + s];
-            if (lo[kMaxSeg + s] < lo[s]) { back = true; c.iv_lo[s] = b.iv_lo[s]; }     // (an unsorted stream: the pass is refuted)
-        }
-        if (back) atomicOr(err_flags, kErrOrder);
-        b.flags &= ~kCutDefer;
-        extra[2 * (long long)e] = b; extra[2 * (long long)e + 1] = c;
     }
 }
 

@@ -1,6 +1,5 @@
 // wave_launch.hip -- instantiations and launches of pileup_wave_kernel.
 #include "wave_launch.hpp"
-#include <cstdlib>
 // The shared headers define (non-template) kernels; this translation unit sees them under a namespace of its own.
 #define raft raft_wave_tu
 #include "pack.hpp"
@@ -27,20 +26,11 @@ constexpr int kIterWin = RAFT_WAVE_SLOTS / 1024 + 1;
 constexpr int kIterCols = RAFT_WAVE_COLS_ITER;
 constexpr int kWaveSlots = RAFT_WAVE_SLOTS;
 
-#ifdef RAFT_WAVE_ALT_ITER
-static bool alt_on() { const char *e = getenv("RAFT_WAVE_ALT"); return e && *e == '1'; }
-#endif
-template <int OW, int IN, bool ALT = false>
+template <int OW, int IN>
 void launch_ow(hipStream_t st, int n_seg, const TileCut *cuts, const PileupArgs &pa, int n_waves)
 {
-#ifdef RAFT_WAVE_ALT_ITER
-    if (!ALT && IN == 0 && OW == 4 && alt_on()) { launch_ow<OW, IN, true>(st, n_seg, cuts, pa, n_waves); return; }
-    constexpr int kIter = IN == 1 ? kIterWin : (ALT ? RAFT_WAVE_ALT_ITER : kIterCols);
-    constexpr int kWps = IN == 1 ? kWpsWin : (ALT ? RAFT_WAVE_ALT_WPS : kWpsCols);
-#else
     constexpr int kIter = IN == 1 ? kIterWin : kIterCols;
     constexpr int kWps = IN == 1 ? kWpsWin : kWpsCols;
-#endif
     const unsigned grid = (unsigned)((n_waves + kWpb - 1) / kWpb);
     if (n_seg <= 1)
         hipLaunchKernelGGL((pileup_wave_kernel<kWaveSlots, 1, kIter + 1, OW, IN, kWpb, kWps>), dim3(grid), dim3(64 * kWpb), 0, st, cuts, pa);
@@ -51,13 +41,7 @@ void launch_ow(hipStream_t st, int n_seg, const TileCut *cuts, const PileupArgs 
 }
 } // namespace
 
-int wave_grid_waves(bool win)
-{
-#ifdef RAFT_WAVE_ALT_ITER
-    if (!win && alt_on()) return 256 * 4 * RAFT_WAVE_ALT_WPS;
-#endif
-    return 256 * 4 * (win ? kWpsWin : kWpsCols);
-}
+int wave_grid_waves(bool win) { return 256 * 4 * (win ? kWpsWin : kWpsCols); }
 
 void launch_wave_variant(int ow, bool win, hipStream_t st, int n_seg, const void *cuts_v, const void *pa_v, int n_waves)
 {
