@@ -3057,13 +3057,12 @@ int raft_hip_presplit_symmetric(raft_hip_ctx *c, void *comm_v, int32_t rank, int
     // second round: one word per rank
     std::vector<long long> flags((size_t)world, 0);
     if (have_first) {
-        const int rc = queue_mirror_search(c, *mine, f, rank == 0);
+        // (whatever fails here is announced in the second round, not returned: the other ranks are on their way into that collective)
         int32_t found = 0;
-        if (rc == RAFT_HIP_OK) {
-            HIP_TRY(c, hipMemcpyAsync(&found, c->gs_err.p, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
-        }
-        flags[(size_t)rank] = rc == RAFT_HIP_OK ? (found ? 1 : 0) : -1;
+        const bool ok = queue_mirror_search(c, *mine, f, rank == 0) == RAFT_HIP_OK &&
+                        hipMemcpyAsync(&found, c->gs_err.p, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        flags[(size_t)rank] = ok ? (found ? 1 : 0) : -1;
     }
     rows.assign((size_t)world, 0);
     rows[(size_t)rank] = flags[(size_t)rank];
