@@ -242,3 +242,48 @@ def test_presplit_symmetric_flag_is_the_or_over_the_ranks(world):
         comm.close()
     for e in engs:
         e.close()
+
+
+def test_non_symmetric_presplit_at_scale_eight_ranks_equal_the_single_pass():
+    """An eighth of BASELINE configs[2] made NON-symmetric (412 k reads, 3.6e7 records, 7e7 intervals), pre-split over eight ranks
+    (contexts of this process): raft_hip_presplit_symmetric_local says "not symmetric", every rank expands and sorts its slice
+    (raft_hip_group_sides), the exchange routes the runs, every rank's grouped pass equals the single non-symmetric pass of one
+    engine over the whole set -- every array, read range by read range -- and the totals add up."""
+    import torch
+    from raft_amd import dist as rdist
+    from raft_amd import engine
+    from raft_amd.synth import make_overlaps
+    world = 8
+    o = make_overlaps(412_500, mean_len=30000.0, coverage=32.0, seed=20241008, device="cuda:0", symmetric=False)
+    p = RaftParams(est_cov=32)
+    one = engine.Engine(p, device=0)
+    one.run_device(o.read_len, *o.columns())
+    s = one.finish()
+    assert s.symmetric == 0
+    ref = {k: v.clone() for k, v in one.outputs_device().items()}
+    one.close()
+    engs = [engine.Engine(RaftParams(est_cov=32, symmetric_mode=1), device=0) for _ in range(world)]
+    cut = [o.n_rec * g // world for g in range(world + 1)]
+    parts = [[c[cut[g]:cut[g + 1]].contiguous() for c in o.columns()] for g in range(world)]
+    assert engine.presplit_symmetric_local(engs, parts) is False
+    weight = torch.bincount(o.qid.long(), minlength=o.n_reads) + torch.bincount(o.tid.long(), minlength=o.n_reads)
+    bounds = rdist.partition_reads(o.read_len.cpu(), p.reso, world, intervals_per_read=weight.cpu()).numpy()
+    slices = [engs[g].group_sides(o.n_reads, *parts[g], symmetric=False) for g in range(world)]
+    assert sum(sl.qs.numel() for sl in slices) == s.n_intervals
+    got = engine.exchange_local(engs, bounds, slices)
+    tot = [0, 0, 0, 0]
+    for g in range(world):
+        b0, b1 = int(bounds[g]), int(bounds[g + 1])
+        rl = o.read_len[b0:b1].contiguous()
+        B = int(((rl.long() + p.reso - 1) // p.reso).sum())
+        engs[g].run_device_grouped(rl, got[g]["rec_offset"], None, got[g]["qs"], got[g]["qe"], n_bins=B)
+        sg = engs[g].finish()
+        out = engs[g].outputs_device()
+        for key, offk in (("cov", "cov_offset"), ("rep_s", "rep_offset"), ("rep_e", "rep_offset"), ("cuts", "cut_offset"),
+                          ("frag_begin", "frag_offset"), ("frag_end", "frag_offset")):
+            lo, hi = int(ref[offk][b0]), int(ref[offk][b1])
+            assert torch.equal(out[key], ref[key][lo:hi]), (g, key)
+        tot = [tot[0] + sg.n_fragments, tot[1] + sg.n_repeats, tot[2] + sg.total_coverage, tot[3] + sg.total_repeat_length]
+    assert tot == [s.n_fragments, s.n_repeats, s.total_coverage, s.total_repeat_length]
+    for e in engs:
+        e.close()
