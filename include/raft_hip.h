@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_ABI_VERSION 9
+#define RAFT_HIP_ABI_VERSION 10
 
 /* error codes (0..5 are shared with oracle/raft_oracle.h) */
 enum {
@@ -263,6 +263,15 @@ int  raft_hip_set_emit_cuts(raft_hip_ctx *ctx, int32_t on);
  * reference: chop.hpp:155-169 fills host vectors.) */
 int  raft_hip_device_alloc(raft_hip_ctx *ctx, int64_t bytes, void **dptr);
 int  raft_hip_device_free(raft_hip_ctx *ctx, void *dptr);
+
+/* The placement's memory (ABI 10).  Physical chunks no buffer maps at the moment wait in a per-device pool for the next
+ * buffer; the pool holds RAFT_VMM_POOL_GB GiB at most (default 64), spare chunks are only made while an eighth of the device's
+ * memory (8 GiB at least) stays free behind them, an allocation that fails hands the pool back and is made once more, and the
+ * last context of a device to be destroyed hands all of it back.  raft_hip_trim does that on demand: every pooled chunk of
+ * the device beyond keep_bytes goes back to the driver (returns the bytes released, or a negative RAFT_HIP_ERR_*);
+ * raft_hip_pool_bytes reports what the pool holds.  (Replaces nothing in the reference.) */
+int64_t raft_hip_trim(int device_id, int64_t keep_bytes);
+int64_t raft_hip_pool_bytes(int device_id);
 
 /* Device arrays of the encoding the finished pass holds (width 0: none -- the pass wrote int32; call
  * raft_hip_fetch_packed_w once to have it encoded).  The exceptions are in no particular order. */

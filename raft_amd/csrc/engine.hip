@@ -153,9 +153,52 @@ struct ChunkPool {                    // per device; handles of 32 MiB physical 
     std::mutex mu;
     std::vector<hipMemGenericAllocationHandle_t> free_chunks;
     unsigned long long rng = 0x9E3779B97F4A7C15ull;
+    int live_ctx = 0;                 // contexts of this device: the last one to go hands the pool back to the driver
     static ChunkPool &of(int dev) { static ChunkPool pools[64]; return pools[dev & 63]; }
     unsigned long long next() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return rng >> 33; }
+    // most chunks the pool keeps (RAFT_VMM_POOL_GB, default 64): what comes back beyond that goes to the driver
+    static size_t cap_chunks()
+    {
+        static const size_t v = [] {
+            const char *e = getenv("RAFT_VMM_POOL_GB");
+            const double gb = e ? std::max(0.0, atof(e)) : 64.0;
+            return (size_t)(gb * 32.0);                    // 32 chunks of 32 MiB per GiB
+        }();
+        return v;
+    }
+    // (mu held) a chunk nobody maps: kept for later buffers while there is room, else released
+    void put(hipMemGenericAllocationHandle_t h)
+    {
+        if (free_chunks.size() < cap_chunks()) free_chunks.push_back(h);
+        else (void)hipMemRelease(h);
+    }
+    // hands all but `keep` chunks back to the driver; returns how many went
+    size_t trim(size_t keep)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t n = 0;
+        while (free_chunks.size() > keep) { (void)hipMemRelease(free_chunks.back()); free_chunks.pop_back(); ++n; }
+        if (free_chunks.empty()) free_chunks.shrink_to_fit();
+        return n;
+    }
 };
+
+// The streams whose work may still use a buffer this thread is about to release or re-map (the context's own and its side
+// stream): release() waits for those instead of the whole device -- other contexts' passes go on.  None named: the device.
+struct SyncScope {
+    static thread_local hipStream_t streams[2];
+    static thread_local int n;
+    int saved_n; hipStream_t saved[2];
+    SyncScope(hipStream_t a, hipStream_t b) { saved_n = n; saved[0] = streams[0]; saved[1] = streams[1]; streams[0] = a; streams[1] = b; n = 2; }
+    ~SyncScope() { n = saved_n; streams[0] = saved[0]; streams[1] = saved[1]; }
+    static void wait()
+    {
+        if (n == 0) { (void)hipDeviceSynchronize(); return; }
+        for (int i = 0; i < n; ++i) (void)hipStreamSynchronize(streams[i]);
+    }
+};
+thread_local hipStream_t SyncScope::streams[2] = {nullptr, nullptr};
+thread_local int SyncScope::n = 0;
 
 struct DevBuf {
     void *p = nullptr;
@@ -163,6 +206,7 @@ struct DevBuf {
     bool big = false;                 // may be backed by pooled chunks
     int dev = 0;                      // device of the chunks
     std::vector<hipMemGenericAllocationHandle_t> chunks;
+    std::vector<size_t> map_order;    // chunk mapped at the i-th 32 MiB of the range
     size_t va_bytes = 0;
     static constexpr size_t kChunk = 32u << 20, kVmmMin = 64u << 20, kSpreadMin = size_t(1) << 30;
     bool map_chunks(size_t want)
@@ -198,6 +242,17 @@ struct DevBuf {
             // device cannot give that many, what was made goes to the pool, serves first, and the rest is tried with fewer spares
             for (size_t k = want >= kSpreadMin ? kSpread : 1; chunks.size() < n; k /= 2) {
                 const size_t need = n - chunks.size();
+                if (k > 1) {
+                    // spares only while the pool has room for them and the device keeps an eighth of its memory (8 GiB at least)
+                    // free behind them: plain hipMalloc buffers of this pass, RCCL, torch and other processes live there
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; total_b = 0; }
+                    const size_t reserve = std::max<size_t>(size_t(8) << 30, total_b / 8);
+                    const size_t room_mem = free_b > reserve + need * kChunk ? (free_b - reserve - need * kChunk) / kChunk : 0;
+                    const size_t room_pool = pool.free_chunks.size() < ChunkPool::cap_chunks() ? ChunkPool::cap_chunks() - pool.free_chunks.size() : 0;
+                    const size_t spares = std::min(room_mem, room_pool);
+                    while (k > 1 && need * (k - 1) > spares) k /= 2;
+                }
                 std::vector<hipMemGenericAllocationHandle_t> all(need * k);
                 size_t made = 0;
                 bool ok = true;
@@ -205,12 +260,12 @@ struct DevBuf {
                 if (!ok) { --made; (void)hipGetLastError(); }
                 for (size_t i = 0; i < made; ++i) {
                     if (ok && i % k == 0) chunks.push_back(all[i]);
-                    else pool.free_chunks.push_back(all[i]);
+                    else pool.free_chunks.push_back(all[i]);       // (drawn from again right below when the device ran out)
                 }
                 if (!ok) { draw(); if (k == 1) break; }
             }
             if (chunks.size() != n) {
-                for (auto &h : chunks) pool.free_chunks.push_back(h);
+                for (auto &h : chunks) pool.put(h);
                 chunks.clear();
             }
         }
@@ -230,11 +285,12 @@ struct DevBuf {
         }
         if (!ok) {
             (void)hipGetLastError();
-            if (mapped) (void)hipMemUnmap(va, mapped * kChunk);
-            { std::lock_guard<std::mutex> lk(pool.mu); for (auto &h : chunks) pool.free_chunks.push_back(h); }
+            for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap((hipDeviceptr_t)((char *)va + i * kChunk), kChunk);
+            { std::lock_guard<std::mutex> lk(pool.mu); for (auto &h : chunks) pool.put(h); }
             chunks.clear();
             return false;                                  // (a range that was mapped, even in part, stays reserved)
         }
+        map_order = order;
         p = va; cap = n * kChunk; va_bytes = n * kChunk;
         return true;
     }
@@ -246,17 +302,31 @@ struct DevBuf {
         if (want == 0) want = 256;
         if (big && want >= kVmmMin && map_chunks(want)) return hipSuccess;
         hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            // out of memory with chunks parked in the pool: they go back to the driver and the request is made once more
+            (void)hipGetLastError();
+            int d = 0;
+            if (hipGetDevice(&d) == hipSuccess && ChunkPool::of(d).trim(0) > 0) {
+                if (big && want >= kVmmMin && map_chunks(want)) return hipSuccess;
+                e = hipMalloc(&p, want);
+            }
+        }
         if (e == hipSuccess) cap = want; else p = nullptr;
         return e;
     }
     void release()
     {
         if (p && va_bytes) {
-            (void)hipDeviceSynchronize();                  // (nothing in flight may still use the range)
-            (void)hipMemUnmap(p, va_bytes);
-            { ChunkPool &pool = ChunkPool::of(dev); std::lock_guard<std::mutex> lk(pool.mu); for (auto &h : chunks) pool.free_chunks.push_back(h); }
+            SyncScope::wait();                             // (nothing in flight may still use the range)
+            // chunk by chunk, as it was mapped; a chunk whose mapping did not go away is neither pooled nor released
+            ChunkPool &pool = ChunkPool::of(dev);
+            std::lock_guard<std::mutex> lk(pool.mu);
+            for (size_t i = 0; i < chunks.size(); ++i) {
+                if (hipMemUnmap((hipDeviceptr_t)((char *)p + i * kChunk), kChunk) == hipSuccess) pool.put(chunks[i < map_order.size() ? map_order[i] : i]);
+                else (void)hipGetLastError();
+            }
             // (the range stays reserved: see above)
-            chunks.clear();
+            chunks.clear(); map_order.clear();
         } else if (p) (void)hipFree(p);
         p = nullptr; cap = 0; va_bytes = 0;
     }
@@ -334,6 +404,7 @@ struct raft_hip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t side_stream = nullptr;   // the general pileup kernel runs beside the fast one
+    bool counted = false;                // this context is one of ChunkPool::live_ctx
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_ifork = nullptr;
     raft_hip_params prm{};
@@ -517,6 +588,8 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     }
     c->stream = c->own_stream;
     memset(c->pinned, 0, 4096);                            // (the pass numbers raft_hip_finish looks for start at 1)
+    { ChunkPool &pool = ChunkPool::of(device_id); std::lock_guard<std::mutex> lk(pool.mu); ++pool.live_ctx; }
+    c->counted = true;
     *out = c;
     return RAFT_HIP_OK;
 }
@@ -527,6 +600,9 @@ void raft_hip_destroy(raft_hip_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (raft_hip_ctx *l : c->lanes) raft_hip_destroy(l);
+    if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+    if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
+    SyncScope scope(c->stream, c->side_stream);            // (the buffers' releases wait for this context's streams, not the device)
     c->lanes.clear();
     for (hipEvent_t e : c->lane_up_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->lane_down_ev) (void)hipEventDestroy(e);
@@ -553,7 +629,29 @@ void raft_hip_destroy(raft_hip_ctx *c)
     if (c->ev_gjoin) (void)hipEventDestroy(c->ev_gjoin);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->counted) {                                      // the device's last context hands the pooled chunks back to the driver
+        ChunkPool &pool = ChunkPool::of(c->device);
+        bool last = false;
+        { std::lock_guard<std::mutex> lk(pool.mu); last = --pool.live_ctx == 0; }
+        if (last && getenv("RAFT_VMM_KEEP_POOL") == nullptr) (void)pool.trim(0);
+    }
     delete c;
+}
+
+int64_t raft_hip_trim(int device_id, int64_t keep_bytes)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev || keep_bytes < 0) return -(int64_t)RAFT_HIP_ERR_PARAM;
+    if (hipSetDevice(device_id) != hipSuccess) return -(int64_t)RAFT_HIP_ERR_DEVICE;
+    return (int64_t)ChunkPool::of(device_id).trim((size_t)(keep_bytes / (int64_t)DevBuf::kChunk)) * (int64_t)DevBuf::kChunk;
+}
+
+int64_t raft_hip_pool_bytes(int device_id)
+{
+    if (device_id < 0 || device_id >= 64) return -(int64_t)RAFT_HIP_ERR_PARAM;
+    ChunkPool &pool = ChunkPool::of(device_id);
+    std::lock_guard<std::mutex> lk(pool.mu);
+    return (int64_t)pool.free_chunks.size() * (int64_t)DevBuf::kChunk;
 }
 
 int raft_hip_set_params(raft_hip_ctx *c, const raft_hip_params *params)
@@ -634,6 +732,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     if (n_rec >= (1LL << 29)) return RAFT_HIP_ERR_TOO_LARGE;   // interval byte offsets are 32-bit (2 sides per record at most)
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    SyncScope scope(c->stream, c->side_stream);            // (a buffer that grows waits for this context's streams only)
     bool expand = false;
     const PileVariant &pv = kVariants[c->variant];
     // tiles that do not fit the fast kernel are re-cut for it (pileup.hpp tile_desc_kernel) unless told otherwise
@@ -1243,36 +1342,39 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
                 if (rc != RAFT_HIP_OK) return rc;
             }
         }
-        if (c->pending_err == RAFT_HIP_OK) {
-            const Ctrl hc = ctrl_block();
-            if ((hc.err_flags & kErrExtra) && !(hc.err_flags & kErrStop)) {   // more extra tiles than room: this pass with the general kernel
-                c->no_recut = true;
+        // Three more reasons to run the pass again, each of which may turn up in the re-run of another: what one of them
+        // forces (the int32 kernels, no re-cut tiles, a longer list) stays in force for every later re-run of this call.
+        //  * kErrExtra: more extra tiles than room -> this pass with the general kernel for those tiles (the wave kernel has no
+        //    other tiles than the ones it cuts itself: int32 kernels);
+        //  * kErrDeep: a wave tile with 2^15 or more intervals (a pile-up that deep does not fit the 16-bit difference array
+        //    of pileup_wave.hpp) -> the int32 kernels;
+        //  * more windows at or above the encoding's limit than the list held -> once more with room for all of them.
+        {
+            int force_variant = -1;
+            bool force_no_recut = false;
+            for (int round = 0; round < 4 && c->pending_err == RAFT_HIP_OK; ++round) {
+                const Ctrl hc = ctrl_block();
+                if (hc.err_flags & kErrStop) break;
+                bool rerun = false;
+                if ((hc.err_flags & kErrExtra) && !force_no_recut) {
+                    force_no_recut = true;
+                    if (kVariants[c->variant].fast == 2) force_variant = 0;
+                    rerun = true;
+                } else if ((hc.err_flags & kErrDeep) && force_variant != 0) {
+                    force_variant = 0;
+                    rerun = true;
+                } else if (c->pass_width != 4 && (long long)hc.n_exc > c->exc_cap && !(hc.err_flags & ~(kErrOrder | kErrExtra | kErrDeep))) {
+                    c->exc_cap = (long long)hc.n_exc;
+                    rerun = true;
+                }
+                if (!rerun) break;
                 const int keep = c->variant;
-                if (kVariants[c->variant].fast == 2) c->variant = 0;      // (the wave kernel has no other tiles than the list's)
+                const bool keep_recut = c->no_recut;
+                if (force_variant >= 0) c->variant = force_variant;
+                if (force_no_recut) c->no_recut = true;
                 const int rc = again(c->args);
                 c->variant = keep;
-                c->no_recut = false;
-                if (rc != RAFT_HIP_OK) return rc;
-            }
-        }
-        if (c->pending_err == RAFT_HIP_OK) {
-            const Ctrl hc = ctrl_block();
-            if ((hc.err_flags & kErrDeep) && !(hc.err_flags & kErrStop)) {
-                // a wave tile with 2^15 or more intervals (a pile-up that deep does not fit the 16-bit difference array of
-                // pileup_wave.hpp): this pass once more with the int32 kernels
-                const int keep = c->variant;
-                c->variant = 0;
-                const int rc = again(c->args);
-                c->variant = keep;
-                if (rc != RAFT_HIP_OK) return rc;
-            }
-        }
-        if (c->pending_err == RAFT_HIP_OK && c->pass_width != 4) {
-            const Ctrl hc = ctrl_block();
-            if ((long long)hc.n_exc > c->exc_cap && !(hc.err_flags & ~(kErrOrder | kErrExtra | kErrDeep))) {
-                // more windows at or above the encoding's limit than the list held: once more with room for all of them
-                c->exc_cap = (long long)hc.n_exc;
-                const int rc = again(c->args);
+                c->no_recut = keep_recut;
                 if (rc != RAFT_HIP_OK) return rc;
             }
         }

@@ -194,13 +194,16 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
     const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
     const int per_xcc = max(1, kCtr / 8);
     int ctr = kCtr >= 8 ? xcc * per_xcc + (wave_id / 8) % per_xcc : wave_id % kCtr, ctr_tried = 0;
+    // counter c hands out segments [c * q + min(c, r), ...) with q, r = n_seg_tiles divmod kCtr: one 32-bit division per worker
+    // (the 64-bit n * c / kCtr this replaces was 800 scalar instructions in every draw)
+    const int share_q = (int)((unsigned)n_seg_tiles / (unsigned)kCtr), share_r = n_seg_tiles - share_q * kCtr;
     auto next_range = [&](Start &t) -> bool {     // synchronous (a draw, two boundary records)
         for (;;) {
             if (ctr_tried == kCtr) return false;
             int drawn = 0;
             if (lane == 0) drawn = __hip_atomic_fetch_add(draw_from + ctr * kCtrStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             wait_all_loads();
-            const int d0 = (int)((long long)n_seg_tiles * ctr / kCtr), d1 = (int)((long long)n_seg_tiles * (ctr + 1) / kCtr);
+            const int d0 = ctr * share_q + min(ctr, share_r), d1 = d0 + share_q + (ctr < share_r ? 1 : 0);
             int k0 = d0 + uni(drawn);
             if (k0 >= d1) k0 = n_seg_tiles;
             if (k0 >= n_seg_tiles) { ctr = ctr + 1 == kCtr ? 0 : ctr + 1; ++ctr_tried; continue; }

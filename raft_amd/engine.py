@@ -29,6 +29,7 @@ EXPORTS = (
     "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local", "raft_hip_warm_up", "raft_hip_reserve",
     "raft_hip_run_device_windows", "raft_hip_run_host_windows", "raft_hip_run_multi_windows",
     "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device", "raft_hip_set_emit_cuts", "raft_hip_device_alloc", "raft_hip_device_free", "raft_hip_group_sides", "raft_hip_presplit_symmetric", "raft_hip_presplit_symmetric_local",
+    "raft_hip_trim", "raft_hip_pool_bytes",
 )
 
 
@@ -169,6 +170,10 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_set_emit_cuts.argtypes = [vp, i32]
     lib.raft_hip_device_alloc.argtypes = [vp, i64, C.POINTER(C.c_void_p)]
     lib.raft_hip_device_free.argtypes = [vp, vp]
+    lib.raft_hip_trim.argtypes = [C.c_int, i64]
+    lib.raft_hip_trim.restype = i64
+    lib.raft_hip_pool_bytes.argtypes = [C.c_int]
+    lib.raft_hip_pool_bytes.restype = i64
     lib.raft_hip_group_sides.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_Slice)]
     lib.raft_hip_presplit_symmetric.argtypes = [vp, vp, i32, i32, C.POINTER(_Records), C.POINTER(i32)]
     lib.raft_hip_presplit_symmetric_local.argtypes = [C.POINTER(vp), i32, C.POINTER(_Records), C.POINTER(i32)]
@@ -798,3 +803,13 @@ class Comm:
 
 def selftest(device: int = 0) -> int:
     return int(load_library().raft_hip_selftest(device))
+
+
+def trim(device: int = 0, keep_bytes: int = 0) -> int:
+    """Hands the device's pooled placement chunks beyond keep_bytes back to the driver; returns the bytes released."""
+    return int(load_library().raft_hip_trim(device, keep_bytes))
+
+
+def pool_bytes(device: int = 0) -> int:
+    """Bytes of physical chunks the placement pool of the device holds at the moment (mapped by no buffer)."""
+    return int(load_library().raft_hip_pool_bytes(device))

@@ -23,7 +23,7 @@ def test_library_exports_every_symbol():
     lib = engine.load_library()
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.raft_hip_abi_version() == 9
+    assert lib.raft_hip_abi_version() == 10
     assert lib.raft_hip_strerror(2).decode().startswith("PAF record names a read id")
 
 

@@ -128,6 +128,29 @@ def test_a_tile_too_deep_for_sixteen_bits_falls_back_to_the_int32_kernels():
     eng.close()
 
 
+def test_a_deep_tile_whose_int32_rerun_overflows_the_exception_list():
+    """kErrDeep sends the pass to the int32 kernels; with one byte per window that re-run lists more windows at
+    or above 255 than the default list holds (max(4096, B / 64)), and the re-run for THAT must stay with the int32 kernels --
+    it used to return to the wave kernel, meet the deep tile again and end in ERR_DEVICE."""
+    from test_gpu_packed_output import check_against, run_width
+    rng = np.random.default_rng(11)
+    rl = np.array([30000, 12000, 400000, 8000], np.int32)          # read 2: 8000 windows, most of them 40,000 deep
+    m = 40000
+    qid = np.concatenate([np.zeros(50, np.int32), np.full(m, 2, np.int32), np.full(30, 3, np.int32)])
+    qs = np.zeros(qid.size, np.int32); qe = np.zeros(qid.size, np.int32)
+    qs[50:50 + m] = rng.integers(0, 20000, m); qe[50:50 + m] = qs[50:50 + m] + rng.integers(330000, 380000, m)
+    qs[:50] = rng.integers(0, 10000, 50); qe[:50] = qs[:50] + 5000
+    qs[50 + m:] = 100; qe[50 + m:] = 7000
+    p = RaftParams(est_cov=30, symmetric_mode=1)
+    cols = (rl, qid, qs, qe, qid, qs, qe)
+    want = oracle_run(p, *cols)
+    want["symmetric"] = 1
+    assert want["cov"].max() >= 32768 and int((want["cov"] >= 255).sum()) > 4096
+    for width in (1, 2):
+        res = run_width(p, cols, width, variant=5)
+        check_against(res, want, width, f"deep tile, width {width}")
+
+
 def test_cut_points_in_the_pass_or_on_demand():
     from raft_amd import engine
     from raft_amd.synth import make_overlaps
@@ -220,3 +243,40 @@ def test_input_columns_in_memory_from_the_engine_give_the_same_result():
     with pytest.raises(engine.RaftError):
         eng.device_free(again[10:])                                # (not a pointer this context handed out)
     eng.close()
+
+
+def test_placement_pool_is_bounded_and_goes_back_to_the_driver():
+    """VERDICT r04 item 7 / ADVICE: the spare chunks of the placement (DevBuf, engine.hip) wait in a per-device pool; the pool
+    is capped (RAFT_VMM_POOL_GB), raft_hip_trim hands it back on demand, and the device's last context to be destroyed hands
+    all of it back: free device memory returns to within 1 GB of where it was.  Own process: the count of live contexts is exact."""
+    import subprocess, sys, os
+    code = r'''
+import numpy as np, torch
+from raft_amd import engine
+from raft_amd.params import RaftParams
+from raft_amd.synth import make_overlaps
+o = make_overlaps(500000, mean_len=30000.0, coverage=8.0, seed=3, device="cuda:0")     # 3e8 windows: a coverage array of 1.2 GB is spread
+cols = (o.read_len,) + o.columns()
+torch.cuda.synchronize(); torch.cuda.empty_cache()
+free0 = torch.cuda.mem_get_info(0)[0]
+eng = engine.Engine(RaftParams(est_cov=8))
+eng.run_device(*cols); s = eng.finish()
+assert s.total_windows * 4 >= (1 << 30)
+pooled = engine.pool_bytes(0)
+assert 0 < pooled <= 2 * (1 << 30), pooled          # (RAFT_VMM_POOL_GB=2 in this process: the cap holds)
+got = engine.trim(0, 1 << 30)
+assert engine.pool_bytes(0) <= (1 << 30) and got == pooled - engine.pool_bytes(0)
+eng2 = engine.Engine(RaftParams(est_cov=8))
+eng.close()
+assert engine.pool_bytes(0) > 0                     # (another context lives: the released buffers' chunks wait for it)
+eng2.close()
+assert engine.pool_bytes(0) == 0
+torch.cuda.synchronize(); torch.cuda.empty_cache()
+free1 = torch.cuda.mem_get_info(0)[0]
+assert free0 - free1 < (1 << 30), (free0, free1)
+print("POOL_OK")
+'''
+    env = dict(os.environ, RAFT_VMM_POOL_GB="2", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env.pop("RAFT_NO_VMM", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "POOL_OK" in r.stdout, r.stdout[-2000:]

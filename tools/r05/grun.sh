@@ -1,0 +1,9 @@
+#!/bin/bash
+# grun.sh <timeout-seconds> <command...>: gpurun with retries while no slot is free (exit code 3)
+T=$1; shift
+for i in $(seq 1 40); do
+  /usr/local/graft/bin/gpurun --timeout $T -- "$@"; rc=$?
+  if [ $rc -ne 3 ]; then exit $rc; fi
+  sleep 60
+done
+exit 3
