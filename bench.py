@@ -645,7 +645,7 @@ def main():
                  "cut_points_span_reads": bool((out["cuts"][out["cut_offset"][:-1]] == 0).all()) and bool((out["cuts"][out["cut_offset"][1:] - 1] == o.read_len).all())
                  and int(out["cut_offset"][-1]) == s.n_cuts}
         del touched, out
-        if not all(check.values()) and "RAFT_BENCH_ABLATION" not in os.environ:      # (ablation builds of tools/ab.sh compute nonsense on purpose)
+        if not all(check.values()) and "RAFT_BENCH_ABLATION" not in os.environ:      # (diagnostic builds with parts of the kernel switched off compute nonsense on purpose)
             raise SystemExit(f"bench.py: self-check failed: {check}")
 
         # ---- several GPUs, weak headline: BASELINE configs[3]'s setting beside it -- the ONE set of configs[2] in `world` read ranges

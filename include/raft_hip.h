@@ -427,6 +427,20 @@ int  raft_hip_presplit_symmetric(raft_hip_ctx *ctx, void *comm, int32_t rank, in
                                  int32_t *symmetric);
 int  raft_hip_presplit_symmetric_local(raft_hip_ctx *const *ctxs, int32_t world, const raft_hip_records *slices, int32_t *symmetric);
 
+/* The whole pre-split job of ONE process (ABI 10; the C++ caller BASELINE configs[3] / SURVEY.md §8e "pre-split" asks for: main.cpp:21-87
+ * + chop.hpp:331-373 with the record stream cut into `world` contiguous slices).  ctxs[r] is rank r -- contexts of this process on
+ * whatever devices the caller made them (one GPU per rank on a node; several ranks on one GPU is how the one-GPU tests run it).
+ * Rank r holds records [n_rec r / world, n_rec (r + 1) / world) of the six HOST columns as they come (any order, symmetric or
+ * not); the call uploads the slices, finds the symmetric flag (raft_hip_presplit_symmetric_local), expands and groups every
+ * slice's sides (raft_hip_group_sides), routes them to the owners of their reads (raft_hip_exchange_local: contiguous read
+ * ranges of equal window counts), runs every rank's grouped pass and writes the ranks' outputs into `out` in read order -- the
+ * same arrays, bounds and errors as raft_hip_run_multi; out->cov_width 1 or 2.  ctxs[0]'s parameters apply to all.
+ * One process per GPU: the same steps with raft_hip_presplit_symmetric / raft_hip_exchange over RCCL. */
+int  raft_hip_run_presplit_local(raft_hip_ctx *const *ctxs, int32_t world, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                                 const int32_t *qid, const int32_t *qs, const int32_t *qe,
+                                 const int32_t *tid, const int32_t *ts, const int32_t *te,
+                                 raft_hip_host_outputs *out, raft_hip_summary *summary);
+
 /* Page-locks / releases a range of the caller's host memory (hipHostRegister, every device of the node).  Arrays handed to
  * the host-to-host entry points move at the link's rate (53 GB/s each way on MI355X) only from page-locked memory; pages
  * that have been written before are pinned at ~120 GB/s, untouched ones at the cost of their first touch.  A caller that

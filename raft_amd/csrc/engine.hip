@@ -4,10 +4,10 @@
 #include "../../include/raft_hip.h"
 
 #include "bucket.hpp"
+#include "sort_pairs.hpp"
 #include "device_scan.hpp"
 #include "finalize.hpp"
 #include "pack.hpp"
-#include <rocprim/device/device_radix_sort.hpp>   // (the exception list's order: a library sort of a few 1e5 pairs, off the hot path)
 #include "pileup.hpp"
 #include "pileup_fast.hpp"
 #include "pileup_wave.hpp"
@@ -420,9 +420,9 @@ struct raft_hip_ctx {
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
-    DevBuf gs_s, gs_e, gs_off, gs_err;  // raft_hip_group_sides: the slice it hands back (+ its error word)
+    DevBuf gs_rid, gs_s, gs_e, gs_off, gs_err;  // raft_hip_group_sides: the slice it hands back (+ its error word)
     std::vector<long long> gs_off_host;
-    DevBuf rs_k0, rs_k1, rs_v0, rs_v1;   // general streams, large inputs: (read id, start | end << 32) per side, before and after the radix sort
+    DevBuf rs_k0, rs_v0, coarse;         // general streams, large inputs: the sides between the two steps of the partition (ids; starts | ends), the coarse buckets' tables
     DevBuf samples;                   // up to kSamples + 2 read ids at evenly spaced records (guess_runs_kernel): coarse index
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
     DevBuf dbg;                       // diagnostic variant only
@@ -566,7 +566,7 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     c->device = device_id;
     for (DevBuf *b : {&c->cov, &c->cov8, &c->cuts, &c->frag_read, &c->frag_begin, &c->frag_end, &c->raw_key, &c->raw_s, &c->raw_e, &c->rep_s, &c->rep_e,
                       &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5], &c->u_s, &c->u_e, &c->exp_qid,
-                      &c->b_rid, &c->b_s, &c->b_e, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1})
+                      &c->b_rid, &c->b_s, &c->b_e, &c->rs_k0, &c->rs_v0, &c->gs_rid, &c->gs_s, &c->gs_e})
         b->big = true;                                         // (what a pass streams through: see DevBuf)
     apply_params(c, params);
     if (const char *w = getenv("RAFT_COV_WIDTH")) {           // (test sweeps: every context of the process in that width)
@@ -612,7 +612,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
     DevBuf *all[] = {&c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
-                     &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->gs_s, &c->gs_e, &c->gs_off, &c->gs_err, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1, &c->in_len,
+                     &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->gs_rid, &c->gs_s, &c->gs_e, &c->gs_off, &c->gs_err, &c->rs_k0, &c->rs_v0, &c->coarse, &c->in_len,
                      &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->exc_idx2, &c->exc_val2, &c->sort_tmp, &c->exc_pidx, &c->exc_pval, &c->exc_tile_n, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     for (DevBuf *b : c->user_bufs) { b->release(); delete b; }
@@ -711,6 +711,46 @@ int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket
 // at hand; without one the ids ARE the offsets, expanded on the device).  A record that does not sit where the offsets
 // say sends the pass to the plain form above.  With the caller's window count (`in.hint_bins`) the host sizes everything
 // without waiting for the device: the pass is one uninterrupted sequence of launches.
+// The sides of a record stream in any order, partitioned by read (bucket.hpp, round 5): o_rid / o_s / o_e hold every read's
+// intervals together, reads in index order; off[r] says where read r's begin, off[n_reads] how many there are.  *done = false:
+// the shape does not fit (more reads than 4096 coarse buckets of 8192 take) and nothing was launched.
+static int partition_sides(raft_hip_ctx *c, hipStream_t st, long long n_rec, int32_t n_reads, int symmetric, const int32_t *d_qid, const int32_t *d_qs,
+                           const int32_t *d_qe, const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te, long long cap_iv, int32_t *o_rid, int32_t *o_s,
+                           int32_t *o_e, long long *off, int32_t *err_flags, long long *err_index, bool *done)
+{
+    *done = false;
+    if (n_rec <= 0 || n_reads <= 0) return RAFT_HIP_OK;
+    // reads per coarse bucket: a power of two with ~2 MB of intervals per bucket (12 bytes each), 16 at least, 8192 at most
+    const double per_read = std::max(1.0, (double)cap_iv / (double)n_reads);
+    int rshift = 4;
+    while (rshift < kFineMaxShift && (double)(2 << rshift) * per_read * 12.0 <= 2.0e6) ++rshift;
+    while (rshift < kFineMaxShift && (((long long)n_reads + (1LL << rshift) - 1) >> rshift) > kCoarseMax) ++rshift;
+    if (const char *e = getenv("RAFT_PART_SHIFT")) rshift = std::max(4, std::min(kFineMaxShift, atoi(e)));      // (tests, sweeps)
+    const long long n_coarse_ll = ((long long)n_reads + (1LL << rshift) - 1) >> rshift;
+    if (n_coarse_ll > kCoarseMax) return RAFT_HIP_OK;
+    const int n_coarse = (int)n_coarse_ll;
+    HIP_TRY(c, c->rs_k0.ensure((size_t)cap_iv * 4));
+    HIP_TRY(c, c->rs_v0.ensure((size_t)cap_iv * 8));
+    HIP_TRY(c, c->coarse.ensure((size_t)(3 * (kCoarseMax + 1)) * 8));
+    unsigned long long *cnt = c->coarse.as<unsigned long long>();
+    long long *base = reinterpret_cast<long long *>(cnt + (kCoarseMax + 1));
+    unsigned long long *cursor = cnt + 2 * (kCoarseMax + 1);
+    int32_t *t_rid = c->rs_k0.as<int32_t>(), *t_s = c->rs_v0.as<int32_t>(), *t_e = c->rs_v0.as<int32_t>() + cap_iv;
+    HIP_TRY(c, hipMemsetAsync(cnt, 0, (size_t)n_coarse * 8, st));
+    const unsigned g0 = (unsigned)std::max<long long>(1, std::min<long long>((n_rec + 255) / 256, 256 * 8));
+    hipLaunchKernelGGL(coarse_hist_kernel, dim3(g0), dim3(256), 0, st, n_rec, n_reads, symmetric, rshift, n_coarse, d_qid, d_tid, cnt, err_flags, err_index);
+    hipLaunchKernelGGL(coarse_scan_kernel, dim3(1), dim3(1024), 0, st, n_coarse, cnt, base, cursor);
+    const int step = kPartThreads * kPartUnroll;
+    const int tile = (int)std::min<long long>(kPartTile, std::max<long long>(2 * step, (n_rec / 512 + step - 1) / step * step));
+    const unsigned g1 = (unsigned)std::max<long long>(1, std::min<long long>((n_rec + tile - 1) / tile, 256 * 2));
+    hipLaunchKernelGGL(coarse_partition_kernel, dim3(g1), dim3(kPartThreads), 0, st, n_rec, tile, n_reads, symmetric, rshift, n_coarse, d_qid, d_qs, d_qe, d_tid, d_ts, d_te,
+                       cursor, t_rid, t_s, t_e);
+    hipLaunchKernelGGL(bucket_finish_kernel, dim3((unsigned)n_coarse), dim3(kPartThreads), 0, st, n_reads, rshift, n_coarse, base, t_rid, t_s, t_e, o_rid, o_s, o_e, off);
+    HIP_TRY(c, hipGetLastError());
+    *done = true;
+    return RAFT_HIP_OK;
+}
+
 static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool verify_in_kernels)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
@@ -1041,28 +1081,17 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         HIP_TRY(c, c->b_rid.ensure((size_t)cap_iv * 4));
         HIP_TRY(c, c->b_s.ensure((size_t)cap_iv * 4));
         HIP_TRY(c, c->b_e.ensure((size_t)cap_iv * 4));
-        // large inputs are sorted, not scattered (bucket.hpp): the counting sort's random 12-byte writes took 87 ms for 2.9e8
-        // shuffled records; it stays for small inputs, where its three launches cost less than the sort's
-        // (... and for a symmetric stream of a few sorted runs that is sent here all the same -- force_bucket, A/B: its scatter is local)
-        const bool radix = cap_iv >= (1LL << 20) && (!symmetric || n_desc + 1 > kMaxSeg) && getenv("RAFT_NO_RADIX_SORT") == nullptr;
-        if (radix) {
-            HIP_TRY(c, c->rs_k0.ensure((size_t)cap_iv * 4)); HIP_TRY(c, c->rs_k1.ensure((size_t)cap_iv * 4));
-            HIP_TRY(c, c->rs_v0.ensure((size_t)cap_iv * 8)); HIP_TRY(c, c->rs_v1.ensure((size_t)cap_iv * 8));
-            const unsigned g1 = (unsigned)std::min<long long>((n_rec + 255) / 256, 256 * 32);
-            hipLaunchKernelGGL(expand_sides_kernel, dim3(g1), dim3(256), 0, st, (long long)n_rec, n_reads, symmetric, d_qid, d_qs, d_qe, d_tid, d_ts, d_te,
-                               c->rs_k0.as<uint32_t>(), c->rs_v0.as<unsigned long long>(), &ctrl->err_flags, &ctrl->err_index);
-            int bits = 1;
-            while (bits < 32 && (1LL << bits) <= N) ++bits;               // keys 0 .. n_reads (the sides that do not exist)
-            size_t tmp = 0;
-            HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
-                                                 c->rs_v1.as<unsigned long long>(), (size_t)cap_iv, 0u, (unsigned)bits, st));
-            HIP_TRY(c, c->sort_tmp.ensure(tmp));
-            HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
-                                                 c->rs_v1.as<unsigned long long>(), (size_t)cap_iv, 0u, (unsigned)bits, st));
-            const unsigned g2 = (unsigned)std::min<long long>((cap_iv + 255) / 256, 256 * 32);
-            hipLaunchKernelGGL(unzip_sorted_kernel, dim3(g2), dim3(256), 0, st, cap_iv, n_reads, c->rs_k1.as<uint32_t>(), c->rs_v1.as<unsigned long long>(),
-                               c->b_rid.as<int32_t>(), c->b_s.as<int32_t>(), c->b_e.as<int32_t>(), c->b_off.as<long long>());
-        } else {
+        // large inputs in any order are partitioned in two steps (bucket.hpp, round 5); the counting sort stays for small inputs, where
+        // its three launches cost less, for a symmetric stream of a few sorted runs that is sent here all the same (force_bucket, A/B:
+        // its scatter is local), and for more reads than the partition's LDS counters take (3.3e7)
+        bool parted = false;
+        if (cap_iv >= (1LL << 20) && (!symmetric || n_desc + 1 > kMaxSeg) && getenv("RAFT_NO_PARTITION") == nullptr) {
+            const int prc = partition_sides(c, st, (long long)n_rec, n_reads, symmetric, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, cap_iv,
+                                            c->b_rid.as<int32_t>(), c->b_s.as<int32_t>(), c->b_e.as<int32_t>(), c->b_off.as<long long>(),
+                                            &ctrl->err_flags, &ctrl->err_index, &parted);
+            if (prc != RAFT_HIP_OK) return prc;
+        }
+        if (!parted) {
         HIP_TRY(c, hipMemsetAsync(c->b_cnt.p, 0, (size_t)std::max(N, 1LL) * 4, st));
         const unsigned grid = (unsigned)std::min<long long>((n_rec + 255) / 256, 8192);
         hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads, symmetric, d_qid,
@@ -1625,14 +1654,12 @@ static int sort_exceptions(raft_hip_ctx *c)
     HIP_TRY(c, c->exc_val2.ensure(std::max(n * 4, c->exc_val.cap)));
     int bits = 1;
     while (bits < 63 && (1LL << bits) <= std::max<long long>(c->sum.n_bins, 1)) ++bits;
-    size_t tmp = 0;
     using Key = unsigned long long;           // (window indices are non-negative)
-    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, c->exc_idx.as<Key>(), c->exc_idx2.as<Key>(), c->exc_val.as<int32_t>(), c->exc_val2.as<int32_t>(), n, 0,
-                                         (unsigned)bits, c->stream));
-    HIP_TRY(c, c->sort_tmp.ensure(tmp));
-    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, c->exc_idx.as<Key>(), c->exc_idx2.as<Key>(), c->exc_val.as<int32_t>(), c->exc_val2.as<int32_t>(), n, 0,
-                                         (unsigned)bits, c->stream));
-    std::swap(c->exc_idx, c->exc_idx2); std::swap(c->exc_val, c->exc_val2);
+    HIP_TRY(c, c->sort_tmp.ensure(sort_pairs_hist_bytes((long long)n)));
+    bool in_b = false;
+    HIP_TRY(c, sort_pairs(c->stream, c->exc_idx.as<Key>(), c->exc_val.as<int32_t>(), c->exc_idx2.as<Key>(), c->exc_val2.as<int32_t>(), (long long)n, bits,
+                          c->sort_tmp.as<int32_t>(), &in_b));
+    if (in_b) { std::swap(c->exc_idx, c->exc_idx2); std::swap(c->exc_val, c->exc_val2); }
     c->exc_sorted = true;
     return RAFT_HIP_OK;
 }
@@ -3025,28 +3052,33 @@ int raft_hip_group_sides(raft_hip_ctx *c, int32_t n_reads_total, int64_t n_rec, 
     c->gs_off_host.assign((size_t)N1, 0);
     long long n_valid = 0;
     if (n_ent > 0) {
-        HIP_TRY(c, c->rs_k0.ensure((size_t)n_ent * 4)); HIP_TRY(c, c->rs_k1.ensure((size_t)n_ent * 4));
-        HIP_TRY(c, c->rs_v0.ensure((size_t)n_ent * 8)); HIP_TRY(c, c->rs_v1.ensure((size_t)n_ent * 8));
+        HIP_TRY(c, c->gs_rid.ensure((size_t)n_ent * 4));
         HIP_TRY(c, c->gs_s.ensure((size_t)n_ent * 4)); HIP_TRY(c, c->gs_e.ensure((size_t)n_ent * 4));
         HIP_TRY(c, c->gs_off.ensure((size_t)N1 * 8));
         HIP_TRY(c, c->gs_err.ensure(16));
         HIP_TRY(c, hipMemsetAsync(c->gs_err.p, 0, 8, st));
         HIP_TRY(c, hipMemsetAsync(c->gs_err.as<char>() + 8, 0xff, 8, st));
-        const unsigned g1 = (unsigned)std::min<long long>((n_rec + 255) / 256, 256 * 32);
-        hipLaunchKernelGGL(expand_sides_kernel, dim3(g1), dim3(256), 0, st, (long long)n_rec, n_reads_total, symmetric ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te,
-                           c->rs_k0.as<uint32_t>(), c->rs_v0.as<unsigned long long>(), c->gs_err.as<int32_t>(), reinterpret_cast<long long *>(c->gs_err.as<char>() + 8));
-        int bits = 1;
-        while (bits < 32 && (1LL << bits) <= (long long)n_reads_total) ++bits;      // keys 0 .. n_reads_total (the sides that do not exist)
-        size_t tmp = 0;
-        HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
-                                             c->rs_v1.as<unsigned long long>(), (size_t)n_ent, 0u, (unsigned)bits, st));
-        HIP_TRY(c, c->sort_tmp.ensure(tmp));
-        HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
-                                             c->rs_v1.as<unsigned long long>(), (size_t)n_ent, 0u, (unsigned)bits, st));
-        const unsigned g2 = (unsigned)std::min<long long>((n_ent + 255) / 256, 256 * 32);
-        // (the unsorted keys are done with: their array takes the id column nobody asks for)
-        hipLaunchKernelGGL(unzip_sorted_kernel, dim3(g2), dim3(256), 0, st, n_ent, n_reads_total, c->rs_k1.as<uint32_t>(), c->rs_v1.as<unsigned long long>(),
-                           c->rs_k0.as<int32_t>(), c->gs_s.as<int32_t>(), c->gs_e.as<int32_t>(), c->gs_off.as<long long>());
+        int32_t *gerr = c->gs_err.as<int32_t>();
+        long long *gerr_index = reinterpret_cast<long long *>(c->gs_err.as<char>() + 8);
+        bool parted = false;
+        {
+            const int prc = partition_sides(c, st, (long long)n_rec, n_reads_total, symmetric ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, n_ent,
+                                            c->gs_rid.as<int32_t>(), c->gs_s.as<int32_t>(), c->gs_e.as<int32_t>(), c->gs_off.as<long long>(), gerr, gerr_index, &parted);
+            if (prc != RAFT_HIP_OK) return prc;
+        }
+        if (!parted) {                               // (more reads than the partition takes: the counting sort)
+            HIP_TRY(c, c->b_cnt.ensure((size_t)std::max<long long>(n_reads_total, 1) * 4));
+            HIP_TRY(c, c->scan_tmp.ensure(((size_t)std::max(scan_blocks(n_reads_total), 1) * 3 + 8) * sizeof(long long)));
+            HIP_TRY(c, hipMemsetAsync(c->b_cnt.p, 0, (size_t)std::max<long long>(n_reads_total, 1) * 4, st));
+            const unsigned grid = (unsigned)std::min<long long>((n_rec + 255) / 256, 8192);
+            hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads_total, symmetric ? 1 : 0, d_qid, d_tid, c->b_cnt.as<int32_t>(), gerr, gerr_index);
+            CountLoader<1> ld{{c->b_cnt.as<int32_t>()}};
+            ScanOut<1> so{{c->gs_off.as<long long>()}};
+            exclusive_scan<CountLoader<1>, 1>(st, ld, (long long)n_reads_total, c->scan_tmp.as<long long>(), so);
+            HIP_TRY(c, hipMemsetAsync(c->b_cnt.p, 0, (size_t)std::max<long long>(n_reads_total, 1) * 4, st));
+            hipLaunchKernelGGL(bucket_scatter_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads_total, symmetric ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te,
+                               c->gs_off.as<long long>(), c->b_cnt.as<int32_t>(), c->gs_rid.as<int32_t>(), c->gs_s.as<int32_t>(), c->gs_e.as<int32_t>());
+        }
         HIP_TRY(c, hipGetLastError());
         long long err[2] = {0, -1};
         HIP_TRY(c, hipMemcpyAsync(c->gs_off_host.data(), c->gs_off.p, (size_t)N1 * 8, hipMemcpyDeviceToHost, st));
@@ -3437,3 +3469,145 @@ int raft_hip_selftest(int device_id)
 }
 
 } // extern "C"
+
+// ---- the pre-split job of ONE process (BASELINE configs[3] behind the CLI: main.cpp:21-87 + chop.hpp:331-373 with the record stream
+// cut into `world` contiguous slices, one per rank; ranks are contexts of this process, on as many devices as the caller made them
+// on).  Every step is the native one: the slices go up as they are; raft_hip_presplit_symmetric_local finds the flag
+// (chop.hpp:171-184); raft_hip_group_sides expands the sides each slice piles up (chop.hpp:165-169) and groups them by read;
+// raft_hip_exchange_local routes every interval to the rank that owns its read (contiguous read ranges of equal window counts);
+// each rank runs the grouped pass on what arrived and its share of the outputs lands in the caller's arrays, in read order --
+// the fragment numbering (chop.hpp:195 read_num) and the stdout sums (repeat.hpp:93-97) are global because the CSR arrays are.
+int raft_hip_run_presplit_local(raft_hip_ctx *const *ctxs, int32_t world, int32_t n_reads, const int32_t *read_len, int64_t n_rec,
+                                const int32_t *qid, const int32_t *qs, const int32_t *qe, const int32_t *tid, const int32_t *ts, const int32_t *te,
+                                raft_hip_host_outputs *out, raft_hip_summary *summary)
+{
+    if (!ctxs || world < 1 || world > 64 || n_reads < 0 || n_rec < 0 || !out) return RAFT_HIP_ERR_PARAM;
+    for (int r = 0; r < world; ++r) if (!ctxs[r]) return RAFT_HIP_ERR_PARAM;
+    if (n_reads > 0 && !read_len) return RAFT_HIP_ERR_PARAM;
+    if (n_rec > 0 && (!qid || !qs || !qe || !tid || !ts || !te)) return RAFT_HIP_ERR_PARAM;
+    const int width = out->cov_width == 2 ? 2 : 1;
+    if (out->cov_width != 0 && out->cov_width != 1 && out->cov_width != 2) return RAFT_HIP_ERR_PARAM;   // (four-bit steps: chunks would have to begin on multiples of four windows)
+    if (!out->cov_offset || !out->cov8 || !out->rep_offset || !out->rep_s || !out->rep_e || !out->frag_offset || !out->frag_begin || !out->frag_end)
+        return RAFT_HIP_ERR_PARAM;
+    raft_hip_ctx *c0 = ctxs[0];
+    const int reso = c0->prm.reso;
+    // read ranges of (nearly) equal window counts: what every rank can compute from the read lengths alone
+    std::vector<int64_t> win_off((size_t)n_reads + 1, 0), bounds((size_t)world + 1, 0);
+    for (int32_t i = 0; i < n_reads; ++i) {
+        if (read_len[i] < 0) { if (summary) { memset(summary, 0, sizeof *summary); summary->error_index = i; } return RAFT_HIP_ERR_PARAM; }
+        win_off[(size_t)i + 1] = win_off[(size_t)i] + ((int64_t)read_len[i] + reso - 1) / reso;
+    }
+    const int64_t W = win_off[(size_t)n_reads];
+    if (W > out->cov8_cap) return RAFT_HIP_ERR_TOO_LARGE;
+    for (int g = 1; g < world; ++g)
+        bounds[(size_t)g] = std::lower_bound(win_off.begin(), win_off.end(), (int64_t)((__int128)W * g / world)) - win_off.begin();
+    bounds[(size_t)world] = n_reads;
+    for (int g = 1; g <= world; ++g) bounds[(size_t)g] = std::min<int64_t>(std::max(bounds[(size_t)g], bounds[(size_t)g - 1]), n_reads);
+
+    std::vector<int> rcs((size_t)world, RAFT_HIP_OK);
+    auto each_rank = [&](const std::function<int(int)> &f) -> int {
+        std::vector<std::thread> th;
+        for (int r = 1; r < world; ++r) th.emplace_back([&, r] { rcs[(size_t)r] = f(r); });
+        rcs[0] = f(0);
+        for (auto &t : th) t.join();
+        for (int r = 0; r < world; ++r) if (rcs[(size_t)r] != RAFT_HIP_OK) { if (r) c0->last_error = "rank " + std::to_string(r) + ": " + ctxs[r]->last_error; return rcs[(size_t)r]; }
+        return RAFT_HIP_OK;
+    };
+    // 1. every rank's slice of the six columns, on its device
+    std::vector<raft_hip_records> recs((size_t)world);
+    const int32_t *src[6] = {qid, qs, qe, tid, ts, te};
+    int rc = each_rank([&](int r) -> int {
+        raft_hip_ctx *c = ctxs[r];
+        const int64_t lo = n_rec * r / world, hi = n_rec * (r + 1) / world, n = hi - lo;
+        HIP_TRY(c, hipSetDevice(c->device));
+        for (int k = 0; k < 6; ++k) {
+            HIP_TRY(c, c->in_col[k].ensure((size_t)std::max<int64_t>(n, 1) * 4));
+            if (n) HIP_TRY(c, hipMemcpyAsync(c->in_col[k].p, src[k] + lo, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        recs[(size_t)r] = raft_hip_records{n, c->in_col[0].as<int32_t>(), c->in_col[1].as<int32_t>(), c->in_col[2].as<int32_t>(),
+                                           c->in_col[3].as<int32_t>(), c->in_col[4].as<int32_t>(), c->in_col[5].as<int32_t>()};
+        return RAFT_HIP_OK;
+    });
+    if (rc != RAFT_HIP_OK) return rc;
+    // 2. the symmetric flag of the whole stream
+    int32_t sym = 0;
+    rc = raft_hip_presplit_symmetric_local(ctxs, world, recs.data(), &sym);
+    if (rc != RAFT_HIP_OK) return rc;
+    // 3. every slice's sides, grouped by read
+    std::vector<raft_hip_slice> slices((size_t)world);
+    rc = each_rank([&](int r) -> int {
+        const raft_hip_records &q = recs[(size_t)r];
+        return raft_hip_group_sides(ctxs[r], n_reads, q.n_rec, q.d_qid, q.d_qs, q.d_qe, q.d_tid, q.d_ts, q.d_te, sym, &slices[(size_t)r]);
+    });
+    if (rc != RAFT_HIP_OK) {
+        if (summary) { memset(summary, 0, sizeof *summary); summary->error_index = -1; }
+        return rc;
+    }
+    // 4. ONE exchange step
+    std::vector<raft_hip_received> got((size_t)world);
+    rc = raft_hip_exchange_local(ctxs, world, n_reads, bounds.data(), slices.data(), got.data());
+    if (rc != RAFT_HIP_OK) return rc;
+    // 5. every rank's pass over what arrived for its reads
+    std::vector<raft_hip_summary> sums((size_t)world);
+    rc = each_rank([&](int r) -> int {
+        raft_hip_ctx *c = ctxs[r];
+        const int64_t b0 = bounds[(size_t)r], b1 = bounds[(size_t)r + 1];
+        const int32_t nr = (int32_t)(b1 - b0);
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, c->in_len.ensure((size_t)std::max<int32_t>(nr, 1) * 4));
+        if (nr) HIP_TRY(c, hipMemcpyAsync(c->in_len.p, read_len + b0, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+        const int keep_mode = c->prm.symmetric_mode, keep_width = c->out_width;
+        c->prm.symmetric_mode = 1;                         // (the sides are expanded: a grouped pass piles up what it is given)
+        c->out_width = width;
+        int prc = raft_hip_run_device_grouped(c, nr, c->in_len.as<int32_t>(), got[(size_t)r].n_rec, got[(size_t)r].n_runs, got[(size_t)r].d_rec_offset, nullptr,
+                                              got[(size_t)r].d_qs, got[(size_t)r].d_qe, win_off[(size_t)b1] - win_off[(size_t)b0]);
+        if (prc == RAFT_HIP_OK) prc = raft_hip_finish(c, &sums[(size_t)r]);
+        c->prm.symmetric_mode = keep_mode; c->out_width = keep_width;
+        return prc;
+    });
+    if (rc != RAFT_HIP_OK) {
+        if (summary) {
+            memset(summary, 0, sizeof *summary); summary->error_index = -1;
+            for (int r = 0; r < world; ++r) if (rcs[(size_t)r] != RAFT_HIP_OK) { *summary = sums[(size_t)r]; break; }
+        }
+        return rc;
+    }
+    // 6. the ranks' shares, in read order
+    int64_t n_exc = 0, rep_at = 0, frag_at = 0;
+    bool overflow = false;
+    for (int r = 0; r < world && rc == RAFT_HIP_OK; ++r) {
+        raft_hip_ctx *c = ctxs[r];
+        const int64_t b0 = bounds[(size_t)r], b1 = bounds[(size_t)r + 1], w0 = win_off[(size_t)b0];
+        const raft_hip_summary &sr = sums[(size_t)r];
+        if (rep_at + sr.n_repeats > out->rep_cap || frag_at + sr.n_fragments > out->frag_cap) { rc = RAFT_HIP_ERR_TOO_LARGE; break; }
+        int64_t ne = 0;
+        const int64_t room = std::max<int64_t>(out->exc_cap - n_exc, 0);
+        int frc = overflow ? raft_hip_fetch_packed_w(c, width, nullptr, nullptr, 0, nullptr, nullptr, &ne, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)
+                           : raft_hip_fetch_packed_w(c, width, out->cov_offset + b0, out->cov8 + (size_t)w0 * (size_t)width, room, out->exc_index ? out->exc_index + n_exc : nullptr,
+                                                     out->exc_value ? out->exc_value + n_exc : nullptr, &ne, out->rep_offset + b0, out->rep_s + rep_at, out->rep_e + rep_at,
+                                                     out->frag_offset + b0, nullptr, out->frag_begin + frag_at, out->frag_end + frag_at);
+        if (frc == RAFT_HIP_ERR_TOO_LARGE && !overflow) { overflow = true; frc = RAFT_HIP_OK; }   // (the later ranks only say how many they have)
+        if (frc != RAFT_HIP_OK) { rc = frc; break; }
+        if (!overflow) {
+            for (int64_t i = b0; i <= b1; ++i) { out->cov_offset[i] += w0; out->rep_offset[i] += rep_at; out->frag_offset[i] += frag_at; }
+            if (out->exc_index) for (int64_t i = 0; i < ne; ++i) out->exc_index[n_exc + i] += w0;
+        }
+        n_exc += ne; rep_at += sr.n_repeats; frag_at += sr.n_fragments;
+    }
+    out->n_exc = n_exc;
+    if (rc == RAFT_HIP_OK && overflow) rc = RAFT_HIP_ERR_TOO_LARGE;
+    if (summary) {
+        raft_hip_summary t{};
+        t.n_reads = n_reads; t.symmetric = sym; t.high_cov = c0->high_cov; t.interval_path = 1; t.n_segments = world; t.n_records = n_rec;
+        t.error_index = -1; t.n_devices_used = world;
+        for (int r = 0; r < world; ++r) {
+            const raft_hip_summary &sr = sums[(size_t)r];
+            t.n_intervals += sr.n_intervals; t.n_bins += sr.n_bins; t.n_repeats += sr.n_repeats; t.n_cuts += sr.n_cuts; t.n_fragments += sr.n_fragments;
+            t.total_coverage += sr.total_coverage; t.total_windows += sr.total_windows; t.total_repeat_length += sr.total_repeat_length;
+            t.total_read_length += sr.total_read_length;
+        }
+        *summary = t;
+    }
+    return rc;
+}

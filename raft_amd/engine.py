@@ -29,7 +29,7 @@ EXPORTS = (
     "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local", "raft_hip_warm_up", "raft_hip_reserve",
     "raft_hip_run_device_windows", "raft_hip_run_host_windows", "raft_hip_run_multi_windows",
     "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device", "raft_hip_set_emit_cuts", "raft_hip_device_alloc", "raft_hip_device_free", "raft_hip_group_sides", "raft_hip_presplit_symmetric", "raft_hip_presplit_symmetric_local",
-    "raft_hip_trim", "raft_hip_pool_bytes",
+    "raft_hip_trim", "raft_hip_pool_bytes", "raft_hip_run_presplit_local",
 )
 
 
@@ -147,6 +147,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_run_pipelined.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_run_multi.argtypes = [C.POINTER(vp), i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_run_device_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, vp, i64]
+    lib.raft_hip_run_presplit_local.argtypes = [C.POINTER(vp), i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_run_host_grouped.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, i64]
     lib.raft_hip_run_multi_grouped.argtypes = [C.POINTER(vp), i32, i32, vp, i64, i32, vp, vp, vp, i32, C.POINTER(_HostOutputs), C.POINTER(_Summary)]
     lib.raft_hip_fetch_delta4.argtypes = [vp, vp, vp, vp, i64, vp, vp, C.POINTER(i64)] + [vp] * 7
@@ -553,6 +554,20 @@ class Engine:
                                               C.byref(ho), C.byref(s))
         else:
             rc = self._lib.raft_hip_run_pipelined(self._ctx, cols[0].size, ptr[0], n_rec, *ptr[1:], int(n_chunks), C.byref(ho), C.byref(s))
+        return self._pipelined_result(rc, s, ho, out)
+
+    def run_presplit(self, read_len, qid, qs, qe, tid, ts, te, others: list, out: dict | None = None):
+        """raft_hip_run_presplit_local: this Engine is rank 0, ``others`` ranks 1 .. -- the record stream is cut into as many
+        contiguous slices, every slice's sides are grouped on its rank's device, ONE exchange routes them to the owners of their
+        reads, every rank runs its grouped pass.  Same return as ``run_pipelined``."""
+        cols = [np.ascontiguousarray(np.asarray(a), dtype=np.int32) for a in (read_len, qid, qs, qe, tid, ts, te)]
+        if out is None:
+            out = self.host_output_buffers(cols[0], pinned=False)
+        ho = self._host_outputs(out)
+        ptr = [C.c_void_p(a.ctypes.data if a.size else 0) for a in cols]
+        s = _Summary()
+        ctxs = (C.c_void_p * (1 + len(others)))(self._ctx, *[e._ctx for e in others])
+        rc = self._lib.raft_hip_run_presplit_local(ctxs, 1 + len(others), cols[0].size, ptr[0], cols[1].size, *ptr[1:], C.byref(ho), C.byref(s))
         return self._pipelined_result(rc, s, ho, out)
 
     def fetch_packed(self, pinned: bool = False, out: dict | None = None, width: int = 1) -> dict:

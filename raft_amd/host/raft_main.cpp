@@ -138,6 +138,15 @@ int main(int argc, char *argv[])
         }
     }
     if (devices.empty()) { const char *e = getenv("RAFT_DEVICE"); devices.push_back(e ? atoi(e) : 0); }
+    // RAFT_RANKS=N: the PRE-SPLIT job (BASELINE configs[3]): the record stream is cut into N contiguous slices, rank r
+    // -- a context on device r modulo the devices named -- holds slice r, and ONE exchange step routes every interval to the rank
+    // that owns its read (raft_hip_run_presplit_local).  Outputs are the single-rank run's, byte for byte.
+    const int ranks = getenv("RAFT_RANKS") ? std::max(1, std::min(64, atoi(getenv("RAFT_RANKS")))) : 0;
+    if (ranks > 0) {
+        const std::vector<int> named = devices;
+        devices.clear();
+        for (int r = 0; r < ranks; ++r) devices.push_back(named[(size_t)r % named.size()]);
+    }
     std::vector<raft_hip_ctx *> ctxs(devices.size(), nullptr);
     std::vector<int> create_rc(devices.size(), RAFT_HIP_OK);
     std::promise<void> devices_up_p;
@@ -249,11 +258,11 @@ int main(int argc, char *argv[])
     // The tokeniser already knows whether the PAF is symmetric (chop.hpp:171-184, found while the lines were in
     // registers): the engine is told, so it neither scans for the mirror of record 0 nor -- for a symmetric PAF -- is
     // handed the target columns at all (half of the upload).
-    hp.symmetric_mode = raft_host_paf_symmetric(paf) ? 1 : 0;
+    hp.symmetric_mode = ranks > 0 ? -1 : (raft_host_paf_symmetric(paf) ? 1 : 0);   // (a pre-split job finds the flag across its ranks)
     out_prep.join();                                  // (its raft_hip_reserve reads the contexts' parameters: done before they change)
     rc = raft_hip_set_params(ctx, &hp);
     if (rc != RAFT_HIP_OK) die(std::string("ERROR, raft_hip_set_params(), ") + raft_hip_strerror(rc));
-    const bool sym = hp.symmetric_mode == 1;
+    const bool sym = hp.symmetric_mode == 1 || (ranks > 0 && raft_host_paf_symmetric(paf));
 
     // hifiasm writes its PAF grouped by query (reference README.md:36-38): a symmetric stream of at most four runs sorted by
     // read id is handed over in its grouped form -- per run, where every read's records begin -- and the query column stays
@@ -264,7 +273,7 @@ int main(int argc, char *argv[])
     // RAFT_CLI_PREPARE=1 keeps them (A/B, and the grouped / window-record entry points through the CLI).
     std::unique_ptr<int64_t[]> rec_off;
     int32_t n_runs = 0;
-    const bool prepare = getenv("RAFT_CLI_PREPARE") != nullptr;
+    const bool prepare = getenv("RAFT_CLI_PREPARE") != nullptr && ranks == 0;
     if (prepare && sym && n_rec > 0 && !getenv("RAFT_NO_GROUPED")) {
         rec_off.reset(new int64_t[(size_t)4 * ((size_t)n_reads + 1)]);
         if (raft_host_group_offsets(n_reads, n_rec, raft_host_paf_column(paf, 0), 4, &n_runs, rec_off.get()) != RAFT_HOST_OK) n_runs = 0;
@@ -312,7 +321,7 @@ int main(int argc, char *argv[])
         }
         few_runs = descents < 4;
     }
-    int cov_width = ((n_runs > 0 || few_runs) && !getenv("RAFT_NO_DELTA4")) ? RAFT_HIP_COV_DELTA4 : (p.est_cov >= 40 ? 2 : 1);
+    int cov_width = ((n_runs > 0 || few_runs) && !getenv("RAFT_NO_DELTA4") && ranks == 0) ? RAFT_HIP_COV_DELTA4 : (p.est_cov >= 40 ? 2 : 1);
     raft_hip_summary s{};
     int64_t n_exc = 0;
     const char *chunks_env = getenv("RAFT_CHUNKS");   // 0 / unset: the engine decides (one piece for small inputs)
@@ -329,7 +338,10 @@ int main(int argc, char *argv[])
         ho.rep_offset = rep_off.data(); ho.rep_s = rep_s.get(); ho.rep_e = rep_e.get(); ho.rep_cap = rep_cap;
         ho.frag_offset = frag_off.data(); ho.frag_begin = fb.get(); ho.frag_end = fe.get(); ho.frag_cap = frag_cap;
         // upload, pass and download of consecutive read ranges overlap, on every device named (one piece for small inputs)
-        if (win)
+        if (ranks > 0)
+            rc = raft_hip_run_presplit_local(ctxs.data(), (int32_t)ctxs.size(), n_reads, rl, n_rec, raft_host_paf_column(paf, 0), raft_host_paf_column(paf, 1),
+                                             raft_host_paf_column(paf, 2), raft_host_paf_column(paf, 3), raft_host_paf_column(paf, 4), raft_host_paf_column(paf, 5), &ho, &s);
+        else if (win)
             rc = raft_hip_run_multi_windows(ctxs.data(), (int32_t)ctxs.size(), n_reads, rl, n_rec, n_runs, rec_off.get(), win,
                                             chunks_env ? atoi(chunks_env) : 0, &ho, &s);
         else if (n_runs > 0)
@@ -356,7 +368,7 @@ int main(int argc, char *argv[])
         die(m);
     }
     stage("engine+fetch");
-    if (timing) fprintf(stderr, "TIMING devices_used %d input %s\n", s.n_devices_used, win ? "windows" : (n_runs > 0 ? "grouped" : (sym ? "columns (offsets and window records derived by the engine)" : "columns")));
+    if (timing) fprintf(stderr, "TIMING devices_used %d input %s\n", s.n_devices_used, ranks > 0 ? "pre-split slices (one exchange step)" : win ? "windows" : (n_runs > 0 ? "grouped" : (sym ? "columns (offsets and window records derived by the engine)" : "columns")));
     if (timing) fprintf(stderr, "TIMING coverage_encoding %s\n", cov_width == RAFT_HIP_COV_DELTA4 ? "delta4" : (cov_width == 2 ? "uint16" : "uint8"));
     fprintf(stdout, "INFO, Symmetric overlaps %d \n", s.symmetric);            // chop.hpp:189-190
     fprintf(stdout, "INFO, length of alignments  %d()\n", (int)s.n_records);

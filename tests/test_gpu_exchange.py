@@ -287,3 +287,39 @@ def test_non_symmetric_presplit_at_scale_eight_ranks_equal_the_single_pass():
     assert tot == [s.n_fragments, s.n_repeats, s.total_coverage, s.total_repeat_length]
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("shape", ["symmetric", "nonsym_shuffled"])
+def test_presplit_job_of_one_process_equals_the_oracle(world, shape):
+    """raft_hip_run_presplit_local (what `raft` runs with RAFT_RANKS=N): the stream cut into `world` slices, flag, sides, ONE
+    exchange, every rank's grouped pass, outputs in read order -- all of it equal to the oracle's outputs for the whole set,
+    in both widths of the coverage encoding."""
+    from raft_amd import engine
+    from raft_amd.synth import make_overlaps
+    o = make_overlaps(3000, seed=31 + world)
+    cols = [c.numpy().copy() for c in (o.read_len,) + o.columns()]
+    if shape == "nonsym_shuffled":           # one record per pair, in random order: target sides are piled up too (chop.hpp:165-169)
+        rng = np.random.default_rng(5)
+        keep = np.flatnonzero(cols[1] < cols[4])
+        keep = keep[rng.permutation(keep.size)]
+        cols = [cols[0]] + [c[keep] for c in cols[1:]]
+    p = RaftParams(est_cov=30)
+    want = oracle_run(p, *cols)
+    assert want["symmetric"] == (1 if shape == "symmetric" else 0)
+    for width in (1, 2):
+        engs = [engine.Engine(p, device=0) for _ in range(world)]
+        out = engs[0].host_output_buffers(cols[0], pinned=False, width=width)
+        res, s = engs[0].run_presplit(*cols, others=engs[1:], out=out)
+        cov = res["cov8"].astype(np.int32)
+        cov[res["exc_index"]] = res["exc_value"]
+        assert np.all(np.diff(res["exc_index"]) > 0)
+        assert np.array_equal(cov, want["cov"]), (world, shape, width)
+        for k in ("cov_offset", "rep_offset", "rep_s", "rep_e", "frag_offset", "frag_begin", "frag_end"):
+            assert np.array_equal(res[k], want[k]), (world, shape, width, k)
+        assert s.symmetric == want["symmetric"] and s.high_cov == want["high_cov"] and s.n_records == cols[1].size
+        for k in ("total_coverage", "total_windows", "total_repeat_length", "total_read_length"):
+            assert getattr(s, k) == want[k], k
+        assert s.n_fragments == want["frag_begin"].size and s.n_devices_used == world
+        for e in engs:
+            e.close()
