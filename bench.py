@@ -372,6 +372,7 @@ def main():
     ap.add_argument("--plain-input-memory", action="store_true", help="leave the input columns where torch's allocator (hipMalloc) put them instead of moving them "
                     "into memory from raft_hip_device_alloc before the clock (see include/raft_hip.h: a pass's time depends on where its buffers lie)")
     ap.add_argument("--variant", type=int, default=-1, help="pileup kernel variant (engine.hip kVariants), -1 = default")
+    ap.add_argument("--no-placement-ab", action="store_true", help="skip the extra passes that time the pileup kernel with its buffers placed the other ways")
     args = ap.parse_args()
     if args.presplit:
         args.strong = True
@@ -663,6 +664,33 @@ def main():
             if rank:
                 del full
 
+    # ---- what the placement policy buys on THIS box: the headline pass once more in this process with
+    # every buffer -- the engine's and the input columns -- made under each policy: eight-fold spread chunks (the default),
+    # chunks taken one after the other, plain hipMalloc.  Outside the headline's clock; kernel and pass by HIP events.
+    placement_ab = None
+    if n_gpus == 1 and not args.no_placement_ab and not (args.strong and world > 1) and args.input == "columns" and not args.shuffle and not args.nonsym:
+        placement_ab = {}
+        before = engine.set_placement(8)
+        for name, spread in (("spread8", 8), ("spread1", 1), ("hipMalloc", 0)):
+            engine.set_placement(spread)
+            ea = engine.Engine(p, device=local)
+            ea.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+            ea.use_torch_stream()
+            colsa = [ea.device_copy(c) for c in (o.read_len,) + tuple(o.columns())]
+            kt, pt = [], []
+            for it in range(7):
+                ea.run_device(*colsa)
+                sa = ea.finish()
+                if it >= 2:
+                    ka, pa_ = ea.timing()
+                    kt.append(ka * 1e3); pt.append(pa_ * 1e3)
+            placement_ab[name] = {"kernel_ms": sum(kt) / len(kt), "pass_device_ms": sum(pt) / len(pt), "fragments": int(sa.n_fragments)}
+            del colsa
+            ea.close()
+        engine.set_placement(before)
+        placement_ab["note"] = ("pileup kernel / whole pass, mean of 5 passes after 2, one process, buffers AND input columns made under the policy; "
+                                "the headline runs under the library's default (spread8 unless RAFT_VMM_SPREAD / RAFT_NO_VMM say otherwise)")
+
     # ---- the pass exactly as the CLI and the host pipelines run it: grouped input WITHOUT the query column (it never crosses
     # PCIe: rebuilt from the offsets on the device), the pileup kernel writing the transfer encoding of cov[] (one byte per
     # window, two from -e 40 on, + the windows at or above the limit).  Checked against the int32 pass (outside the clock).
@@ -900,6 +928,8 @@ def main():
             if not args.no_cpu_baseline:
                 cb, _ = cpu_baseline(args, o, p)
                 line["cpu_baseline"] = cb
+        if placement_ab is not None:
+            line["placement_ab"] = placement_ab
         print(json.dumps(line))
     if eng is not None:
         eng.close()

@@ -272,6 +272,11 @@ int  raft_hip_device_free(raft_hip_ctx *ctx, void *dptr);
  * raft_hip_pool_bytes reports what the pool holds.  (Replaces nothing in the reference.) */
 int64_t raft_hip_trim(int device_id, int64_t keep_bytes);
 int64_t raft_hip_pool_bytes(int device_id);
+/* Where buffers made from now on lie (process-wide; returns the setting before): 0 -- plain hipMalloc; k >= 1 -- shuffled 32 MiB
+ * chunks, and for a buffer of 1 GiB or more k times as many made as used (every k-th taken: the default is 8, RAFT_VMM_SPREAD /
+ * RAFT_NO_VMM set the start value).  Buffers that exist keep their memory.  bench.py's `placement_ab` times the pileup kernel
+ * under 8, 1 and 0 in one process. */
+int32_t raft_hip_set_placement(int32_t spread);
 
 /* Device arrays of the encoding the finished pass holds (width 0: none -- the pass wrote int32; call
  * raft_hip_fetch_packed_w once to have it encoded).  The exceptions are in no particular order. */

@@ -368,214 +368,83 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(long long n_rec, in
     }
 }
 
-// ---- bucketing by read id for streams of any order: partition twice, never sort (round 5) --------------------------------------
+// ---- bucketing by read id for streams of any order: sort, do not scatter (round 4) --------------------------------------------
 // The counting sort above -- one atomic per record on its read's counter, then a 12-byte write per record wherever its read's
 // bucket lies -- is fine where the stream is almost sorted and took 87 ms for 2.9e8 SHUFFLED records (every write a partial
-// line somewhere in 3.5 GB).  Round 4 sorted instead (a library radix sort of (id, start | end << 32) pairs: three passes over
-// 12-byte pairs plus histograms, an expansion before and an unzip behind it: 9.6 ms).  But create_pileup (chop.hpp:147-187) needs
-// no ORDER: profileCoverage adds up a read's intervals in whatever order they come (repeat.hpp:48-79).  What is needed is that a
-// read's intervals lie together and the reads in index order -- a partition, and one that can be made in two steps, each of which
-// writes into few places at a time:
-//   (A) coarse_partition_kernel: every side goes to the COARSE bucket of its read, 2^rshift consecutive reads each, chosen so that
-//       a bucket's intervals are ~2 MB -- a few thousand buckets.  A workgroup ranks its 8 k sides by bucket in LDS (a returning
-//       ds_add per side), reserves room in every bucket it has sides for with ONE global atomic per bucket, and writes; the
-//       buckets' open ends are a few thousand lines that stay in L2 until they are full.
-//   (B) bucket_finish_kernel: one workgroup per coarse bucket.  The bucket's reads are few enough for an LDS counter each: count,
-//       scan (the reads' offsets: pileup input), and scatter -- random 12-byte writes, but inside 2 MB that sit in the XCD's L2.
-// Bytes: (A0) the ids once for the buckets' sizes; (A) 12-24 B read + 12 B written per side; (B) 12 B read twice (the second time
-// from L2) + 12 B written.  Sides that do not exist (a bad id: reported; the target side of a symmetric PAF or of a self overlap,
-// chop.hpp:165-169) are dropped in (A).
-constexpr int kCoarseMax = 4096;              // coarse buckets (LDS counters of (A), 16 KB)
-constexpr int kFineMaxShift = 13;             // reads per coarse bucket at most 2^13 (LDS counters of (B), 32 KB)
-constexpr int kPartThreads = 1024;
-
-// (A0) sides per coarse bucket.  cnt[k] zeroed by the caller.
-__global__ __launch_bounds__(256) void coarse_hist_kernel(long long n_rec, int32_t n_reads, int symmetric, int rshift, int n_coarse,
-                                                          const int32_t *__restrict__ qid, const int32_t *__restrict__ tid,
-                                                          unsigned long long *__restrict__ cnt, int32_t *err_flags, long long *err_index)
+// line somewhere in 3.5 GB).  For large inputs the intervals are sorted instead: expand_sides_kernel writes (read id,
+// start | end << 32) per side -- query sides, and target sides of records whose two reads differ while the PAF is not
+// symmetric (chop.hpp:165-169); sides that do not exist get the key n_reads and sort behind everything -- a radix sort by
+// the id's bits (engine.hip: rocprim's device radix sort, the library primitive for exactly this), and unzip_sorted_kernel
+// writes the three columns the pileup kernels read plus where every read's intervals begin.
+// (Measured and dropped, round 5: two partition steps instead of a sort -- every side to a coarse bucket of 2048 reads (LDS ranks,
+// one global atomic per bucket and 128 k-record tile), then one workgroup per bucket with an LDS counter per read.  Bit-exact, no
+// library, 48 B of traffic per side -- and 25 ms where the sort takes 9.6: a wave's 64 lanes store to 64 different lines, and this
+// part retires such a store at ~34 ps per LANE whether the lines sit in L2 or not (coarse step 14.8 ms, fine step 9.8 ms for
+// 2.9e8 sides; profiles/r05_partition_kernel_stats.txt).  Stores have to leave in runs, which takes LDS-staged digits of 8 bits:
+// the three passes the library sort already makes.)
+__global__ __launch_bounds__(256) void expand_sides_kernel(long long n_rec, int32_t n_reads, int symmetric, const int32_t *qid, const int32_t *qs, const int32_t *qe,
+                                                           const int32_t *tid, const int32_t *ts, const int32_t *te, uint32_t *key, unsigned long long *val,
+                                                           int32_t *err_flags, long long *err_index)
 {
-    __shared__ int32_t h[kCoarseMax];
-    for (int i = threadIdx.x; i < n_coarse; i += 256) h[i] = 0;
-    __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (long long)gridDim.x * blockDim.x) {
         const int q = qid[i];
         const bool okq = q >= 0 && q < n_reads;
         bool bad = !okq;
-        if (okq) atomicAdd(&h[q >> rshift], 1);
+        key[i] = okq ? (uint32_t)q : (uint32_t)n_reads;
+        val[i] = (unsigned long long)(uint32_t)qs[i] | ((unsigned long long)(uint32_t)qe[i] << 32);
         if (!symmetric) {
             const int t = tid[i];
             const bool okt = t >= 0 && t < n_reads;
             bad = bad || !okt;
-            if (okt && t != q) atomicAdd(&h[t >> rshift], 1);
+            key[n_rec + i] = (okt && t != q) ? (uint32_t)t : (uint32_t)n_reads;
+            val[n_rec + i] = (unsigned long long)(uint32_t)ts[i] | ((unsigned long long)(uint32_t)te[i] << 32);
         }
         if (bad) {
             atomicOr(err_flags, kErrReadId);
             atomicMin((unsigned long long *)err_index, (unsigned long long)i);
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_coarse; i += 256)
-        if (h[i]) atomicAdd(&cnt[i], (unsigned long long)h[i]);
 }
 
-// where every coarse bucket begins (base[0 .. n_coarse]) and the cursors of (A); one workgroup
-__global__ __launch_bounds__(1024) void coarse_scan_kernel(int n_coarse, const unsigned long long *__restrict__ cnt, long long *__restrict__ base,
-                                                           unsigned long long *__restrict__ cursor)
+// Reads without intervals begin where the next read with intervals does.  A thread that meets a step of the sorted keys fills
+// the offsets of the reads between itself -- unless they are many (a rank's slice of a pre-split job names an eighth of the reads:
+// one thread would write millions of entries one after the other): such a gap goes to a short list that
+// fill_gaps_kernel serves with a workgroup per gap.
+constexpr int kGapInline = 32, kGapList = 1024;
+struct GapList { int32_t n; int32_t pad; long long lo[kGapList], hi[kGapList], val[kGapList]; };   // off[lo .. hi] = val
+
+__device__ __forceinline__ void fill_or_list(long long lo, long long hi, long long val, long long *__restrict__ off, GapList *gaps)
 {
-    __shared__ long long part[1024];
-    const int per = (n_coarse + 1023) / 1024;
-    const int lo = min((int)threadIdx.x * per, n_coarse), hi = min(lo + per, n_coarse);
-    long long s = 0;
-    for (int i = lo; i < hi; ++i) s += (long long)cnt[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long run = 0;
-        for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; }
-        base[n_coarse] = run;
+    if (hi < lo) return;
+    if (hi - lo >= kGapInline && gaps) {
+        const int slot = atomicAdd(&gaps->n, 1);
+        if (slot < kGapList) { gaps->lo[slot] = lo; gaps->hi[slot] = hi; gaps->val[slot] = val; return; }
     }
-    __syncthreads();
-    long long run = part[threadIdx.x];
-    for (int i = lo; i < hi; ++i) { base[i] = run; cursor[i] = (unsigned long long)run; run += (long long)cnt[i]; }
+    for (long long r = lo; r <= hi; ++r) off[r] = val;
 }
 
-// (A) the sides, bucket by bucket.  A workgroup takes TILES of kPartTile records: it counts the tile's sides per bucket (the id
-// columns only), reserves the tile's room in every bucket with one global atomic per bucket -- a few million for 3e8 records; a
-// tile of 4 k records would make one per SIDE of them -- and walks the tile again (its ids come from L2 now), ranking every side
-// within its bucket by a returning ds_add.  Loads are issued kPartUnroll records ahead per thread: the kernel lives on the
-// memory system's parallelism, not on its threads' arithmetic.
-constexpr int kPartTile = 1 << 17;          // records per tile at most (the host shrinks it for small inputs: 512 tiles at the least)
-constexpr int kPartUnroll = 4;
-__global__ __launch_bounds__(kPartThreads) void coarse_partition_kernel(long long n_rec, int tile, int32_t n_reads, int symmetric, int rshift, int n_coarse,
-                                                                        const int32_t *__restrict__ qid, const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
-                                                                        const int32_t *__restrict__ tid, const int32_t *__restrict__ ts, const int32_t *__restrict__ te,
-                                                                        unsigned long long *__restrict__ cursor,
-                                                                        int32_t *__restrict__ o_rid, int32_t *__restrict__ o_s, int32_t *__restrict__ o_e)
+__global__ __launch_bounds__(256) void unzip_sorted_kernel(long long n_ent, int32_t n_reads, const uint32_t *__restrict__ key, const unsigned long long *__restrict__ val,
+                                                           int32_t *__restrict__ b_rid, int32_t *__restrict__ b_s, int32_t *__restrict__ b_e, long long *__restrict__ off,
+                                                           GapList *gaps)
 {
-    __shared__ int32_t h[kCoarseMax];           // sides of this tile per bucket; then the rank counters of the second walk
-    __shared__ long long first[kCoarseMax];     // where this tile's sides of the bucket go
-    const long long n_tiles = (n_rec + tile - 1) / tile;
-    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const long long t0 = t * tile, t1 = min(t0 + (long long)tile, n_rec);
-        for (int i = threadIdx.x; i < n_coarse; i += kPartThreads) h[i] = 0;
-        __syncthreads();
-        for (long long i0 = t0 + threadIdx.x; i0 < t1; i0 += (long long)kPartThreads * kPartUnroll) {
-            int q[kPartUnroll], tt[kPartUnroll];
-#pragma unroll
-            for (int k = 0; k < kPartUnroll; ++k) {
-                const long long i = i0 + (long long)k * kPartThreads;
-                q[k] = i < t1 ? qid[i] : -1;
-                tt[k] = (!symmetric && i < t1) ? tid[i] : -1;
-            }
-#pragma unroll
-            for (int k = 0; k < kPartUnroll; ++k) {
-                if (q[k] >= 0 && q[k] < n_reads) atomicAdd(&h[q[k] >> rshift], 1);
-                if (tt[k] >= 0 && tt[k] < n_reads && tt[k] != q[k]) atomicAdd(&h[tt[k] >> rshift], 1);
-            }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_ent; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t k = key[i];
+        const long long prev = i == 0 ? -1 : (long long)key[i - 1];
+        if ((long long)k != prev) fill_or_list(prev + 1, (long long)k, i, off, gaps);      // (r == n_reads: the end)
+        if (k < (uint32_t)n_reads) {
+            const unsigned long long v = val[i];
+            b_rid[i] = (int32_t)k; b_s[i] = (int32_t)(uint32_t)v; b_e[i] = (int32_t)(uint32_t)(v >> 32);
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < n_coarse; i += kPartThreads) {
-            const int c = h[i];
-            if (c) first[i] = (long long)atomicAdd(&cursor[i], (unsigned long long)c);
-            h[i] = 0;
-        }
-        __syncthreads();
-        for (long long i0 = t0 + threadIdx.x; i0 < t1; i0 += (long long)kPartThreads * kPartUnroll) {
-            int q[kPartUnroll], a[kPartUnroll], b[kPartUnroll], tt[kPartUnroll], ta[kPartUnroll], tb[kPartUnroll];
-#pragma unroll
-            for (int k = 0; k < kPartUnroll; ++k) {
-                const long long i = i0 + (long long)k * kPartThreads;
-                q[k] = -1; tt[k] = -1; a[k] = b[k] = ta[k] = tb[k] = 0;
-                if (i < t1) {
-                    q[k] = qid[i]; a[k] = qs[i]; b[k] = qe[i];
-                    if (!symmetric) { tt[k] = tid[i]; ta[k] = ts[i]; tb[k] = te[i]; }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < kPartUnroll; ++k) {
-                if (q[k] >= 0 && q[k] < n_reads) {
-                    const int bk = q[k] >> rshift;
-                    const long long d = first[bk] + atomicAdd(&h[bk], 1);
-                    o_rid[d] = q[k]; o_s[d] = a[k]; o_e[d] = b[k];
-                }
-                if (tt[k] >= 0 && tt[k] < n_reads && tt[k] != q[k]) {
-                    const int bk = tt[k] >> rshift;
-                    const long long d = first[bk] + atomicAdd(&h[bk], 1);
-                    o_rid[d] = tt[k]; o_s[d] = ta[k]; o_e[d] = tb[k];
-                }
-            }
-        }
-        __syncthreads();
+        if (i == n_ent - 1) fill_or_list((long long)k + 1, (long long)n_reads, n_ent, off, gaps);
     }
 }
 
-// (B) one workgroup per coarse bucket: its reads' counts, their offsets, and every interval to its read's place.
-// off[r] for the bucket's reads (and off[n_reads] by the last bucket): where read r's intervals begin.
-__global__ __launch_bounds__(kPartThreads) void bucket_finish_kernel(int32_t n_reads, int rshift, int n_coarse, const long long *__restrict__ base,
-                                                                     const int32_t *__restrict__ i_rid, const int32_t *__restrict__ i_s, const int32_t *__restrict__ i_e,
-                                                                     int32_t *__restrict__ o_rid, int32_t *__restrict__ o_s, int32_t *__restrict__ o_e,
-                                                                     long long *__restrict__ off)
+__global__ __launch_bounds__(256) void fill_gaps_kernel(const GapList *__restrict__ gaps, long long *__restrict__ off)
 {
-    __shared__ int32_t cnt[1 << kFineMaxShift];
-    __shared__ int32_t wsum[kPartThreads / 64];
-    const int R = 1 << rshift;
-    const int per = max(1, R / kPartThreads);           // consecutive counters per thread in the scan (R <= 8 k: at most 8)
-    constexpr int UN = 8;
-    for (int b = blockIdx.x; b < n_coarse; b += gridDim.x) {
-        const long long lo = base[b], hi = base[b + 1];
-        const int r0 = b << rshift;
-        const int nr = min(R, n_reads - r0);
-        for (int i = threadIdx.x; i < R; i += kPartThreads) cnt[i] = 0;
-        __syncthreads();
-        for (long long i0 = lo + threadIdx.x; i0 < hi; i0 += (long long)kPartThreads * UN) {
-            int r[UN];
-#pragma unroll
-            for (int k = 0; k < UN; ++k) { const long long i = i0 + (long long)k * kPartThreads; r[k] = i < hi ? i_rid[i] : -1; }
-#pragma unroll
-            for (int k = 0; k < UN; ++k) if (r[k] >= 0) atomicAdd(&cnt[r[k] - r0], 1);
-        }
-        __syncthreads();
-        // exclusive scan of cnt[0 .. R): thread t owns counters [t * per, t * per + per)
-        int mine = 0;
-        const int c0 = (int)threadIdx.x * per;
-        if (c0 < R) for (int k = 0; k < per; ++k) mine += cnt[c0 + k];
-        const int incl = wave_incl_scan_add(mine);
-        const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        if (lane == 63) wsum[wid] = incl;
-        __syncthreads();
-        if (threadIdx.x < kPartThreads / 64) {            // (16 wave sums: one partial wave scans them)
-            const int v = wsum[threadIdx.x];
-            int acc = v;
-            for (int d = 1; d < kPartThreads / 64; d <<= 1) { const int o = __shfl_up(acc, d, kWave); if ((int)threadIdx.x >= d) acc += o; }
-            wsum[threadIdx.x] = acc - v;
-        }
-        __syncthreads();
-        int run = wsum[wid] + incl - mine;
-        if (c0 < R) for (int k = 0; k < per; ++k) {
-            const int v = cnt[c0 + k];
-            cnt[c0 + k] = run;                             // the read's cursor from here on
-            if (c0 + k < nr) off[r0 + c0 + k] = lo + run;
-            run += v;
-        }
-        if (b == n_coarse - 1 && threadIdx.x == 0) off[n_reads] = hi;
-        __syncthreads();
-        constexpr int U2 = 4;
-        for (long long i0 = lo + threadIdx.x; i0 < hi; i0 += (long long)kPartThreads * U2) {
-            int r[U2], a[U2], e[U2];
-#pragma unroll
-            for (int k = 0; k < U2; ++k) {
-                const long long i = i0 + (long long)k * kPartThreads;
-                r[k] = -1; a[k] = 0; e[k] = 0;
-                if (i < hi) { r[k] = i_rid[i]; a[k] = i_s[i]; e[k] = i_e[i]; }
-            }
-#pragma unroll
-            for (int k = 0; k < U2; ++k) {
-                if (r[k] < 0) continue;
-                const long long d = lo + atomicAdd(&cnt[r[k] - r0], 1);
-                o_rid[d] = r[k]; o_s[d] = a[k]; o_e[d] = e[k];
-            }
-        }
-        __syncthreads();
+    const int n = min(gaps->n, kGapList);
+    for (int g = blockIdx.x; g < n; g += gridDim.x) {
+        const long long lo = gaps->lo[g], hi = gaps->hi[g], v = gaps->val[g];
+        for (long long r = lo + threadIdx.x; r <= hi; r += blockDim.x) off[r] = v;
     }
 }
 

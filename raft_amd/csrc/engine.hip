@@ -3,6 +3,7 @@
 // buffers; one pass = the kernels listed in DESIGN.md §Kernels, in order.
 #include "../../include/raft_hip.h"
 
+#include <rocprim/device/device_radix_sort.hpp>   // (the general bucketing path's sort by read id: bucket.hpp says why it stays a library sort)
 #include "bucket.hpp"
 #include "sort_pairs.hpp"
 #include "device_scan.hpp"
@@ -209,10 +210,17 @@ struct DevBuf {
     std::vector<size_t> map_order;    // chunk mapped at the i-th 32 MiB of the range
     size_t va_bytes = 0;
     static constexpr size_t kChunk = 32u << 20, kVmmMin = 64u << 20, kSpreadMin = size_t(1) << 30;
+    // the placement policy of buffers made from now on (process-wide): 0 = plain hipMalloc, k >= 1 = chunks, k times as many made
+    // as used for buffers of 1 GiB or more.  RAFT_NO_VMM=1 / RAFT_VMM_SPREAD=<k> set the start value; raft_hip_set_placement changes it.
+    static std::atomic<int> &policy()
+    {
+        static std::atomic<int> p{getenv("RAFT_NO_VMM") ? 0 : (getenv("RAFT_VMM_SPREAD") ? std::max(1, atoi(getenv("RAFT_VMM_SPREAD"))) : 8)};
+        return p;
+    }
     bool map_chunks(size_t want)
     {
-        static const bool off = getenv("RAFT_NO_VMM") != nullptr;
-        if (off) return false;
+        const int pol = policy().load();
+        if (pol <= 0) return false;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         hipMemAllocationProp prop{};
         prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
@@ -221,7 +229,7 @@ struct DevBuf {
             (void)hipGetLastError(); return false;
         }
         const size_t n = (want + kChunk - 1) / kChunk;
-        static const size_t kSpread = (size_t)(getenv("RAFT_VMM_SPREAD") ? std::max(1, atoi(getenv("RAFT_VMM_SPREAD"))) : 8);
+        const size_t kSpread = (size_t)pol;
         hipDeviceptr_t va = nullptr;
         if (hipMemAddressReserve(&va, n * kChunk, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
         ChunkPool &pool = ChunkPool::of(dev);
@@ -422,7 +430,7 @@ struct raft_hip_ctx {
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
     DevBuf gs_rid, gs_s, gs_e, gs_off, gs_err;  // raft_hip_group_sides: the slice it hands back (+ its error word)
     std::vector<long long> gs_off_host;
-    DevBuf rs_k0, rs_v0, coarse;         // general streams, large inputs: the sides between the two steps of the partition (ids; starts | ends), the coarse buckets' tables
+    DevBuf rs_k0, rs_k1, rs_v0, rs_v1, gaps;   // general streams, large inputs: (read id, start | end << 32) per side, before and after the radix sort; long runs of reads without intervals
     DevBuf samples;                   // up to kSamples + 2 read ids at evenly spaced records (guess_runs_kernel): coarse index
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
     DevBuf dbg;                       // diagnostic variant only
@@ -566,7 +574,7 @@ int raft_hip_create(int device_id, const raft_hip_params *params, raft_hip_ctx *
     c->device = device_id;
     for (DevBuf *b : {&c->cov, &c->cov8, &c->cuts, &c->frag_read, &c->frag_begin, &c->frag_end, &c->raw_key, &c->raw_s, &c->raw_e, &c->rep_s, &c->rep_e,
                       &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5], &c->u_s, &c->u_e, &c->exp_qid,
-                      &c->b_rid, &c->b_s, &c->b_e, &c->rs_k0, &c->rs_v0, &c->gs_rid, &c->gs_s, &c->gs_e})
+                      &c->b_rid, &c->b_s, &c->b_e, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1, &c->gs_rid, &c->gs_s, &c->gs_e})
         b->big = true;                                         // (what a pass streams through: see DevBuf)
     apply_params(c, params);
     if (const char *w = getenv("RAFT_COV_WIDTH")) {           // (test sweeps: every context of the process in that width)
@@ -612,7 +620,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
     DevBuf *all[] = {&c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
-                     &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->gs_rid, &c->gs_s, &c->gs_e, &c->gs_off, &c->gs_err, &c->rs_k0, &c->rs_v0, &c->coarse, &c->in_len,
+                     &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->gs_rid, &c->gs_s, &c->gs_e, &c->gs_off, &c->gs_err, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1, &c->gaps, &c->in_len,
                      &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->exc_idx2, &c->exc_val2, &c->sort_tmp, &c->exc_pidx, &c->exc_pval, &c->exc_tile_n, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     for (DevBuf *b : c->user_bufs) { b->release(); delete b; }
@@ -644,6 +652,11 @@ int64_t raft_hip_trim(int device_id, int64_t keep_bytes)
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev || keep_bytes < 0) return -(int64_t)RAFT_HIP_ERR_PARAM;
     if (hipSetDevice(device_id) != hipSuccess) return -(int64_t)RAFT_HIP_ERR_DEVICE;
     return (int64_t)ChunkPool::of(device_id).trim((size_t)(keep_bytes / (int64_t)DevBuf::kChunk)) * (int64_t)DevBuf::kChunk;
+}
+
+int32_t raft_hip_set_placement(int32_t spread)
+{
+    return (int32_t)DevBuf::policy().exchange(spread < 0 ? 0 : std::min(spread, 64));
 }
 
 int64_t raft_hip_pool_bytes(int device_id)
@@ -711,43 +724,32 @@ int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket
 // at hand; without one the ids ARE the offsets, expanded on the device).  A record that does not sit where the offsets
 // say sends the pass to the plain form above.  With the caller's window count (`in.hint_bins`) the host sizes everything
 // without waiting for the device: the pass is one uninterrupted sequence of launches.
-// The sides of a record stream in any order, partitioned by read (bucket.hpp, round 5): o_rid / o_s / o_e hold every read's
-// intervals together, reads in index order; off[r] says where read r's begin, off[n_reads] how many there are.  *done = false:
-// the shape does not fit (more reads than 4096 coarse buckets of 8192 take) and nothing was launched.
-static int partition_sides(raft_hip_ctx *c, hipStream_t st, long long n_rec, int32_t n_reads, int symmetric, const int32_t *d_qid, const int32_t *d_qs,
-                           const int32_t *d_qe, const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te, long long cap_iv, int32_t *o_rid, int32_t *o_s,
-                           int32_t *o_e, long long *off, int32_t *err_flags, long long *err_index, bool *done)
+// The sides of a record stream in any order, sorted by read (bucket.hpp): o_rid / o_s / o_e hold every read's intervals
+// together, reads in index order; off[r] says where read r's begin, off[n_reads] how many there are.
+static int sort_sides(raft_hip_ctx *c, hipStream_t st, long long n_rec, int32_t n_reads, int symmetric, const int32_t *d_qid, const int32_t *d_qs,
+                      const int32_t *d_qe, const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te, long long cap_iv, int32_t *o_rid, int32_t *o_s,
+                      int32_t *o_e, long long *off, int32_t *err_flags, long long *err_index)
 {
-    *done = false;
-    if (n_rec <= 0 || n_reads <= 0) return RAFT_HIP_OK;
-    // reads per coarse bucket: a power of two with ~2 MB of intervals per bucket (12 bytes each), 16 at least, 8192 at most
-    const double per_read = std::max(1.0, (double)cap_iv / (double)n_reads);
-    int rshift = 4;
-    while (rshift < kFineMaxShift && (double)(2 << rshift) * per_read * 12.0 <= 2.0e6) ++rshift;
-    while (rshift < kFineMaxShift && (((long long)n_reads + (1LL << rshift) - 1) >> rshift) > kCoarseMax) ++rshift;
-    if (const char *e = getenv("RAFT_PART_SHIFT")) rshift = std::max(4, std::min(kFineMaxShift, atoi(e)));      // (tests, sweeps)
-    const long long n_coarse_ll = ((long long)n_reads + (1LL << rshift) - 1) >> rshift;
-    if (n_coarse_ll > kCoarseMax) return RAFT_HIP_OK;
-    const int n_coarse = (int)n_coarse_ll;
-    HIP_TRY(c, c->rs_k0.ensure((size_t)cap_iv * 4));
-    HIP_TRY(c, c->rs_v0.ensure((size_t)cap_iv * 8));
-    HIP_TRY(c, c->coarse.ensure((size_t)(3 * (kCoarseMax + 1)) * 8));
-    unsigned long long *cnt = c->coarse.as<unsigned long long>();
-    long long *base = reinterpret_cast<long long *>(cnt + (kCoarseMax + 1));
-    unsigned long long *cursor = cnt + 2 * (kCoarseMax + 1);
-    int32_t *t_rid = c->rs_k0.as<int32_t>(), *t_s = c->rs_v0.as<int32_t>(), *t_e = c->rs_v0.as<int32_t>() + cap_iv;
-    HIP_TRY(c, hipMemsetAsync(cnt, 0, (size_t)n_coarse * 8, st));
-    const unsigned g0 = (unsigned)std::max<long long>(1, std::min<long long>((n_rec + 255) / 256, 256 * 8));
-    hipLaunchKernelGGL(coarse_hist_kernel, dim3(g0), dim3(256), 0, st, n_rec, n_reads, symmetric, rshift, n_coarse, d_qid, d_tid, cnt, err_flags, err_index);
-    hipLaunchKernelGGL(coarse_scan_kernel, dim3(1), dim3(1024), 0, st, n_coarse, cnt, base, cursor);
-    const int step = kPartThreads * kPartUnroll;
-    const int tile = (int)std::min<long long>(kPartTile, std::max<long long>(2 * step, (n_rec / 512 + step - 1) / step * step));
-    const unsigned g1 = (unsigned)std::max<long long>(1, std::min<long long>((n_rec + tile - 1) / tile, 256 * 2));
-    hipLaunchKernelGGL(coarse_partition_kernel, dim3(g1), dim3(kPartThreads), 0, st, n_rec, tile, n_reads, symmetric, rshift, n_coarse, d_qid, d_qs, d_qe, d_tid, d_ts, d_te,
-                       cursor, t_rid, t_s, t_e);
-    hipLaunchKernelGGL(bucket_finish_kernel, dim3((unsigned)n_coarse), dim3(kPartThreads), 0, st, n_reads, rshift, n_coarse, base, t_rid, t_s, t_e, o_rid, o_s, o_e, off);
+    HIP_TRY(c, c->rs_k0.ensure((size_t)cap_iv * 4)); HIP_TRY(c, c->rs_k1.ensure((size_t)cap_iv * 4));
+    HIP_TRY(c, c->rs_v0.ensure((size_t)cap_iv * 8)); HIP_TRY(c, c->rs_v1.ensure((size_t)cap_iv * 8));
+    HIP_TRY(c, c->gaps.ensure(sizeof(GapList)));
+    HIP_TRY(c, hipMemsetAsync(c->gaps.p, 0, 8, st));
+    const unsigned g1 = (unsigned)std::max<long long>(1, std::min<long long>((n_rec + 255) / 256, 256 * 32));
+    hipLaunchKernelGGL(expand_sides_kernel, dim3(g1), dim3(256), 0, st, n_rec, n_reads, symmetric, d_qid, d_qs, d_qe, d_tid, d_ts, d_te,
+                       c->rs_k0.as<uint32_t>(), c->rs_v0.as<unsigned long long>(), err_flags, err_index);
+    int bits = 1;
+    while (bits < 32 && (1LL << bits) <= (long long)n_reads) ++bits;               // keys 0 .. n_reads (the sides that do not exist)
+    size_t tmp = 0;
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
+                                         c->rs_v1.as<unsigned long long>(), (size_t)cap_iv, 0u, (unsigned)bits, st));
+    HIP_TRY(c, c->sort_tmp.ensure(tmp));
+    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
+                                         c->rs_v1.as<unsigned long long>(), (size_t)cap_iv, 0u, (unsigned)bits, st));
+    const unsigned g2 = (unsigned)std::max<long long>(1, std::min<long long>((cap_iv + 255) / 256, 256 * 32));
+    hipLaunchKernelGGL(unzip_sorted_kernel, dim3(g2), dim3(256), 0, st, cap_iv, n_reads, c->rs_k1.as<uint32_t>(), c->rs_v1.as<unsigned long long>(),
+                       o_rid, o_s, o_e, off, c->gaps.as<GapList>());
+    hipLaunchKernelGGL(fill_gaps_kernel, dim3(64), dim3(256), 0, st, c->gaps.as<GapList>(), off);
     HIP_TRY(c, hipGetLastError());
-    *done = true;
     return RAFT_HIP_OK;
 }
 
@@ -1081,14 +1083,14 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         HIP_TRY(c, c->b_rid.ensure((size_t)cap_iv * 4));
         HIP_TRY(c, c->b_s.ensure((size_t)cap_iv * 4));
         HIP_TRY(c, c->b_e.ensure((size_t)cap_iv * 4));
-        // large inputs in any order are partitioned in two steps (bucket.hpp, round 5); the counting sort stays for small inputs, where
-        // its three launches cost less, for a symmetric stream of a few sorted runs that is sent here all the same (force_bucket, A/B:
-        // its scatter is local), and for more reads than the partition's LDS counters take (3.3e7)
-        bool parted = false;
-        if (cap_iv >= (1LL << 20) && (!symmetric || n_desc + 1 > kMaxSeg) && getenv("RAFT_NO_PARTITION") == nullptr) {
-            const int prc = partition_sides(c, st, (long long)n_rec, n_reads, symmetric, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, cap_iv,
-                                            c->b_rid.as<int32_t>(), c->b_s.as<int32_t>(), c->b_e.as<int32_t>(), c->b_off.as<long long>(),
-                                            &ctrl->err_flags, &ctrl->err_index, &parted);
+        // large inputs are sorted, not scattered (bucket.hpp): the counting sort's random 12-byte writes took 87 ms for 2.9e8
+        // shuffled records; it stays for small inputs, where its three launches cost less than the sort's
+        // (... and for a symmetric stream of a few sorted runs that is sent here all the same -- force_bucket, A/B: its scatter is local)
+        const bool parted = cap_iv >= (1LL << 20) && (!symmetric || n_desc + 1 > kMaxSeg) && getenv("RAFT_NO_RADIX_SORT") == nullptr;
+        if (parted) {
+            const int prc = sort_sides(c, st, (long long)n_rec, n_reads, symmetric, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, cap_iv,
+                                       c->b_rid.as<int32_t>(), c->b_s.as<int32_t>(), c->b_e.as<int32_t>(), c->b_off.as<long long>(),
+                                       &ctrl->err_flags, &ctrl->err_index);
             if (prc != RAFT_HIP_OK) return prc;
         }
         if (!parted) {
@@ -3060,24 +3062,10 @@ int raft_hip_group_sides(raft_hip_ctx *c, int32_t n_reads_total, int64_t n_rec, 
         HIP_TRY(c, hipMemsetAsync(c->gs_err.as<char>() + 8, 0xff, 8, st));
         int32_t *gerr = c->gs_err.as<int32_t>();
         long long *gerr_index = reinterpret_cast<long long *>(c->gs_err.as<char>() + 8);
-        bool parted = false;
         {
-            const int prc = partition_sides(c, st, (long long)n_rec, n_reads_total, symmetric ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, n_ent,
-                                            c->gs_rid.as<int32_t>(), c->gs_s.as<int32_t>(), c->gs_e.as<int32_t>(), c->gs_off.as<long long>(), gerr, gerr_index, &parted);
+            const int prc = sort_sides(c, st, (long long)n_rec, n_reads_total, symmetric ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, n_ent,
+                                       c->gs_rid.as<int32_t>(), c->gs_s.as<int32_t>(), c->gs_e.as<int32_t>(), c->gs_off.as<long long>(), gerr, gerr_index);
             if (prc != RAFT_HIP_OK) return prc;
-        }
-        if (!parted) {                               // (more reads than the partition takes: the counting sort)
-            HIP_TRY(c, c->b_cnt.ensure((size_t)std::max<long long>(n_reads_total, 1) * 4));
-            HIP_TRY(c, c->scan_tmp.ensure(((size_t)std::max(scan_blocks(n_reads_total), 1) * 3 + 8) * sizeof(long long)));
-            HIP_TRY(c, hipMemsetAsync(c->b_cnt.p, 0, (size_t)std::max<long long>(n_reads_total, 1) * 4, st));
-            const unsigned grid = (unsigned)std::min<long long>((n_rec + 255) / 256, 8192);
-            hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads_total, symmetric ? 1 : 0, d_qid, d_tid, c->b_cnt.as<int32_t>(), gerr, gerr_index);
-            CountLoader<1> ld{{c->b_cnt.as<int32_t>()}};
-            ScanOut<1> so{{c->gs_off.as<long long>()}};
-            exclusive_scan<CountLoader<1>, 1>(st, ld, (long long)n_reads_total, c->scan_tmp.as<long long>(), so);
-            HIP_TRY(c, hipMemsetAsync(c->b_cnt.p, 0, (size_t)std::max<long long>(n_reads_total, 1) * 4, st));
-            hipLaunchKernelGGL(bucket_scatter_kernel, dim3(grid), dim3(256), 0, st, (long long)n_rec, n_reads_total, symmetric ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te,
-                               c->gs_off.as<long long>(), c->b_cnt.as<int32_t>(), c->gs_rid.as<int32_t>(), c->gs_s.as<int32_t>(), c->gs_e.as<int32_t>());
         }
         HIP_TRY(c, hipGetLastError());
         long long err[2] = {0, -1};

@@ -29,7 +29,7 @@ EXPORTS = (
     "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local", "raft_hip_warm_up", "raft_hip_reserve",
     "raft_hip_run_device_windows", "raft_hip_run_host_windows", "raft_hip_run_multi_windows",
     "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device", "raft_hip_set_emit_cuts", "raft_hip_device_alloc", "raft_hip_device_free", "raft_hip_group_sides", "raft_hip_presplit_symmetric", "raft_hip_presplit_symmetric_local",
-    "raft_hip_trim", "raft_hip_pool_bytes", "raft_hip_run_presplit_local",
+    "raft_hip_trim", "raft_hip_pool_bytes", "raft_hip_run_presplit_local", "raft_hip_set_placement",
 )
 
 
@@ -175,6 +175,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_trim.restype = i64
     lib.raft_hip_pool_bytes.argtypes = [C.c_int]
     lib.raft_hip_pool_bytes.restype = i64
+    lib.raft_hip_set_placement.argtypes = [i32]
+    lib.raft_hip_set_placement.restype = i32
     lib.raft_hip_group_sides.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_Slice)]
     lib.raft_hip_presplit_symmetric.argtypes = [vp, vp, i32, i32, C.POINTER(_Records), C.POINTER(i32)]
     lib.raft_hip_presplit_symmetric_local.argtypes = [C.POINTER(vp), i32, C.POINTER(_Records), C.POINTER(i32)]
@@ -823,6 +825,11 @@ def selftest(device: int = 0) -> int:
 def trim(device: int = 0, keep_bytes: int = 0) -> int:
     """Hands the device's pooled placement chunks beyond keep_bytes back to the driver; returns the bytes released."""
     return int(load_library().raft_hip_trim(device, keep_bytes))
+
+
+def set_placement(spread: int) -> int:
+    """Placement of buffers made from now on: 0 hipMalloc, k >= 1 shuffled chunks with k-fold spread (default 8); returns the old setting."""
+    return int(load_library().raft_hip_set_placement(spread))
 
 
 def pool_bytes(device: int = 0) -> int:

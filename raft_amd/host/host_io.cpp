@@ -352,7 +352,10 @@ struct raft_host_reads {
     std::string bases;                // streaming reader: all sequences, concatenated
     std::unique_ptr<char[]> raw_bases;   // mapped-file reader: the same, allocated without being touched (a GB-sized
                                       // zero fill on one thread cost as much as the parallel copy that follows)
-    const char *base_ptr() const { return raw_bases ? raw_bases.get() : bases.data(); }
+    void *map_ptr = nullptr;          // ... or, when every sequence of the file is one line, the mapped file itself (base_off: byte positions in it)
+    size_t map_n = 0;
+    ~raft_host_reads() { if (map_ptr) munmap(map_ptr, map_n); }
+    const char *base_ptr() const { return map_ptr ? static_cast<const char *>(map_ptr) : (raw_bases ? raw_bases.get() : bases.data()); }
     int real_reads = 1;
     // simulated-read mode (chop.hpp:116-121): parsed from every name
     std::vector<int32_t> start_pos, end_pos;
@@ -416,45 +419,61 @@ int load_plain_fasta_parallel(const char *path, raft_host_reads *R)
     close(fd);
     if (map == MAP_FAILED) return -1;
     const char *d = static_cast<const char *>(map);
-    struct Unmap { void *p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, n};
+    struct Unmap { void *p; size_t n; ~Unmap() { if (p) munmap(p, n); } } unmap{map, n};
     if (d[0] != '>') return -1;
 
-    // pass 0: record starts per byte range; eligibility
-    std::vector<std::vector<size_t>> starts((size_t)T);
-    std::vector<char> bad((size_t)T, 0);
+    // The ONE pass over the file's bytes (round 5; three before: record starts, newlines per record, copy): every worker walks
+    // the lines of its byte range -- the '\n' scan brings a line in, the '\r' check runs over it while it is in cache -- and
+    // notes the record starts together with how many other lines follow each of them inside the range.  A record's sequence
+    // length is then its span minus its newlines, known without looking at the bases again; and when every sequence is ONE
+    // line (hifiasm's corrected reads, any FASTA written one line per record) the bases are not copied at all: the mapping
+    // stays and every read points into it.
+    struct Range { std::vector<size_t> starts; std::vector<uint32_t> lines; size_t lead = 0; char bad = 0; };
+    std::vector<Range> rg((size_t)T);
     parallel_for(T, [&](int t) {
         const size_t lo = n * (size_t)t / (size_t)T, hi = n * ((size_t)t + 1) / (size_t)T;
         if (lo >= hi) return;
-        if (memchr(d + lo, '\r', hi - lo)) { bad[(size_t)t] = 1; return; }
-        auto &v = starts[(size_t)t];
+        Range &g = rg[(size_t)t];
         auto line_start = [&](size_t q) {
             const char c = d[q];
-            if (c == '>') v.push_back(q);
-            else if (c == '@' || c == '+') bad[(size_t)t] = 1;
+            if (c == '>') { g.starts.push_back(q); g.lines.push_back(0); }
+            else {
+                if (c == '@' || c == '+') g.bad = 1;
+                if (g.starts.empty()) ++g.lead; else ++g.lines.back();
+            }
         };
         if (lo == 0) line_start(0);
         // a line start q belongs to the range holding q; its '\n' is at q-1 >= lo-1
         size_t p = lo == 0 ? 0 : lo - 1;
-        while (p < hi - 1) {
+        while (p < hi - 1 && !g.bad) {
             const char *nl = static_cast<const char *>(memchr(d + p, '\n', hi - 1 - p));
+            const size_t le = nl ? (size_t)(nl - d) : hi - 1;
+            if (memchr(d + p, '\r', le - p)) { g.bad = 1; break; }
             if (!nl) break;
-            const size_t q = (size_t)(nl - d) + 1;
-            line_start(q);
-            p = q;
+            line_start(le + 1);
+            p = le + 1;
         }
+        if (!g.bad && hi == n && n >= 1 && d[n - 1] == '\r') g.bad = 1;   // (the file's last byte is scanned by nobody else)
     });
-    for (char b : bad) if (b) return -1;
+    for (const Range &g : rg) if (g.bad) return -1;
     std::vector<size_t> rec;
-    for (auto &v : starts) rec.insert(rec.end(), v.begin(), v.end());
+    std::vector<uint32_t> seq_lines;             // lines of the record other than its header line
+    for (int t = 0; t < T; ++t) {
+        const Range &g = rg[(size_t)t];
+        if (g.lead) { if (seq_lines.empty()) return -1; seq_lines.back() += (uint32_t)g.lead; }   // (lines of a record that began in an earlier range)
+        rec.insert(rec.end(), g.starts.begin(), g.starts.end());
+        seq_lines.insert(seq_lines.end(), g.lines.begin(), g.lines.end());
+    }
     size_t data_end = n;
-    if (!rec.empty() && rec.back() + 1 == n) { data_end = rec.back(); rec.pop_back(); }   // bare '>' as the last byte: kseq finds no name and stops
+    if (!rec.empty() && rec.back() + 1 == n) { data_end = rec.back(); rec.pop_back(); seq_lines.pop_back(); }   // bare '>' as the last byte: kseq finds no name and stops
     const size_t n_rec = rec.size();
     if (n_rec > 0x7fffffffull) return RAFT_HOST_ERR_ARG;
 
-    // pass 1: name span, first sequence byte, sequence length of every record
+    // name span, first sequence byte, sequence length of every record: a look at the header line only
     std::vector<size_t> name_end(n_rec), seq_begin(n_rec);
     R->lens.assign(n_rec, 0);
     auto rec_range = [&](int t, size_t &a, size_t &b) { a = n_rec * (size_t)t / (size_t)T; b = n_rec * ((size_t)t + 1) / (size_t)T; };
+    std::vector<char> multi((size_t)T, 0);
     parallel_for(T, [&](int t) {
         size_t a, b;
         rec_range(t, a, b);
@@ -469,37 +488,45 @@ int load_plain_fasta_parallel(const char *path, raft_host_reads *R)
             }
             const size_t sb = q < end ? q + 1 : end;
             seq_begin[i] = sb;
+            // newlines inside [sb, end): one between two of its lines, one behind the last line unless the file ends without
             size_t newlines = 0;
-            for (size_t p = sb; p < end;) {
-                const char *nl = static_cast<const char *>(memchr(d + p, '\n', end - p));
-                if (!nl) break;
-                ++newlines;
-                p = (size_t)(nl - d) + 1;
+            if (sb < end) {
+                const size_t lines = seq_lines[i];                   // (>= 1: sb itself is a line start that is not a record start)
+                newlines = (lines ? lines - 1 : 0) + (d[end - 1] == '\n' ? 1 : 0);
+                if (lines > 1) multi[(size_t)t] = 1;
             }
             R->lens[i] = (int32_t)(end - sb - newlines);
         }
     });
+    bool any_multi = false;
+    for (char m : multi) any_multi = any_multi || m;
     R->base_off.resize(n_rec);
-    size_t total = 0;
-    for (size_t i = 0; i < n_rec; ++i) { R->base_off[i] = total; total += (size_t)R->lens[i]; }
-    R->raw_bases.reset(new char[total ? total : 1]);
-
-    // pass 2: bases, lines joined
-    parallel_for(T, [&](int t) {
-        size_t a, b;
-        rec_range(t, a, b);
-        for (size_t i = a; i < b; ++i) {
-            const size_t end = i + 1 < n_rec ? rec[i + 1] : data_end;
-            char *dst = R->raw_bases.get() + R->base_off[i];
-            for (size_t p = seq_begin[i]; p < end;) {
-                const char *nl = static_cast<const char *>(memchr(d + p, '\n', end - p));
-                const size_t le = nl ? (size_t)(nl - d) : end;
-                memcpy(dst, d + p, le - p);
-                dst += le - p;
-                p = le + 1;
+    if (!any_multi) {
+        // every sequence is one line: the reads ARE the mapping
+        for (size_t i = 0; i < n_rec; ++i) R->base_off[i] = seq_begin[i];
+        R->map_ptr = map; R->map_n = n;
+        unmap.p = nullptr;                                           // (kept until raft_host_reads_free)
+    } else {
+        size_t total = 0;
+        for (size_t i = 0; i < n_rec; ++i) { R->base_off[i] = total; total += (size_t)R->lens[i]; }
+        R->raw_bases.reset(new char[total ? total : 1]);
+        // bases, lines joined
+        parallel_for(T, [&](int t) {
+            size_t a, b;
+            rec_range(t, a, b);
+            for (size_t i = a; i < b; ++i) {
+                const size_t end = i + 1 < n_rec ? rec[i + 1] : data_end;
+                char *dst = R->raw_bases.get() + R->base_off[i];
+                for (size_t p = seq_begin[i]; p < end;) {
+                    const char *nl = static_cast<const char *>(memchr(d + p, '\n', end - p));
+                    const size_t le = nl ? (size_t)(nl - d) : end;
+                    memcpy(dst, d + p, le - p);
+                    dst += le - p;
+                    p = le + 1;
+                }
             }
-        }
-    });
+        });
+    }
 
     // names, in file order (ids are FASTA positions)
     std::string name;
@@ -1065,40 +1092,109 @@ int raft_host_write_fasta(const char *path, const raft_host_reads *reads, const 
                           const int32_t *frag_begin, const int32_t *frag_end)
 {
     const int32_t n = (int32_t)reads->lens.size();
-    auto one_read = [&](long long i, std::string &o) {
+    // the header line of fragment f of read i (empty: chop.hpp:293-311 writes none for that orientation)
+    auto one_header = [&](long long i, int64_t f, std::string &o) {
         const char *name = reads->names.name((int32_t)i);
         const size_t name_n = reads->names.name_len((int32_t)i);
-        const char *seq = reads->base_ptr() + reads->base_off[(size_t)i];
         const int64_t f0 = frag_offset[i], f1 = frag_offset[i + 1];
         const bool whole = (f1 - f0) == 1;             // kept in one piece (chop.hpp:250-267)
-        for (int64_t f = f0; f < f1; ++f) {
-            const long long read_num = f + 1;
-            const int32_t b = frag_begin[f], e = frag_end[f];
-            if (reads->real_reads) {
-                o.append(">read=", 6); put_num(o, read_num); o.push_back(','); o.append(name, name_n);
-                o.append(",pos_on_original_read=", 22); put_num(o, b); o.push_back('-'); put_num(o, e); o.push_back('\n');
-            } else {
-                // tail = name.substr(name.find_last_of(','))  -> ",<contig>"
-                const std::string nm(name, name_n);
-                const size_t lc = nm.find_last_of(',');
-                const std::string tail = lc == std::string::npos ? std::string() : nm.substr(lc);
-                const std::string &al = reads->align[(size_t)i];
-                const int32_t sp = reads->start_pos[(size_t)i], ep = reads->end_pos[(size_t)i];
-                bool header = true;
-                long long p0 = 0, p1 = 0, ln = 0;
-                if (whole) { p0 = sp; p1 = ep; ln = reads->lens[(size_t)i]; }
-                else if (al == "forward") { p0 = (long long)sp + b; p1 = (long long)sp + e; ln = e - b; }
-                else if (al == "reverse") { p0 = (long long)ep - e; p1 = (long long)ep - b; ln = e - b; }
-                else header = false;                     // chop.hpp:293-311 writes no header for other orientations
-                if (header) {
-                    o.append(">read=", 6); put_num(o, read_num); o.push_back(','); o.append(al); o.append(",position=", 10);
-                    put_num(o, p0); o.push_back('-'); put_num(o, p1); o.append(",length=", 8); put_num(o, ln); o.append(tail); o.push_back('\n');
-                }
+        const long long read_num = f + 1;
+        const int32_t b = frag_begin[f], e = frag_end[f];
+        if (reads->real_reads) {
+            o.append(">read=", 6); put_num(o, read_num); o.push_back(','); o.append(name, name_n);
+            o.append(",pos_on_original_read=", 22); put_num(o, b); o.push_back('-'); put_num(o, e); o.push_back('\n');
+        } else {
+            // tail = name.substr(name.find_last_of(','))  -> ",<contig>"
+            const std::string nm(name, name_n);
+            const size_t lc = nm.find_last_of(',');
+            const std::string tail = lc == std::string::npos ? std::string() : nm.substr(lc);
+            const std::string &al = reads->align[(size_t)i];
+            const int32_t sp = reads->start_pos[(size_t)i], ep = reads->end_pos[(size_t)i];
+            bool header = true;
+            long long p0 = 0, p1 = 0, ln = 0;
+            if (whole) { p0 = sp; p1 = ep; ln = reads->lens[(size_t)i]; }
+            else if (al == "forward") { p0 = (long long)sp + b; p1 = (long long)sp + e; ln = e - b; }
+            else if (al == "reverse") { p0 = (long long)ep - e; p1 = (long long)ep - b; ln = e - b; }
+            else header = false;                     // chop.hpp:293-311 writes no header for other orientations
+            if (header) {
+                o.append(">read=", 6); put_num(o, read_num); o.push_back(','); o.append(al); o.append(",position=", 10);
+                put_num(o, p0); o.push_back('-'); put_num(o, p1); o.append(",length=", 8); put_num(o, ln); o.append(tail); o.push_back('\n');
             }
-            o.append(seq + b, (size_t)(e - b));
+        }
+    };
+    auto one_read_headers = [&](long long i, std::string &o) {
+        for (int64_t f = frag_offset[i]; f < frag_offset[i + 1]; ++f) one_header(i, f, o);
+    };
+    auto one_read = [&](long long i, std::string &o) {
+        const char *seq = reads->base_ptr() + reads->base_off[(size_t)i];
+        for (int64_t f = frag_offset[i]; f < frag_offset[i + 1]; ++f) {
+            one_header(i, f, o);
+            o.append(seq + frag_begin[f], (size_t)(frag_end[f] - frag_begin[f]));
             o.push_back('\n');
         }
     };
+    // Round 5: the file is sized first (a pass over the fragment table: header lengths), created at that size, mapped, and the
+    // workers format their blocks of reads straight into the mapping -- one copy of every base, made by all threads at once,
+    // where the buffered writer made two (into a block buffer, then by ONE thread's write() into the page cache: 1.4 s of a 7 s
+    // run on the 10 GB set).  RAFT_FASTA_MMAP=0, or any failure on the way, keeps the buffered writer.
+    if (n > 0 && !(getenv("RAFT_FASTA_MMAP") && atoi(getenv("RAFT_FASTA_MMAP")) == 0)) {
+        const int T = host_threads();
+        const int nblk = (int)std::min<long long>((long long)n, (long long)T * 16);
+        std::vector<size_t> blk_bytes((size_t)nblk, 0);
+        auto blk_range = [&](int t, long long &a, long long &b) { a = (long long)n * t / nblk; b = (long long)n * (t + 1) / nblk; };
+        parallel_for(nblk, [&](int t) {
+            long long a, b;
+            blk_range(t, a, b);
+            std::string h;
+            size_t bytes = 0;
+            for (long long i = a; i < b; ++i) {          // the headers are formatted once more below: they are a thousandth of the bytes
+                const int64_t f0 = frag_offset[i], f1 = frag_offset[i + 1];
+                size_t seq = 0;
+                for (int64_t f = f0; f < f1; ++f) seq += (size_t)(frag_end[f] - frag_begin[f]);
+                h.clear();
+                one_read_headers(i, h);
+                bytes += h.size() + seq + (size_t)(f1 - f0);
+            }
+            blk_bytes[(size_t)t] = bytes;
+        });
+        std::vector<size_t> blk_off((size_t)nblk + 1, 0);
+        for (int t = 0; t < nblk; ++t) blk_off[(size_t)t + 1] = blk_off[(size_t)t] + blk_bytes[(size_t)t];
+        const size_t total = blk_off[(size_t)nblk];
+        const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0666);
+        if (fd >= 0 && total > 0 && ftruncate(fd, (off_t)total) == 0) {
+            void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (m != MAP_FAILED) {
+                char *out = static_cast<char *>(m);
+                std::vector<char> bad((size_t)nblk, 0);
+                parallel_for(nblk, [&](int t) {
+                    long long a, b;
+                    blk_range(t, a, b);
+                    char *w = out + blk_off[(size_t)t];
+                    std::string h;
+                    for (long long i = a; i < b; ++i) {
+                        const char *seq = reads->base_ptr() + reads->base_off[(size_t)i];
+                        const int64_t f0 = frag_offset[i], f1 = frag_offset[i + 1];
+                        for (int64_t f = f0; f < f1; ++f) {
+                            h.clear();
+                            one_header(i, f, h);
+                            memcpy(w, h.data(), h.size()); w += h.size();
+                            const size_t len = (size_t)(frag_end[f] - frag_begin[f]);
+                            memcpy(w, seq + frag_begin[f], len); w += len;
+                            *w++ = '\n';
+                        }
+                    }
+                    if (w != out + blk_off[(size_t)t + 1]) bad[(size_t)t] = 1;
+                });
+                bool ok = true;
+                for (char c : bad) ok = ok && !c;
+                if (munmap(m, total) != 0) ok = false;
+                if (close(fd) != 0) ok = false;
+                if (ok) return RAFT_HOST_OK;
+                return RAFT_HOST_ERR_IO;
+            }
+        }
+        if (fd >= 0) close(fd);
+    }
     return write_ordered(path, n, 8 << 20, [&](long long i) { return (long long)reads->lens[(size_t)i] + 64; }, one_read);
 }
 

@@ -211,3 +211,33 @@ def test_cli_input_forms(tmp_path, name, knob, form):
     # grouped input brings the coverage back as four-bit steps unless told otherwise; the plain columns keep the byte encodings
     enc = "delta4" if (form != "columns" and knob != "RAFT_NO_DELTA4") else ("uint16" if p.est_cov >= 40 else "uint8")
     assert f"coverage_encoding {enc}" in r.stderr.decode(), r.stderr.decode()
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("name", ["s300_nonsym_shuffled", "s300_default", "g3"])
+def test_cli_presplit_ranks(tmp_path, name, ranks):
+    """RAFT_RANKS=N: the pre-split job (BASELINE configs[3]) behind the reference's command line -- N ranks as
+    contexts of the one GPU, each holding a contiguous slice of the record stream, ONE exchange step (raft_hip_run_presplit_local).
+    The four files and stdout are the single-process run's = the reference's, byte for byte."""
+    if name in MAN["micro"]:
+        d = os.path.join(GOLDEN, "micro", name)
+        meta = MAN["micro"][name]
+        shutil.copy(os.path.join(d, "reads.fa"), tmp_path)
+        shutil.copy(os.path.join(d, "overlaps.paf"), tmp_path)
+        want_out = open(os.path.join(d, "expect.stdout")).read()
+        want_files = {f: md5(open(os.path.join(d, "expect." + f), "rb").read()) for f in meta["outputs"]}
+    else:
+        p, cols, exp, meta = load_case(name)
+        names = [f"r{i}" for i in range(len(cols[0]))]
+        write_fasta(tmp_path / "reads.fa", names, cols[0])
+        write_paf(tmp_path / "overlaps.paf", names, *cols)
+        want_out = meta["stdout"]
+        want_files = {"out." + f: digest for f, digest in meta["md5"].items()}
+    r = subprocess.run([RAFT] + meta["args"] + ["reads.fa", "overlaps.paf"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300, env=dict(os.environ, RAFT_RANKS=str(ranks), RAFT_TIMING="1"))
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
+    assert strip_timing(r.stdout.decode()) == want_out
+    for f, digest in want_files.items():
+        assert md5(open(tmp_path / f, "rb").read()) == digest, (name, f)
+    line = [l for l in r.stderr.decode().splitlines() if l.startswith("TIMING devices_used")]
+    assert line and line[0].split()[2] == str(ranks) and "pre-split" in line[0], r.stderr.decode()

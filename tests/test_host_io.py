@@ -234,6 +234,50 @@ def test_loaders_and_writers_thread_count_random(tmp_path):
     assert len(outs[1]["reads.fasta"]) > 0 and len(outs[1]["coverage.txt"]) > 0
 
 
+@pytest.mark.parametrize("single_line", [True, False])
+def test_fasta_writer_mapped_output_equals_buffered(tmp_path, single_line, monkeypatch):
+    """Round 5: the fragment writer sizes the file, maps it and lets every worker format into the mapping; RAFT_FASTA_MMAP=0 keeps
+    the buffered writer.  Same bytes -- from reads that point into the mapped input (every sequence one line) and from copied ones."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    n = 900
+    lens = rng.integers(0, 3000, n)
+    lens[::41] = 0
+    with open(tmp_path / "r.fa", "wb") as f:
+        for i in range(n):
+            seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(lens[i])))
+            f.write(b">q%d" % i + (b" c" if i % 4 == 0 else b"") + b"\n")
+            if single_line or i % 2:
+                f.write(seq + (b"" if i == n - 1 else b"\n"))          # (the file ends without a newline)
+            else:
+                for k in range(0, len(seq), 50):
+                    f.write(seq[k:k + 50] + b"\n")
+    fo, fb, fe = [0], [], []
+    for L in lens:
+        cuts = sorted(set([0, int(L)] + rng.integers(0, int(L) + 1, 3).tolist())) if L > 20 else [0, int(L)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            fb.append(max(a - 5, 0)); fe.append(b)
+        if len(cuts) < 2:
+            fb.append(0); fe.append(int(L))
+        fo.append(len(fb))
+    fo, fb, fe = np.array(fo, np.int64), np.array(fb, np.int32), np.array(fe, np.int32)
+    lib = hostio.load_library()
+    out = {}
+    try:
+        hostio.set_threads(6)
+        reads = hostio.Reads(str(tmp_path / "r.fa"))
+        assert reads.lengths.tolist() == lens.tolist()
+        for mode in ("1", "0"):
+            monkeypatch.setenv("RAFT_FASTA_MMAP", mode)
+            path = str(tmp_path / f"o{mode}.fa")
+            assert lib.raft_host_write_fasta(path.encode(), reads._h, C.c_void_p(fo.ctypes.data), C.c_void_p(fb.ctypes.data), C.c_void_p(fe.ctypes.data)) == 0
+            out[mode] = open(path, "rb").read()
+        reads.close()
+    finally:
+        hostio.set_threads(0)
+    assert out["1"] == out["0"] and out["1"].count(b">") == len(fb)
+
+
 # ---- split_naive (the reference's comparator tool) ----------------------------------------------------------------
 
 SPLIT_INPUT = (">a first\nACGTACGTAC\nGTAC\n>empty\n>b\nTT\n>a\nCCCCCCCCCCCCCCCCCCCCCC\n"      # a repeated name, an empty read
