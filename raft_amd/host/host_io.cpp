@@ -189,6 +189,73 @@ private:
     bool stop_ = false, done_ = false;
 };
 
+// ---- BGZF (blocked gzip: bgzip, htslib, samtools) inflated by all workers --------------------------------------------
+// A plain .gz is ONE deflate stream and inflates on one thread (the Stream above: the floor of a gz run).  A BGZF file is a
+// series of gzip members of at most 64 KiB, each carrying its compressed size in an extra field ('B','C', RFC 1952 / SAM spec
+// 4.1): the members are found by hopping from header to header and inflate independently.  Returns false -- and leaves the
+// single-stream reader to it -- unless the WHOLE file is well-formed BGZF; `out` gets one spare byte behind the data.
+bool inflate_bgzf_parallel(const char *path, std::unique_ptr<char[]> &out, size_t &out_n)
+{
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 28) { close(fd); return false; }
+    const size_t n = (size_t)st.st_size;
+    void *map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return false;
+    struct Unmap { void *p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, n};
+    const unsigned char *d = static_cast<const unsigned char *>(map);
+    struct Member { size_t at, data, dlen, isize, dst; };
+    std::vector<Member> mem;
+    size_t total = 0;
+    for (size_t p = 0; p < n;) {
+        if (n - p < 18 || d[p] != 0x1f || d[p + 1] != 0x8b || d[p + 2] != 8 || !(d[p + 3] & 4)) return false;
+        if (d[p + 3] & ~4) return false;                                   // (name / comment / header crc: not what bgzip writes)
+        const size_t xlen = (size_t)d[p + 10] | ((size_t)d[p + 11] << 8);
+        if (p + 12 + xlen > n) return false;
+        size_t bsize = 0;
+        for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+            const size_t slen = (size_t)d[q + 2] | ((size_t)d[q + 3] << 8);
+            if (d[q] == 'B' && d[q + 1] == 'C' && slen == 2 && q + 6 <= p + 12 + xlen) bsize = ((size_t)d[q + 4] | ((size_t)d[q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || p + bsize > n) return false;
+        const size_t isize = (size_t)d[p + bsize - 4] | ((size_t)d[p + bsize - 3] << 8) | ((size_t)d[p + bsize - 2] << 16) | ((size_t)d[p + bsize - 1] << 24);
+        if (isize > 65536) return false;
+        mem.push_back(Member{p, p + 12 + xlen, bsize - 12 - xlen - 8, isize, total});
+        total += isize;
+        p += bsize;
+    }
+    if (mem.empty()) return false;
+    std::unique_ptr<char[]> buf(new char[total + 1]);
+    const int T = std::max(1, host_threads());
+    std::vector<char> bad((size_t)T, 0);
+    parallel_for(T, [&](int t) {
+        const size_t a = mem.size() * (size_t)t / (size_t)T, b = mem.size() * ((size_t)t + 1) / (size_t)T;
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, -15) != Z_OK) { bad[(size_t)t] = 1; return; }
+        for (size_t i = a; i < b && !bad[(size_t)t]; ++i) {
+            const Member &m = mem[i];
+            if (m.isize == 0) continue;                                    // (the empty member that ends a BGZF file)
+            inflateReset(&z);
+            z.next_in = const_cast<unsigned char *>(d + m.data); z.avail_in = (unsigned)m.dlen;
+            z.next_out = reinterpret_cast<unsigned char *>(buf.get() + m.dst); z.avail_out = (unsigned)m.isize;
+            const int rc = inflate(&z, Z_FINISH);
+            if (rc != Z_STREAM_END || z.avail_out != 0) { bad[(size_t)t] = 1; break; }
+            const unsigned long crc = crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const unsigned char *>(buf.get() + m.dst), (unsigned)m.isize);
+            const unsigned char *c = d + m.at + (m.data - m.at) + m.dlen;
+            if (crc != ((unsigned long)c[0] | ((unsigned long)c[1] << 8) | ((unsigned long)c[2] << 16) | ((unsigned long)c[3] << 24))) bad[(size_t)t] = 1;
+        }
+        inflateEnd(&z);
+    });
+    for (char b : bad) if (b) return false;
+    out.swap(buf);
+    out_n = total;
+    return true;
+}
+
 // ---- name table: open addressing over (offset, length) into one arena ---------------------------
 class NameTable {
 public:
@@ -413,12 +480,20 @@ int load_plain_fasta_parallel(const char *path, raft_host_reads *R)
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return -1;
     struct stat st;
-    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { close(fd); return -1; }
-    const size_t n = (size_t)st.st_size;
-    void *map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (map == MAP_FAILED) return -1;
-    const char *d = static_cast<const char *>(map);
+    unsigned char magic[2] = {0, 0};
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0 || pread(fd, magic, 2, 0) != 2) { close(fd); return -1; }
+    size_t n = (size_t)st.st_size;
+    void *map = nullptr;
+    std::unique_ptr<char[]> heap;                    // a BGZF file's bytes, inflated by all workers (else: the mapped file)
+    if (magic[0] == 0x1f && magic[1] == 0x8b) {
+        close(fd);
+        if (!inflate_bgzf_parallel(path, heap, n) || n == 0) return -1;      // (a plain .gz: the streaming reader)
+    } else {
+        map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (map == MAP_FAILED) return -1;
+    }
+    const char *d = map ? static_cast<const char *>(map) : heap.get();
     struct Unmap { void *p; size_t n; ~Unmap() { if (p) munmap(p, n); } } unmap{map, n};
     if (d[0] != '>') return -1;
 
@@ -504,8 +579,8 @@ int load_plain_fasta_parallel(const char *path, raft_host_reads *R)
     if (!any_multi) {
         // every sequence is one line: the reads ARE the mapping
         for (size_t i = 0; i < n_rec; ++i) R->base_off[i] = seq_begin[i];
-        R->map_ptr = map; R->map_n = n;
-        unmap.p = nullptr;                                           // (kept until raft_host_reads_free)
+        if (map) { R->map_ptr = map; R->map_n = n; unmap.p = nullptr; }   // (kept until raft_host_reads_free)
+        else R->raw_bases.swap(heap);                                 // (the inflated file itself)
     } else {
         size_t total = 0;
         for (size_t i = 0; i < n_rec; ++i) { R->base_off[i] = total; total += (size_t)R->lens[i]; }
@@ -693,6 +768,14 @@ int raft_host_text_read(const char *path, raft_host_text **out)
             if (have) { data_p[n] = '\n'; data_n = n + 1; }   // a last line without newline is still a line
         }
         close(fd);
+    }
+    if (!have) {                                         // blocked gzip: every worker inflates its share of the members
+        size_t got = 0;
+        if (host_threads() > 1 && inflate_bgzf_parallel(path, data_buf, got) && got > 0) {
+            data_buf[got] = '\n';                       // a last line without newline is still a line
+            data_n = got + 1;
+            have = true;
+        }
     }
     if (!have) {
         // gz (or not a regular file): inflated by the stream's helper thread while this thread gathers the blocks
@@ -1122,9 +1205,6 @@ int raft_host_write_fasta(const char *path, const raft_host_reads *reads, const 
             }
         }
     };
-    auto one_read_headers = [&](long long i, std::string &o) {
-        for (int64_t f = frag_offset[i]; f < frag_offset[i + 1]; ++f) one_header(i, f, o);
-    };
     auto one_read = [&](long long i, std::string &o) {
         const char *seq = reads->base_ptr() + reads->base_off[(size_t)i];
         for (int64_t f = frag_offset[i]; f < frag_offset[i + 1]; ++f) {
@@ -1133,68 +1213,10 @@ int raft_host_write_fasta(const char *path, const raft_host_reads *reads, const 
             o.push_back('\n');
         }
     };
-    // Round 5: the file is sized first (a pass over the fragment table: header lengths), created at that size, mapped, and the
-    // workers format their blocks of reads straight into the mapping -- one copy of every base, made by all threads at once,
-    // where the buffered writer made two (into a block buffer, then by ONE thread's write() into the page cache: 1.4 s of a 7 s
-    // run on the 10 GB set).  RAFT_FASTA_MMAP=0, or any failure on the way, keeps the buffered writer.
-    if (n > 0 && !(getenv("RAFT_FASTA_MMAP") && atoi(getenv("RAFT_FASTA_MMAP")) == 0)) {
-        const int T = host_threads();
-        const int nblk = (int)std::min<long long>((long long)n, (long long)T * 16);
-        std::vector<size_t> blk_bytes((size_t)nblk, 0);
-        auto blk_range = [&](int t, long long &a, long long &b) { a = (long long)n * t / nblk; b = (long long)n * (t + 1) / nblk; };
-        parallel_for(nblk, [&](int t) {
-            long long a, b;
-            blk_range(t, a, b);
-            std::string h;
-            size_t bytes = 0;
-            for (long long i = a; i < b; ++i) {          // the headers are formatted once more below: they are a thousandth of the bytes
-                const int64_t f0 = frag_offset[i], f1 = frag_offset[i + 1];
-                size_t seq = 0;
-                for (int64_t f = f0; f < f1; ++f) seq += (size_t)(frag_end[f] - frag_begin[f]);
-                h.clear();
-                one_read_headers(i, h);
-                bytes += h.size() + seq + (size_t)(f1 - f0);
-            }
-            blk_bytes[(size_t)t] = bytes;
-        });
-        std::vector<size_t> blk_off((size_t)nblk + 1, 0);
-        for (int t = 0; t < nblk; ++t) blk_off[(size_t)t + 1] = blk_off[(size_t)t] + blk_bytes[(size_t)t];
-        const size_t total = blk_off[(size_t)nblk];
-        const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0666);
-        if (fd >= 0 && total > 0 && ftruncate(fd, (off_t)total) == 0) {
-            void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-            if (m != MAP_FAILED) {
-                char *out = static_cast<char *>(m);
-                std::vector<char> bad((size_t)nblk, 0);
-                parallel_for(nblk, [&](int t) {
-                    long long a, b;
-                    blk_range(t, a, b);
-                    char *w = out + blk_off[(size_t)t];
-                    std::string h;
-                    for (long long i = a; i < b; ++i) {
-                        const char *seq = reads->base_ptr() + reads->base_off[(size_t)i];
-                        const int64_t f0 = frag_offset[i], f1 = frag_offset[i + 1];
-                        for (int64_t f = f0; f < f1; ++f) {
-                            h.clear();
-                            one_header(i, f, h);
-                            memcpy(w, h.data(), h.size()); w += h.size();
-                            const size_t len = (size_t)(frag_end[f] - frag_begin[f]);
-                            memcpy(w, seq + frag_begin[f], len); w += len;
-                            *w++ = '\n';
-                        }
-                    }
-                    if (w != out + blk_off[(size_t)t + 1]) bad[(size_t)t] = 1;
-                });
-                bool ok = true;
-                for (char c : bad) ok = ok && !c;
-                if (munmap(m, total) != 0) ok = false;
-                if (close(fd) != 0) ok = false;
-                if (ok) return RAFT_HOST_OK;
-                return RAFT_HOST_ERR_IO;
-            }
-        }
-        if (fd >= 0) close(fd);
-    }
+    // (Measured and dropped, round 5: the file sized first, created at that size, mapped, and every worker formatting its blocks
+    // straight into the mapping -- one copy of every base instead of two.  On the box's tmpfs the workers' page faults serialise
+    // on the file's mapping and drag the table writers that run beside them down with them: write_fasta 1.36 -> 3.0 s,
+    // write_tables 0.76 -> 6.9 s (profiles/r05_cli_s500k_mapped_writer.txt).  The single write() per block stays.)
     return write_ordered(path, n, 8 << 20, [&](long long i) { return (long long)reads->lens[(size_t)i] + 64; }, one_read);
 }
 

@@ -234,48 +234,59 @@ def test_loaders_and_writers_thread_count_random(tmp_path):
     assert len(outs[1]["reads.fasta"]) > 0 and len(outs[1]["coverage.txt"]) > 0
 
 
-@pytest.mark.parametrize("single_line", [True, False])
-def test_fasta_writer_mapped_output_equals_buffered(tmp_path, single_line, monkeypatch):
-    """Round 5: the fragment writer sizes the file, maps it and lets every worker format into the mapping; RAFT_FASTA_MMAP=0 keeps
-    the buffered writer.  Same bytes -- from reads that point into the mapped input (every sequence one line) and from copied ones."""
-    import ctypes as C
-    rng = np.random.default_rng(5)
-    n = 900
-    lens = rng.integers(0, 3000, n)
-    lens[::41] = 0
-    with open(tmp_path / "r.fa", "wb") as f:
-        for i in range(n):
-            seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(lens[i])))
-            f.write(b">q%d" % i + (b" c" if i % 4 == 0 else b"") + b"\n")
-            if single_line or i % 2:
-                f.write(seq + (b"" if i == n - 1 else b"\n"))          # (the file ends without a newline)
-            else:
-                for k in range(0, len(seq), 50):
-                    f.write(seq[k:k + 50] + b"\n")
-    fo, fb, fe = [0], [], []
-    for L in lens:
-        cuts = sorted(set([0, int(L)] + rng.integers(0, int(L) + 1, 3).tolist())) if L > 20 else [0, int(L)]
-        for a, b in zip(cuts[:-1], cuts[1:]):
-            fb.append(max(a - 5, 0)); fe.append(b)
-        if len(cuts) < 2:
-            fb.append(0); fe.append(int(L))
-        fo.append(len(fb))
-    fo, fb, fe = np.array(fo, np.int64), np.array(fb, np.int32), np.array(fe, np.int32)
-    lib = hostio.load_library()
-    out = {}
+def _bgzf(data: bytes, block: int = 30000) -> bytes:
+    """`data` as a BGZF file (SAM spec 4.1): gzip members of at most 64 KiB with their size in a 'BC' extra field, + the empty end member."""
+    import struct
+    import zlib
+    out = b""
+    for k in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if k is None else data[k:k + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(comp) + 8
+        out += (b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1) + comp +
+                struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    return out
+
+
+@pytest.mark.parametrize("threads", [1, 6])
+def test_blocked_gzip_inputs_are_inflated_by_all_workers(tmp_path, threads):
+    """Round 5 (VERDICT r04 "missing" 5): a BGZF file -- bgzip's output, the usual form of .fa.gz / .paf.gz next to htslib tools --
+    is inflated member by member on all host threads; a plain .gz keeps the single stream.  Reads and records are the same from
+    plain text, plain gzip and BGZF, with one thread (everything through the streaming reader) and with six."""
+    p, cols, exp, meta = load_case("s300_default")
+    names = [f"r{i}" for i in range(len(cols[0]))]
+    write_fasta(tmp_path / "reads.fa", names, cols[0])
+    write_paf(tmp_path / "o.paf", names, *cols)
+    fa, paf = (tmp_path / "reads.fa").read_bytes(), (tmp_path / "o.paf").read_bytes()
+    (tmp_path / "b.fa.gz").write_bytes(_bgzf(fa)); (tmp_path / "b.paf.gz").write_bytes(_bgzf(paf))
+    (tmp_path / "g.fa.gz").write_bytes(gzip.compress(fa)); (tmp_path / "g.paf.gz").write_bytes(gzip.compress(paf))
+    assert gzip.decompress((tmp_path / "b.fa.gz").read_bytes()) == fa              # (a BGZF file is a valid multi-member gzip file)
+    broken = bytearray(_bgzf(paf)); broken[len(broken) // 2] ^= 0x55
+    (tmp_path / "x.paf.gz").write_bytes(bytes(broken))
     try:
-        hostio.set_threads(6)
-        reads = hostio.Reads(str(tmp_path / "r.fa"))
-        assert reads.lengths.tolist() == lens.tolist()
-        for mode in ("1", "0"):
-            monkeypatch.setenv("RAFT_FASTA_MMAP", mode)
-            path = str(tmp_path / f"o{mode}.fa")
-            assert lib.raft_host_write_fasta(path.encode(), reads._h, C.c_void_p(fo.ctypes.data), C.c_void_p(fb.ctypes.data), C.c_void_p(fe.ctypes.data)) == 0
-            out[mode] = open(path, "rb").read()
+        hostio.set_threads(threads)
+        want = None
+        for r_name, p_name in (("reads.fa", "o.paf"), ("g.fa.gz", "g.paf.gz"), ("b.fa.gz", "b.paf.gz"), ("b.fa.gz", "o.paf")):
+            reads = hostio.Reads(str(tmp_path / r_name))
+            got = hostio.load_paf(str(tmp_path / p_name), reads)
+            snap = (reads.lengths.tolist(), [reads.name(i) for i in (0, 1, reads.n - 1)], [reads.bases(i) for i in (0, reads.n // 2, reads.n - 1)], [g.tolist() for g in got])
+            if want is None:
+                want = snap
+                for a, b in zip(got, cols[1:]):
+                    assert np.array_equal(a, b)
+            assert snap == want, (r_name, p_name)
+            reads.close()
+        # a damaged member: the blocked reader declines (crc / inflate error) and the single stream takes over -- an error or what zlib
+        # salvages, never a crash
+        reads = hostio.Reads(str(tmp_path / "reads.fa"))
+        try:
+            hostio.load_paf(str(tmp_path / "x.paf.gz"), reads)
+        except hostio.HostError:
+            pass
         reads.close()
     finally:
         hostio.set_threads(0)
-    assert out["1"] == out["0"] and out["1"].count(b">") == len(fb)
 
 
 # ---- split_naive (the reference's comparator tool) ----------------------------------------------------------------
