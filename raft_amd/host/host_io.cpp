@@ -35,9 +35,11 @@
 
 namespace {
 
-// Worker threads of the host layer: RAFT_HOST_THREADS (default: hardware threads, at most kMaxThreads = 128).  1 = everything
+// Worker threads of the host layer: RAFT_HOST_THREADS (at most kMaxThreads = 128); default: the hardware threads, at most 16 --
+// the loaders and writers are bound by memory and by the page cache, not by arithmetic, and on the 256-thread MI355X box the
+// 10 GB set ran 3.7 s with 16 workers against 4.1 / 4.7 / 4.4 s with 32 / 64 / 128 (profiles/r05_cli_thread_sweep.txt).  1 = everything
 // inline on the calling thread (the reference's own behaviour; used by tests to cross-check the parallel paths).
-constexpr int kMaxThreads = 128;
+constexpr int kMaxThreads = 128, kDefaultThreads = 16;
 std::atomic<int> g_threads{0};   // 0 = not chosen yet
 
 int host_threads()
@@ -45,7 +47,7 @@ int host_threads()
     int n = g_threads.load(std::memory_order_relaxed);
     if (n > 0) return n;
     const char *e = getenv("RAFT_HOST_THREADS");
-    int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    int v = e ? atoi(e) : std::min((int)std::thread::hardware_concurrency(), kDefaultThreads);
     n = std::min(std::max(v, 1), kMaxThreads);
     g_threads.store(n, std::memory_order_relaxed);
     return n;
@@ -948,6 +950,9 @@ int raft_host_paf_parse(raft_host_text *text, const raft_host_reads *reads, raft
             if (!chunks[(size_t)t].col[k].empty())
                 memcpy(P->col[k].get() + off[(size_t)t], chunks[(size_t)t].col[k].data(), chunks[(size_t)t].col[k].size() * sizeof(int32_t));
     });
+    // (the workers' columns -- a GB of touched pages at human scale -- go back to the system on a thread of their own: unmapping
+    // them took as long as tokenising them)
+    if (P->n > (1u << 22)) std::thread([c = std::move(chunks)]() mutable { c.clear(); }).detach();
     *out = P;
     return RAFT_HOST_OK;
 }

@@ -243,7 +243,7 @@ int main(int argc, char *argv[])
     stage("paf_read (rest)");
     rc = paf_text_rc;
     if (rc == RAFT_HOST_OK) rc = raft_host_paf_parse(paf_text, reads, &paf, bad, sizeof bad);
-    raft_host_text_free(paf_text);
+    if (paf_text) std::thread([paf_text] { raft_host_text_free(paf_text); }).detach();   // (GBs of touched pages: unmapped beside the pass)
     if (rc == RAFT_HOST_ERR_UNKNOWN_NAME) die(std::string("ERROR, create_pileup(), read ") + bad + " of the overlaps file is not in the reads file");
     if (rc != RAFT_HOST_OK) die(std::string("ERROR, create_pileup(), cannot read ") + paf_fn);
     const int64_t n_rec = raft_host_paf_count(paf);
