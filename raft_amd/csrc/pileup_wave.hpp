@@ -373,26 +373,6 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         if constexpr (IN == 0) {
             auto win = [&](unsigned n) -> int { return (int)(((n & win_m1) | __umulhi(n, a.div_magic)) >> win_sh); };
             // (`mine`: the slot's lane holds a record of this tile -- the lanes behind the tile's count hold the next tile's)
-            // (the read's first slot and window count: two LDS reads.  `look` issues them, `pile` uses them -- the slot loop below
-            // looks one slot AHEAD, so that a slot's reads are in flight while the slot before is piled up and are not queued
-            // behind its two ds_add in the in-order LDS counter: the compiler may not move a read above an atomic of the same
-            // LDS block by itself)
-            auto look = [&](int rid, int &b0, int &b1) {            // (two raw values: nothing here depends on what comes back)
-                const unsigned j = min((unsigned)(rid - r_a), (unsigned)nr);
-                b0 = sm.roff[j]; b1 = sm.roff[(j + 1u) & 63u];
-            };
-            auto pile = [&](int rid, int st, int en, bool mine, int b0, int b1) {
-                const unsigned jr = (unsigned)(rid - r_a);
-                const int nb_r = b1 - b0;
-                const int first = win((unsigned)st);
-                const int last1 = win((unsigned)(en - 1)) + 1;
-                const bool valid = mine && jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
-                const bool over = last1 > first && last1 > nb_r;
-                const int pf = max(b0 + first, off0), pl1 = min(b0 + min(last1, nb_r), t_end);
-                bad_any |= valid && (!sign_ok || (pos && over));
-                bad_order |= mine && !valid;
-                if (valid && sign_ok && pos && pf < pl1) add_pm(pf, pl1);
-            };
             auto one = [&](int rid, int st, int en, bool mine) {
                 const unsigned jr = (unsigned)(rid - r_a);
                 const unsigned j = min(jr, (unsigned)nr);
@@ -406,16 +386,10 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 bad_order |= mine && !valid;
                 if (valid && sign_ok && pos && pf < pl1) add_pm(pf, pl1);
             };
-            {
-                int b0c = 0, nbc = 0, b0n = 0, nbn = 0;
-                if (cur.cnt[0] > 0) look(g.rid[0], b0c, nbc);
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int left = cur.cnt[u % NSEG] - (u / NSEG) * 64;
-                    if (u + 1 < U && cur.cnt[(u + 1) % NSEG] - ((u + 1) / NSEG) * 64 > 0) look(g.rid[u + 1 < U ? u + 1 : u], b0n, nbn);
-                    if (left > 0) pile(g.rid[u], g.st[u], g.en[u], lane < left, b0c, nbc);
-                    b0c = b0n; nbc = nbn;
-                }
+            for (int u = 0; u < U; ++u) {
+                const int left = cur.cnt[u % NSEG] - (u / NSEG) * 64;
+                if (left > 0) one(g.rid[u], g.st[u], g.en[u], lane < left);
             }
             if (cur.more) {
                 // records behind the slots: streamed until an id at or beyond the tile's last read (or the range's end) says stop,

@@ -3,7 +3,7 @@
 # ones to be judged into profiles/).  usage: tools/evidence_round.sh <tag>
 TAG=${1:-r04_z}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/$TAG
-B="--no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg"
+B="--no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg --no-placement-ab"
 # 0. which box: partition modes, memory vendor, clocks (the kernel's time differs by box and by session: DESIGN.md I.4)
 rocm-smi --showmemorypartition --showcomputepartition --showperflevel --showmaxpower --showmemvendor --showvbios --showclocks 2>&1 | grep -v "^=\|^$" > gpurun_out/$TAG/box.txt
 # 1. the headline line (default bench), rocprofv3 kernel stats of the same command, PMC traffic (FETCH_SIZE / WRITE_SIZE in passes of their own)

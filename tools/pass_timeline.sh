@@ -4,7 +4,7 @@
 TAG=${1:-r03_tl}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$TAG/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg "$@" > gpurun_out/$TAG/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$TAG/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg --no-placement-ab "$@" > gpurun_out/$TAG/bench.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("gpurun_out/$TAG/trace/**/*kernel_trace.csv", recursive=True)[0]

@@ -5,9 +5,9 @@ TAG=${1:-r03_a}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 python bench.py "$@" > gpurun_out/$TAG/bench.log 2>&1; echo "bench rc=$?"; grep '^{' gpurun_out/$TAG/bench.log > gpurun_out/$TAG/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg "$@" > gpurun_out/$TAG/stats.log 2>&1; echo "stats rc=$?"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$TAG/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg "$@" > gpurun_out/$TAG/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/$TAG/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg "$@" > gpurun_out/$TAG/pmc_write.log 2>&1; echo "pmc write rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg --no-placement-ab "$@" > gpurun_out/$TAG/stats.log 2>&1; echo "stats rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$TAG/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg --no-placement-ab "$@" > gpurun_out/$TAG/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/$TAG/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-six-column-leg --no-packed-leg --no-placement-ab "$@" > gpurun_out/$TAG/pmc_write.log 2>&1; echo "pmc write rc=$?"
 python3 - <<PY
 import csv, glob, json, collections
 tag = "$TAG"
