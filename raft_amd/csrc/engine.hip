@@ -3284,7 +3284,6 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
     RcclApi *r = rccl_api();
     if (!c || !comm_v || !bounds || !mine || !out || world < 1 || rank < 0 || rank >= world) return RAFT_HIP_ERR_PARAM;
     if (!r) { c->last_error = "librccl.so.1 could not be loaded"; return RAFT_HIP_ERR_DEVICE; }
-    if (!slice_ok(*mine, n_reads_total) || bounds[0] != 0 || bounds[world] != n_reads_total) return RAFT_HIP_ERR_PARAM;
     ncclComm_t comm = reinterpret_cast<ncclComm_t>(comm_v);
     const long long N1 = (long long)n_reads_total + 1;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -3301,7 +3300,8 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
     constexpr long long kBadRow = -2;
     const size_t row = (size_t)world * kMaxSeg;
     std::vector<long long> cnt(row * (size_t)world, 0);
-    bool mine_ok = true;
+    // (a slice or bounds that are wrong as a whole -- ADVICE r04: these used to return before the all-gather the peers were in)
+    bool mine_ok = slice_ok(*mine, n_reads_total) && bounds[0] == 0 && bounds[world] == n_reads_total;
     for (int g = 0; g < world && mine_ok; ++g) {
         if (bounds[g] < 0 || bounds[g] > bounds[g + 1] || bounds[g + 1] > n_reads_total) { mine_ok = false; break; }
         for (int j = 0; j < kMaxSeg; ++j) {
@@ -3320,7 +3320,7 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
     NCCL_TRY(r->AllGather(c->x_cnt.as<long long>() + (size_t)rank * row, c->x_cnt.p, row, ncclInt64, comm, st));
     HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->x_cnt.p, cnt.size() * 8, hipMemcpyDeviceToHost, st));
     // (meanwhile: this rank's offsets go to the device, from where their slices are sent)
-    HIP_TRY(c, c->x_send_off.ensure((size_t)mine->n_runs * (size_t)N1 * 8));
+    HIP_TRY(c, c->x_send_off.ensure((size_t)(mine_ok ? mine->n_runs : 1) * (size_t)N1 * 8));
     if (mine_ok) HIP_TRY(c, hipMemcpyAsync(c->x_send_off.p, mine->rec_offset, (size_t)mine->n_runs * (size_t)N1 * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     // ---- the same verdict on every rank: a rank with invalid arguments; more runs arriving at SOME rank than a pass takes

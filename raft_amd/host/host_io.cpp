@@ -451,6 +451,7 @@ struct raft_host_text {                  // a file's bytes in memory (inflated i
 };
 
 struct raft_host_paf {
+    std::vector<std::vector<int32_t>> scratch;   // the tokeniser's per-worker columns, kept so that nobody pays for unmapping them in between
     std::unique_ptr<int32_t[]> col[6];   // allocated untouched: the workers' copies are the first writes
     size_t n = 0;
     int symmetric = 0;                   // chop.hpp:175-184: some record after the first mirrors the first
@@ -964,9 +965,12 @@ int raft_host_paf_parse(raft_host_text *text, const raft_host_reads *reads, raft
             if (!chunks[(size_t)t].col[k].empty())
                 memcpy(P->col[k].get() + off[(size_t)t], chunks[(size_t)t].col[k].data(), chunks[(size_t)t].col[k].size() * sizeof(int32_t));
     });
-    // (the workers' columns -- a GB of touched pages at human scale -- go back to the system on a thread of their own: unmapping
-    // them took as long as tokenising them)
-    if (P->n > (1u << 22)) std::thread([c = std::move(chunks)]() mutable { c.clear(); }).detach();
+    // (the workers' columns -- a GB of touched pages at human scale -- stay with the object until raft_host_paf_free: unmapping them
+    // here took as long as tokenising them, and unmapping them on a thread of their own held the address space's lock against the
+    // page-locking and the engine's pipeline that run next: 0.4 s either way on the 10 GB set.  The CLI never frees: it exits)
+    if (P->n > (1u << 22))
+        for (Chunk &C : chunks)
+            for (auto &v : C.col) if (v.capacity()) P->scratch.push_back(std::move(v));
     *out = P;
     return RAFT_HOST_OK;
 }

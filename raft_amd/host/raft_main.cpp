@@ -243,7 +243,8 @@ int main(int argc, char *argv[])
     stage("paf_read (rest)");
     rc = paf_text_rc;
     if (rc == RAFT_HOST_OK) rc = raft_host_paf_parse(paf_text, reads, &paf, bad, sizeof bad);
-    if (paf_text) std::thread([paf_text] { raft_host_text_free(paf_text); }).detach();   // (GBs of touched pages: unmapped beside the pass)
+    if (raft_host_paf_count(paf) < (1 << 22)) raft_host_text_free(paf_text);   // (a big file's GBs of touched pages are left to the process exit: unmapping them here -- or beside
+                                                                                   // the pass, where it holds the address space's lock against the page-locking -- cost 0.3 s of a 4 s run)
     if (rc == RAFT_HOST_ERR_UNKNOWN_NAME) die(std::string("ERROR, create_pileup(), read ") + bad + " of the overlaps file is not in the reads file");
     if (rc != RAFT_HOST_OK) die(std::string("ERROR, create_pileup(), cannot read ") + paf_fn);
     const int64_t n_rec = raft_host_paf_count(paf);
