@@ -374,14 +374,15 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(long long n_rec, in
 // line somewhere in 3.5 GB).  For large inputs the intervals are sorted instead: expand_sides_kernel writes (read id,
 // start | end << 32) per side -- query sides, and target sides of records whose two reads differ while the PAF is not
 // symmetric (chop.hpp:165-169); sides that do not exist get the key n_reads and sort behind everything -- a radix sort by
-// the id's bits (engine.hip: rocprim's device radix sort, the library primitive for exactly this), and unzip_sorted_kernel
+// the id's bits (sort_pairs.hpp radix_sort_by_key: hand-written since round 5 -- LDS-staged digits of eight bits, every store part
+// of a run, tiles dealt to the XCDs in contiguous eighths; round 4 called rocprim's device radix sort here), and unzip_sorted_kernel
 // writes the three columns the pileup kernels read plus where every read's intervals begin.
 // (Measured and dropped, round 5: two partition steps instead of a sort -- every side to a coarse bucket of 2048 reads (LDS ranks,
 // one global atomic per bucket and 128 k-record tile), then one workgroup per bucket with an LDS counter per read.  Bit-exact, no
 // library, 48 B of traffic per side -- and 25 ms where the sort takes 9.6: a wave's 64 lanes store to 64 different lines, and this
 // part retires such a store at ~34 ps per LANE whether the lines sit in L2 or not (coarse step 14.8 ms, fine step 9.8 ms for
 // 2.9e8 sides; profiles/r05_partition_kernel_stats.txt).  Stores have to leave in runs, which takes LDS-staged digits of 8 bits:
-// the three passes the library sort already makes.)
+// the three passes of sort_pairs.hpp.)
 __global__ __launch_bounds__(256) void expand_sides_kernel(long long n_rec, int32_t n_reads, int symmetric, const int32_t *qid, const int32_t *qs, const int32_t *qe,
                                                            const int32_t *tid, const int32_t *ts, const int32_t *te, uint32_t *key, unsigned long long *val,
                                                            int32_t *err_flags, long long *err_index)

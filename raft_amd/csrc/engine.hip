@@ -3,7 +3,6 @@
 // buffers; one pass = the kernels listed in DESIGN.md §Kernels, in order.
 #include "../../include/raft_hip.h"
 
-#include <rocprim/device/device_radix_sort.hpp>   // (the general bucketing path's sort by read id: bucket.hpp says why it stays a library sort)
 #include "bucket.hpp"
 #include "sort_pairs.hpp"
 #include "device_scan.hpp"
@@ -739,14 +738,17 @@ static int sort_sides(raft_hip_ctx *c, hipStream_t st, long long n_rec, int32_t 
                        c->rs_k0.as<uint32_t>(), c->rs_v0.as<unsigned long long>(), err_flags, err_index);
     int bits = 1;
     while (bits < 32 && (1LL << bits) <= (long long)n_reads) ++bits;               // keys 0 .. n_reads (the sides that do not exist)
-    size_t tmp = 0;
-    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
-                                         c->rs_v1.as<unsigned long long>(), (size_t)cap_iv, 0u, (unsigned)bits, st));
-    HIP_TRY(c, c->sort_tmp.ensure(tmp));
-    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, c->rs_k0.as<uint32_t>(), c->rs_k1.as<uint32_t>(), c->rs_v0.as<unsigned long long>(),
-                                         c->rs_v1.as<unsigned long long>(), (size_t)cap_iv, 0u, (unsigned)bits, st));
+    uint32_t *k_sorted = c->rs_k1.as<uint32_t>();
+    unsigned long long *v_sorted = c->rs_v1.as<unsigned long long>();
+    {   // sort_pairs.hpp: LSD radix sort, eight bits per pass, every store part of a run (hand-written since round 5: no library call on this path)
+        HIP_TRY(c, c->sort_tmp.ensure(rs_tmp_bytes<unsigned long long>(cap_iv)));
+        bool in_b = false;
+        HIP_TRY(c, radix_sort_by_key<unsigned long long>(st, c->rs_k0.as<uint32_t>(), c->rs_v0.as<unsigned long long>(), c->rs_k1.as<uint32_t>(),
+                                                         c->rs_v1.as<unsigned long long>(), cap_iv, bits, c->sort_tmp.p, &in_b));
+        if (!in_b) { k_sorted = c->rs_k0.as<uint32_t>(); v_sorted = c->rs_v0.as<unsigned long long>(); }
+    }
     const unsigned g2 = (unsigned)std::max<long long>(1, std::min<long long>((cap_iv + 255) / 256, 256 * 32));
-    hipLaunchKernelGGL(unzip_sorted_kernel, dim3(g2), dim3(256), 0, st, cap_iv, n_reads, c->rs_k1.as<uint32_t>(), c->rs_v1.as<unsigned long long>(),
+    hipLaunchKernelGGL(unzip_sorted_kernel, dim3(g2), dim3(256), 0, st, cap_iv, n_reads, k_sorted, v_sorted,
                        o_rid, o_s, o_e, off, c->gaps.as<GapList>());
     hipLaunchKernelGGL(fill_gaps_kernel, dim3(64), dim3(256), 0, st, c->gaps.as<GapList>(), off);
     HIP_TRY(c, hipGetLastError());

@@ -98,4 +98,184 @@ inline hipError_t sort_pairs(hipStream_t st, unsigned long long *key_a, int32_t 
 }
 inline size_t sort_pairs_hist_bytes(long long n) { return (size_t)256 * (size_t)((n + kSortTile - 1) / kSortTile + 1) * 4; }
 
+// ---- the big one: sides of a record stream by read id (bucket.hpp: general bucketing; round 5, replaces rocprim::radix_sort_pairs) -------
+// LSD radix sort of (32-bit key, 32- or 64-bit value) pairs, 8 bits per pass, every global store part of a RUN: a workgroup takes a
+// tile, ranks its pairs by digit (stable: waves own consecutive quarters of the tile, a wave walks its quarter 64 pairs at a time
+// and finds the lanes with its digit by eight ballots), places them in LDS in digit order and writes the tile out from there --
+// consecutive lanes, consecutive addresses, ~32 pairs per digit and tile.  (What bucket.hpp's dropped two-step partition did not do:
+// a wave's 64 lanes storing to 64 different lines retire at ~34 ps per lane on this part.)
+//   rs_hist                          digit counts of every tile -> hist[tile][digit]                  (4 B read per pair)
+//   rs_segsum / segscan / tilescan   the table's exclusive scan, digit-major: where every (tile, digit) goes (coalesced, < 1 % of the bytes)
+//   rs_scatter                       rank, stage in LDS, write runs                                     (8-12 B read, 8-12 B written per pair)
+#ifndef RAFT_RS_WAVES
+#define RAFT_RS_WAVES 4            // waves per workgroup of the sort's tile kernels
+#endif
+constexpr int kRsWaves = RAFT_RS_WAVES, kRsThreads = 64 * kRsWaves;
+// Workgroups go to the eight XCDs round-robin; tile = (b % 8) * ceil(n / 8) + b / 8 hands every XCD a CONTIGUOUS eighth of the tiles, so
+// that the runs two neighbouring tiles write for one digit -- which are neighbours in memory -- meet in one L2 and leave it as whole lines.
+__device__ __forceinline__ int rs_tile_of_block(int b, int n_tiles) { const int per = (n_tiles + 7) >> 3; return (b & 7) * per + (b >> 3); }
+inline unsigned rs_grid(int n_tiles) { return (unsigned)(((n_tiles + 7) >> 3) * 8); }
+template <int IPT> struct RsGeom { static constexpr int kTile = kRsThreads * IPT, kQuarter = 64 * IPT; };
+
+template <int IPT>
+__global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t *__restrict__ key, long long n, int shift, int n_tiles, int32_t *__restrict__ hist)
+{
+    __shared__ int32_t h[256];
+    const int tile = rs_tile_of_block((int)blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const long long t0 = (long long)tile * RsGeom<IPT>::kTile;
+#pragma unroll 8
+    for (int b = 0; b < IPT; ++b) {
+        const long long i = t0 + (long long)b * kRsThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[(key[i] >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) hist[(long long)tile * 256 + threadIdx.x] = h[threadIdx.x];      // [tile][digit]: every access below is 256 consecutive words
+}
+
+// The table's exclusive scan in digit-major order (all tiles' digit 0, then all tiles' digit 1, ...) in three coalesced steps over
+// kRsSegs segments of consecutive tiles; thread d owns digit d everywhere.
+constexpr int kRsSegs = 256;
+__global__ __launch_bounds__(256) void rs_segsum_kernel(int n_tiles, const int32_t *__restrict__ hist, int32_t *__restrict__ segtot)
+{
+    const int L = (n_tiles + kRsSegs - 1) / kRsSegs;
+    const int t0 = blockIdx.x * L, t1 = min(t0 + L, n_tiles);
+    int s = 0;
+#pragma unroll 8
+    for (int t = t0; t < t1; ++t) s += hist[(long long)t * 256 + threadIdx.x];
+    segtot[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void rs_segscan_kernel(int32_t *__restrict__ segtot)      // in place: where every (segment, digit) begins
+{
+    __shared__ int32_t wsum[4];
+    int run = 0;
+    for (int s = 0; s < kRsSegs; ++s) { const int v = segtot[s * 256 + threadIdx.x]; segtot[s * 256 + threadIdx.x] = run; run += v; }
+    const int incl = wave_incl_scan_add(run);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = incl - run;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+    for (int s = 0; s < kRsSegs; ++s) segtot[s * 256 + threadIdx.x] += base;
+}
+__global__ __launch_bounds__(256) void rs_tilescan_kernel(int n_tiles, int32_t *__restrict__ hist, const int32_t *__restrict__ segbase)
+{
+    const int L = (n_tiles + kRsSegs - 1) / kRsSegs;
+    const int t0 = blockIdx.x * L, t1 = min(t0 + L, n_tiles);
+    int run = segbase[blockIdx.x * 256 + threadIdx.x];
+    for (int t = t0; t < t1; t += 8) {
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = t + k < t1 ? hist[(long long)(t + k) * 256 + threadIdx.x] : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (t + k < t1) { hist[(long long)(t + k) * 256 + threadIdx.x] = run; run += v[k]; }
+    }
+}
+
+template <class V, int IPT>
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint32_t *__restrict__ key_in, const V *__restrict__ val_in, long long n, int shift, int n_tiles,
+                                                         const int32_t *__restrict__ tile_off, uint32_t *__restrict__ key_out, V *__restrict__ val_out)
+{
+    constexpr int TILE = RsGeom<IPT>::kTile, QUARTER = RsGeom<IPT>::kQuarter;
+    __shared__ int32_t cnt[kRsWaves][256];     // per wave: pairs of its share with the digit; then: where its next pair with the digit goes (tile-local)
+    __shared__ int32_t goff[256];              // global place of the tile's first pair with the digit, minus its tile-local place
+    __shared__ int32_t wsum[4];
+    __shared__ uint32_t s_key[TILE];
+    __shared__ V s_val[TILE];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = rs_tile_of_block((int)blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;
+    const long long t0 = (long long)tile * TILE;
+    const int n_valid = (int)min((long long)TILE, n - t0);
+    for (int i = tid; i < kRsWaves * 256; i += kRsThreads) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    // 1. the keys of this thread's pairs (wave w: quarter w, 64 consecutive pairs per step) and the waves' digit counts
+    uint32_t k[IPT];
+    V v[IPT];                                  // (the values too: a load per step inside the ranking loop below is a latency per step)
+#pragma unroll
+    for (int b = 0; b < IPT; ++b) {
+        const int j = w * QUARTER + b * 64 + lane;
+        k[b] = j < n_valid ? key_in[t0 + j] : 0xffffffffu;
+        v[b] = j < n_valid ? val_in[t0 + j] : V(0);
+    }
+#pragma unroll
+    for (int b = 0; b < IPT; ++b)
+        if (w * QUARTER + b * 64 + lane < n_valid) atomicAdd(&cnt[w][(k[b] >> shift) & 255u], 1);
+    __syncthreads();
+    // 2. thread d: the tile's pairs with digit d begin at lstart (exclusive scan over the digits); wave w's at lstart + the waves before
+    {
+        int c[kRsWaves], tot = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int q = 0; q < kRsWaves; ++q) { c[q] = cnt[q][tid]; tot += c[q]; }
+        }
+        const int incl = wave_incl_scan_add(tot);                 // (threads 256 and up carry zeros: every wave takes part in the scan)
+        if (tid < 256 && lane == 63) wsum[w] = incl;
+        __syncthreads();
+        if (tid < 256) {
+            int lstart = incl - tot;
+            for (int q = 0; q < w; ++q) lstart += wsum[q];
+            int run = lstart;
+#pragma unroll
+            for (int q = 0; q < kRsWaves; ++q) { cnt[q][tid] = run; run += c[q]; }
+            goff[tid] = tile_off[(long long)tile * 256 + tid] - lstart;
+        }
+    }
+    __syncthreads();
+    // 3. every wave walks its quarter in order: lanes with the same digit find each other, the lowest draws the group's place
+#pragma unroll
+    for (int b = 0; b < IPT; ++b) {
+        const int j = w * QUARTER + b * 64 + lane;
+        const bool live = j < n_valid;
+        if (__ballot(live) == 0ull) break;
+        const int d = (int)((k[b] >> shift) & 255u);
+        unsigned long long peers = __ballot(live);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long m = __ballot((d >> bit) & 1);
+            peers &= ((d >> bit) & 1) ? m : ~m;
+        }
+        const int rank = (int)__popcll(peers & ((1ull << lane) - 1ull));
+        const int leader = (int)__builtin_ctzll(peers | (1ull << 63));
+        int first = 0;
+        if (live && lane == leader) { first = cnt[w][d]; cnt[w][d] = first + (int)__popcll(peers); }
+        first = __shfl(first, leader, kWave);
+        if (live) { s_key[first + rank] = k[b]; s_val[first + rank] = v[b]; }
+    }
+    __syncthreads();
+    // 4. the tile in digit order, written as runs
+    for (int j = tid; j < n_valid; j += kRsThreads) {
+        const uint32_t kk = s_key[j];
+        const int dst = goff[(kk >> shift) & 255u] + j;
+        key_out[dst] = kk; val_out[dst] = s_val[j];
+    }
+}
+
+// n pairs by the low `bits` bits of the key.  Buffers a and b ping-pong; *in_b says where the result is.  tmp: rs_tmp_bytes(n) bytes.
+template <class V> struct RsIpt { static constexpr int v = sizeof(V) == 8 ? 16 : 32; };      // 4096 pairs of 12 bytes / 8192 of 8: 48 / 64 KB of LDS per tile
+template <class V>
+inline size_t rs_tmp_bytes(long long n) { return ((size_t)256 * (size_t)((n + RsGeom<RsIpt<V>::v>::kTile - 1) / RsGeom<RsIpt<V>::v>::kTile + 1) + (size_t)256 * kRsSegs) * 4; }
+template <class V>
+inline hipError_t radix_sort_by_key(hipStream_t st, uint32_t *key_a, V *val_a, uint32_t *key_b, V *val_b, long long n, int bits, void *tmp, bool *in_b)
+{
+    constexpr int IPT = RsIpt<V>::v;
+    *in_b = false;
+    if (n < 2) return hipSuccess;
+    const int n_tiles = (int)((n + RsGeom<IPT>::kTile - 1) / RsGeom<IPT>::kTile);
+    int32_t *hist = static_cast<int32_t *>(tmp), *seg = hist + (size_t)256 * n_tiles;
+    uint32_t *ki = key_a, *ko = key_b;
+    V *vi = val_a, *vo = val_b;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL((rs_hist_kernel<IPT>), dim3(rs_grid(n_tiles)), dim3(kRsThreads), 0, st, ki, n, shift, n_tiles, hist);
+        hipLaunchKernelGGL(rs_segsum_kernel, dim3(kRsSegs), dim3(256), 0, st, n_tiles, hist, seg);
+        hipLaunchKernelGGL(rs_segscan_kernel, dim3(1), dim3(256), 0, st, seg);
+        hipLaunchKernelGGL(rs_tilescan_kernel, dim3(kRsSegs), dim3(256), 0, st, n_tiles, hist, seg);
+        hipLaunchKernelGGL((rs_scatter_kernel<V, IPT>), dim3(rs_grid(n_tiles)), dim3(kRsThreads), 0, st, ki, vi, n, shift, n_tiles, hist, ko, vo);
+        std::swap(ki, ko); std::swap(vi, vo);
+        *in_b = !*in_b;
+    }
+    return hipGetLastError();
+}
+
 } // namespace raft
