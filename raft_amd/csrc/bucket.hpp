@@ -449,4 +449,63 @@ __global__ __launch_bounds__(256) void fill_gaps_kernel(const GapList *__restric
     }
 }
 
+// ---- the same with WINDOW RECORDS (round 5): what profileCoverage uses of an interval is the windows it touches (repeat.hpp:69-72),
+// two 16-bit indices where reads stay below 65,535 windows.  A side is then ONE 64-bit item -- read id | first window << 32 | one past
+// the last << 48 -- 8 bytes through every pass of the sort instead of 12, and what comes out is the pileup kernel's leanest input
+// (pileup_wave.hpp IN = 1: a word per record, the reads' offsets).  A side whose windows do not fit 16 bits raises kErrWide and the
+// pass is run again with the coordinate pairs above; a negative coordinate is reported here (the record's index), an interval past
+// its read's last window by the pileup kernel (the index into the bucketed array), as on the coordinate route.
+constexpr int kErrWide = 1 << 10;
+__device__ __forceinline__ unsigned long long side_item(int rid, int s, int e, int reso, bool &neg, bool &wide)
+{
+    neg = neg || (s | e) < 0;
+    unsigned first = 0, last1 = 0;
+    if (e > 0 && (s | e) >= 0) { first = (unsigned)s / (unsigned)reso; last1 = (unsigned)(e - 1) / (unsigned)reso + 1u; }
+    wide = wide || first > 65535u || last1 > 65535u;
+    return (unsigned long long)(uint32_t)rid | ((unsigned long long)(first & 0xffffu) << 32) | ((unsigned long long)(last1 & 0xffffu) << 48);
+}
+__global__ __launch_bounds__(256) void expand_sides_win_kernel(long long n_rec, int32_t n_reads, int symmetric, int reso, const int32_t *qid, const int32_t *qs, const int32_t *qe,
+                                                               const int32_t *tid, const int32_t *ts, const int32_t *te, unsigned long long *item,
+                                                               int32_t *err_flags, long long *err_index)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (long long)gridDim.x * blockDim.x) {
+        const int q = qid[i];
+        const bool okq = q >= 0 && q < n_reads;
+        bool bad = !okq, neg = false, wide = false;
+        const unsigned long long xq = side_item(okq ? q : n_reads, qs[i], qe[i], reso, neg, wide);
+        item[i] = okq ? xq : (unsigned long long)(uint32_t)n_reads;
+        if (!okq) { neg = false; wide = false; }
+        if (!symmetric) {
+            const int t = tid[i];
+            const bool okt = t >= 0 && t < n_reads;
+            bad = bad || !okt;
+            const bool use = okt && t != q;
+            bool n2 = false, w2 = false;
+            const unsigned long long xt = side_item(use ? t : n_reads, ts[i], te[i], reso, n2, w2);
+            item[n_rec + i] = use ? xt : (unsigned long long)(uint32_t)n_reads;
+            if (use) { neg = neg || n2; wide = wide || w2; }
+        }
+        if (bad) {
+            atomicOr(err_flags, kErrReadId);
+            atomicMin((unsigned long long *)err_index, (unsigned long long)i);
+        } else if (neg) {
+            atomicOr(err_flags, kErrCoord);
+            atomicMin((unsigned long long *)err_index, (unsigned long long)i);
+        } else if (wide) atomicOr(err_flags, kErrWide);
+    }
+}
+
+__global__ __launch_bounds__(256) void unzip_items_kernel(long long n_ent, int32_t n_reads, const unsigned long long *__restrict__ item, uint32_t *__restrict__ b_win,
+                                                          long long *__restrict__ off, GapList *gaps)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_ent; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long x = item[i];
+        const uint32_t k = (uint32_t)x;
+        const long long prev = i == 0 ? -1 : (long long)(uint32_t)item[i - 1];
+        if ((long long)k != prev) fill_or_list(prev + 1, (long long)k, i, off, gaps);
+        if (k < (uint32_t)n_reads) b_win[i] = (uint32_t)(x >> 32);
+        if (i == n_ent - 1) fill_or_list((long long)k + 1, (long long)n_reads, n_ent, off, gaps);
+    }
+}
+
 } // namespace raft

@@ -420,6 +420,7 @@ struct raft_hip_ctx {
     int32_t variant = default_variant();
     int32_t force_bucket = 0;
     bool no_recut = false;            // leave tiles that do not fit the fast kernel to the general kernel (fallback, A/B)
+    bool no_bucket_win = false;       // general bucketing: a side's windows did not fit 16 bits once (kErrWide): coordinate pairs from then on
     std::string last_error;
 
     // device buffers
@@ -755,6 +756,33 @@ static int sort_sides(raft_hip_ctx *c, hipStream_t st, long long n_rec, int32_t 
     return RAFT_HIP_OK;
 }
 
+// ... the same as window records (bucket.hpp, round 5): o_win holds every read's records together, one word each (first window | one
+// past the last << 16), off[] where every read's begin -- the pileup kernel's window-record input with one run.  8 bytes per side
+// through the sort instead of 12.  A side whose windows need more than 16 bits raises kErrWide (raft_hip_finish runs the pass again
+// with the coordinate route).
+static int sort_sides_win(raft_hip_ctx *c, hipStream_t st, long long n_rec, int32_t n_reads, int symmetric, const int32_t *d_qid, const int32_t *d_qs,
+                          const int32_t *d_qe, const int32_t *d_tid, const int32_t *d_ts, const int32_t *d_te, long long cap_iv, uint32_t *o_win,
+                          long long *off, int32_t *err_flags, long long *err_index)
+{
+    HIP_TRY(c, c->rs_v0.ensure((size_t)cap_iv * 8)); HIP_TRY(c, c->rs_v1.ensure((size_t)cap_iv * 8));
+    HIP_TRY(c, c->gaps.ensure(sizeof(GapList)));
+    HIP_TRY(c, hipMemsetAsync(c->gaps.p, 0, 8, st));
+    const unsigned g1 = (unsigned)std::max<long long>(1, std::min<long long>((n_rec + 255) / 256, 256 * 32));
+    hipLaunchKernelGGL(expand_sides_win_kernel, dim3(g1), dim3(256), 0, st, n_rec, n_reads, symmetric, c->prm.reso, d_qid, d_qs, d_qe, d_tid, d_ts, d_te,
+                       c->rs_v0.as<unsigned long long>(), err_flags, err_index);
+    int bits = 1;
+    while (bits < 32 && (1LL << bits) <= (long long)n_reads) ++bits;               // keys 0 .. n_reads (the sides that do not exist)
+    HIP_TRY(c, c->sort_tmp.ensure(rs_items_tmp_bytes(cap_iv)));
+    bool in_b = false;
+    HIP_TRY(c, radix_sort_items(st, c->rs_v0.as<unsigned long long>(), c->rs_v1.as<unsigned long long>(), cap_iv, bits, c->sort_tmp.p, &in_b));
+    const unsigned long long *sorted = in_b ? c->rs_v1.as<unsigned long long>() : c->rs_v0.as<unsigned long long>();
+    const unsigned g2 = (unsigned)std::max<long long>(1, std::min<long long>((cap_iv + 255) / 256, 256 * 32));
+    hipLaunchKernelGGL(unzip_items_kernel, dim3(g2), dim3(256), 0, st, cap_iv, n_reads, sorted, o_win, off, c->gaps.as<GapList>());
+    hipLaunchKernelGGL(fill_gaps_kernel, dim3(64), dim3(256), 0, st, c->gaps.as<GapList>(), off);
+    HIP_TRY(c, hipGetLastError());
+    return RAFT_HIP_OK;
+}
+
 static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool verify_in_kernels)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
@@ -1060,6 +1088,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     }
 
     const bool fast = n_rec > 0 && symmetric && !c->force_bucket && n_desc + 1 <= kMaxSeg;
+    bool bwin = false;                                // the general bucketing hands the pileup kernel window records (below)
     SegStarts sb{};
     const long long *seg_end_dev = nullptr;
     if (n_rec == 0) {
@@ -1089,7 +1118,14 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         // shuffled records; it stays for small inputs, where its three launches cost less than the sort's
         // (... and for a symmetric stream of a few sorted runs that is sent here all the same -- force_bucket, A/B: its scatter is local)
         const bool parted = cap_iv >= (1LL << 20) && (!symmetric || n_desc + 1 > kMaxSeg) && getenv("RAFT_NO_RADIX_SORT") == nullptr;
-        if (parted) {
+        // ... and as window records where the wave kernel runs and a window index fits 16 bits: 8 bytes per side through the sort,
+        // the kernel's leanest input behind it
+        bwin = parted && wave && c->prm.reso <= 32767 && !c->no_bucket_win && getenv("RAFT_NO_BUCKET_WINDOWS") == nullptr;
+        if (bwin) {
+            const int prc = sort_sides_win(c, st, (long long)n_rec, n_reads, symmetric, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, cap_iv,
+                                           c->b_s.as<uint32_t>(), c->b_off.as<long long>(), &ctrl->err_flags, &ctrl->err_index);
+            if (prc != RAFT_HIP_OK) return prc;
+        } else if (parted) {
             const int prc = sort_sides(c, st, (long long)n_rec, n_reads, symmetric, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, cap_iv,
                                        c->b_rid.as<int32_t>(), c->b_s.as<int32_t>(), c->b_e.as<int32_t>(), c->b_off.as<long long>(),
                                        &ctrl->err_flags, &ctrl->err_index);
@@ -1113,6 +1149,11 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         sb.n_seg = 1; sb.start[0] = 0; sb.start[1] = cap_iv;
         seg_end_dev = c->b_off.as<long long>() + N;   // the true interval count lives at b_off[N]
         pa.iv_rid = c->b_rid.as<int32_t>(); pa.iv_s = c->b_s.as<int32_t>(); pa.iv_e = c->b_e.as<int32_t>(); pa.n_seg = 1;
+        if (bwin) {                                   // (the kernel takes its records' reads from the offsets: pileup_wave.hpp IN = 1)
+            pa.iv_w = c->b_s.as<uint32_t>();
+            pa.grp.off = c->b_off.as<long long>(); pa.grp.stride = N + 1;
+            for (int s2 = 0; s2 < kMaxSeg; ++s2) pa.grp.adj[s2] = 0;
+        }
         c->sum.interval_path = 1; c->sum.n_segments = n_desc + 1; c->sum.n_intervals = -1; // read back in finish
     }
     // the detection of a pass that assumes a symmetric PAF: one more boundary search of this kernel (pileup.hpp MirrorArgs)
@@ -1145,7 +1186,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     if (wave) {
         // ONE launch, no second stream: a persistent grid of single-wave workers, each drawing wave tiles from the list
         // tile_desc_kernel cut (its length is known on the device only: workers without a tile leave at once)
-        int n_waves = (int)std::max<long long>(1, std::min<long long>(wave_grid_waves(lean), n_tiles));
+        int n_waves = (int)std::max<long long>(1, std::min<long long>(wave_grid_waves(lean || bwin), n_tiles));
         pa.tile_batch = 1;
         int n_ctr = 8;
 #ifdef RAFT_WAVE_DIAG   // (make DEFS=-DRAFT_WAVE_DIAG: run-time switches for tools/mode_probe.py -- workers, parts of the kernel, counters)
@@ -1157,7 +1198,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         pa.tile_counter = c->wave_ctr.as<int32_t>();
         pa.n_extra = nullptr;
         pa.piece_w = (int32_t)std::min<long long>(extra_cap, INT32_MAX);    // (delta4: tile ids below this have slots of their own)
-        launch_wave_variant(ow, lean, st, pa.n_seg, c->tile_cuts.p, &pa, n_waves);
+        launch_wave_variant(ow, lean || bwin, st, pa.n_seg, c->tile_cuts.p, &pa, n_waves);
         n_sum_blocks = (unsigned)n_waves;
     } else if (pv.fast) {
         const TileCut *cuts = c->tile_cuts.as<TileCut>();
@@ -1393,10 +1434,13 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
                     force_no_recut = true;
                     if (kVariants[c->variant].fast == 2) force_variant = 0;
                     rerun = true;
+                } else if ((hc.err_flags & kErrWide) && !c->no_bucket_win) {
+                    c->no_bucket_win = true;            // a side's windows do not fit 16 bits: this context buckets coordinate pairs from now on
+                    rerun = true;
                 } else if ((hc.err_flags & kErrDeep) && force_variant != 0) {
                     force_variant = 0;
                     rerun = true;
-                } else if (c->pass_width != 4 && (long long)hc.n_exc > c->exc_cap && !(hc.err_flags & ~(kErrOrder | kErrExtra | kErrDeep))) {
+                } else if (c->pass_width != 4 && (long long)hc.n_exc > c->exc_cap && !(hc.err_flags & ~(kErrOrder | kErrExtra | kErrDeep | kErrWide))) {
                     c->exc_cap = (long long)hc.n_exc;
                     rerun = true;
                 }

@@ -278,4 +278,118 @@ inline hipError_t radix_sort_by_key(hipStream_t st, uint32_t *key_a, V *val_a, u
     return hipGetLastError();
 }
 
+// ---- the same sort over 64-bit ITEMS whose low 32 bits are the key (the general bucketing's window-record route: an interval is
+// (read id, first window | one past the last << 16) -- 8 bytes where the coordinate pair takes 12, one load and one store per pair and
+// pass instead of two, runs of twice the bytes)
+template <int IPT>
+__global__ __launch_bounds__(kRsThreads) void rs_hist_items_kernel(const unsigned long long *__restrict__ item, long long n, int shift, int n_tiles, int32_t *__restrict__ hist)
+{
+    __shared__ int32_t h[256];
+    const int tile = rs_tile_of_block((int)blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const long long t0 = (long long)tile * RsGeom<IPT>::kTile;
+#pragma unroll 8
+    for (int b = 0; b < IPT; ++b) {
+        const long long i = t0 + (long long)b * kRsThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[((uint32_t)item[i] >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) hist[(long long)tile * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+template <int IPT>
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_items_kernel(const unsigned long long *__restrict__ in, long long n, int shift, int n_tiles,
+                                                               const int32_t *__restrict__ tile_off, unsigned long long *__restrict__ out)
+{
+    constexpr int TILE = RsGeom<IPT>::kTile, SHARE = RsGeom<IPT>::kQuarter;
+    __shared__ int32_t cnt[kRsWaves][256];
+    __shared__ int32_t goff[256];
+    __shared__ int32_t wsum[4];
+    __shared__ unsigned long long s_item[TILE];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = rs_tile_of_block((int)blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;
+    const long long t0 = (long long)tile * TILE;
+    const int n_valid = (int)min((long long)TILE, n - t0);
+    for (int i = tid; i < kRsWaves * 256; i += kRsThreads) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    unsigned long long it[IPT];
+#pragma unroll
+    for (int b = 0; b < IPT; ++b) {
+        const int j = w * SHARE + b * 64 + lane;
+        it[b] = j < n_valid ? in[t0 + j] : ~0ull;
+    }
+#pragma unroll
+    for (int b = 0; b < IPT; ++b)
+        if (w * SHARE + b * 64 + lane < n_valid) atomicAdd(&cnt[w][((uint32_t)it[b] >> shift) & 255u], 1);
+    __syncthreads();
+    {
+        int c[kRsWaves], tot = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int q = 0; q < kRsWaves; ++q) { c[q] = cnt[q][tid]; tot += c[q]; }
+        }
+        const int incl = wave_incl_scan_add(tot);
+        if (tid < 256 && lane == 63) wsum[w] = incl;
+        __syncthreads();
+        if (tid < 256) {
+            int lstart = incl - tot;
+            for (int q = 0; q < w; ++q) lstart += wsum[q];
+            int run = lstart;
+#pragma unroll
+            for (int q = 0; q < kRsWaves; ++q) { cnt[q][tid] = run; run += c[q]; }
+            goff[tid] = tile_off[(long long)tile * 256 + tid] - lstart;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < IPT; ++b) {
+        const int j = w * SHARE + b * 64 + lane;
+        const bool live = j < n_valid;
+        if (__ballot(live) == 0ull) break;
+        const int d = (int)(((uint32_t)it[b] >> shift) & 255u);
+        unsigned long long peers = __ballot(live);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long m = __ballot((d >> bit) & 1);
+            peers &= ((d >> bit) & 1) ? m : ~m;
+        }
+        const int rank = (int)__popcll(peers & ((1ull << lane) - 1ull));
+        const int leader = (int)__builtin_ctzll(peers | (1ull << 63));
+        int first = 0;
+        if (live && lane == leader) { first = cnt[w][d]; cnt[w][d] = first + (int)__popcll(peers); }
+        first = __shfl(first, leader, kWave);
+        if (live) s_item[first + rank] = it[b];
+    }
+    __syncthreads();
+    for (int j = tid; j < n_valid; j += kRsThreads) {
+        const unsigned long long x = s_item[j];
+        out[goff[((uint32_t)x >> shift) & 255u] + j] = x;
+    }
+}
+
+constexpr int kRsItemsIpt = 32;      // 8192 items of 8 bytes: 64 KB of LDS per tile, runs of 256 bytes
+inline size_t rs_items_tmp_bytes(long long n) { return ((size_t)256 * (size_t)((n + RsGeom<kRsItemsIpt>::kTile - 1) / RsGeom<kRsItemsIpt>::kTile + 1) + (size_t)256 * kRsSegs) * 4; }
+inline hipError_t radix_sort_items(hipStream_t st, unsigned long long *a, unsigned long long *b, long long n, int bits, void *tmp, bool *in_b)
+{
+    constexpr int IPT = kRsItemsIpt;
+    *in_b = false;
+    if (n < 2) return hipSuccess;
+    const int n_tiles = (int)((n + RsGeom<IPT>::kTile - 1) / RsGeom<IPT>::kTile);
+    int32_t *hist = static_cast<int32_t *>(tmp), *seg = hist + (size_t)256 * n_tiles;
+    unsigned long long *xi = a, *xo = b;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL((rs_hist_items_kernel<IPT>), dim3(rs_grid(n_tiles)), dim3(kRsThreads), 0, st, xi, n, shift, n_tiles, hist);
+        hipLaunchKernelGGL(rs_segsum_kernel, dim3(kRsSegs), dim3(256), 0, st, n_tiles, hist, seg);
+        hipLaunchKernelGGL(rs_segscan_kernel, dim3(1), dim3(256), 0, st, seg);
+        hipLaunchKernelGGL(rs_tilescan_kernel, dim3(kRsSegs), dim3(256), 0, st, n_tiles, hist, seg);
+        hipLaunchKernelGGL((rs_scatter_items_kernel<IPT>), dim3(rs_grid(n_tiles)), dim3(kRsThreads), 0, st, xi, n, shift, n_tiles, hist, xo);
+        std::swap(xi, xo);
+        *in_b = !*in_b;
+    }
+    return hipGetLastError();
+}
+
 } // namespace raft

@@ -127,3 +127,56 @@ def test_more_records_than_one_pass_takes():
     fo = res["frag_offset"]
     assert np.all(res["frag_begin"][fo[:-1]] == 0) and np.all(res["frag_end"][fo[1:] - 1] == rl)
     eng.close(); other.close()
+
+
+@pytest.mark.parametrize("shape", ["fits", "wide", "errors"])
+def test_large_shuffled_stream_buckets_window_records_or_coordinate_pairs(shape, monkeypatch):
+    """The device pass over a million-odd records in random order (round 5: a hand-written LSD radix sort by read id,
+    sort_pairs.hpp).  Where every window index fits 16 bits a side is ONE 64-bit item through the sort and the pileup kernel gets
+    window records; `wide`: reads of 70,000 windows (-r 1) -- a side raises kErrWide and the pass is run again with coordinate
+    pairs, for good on that context; `errors`: a negative coordinate / an interval past its read's end are reported by either
+    route.  Outputs equal the oracle's on both routes (RAFT_NO_BUCKET_WINDOWS=1 forces the second)."""
+    from raft_amd import engine
+    from raft_testlib import assert_same_result
+    rng = np.random.default_rng(23)
+    wide = shape == "wide"
+    p = RaftParams(est_cov=25, reso=1 if wide else 50, repeat_length=2000, interval_length=2000, read_length=6000, overlap_length=100, flanking_length=50)
+    n_reads = 160 if wide else 9000
+    rl = rng.integers(60000, 71000, n_reads).astype(np.int32) if wide else rng.integers(2000, 40000, n_reads).astype(np.int32)
+    n = (1 << 20) + 12345                                     # (the sort takes over from the counting sort at 2^20 intervals)
+    qid = rng.integers(0, n_reads, n).astype(np.int32); tid = rng.integers(0, n_reads, n).astype(np.int32)
+    a = (rng.random(n) * rl[qid] * 0.9).astype(np.int32); b = np.minimum(rl[qid], a + 1 + (rng.random(n) * rl[qid] * 0.1).astype(np.int32)).astype(np.int32)
+    ta = (rng.random(n) * rl[tid] * 0.9).astype(np.int32); tb = np.minimum(rl[tid], ta + 1 + (rng.random(n) * rl[tid] * 0.1).astype(np.int32)).astype(np.int32)
+    a[5] = b[5] = 77                                           # an empty, unaligned interval (SURVEY G1: still one window)
+    cols = (rl, qid, a, b, tid, ta, tb)
+    want = oracle_run(p, *cols)
+    assert want["symmetric"] == 0
+    for force_pairs in (False, True):
+        if force_pairs:
+            monkeypatch.setenv("RAFT_NO_BUCKET_WINDOWS", "1")
+        eng = engine.Engine(p, device=0)
+        for rep in range(2):                                   # (`wide`: the second pass goes straight to coordinate pairs)
+            eng.run_host(*cols)
+            s = eng.finish()
+            got = eng.fetch()
+            got.update(symmetric=s.symmetric, high_cov=s.high_cov, total_coverage=s.total_coverage, total_windows=s.total_windows,
+                       total_repeat_length=s.total_repeat_length, total_read_length=s.total_read_length)
+            assert_same_result(got, want, f"{shape} pairs={force_pairs} pass {rep}")
+            assert s.interval_path == 1 and s.n_intervals == int((qid != tid).sum()) + n
+        if shape == "errors":
+            b2 = tb.copy(); b2[4242] = rl[tid[4242]] + 9000
+            eng.run_host(rl, qid, a, b, tid, ta, b2)
+            with pytest.raises(engine.RaftError) as e1:
+                eng.finish()
+            assert e1.value.code == engine.ERR_COORD
+            a2 = a.copy(); a2[999] = -3
+            eng.run_host(rl, qid, a2, b, tid, ta, tb)
+            with pytest.raises(engine.RaftError) as e2:
+                eng.finish()
+            assert e2.value.code == engine.ERR_COORD
+            t2 = tid.copy(); t2[31337] = n_reads
+            eng.run_host(rl, qid, a, b, t2, ta, tb)
+            with pytest.raises(engine.RaftError) as e3:
+                eng.finish()
+            assert e3.value.code == engine.ERR_READ_ID and e3.value.index == 31337
+        eng.close()
