@@ -930,6 +930,14 @@ def main():
                 line["cpu_baseline"] = cb
         if placement_ab is not None:
             line["placement_ab"] = placement_ab
+        if eng is not None:
+            tr = eng.placement_trial()
+            if tr is not None:
+                # the headline context's own choice (its first, untimed pass): the pileup kernel into the coverage array as the policy placed
+                # it and into a few more candidates (plain blocks, other chunk mappings); the timed passes run with the one that was kept
+                line["placement_trial"] = {"first_placement_ms": tr[0], "best_other_candidate_ms": tr[1],
+                                           "kept": ("first placement", "a plain hipMalloc block", "another chunk mapping")[tr[2]],
+                                           "note": "the context's first (untimed) pass ran the pileup kernel into four candidate coverage arrays, warm; the timed passes use the fastest"}
         print(json.dumps(line))
     if eng is not None:
         eng.close()

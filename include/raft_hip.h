@@ -277,6 +277,14 @@ int64_t raft_hip_pool_bytes(int device_id);
  * RAFT_NO_VMM set the start value).  Buffers that exist keep their memory.  bench.py's `placement_ab` times the pileup kernel
  * under 8, 1 and 0 in one process. */
 int32_t raft_hip_set_placement(int32_t spread);
+/* The placement trial of the context's coverage array (ABI 10).  What the pileup kernel gets from this part follows the array it
+ * stores into -- by the draw, not by the kind of memory: two hipMalloc blocks of one process gave 2.24 and 2.63 ms.
+ * So a context whose first pass makes an int32 coverage array of 1 GiB or more draws RAFT_PLACEMENT_TRIALS - 1 more arrays (default
+ * 4 candidates: plain blocks and chunk mappings in turn), runs the kernel into each of them warm in that pass and keeps the fastest
+ * (not after raft_hip_set_placement / RAFT_NO_VMM / RAFT_VMM_SPREAD chose by hand; RAFT_NO_PLACEMENT_TRIAL=1 switches it off).
+ * Reports the kernel's ms into the first placement and into the best other candidate, and what was kept (0 the first placement,
+ * 1 a plain block, 2 another chunk mapping); RAFT_HIP_ERR_STATE when no trial has run. */
+int  raft_hip_placement_trial(raft_hip_ctx *ctx, double *first_ms, double *best_other_ms, int32_t *kept);
 
 /* Device arrays of the encoding the finished pass holds (width 0: none -- the pass wrote int32; call
  * raft_hip_fetch_packed_w once to have it encoded).  The exceptions are in no particular order. */

@@ -211,6 +211,12 @@ struct DevBuf {
     static constexpr size_t kChunk = 32u << 20, kVmmMin = 64u << 20, kSpreadMin = size_t(1) << 30;
     // the placement policy of buffers made from now on (process-wide): 0 = plain hipMalloc, k >= 1 = chunks, k times as many made
     // as used for buffers of 1 GiB or more.  RAFT_NO_VMM=1 / RAFT_VMM_SPREAD=<k> set the start value; raft_hip_set_placement changes it.
+    // set once the policy was chosen by hand (RAFT_NO_VMM / RAFT_VMM_SPREAD / raft_hip_set_placement): no placement trial then
+    static std::atomic<bool> &policy_explicit()
+    {
+        static std::atomic<bool> e{getenv("RAFT_NO_VMM") != nullptr || getenv("RAFT_VMM_SPREAD") != nullptr};
+        return e;
+    }
     static std::atomic<int> &policy()
     {
         static std::atomic<int> p{getenv("RAFT_NO_VMM") ? 0 : (getenv("RAFT_VMM_SPREAD") ? std::max(1, atoi(getenv("RAFT_VMM_SPREAD"))) : 8)};
@@ -421,6 +427,9 @@ struct raft_hip_ctx {
     int32_t force_bucket = 0;
     bool no_recut = false;            // leave tiles that do not fit the fast kernel to the general kernel (fallback, A/B)
     bool no_bucket_win = false;       // general bucketing: a side's windows did not fit 16 bits once (kErrWide): coordinate pairs from then on
+    size_t cov_trial_cap = 0;         // capacity of `cov` the placement trial has been run for (run_pass)
+    double trial_ms[2] = {0.0, 0.0};  // that trial: the pileup kernel into `cov` as first placed / into the best of the other candidates (ms)
+    int32_t trial_kept_plain = 0;     // 0: the first placement stayed, 1: a plain hipMalloc block was kept, 2: another chunk mapping
     std::string last_error;
 
     // device buffers
@@ -656,7 +665,17 @@ int64_t raft_hip_trim(int device_id, int64_t keep_bytes)
 
 int32_t raft_hip_set_placement(int32_t spread)
 {
+    DevBuf::policy_explicit().store(true);
     return (int32_t)DevBuf::policy().exchange(spread < 0 ? 0 : std::min(spread, 64));
+}
+
+int raft_hip_placement_trial(raft_hip_ctx *c, double *chunks_ms, double *plain_ms, int32_t *kept_plain)
+{
+    if (!c) return RAFT_HIP_ERR_PARAM;
+    if (chunks_ms) *chunks_ms = c->trial_ms[0];
+    if (plain_ms) *plain_ms = c->trial_ms[1];
+    if (kept_plain) *kept_plain = c->trial_kept_plain;
+    return c->trial_ms[0] > 0.0 ? RAFT_HIP_OK : RAFT_HIP_ERR_STATE;
 }
 
 int64_t raft_hip_pool_bytes(int device_id)
@@ -1200,6 +1219,63 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         pa.piece_w = (int32_t)std::min<long long>(extra_cap, INT32_MAX);    // (delta4: tile ids below this have slots of their own)
         launch_wave_variant(ow, lean || bwin, st, pa.n_seg, c->tile_cuts.p, &pa, n_waves);
         n_sum_blocks = (unsigned)n_waves;
+        // ---- where the coverage array lies, decided by measurement (round 5).  What this kernel gets from the part follows the array
+        // it stores into, and not by the KIND of memory: two hipMalloc blocks of one process gave 2.24 and 2.63 ms, two chunk
+        // mappings 2.49 and 2.67, and which kind had the better draw changed from lease to lease.  So the first
+        // pass of a context that makes a coverage array of a GiB or more draws a few more arrays -- plain blocks and chunk mappings
+        // in turn --, runs the kernel into each of them warm, and keeps the one it was fastest with.  Once per context and array
+        // size: 2 K - 1 more launches for K candidates (RAFT_PLACEMENT_TRIALS, default 4), K - 1 more allocations, one host wait.
+        static const int kTrials = [] { const char *e = getenv("RAFT_PLACEMENT_TRIALS"); return e ? std::max(1, std::min(8, atoi(e))) : 4; }();
+        if (ow == 4 && c->cov.cap >= DevBuf::kSpreadMin && c->cov.va_bytes && c->cov_trial_cap != c->cov.cap && !c->is_lane && kTrials > 1 &&
+            !DevBuf::policy_explicit().load() && getenv("RAFT_NO_PLACEMENT_TRIAL") == nullptr) {
+            c->cov_trial_cap = c->cov.cap;
+            std::vector<DevBuf> cand((size_t)kTrials - 1);
+            std::vector<hipEvent_t> ev((size_t)2 * kTrials, nullptr);
+            int n_cand = 0;
+            for (int k = 0; k + 1 < kTrials; ++k) {
+                cand[(size_t)k].big = (k & 1) != 0;       // plain block, chunk mapping, plain block, ...
+                if (cand[(size_t)k].ensure(c->cov.cap) != hipSuccess) { (void)hipGetLastError(); break; }
+                ++n_cand;
+            }
+            bool ok = n_cand > 0;
+            for (size_t i = 0; ok && i < ev.size(); ++i) ok = hipEventCreate(&ev[i]) == hipSuccess;
+            if (ok) {
+                // (the launch above was the context's first -- code going to the device, cold translations: 3 ms, or 200 -- and says
+                // nothing; the first run into an array pays for its first touch; the second is the measurement.  What a run leaves
+                // behind and the next must not see: the reads' repeat counters, the hand-out counters)
+                auto one_run = [&](int32_t *cov_p, hipEvent_t e0, hipEvent_t e1) -> int {
+                    PileupArgs x = pa;
+                    x.cov = cov_p;
+                    HIP_TRY(c, hipMemsetAsync(c->rep_cnt.p, 0, (size_t)std::max(N, 1LL) * 4, st));
+                    HIP_TRY(c, hipMemsetAsync(c->wave_ctr.p, 0, (size_t)kWaveCounters * kCtrStride * 4, st));
+                    if (e0) HIP_TRY(c, hipEventRecord(e0, st));
+                    launch_wave_variant(ow, lean || bwin, st, x.n_seg, c->tile_cuts.p, &x, n_waves);
+                    if (e1) HIP_TRY(c, hipEventRecord(e1, st));
+                    return RAFT_HIP_OK;
+                };
+                int trc = RAFT_HIP_OK;
+                for (int k = 0; k < n_cand && trc == RAFT_HIP_OK; ++k) trc = one_run(cand[(size_t)k].as<int32_t>(), nullptr, nullptr);
+                if (trc == RAFT_HIP_OK) trc = one_run(c->cov.as<int32_t>(), ev[0], ev[1]);
+                for (int k = 0; k < n_cand && trc == RAFT_HIP_OK; ++k) trc = one_run(cand[(size_t)k].as<int32_t>(), ev[(size_t)2 * k + 2], ev[(size_t)2 * k + 3]);
+                if (trc != RAFT_HIP_OK) return trc;
+                HIP_TRY(c, hipEventSynchronize(ev[(size_t)2 * n_cand + 1]));
+                float best = 0.f;
+                HIP_TRY(c, hipEventElapsedTime(&best, ev[0], ev[1]));
+                c->trial_ms[0] = best; c->trial_ms[1] = 0.0;
+                int keep = -1;
+                for (int k = 0; k < n_cand; ++k) {
+                    float t = 0.f;
+                    HIP_TRY(c, hipEventElapsedTime(&t, ev[(size_t)2 * k + 2], ev[(size_t)2 * k + 3]));
+                    if (c->trial_ms[1] == 0.0 || t < c->trial_ms[1]) c->trial_ms[1] = t;
+                    if (t < best * 0.985f) { best = t; keep = k; }      // (a candidate has to win by more than the noise of two launches)
+                }
+                c->trial_kept_plain = keep >= 0 ? (cand[(size_t)keep].big ? 2 : 1) : 0;
+                if (keep >= 0) { std::swap(c->cov, cand[(size_t)keep]); c->cov_trial_cap = c->cov.cap; }
+                // (whichever array is kept holds this pass's coverage: every run wrote all of it)
+            }
+            for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+            for (DevBuf &b : cand) b.release();
+        }
     } else if (pv.fast) {
         const TileCut *cuts = c->tile_cuts.as<TileCut>();
         // The tiles the fast kernel does not take (reads longer than the LDS window, very many reads) go to the general

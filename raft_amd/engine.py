@@ -29,7 +29,7 @@ EXPORTS = (
     "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local", "raft_hip_warm_up", "raft_hip_reserve",
     "raft_hip_run_device_windows", "raft_hip_run_host_windows", "raft_hip_run_multi_windows",
     "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device", "raft_hip_set_emit_cuts", "raft_hip_device_alloc", "raft_hip_device_free", "raft_hip_group_sides", "raft_hip_presplit_symmetric", "raft_hip_presplit_symmetric_local",
-    "raft_hip_trim", "raft_hip_pool_bytes", "raft_hip_run_presplit_local", "raft_hip_set_placement",
+    "raft_hip_trim", "raft_hip_pool_bytes", "raft_hip_run_presplit_local", "raft_hip_set_placement", "raft_hip_placement_trial",
 )
 
 
@@ -177,6 +177,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_pool_bytes.restype = i64
     lib.raft_hip_set_placement.argtypes = [i32]
     lib.raft_hip_set_placement.restype = i32
+    lib.raft_hip_placement_trial.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)]
     lib.raft_hip_group_sides.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_Slice)]
     lib.raft_hip_presplit_symmetric.argtypes = [vp, vp, i32, i32, C.POINTER(_Records), C.POINTER(i32)]
     lib.raft_hip_presplit_symmetric_local.argtypes = [C.POINTER(vp), i32, C.POINTER(_Records), C.POINTER(i32)]
@@ -240,6 +241,14 @@ class Engine:
 
     def set_tuning(self, tile_bins: int = 0, force_bucket_path: bool = False, variant: int = -1):
         self._check(self._lib.raft_hip_set_tuning(self._ctx, tile_bins, int(force_bucket_path), variant))
+
+    def placement_trial(self):
+        """(first_ms, best_other_ms, kept) of the coverage array's placement trial -- kept: 0 the first placement, 1 a plain block, 2 another
+        chunk mapping -- or None when none has run (raft_hip_placement_trial)."""
+        a, b, k = C.c_double(), C.c_double(), C.c_int32()
+        if self._lib.raft_hip_placement_trial(self._ctx, C.byref(a), C.byref(b), C.byref(k)) != OK:
+            return None
+        return a.value, b.value, int(k.value)
 
     def set_output_width(self, width: int):
         """4: cov[] as int32 (default); 1 / 2: later passes write the transfer encoding directly (raft_hip_set_output_width)."""
