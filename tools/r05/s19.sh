@@ -16,3 +16,4 @@ python3 bench.py --reads 412500 --no-cpu-baseline --steps 20 --warmup 3 --no-pla
 timeout 900 python3 tools/full_compare.py --workload hg002 > $OUT/full_compare_hg002.txt 2>&1; tail -3 $OUT/full_compare_hg002.txt
 timeout 900 python3 tools/full_compare.py --workload ultralong > $OUT/full_compare_ultralong.txt 2>&1; tail -3 $OUT/full_compare_ultralong.txt
 tail -4 $OUT/profile_round.log
+bash tools/r05/s9.sh
