@@ -63,6 +63,12 @@ __device__ __forceinline__ unsigned pk_add_bcast(unsigned a, unsigned b)
     else    asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ unsigned pk_add_u16(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b)
 {
     unsigned r;
@@ -613,6 +619,36 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                     }
                 } else {
                     // four-bit steps: a step IS the difference array's value; the lane's four steps are one aligned ushort
+                    if (full && base > off0) {
+                        // the common row (every slot a window of the tile, none of them its first): the four codes by packed
+                        // arithmetic -- step + 7 clamped to 15 per half (a step outside [-7, 7] wraps or exceeds: 15), + 1 modulo 16 makes
+                        // 1 .. 15 of a step that fits and 0, "listed", of one that does not; two shifts put the nibbles side by side
+                        const unsigned m0 = pk_min_u16(pk_add_u16(d0, 0x00070007u), 0x000f000fu), m1 = pk_min_u16(pk_add_u16(d1, 0x00070007u), 0x000f000fu);
+                        const unsigned k0 = pk_add_u16(m0, 0x00010001u) & 0x000f000fu, k1 = pk_add_u16(m1, 0x00010001u) & 0x000f000fu;
+                        const unsigned code = ((k0 | (k0 >> 12)) & 0xffu) | (((k1 | (k1 >> 12)) & 0xffu) << 8);
+                        *reinterpret_cast<uint16_t *>(covp0 + ((unsigned)p0 >> 1)) = (uint16_t)code;
+                        if ((((unsigned)a0 + (unsigned)p0 + (unsigned)a.d4_shift) & 1023u) == 0u)
+                            a.cov_anchor[(a0 + p0 + a.d4_shift) >> 10] = (int)c0 - (int)(short)d0;
+                        unsigned t = code | (code >> 1);
+                        t |= t >> 2;
+                        unsigned esc = ~t & 0x1111u;                                  // bit 4q: window q of this lane is listed
+                        if (esc && pend_p < 0) {
+                            const int q = (__ffs((int)esc) - 1) >> 2;
+                            esc &= esc - 1u;
+                            pend_p = p0 + q; pend_c = q == 0 ? (int)c0 : q == 1 ? (int)c1 : q == 2 ? (int)c2 : (int)c3;
+                        }
+                        unsigned long long em = __ballot(esc != 0u);
+                        while (em) {
+                            if (esc) {
+                                const int q = (__ffs((int)esc) - 1) >> 2;
+                                esc &= esc - 1u;
+                                d4_list(p0 + q, q == 0 ? (int)c0 : q == 1 ? (int)c1 : q == 2 ? (int)c2 : (int)c3, d4_n + (int)__popcll(em & ((1ull << lane) - 1ull)));
+                            }
+                            d4_n += (int)__popcll(em);
+                            em = __ballot(esc != 0u);
+                        }
+                        return;
+                    }
                     const int s0 = (int)(short)d0, s1 = (int)d0 >> 16, s2 = (int)(short)d1, s3 = (int)d1 >> 16;
                     const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
                     const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
