@@ -91,11 +91,11 @@ __global__ __launch_bounds__(256) void inspect_kernel(long long n_rec, int32_t n
     }
 }
 
-// Sorted runs of the record stream as up to 16 k evenly spaced samples show them: where one sample is smaller than the one
+// Sorted runs of the record stream as up to 256 k evenly spaced samples show them: where one sample is smaller than the one
 // before, a run ends in between, and a bisection (left part >= the earlier sample, right part below it) finds the first
 // record of the next run.  inspect_kernel, which looks at every record, confirms or refutes it.
-// The samples themselves are kept (64 KB): they are a coarse index of the stream.  tile_desc_kernel bisects them first
-// -- cache hits -- and then only the 9 k records between two samples, instead of 28 dependent probes spread over a
+// The samples themselves are kept (1 MB): they are a coarse index of the stream.  tile_desc_kernel bisects them first
+// -- cache hits -- and then only the ~1 k records between two samples, instead of 28 dependent probes spread over a
 // GB-sized column (every one of them a TLB miss).
 struct GuessOut {
     int32_t n_desc, pad;
@@ -113,6 +113,13 @@ __global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const 
     const long long p0 = sample_pos(i - 1, n_rec, sh), p1 = sample_pos(i, n_rec, sh);
     const int32_t v = qid[p0], w = qid[p1];
     if (samples) samples[i] = w;
+    // (a stream that is not a handful of sorted runs: a wave that alone sees more descents than the pass accepts says so with ONE
+    // atomic and looks no further -- with one per descent, the 128 k of a shuffled stream's 256 k samples would queue up on the word)
+    const unsigned long long dm = __ballot(w < v);
+    if (__popcll(dm) > kMaxSeg) {
+        if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(dm)) atomicAdd(&out->n_desc, (int)__popcll(dm));
+        return;
+    }
     if (w < v) {
         long long lo = p0, hi = p1;
         while (hi - lo > 1) {

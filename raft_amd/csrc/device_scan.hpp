@@ -67,41 +67,29 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(Loader ld, 
     }
 }
 
-// one workgroup: exclusive scan of the per-block partials in place; grand totals go to totals[K]
-template <int K>
-__global__ __launch_bounds__(1024) void scan_partials_scan_kernel(long long *partials, int nblocks, long long *totals)
-{
-    __shared__ long long lds[1024 / 64 + 1];
-    long long carry[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) carry[k] = 0;
-    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
-        int b = b0 + threadIdx.x;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            long long v = (b < nblocks) ? partials[(long long)b * K + k] : 0;
-            long long tot;
-            long long ex = block_excl_scan64<1024>(v, &tot, lds);
-            if (b < nblocks) partials[(long long)b * K + k] = carry[k] + ex;
-            carry[k] += tot;
-        }
-    }
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) totals[k] = carry[k];
-    }
-}
-
 // FUSED: `partials` holds the workgroups' raw totals (scan_partials_kernel) and every workgroup adds up the ones before it by
 // itself -- a few KB from L2 per workgroup -- instead of waiting for a one-workgroup kernel to scan them (12 us per scan at
 // human scale, twice per pass); the last workgroup writes the grand totals.
-template <class Loader, int K, bool FUSED = false>
+template <class Loader, int K, bool FUSED = true>
 __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, long long n, const long long *partials,
                                                                   long long *totals, ScanOut<K> out)
 {
     __shared__ long long lds[kScanThreads / 64 + 1];
     __shared__ long long stage[kScanTile];      // blocked -> striped, so that the stores are coalesced
     long long base[K];
+    // (the workgroup's own elements are asked for first: they arrive while the totals of the workgroups before are added up)
+    long long v[kScanItems][K];
+    const long long block0 = (long long)blockIdx.x * kScanTile;
+    const long long i0 = block0 + (long long)threadIdx.x * kScanItems;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        const long long i = i0 + j;
+        if (i < n) ld(i, v[j]);
+        else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[j][k] = 0;
+        }
+    }
     if (FUSED) {
         long long mine[K];
 #pragma unroll
@@ -117,20 +105,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, lon
             base[k] = tot;
         }
     }
-    long long v[kScanItems][K];
     long long acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0;
-    const long long block0 = (long long)blockIdx.x * kScanTile;
-    long long i0 = block0 + (long long)threadIdx.x * kScanItems;
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
-        long long i = i0 + j;
-        if (i < n) ld(i, v[j]);
-        else {
-#pragma unroll
-            for (int k = 0; k < K; ++k) v[j][k] = 0;
-        }
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] += v[j][k];
     }
@@ -169,19 +148,6 @@ inline void exclusive_scan(hipStream_t st, Loader ld, long long n, long long *pa
     hipLaunchKernelGGL((scan_partials_kernel<Loader, K>), dim3(nb), dim3(kScanThreads), 0, st, ld, n, partials);
     hipLaunchKernelGGL((scan_apply_kernel<Loader, K, true>), dim3(nb), dim3(kScanThreads), 0, st, ld, n, partials, totals, out);
     if (totals_dev) *totals_dev = totals;
-}
-
-// The same with a loader of its own for each pass: `first` may do work per element (and store what it found); `second`
-// re-reads the values that work left behind.
-template <class LoaderA, class LoaderB, int K>
-inline void exclusive_scan2(hipStream_t st, LoaderA first, LoaderB second, long long n, long long *partials, ScanOut<K> out)
-{
-    int nb = scan_blocks(n);
-    if (nb < 1) nb = 1;
-    long long *totals = partials + (long long)nb * K;
-    hipLaunchKernelGGL((scan_partials_kernel<LoaderA, K>), dim3(nb), dim3(kScanThreads), 0, st, first, n, partials);
-    hipLaunchKernelGGL((scan_partials_scan_kernel<K>), dim3(1), dim3(1024), 0, st, partials, nb, totals);
-    hipLaunchKernelGGL((scan_apply_kernel<LoaderB, K>), dim3(nb), dim3(kScanThreads), 0, st, second, n, partials, totals, out);
 }
 
 } // namespace raft

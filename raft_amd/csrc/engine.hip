@@ -352,6 +352,8 @@ struct ReadPrepLoader {               // per read: windows, reserved repeat slot
     int32_t long_windows, piece_w;    // reads longer than long_windows are piled up in pieces of piece_w windows
     int32_t *err_flags;
     long long *err_index;
+    FastDiv by_reso, by_mb1, by_L;    // reso, minbins + 1, L as divisors (three hardware divisions per read, one of them 64 bits wide,
+                                      // twice per pass, were most of what the two scan kernels executed)
     __device__ void operator()(long long i, long long (&v)[3]) const
     {
         int l = len[i];
@@ -360,11 +362,13 @@ struct ReadPrepLoader {               // per read: windows, reserved repeat slot
             atomicMin((unsigned long long *)err_index, (unsigned long long)i);
             l = 0;
         }
-        const long long nb = l / reso + ((l % reso) ? 1 : 0);   // repeat.hpp:32-37
+        const int q = fdiv(by_reso, l);
+        const long long nb = (long long)q + ((l - q * reso) ? 1 : 0);   // repeat.hpp:32-37
         v[0] = nb;
-        v[1] = (nb + 1) / ((long long)minbins + 1);              // most runs of >= minbins windows a read can hold
+        // most runs of >= minbins windows a read can hold
+        v[1] = nb + 1 < (1LL << 31) && minbins < INT32_MAX ? (long long)fdiv(by_mb1, (int)(nb + 1)) : (nb + 1) / ((long long)minbins + 1);
         if (nb > long_windows) v[1] += 2 * ((nb + piece_w - 1) / piece_w);   // + two runs per piece that touch its edges
-        v[2] = l / L + 2;                                        // chop.hpp:209-223
+        v[2] = fdiv(by_L, l) + 2;                                // chop.hpp:209-223
     }
 };
 
@@ -378,17 +382,18 @@ template <int K> struct CountLoader {
 };
 
 // What the host reads back goes straight into its page-locked block (device-visible host memory): a copy command per
-// few bytes cost ~25 us each on the device timeline (three of them ahead of the pass's host wait).
-__global__ void publish_sizes_kernel(const long long *scan_totals, const Ctrl *ctrl, long long *host)
+// few bytes cost ~25 us each on the device timeline (three of them ahead of the pass's host wait).  Stamped lines (finalize.hpp):
+// run_pass looks for them itself instead of sleeping in the runtime's wait (as raft_hip_finish does for the pass's end).
+constexpr int kInspWords = (int)(sizeof(InspectOut) / 8), kGuessWords = (int)(sizeof(GuessOut) / 8);
+constexpr int kSizesWords = 3 + 2 + kInspWords + kGuessWords;      // scan totals; err_flags | n_slow, err_index; InspectOut; GuessOut
+static_assert(kSizesWords <= 48 && stamped_lines(kSizesWords) * 8 <= 96, "the sizes block outgrew its place");
+constexpr int kPackCountWord = 100;   // (raft_hip_pack's count of listed windows: a word of the block outside the stamped lines)
+__global__ void publish_sizes_kernel(const long long *scan_totals, const Ctrl *ctrl, long long *host, long long seq)
 {
-    const int t = threadIdx.x;
-    if (t < 3) host[t] = scan_totals[t];
     const long long *c8 = reinterpret_cast<const long long *>(ctrl);
-    if (t < 2) host[4 + t] = c8[t];                                           // err_flags, n_slow, err_index
-    constexpr int kInsp = (int)(sizeof(InspectOut) / 8), kGuess = (int)(sizeof(GuessOut) / 8);
     const long long *in = reinterpret_cast<const long long *>(&ctrl->insp), *gu = reinterpret_cast<const long long *>(&ctrl->guess);
-    if (t < kInsp) host[8 + t] = in[t];
-    if (t < kGuess) host[32 + t] = gu[t];
+    publish_stamped(host, [&](int i) { return i < 3 ? scan_totals[i] : i < 5 ? c8[i - 3] : i < 5 + kInspWords ? in[i - 5] : gu[i - 5 - kInspWords]; },
+                    kSizesWords, seq, (int)threadIdx.x);
     __threadfence_system();
 }
 
@@ -479,6 +484,7 @@ struct raft_hip_ctx {
     DevBuf exc_idx2, exc_val2, sort_tmp;   // the exception list in ascending order (sort_exceptions)
     DevBuf exc_pidx, exc_pval, exc_tile_n; // delta4: the windows each tile lists, kExcPerTile slots per tile (compact_exceptions_kernel)
     bool exc_sorted = false;
+    long long sizes_seq = 0;           // number of the last sizes hand-over of run_pass (publish_sizes_kernel)
     long long pass_seq = 0;            // number of the pass whose totals_kernel is queued (written behind the control block when it is through)
     bool seq_armed = false;
     int d4_shift = 0;                  // delta4 on a chunk of a larger array (the host pipelines' lanes): windows of the block its first window lies in that precede it
@@ -901,9 +907,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     //      verifies in its kernels, every record by inspect_kernel: ids in range? the runs as sampled? mirror of record 0?
     //  (side stream) the per-read geometry: windows, reserved repeat slots, marker capacity (one scan, three sums).
     // (a grouped pass has nothing to find out about the stream: the scan runs on the main stream, nothing beside it)
-    long long *h = reinterpret_cast<long long *>(c->pinned);
-    InspectOut *hi = reinterpret_cast<InspectOut *>(h + 8);
-    GuessOut *hg = reinterpret_cast<GuessOut *>(h + 32);
+    long long h[kSizesWords] = {};                    // the sizes hand-over, taken out of its stamped lines (below)
+    InspectOut *hi = reinterpret_cast<InspectOut *>(h + 5);
+    GuessOut *hg = reinterpret_cast<GuessOut *>(h + 5 + kInspWords);
     const unsigned igrid = (unsigned)std::max<long long>(1, std::min<long long>((n_rec / 4 + 255) / 256, 256 * 8));
     const int nb_scan = std::max(scan_blocks(N), 1);
     HIP_TRY(c, c->scan_tmp.ensure(((size_t)nb_scan * 3 + 8) * sizeof(long long)));
@@ -925,7 +931,8 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
             HIP_TRY(c, hipStreamWaitEvent(gst, c->ev_ifork, 0));
         }
         ReadPrepLoader ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, recut ? pv.cap : INT32_MAX, pv.cap,
-                          &ctrl->err_flags, &ctrl->err_index};
+                          &ctrl->err_flags, &ctrl->err_index, make_fast_div(c->prm.reso),
+                          make_fast_div(c->minbins < INT32_MAX ? c->minbins + 1 : 1), make_fast_div(c->prm.interval_length)};
         ScanOut<3> so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), c->cutcap_off.as<long long>()}};
         exclusive_scan<ReadPrepLoader, 3>(gst, ld, N, c->scan_tmp.as<long long>(), so, &scan_totals);
         if (!grouped) HIP_TRY(c, hipEventRecord(c->ev_gjoin, gst));
@@ -950,13 +957,23 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         CU = B / std::max(1, c->prm.interval_length / c->prm.reso) + 2 * N + 2;
         if (c->prm.interval_length < c->prm.reso) CU = B * ((long long)c->prm.reso / c->prm.interval_length + 1) + 2 * N + 2;
     } else {
-        hipLaunchKernelGGL(publish_sizes_kernel, dim3(1), dim3(64), 0, st, scan_totals, ctrl, c->pinned_dev);
-        HIP_TRY(c, hipStreamSynchronize(st));                               // the pass's only host wait: sizes + path choice
+        hipLaunchKernelGGL(publish_sizes_kernel, dim3(1), dim3(64), 0, st, scan_totals, ctrl, c->pinned_dev, ++c->sizes_seq);
+        // the pass's only host wait: sizes + path choice
+        bool seen = false;
+        const volatile long long *lines = reinterpret_cast<const volatile long long *>(c->pinned);
+        if (!c->is_lane && getenv("RAFT_NO_SPIN") == nullptr) {
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+            for (int it = 0; !(seen = stamped_seen(lines, kSizesWords, c->sizes_seq)); ++it)
+                if ((it & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) HIP_TRY(c, hipStreamSynchronize(st));
+        unstamp(lines, kSizesWords, h);
         B = h[0]; RU = h[1]; CU = h[2];
-        const int32_t flags = reinterpret_cast<int32_t *>(h + 4)[0];
+        const int32_t flags = reinterpret_cast<int32_t *>(h + 3)[0];
         if (flags) {
             c->pending_err = code_from_flags(flags);
-            c->pending_err_index = h[5];
+            c->pending_err_index = h[4];
             c->ran = true;
             HIP_TRY(c, hipEventRecord(c->ev_pile0, st)); HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
             HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
@@ -1428,6 +1445,17 @@ int raft_hip_run_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len,
                                six ? c->in_col[4].as<int32_t>() : nullptr, six ? c->in_col[5].as<int32_t>() : nullptr);
 }
 
+// the control block as the pass's last workgroup handed it over (totals_kernel: stamped lines, 1024 bytes into the page-locked block)
+static Ctrl host_ctrl(const raft_hip_ctx *c)
+{
+    static_assert(sizeof(Ctrl) % 8 == 0 && sizeof(Ctrl) / 8 <= 48, "the control block travels in one wave's stamped lines");
+    long long w[sizeof(Ctrl) / 8];
+    unstamp(reinterpret_cast<const volatile long long *>(c->pinned) + 128, (int)(sizeof(Ctrl) / 8), w);
+    Ctrl hc;
+    memcpy(&hc, w, sizeof(Ctrl));
+    return hc;
+}
+
 int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
@@ -1441,9 +1469,9 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
         // (bounded by what a pass takes: 4 ms; a pipeline lane does not spin at all -- its thread shares the host's cores with
         // the other lanes, the tokeniser's and the formatter's workers, and its pass is a tenth of its transfers)
         if (c->seq_armed && !c->is_lane && getenv("RAFT_NO_SPIN") == nullptr) {
-            const volatile long long *seq = reinterpret_cast<const volatile long long *>(c->pinned) + 128 + kSeqWord;
+            const volatile long long *lines = reinterpret_cast<const volatile long long *>(c->pinned) + 128;
             const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(4);
-            for (int it = 0; !(seen = *seq == c->pass_seq); ++it)
+            for (int it = 0; !(seen = stamped_seen(lines, (int)(sizeof(Ctrl) / 8), c->pass_seq)); ++it)
                 if ((it & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
             std::atomic_thread_fence(std::memory_order_acquire);
         }
@@ -1452,7 +1480,7 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
             const hipError_t q = hipStreamQuery(c->stream);
             if (q != hipSuccess && q != hipErrorNotReady) return fail_hip(c, q, "hipStreamQuery after the pass");
         }
-        auto ctrl_block = [&]() { Ctrl hc; memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl)); return hc; };
+        auto ctrl_block = [&]() { return host_ctrl(c); };
         auto again = [&](const raft_hip_ctx::PassArgs &a) -> int {       // the pass once more, this time nothing assumed
             const int rc = run_pass(c, a, false);
             if (rc != RAFT_HIP_OK) return rc;
@@ -1533,7 +1561,7 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
         }
         if (c->pending_err == RAFT_HIP_OK) {
             Ctrl hc;
-            memcpy(&hc, reinterpret_cast<char *>(c->pinned) + 1024, sizeof(Ctrl));   // copied at the end of the pass
+            hc = host_ctrl(c);   // copied at the end of the pass
             if (c->pass_width != 4) { c->n_exc = (long long)hc.n_exc; c->packed_width = c->pass_width; c->exc_sorted = false; }
             c->sum.n_repeats = hc.out_totals[0]; c->sum.n_cuts = hc.out_totals[1]; c->sum.n_fragments = hc.out_totals[2];
             if (c->sum.interval_path == 1) c->sum.n_intervals = hc.out_totals[3];
@@ -1755,7 +1783,7 @@ static int pack_coverage(raft_hip_ctx *c, int width)
             }
             HIP_TRY(c, hipGetLastError());
         }
-        long long *h = reinterpret_cast<long long *>(c->pinned) + 16;
+        long long *h = reinterpret_cast<long long *>(c->pinned) + kPackCountWord;
         HIP_TRY(c, hipMemcpyAsync(h, c->exc_cnt.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->n_exc = *h; c->exc_sorted = false;

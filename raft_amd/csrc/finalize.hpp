@@ -64,7 +64,9 @@ __device__ void sort_repeats(int32_t *k, int32_t *s, int32_t *e, int n)
 {
     if (n <= 24) {
         for (int i = 1; i < n; ++i) {
-            const int32_t kk = k[i], ss = s[i], ee = e[i];
+            const int32_t kk = k[i];
+            if (k[i - 1] <= kk) continue;         // (in place already -- a read's runs mostly arrive in order: nothing to load or store)
+            const int32_t ss = s[i], ee = e[i];
             int j = i - 1;
             while (j >= 0 && k[j] > kk) { k[j + 1] = k[j]; s[j + 1] = s[j]; e[j + 1] = e[j]; --j; }
             k[j + 1] = kk; s[j + 1] = ss; e[j + 1] = ee;
@@ -158,14 +160,18 @@ __device__ inline void rep_insertion_sort(const RepView &v, int first, int last)
     }
 }
 
-__device__ __noinline__ void rep_std_sort(int32_t *s, int32_t *e, int n)
+// (stk: 3 x 64 ints of the caller's -- LDS in the kernels: as arrays of its own they were 784 bytes of scratch per LANE of
+// finalize_count_kernel, 50 KB per wave whether the wave met such a read or not)
+constexpr int kSortStack = 3 * 64;
+__device__ __noinline__ void rep_std_sort(int32_t *s, int32_t *e, int n, int32_t *stk)
 {
     const RepView v{s, e};
     if (n <= 0) return;
     int lg = 0;
     for (int m = n; m > 1; m >>= 1) ++lg;
     // __introsort_loop: the recursive call (right part) becomes a stack entry; depth <= 2*lg <= 62
-    int stk_first[64], stk_last[64], stk_depth[64], sp = 0;
+    int32_t *const stk_first = stk, *const stk_last = stk + 64, *const stk_depth = stk + 128;
+    int sp = 0;
     stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = 2 * lg; sp = 1;
     while (sp > 0) {
         --sp;
@@ -218,18 +224,31 @@ __device__ __noinline__ void rep_std_sort(int32_t *s, int32_t *e, int n)
 // Walks the candidate markers 0, L, 2L, ..., (+len) of one read (chop.hpp:209-223) and keeps
 // the first, the last, and every marker not inside a flanked repeat [s,e] (chop.hpp:225-246).
 // Calls keep(m) for each kept marker in ascending order; returns their number.
-template <class Keep>
-__device__ __forceinline__ int walk_cuts(int len, int L, const int32_t *s, const int32_t *e, int n, Keep keep)
+// A read's ordered, flanked repeats: in memory, or -- up to four of them, which is nearly every read that has any -- in registers
+// (finalize_fill_kernel asks for them in one batch; one after the other, every repeat a sweep passes was a round trip of its thread)
+struct RepMem {
+    const int32_t *s, *e;
+    __device__ __forceinline__ int S(int k) const { return s[k]; }
+    __device__ __forceinline__ int E(int k) const { return e[k]; }
+};
+struct RepReg {
+    int s0, s1, s2, s3, e0, e1, e2, e3;
+    __device__ __forceinline__ int S(int k) const { return k == 0 ? s0 : k == 1 ? s1 : k == 2 ? s2 : s3; }
+    __device__ __forceinline__ int E(int k) const { return k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3; }
+};
+
+template <class Rep, class Keep>
+__device__ __forceinline__ int walk_cuts(int len, int L, const FastDiv &by_L, const Rep &rep, int n, Keep keep)
 {
-    const int parts = len / L;
-    const int nm = parts + 1 + ((len % L) ? 1 : 0);
+    const int parts = fdiv(by_L, len);
+    const int nm = parts + 1 + ((len - parts * L) ? 1 : 0);
     int kept = 0, k = 0;
     for (int j = 0; j < nm; ++j) {
         const int m = (j <= parts) ? j * L : len;
         bool covered = false;
         if (j > 0 && j < nm - 1) {
-            while (k < n && e[k] < m) ++k;     // repeats are ordered by start and by end
-            covered = (k < n) && (s[k] <= m);
+            while (k < n && rep.E(k) < m) ++k; // repeats are ordered by start and by end
+            covered = (k < n) && (rep.S(k) <= m);
         }
         if (!covered) { keep(m); ++kept; }
     }
@@ -239,16 +258,53 @@ __device__ __forceinline__ int walk_cuts(int len, int L, const int32_t *s, const
 // one read: order (and, for a long read, join) its repeats; count its kept markers and fragments
 // (rep_bp_out: unclamped repeat bases of a read joined from pieces -- repeat.hpp:127,152 -- for the caller to add to the total:
 // one atomic per READ on the one word serialised to 0.4 ms once a human-scale set had 1e4 such reads)
-__device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, int r, int &n_out, int &nF_out, int &nf_out, long long &rep_bp_out)
+// (`live`: the lane has a read; every lane of the wave calls -- the lanes whose read needs the tie order below take turns with the
+// wave's one stack.  stk: kSortStack ints of LDS per wave)
+__device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, bool live, int r, int &n_out, int &nF_out, int &nf_out, long long &rep_bp_out,
+                                                   int32_t *stk)
 {
-    int n = a.rep_cnt[r];
+    n_out = nF_out = nf_out = 0;
+    if (!live) r = 0;                             // (any read: nothing is stored for it)
+    // (the read's three scalars before anything is stored: the sorts below write int32 arrays, which the compiler must assume to
+    // overlap read_len -- a load behind them waits for them)
+    int n = live ? a.rep_cnt[r] : 0;
     const long long base = a.rep_res_off[r];
-    if (n > 1) sort_repeats(a.raw_key + base, a.raw_s + base, a.raw_e + base, n);
-    {
-        const int len = a.read_len[r];
-        const int nbq = fdiv(a.by_reso, len);
-        const int nb = nbq + ((len - nbq * a.reso) ? 1 : 0);
-        if (nb > a.long_windows && n > 0) {
+    const int len = a.read_len[r];
+    const int nbq = fdiv(a.by_reso, len);
+    const int nb = nbq + ((len - nbq * a.reso) ? 1 : 0);
+    const bool pieces = nb > a.long_windows;      // a long read, piled up in pieces
+    // Up to four repeats -- nearly every read that has any: all of them asked for at once and ordered in registers.  (One after
+    // the other through memory, a read's thread made two dependent round trips per repeat -- the ordering's, the sweep's -- and a
+    // wave waits for its slowest lane: the kernel's 46 us at human scale were those chains, not its 80 MB.)
+    const bool few = n >= 1 && n <= 4 && !pieces;
+    int fs[4] = {0, 0, 0, 0}, fe[4] = {0, 0, 0, 0};
+    if (few) {
+        int32_t *K = a.raw_key + base, *S = a.raw_s + base, *E = a.raw_e + base;
+        int fk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int at = min(i, n - 1);
+            fk[i] = K[at]; fs[i] = S[at]; fe[i] = E[at];
+            if (i >= n) fk[i] = 0x7fffffff;       // (sinks behind the read's own)
+        }
+        bool moved = false;
+        auto cx = [&](int x, int y) {
+            if (fk[y] < fk[x]) {
+                int t = fk[x]; fk[x] = fk[y]; fk[y] = t;
+                t = fs[x]; fs[x] = fs[y]; fs[y] = t;
+                t = fe[x]; fe[x] = fe[y]; fe[y] = t;
+                moved = true;
+            }
+        };
+        cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+        if (moved) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < n) { K[i] = fk[i]; S[i] = fs[i]; E[i] = fe[i]; }
+        }
+    } else if (n > 1) sort_repeats(a.raw_key + base, a.raw_s + base, a.raw_e + base, n);
+    if (live) {
+        if (pieces && n > 0) {
             // a long read, piled up in pieces: runs that meet at a piece boundary are one run (repeat.hpp:111-168 on the
             // whole read); then the length test, the flanks and the clamp, as pileup.hpp emit_run_of does for other reads
             int32_t *S = a.raw_s + base, *E = a.raw_e + base, *K = a.raw_key + base;
@@ -273,21 +329,35 @@ __device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, int r,
             rep_bp_out += rep_bp;
         }
     }
-    if (n > 16 && a.raw_s[base + 1] == 0) rep_std_sort(a.raw_s + base, a.raw_e + base, n);   // tied starts: repeat.hpp:170
+    {   // tied starts: repeat.hpp:170
+        unsigned long long need = __ballot(n > 16 && a.raw_s[base + 1] == 0);
+        while (need) {
+            const int l = (int)__builtin_ctzll(need);
+            need &= need - 1ull;
+            if ((int)(threadIdx.x & 63u) == l) rep_std_sort(a.raw_s + base, a.raw_e + base, n, stk);
+        }
+    }
+    if (!live) return;
     // Number of markers walk_cuts() keeps, without walking them: the interior markers are L, 2L, .., J*L; a flanked
     // repeat [s,e] covers the multiples of L inside it; repeats are ordered by start and by end, so the union is
     // counted in one sweep over the read's (few) repeats.
-    const int len = a.read_len[r], L = a.interval_length;
+    const int L = a.interval_length;
     const int parts = fdiv(a.by_L, len);
     const int tail = (len - parts * L) ? 1 : 0;
     const int J = tail ? parts : parts - 1;       // last interior marker is J * L
     int covered = 0, done = 0;                    // multiples 1 .. done are accounted for
-    for (int k = 0; k < n && done < J; ++k) {
-        const int s = a.raw_s[base + k], e = a.raw_e[base + k];
+    auto sweep = [&](int s, int e) {
         int lo = s <= 0 ? 0 : fdiv(a.by_L, s + L - 1);
         lo = max(lo, done + 1);
         const int hi = e < 0 ? -1 : min(fdiv(a.by_L, e), J);
         if (hi >= lo) { covered += hi - lo + 1; done = hi; }
+    };
+    if (few) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < n && done < J) sweep(fs[k], fe[k]);
+    } else {
+        for (int k = 0; k < n && done < J; ++k) sweep(a.raw_s[base + k], a.raw_e[base + k]);
     }
     const int nF = parts + 1 + tail - covered;
     int nf = 1;                                   // chop.hpp:250-276
@@ -297,23 +367,6 @@ __device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, int r,
     n_out = n; nF_out = nF; nf_out = nf;
 }
 
-// finalize_count_one as the loader of the output scan's first pass (device_scan.hpp exclusive_scan2): that pass walks the
-// reads one per thread, coalesced, exactly as finalize_count_kernel does, so the count rides in it for free (one launch
-// less; the second pass re-reads the three counts).
-struct FinalizeCountLoader {
-    FinalizeArgs a;
-    __device__ void operator()(long long i, long long (&v)[3]) const
-    {
-        v[0] = v[1] = v[2] = 0;
-        if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
-        int n, nF, nf;
-        long long bp = 0;
-        finalize_count_one(a, (int)i, n, nF, nf, bp);
-        if (bp) atomicAdd(a.total_repeat, (unsigned long long)bp);
-        v[0] = n; v[1] = nF; v[2] = nf;
-    }
-};
-
 // (Measured and dropped, round 3: a long read's raw runs ordered and joined by its whole wave -- a lane per run, rank by 64
 // compare steps, joined through ballots -- instead of its thread's loops in global memory.  The long reads of a wave then
 // take their turns, where the threads' loops had run side by side: finalize_count 0.11 -> 0.21 ms on the ultralong set.)
@@ -321,10 +374,11 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
+    __shared__ int32_t sort_stk[256 / 64][kSortStack];
     long long bp = 0;
-    if (r < a.n_reads) {
+    {
         int n, nF, nf;
-        finalize_count_one(a, r, n, nF, nf, bp);
+        finalize_count_one(a, r < a.n_reads, r, n, nF, nf, bp, sort_stk[threadIdx.x >> 6]);
     }
     // one atomic per wave that has anything to add
     if (__ballot(bp != 0) != 0ull) {
@@ -337,11 +391,10 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
 // marker: 0.4 GB on the human-scale set) are neither stored nor walked here: fragment j begins at the kept marker
 // with index (j-1)*div and ends at the one with index j*div, the first marker is 0 and the last is the read length.
 // finalize_cuts_kernel materialises them when a caller asks for them.
-__device__ __forceinline__ void finalize_fill_one(const FinalizeArgs &a, int r, long long ro, long long fo, int n, int nF)
+template <class Rep>
+__device__ __forceinline__ void finalize_fill_one(const FinalizeArgs &a, int r, long long ro, long long fo, int n, int nF, int len, const Rep &rep)
 {
-    const long long base = a.rep_res_off[r];
-    for (int i = 0; i < n; ++i) { a.rep_s[ro + i] = a.raw_s[base + i]; a.rep_e[ro + i] = a.raw_e[base + i]; }
-    const int len = a.read_len[r];
+    for (int i = 0; i < n; ++i) { a.rep_s[ro + i] = rep.S(i); a.rep_e[ro + i] = rep.E(i); }
     if (nF <= a.div + 1) {                        // chop.hpp:250-267: the read is kept whole
         a.frag_read[fo] = r; a.frag_begin[fo] = 0; a.frag_end[fo] = len;
         return;
@@ -360,7 +413,7 @@ __device__ __forceinline__ void finalize_fill_one(const FinalizeArgs &a, int r, 
     for (int j = 1; j < nf; ++j) {
         int v = j * a.div + passed;
         while (k < n && done < J) {
-            const int s = a.raw_s[base + k], e = a.raw_e[base + k];
+            const int s = rep.S(k), e = rep.E(k);
             int lo = s <= 0 ? 0 : fdiv(a.by_L, s + L - 1);
             lo = max(lo, done + 1);
             const int hi = e < 0 ? -1 : min(fdiv(a.by_L, e), J);
@@ -391,12 +444,22 @@ __global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_reads) return;
     if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
-    const int n = a.rep_cnt[r];
-    finalize_fill_one(a, r, a.rep_off[r], a.frag_off[r], n, a.cut_cnt[r]);
-    if (CUTS) {
-        int32_t *F = a.cuts + a.cut_off[r];
-        int w = 0;
-        (void)walk_cuts(a.read_len[r], a.interval_length, a.raw_s + a.rep_res_off[r], a.raw_e + a.rep_res_off[r], n, [&](int m) { F[w++] = m; });
+    // everything the read's thread needs, asked for at once: behind the first store a load of an int32 array would wait for the
+    // stores (they may overlap, as far as the compiler knows), and a thread's time here is its chain of dependent loads
+    const int n = a.rep_cnt[r], nF = a.cut_cnt[r], len = a.read_len[r];
+    const long long ro = a.rep_off[r], fo = a.frag_off[r], base = a.rep_res_off[r], co = CUTS ? a.cut_off[r] : 0;
+    int32_t *F = a.cuts + co;
+    int w = 0;
+    if (n >= 1 && n <= 4) {
+        const int32_t *S = a.raw_s + base, *E = a.raw_e + base;
+        const int i1 = min(1, n - 1), i2 = min(2, n - 1), i3 = n - 1;
+        const RepReg rep{S[0], S[i1], S[i2], S[i3], E[0], E[i1], E[i2], E[i3]};
+        finalize_fill_one(a, r, ro, fo, n, nF, len, rep);
+        if (CUTS) (void)walk_cuts(len, a.interval_length, a.by_L, rep, n, [&](int m) { F[w++] = m; });
+    } else {
+        const RepMem rep{a.raw_s + base, a.raw_e + base};
+        finalize_fill_one(a, r, ro, fo, n, nF, len, rep);
+        if (CUTS) (void)walk_cuts(len, a.interval_length, a.by_L, rep, n, [&](int m) { F[w++] = m; });
     }
 }
 
@@ -413,14 +476,43 @@ __global__ __launch_bounds__(256) void finalize_cuts_kernel(FinalizeArgs a)
     if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
     int32_t *F = a.cuts + a.cut_off[r];
     int w = 0;
-    (void)walk_cuts(a.read_len[r], a.interval_length, a.raw_s + a.rep_res_off[r], a.raw_e + a.rep_res_off[r], a.rep_cnt[r],
+    (void)walk_cuts(a.read_len[r], a.interval_length, a.by_L, RepMem{a.raw_s + a.rep_res_off[r], a.raw_e + a.rep_res_off[r]}, a.rep_cnt[r],
                     [&](int m) { F[w++] = m; });
 }
 
 // totals[0] = sum coverage, [1] = sum unclamped repeat bp, [2] = sum read length.  One atomic per workgroup and
 // total (a few hundred per launch): with one per wave the three counters saw 12 k serialised atomics and the kernel
 // took 56 us for 13 MB of input.
-constexpr int kSeqWord = 256;     // (in 8-byte words behind the control block's copy in the page-locked block)
+// What the host reads back without the runtime's wait travels in STAMPED LINES: 64 bytes of the context's page-locked block hold six
+// 8-byte data words and, in words 3 and 7, the number of the hand-over; one store instruction of the wave writes all lines, and a
+// line (at the least each 32-byte half of it) arrives whole.  The host takes a line when both stamps are the number it waits for.
+// (Round 4's form -- the words, a system-scope fence, then the number in a word of its own -- is NOT safe: stores to host memory
+// are posted writes that may pass each other.  tools/r05/s27.sh: the sizes hand-over read that way gave a stale window count in
+// 1 of 25 runs of the parity tests; none in 25 with the runtime's wait.)
+constexpr int kStampData = 6;
+__host__ __device__ constexpr int stamped_lines(int n_words) { return (n_words + kStampData - 1) / kStampData; }
+// lane t of one wave (0 .. 63) stores its word of the stamped form of src(0 .. n_words - 1); n_words <= 48
+template <class Src>
+__device__ __forceinline__ void publish_stamped(long long *host, Src src, int n_words, long long seq, int t)
+{
+    const int line = t >> 3, pos = t & 7;
+    long long v = seq;
+    if ((pos & 3) != 3) {
+        const int idx = line * kStampData + (pos < 3 ? pos : pos - 1);
+        v = idx < n_words ? src(idx) : 0;
+    }
+    if (line < stamped_lines(n_words)) host[t] = v;
+}
+inline bool stamped_seen(const volatile long long *h, int n_words, long long seq)
+{
+    for (int line = 0; line < stamped_lines(n_words); ++line)
+        if (h[line * 8 + 3] != seq || h[line * 8 + 7] != seq) return false;
+    return true;
+}
+inline void unstamp(const volatile long long *h, int n_words, long long *out)
+{
+    for (int i = 0; i < n_words; ++i) { const int pos = i % kStampData; out[i] = h[(i / kStampData) * 8 + (pos < 3 ? pos : pos + 1)]; }
+}
 __global__ __launch_bounds__(256) void totals_kernel(long long n_tiles, const long long *tile_sums, int32_t n_reads,
                                                      const int32_t *read_len, unsigned long long *totals,
                                                      const long long *rep_off, const long long *cut_off,
@@ -437,7 +529,17 @@ __global__ __launch_bounds__(256) void totals_kernel(long long n_tiles, const lo
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (long long i = i0; i < n_tiles; i += stride) { c += tile_sums[2 * i]; rp += tile_sums[2 * i + 1]; }
-    for (long long i = i0; i < n_reads; i += stride) l += read_len[i];
+    {   // (eight loads in flight per thread: one after the other, a thread's 25 strides of a human-scale set were the kernel's 20 us)
+        long long i = i0;
+        for (; i + 7 * stride < n_reads; i += 8 * stride) {
+            int32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = read_len[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) l += v[u];
+        }
+        for (; i < n_reads; i += stride) l += read_len[i];
+    }
     c = wave_reduce_add64(c); rp = wave_reduce_add64(rp); l = wave_reduce_add64(l);
     const int wid = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { part[0][wid] = c; part[1][wid] = rp; part[2][wid] = l; }
@@ -457,11 +559,10 @@ __global__ __launch_bounds__(256) void totals_kernel(long long n_tiles, const lo
     __syncthreads();
     if (last && (int)threadIdx.x < 64) {
         __threadfence();
-        if ((int)threadIdx.x < n_ctrl_words) host_block[threadIdx.x] = reinterpret_cast<const volatile long long *>(ctrl_words)[threadIdx.x];
-        __threadfence_system();
-        // ... and then the pass's number, behind the block: raft_hip_finish spins on it instead of sleeping in the runtime's wait
+        // ... stamped with the pass's number: raft_hip_finish looks for it itself instead of sleeping in the runtime's wait
         // (whose wake-up is 20-30 us of a pass that may take 200)
-        if (threadIdx.x == 0) { host_block[kSeqWord] = pass_seq; __threadfence_system(); }
+        publish_stamped(host_block, [&](int i) { return reinterpret_cast<const volatile long long *>(ctrl_words)[i]; }, n_ctrl_words, pass_seq, (int)threadIdx.x);
+        __threadfence_system();
     }
 }
 

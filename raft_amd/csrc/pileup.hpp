@@ -148,7 +148,8 @@ struct PileupArgs {
 
 // Coarse index of the record stream (bucket.hpp guess_runs_kernel writes it, tile_desc_kernel reads it): the read id of
 // every 2^sh-th record and of the last one, with sh the smallest shift that leaves at most kSamples strides.
-constexpr int kGuessBlocks = 64;                           // x 256 threads: one sample per thread
+constexpr int kGuessBlocks = 1024;                         // x 256 threads: one sample per thread (64 blocks, 16 k samples until round 5:
+                                                           // tile_desc_kernel's time is the lines its probes BEHIND the samples pull in)
 constexpr int kSamples = kGuessBlocks * 256;
 __host__ __device__ __forceinline__ int sample_shift(long long n)
 {
@@ -899,30 +900,52 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
         }
     }
     // Before bisecting the record stream itself: the counting sort's own offsets answer directly; on the sorted-segment
-    // path the 16 k samples guess_runs_kernel kept (a coarse index, cache-resident) are bisected first, which leaves the
-    // ~9 k records between two samples -- 13 probes into one or two pages instead of 28 all over a GB-sized column.
+    // path the 256 k samples guess_runs_kernel kept (a coarse index, cache-resident) are bisected first, which leaves the
+    // ~1 k records between two samples -- 10 probes into a handful of lines instead of 28 all over a GB-sized column.
     if (bucket_off) {
 #pragma unroll
         for (int q = 0; q < 2 * kMaxSeg; ++q)
             if (blo[q] < bhi[q]) blo[q] = bhi[q] = bucket_off[q < kMaxSeg ? d.r_lo : d.r_hi];
     } else if (samples) {
+        // (all searches of a thread advance together here too: one after the other, the wave waited for its last lane, which has
+        // twice the searches.  Measured and dropped, round 5: EIGHT ways a round, seven probes at the eighths of what is left, here
+        // and in the record stream below -- a third of the rounds and 109 us instead of 74: the kernel's time is the number of
+        // lines its probes pull in, not the length of a thread's chain.  What helps is a finer index: kSamples.)
         const int sh = sample_shift(n_rec);
+        int sx[2 * kMaxSeg], sy[2 * kMaxSeg], sjl[2 * kMaxSeg], sjh[2 * kMaxSeg];
 #pragma unroll
         for (int q = 0; q < 2 * kMaxSeg; ++q) {
+            sx[q] = sy[q] = sjl[q] = 0; sjh[q] = -1;
             if (blo[q] < bhi[q]) {
-                const int key = q < kMaxSeg ? d.r_lo : d.r_hi;
                 // samples inside this run: jl = first at or after its start, jh = last before its end (the closing sample
                 // n_samples - 1 repeats the last record and is not needed: the run's own end bounds the search)
-                const long long jl = (blo[q] + (1LL << sh) - 1) >> sh, jh = (bhi[q] - 1) >> sh;
-                if (jl <= jh) {
-                    long long x = jl, y = jh + 1;          // first sample in [jl, jh] with an id >= key, or jh + 1
-                    while (x < y) {
-                        const long long m = (x + y) >> 1;
-                        if (samples[m] < key) x = m + 1; else y = m;
-                    }
-                    if (x > jl) blo[q] = ((x - 1) << sh) + 1;
-                    if (x <= jh) bhi[q] = x << sh;
+                sjl[q] = (int)((blo[q] + (1LL << sh) - 1) >> sh); sjh[q] = (int)((bhi[q] - 1) >> sh);
+                if (sjl[q] <= sjh[q]) { sx[q] = sjl[q]; sy[q] = sjh[q] + 1; }   // first sample in [jl, jh] with an id >= key, or jh + 1
+            }
+        }
+        for (;;) {
+            int v[2 * kMaxSeg];
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 2 * kMaxSeg; ++q) {
+                v[q] = 0;
+                if (sx[q] < sy[q]) { v[q] = samples[(sx[q] + sy[q]) >> 1]; any = true; }
+            }
+            if (!any) break;
+#pragma unroll
+            for (int q = 0; q < 2 * kMaxSeg; ++q) {
+                if (sx[q] < sy[q]) {
+                    const int m = (sx[q] + sy[q]) >> 1;
+                    if (v[q] < (q < kMaxSeg ? d.r_lo : d.r_hi)) sx[q] = m + 1; else sy[q] = m;
                 }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * kMaxSeg; ++q) {
+            if (blo[q] < bhi[q] && sjl[q] <= sjh[q]) {
+                const long long x = sx[q];
+                if (x > sjl[q]) blo[q] = ((x - 1) << sh) + 1;
+                if (x <= sjh[q]) bhi[q] = x << sh;
             }
         }
     }

@@ -164,6 +164,13 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             }
         }
         if (tables && idx < a.n_reads) rd.rl = a.read_len[idx];
+        // The record slots: raw buffer loads from a descriptor per column and run that begins at the tile's first record and ends
+        // with the range -- the lane's part of the address is a constant (lane * 4 + the slot's 256 bytes), the tile's part is in the
+        // descriptor, and so is the end of the range (a lane beyond it gets 0 and touches no memory; every use of a slot is masked
+        // by the tile's count).  As plain loads a slot cost a 64-bit add and compare, three 64-bit address computations, three
+        // selects and an exec mask -- ~70 of a tile's ~1600 vector instructions, in a kernel whose vector pipe is busy two thirds of
+        // the time (SQ counters, round 5).  (No scalar offset: the hardware's range check does not look at it.)
+#ifdef RAFT_W_NOBUF
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int s = u % NSEG, first = (u / NSEG) * 64;
@@ -174,6 +181,29 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             } else {
                 g.rid[u] = 0x7fffffff; g.st[u] = 0; g.en[u] = 0;
                 if (at < pend[s]) { g.rid[u] = a.iv_rid[at]; g.st[u] = a.iv_s[at]; g.en[u] = a.iv_e[at]; }
+            }
+        }
+        return;
+#endif
+        const int lane4 = lane * 4;
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+            const int p0 = uni(t.pos[s]);        // (uniform by construction; said again so that the descriptors are built in scalar registers)
+            const unsigned bytes = (unsigned)uni(min(max(pend[s] - p0, 0), 64 * ITER)) * 4u;    // (the clamp is a vector instruction)
+            if (IN == 1) {
+                const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_w + p0), 0, bytes, 0x00020000);
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) g.st[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, 0);
+            } else {
+                const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_rid + p0), 0, bytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_s + p0), 0, bytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_e + p0), 0, bytes, 0x00020000);
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    g.rid[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(rr, lane4 + it * 256, 0, 0);
+                    g.st[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + it * 256, 0, 0);
+                    g.en[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(re, lane4 + it * 256, 0, 0);
+                }
             }
         }
     };
@@ -368,7 +398,9 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
 
         // ---- 1. intervals -> +1 / -1 on 16-bit slots
         int covsum = 0;
-        bool bad_any = false, bad_order = false;
+        // (as lane masks in scalar registers: as per-lane flags carried across the slots' branches they were five vector
+        // instructions a slot)
+        unsigned long long bad_any = 0ull, bad_order = 0ull;
         auto add_pm = [&](int pf, int pl1) {
             const unsigned vp = 1u << ((pf & 1) << 4), vm = 0u - (1u << ((pl1 & 1) << 4));
             if (kMode & 4) { covsum += pl1 - pf + (int)vp + (int)vm; return; }      // (diagnostic: no scatter)
@@ -382,14 +414,16 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             auto one = [&](int rid, int st, int en, bool mine) {
                 const unsigned jr = (unsigned)(rid - r_a);
                 const unsigned j = min(jr, (unsigned)nr);
-                const int b0 = sm.roff[j], nb_r = sm.roff[(j + 1u) & 63u] - b0;
+                // (j + 1 <= 64: entry 64 is rcnt[0], read only for a record that is not the tile's -- j == nr == 63 -- whose values are
+                // not used; unmasked, the two entries are one ds_read2)
+                const int b0 = sm.roff[j], nb_r = sm.roff[j + 1u] - b0;
                 const int first = win((unsigned)st);
                 const int last1 = win((unsigned)(en - 1)) + 1;
                 const bool valid = mine && jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
                 const bool over = last1 > first && last1 > nb_r;
                 const int pf = max(b0 + first, off0), pl1 = min(b0 + min(last1, nb_r), t_end);
-                bad_any |= valid && (!sign_ok || (pos && over));
-                bad_order |= mine && !valid;
+                bad_any |= __ballot(valid && (!sign_ok || (pos && over)));
+                bad_order |= __ballot(mine && !valid);
                 if (valid && sign_ok && pos && pf < pl1) add_pm(pf, pl1);
             };
 #pragma unroll
@@ -425,8 +459,8 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) cur.n_total += cur.cnt[s];
             }
-            if (__ballot(bad_order) != 0ull && lane == 0) atomicOr(a.err_flags, kErrOrder);
-            if (__ballot(bad_any) != 0ull) {         // rare: find the offending records again and report the first index
+            if (bad_order != 0ull && lane == 0) atomicOr(a.err_flags, kErrOrder);
+            if (bad_any != 0ull) {         // rare: find the offending records again and report the first index
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) {
                     const long long base = (long long)cur.lo[s];
@@ -443,6 +477,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         } else {
             // window records: (first window, one past the last) in one word; the read from the caller's offsets.  Boundary
             // lane + 1 of a run: where the records of read r_a + lane + 1 begin (relative to the tile's first record of the run)
+            bool bad_w = false;
             int bnd[NSEG];
 #pragma unroll
             for (int s = 0; s < NSEG; ++s) {
@@ -454,7 +489,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 const int first = (int)(w & 0xffffu), last1 = (int)(w >> 16);
                 const bool over = last1 > first && last1 > nb_r;
                 const int pf = max(b0 + first, off0), pl1 = min(b0 + min(last1, nb_r), t_end);
-                bad_any |= over;
+                bad_w |= over;
                 if (pf < pl1) add_pm(pf, pl1);
             };
             auto read_of = [&](int s, int i0, int i) -> int {   // read of record i of run s; the wave's records are [i0, i0 + 64)
@@ -484,7 +519,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                     }
                 }
             }
-            if (__ballot(bad_any) != 0ull) {
+            if (__ballot(bad_w) != 0ull) {
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) {
                     const long long base = (long long)cur.lo[s];
@@ -567,8 +602,14 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             constexpr uint64_t kZero2 = ((uint64_t)kZero << 32) | kZero;
             reinterpret_cast<uint64_t *>(sm.diff)[row * 128 + lane] = kZero2;
             reinterpret_cast<uint64_t *>(sm.diff)[row * 128 + 64 + lane] = kZero2;
-            // (bias off: two independent 16-bit steps per dword from here on)
+            // (the bias stays on: 0x8000 in the low half of every dword.  A lane's two dwords of a half-row carry two of them, which
+            // cancel modulo 2^16 from the lane's third slot on -- the lanes' totals, the scan and the carry never see them -- and the
+            // first two slots lose theirs with the start value: one xor per row instead of four)
+#ifdef RAFT_W_NOBIAS
             const unsigned dA0 = (unsigned)cA ^ kZero, dA1 = (unsigned)(cA >> 32) ^ kZero, dB0 = (unsigned)cB ^ kZero, dB1 = (unsigned)(cB >> 32) ^ kZero;
+#else
+            const unsigned dA0 = (unsigned)cA, dA1 = (unsigned)(cA >> 32), dB0 = (unsigned)cB, dB1 = (unsigned)(cB >> 32);
+#endif
             // in-lane prefix of each half-row's four slots (packed, modulo 2^16 per half)
             const unsigned qA0 = dA0 + (dA0 << 16), qB0 = dB0 + (dB0 << 16);
             const unsigned qA1 = pk_add_bcast<true>(dA1 + (dA1 << 16), qA0), qB1 = pk_add_bcast<true>(dB1 + (dB1 << 16), qB0);
@@ -580,55 +621,93 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             // start values: low half = carry + lanes before in half-row A; high half = carry + all of A + lanes before in B
             const unsigned E = (unsigned)(incl - V) + (unsigned)carry * 0x10001u + ((unsigned)totA << 16);
             carry += totA + totB;
-            const unsigned rA0 = pk_add_bcast<false>(qA0, E), rA1 = pk_add_bcast<false>(qA1, E);
-            const unsigned rB0 = pk_add_bcast<true>(qB0, E), rB1 = pk_add_bcast<true>(qB1, E);
+#ifdef RAFT_W_NOBIAS
+            const unsigned E0 = E;
+#else
+            const unsigned E0 = E ^ 0x80008000u;
+#endif
+            const unsigned rA0 = pk_add_bcast<false>(qA0, E0), rA1 = pk_add_bcast<false>(qA1, E);
+            const unsigned rB0 = pk_add_bcast<true>(qB0, E0), rB1 = pk_add_bcast<true>(qB1, E);
             const int pA = base + lane * 4, pB = base + 256 + lane * 4;        // this lane's first slot in each half-row
             const unsigned mx = pk_max_u16(pk_max_u16(rA0, rA1), pk_max_u16(rB0, rB1));
             const bool full = base >= off0 && base + 512 <= t_end;              // every slot of the row is a window of the tile
             // ---- store
-            auto store_half = [&](unsigned r0, unsigned r1, int p0, unsigned d0, unsigned d1) {
+            // (a full row's stores: the lane's part of the address is a constant -- lane * 4 windows -- and the half-row's a scalar)
+            const int hbase = base;
+            auto store_half = [&](unsigned r0, unsigned r1, int p0, unsigned d0, unsigned d1, int h) {
                 const unsigned c0 = r0 & 0xffffu, c1 = r0 >> 16, c2 = r1 & 0xffffu, c3 = r1 >> 16;
+                // (one register for both halves: the half's 256 windows go with the row's scalar.  NOT for the 16-byte stores of int32
+                // coverage: a buffer store of more than 8 bytes whose offset comes from a scalar register may still be reading its data
+                // registers when the next vector instruction overwrites them -- the compiler pads that hazard only for the form without
+                // the scalar offset, and the pass stored the next half-row's packed words into 155 of 444,741 windows of a test set.
+                // There the row goes into the lane's offset, one v_lshl_or per row.)
+                const int lane_w = OW == 4 ? lane * 4 + hbase + h * 256 : lane * 4;
+                const int base = OW == 4 ? 0 : hbase + h * 256;
                 if (OW == 4) {
-                    int32_t *o = cov0 + p0;
-                    if (full) __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)c0, (int)c1, (int)c2, (int)c3}, rsrc, p0 * 4, 0, 0);
-                    else {
+                    if (full) __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)c0, (int)c1, (int)c2, (int)c3}, rsrc, lane_w * 4, base * 4, 0);
+                    else {      // (a tile's first and last row: the same addressing, element by element where the lane straddles the edge)
                         const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
                         const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
-                        if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)c0, (int)c1, (int)c2, (int)c3}, rsrc, p0 * 4, 0, 0);
-                        else { if (v0) o[0] = (int)c0; if (v1) o[1] = (int)c1; if (v2) o[2] = (int)c2; if (v3) o[3] = (int)c3; }
+                        if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)c0, (int)c1, (int)c2, (int)c3}, rsrc, lane_w * 4, base * 4, 0);
+                        else {
+                            if (v0) __builtin_amdgcn_raw_buffer_store_b32((int)c0, rsrc, lane_w * 4, base * 4, 0);
+                            if (v1) __builtin_amdgcn_raw_buffer_store_b32((int)c1, rsrc, lane_w * 4 + 4, base * 4, 0);
+                            if (v2) __builtin_amdgcn_raw_buffer_store_b32((int)c2, rsrc, lane_w * 4 + 8, base * 4, 0);
+                            if (v3) __builtin_amdgcn_raw_buffer_store_b32((int)c3, rsrc, lane_w * 4 + 12, base * 4, 0);
+                        }
                     }
                 } else if (OW == 1 || OW == 2) {
                     // (the windows at or above the limit are listed once per row, below: the common row has none)
                     const unsigned m0 = pk_min_u16(r0, kLimit * 0x10001u), m1 = pk_min_u16(r1, kLimit * 0x10001u);
                     if (full) {
-                        if (OW == 1) __builtin_amdgcn_raw_buffer_store_b32((int)__builtin_amdgcn_perm(m1, m0, 0x06040200u), rsrc, p0, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, p0 * 2, 0, 0);
+                        if (OW == 1) __builtin_amdgcn_raw_buffer_store_b32((int)__builtin_amdgcn_perm(m1, m0, 0x06040200u), rsrc, lane_w, base, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, lane_w * 2, base * 2, 0);
                     } else {
                         const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
                         const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
-                        if (OW == 1) {
+                        // (window records: the edge rows' element stores by the same addressing as the full rows'; with coordinate columns
+                        // in, the registers that takes are the ones the kernel does not have: 12 bytes of scratch)
+                        if (IN == 0 && OW == 1) {
                             uint8_t *o = reinterpret_cast<uint8_t *>(covp0) + p0;
                             const unsigned pk4 = __builtin_amdgcn_perm(m1, m0, 0x06040200u);
                             if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b32((int)pk4, rsrc, p0, 0, 0);
                             else { if (v0) o[0] = (uint8_t)pk4; if (v1) o[1] = (uint8_t)(pk4 >> 8); if (v2) o[2] = (uint8_t)(pk4 >> 16); if (v3) o[3] = (uint8_t)(pk4 >> 24); }
-                        } else {
+                        } else if (IN == 0) {
                             uint16_t *o = reinterpret_cast<uint16_t *>(covp0) + p0;
                             if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, p0 * 2, 0, 0);
                             else { if (v0) o[0] = (uint16_t)m0; if (v1) o[1] = (uint16_t)(m0 >> 16); if (v2) o[2] = (uint16_t)m1; if (v3) o[3] = (uint16_t)(m1 >> 16); }
+                        } else if (OW == 1) {
+                            const unsigned pk4 = __builtin_amdgcn_perm(m1, m0, 0x06040200u);
+                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b32((int)pk4, rsrc, lane_w, base, 0);
+                            else {
+                                if (v0) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pk4, rsrc, lane_w, base, 0);
+                                if (v1) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(pk4 >> 8), rsrc, lane_w + 1, base, 0);
+                                if (v2) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(pk4 >> 16), rsrc, lane_w + 2, base, 0);
+                                if (v3) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(pk4 >> 24), rsrc, lane_w + 3, base, 0);
+                            }
+                        } else {
+                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, lane_w * 2, base * 2, 0);
+                            else {
+                                if (v0) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)m0, rsrc, lane_w * 2, base * 2, 0);
+                                if (v1) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(m0 >> 16), rsrc, lane_w * 2 + 2, base * 2, 0);
+                                if (v2) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)m1, rsrc, lane_w * 2 + 4, base * 2, 0);
+                                if (v3) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(m1 >> 16), rsrc, lane_w * 2 + 6, base * 2, 0);
+                            }
                         }
                     }
                 } else {
                     // four-bit steps: a step IS the difference array's value; the lane's four steps are one aligned ushort
-                    if (full && base > off0) {
+                    if (full && hbase > off0) {
                         // the common row (every slot a window of the tile, none of them its first): the four codes by packed
                         // arithmetic -- step + 7 clamped to 15 per half (a step outside [-7, 7] wraps or exceeds: 15), + 1 modulo 16 makes
                         // 1 .. 15 of a step that fits and 0, "listed", of one that does not; two shifts put the nibbles side by side
-                        const unsigned m0 = pk_min_u16(pk_add_u16(d0, 0x00070007u), 0x000f000fu), m1 = pk_min_u16(pk_add_u16(d1, 0x00070007u), 0x000f000fu);
+                        // (d0 / d1 still carry the array's bias in their low halves: taken off with the + 7)
+                        const unsigned m0 = pk_min_u16(pk_add_u16(d0, 0x00078007u), 0x000f000fu), m1 = pk_min_u16(pk_add_u16(d1, 0x00078007u), 0x000f000fu);
                         const unsigned k0 = pk_add_u16(m0, 0x00010001u) & 0x000f000fu, k1 = pk_add_u16(m1, 0x00010001u) & 0x000f000fu;
                         const unsigned code = ((k0 | (k0 >> 12)) & 0xffu) | (((k1 | (k1 >> 12)) & 0xffu) << 8);
                         *reinterpret_cast<uint16_t *>(covp0 + ((unsigned)p0 >> 1)) = (uint16_t)code;
                         if ((((unsigned)a0 + (unsigned)p0 + (unsigned)a.d4_shift) & 1023u) == 0u)
-                            a.cov_anchor[(a0 + p0 + a.d4_shift) >> 10] = (int)c0 - (int)(short)d0;
+                            a.cov_anchor[(a0 + p0 + a.d4_shift) >> 10] = (int)c0 - (int)(short)(d0 ^ kZero);
                         unsigned t = code | (code >> 1);
                         t |= t >> 2;
                         unsigned esc = ~t & 0x1111u;                                  // bit 4q: window q of this lane is listed
@@ -649,7 +728,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                         }
                         return;
                     }
-                    const int s0 = (int)(short)d0, s1 = (int)d0 >> 16, s2 = (int)(short)d1, s3 = (int)d1 >> 16;
+                    const int s0 = (int)(short)(d0 ^ kZero), s1 = (int)d0 >> 16, s2 = (int)(short)(d1 ^ kZero), s3 = (int)d1 >> 16;
                     const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
                     const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
                     const unsigned valid = full ? 15u : ((v0 ? 1u : 0u) | (v1 ? 2u : 0u) | (v2 ? 4u : 0u) | (v3 ? 8u : 0u));
@@ -697,8 +776,8 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 }
             };
             if (!(kMode & 8)) {                  // (diagnostic: no coverage stores)
-                store_half(rA0, rA1, pA, dA0, dA1);
-                store_half(rB0, rB1, pB, dB0, dB1);
+                store_half(rA0, rA1, pA, dA0, dA1, 0);
+                store_half(rB0, rB1, pB, dB0, dB1, 1);
             }
             // windows at or above a byte's limit (a 16-bit tile's values are below 32768: the two-byte encoding's 65535 is never
             // reached here): ONE test per row on the packed maximum, c + (0x8000 - limit) has bit 15 set <=> c >= limit
