@@ -273,36 +273,10 @@ __device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, bool l
     const int nbq = fdiv(a.by_reso, len);
     const int nb = nbq + ((len - nbq * a.reso) ? 1 : 0);
     const bool pieces = nb > a.long_windows;      // a long read, piled up in pieces
-    // Up to four repeats -- nearly every read that has any: all of them asked for at once and ordered in registers.  (One after
-    // the other through memory, a read's thread made two dependent round trips per repeat -- the ordering's, the sweep's -- and a
-    // wave waits for its slowest lane: the kernel's 46 us at human scale were those chains, not its 80 MB.)
-    const bool few = n >= 1 && n <= 4 && !pieces;
-    int fs[4] = {0, 0, 0, 0}, fe[4] = {0, 0, 0, 0};
-    if (few) {
-        int32_t *K = a.raw_key + base, *S = a.raw_s + base, *E = a.raw_e + base;
-        int fk[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int at = min(i, n - 1);
-            fk[i] = K[at]; fs[i] = S[at]; fe[i] = E[at];
-            if (i >= n) fk[i] = 0x7fffffff;       // (sinks behind the read's own)
-        }
-        bool moved = false;
-        auto cx = [&](int x, int y) {
-            if (fk[y] < fk[x]) {
-                int t = fk[x]; fk[x] = fk[y]; fk[y] = t;
-                t = fs[x]; fs[x] = fs[y]; fs[y] = t;
-                t = fe[x]; fe[x] = fe[y]; fe[y] = t;
-                moved = true;
-            }
-        };
-        cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
-        if (moved) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < n) { K[i] = fk[i]; S[i] = fs[i]; E[i] = fe[i]; }
-        }
-    } else if (n > 1) sort_repeats(a.raw_key + base, a.raw_s + base, a.raw_e + base, n);
+    // (Measured and dropped, round 5: up to four repeats asked for at once, ordered by a network in registers and swept from there --
+    // 48.1 against 45.7 us at human scale, 102.7 against 100.2 on the ultralong set: nearly every wave holds a read with a repeat or
+    // two, so every wave executed the network; the kernel's time is the instructions its waves execute, not its threads' chains.)
+    if (n > 1) sort_repeats(a.raw_key + base, a.raw_s + base, a.raw_e + base, n);
     if (live) {
         if (pieces && n > 0) {
             // a long read, piled up in pieces: runs that meet at a piece boundary are one run (repeat.hpp:111-168 on the
@@ -352,13 +326,7 @@ __device__ __forceinline__ void finalize_count_one(const FinalizeArgs &a, bool l
         const int hi = e < 0 ? -1 : min(fdiv(a.by_L, e), J);
         if (hi >= lo) { covered += hi - lo + 1; done = hi; }
     };
-    if (few) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < n && done < J) sweep(fs[k], fe[k]);
-    } else {
-        for (int k = 0; k < n && done < J; ++k) sweep(a.raw_s[base + k], a.raw_e[base + k]);
-    }
+    for (int k = 0; k < n && done < J; ++k) sweep(a.raw_s[base + k], a.raw_e[base + k]);
     const int nF = parts + 1 + tail - covered;
     int nf = 1;                                   // chop.hpp:250-276
     if (nF > a.div + 1) nf = fdiv(a.by_div, nF - 1 + a.div - 1);
@@ -450,10 +418,11 @@ __global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
     const long long ro = a.rep_off[r], fo = a.frag_off[r], base = a.rep_res_off[r], co = CUTS ? a.cut_off[r] : 0;
     int32_t *F = a.cuts + co;
     int w = 0;
-    if (n >= 1 && n <= 4) {
+    if (n <= 4) {                                 // (the reads without a repeat too: one instruction stream for nearly every wave)
         const int32_t *S = a.raw_s + base, *E = a.raw_e + base;
-        const int i1 = min(1, n - 1), i2 = min(2, n - 1), i3 = n - 1;
-        const RepReg rep{S[0], S[i1], S[i2], S[i3], E[0], E[i1], E[i2], E[i3]};
+        const int i0 = n > 0 ? 0 : -1, i1 = min(1, n - 1), i2 = min(2, n - 1), i3 = n - 1;
+        auto at = [&](const int32_t *p, int i) { return i >= 0 ? p[i] : 0; };
+        const RepReg rep{at(S, i0), at(S, i1), at(S, i2), at(S, i3), at(E, i0), at(E, i1), at(E, i2), at(E, i3)};
         finalize_fill_one(a, r, ro, fo, n, nF, len, rep);
         if (CUTS) (void)walk_cuts(len, a.interval_length, a.by_L, rep, n, [&](int m) { F[w++] = m; });
     } else {
