@@ -987,12 +987,14 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     // the room left above Q has to follow the read lengths or most tiles of a long-read set overflow the LDS window
     // (measured optima, mean windows per read -> room: 600 -> 1.7 k, 1200 -> 2.7 k, 3000 -> 3.9 k of a 7936-window tile).
     int Q = c->tile_q ? std::min(c->tile_q, pv.cap) : pv.cap - pv.short_max;
-    // (wave tiles: the quantum only says which thread of tile_desc_kernel walks which reads -- four tiles' worth each)
+    // (wave tiles: the quantum only says which thread of tile_desc_kernel walks which reads -- three tiles' worth each)
     if (wave) {
-        // four tiles' worth, but never so few quantum tiles that workers stay without one (a 50 k-read set) or that the last draws
+        // three tiles' worth (four until round 5: the kernel likes short ranges -- 2.42 / 2.45 / 2.49 / 2.56 ms at two / three / four /
+        // eight tiles' worth in one context -- and tile_desc_kernel long ones; the pass is shortest at three, profiles/r05_quantum_sweep.txt),
+        // but never so few quantum tiles that workers stay without one (a 50 k-read set) or that the last draws
         // of the kernel are a fifth of its duration (an eighth of the human-scale set: two tiles' worth)
-        const long long q4 = 4LL * (pv.cap / 128) * 128, q1 = (pv.cap / 128) * 128;
-        Q = c->tile_q ? std::max(256, c->tile_q) : (int)std::max(q1, std::min(q4, (B / (8LL * wave_grid_waves(true))) / 128 * 128));
+        const long long q3 = 3LL * (pv.cap / 128) * 128, q1 = (pv.cap / 128) * 128;
+        Q = c->tile_q ? std::max(256, c->tile_q) : (int)std::max(q1, std::min(q3, (B / (8LL * wave_grid_waves(true))) / 128 * 128));
     }
     if (!c->tile_q && pv.fast == 1 && N > 0) {
         const double mean_w = (double)B / (double)N;

@@ -91,6 +91,12 @@ __device__ __forceinline__ int wave_shl1(int v, int last)      // lane l takes l
 // lanes were merged into a 12-byte plus a 4-byte store per half-row: twice the store instructions, none of them a whole
 // 16 bytes -- the int32 pass took 3.2 ms where the byte pass took 1.9.  Inline asm stores are not an option either: the
 // compiler does not pad the wait states behind them and overwrote their data registers.)
+// The int32 coverage stores are NON-TEMPORAL (aux bit 1, `nt`): the kernel never reads a coverage line again, and lines stored that
+// way are the first to leave the L2 -- the record columns and per-read tables that neighbouring tiles share stay a little longer.
+// Three processes each, `profiles/r05_store_policy_ab.txt`: ultralong columns 2.65 -> 2.58 ms every time, headline 2.04-2.07 where plain
+// stores gave 2.05-2.22, the pass 1.5 % shorter.  Write-through (`sc1`: the line is dropped from the L2 at once) fetched 8 % less
+// and took 12 % longer; the packed encodings (a quarter / an eighth of the bytes) gain nothing from `nt` and stay plain.
+template <int OW> struct CovAux { static constexpr int v = OW == 4 ? 2 : 0; };
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
@@ -644,24 +650,24 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 const int lane_w = OW == 4 ? lane * 4 + hbase + h * 256 : lane * 4;
                 const int base = OW == 4 ? 0 : hbase + h * 256;
                 if (OW == 4) {
-                    if (full) __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)c0, (int)c1, (int)c2, (int)c3}, rsrc, lane_w * 4, base * 4, 0);
+                    if (full) __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)c0, (int)c1, (int)c2, (int)c3}, rsrc, lane_w * 4, base * 4, CovAux<OW>::v);
                     else {      // (a tile's first and last row: the same addressing, element by element where the lane straddles the edge)
                         const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
                         const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
-                        if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)c0, (int)c1, (int)c2, (int)c3}, rsrc, lane_w * 4, base * 4, 0);
+                        if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)c0, (int)c1, (int)c2, (int)c3}, rsrc, lane_w * 4, base * 4, CovAux<OW>::v);
                         else {
-                            if (v0) __builtin_amdgcn_raw_buffer_store_b32((int)c0, rsrc, lane_w * 4, base * 4, 0);
-                            if (v1) __builtin_amdgcn_raw_buffer_store_b32((int)c1, rsrc, lane_w * 4 + 4, base * 4, 0);
-                            if (v2) __builtin_amdgcn_raw_buffer_store_b32((int)c2, rsrc, lane_w * 4 + 8, base * 4, 0);
-                            if (v3) __builtin_amdgcn_raw_buffer_store_b32((int)c3, rsrc, lane_w * 4 + 12, base * 4, 0);
+                            if (v0) __builtin_amdgcn_raw_buffer_store_b32((int)c0, rsrc, lane_w * 4, base * 4, CovAux<OW>::v);
+                            if (v1) __builtin_amdgcn_raw_buffer_store_b32((int)c1, rsrc, lane_w * 4 + 4, base * 4, CovAux<OW>::v);
+                            if (v2) __builtin_amdgcn_raw_buffer_store_b32((int)c2, rsrc, lane_w * 4 + 8, base * 4, CovAux<OW>::v);
+                            if (v3) __builtin_amdgcn_raw_buffer_store_b32((int)c3, rsrc, lane_w * 4 + 12, base * 4, CovAux<OW>::v);
                         }
                     }
                 } else if (OW == 1 || OW == 2) {
                     // (the windows at or above the limit are listed once per row, below: the common row has none)
                     const unsigned m0 = pk_min_u16(r0, kLimit * 0x10001u), m1 = pk_min_u16(r1, kLimit * 0x10001u);
                     if (full) {
-                        if (OW == 1) __builtin_amdgcn_raw_buffer_store_b32((int)__builtin_amdgcn_perm(m1, m0, 0x06040200u), rsrc, lane_w, base, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, lane_w * 2, base * 2, 0);
+                        if (OW == 1) __builtin_amdgcn_raw_buffer_store_b32((int)__builtin_amdgcn_perm(m1, m0, 0x06040200u), rsrc, lane_w, base, CovAux<OW>::v);
+                        else __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, lane_w * 2, base * 2, CovAux<OW>::v);
                     } else {
                         const unsigned q0 = (unsigned)(p0 - off0), nw = (unsigned)cur.nwin;
                         const bool v0 = q0 < nw, v1 = q0 + 1u < nw, v2 = q0 + 2u < nw, v3 = q0 + 3u < nw;
@@ -670,28 +676,28 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                         if (IN == 0 && OW == 1) {
                             uint8_t *o = reinterpret_cast<uint8_t *>(covp0) + p0;
                             const unsigned pk4 = __builtin_amdgcn_perm(m1, m0, 0x06040200u);
-                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b32((int)pk4, rsrc, p0, 0, 0);
+                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b32((int)pk4, rsrc, p0, 0, CovAux<OW>::v);
                             else { if (v0) o[0] = (uint8_t)pk4; if (v1) o[1] = (uint8_t)(pk4 >> 8); if (v2) o[2] = (uint8_t)(pk4 >> 16); if (v3) o[3] = (uint8_t)(pk4 >> 24); }
                         } else if (IN == 0) {
                             uint16_t *o = reinterpret_cast<uint16_t *>(covp0) + p0;
-                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, p0 * 2, 0, 0);
+                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, p0 * 2, 0, CovAux<OW>::v);
                             else { if (v0) o[0] = (uint16_t)m0; if (v1) o[1] = (uint16_t)(m0 >> 16); if (v2) o[2] = (uint16_t)m1; if (v3) o[3] = (uint16_t)(m1 >> 16); }
                         } else if (OW == 1) {
                             const unsigned pk4 = __builtin_amdgcn_perm(m1, m0, 0x06040200u);
-                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b32((int)pk4, rsrc, lane_w, base, 0);
+                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b32((int)pk4, rsrc, lane_w, base, CovAux<OW>::v);
                             else {
-                                if (v0) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pk4, rsrc, lane_w, base, 0);
-                                if (v1) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(pk4 >> 8), rsrc, lane_w + 1, base, 0);
-                                if (v2) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(pk4 >> 16), rsrc, lane_w + 2, base, 0);
-                                if (v3) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(pk4 >> 24), rsrc, lane_w + 3, base, 0);
+                                if (v0) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pk4, rsrc, lane_w, base, CovAux<OW>::v);
+                                if (v1) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(pk4 >> 8), rsrc, lane_w + 1, base, CovAux<OW>::v);
+                                if (v2) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(pk4 >> 16), rsrc, lane_w + 2, base, CovAux<OW>::v);
+                                if (v3) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(pk4 >> 24), rsrc, lane_w + 3, base, CovAux<OW>::v);
                             }
                         } else {
-                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, lane_w * 2, base * 2, 0);
+                            if (v0 && v3) __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)m0, (int)m1}, rsrc, lane_w * 2, base * 2, CovAux<OW>::v);
                             else {
-                                if (v0) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)m0, rsrc, lane_w * 2, base * 2, 0);
-                                if (v1) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(m0 >> 16), rsrc, lane_w * 2 + 2, base * 2, 0);
-                                if (v2) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)m1, rsrc, lane_w * 2 + 4, base * 2, 0);
-                                if (v3) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(m1 >> 16), rsrc, lane_w * 2 + 6, base * 2, 0);
+                                if (v0) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)m0, rsrc, lane_w * 2, base * 2, CovAux<OW>::v);
+                                if (v1) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(m0 >> 16), rsrc, lane_w * 2 + 2, base * 2, CovAux<OW>::v);
+                                if (v2) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)m1, rsrc, lane_w * 2 + 4, base * 2, CovAux<OW>::v);
+                                if (v3) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(m1 >> 16), rsrc, lane_w * 2 + 6, base * 2, CovAux<OW>::v);
                             }
                         }
                     }
