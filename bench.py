@@ -937,7 +937,7 @@ def main():
                 # it and into a few more candidates (plain blocks, other chunk mappings); the timed passes run with the one that was kept
                 line["placement_trial"] = {"first_placement_ms": tr[0], "best_other_candidate_ms": tr[1],
                                            "kept": ("first placement", "a plain hipMalloc block", "another chunk mapping")[tr[2]],
-                                           "note": "the context's first (untimed) pass ran the pileup kernel into four candidate coverage arrays, warm; the timed passes use the fastest"}
+                                           "note": "opt-in (RAFT_PLACEMENT_TRIALS=<k>): the context's first (untimed) pass ran the pileup kernel into k candidate coverage arrays, warm; the timed passes use the fastest"}
         print(json.dumps(line))
     if eng is not None:
         eng.close()

@@ -34,7 +34,12 @@
 extern "C" {
 #endif
 
-#define RAFT_HIP_ABI_VERSION 10
+/* The library is built with -fvisibility=hidden: what this header declares is everything it exports. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+#define RAFT_HIP_ABI_VERSION 11
 
 /* error codes (0..5 are shared with oracle/raft_oracle.h) */
 enum {
@@ -277,13 +282,18 @@ int64_t raft_hip_pool_bytes(int device_id);
  * RAFT_NO_VMM set the start value).  Buffers that exist keep their memory.  bench.py's `placement_ab` times the pileup kernel
  * under 8, 1 and 0 in one process. */
 int32_t raft_hip_set_placement(int32_t spread);
-/* The placement trial of the context's coverage array (ABI 10).  What the pileup kernel gets from this part follows the array it
- * stores into -- by the draw, not by the kind of memory: two hipMalloc blocks of one process gave 2.24 and 2.63 ms.
- * So a context whose first pass makes an int32 coverage array of 1 GiB or more draws RAFT_PLACEMENT_TRIALS - 1 more arrays (default
- * 4 candidates: plain blocks and chunk mappings in turn), runs the kernel into each of them warm in that pass and keeps the fastest
- * (not after raft_hip_set_placement / RAFT_NO_VMM / RAFT_VMM_SPREAD chose by hand; RAFT_NO_PLACEMENT_TRIAL=1 switches it off).
- * Reports the kernel's ms into the first placement and into the best other candidate, and what was kept (0 the first placement,
- * 1 a plain block, 2 another chunk mapping); RAFT_HIP_ERR_STATE when no trial has run. */
+/* The placement trial of the context's coverage array (ABI 10; OPT-IN since ABI 11).  What the pileup kernel gets from this part
+ * follows the array it stores into -- by the draw, not by the kind of memory: two hipMalloc blocks of one process gave 2.24 and
+ * 2.63 ms.  A context that asked for it (raft_hip_set_placement_trial(ctx, k), k = 2..8 candidates; or
+ * RAFT_PLACEMENT_TRIALS=<k> for every context of the process; 0 / 1 = off, the default) draws k - 1 more arrays at the first pass
+ * that makes an int32 coverage array of 1 GiB or more -- plain blocks and chunk mappings in turn, each only while an eighth of
+ * the device's memory (8 GiB at least) stays free behind it --, runs the kernel into each of them warm in that pass (2 k - 1
+ * more launches, one host wait) and keeps the fastest; not after raft_hip_set_placement / RAFT_NO_VMM / RAFT_VMM_SPREAD chose
+ * by hand.  Off by default because a one-shot caller has nothing to amortise it over and the bench's own A/B of the policies
+ * shows differences of 0.2 % on most leases.  raft_hip_placement_trial reports the kernel's ms into the first placement and
+ * into the best other candidate, and what was kept (0 the first placement, 1 a plain block, 2 another chunk mapping);
+ * RAFT_HIP_ERR_STATE when no trial has run. */
+int  raft_hip_set_placement_trial(raft_hip_ctx *ctx, int32_t candidates);
 int  raft_hip_placement_trial(raft_hip_ctx *ctx, double *first_ms, double *best_other_ms, int32_t *kept);
 
 /* Device arrays of the encoding the finished pass holds (width 0: none -- the pass wrote int32; call
@@ -487,6 +497,10 @@ int  raft_hip_debug_stamps(raft_hip_ctx *ctx, unsigned long long *host, int64_t 
 
 /* On-device self test of the wavefront primitives (scan, ballots); 0 = pass. */
 int  raft_hip_selftest(int device_id);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,13 @@ int default_variant()
     }();
     return v;
 }
+// coverage arrays a context's placement trial compares (run_pass): off unless asked for -- RAFT_PLACEMENT_TRIALS=<k>, k >= 2, or
+// raft_hip_set_placement_trial
+int default_trial_candidates()
+{
+    static const int v = [] { const char *e = getenv("RAFT_PLACEMENT_TRIALS"); return e ? std::max(0, std::min(8, atoi(e))) : 0; }();
+    return v;
+}
 constexpr int kFastSlots = 4;     // default number of prefetched intervals per lane and tile in the fast kernel
 
 template <int CAP, int MINW>
@@ -273,7 +280,8 @@ struct DevBuf {
                 if (!ok) { --made; (void)hipGetLastError(); }
                 for (size_t i = 0; i < made; ++i) {
                     if (ok && i % k == 0) chunks.push_back(all[i]);
-                    else pool.free_chunks.push_back(all[i]);       // (drawn from again right below when the device ran out)
+                    else if (ok) pool.put(all[i]);                 // spares: kept while the pool has room, else handed back
+                    else pool.free_chunks.push_back(all[i]);       // (the device ran out: drawn from again right below, whatever the cap)
                 }
                 if (!ok) { draw(); if (k == 1) break; }
             }
@@ -434,7 +442,8 @@ struct raft_hip_ctx {
     bool no_bucket_win = false;       // general bucketing: a side's windows did not fit 16 bits once (kErrWide): coordinate pairs from then on
     size_t cov_trial_cap = 0;         // capacity of `cov` the placement trial has been run for (run_pass)
     double trial_ms[2] = {0.0, 0.0};  // that trial: the pileup kernel into `cov` as first placed / into the best of the other candidates (ms)
-    int32_t trial_kept_plain = 0;     // 0: the first placement stayed, 1: a plain hipMalloc block was kept, 2: another chunk mapping
+    int32_t trial_kept = 0;           // 0: the first placement stayed, 1: a plain hipMalloc block was kept, 2: another chunk mapping
+    int32_t trial_candidates = default_trial_candidates();   // coverage arrays the placement trial compares; < 2: no trial (the default)
     std::string last_error;
 
     // device buffers
@@ -665,7 +674,7 @@ int64_t raft_hip_trim(int device_id, int64_t keep_bytes)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev || keep_bytes < 0) return -(int64_t)RAFT_HIP_ERR_PARAM;
-    if (hipSetDevice(device_id) != hipSuccess) return -(int64_t)RAFT_HIP_ERR_DEVICE;
+    // (hipMemRelease needs no current device: the caller's stays as it is)
     return (int64_t)ChunkPool::of(device_id).trim((size_t)(keep_bytes / (int64_t)DevBuf::kChunk)) * (int64_t)DevBuf::kChunk;
 }
 
@@ -675,18 +684,26 @@ int32_t raft_hip_set_placement(int32_t spread)
     return (int32_t)DevBuf::policy().exchange(spread < 0 ? 0 : std::min(spread, 64));
 }
 
-int raft_hip_placement_trial(raft_hip_ctx *c, double *chunks_ms, double *plain_ms, int32_t *kept_plain)
+int raft_hip_placement_trial(raft_hip_ctx *c, double *first_ms, double *best_other_ms, int32_t *kept)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
-    if (chunks_ms) *chunks_ms = c->trial_ms[0];
-    if (plain_ms) *plain_ms = c->trial_ms[1];
-    if (kept_plain) *kept_plain = c->trial_kept_plain;
+    if (first_ms) *first_ms = c->trial_ms[0];
+    if (best_other_ms) *best_other_ms = c->trial_ms[1];
+    if (kept) *kept = c->trial_kept;
     return c->trial_ms[0] > 0.0 ? RAFT_HIP_OK : RAFT_HIP_ERR_STATE;
+}
+
+int raft_hip_set_placement_trial(raft_hip_ctx *c, int32_t candidates)
+{
+    if (!c || candidates < 0 || candidates > 8) return RAFT_HIP_ERR_PARAM;
+    c->trial_candidates = candidates;
+    return RAFT_HIP_OK;
 }
 
 int64_t raft_hip_pool_bytes(int device_id)
 {
-    if (device_id < 0 || device_id >= 64) return -(int64_t)RAFT_HIP_ERR_PARAM;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev || device_id >= 64) return -(int64_t)RAFT_HIP_ERR_PARAM;
     ChunkPool &pool = ChunkPool::of(device_id);
     std::lock_guard<std::mutex> lk(pool.mu);
     return (int64_t)pool.free_chunks.size() * (int64_t)DevBuf::kChunk;
@@ -1238,20 +1255,37 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         pa.piece_w = (int32_t)std::min<long long>(extra_cap, INT32_MAX);    // (delta4: tile ids below this have slots of their own)
         launch_wave_variant(ow, lean || bwin, st, pa.n_seg, c->tile_cuts.p, &pa, n_waves);
         n_sum_blocks = (unsigned)n_waves;
-        // ---- where the coverage array lies, decided by measurement (round 5).  What this kernel gets from the part follows the array
-        // it stores into, and not by the KIND of memory: two hipMalloc blocks of one process gave 2.24 and 2.63 ms, two chunk
-        // mappings 2.49 and 2.67, and which kind had the better draw changed from lease to lease.  So the first
-        // pass of a context that makes a coverage array of a GiB or more draws a few more arrays -- plain blocks and chunk mappings
-        // in turn --, runs the kernel into each of them warm, and keeps the one it was fastest with.  Once per context and array
-        // size: 2 K - 1 more launches for K candidates (RAFT_PLACEMENT_TRIALS, default 4), K - 1 more allocations, one host wait.
-        static const int kTrials = [] { const char *e = getenv("RAFT_PLACEMENT_TRIALS"); return e ? std::max(1, std::min(8, atoi(e))) : 4; }();
+        // ---- where the coverage array lies, decided by measurement: OPT-IN (raft_hip_set_placement_trial / RAFT_PLACEMENT_TRIALS=<k>;
+        // round 5 ran it by default, round 6 does not: the driver's own A/B showed 0.2 % between the policies, and a one-shot caller
+        // paid 2 K - 1 extra launches and K - 1 coverage-sized allocations for nothing).  What this kernel gets from the part follows
+        // the array it stores into, and not by the KIND of memory: two hipMalloc blocks of one process gave 2.24 and 2.63 ms, two chunk
+        // mappings 2.49 and 2.67.  A context that asked for a trial draws K - 1 more arrays at the first pass that makes
+        // a coverage array of a GiB or more -- plain blocks and chunk mappings in turn, each only while the device keeps its reserve
+        // free behind it --, runs the kernel into each of them warm, and keeps the one it was fastest with.
+        const int kTrials = c->trial_candidates;
         if (ow == 4 && c->cov.cap >= DevBuf::kSpreadMin && c->cov.va_bytes && c->cov_trial_cap != c->cov.cap && !c->is_lane && kTrials > 1 &&
-            !DevBuf::policy_explicit().load() && getenv("RAFT_NO_PLACEMENT_TRIAL") == nullptr) {
+            !DevBuf::policy_explicit().load()) {
             c->cov_trial_cap = c->cov.cap;
-            std::vector<DevBuf> cand((size_t)kTrials - 1);
-            std::vector<hipEvent_t> ev((size_t)2 * kTrials, nullptr);
+            struct TrialGuard {                       // every way out of this block releases the candidates and the events
+                std::vector<DevBuf> cand;
+                std::vector<hipEvent_t> ev;
+                ~TrialGuard()
+                {
+                    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+                    for (DevBuf &b : cand) b.release();
+                }
+            } tg;
+            tg.cand.resize((size_t)kTrials - 1);
+            tg.ev.assign((size_t)2 * kTrials, nullptr);
+            std::vector<DevBuf> &cand = tg.cand;
+            std::vector<hipEvent_t> &ev = tg.ev;
             int n_cand = 0;
             for (int k = 0; k + 1 < kTrials; ++k) {
+                // a candidate is drawn only while an eighth of the device's memory (8 GiB at least) stays free behind it: the same
+                // reserve map_chunks keeps for its spare chunks (torch, RCCL and other processes live there)
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
+                if (free_b < c->cov.cap + std::max<size_t>(size_t(8) << 30, total_b / 8)) break;
                 cand[(size_t)k].big = (k & 1) != 0;       // plain block, chunk mapping, plain block, ...
                 if (cand[(size_t)k].ensure(c->cov.cap) != hipSuccess) { (void)hipGetLastError(); break; }
                 ++n_cand;
@@ -1276,7 +1310,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
                 for (int k = 0; k < n_cand && trc == RAFT_HIP_OK; ++k) trc = one_run(cand[(size_t)k].as<int32_t>(), nullptr, nullptr);
                 if (trc == RAFT_HIP_OK) trc = one_run(c->cov.as<int32_t>(), ev[0], ev[1]);
                 for (int k = 0; k < n_cand && trc == RAFT_HIP_OK; ++k) trc = one_run(cand[(size_t)k].as<int32_t>(), ev[(size_t)2 * k + 2], ev[(size_t)2 * k + 3]);
-                if (trc != RAFT_HIP_OK) return trc;
+                if (trc != RAFT_HIP_OK) { (void)hipStreamSynchronize(st); return trc; }      // (nothing in flight may still use a candidate)
                 HIP_TRY(c, hipEventSynchronize(ev[(size_t)2 * n_cand + 1]));
                 float best = 0.f;
                 HIP_TRY(c, hipEventElapsedTime(&best, ev[0], ev[1]));
@@ -1288,12 +1322,10 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
                     if (c->trial_ms[1] == 0.0 || t < c->trial_ms[1]) c->trial_ms[1] = t;
                     if (t < best * 0.985f) { best = t; keep = k; }      // (a candidate has to win by more than the noise of two launches)
                 }
-                c->trial_kept_plain = keep >= 0 ? (cand[(size_t)keep].big ? 2 : 1) : 0;
+                c->trial_kept = keep >= 0 ? (cand[(size_t)keep].big ? 2 : 1) : 0;
                 if (keep >= 0) { std::swap(c->cov, cand[(size_t)keep]); c->cov_trial_cap = c->cov.cap; }
                 // (whichever array is kept holds this pass's coverage: every run wrote all of it)
             }
-            for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-            for (DevBuf &b : cand) b.release();
         }
     } else if (pv.fast) {
         const TileCut *cuts = c->tile_cuts.as<TileCut>();

@@ -43,8 +43,9 @@ template <int SLOTS>
 struct WaveSmem {                    // ONE wave's LDS
     static_assert(SLOTS % 512 == 0, "rows of 512 slots");
     uint32_t diff[SLOTS / 2];        // two 16-bit slots per dword, slot order; all kZero between tiles
-    int32_t roff[64];                // first slot of read r_a + j relative to a0 (j <= nr)
-    int32_t rcnt[64];                // raw repeats emitted for the read in this tile
+    // ONE array for the two per-read tables, so that what the record pass relies on is in the type: entry 64 -- read for a record that
+    // is not the tile's (j == nr == 63), value unused -- exists, and the unmasked pair (roff[j], roff[j + 1]) is one ds_read2
+    int32_t rtab[128];               // [0, 64): roff, first slot of read r_a + j relative to a0 (j <= nr); [64, 128): rcnt, raw repeats emitted for the read in this tile
     int32_t runq[2 * kRunQ];         // closed runs parked for emission
 };
 
@@ -398,8 +399,8 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         const int rows = (t_end + 1 + 511) >> 9;
         // ---- per-read table of this tile
         const int ro = rd.cv - (int)a0;                     // 32-bit wrap-around is exact
-        if (lane <= nr) sm.roff[lane] = ro;
-        sm.rcnt[lane] = 0;
+        if (lane <= nr) sm.rtab[lane] = ro;
+        sm.rtab[64 + lane] = 0;
         const int ro_s = (lane < nr) ? ro : 0x7fffffff;     // first slots of the tile's reads, for the run scan and the owner search
 
         // ---- 1. intervals -> +1 / -1 on 16-bit slots
@@ -420,9 +421,9 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             auto one = [&](int rid, int st, int en, bool mine) {
                 const unsigned jr = (unsigned)(rid - r_a);
                 const unsigned j = min(jr, (unsigned)nr);
-                // (j + 1 <= 64: entry 64 is rcnt[0], read only for a record that is not the tile's -- j == nr == 63 -- whose values are
-                // not used; unmasked, the two entries are one ds_read2)
-                const int b0 = sm.roff[j], nb_r = sm.roff[j + 1u] - b0;
+                // (j + 1 <= 64: entry 64 of the table -- the first repeat counter -- is read only for a record that is not the tile's,
+                // j == nr == 63, whose values are not used; unmasked, the two entries are one ds_read2)
+                const int b0 = sm.rtab[j], nb_r = sm.rtab[j + 1u] - b0;
                 const int first = win((unsigned)st);
                 const int last1 = win((unsigned)(en - 1)) + 1;
                 const bool valid = mine && jr < (unsigned)nr, sign_ok = (st | en) >= 0, pos = en > 0;
@@ -474,7 +475,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                         const int rid = (a.iv_rid + base)[i], st = (a.iv_s + base)[i], en = (a.iv_e + base)[i];
                         if ((unsigned)(rid - r_a) >= (unsigned)nr) continue;
                         const int j = rid - r_a;
-                        const int nb_r = sm.roff[j + 1] - sm.roff[j];
+                        const int nb_r = sm.rtab[j + 1] - sm.rtab[j];
                         const int first = (int)win_of(a, (unsigned)st), last1 = (int)win_of(a, (unsigned)(en - 1)) + 1;
                         if ((st | en) < 0 || (en > 0 && last1 > first && last1 > nb_r)) raise_error(a, kErrCoord, base + i);
                     }
@@ -491,7 +492,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 bnd[s] = (lane < nr) ? nx : 0x7fffffff;
             }
             auto one_w = [&](int j, unsigned w) {
-                const int b0 = sm.roff[j], nb_r = sm.roff[j + 1] - b0;
+                const int b0 = sm.rtab[j], nb_r = sm.rtab[j + 1] - b0;
                 const int first = (int)(w & 0xffffu), last1 = (int)(w >> 16);
                 const bool over = last1 > first && last1 > nb_r;
                 const int pf = max(b0 + first, off0), pl1 = min(b0 + min(last1, nb_r), t_end);
@@ -535,7 +536,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                         if (i < cur.cnt[s]) {
                             const unsigned w = (a.iv_w + base)[i];
                             const int first = (int)(w & 0xffffu), last1 = (int)(w >> 16);
-                            if (last1 > first && last1 > sm.roff[j + 1] - sm.roff[j]) raise_error(a, kErrCoord, base + i);
+                            if (last1 > first && last1 > sm.rtab[j + 1] - sm.rtab[j]) raise_error(a, kErrCoord, base + i);
                         }
                     }
                 }
@@ -574,19 +575,19 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 const int r0 = reinterpret_cast<const int32_t *>(a.rep_res_off + r_a)[0], r1 = reinterpret_cast<const int32_t *>(a.rep_res_off + r_a)[2];
                 const int slot = atomicAdd(&a.rep_cnt[r_a], 1);
                 if (slot >= r1 - r0) { raise_error(a, kErrInternal, r_a); return; }
-                const int start = (sS - sm.roff[0]) * a.reso;
+                const int start = (sS - sm.rtab[0]) * a.reso;
                 const long long ix = (long long)r0 + slot;
                 a.raw_key[ix] = start; a.raw_s[ix] = start; a.raw_e[ix] = start + (sT - sS) * a.reso;
                 return;
             }
             int jo = 0;                          // owner: the last read that begins at or before the run's first slot
-            for (int q = 1; q < nr; ++q) if (sm.roff[q] <= sS) jo = q;
+            for (int q = 1; q < nr; ++q) if (sm.rtab[q] <= sS) jo = q;
             const int nwin_r = sT - sS;
             if ((long long)nwin_r * a.reso < (long long)a.repeat_length) return;
             const int len = a.read_len[r_a + jo];
             const int r0 = reinterpret_cast<const int32_t *>(a.rep_res_off + r_a + jo)[0], r1 = reinterpret_cast<const int32_t *>(a.rep_res_off + r_a + jo)[2];
-            const int slot = atomicAdd(&sm.rcnt[jo], 1);
-            const int start = (sS - sm.roff[jo]) * a.reso, end = start + nwin_r * a.reso;
+            const int slot = atomicAdd(&sm.rtab[64 + jo], 1);
+            const int start = (sS - sm.rtab[jo]) * a.reso, end = start + nwin_r * a.reso;
             int s2 = start - a.flank, e2 = end + a.flank;
             if (s2 <= 0) s2 = 0;
             if (e2 >= len) e2 = len;
@@ -896,7 +897,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                     const int slot = atomicAdd(&a.rep_cnt[r_a], 1);
                     if (slot >= r1 - r0) raise_error(a, kErrInternal, r_a);
                     else {
-                        const int start = (sS - sm.roff[0]) * a.reso;
+                        const int start = (sS - sm.rtab[0]) * a.reso;
                         const long long ix = (long long)r0 + slot;
                         a.raw_key[ix] = start; a.raw_s[ix] = start; a.raw_e[ix] = start + (sT - sS) * a.reso;
                     }
@@ -908,8 +909,8 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 const bool live = lane < nq && (long long)nwin_r * a.reso >= (long long)a.repeat_length;
                 const int len = __shfl(rd.rl, jj), r0 = __shfl(rd.rr, jj), r1 = __shfl(rd.rr, jj + 1);
                 if (live) {
-                    const int off = sm.roff[jj];
-                    const int slot = atomicAdd(&sm.rcnt[jj], 1);
+                    const int off = sm.rtab[jj];
+                    const int slot = atomicAdd(&sm.rtab[64 + jj], 1);
                     const int start = (sS - off) * a.reso, end = start + nwin_r * a.reso;
                     int s = start - a.flank, e = end + a.flank;
                     if (s <= 0) s = 0;
@@ -923,7 +924,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 }
             }
             if (!piece && lane < nr) {
-                const int c = sm.rcnt[lane];
+                const int c = sm.rtab[64 + lane];
                 if (c) a.rep_cnt[r_a + lane] = c;
             }
         }

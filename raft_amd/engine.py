@@ -30,6 +30,7 @@ EXPORTS = (
     "raft_hip_run_device_windows", "raft_hip_run_host_windows", "raft_hip_run_multi_windows",
     "raft_hip_fetch_delta4", "raft_hip_packed_anchor_device", "raft_hip_set_emit_cuts", "raft_hip_device_alloc", "raft_hip_device_free", "raft_hip_group_sides", "raft_hip_presplit_symmetric", "raft_hip_presplit_symmetric_local",
     "raft_hip_trim", "raft_hip_pool_bytes", "raft_hip_run_presplit_local", "raft_hip_set_placement", "raft_hip_placement_trial",
+    "raft_hip_set_placement_trial",
 )
 
 
@@ -178,6 +179,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_set_placement.argtypes = [i32]
     lib.raft_hip_set_placement.restype = i32
     lib.raft_hip_placement_trial.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)]
+    lib.raft_hip_set_placement_trial.argtypes = [vp, i32]
     lib.raft_hip_group_sides.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(_Slice)]
     lib.raft_hip_presplit_symmetric.argtypes = [vp, vp, i32, i32, C.POINTER(_Records), C.POINTER(i32)]
     lib.raft_hip_presplit_symmetric_local.argtypes = [C.POINTER(vp), i32, C.POINTER(_Records), C.POINTER(i32)]
@@ -241,6 +243,10 @@ class Engine:
 
     def set_tuning(self, tile_bins: int = 0, force_bucket_path: bool = False, variant: int = -1):
         self._check(self._lib.raft_hip_set_tuning(self._ctx, tile_bins, int(force_bucket_path), variant))
+
+    def set_placement_trial(self, candidates: int):
+        """Opt in to the coverage array's placement trial at the context's first large pass: 2..8 candidate arrays, 0 = off (the default)."""
+        self._check(self._lib.raft_hip_set_placement_trial(self._ctx, candidates))
 
     def placement_trial(self):
         """(first_ms, best_other_ms, kept) of the coverage array's placement trial -- kept: 0 the first placement, 1 a plain block, 2 another

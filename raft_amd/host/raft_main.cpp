@@ -243,7 +243,7 @@ int main(int argc, char *argv[])
     stage("paf_read (rest)");
     rc = paf_text_rc;
     if (rc == RAFT_HOST_OK) rc = raft_host_paf_parse(paf_text, reads, &paf, bad, sizeof bad);
-    if (raft_host_paf_count(paf) < (1 << 22)) raft_host_text_free(paf_text);   // (a big file's GBs of touched pages are left to the process exit: unmapping them here -- or beside
+    if (raft_host_paf_count(paf) < (1 << 22)) { raft_host_text_free(paf_text); paf_text = nullptr; }   // (a big file's GBs of touched pages are left to the process exit: unmapping them here -- or beside
                                                                                    // the pass, where it holds the address space's lock against the page-locking -- cost 0.3 s of a 4 s run)
     if (rc == RAFT_HOST_ERR_UNKNOWN_NAME) die(std::string("ERROR, create_pileup(), read ") + bad + " of the overlaps file is not in the reads file");
     if (rc != RAFT_HOST_OK) die(std::string("ERROR, create_pileup(), cannot read ") + paf_fn);
@@ -424,6 +424,7 @@ int main(int argc, char *argv[])
                          has("ASAN_OPTIONS") || has("LSAN_OPTIONS") || has("UBSAN_OPTIONS") ||
                          (preload && (strstr(preload, "rocprof") || strstr(preload, "asan") || strstr(preload, "tsan")));
     if (!tooling) _exit(0);
+    if (paf_text) raft_host_text_free(paf_text);     // (the clean exit gives everything back: leak checkers see none)
     raft_host_paf_free(paf);
     raft_host_reads_free(reads);
     for (raft_hip_ctx *c : ctxs) raft_hip_destroy(c);

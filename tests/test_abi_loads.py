@@ -23,7 +23,7 @@ def test_library_exports_every_symbol():
     lib = engine.load_library()
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.raft_hip_abi_version() == 10
+    assert lib.raft_hip_abi_version() == 11
     assert lib.raft_hip_strerror(2).decode().startswith("PAF record names a read id")
 
 
@@ -56,3 +56,16 @@ def test_invalid_params_rejected_before_any_device_work():
     assert lib.raft_hip_create(0, C.byref(bad), C.byref(ctx)) == engine.ERR_PARAM
     bad = engine._cparams(RaftParams(est_cov=3, read_length=100, interval_length=200, repeat_length=200))
     assert lib.raft_hip_create(0, C.byref(bad), C.byref(ctx)) == engine.ERR_PARAM
+
+
+def test_library_exports_nothing_but_the_abi():
+    """Built with -fvisibility=hidden and a version script: kernel handles, template instances of the standard library and the
+    engine's internals stay local (`nm -D | grep -v raft_hip_` empty)."""
+    import shutil
+    import subprocess
+    if shutil.which("nm") is None:
+        pytest.skip("no nm")
+    out = subprocess.run(["nm", "-D", "--defined-only", engine._LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert names and all(n.startswith("raft_hip_") for n in names), [n for n in names if not n.startswith("raft_hip_")][:10]
+    assert sorted(names) == declared_symbols()

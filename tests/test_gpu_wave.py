@@ -276,16 +276,17 @@ free1 = torch.cuda.mem_get_info(0)[0]
 assert free0 - free1 < (1 << 30), (free0, free1)
 print("POOL_OK")
 '''
-    env = dict(os.environ, RAFT_VMM_POOL_GB="2", RAFT_NO_PLACEMENT_TRIAL="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, RAFT_VMM_POOL_GB="2", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     env.pop("RAFT_NO_VMM", None)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "POOL_OK" in r.stdout, r.stdout[-2000:]
 
 
 def test_placement_trial_of_the_coverage_array_keeps_results_and_reports():
-    """Round 5: a context whose first pass makes an int32 coverage array of 1 GiB or more runs the pileup kernel twice in that pass
-    (array in spread chunks / in one hipMalloc block) and keeps the faster array.  Own process (the trial is off once the policy
-    was set by hand anywhere in a process): results of the trial pass and of the next one are the same and sane, the report is there."""
+    """Round 5: a context whose first pass makes an int32 coverage array of 1 GiB or more runs the pileup kernel into a few candidate
+    arrays in that pass and keeps the fastest.  Round 6: only a context that asked for it (raft_hip_set_placement_trial) -- a context
+    that did not runs no trial.  Own process (the trial is off once the policy was set by hand anywhere in a process): results of the
+    trial pass and of the next one are the same and sane, the report is there."""
     import subprocess, sys, os
     code = r'''
 import torch
@@ -294,7 +295,12 @@ from raft_amd.params import RaftParams
 from raft_amd.synth import make_overlaps
 o = make_overlaps(500000, mean_len=30000.0, coverage=8.0, seed=3, device="cuda:0")
 cols = (o.read_len,) + o.columns()
+eng0 = engine.Engine(RaftParams(est_cov=8))          # the default: no trial
+eng0.run_device(*cols); s0 = eng0.finish()
+assert eng0.placement_trial() is None
+eng0.close()
 eng = engine.Engine(RaftParams(est_cov=8))
+eng.set_placement_trial(4)
 sig = []
 for rep in range(3):
     eng.run_device(*cols); s = eng.finish()
@@ -303,15 +309,16 @@ for rep in range(3):
     if rep == 0:
         tr = eng.placement_trial()
         assert tr is not None and tr[0] > 0 and tr[1] > 0, tr
-assert sig[0] == sig[1] == sig[2] and sig[0][2] == sig[0][4], sig
+assert sig[0] == sig[1] == sig[2] and sig[0][2] == sig[0][4] and s0.n_fragments == sig[0][0], sig
 eng2 = engine.Engine(RaftParams(est_cov=8))
+eng2.set_placement_trial(4)
 engine.set_placement(8)                      # chosen by hand: no trial from here on
 eng2.run_device(*cols); s2 = eng2.finish()
 assert eng2.placement_trial() is None and s2.n_fragments == sig[0][0]
 print("TRIAL_OK", tr)
 '''
     env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    for k in ("RAFT_NO_VMM", "RAFT_VMM_SPREAD", "RAFT_NO_PLACEMENT_TRIAL"):
+    for k in ("RAFT_NO_VMM", "RAFT_VMM_SPREAD", "RAFT_PLACEMENT_TRIALS"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "TRIAL_OK" in r.stdout, r.stdout[-2000:]

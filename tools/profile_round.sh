@@ -28,7 +28,8 @@ if fetch is not None and write is not None:
     json.dump({"hbm_bytes_per_launch": traffic, "fetch_size_kib": fetch, "write_size_kib": write,
                "records_per_gpu": b["config"]["records_per_gpu"], "kernel_source_hash": b["roofline"]["kernel_source_hash"],
                "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), every pileup kernel of a pass (regular tiles, extra tiles), means per launch summed; "
-                         f"bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section; profiles/{tag}_pmc_traffic.json"},
+                         f"bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section; session {tag} (gpurun_out/{tag}/pmc_traffic.json, kept as profiles/{tag}_pmc_traffic.json)",
+               "session": tag},
               open(f"gpurun_out/{tag}/pmc_traffic.json", "w"), indent=1)
     print("traffic bytes", traffic, "algorithmic", b["roofline"]["bytes_algorithmic"])
 PY
