@@ -91,8 +91,10 @@ typedef struct raft_hip_summary {
                                    sorted-segment path, RAFT_HIP_ERR_COORD; on the counting-sort path (interval_path
                                    == 1) RAFT_HIP_ERR_COORD reports the index into the BUCKETED interval array */
     int32_t n_devices_used;     /* host-to-host entry points: contexts that took part in the job (1 for a one-piece pass) */
-    int32_t reserved;
+    int32_t flags;              /* RAFT_HIP_SUM_*: bit 0 -- the general bucketing (interval_path == 1) sorted its sides as window-record items
+                                   and the pileup kernel read those (4 bytes per interval) instead of coordinate columns */
 } raft_hip_summary;
+#define RAFT_HIP_SUM_BUCKET_WINDOWS 1
 
 /* Device-resident outputs of the last run (valid until the next run/destroy).
  * Layout is CSR per read, FASTA-index order (= reference output order):
@@ -388,6 +390,10 @@ int  raft_hip_run_multi_windows(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_
  * (chop.hpp:195) and the stdout sums (repeat.hpp:93-97) -- one all-gather of five integers per rank, the caller's.
  *   raft_hip_exchange        one process per GPU: RCCL over xGMI -- piece sizes by ncclAllGather, payload by grouped
  *                            ncclSend / ncclRecv on the context's stream; returns in stream order (no host wait at the end).
+ *                            Errors are COLLECTIVE: whatever one rank finds wrong on its side -- bounds or offsets that do not fit its
+ *                            slice, a device allocation or staging copy that failed -- travels in its row of the gather, and every rank
+ *                            returns the same code (RAFT_HIP_ERR_PARAM / _NOMEM / _TOO_LARGE) before any send or receive is posted; no
+ *                            rank is left waiting in a collective for a peer that has returned.
  *                            `comm`: an ncclComm_t of the caller's, or one made by raft_hip_comm_create from an id that rank 0
  *                            obtained with raft_hip_comm_unique_id (128 bytes) and handed to the others by its own means.
  *                            librccl.so.1 is loaded when first used (a single-GPU run never maps it).
@@ -404,6 +410,9 @@ typedef struct raft_hip_slice {
     int32_t n_runs;             /* sorted runs of the slice, 1..4 */
     const int64_t *rec_offset;  /* HOST: [n_runs * (n_reads_total + 1)], first record (index into the slice) of every read in every run */
     const int32_t *d_qs, *d_qe; /* DEVICE: the slice's query coordinates */
+    const int64_t *d_rec_offset;/* DEVICE, optional (ABI 11): the same offsets on the rank's device.  raft_hip_exchange sends the slices of
+                                   the offsets from there and otherwise uploads rec_offset at every call (8 bytes per read and run: 53 MB
+                                   for 3.3 M reads in two runs); a caller that exchanges the same slice again keeps a copy.  NULL: uploaded */
 } raft_hip_slice;
 typedef struct raft_hip_received {
     int32_t n_reads;            /* reads this rank owns */

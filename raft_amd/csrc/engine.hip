@@ -1210,6 +1210,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
             for (int s2 = 0; s2 < kMaxSeg; ++s2) pa.grp.adj[s2] = 0;
         }
         c->sum.interval_path = 1; c->sum.n_segments = n_desc + 1; c->sum.n_intervals = -1; // read back in finish
+        c->sum.flags = bwin ? RAFT_HIP_SUM_BUCKET_WINDOWS : 0;
     }
     // the detection of a pass that assumes a symmetric PAF: one more boundary search of this kernel (pileup.hpp MirrorArgs)
     MirrorArgs mir{};
@@ -3262,7 +3263,7 @@ int raft_hip_group_sides(raft_hip_ctx *c, int32_t n_reads_total, int64_t n_rec, 
         }
         n_valid = c->gs_off_host[(size_t)n_reads_total];
     }
-    *out = raft_hip_slice{n_valid, 1, reinterpret_cast<const int64_t *>(c->gs_off_host.data()), c->gs_s.as<int32_t>(), c->gs_e.as<int32_t>()};
+    *out = raft_hip_slice{n_valid, 1, reinterpret_cast<const int64_t *>(c->gs_off_host.data()), c->gs_s.as<int32_t>(), c->gs_e.as<int32_t>(), nullptr};
     return RAFT_HIP_OK;
 }
 
@@ -3472,19 +3473,18 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
     const long long N1 = (long long)n_reads_total + 1;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-#define NCCL_TRY(expr)                                                                                     \
-    do {                                                                                                   \
-        const ncclResult_t e_ = (expr);                                                                    \
-        if (e_ != ncclSuccess) { c->last_error = std::string(#expr ": ") + r->GetErrorString(e_); return RAFT_HIP_ERR_DEVICE; } \
-    } while (0)
-    // ---- who sends how much to whom: every rank's row of piece sizes, gathered (world * world * kMaxSeg numbers).
-    // Every rank must reach every collective, so nothing a single rank finds wrong with its own arguments ends the call
-    // before the all-gather: such a rank announces a row of kBadRow instead, and ALL ranks return the same error once the
-    // rows are in (the matrix is complete on every rank) -- before any send or receive is posted.
-    constexpr long long kBadRow = -2;
-    const size_t row = (size_t)world * kMaxSeg;
+    // ---- Every rank must reach every collective: a rank that returned on its own would leave its peers waiting in theirs for
+    // ever.  So NOTHING a single rank finds wrong on its side ends the call before the rows are gathered -- arguments that do not
+    // fit (kBadRow), a device allocation or copy that failed (kNoMemRow) travel in the rank's row, and ALL ranks return the same
+    // error once the matrix is in, before any send or receive is posted.  The row also carries what the rank's receive buffers
+    // hold at the moment: every rank can then tell whether ANY rank has to grow a buffer for what is about to arrive, and only
+    // in that case a second, one-word gather ("my buffers are ready" / "they are not") follows -- a rank whose allocation fails
+    // there is announced the same way.  (What is left on this side of the first gather is its own 8 * world^2 * 5 bytes on the
+    // device -- 2.5 KB for 8 ranks, made at the context's first exchange.)
+    constexpr long long kBadRow = -2, kNoMemRow = -3;
+    const size_t row = (size_t)world * kMaxSeg + 2;       // piece sizes per (destination, run); records / offset entries the receive buffers hold
     std::vector<long long> cnt(row * (size_t)world, 0);
-    // (a slice or bounds that are wrong as a whole -- ADVICE r04: these used to return before the all-gather the peers were in)
+    long long *my = cnt.data() + (size_t)rank * row;
     bool mine_ok = slice_ok(*mine, n_reads_total) && bounds[0] == 0 && bounds[world] == n_reads_total;
     for (int g = 0; g < world && mine_ok; ++g) {
         if (bounds[g] < 0 || bounds[g] > bounds[g + 1] || bounds[g + 1] > n_reads_total) { mine_ok = false; break; }
@@ -3495,32 +3495,61 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
                 if (lo < 0 || hi < lo || hi > mine->n_rec) { mine_ok = false; break; }
                 n = hi - lo;
             }
-            cnt[(size_t)rank * row + (size_t)g * kMaxSeg + (size_t)j] = n;
+            my[(size_t)g * kMaxSeg + (size_t)j] = n;
         }
     }
-    if (!mine_ok) for (size_t i = 0; i < row; ++i) cnt[(size_t)rank * row + i] = kBadRow;
-    HIP_TRY(c, c->x_cnt.ensure(cnt.size() * 8));
-    HIP_TRY(c, hipMemcpyAsync(c->x_cnt.as<long long>() + (size_t)rank * row, cnt.data() + (size_t)rank * row, row * 8, hipMemcpyHostToDevice, st));
-    NCCL_TRY(r->AllGather(c->x_cnt.as<long long>() + (size_t)rank * row, c->x_cnt.p, row, ncclInt64, comm, st));
-    HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->x_cnt.p, cnt.size() * 8, hipMemcpyDeviceToHost, st));
-    // (meanwhile: this rank's offsets go to the device, from where their slices are sent)
-    HIP_TRY(c, c->x_send_off.ensure((size_t)(mine_ok ? mine->n_runs : 1) * (size_t)N1 * 8));
-    if (mine_ok) HIP_TRY(c, hipMemcpyAsync(c->x_send_off.p, mine->rec_offset, (size_t)mine->n_runs * (size_t)N1 * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    // ---- the same verdict on every rank: a rank with invalid arguments; more runs arriving at SOME rank than a pass takes
-    for (int p = 0; p < world; ++p)
-        if (cnt[(size_t)p * row] == kBadRow) {
+    const bool one_col = mine->d_qe == nullptr;           // window records: one column travels (the same on every rank: the caller's protocol)
+    my[row - 2] = (long long)std::min(c->x_qs.cap, one_col ? c->x_qs.cap : c->x_qe.cap) / 4;
+    my[row - 1] = (long long)std::min(c->x_off.cap, c->x_raw.cap) / 8;
+    // this rank's offsets on the device, from where their slices are sent: the caller's copy, or uploaded here
+    const long long *d_send_off = mine_ok ? reinterpret_cast<const long long *>(mine->d_rec_offset) : nullptr;
+    hipError_t my_err = hipSuccess;
+    if (mine_ok && !d_send_off) {
+        my_err = c->x_send_off.ensure((size_t)mine->n_runs * (size_t)N1 * 8);
+        if (my_err == hipSuccess) my_err = hipMemcpyAsync(c->x_send_off.p, mine->rec_offset, (size_t)mine->n_runs * (size_t)N1 * 8, hipMemcpyHostToDevice, st);
+        d_send_off = c->x_send_off.as<long long>();
+    }
+    if (!mine_ok) for (size_t i = 0; i < row; ++i) my[i] = kBadRow;
+    else if (my_err != hipSuccess) { (void)hipGetLastError(); for (size_t i = 0; i < row; ++i) my[i] = kNoMemRow; }
+    HIP_TRY(c, c->x_cnt.ensure(cnt.size() * 8));                             // (the one allocation ahead of the first gather: see above)
+    auto nccl_fail = [&](ncclResult_t e, const char *what) { c->last_error = std::string(what) + ": " + r->GetErrorString(e); return RAFT_HIP_ERR_DEVICE; };
+    {
+        // (a copy that fails here leaves the gather to send whatever the buffer holds -- possible only with a broken device, which
+        // the stream's synchronize below reports on this rank; the collective itself is still entered)
+        const hipError_t e1 = hipMemcpyAsync(c->x_cnt.as<long long>() + (size_t)rank * row, my, row * 8, hipMemcpyHostToDevice, st);
+        const ncclResult_t ge = r->AllGather(c->x_cnt.as<long long>() + (size_t)rank * row, c->x_cnt.p, row, ncclInt64, comm, st);
+        if (ge != ncclSuccess) return nccl_fail(ge, "ncclAllGather(piece sizes)");
+        if (e1 != hipSuccess) return fail_hip(c, e1, "hipMemcpyAsync(piece sizes)");
+        HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->x_cnt.p, cnt.size() * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+    }
+    // ---- the same verdict on every rank
+    for (int p = 0; p < world; ++p) {
+        const long long v = cnt[(size_t)p * row];
+        if (v == kBadRow) {
             c->last_error = "raft_hip_exchange: rank " + std::to_string(p) + " was handed bounds or offsets that do not fit its slice";
             return RAFT_HIP_ERR_PARAM;
         }
+        if (v == kNoMemRow) {
+            c->last_error = "raft_hip_exchange: rank " + std::to_string(p) + " could not stage its offsets on its device";
+            return RAFT_HIP_ERR_NOMEM;
+        }
+    }
+    bool any_grows = false;
     for (int g = 0; g < world; ++g) {
         int arriving = 0;
+        long long n_in = 0;
         for (int p = 0; p < world; ++p)
-            for (int j = 0; j < kMaxSeg; ++j) arriving += cnt[(size_t)p * row + (size_t)g * kMaxSeg + (size_t)j] > 0 ? 1 : 0;
+            for (int j = 0; j < kMaxSeg; ++j) {
+                const long long n = cnt[(size_t)p * row + (size_t)g * kMaxSeg + (size_t)j];
+                if (n > 0) { ++arriving; n_in += n; }
+            }
         if (arriving > kMaxRuns) {
             c->last_error = "raft_hip_exchange: more than 16 runs arrive at rank " + std::to_string(g);
             return RAFT_HIP_ERR_TOO_LARGE;
         }
+        const long long n1g = bounds[g + 1] - bounds[g] + 1;
+        any_grows = any_grows || std::max(n_in, 1LL) > cnt[(size_t)g * row + row - 2] || (long long)std::max(arriving, 1) * n1g > cnt[(size_t)g * row + row - 1];
     }
     // ---- what arrives here: one run per (peer, run) with records for this rank
     const long long b0 = bounds[rank], n1 = bounds[rank + 1] - b0 + 1;
@@ -3532,11 +3561,28 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
             if (n > 0) { runs.push_back(XRun{p, j, 0, n}); n_rec += n; }
         }
     const int K = std::max<int>(1, (int)runs.size());
-    const bool one_col = mine->d_qe == nullptr;           // window records: one column travels (the same on every rank: the caller's protocol)
-    HIP_TRY(c, c->x_qs.ensure((size_t)std::max(n_rec, 1LL) * 4));
-    if (!one_col) HIP_TRY(c, c->x_qe.ensure((size_t)std::max(n_rec, 1LL) * 4));
-    HIP_TRY(c, c->x_off.ensure((size_t)K * (size_t)n1 * 8));
-    HIP_TRY(c, c->x_raw.ensure((size_t)K * (size_t)n1 * 8));
+    {
+        hipError_t ea = c->x_qs.ensure((size_t)std::max(n_rec, 1LL) * 4);
+        if (ea == hipSuccess && !one_col) ea = c->x_qe.ensure((size_t)std::max(n_rec, 1LL) * 4);
+        if (ea == hipSuccess) ea = c->x_off.ensure((size_t)K * (size_t)n1 * 8);
+        if (ea == hipSuccess) ea = c->x_raw.ensure((size_t)K * (size_t)n1 * 8);
+        if (ea != hipSuccess) (void)hipGetLastError();
+        if (any_grows) {                                  // (every rank computed the same `any_grows` from the same matrix)
+            std::vector<long long> ready((size_t)world, 0);
+            ready[(size_t)rank] = ea == hipSuccess ? 1 : 0;
+            const hipError_t e1 = hipMemcpyAsync(c->x_cnt.as<long long>() + rank, &ready[(size_t)rank], 8, hipMemcpyHostToDevice, st);
+            const ncclResult_t ge = r->AllGather(c->x_cnt.as<long long>() + rank, c->x_cnt.p, 1, ncclInt64, comm, st);
+            if (ge != ncclSuccess) return nccl_fail(ge, "ncclAllGather(buffers ready)");
+            if (e1 != hipSuccess) return fail_hip(c, e1, "hipMemcpyAsync(buffers ready)");
+            HIP_TRY(c, hipMemcpyAsync(ready.data(), c->x_cnt.p, (size_t)world * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            for (int p = 0; p < world; ++p)
+                if (ready[(size_t)p] != 1) {
+                    c->last_error = "raft_hip_exchange: rank " + std::to_string(p) + " has no device memory for what it is about to receive";
+                    return RAFT_HIP_ERR_NOMEM;
+                }
+        } else if (ea != hipSuccess) return fail_hip(c, ea, "raft_hip_exchange: receive buffers");   // (cannot happen: nothing had to grow)
+    }
     RunBases rb{};
     {
         long long base = 0;
@@ -3544,8 +3590,9 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
     }
     // ---- the exchange: per ordered pair of ranks the sends and the receives are issued in the same order (run by run:
     // qs, qe, offsets), all inside one group -- xGMI is point-to-point, every pair has its own link
-    NCCL_TRY(r->GroupStart());
     {
+        const ncclResult_t gs = r->GroupStart();
+        if (gs != ncclSuccess) return nccl_fail(gs, "ncclGroupStart");
         // (a failed post must not leave the group open: the first error is kept, the group is closed, then the call returns)
         ncclResult_t first = ncclSuccess;
         const char *what = "";
@@ -3556,7 +3603,7 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
                 if (n <= 0) continue;
                 if (!post(r->Send(mine->d_qs + lo, (size_t)n, ncclInt32, g, comm, st), "ncclSend(qs)")) break;
                 if (!one_col && !post(r->Send(mine->d_qe + lo, (size_t)n, ncclInt32, g, comm, st), "ncclSend(qe)")) break;
-                post(r->Send(c->x_send_off.as<long long>() + j * N1 + bounds[g], (size_t)(bounds[g + 1] - bounds[g] + 1), ncclInt64, g, comm, st), "ncclSend(offsets)");
+                post(r->Send(d_send_off + j * N1 + bounds[g], (size_t)(bounds[g + 1] - bounds[g] + 1), ncclInt64, g, comm, st), "ncclSend(offsets)");
             }
         for (size_t k = 0; k < runs.size() && first == ncclSuccess; ++k) {
             if (!post(r->Recv(c->x_qs.as<int32_t>() + rb.base[k], (size_t)runs[k].n, ncclInt32, runs[k].peer, comm, st), "ncclRecv(qs)")) break;
@@ -3564,10 +3611,9 @@ int raft_hip_exchange(raft_hip_ctx *c, void *comm_v, int32_t rank, int32_t world
             post(r->Recv(c->x_raw.as<long long>() + (long long)k * n1, (size_t)n1, ncclInt64, runs[k].peer, comm, st), "ncclRecv(offsets)");
         }
         const ncclResult_t ge = r->GroupEnd();
-        if (first != ncclSuccess) { c->last_error = std::string(what) + ": " + r->GetErrorString(first); return RAFT_HIP_ERR_DEVICE; }
-        if (ge != ncclSuccess) { c->last_error = std::string("ncclGroupEnd: ") + r->GetErrorString(ge); return RAFT_HIP_ERR_DEVICE; }
+        if (first != ncclSuccess) return nccl_fail(first, what);
+        if (ge != ncclSuccess) return nccl_fail(ge, "ncclGroupEnd");
     }
-#undef NCCL_TRY
     if (runs.empty()) HIP_TRY(c, hipMemsetAsync(c->x_off.p, 0, (size_t)n1 * 8, st));
     else
         hipLaunchKernelGGL(rebase_offsets_kernel, dim3((unsigned)((n1 * K + 255) / 256)), dim3(256), 0, st, K, n1, c->x_raw.as<long long>(), rb,

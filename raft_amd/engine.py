@@ -47,7 +47,7 @@ class _Summary(C.Structure):
                 ("n_repeats", C.c_int64), ("n_cuts", C.c_int64), ("n_fragments", C.c_int64),
                 ("total_coverage", C.c_int64), ("total_windows", C.c_int64),
                 ("total_repeat_length", C.c_int64), ("total_read_length", C.c_int64),
-                ("error_index", C.c_int64), ("n_devices_used", C.c_int32), ("reserved", C.c_int32)]
+                ("error_index", C.c_int64), ("n_devices_used", C.c_int32), ("flags", C.c_int32)]
 
 
 class _HostOutputs(C.Structure):
@@ -59,7 +59,8 @@ class _HostOutputs(C.Structure):
 
 
 class _Slice(C.Structure):
-    _fields_ = [("n_rec", C.c_int64), ("n_runs", C.c_int32), ("rec_offset", C.c_void_p), ("d_qs", C.c_void_p), ("d_qe", C.c_void_p)]
+    _fields_ = [("n_rec", C.c_int64), ("n_runs", C.c_int32), ("rec_offset", C.c_void_p), ("d_qs", C.c_void_p), ("d_qe", C.c_void_p),
+                ("d_rec_offset", C.c_void_p)]
 
 
 class _Records(C.Structure):
@@ -95,7 +96,7 @@ class Summary:
     total_read_length: int
     error_index: int
     n_devices_used: int = 0
-    reserved: int = 0
+    flags: int = 0                # RAFT_HIP_SUM_*: bit 0 = the general bucketing handed the pileup kernel window records
 
 
 class RaftError(RuntimeError):
@@ -719,8 +720,10 @@ class Slice:
     grouped form -- int64 [n_runs, n_reads_total + 1], where every read of the whole set begins in every sorted run of the slice
     (raft_amd.hostio.group_offsets on the slice's query column)."""
 
-    def __init__(self, rec_offset, qs, qe=None):
-        """``qe=None``: ``qs`` holds window records (one int32-viewed word per record, hostio.pack_windows) -- one column travels."""
+    def __init__(self, rec_offset, qs, qe=None, device_offsets=False):
+        """``qe=None``: ``qs`` holds window records (one int32-viewed word per record, hostio.pack_windows) -- one column travels.
+        ``device_offsets``: keep a copy of the offsets on the slice's device (raft_hip_slice::d_rec_offset), so that exchanging the
+        same slice again uploads nothing."""
         import torch
         self.off = np.ascontiguousarray(np.asarray(rec_offset), dtype=np.int64)
         if self.off.ndim != 2 or not (1 <= self.off.shape[0] <= 4):
@@ -729,10 +732,12 @@ class Slice:
             if t is not None and (t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous()):
                 raise TypeError("Slice needs contiguous int32 CUDA tensors")
         self.qs, self.qe = qs, qe
+        self.d_off = torch.as_tensor(self.off).to(qs.device) if device_offsets else None
 
     def c(self) -> "_Slice":
         return _Slice(int(self.qs.numel()), int(self.off.shape[0]), self.off.ctypes.data, self.qs.data_ptr() if self.qs.numel() else 0,
-                      self.qe.data_ptr() if (self.qe is not None and self.qe.numel()) else 0)
+                      self.qe.data_ptr() if (self.qe is not None and self.qe.numel()) else 0,
+                      self.d_off.data_ptr() if self.d_off is not None else 0)
 
 
 def _received_views(eng, r: "_Received") -> dict:
