@@ -447,6 +447,7 @@ struct raft_hip_ctx {
     std::string last_error;
 
     // device buffers
+    DevBuf tail_buf;                  // the fused tail's sums (finalize.hpp FinalizeArgs::tail_part ...)
     DevBuf wave_ctr, ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_desc, tile_cuts, slow_list, block_sums;
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
@@ -641,7 +642,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
     c->lane_up_ev.clear(); c->lane_down_ev.clear();
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
-    DevBuf *all[] = {&c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
+    DevBuf *all[] = {&c->tail_buf, &c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->gs_rid, &c->gs_s, &c->gs_e, &c->gs_off, &c->gs_err, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1, &c->gaps, &c->in_len,
@@ -1066,6 +1067,10 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     HIP_TRY(c, c->rep_off.ensure((size_t)(N + 1) * 8));
     HIP_TRY(c, c->cut_off.ensure((size_t)(N + 1) * 8));
     HIP_TRY(c, c->frag_off.ensure((size_t)(N + 1) * 8));
+    // the tail's sums: per workgroup of 256 reads four words from the count kernel, three of their prefix
+    const int tail_blocks = (int)std::max<long long>(1, (N + 255) / 256);
+    HIP_TRY(c, c->tail_buf.ensure((size_t)7 * tail_blocks * 8));
+    long long *const tail_part = c->tail_buf.as<long long>(), *const tail_prefix = tail_part + (size_t)4 * tail_blocks;
 
     hipLaunchKernelGGL(tile_first_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, st, n_reads,
                        c->cov_off.as<long long>(), Q, n_tiles, c->tile_first.as<int32_t>(), &ctrl->err_flags, &ctrl->err_index, grp,
@@ -1376,32 +1381,26 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     fa.by_L = make_fast_div(c->prm.interval_length); fa.by_div = make_fast_div(c->div); fa.by_reso = make_fast_div(c->prm.reso);
     fa.long_windows = recut ? pv.cap : INT32_MAX; fa.reso = c->prm.reso; fa.repeat_length = c->prm.repeat_length;
     fa.flank = c->prm.flanking_length; fa.rep_cnt_rw = c->rep_cnt.as<int32_t>(); fa.total_repeat = &ctrl->totals[1];
-    if (N > 0) {
-        // (Measured and dropped: count and fill riding in the scan's first / last pass -- the scan walks eight consecutive
-        // reads per thread, and the fill's stores from that shape took 320 us against 65 us; and a single-launch version
-        // with decoupled look-back, finalize.hpp.)
-        const unsigned rgrid = (unsigned)((N + 255) / 256);
-        // (Measured and dropped, round 3: the per-read count as the loader of the scan's first pass -- finalize.hpp
-        // FinalizeCountLoader, one launch less: that pass walks eight reads per thread, and 32 us replaced 9 + 7 on an eighth
-        // of the human-scale set.)
-        hipLaunchKernelGGL(finalize_count_kernel, dim3(rgrid), dim3(256), 0, st, fa);
-        CountLoader<3> ld{{c->rep_cnt.as<int32_t>(), c->cut_cnt.as<int32_t>(), c->frag_cnt.as<int32_t>()}};
-        ScanOut<3> so{{c->rep_off.as<long long>(), c->cut_off.as<long long>(), c->frag_off.as<long long>()}};
-        exclusive_scan<CountLoader<3>, 3>(st, ld, N, c->scan_tmp.as<long long>(), so);
-        if (c->emit_cuts) hipLaunchKernelGGL(finalize_fill_kernel<true>, dim3(rgrid), dim3(256), 0, st, fa);
-        else hipLaunchKernelGGL(finalize_fill_kernel<false>, dim3(rgrid), dim3(256), 0, st, fa);
-    } else {
-        HIP_TRY(c, hipMemsetAsync(c->rep_off.p, 0, 8, st));
-        HIP_TRY(c, hipMemsetAsync(c->cut_off.p, 0, 8, st));
-        HIP_TRY(c, hipMemsetAsync(c->frag_off.p, 0, 8, st));
-    }
+    fa.tail_part = tail_part; fa.tail_prefix = tail_prefix; fa.tail_blocks = tail_blocks;
+    fa.rep_off_w = c->rep_off.as<long long>(); fa.cut_off_w = c->cut_off.as<long long>(); fa.frag_off_w = c->frag_off.as<long long>();
     {
-        const unsigned g = (unsigned)std::min<long long>((std::max(n_tiles, N) + 255) / 256, 512);
-        hipLaunchKernelGGL(totals_kernel, dim3(std::max(g, 1u)), dim3(256), 0, st, (long long)n_sum_blocks, c->block_sums.as<long long>(),
-                           n_reads, d_len, ctrl->totals, c->rep_off.as<long long>(), c->cut_off.as<long long>(),
-                           c->frag_off.as<long long>(), c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr,
-                           ctrl->out_totals, &ctrl->totals_done, reinterpret_cast<const long long *>(ctrl), (int)(sizeof(Ctrl) / 8),
-                           c->pinned_dev + 128, ++c->pass_seq);   // everything finish() reports travels in one block (+1024 bytes), written by the last workgroup
+        // The tail: count -> prefix -> fill -> publish (finalize.hpp FinalizeArgs::tail_part).  The fill kernel makes the three offset
+        // arrays on its way; one workgroup in between turns the count kernel's per-workgroup sums into bases and into the totals the
+        // host is handed; the last kernel, one wave, hands the control block over -- one block (+1024 bytes) of the context's
+        // page-locked memory, stamped with the pass's number.
+        const unsigned rgrid = (unsigned)tail_blocks;
+        TailPublish tp{};
+        tp.n_tiles = (long long)n_sum_blocks; tp.tile_sums = c->block_sums.as<long long>(); tp.totals = ctrl->totals;
+        tp.bucket_off = c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr; tp.tails = ctrl->out_totals;
+        tp.ctrl_words = reinterpret_cast<const long long *>(ctrl); tp.n_ctrl_words = (int)(sizeof(Ctrl) / 8);
+        tp.host_block = c->pinned_dev + 128; tp.pass_seq = ++c->pass_seq;
+        if (N > 0) hipLaunchKernelGGL(finalize_count_kernel, dim3(rgrid), dim3(256), 0, st, fa);
+        hipLaunchKernelGGL(tail_prefix_kernel, dim3((unsigned)((tail_blocks + 1023) / 1024)), dim3(1024), 0, st, fa, tp);
+        if (N > 0) {
+            if (c->emit_cuts) hipLaunchKernelGGL(finalize_fill_kernel<true>, dim3(rgrid), dim3(256), 0, st, fa);
+            else hipLaunchKernelGGL(finalize_fill_kernel<false>, dim3(rgrid), dim3(256), 0, st, fa);
+        }
+        hipLaunchKernelGGL(publish_ctrl_kernel, dim3(1), dim3(64), 0, st, tp);
         c->seq_armed = true;
     }
     c->fa = fa; c->cuts_ready = c->emit_cuts;

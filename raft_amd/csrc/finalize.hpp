@@ -49,6 +49,20 @@ struct FinalizeArgs {
     int32_t *rep_s, *rep_e, *cuts, *frag_read, *frag_begin, *frag_end;
     int32_t *err_flags;
     long long *err_index;
+    // the tail's offsets without a scan of their own (round 6): finalize_count_kernel leaves every workgroup's sums of (repeats, cut
+    // points, fragments, read length) in tail_part[]; tail_prefix_kernel -- ONE workgroup -- turns them into where every workgroup's
+    // reads begin, and into the totals the host is handed; finalize_fill_kernel scans its 256 reads in the workgroup and writes
+    // rep_off / cut_off / frag_off itself; publish_ctrl_kernel hands the control block over.  count -> prefix -> fill -> publish:
+    // four launches, the middle one over N / 256 words, where there were five with two passes over the reads' counts and a third over
+    // their lengths (count, scan_partials, scan_apply, fill, totals).
+    // (Measured and dropped on the way, profiles/r06_tail_parts.txt: TWO launches, what crosses workgroups inside a kernel travelling in
+    // device-scope atomics -- per wave: non-returning adds into shared sums cost the count kernel 35 us of a pass over 3.3 M reads, a
+    // returning one per wave the fill kernel 55 us; per workgroup of 1024 reads: fill 206 us against 100, its sixteen waves waiting
+    // for each other at the barrier their common sums need.)
+    long long *tail_part;                 // [4][tail_blocks]
+    long long *tail_prefix;               // [3][tail_blocks]
+    int32_t tail_blocks;
+    long long *rep_off_w, *cut_off_w, *frag_off_w;   // (the offset arrays, writable)
 };
 
 __device__ __forceinline__ void swap3(int32_t *k, int32_t *s, int32_t *e, long long i, long long j)
@@ -343,17 +357,98 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
     __shared__ int32_t sort_stk[256 / 64][kSortStack];
+    __shared__ long long scr[4][4];
     long long bp = 0;
-    {
-        int n, nF, nf;
-        finalize_count_one(a, r < a.n_reads, r, n, nF, nf, bp, sort_stk[threadIdx.x >> 6]);
-    }
+    int n, nF, nf;
+    finalize_count_one(a, r < a.n_reads, r, n, nF, nf, bp, sort_stk[threadIdx.x >> 6]);
     // one atomic per wave that has anything to add
     if (__ballot(bp != 0) != 0ull) {
         const long long s = wave_reduce_add64(bp);
         if ((threadIdx.x & 63) == 0) atomicAdd(a.total_repeat, (unsigned long long)s);
     }
+    // what the offsets and the totals are made of: this workgroup's sums (the kernel's one barrier, at its end)
+    const long long v[4] = {wave_reduce_add64(n), wave_reduce_add64(nF), wave_reduce_add64(nf), wave_reduce_add64(r < a.n_reads ? a.read_len[r] : 0)};
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) scr[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) a.tail_part[(long long)threadIdx.x * a.tail_blocks + blockIdx.x] = scr[threadIdx.x][0] + scr[threadIdx.x][1] + scr[threadIdx.x][2] + scr[threadIdx.x][3];
 }
+
+// What the pass hands the host at its end: the sums of the pileup kernel's workers, the control block, the page-locked block the
+// host looks at.
+struct TailPublish {
+    long long n_tiles;                    // workers of the pileup kernel(s): two sums each in tile_sums
+    const long long *tile_sums;
+    unsigned long long *totals;           // Ctrl::totals: coverage, repeat bp, read length
+    const long long *bucket_off;          // general bucketing: its offsets (the true interval count at [n_reads]), else nullptr
+    long long *tails;                     // Ctrl::out_totals
+    const long long *ctrl_words;
+    int n_ctrl_words;
+    long long *host_block;
+    long long pass_seq;
+};
+
+// tail_part -> tail_prefix (exclusive) and the totals.  A workgroup per 1024 entries (N / 256 entries per array: 13 k for 3.3 M
+// reads): it adds up the entries before its own by itself -- a few KB from L2, all workgroups at once -- and scans its 1024.  The
+// last one also adds up what totals_kernel added up until round 5: the pileup workers' sums, the reads' lengths (the count kernel's
+// fourth sum).  (ONE workgroup walking the array 1024 entries at a time took 53 us at that size; with its entries held in registers
+// between two looks at them, 64.)
+__global__ __launch_bounds__(1024) void tail_prefix_kernel(FinalizeArgs a, TailPublish tp)
+{
+    __shared__ long long scr[4][16], bas[4][16];
+    const int lane = (int)threadIdx.x & 63, wid = (int)threadIdx.x >> 6;
+    const bool stop = (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) != 0;
+    const int nb = stop || a.n_reads == 0 ? 0 : a.tail_blocks;
+    const int first = (int)blockIdx.x * 1024, i = first + (int)threadIdx.x;
+    const bool closing = blockIdx.x == gridDim.x - 1;
+    long long base[4] = {0, 0, 0, 0}, v[4], inc[4];
+    for (int j = (int)threadIdx.x; j < min(first, nb); j += 1024) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) base[k] += a.tail_part[(long long)k * a.tail_blocks + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = i < nb ? a.tail_part[(long long)k * a.tail_blocks + i] : 0;
+        inc[k] = wave_incl_scan_add64(v[k]);
+        base[k] = wave_reduce_add64(base[k]);
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { scr[k][wid] = inc[k]; bas[k][wid] = base[k]; }
+    }
+    __syncthreads();
+    long long run[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long x = lane < 16 ? scr[k][lane] : 0, y = lane < 16 ? bas[k][lane] : 0;
+        const long long all = wave_reduce_add64(x), before = wave_reduce_add64(lane < wid ? x : 0), b0 = wave_reduce_add64(y);
+        if (k < 3 && i < nb) a.tail_prefix[(long long)k * a.tail_blocks + i] = b0 + before + inc[k] - v[k];
+        run[k] = b0 + all;
+    }
+    if (!closing) return;
+    long long v0 = 0, v1 = 0;                     // coverage, repeat bp: the sums of the pileup workers
+    for (long long j = threadIdx.x; j < tp.n_tiles; j += 1024) { v0 += tp.tile_sums[2 * j]; v1 += tp.tile_sums[2 * j + 1]; }
+    v0 = wave_reduce_add64(v0); v1 = wave_reduce_add64(v1);
+    __syncthreads();
+    if (lane == 0) { scr[0][wid] = v0; scr[1][wid] = v1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long c0 = 0, c1 = 0;
+        for (int w = 0; w < 16; ++w) { c0 += scr[0][w]; c1 += scr[1][w]; }
+        tp.totals[0] += (unsigned long long)c0; tp.totals[1] += (unsigned long long)c1;     // ([1]: finalize_count_kernel's joined long reads are in already)
+        tp.totals[2] += (unsigned long long)run[3];
+        tp.tails[0] = run[0]; tp.tails[1] = run[1]; tp.tails[2] = run[2];
+        tp.tails[3] = tp.bucket_off ? tp.bucket_off[a.n_reads] : 0;
+        a.rep_off_w[a.n_reads] = run[0]; a.cut_off_w[a.n_reads] = run[1]; a.frag_off_w[a.n_reads] = run[2];
+    }
+}
+
+// the pass's last kernel: one wave copies the control block -- everything raft_hip_finish reports -- into the context's page-locked
+// block, stamped with the pass's number: raft_hip_finish looks for it itself instead of sleeping in the runtime's wait (whose
+// wake-up is 20-30 us of a pass that may take 200)
+__global__ __launch_bounds__(64) void publish_ctrl_kernel(TailPublish tp);
 
 // Compact repeats and the fragments of every read.  The cut points themselves (chop.hpp's final_stars, 4 B per
 // marker: 0.4 GB on the human-scale set) are neither stored nor walked here: fragment j begins at the kept marker
@@ -404,54 +499,6 @@ __device__ __forceinline__ void finalize_fill_one(const FinalizeArgs &a, int r, 
     a.frag_end[fo + nf - 1] = len;                // the last kept marker is the read's end
 }
 
-// CUTS: the pass also writes the cut points themselves (chop.hpp:225-246 final_stars; SURVEY.md §8 row a7) -- the default of a
-// context (raft_hip_set_emit_cuts); the host pipelines, whose outputs hold no cut points, leave them to finalize_cuts_kernel.
-template <bool CUTS>
-__global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_reads) return;
-    if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
-    // everything the read's thread needs, asked for at once: behind the first store a load of an int32 array would wait for the
-    // stores (they may overlap, as far as the compiler knows), and a thread's time here is its chain of dependent loads
-    const int n = a.rep_cnt[r], nF = a.cut_cnt[r], len = a.read_len[r];
-    const long long ro = a.rep_off[r], fo = a.frag_off[r], base = a.rep_res_off[r], co = CUTS ? a.cut_off[r] : 0;
-    int32_t *F = a.cuts + co;
-    int w = 0;
-    if (n <= 4) {                                 // (the reads without a repeat too: one instruction stream for nearly every wave)
-        const int32_t *S = a.raw_s + base, *E = a.raw_e + base;
-        const int i0 = n > 0 ? 0 : -1, i1 = min(1, n - 1), i2 = min(2, n - 1), i3 = n - 1;
-        auto at = [&](const int32_t *p, int i) { return i >= 0 ? p[i] : 0; };
-        const RepReg rep{at(S, i0), at(S, i1), at(S, i2), at(S, i3), at(E, i0), at(E, i1), at(E, i2), at(E, i3)};
-        finalize_fill_one(a, r, ro, fo, n, nF, len, rep);
-        if (CUTS) (void)walk_cuts(len, a.interval_length, a.by_L, rep, n, [&](int m) { F[w++] = m; });
-    } else {
-        const RepMem rep{a.raw_s + base, a.raw_e + base};
-        finalize_fill_one(a, r, ro, fo, n, nF, len, rep);
-        if (CUTS) (void)walk_cuts(len, a.interval_length, a.by_L, rep, n, [&](int m) { F[w++] = m; });
-    }
-}
-
-// (Measured and dropped: count, offsets and fill in ONE launch -- a single-pass scan with decoupled look-back over
-// per-workgroup sums, 256 or 1024 reads per workgroup.  Bit-exact on the whole suite, but 0.07-0.17 ms SLOWER than the
-// five-launch chain on the human-scale set: every resident workgroup reaches its look-back at about the same time and
-// walks over all the others, and the fill cannot start before that.)
-
-// cut points of every read (final_stars), on demand
-__global__ __launch_bounds__(256) void finalize_cuts_kernel(FinalizeArgs a)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_reads) return;
-    if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
-    int32_t *F = a.cuts + a.cut_off[r];
-    int w = 0;
-    (void)walk_cuts(a.read_len[r], a.interval_length, a.by_L, RepMem{a.raw_s + a.rep_res_off[r], a.raw_e + a.rep_res_off[r]}, a.rep_cnt[r],
-                    [&](int m) { F[w++] = m; });
-}
-
-// totals[0] = sum coverage, [1] = sum unclamped repeat bp, [2] = sum read length.  One atomic per workgroup and
-// total (a few hundred per launch): with one per wave the three counters saw 12 k serialised atomics and the kernel
-// took 56 us for 13 MB of input.
 // What the host reads back without the runtime's wait travels in STAMPED LINES: 64 bytes of the context's page-locked block hold six
 // 8-byte data words and, in words 3 and 7, the number of the hand-over; one store instruction of the wave writes all lines, and a
 // line (at the least each 32-byte half of it) arrives whole.  The host takes a line when both stamps are the number it waits for.
@@ -482,57 +529,81 @@ inline void unstamp(const volatile long long *h, int n_words, long long *out)
 {
     for (int i = 0; i < n_words; ++i) { const int pos = i % kStampData; out[i] = h[(i / kStampData) * 8 + (pos < 3 ? pos : pos + 1)]; }
 }
-__global__ __launch_bounds__(256) void totals_kernel(long long n_tiles, const long long *tile_sums, int32_t n_reads,
-                                                     const int32_t *read_len, unsigned long long *totals,
-                                                     const long long *rep_off, const long long *cut_off,
-                                                     const long long *frag_off, const long long *bucket_off, long long *tails,
-                                                     unsigned *done_blocks, const long long *ctrl_words, int n_ctrl_words,
-                                                     long long *host_block, long long pass_seq)
+// CUTS: the pass also writes the cut points themselves (chop.hpp:225-246 final_stars; SURVEY.md §8 row a7) -- the default of a
+// context (raft_hip_set_emit_cuts); the host pipelines, whose outputs hold no cut points, leave them to finalize_cuts_kernel.
+// Round 6: the kernel makes the three offset arrays itself (see FinalizeArgs::tail_part), adds up what totals_kernel added up and
+// its last workgroup publishes the control block -- the pass's tail is count -> fill.
+template <bool CUTS>
+__global__ __launch_bounds__(256) void finalize_fill_kernel(FinalizeArgs a)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {    // output sizes, so that the host reads one block back
-        tails[0] = rep_off[n_reads]; tails[1] = cut_off[n_reads]; tails[2] = frag_off[n_reads];
-        tails[3] = bucket_off ? bucket_off[n_reads] : 0;
-    }
-    __shared__ long long part[3][4];
-    long long c = 0, rp = 0, l = 0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (long long i = i0; i < n_tiles; i += stride) { c += tile_sums[2 * i]; rp += tile_sums[2 * i + 1]; }
-    {   // (eight loads in flight per thread: one after the other, a thread's 25 strides of a human-scale set were the kernel's 20 us)
-        long long i = i0;
-        for (; i + 7 * stride < n_reads; i += 8 * stride) {
-            int32_t v[8];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
+    const int lane = (int)threadIdx.x & 63, wid = (int)threadIdx.x >> 6;
+    const bool live = r < a.n_reads;
+    __shared__ long long wtot[3][4];
+    // everything the read's thread needs, asked for at once: behind the first store a load of an int32 array would wait for the
+    // stores (they may overlap, as far as the compiler knows), and a thread's time here is its chain of dependent loads
+    const int n = live ? a.rep_cnt[r] : 0, nF = live ? a.cut_cnt[r] : 0, nf = live ? a.frag_cnt[r] : 0, len = live ? a.read_len[r] : 0;
+    const long long rbase = live ? a.rep_res_off[r] : 0;
+    // where this read's outputs begin: the workgroup's base (tail_prefix_kernel), the reads of the workgroup before this one -- a scan
+    // in the wave, the waves' totals through LDS (the kernel's one barrier, near its start)
+    long long ex[3];
+    {
+        const long long v[3] = {n, nF, nf};
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = read_len[i + u * stride];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) l += v[u];
+        for (int k = 0; k < 3; ++k) {
+            const long long inc = wave_incl_scan_add64(v[k]);
+            ex[k] = inc - v[k] + a.tail_prefix[(long long)k * a.tail_blocks + blockIdx.x];
+            if (lane == 63) wtot[k][wid] = inc;
         }
-        for (; i < n_reads; i += stride) l += read_len[i];
-    }
-    c = wave_reduce_add64(c); rp = wave_reduce_add64(rp); l = wave_reduce_add64(l);
-    const int wid = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { part[0][wid] = c; part[1][wid] = rp; part[2][wid] = l; }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const long long v = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
-        if (v) atomicAdd(&totals[threadIdx.x], (unsigned long long)v);
-    }
-    // The workgroup that finishes last copies the control block -- everything raft_hip_finish reports -- into the context's
-    // page-locked block (a one-wave kernel of its own before: one launch less at the end of every pass).
-    __shared__ int last;
-    __syncthreads();                                     // (this workgroup's three atomics are issued)
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(done_blocks, 1u) == gridDim.x - 1 ? 1 : 0;
     }
     __syncthreads();
-    if (last && (int)threadIdx.x < 64) {
-        __threadfence();
-        // ... stamped with the pass's number: raft_hip_finish looks for it itself instead of sleeping in the runtime's wait
-        // (whose wake-up is 20-30 us of a pass that may take 200)
-        publish_stamped(host_block, [&](int i) { return reinterpret_cast<const volatile long long *>(ctrl_words)[i]; }, n_ctrl_words, pass_seq, (int)threadIdx.x);
-        __threadfence_system();
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int w = 0; w < 3; ++w) ex[k] += w < wid ? wtot[k][w] : 0;
+    if (!live) return;
+    const long long ro = ex[0], co = ex[1], fo = ex[2];
+    a.rep_off_w[r] = ro; a.cut_off_w[r] = co; a.frag_off_w[r] = fo;
+    int32_t *F = a.cuts + co;
+    int wr = 0;
+    if (n <= 4) {                                 // (the reads without a repeat too: one instruction stream for nearly every wave)
+        const int32_t *S = a.raw_s + rbase, *E = a.raw_e + rbase;
+        const int i0 = n > 0 ? 0 : -1, i1 = min(1, n - 1), i2 = min(2, n - 1), i3 = n - 1;
+        auto at = [&](const int32_t *p, int i) { return i >= 0 ? p[i] : 0; };
+        const RepReg rep{at(S, i0), at(S, i1), at(S, i2), at(S, i3), at(E, i0), at(E, i1), at(E, i2), at(E, i3)};
+        finalize_fill_one(a, r, ro, fo, n, nF, len, rep);
+        if (CUTS) (void)walk_cuts(len, a.interval_length, a.by_L, rep, n, [&](int m) { F[wr++] = m; });
+    } else {
+        const RepMem rep{a.raw_s + rbase, a.raw_e + rbase};
+        finalize_fill_one(a, r, ro, fo, n, nF, len, rep);
+        if (CUTS) (void)walk_cuts(len, a.interval_length, a.by_L, rep, n, [&](int m) { F[wr++] = m; });
     }
 }
 
+__global__ __launch_bounds__(64) void publish_ctrl_kernel(TailPublish tp)
+{
+    publish_stamped(tp.host_block, [&](int i) { return reinterpret_cast<const volatile long long *>(tp.ctrl_words)[i]; }, tp.n_ctrl_words, tp.pass_seq, (int)threadIdx.x);
+    __threadfence_system();
+}
+
+// (Measured and dropped: count, offsets and fill in ONE launch -- a single-pass scan with decoupled look-back over
+// per-workgroup sums, 256 or 1024 reads per workgroup.  Bit-exact on the whole suite, but 0.07-0.17 ms SLOWER than the
+// five-launch chain on the human-scale set: every resident workgroup reaches its look-back at about the same time and
+// walks over all the others, and the fill cannot start before that.)
+
+// cut points of every read (final_stars), on demand
+__global__ __launch_bounds__(256) void finalize_cuts_kernel(FinalizeArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    if (*(volatile int32_t *)a.err_flags & (kErrStop | kErrLen)) return;   // (sizes or lengths are not what the pass was built on)
+    int32_t *F = a.cuts + a.cut_off[r];
+    int w = 0;
+    (void)walk_cuts(a.read_len[r], a.interval_length, a.by_L, RepMem{a.raw_s + a.rep_res_off[r], a.raw_e + a.rep_res_off[r]}, a.rep_cnt[r],
+                    [&](int m) { F[w++] = m; });
+}
+
+// totals[0] = sum coverage, [1] = sum unclamped repeat bp, [2] = sum read length.  One atomic per workgroup and
+// total (a few hundred per launch): with one per wave the three counters saw 12 k serialised atomics and the kernel
+// took 56 us for 13 MB of input.
 } // namespace raft
