@@ -92,9 +92,12 @@ typedef struct raft_hip_summary {
                                    == 1) RAFT_HIP_ERR_COORD reports the index into the BUCKETED interval array */
     int32_t n_devices_used;     /* host-to-host entry points: contexts that took part in the job (1 for a one-piece pass) */
     int32_t flags;              /* RAFT_HIP_SUM_*: bit 0 -- the general bucketing (interval_path == 1) sorted its sides as window-record items
-                                   and the pileup kernel read those (4 bytes per interval) instead of coordinate columns */
+                                   and the pileup kernel read those (4 bytes per interval) instead of coordinate columns;
+                                   bit 1 -- the pass was built, without its host wait, on what the context's previous pass over a stream
+                                   of the same shape had found (sizes, sorted runs), and the device confirmed it (raft_hip_run_device) */
 } raft_hip_summary;
 #define RAFT_HIP_SUM_BUCKET_WINDOWS 1
+#define RAFT_HIP_SUM_SPECULATED 2
 
 /* Device-resident outputs of the last run (valid until the next run/destroy).
  * Layout is CSR per read, FASTA-index order (= reference output order):

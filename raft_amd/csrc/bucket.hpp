@@ -97,17 +97,14 @@ __global__ __launch_bounds__(256) void inspect_kernel(long long n_rec, int32_t n
 // The samples themselves are kept (1 MB): they are a coarse index of the stream.  tile_desc_kernel bisects them first
 // -- cache hits -- and then only the ~1 k records between two samples, instead of 28 dependent probes spread over a
 // GB-sized column (every one of them a TLB miss).
-struct GuessOut {
-    int32_t n_desc, pad;
-    long long desc_pos[kMaxSeg];
-};
+// (struct GuessOut: pileup.hpp, beside tile_desc_kernel, which checks a speculative pass against it)
 
 
-__global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const int32_t *qid, GuessOut *out, int32_t *samples)
+__device__ __forceinline__ void guess_runs_body(long long block, long long n_rec, const int32_t *qid, GuessOut *out, int32_t *samples)
 {
     const int sh = sample_shift(n_rec);                   // (out->n_desc was zeroed with the control block)
     const long long S = n_samples(n_rec, sh);
-    const long long i = 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = 1 + block * blockDim.x + threadIdx.x;
     if (i == 1 && samples) samples[0] = qid[0];
     if (i >= S) return;
     const long long p0 = sample_pos(i - 1, n_rec, sh), p1 = sample_pos(i, n_rec, sh);
@@ -130,6 +127,19 @@ __global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const 
         if (slot < kMaxSeg) out->desc_pos[slot] = hi;
     }
 }
+
+__global__ __launch_bounds__(256) void guess_runs_kernel(long long n_rec, const int32_t *qid, GuessOut *out, int32_t *samples)
+{
+    guess_runs_body((long long)blockIdx.x, n_rec, qid, out, samples);
+}
+// ... riding in the geometry scan's first launch (device_scan.hpp Beside): the workgroups behind the scan's own
+struct GuessBeside {
+    long long n_rec;
+    const int32_t *qid;
+    GuessOut *out;
+    int32_t *samples;
+    __device__ void operator()(int block) const { guess_runs_body(block, n_rec, qid, out, samples); }
+};
 
 // tile_first[k] = first read whose first window lies in tile k or later (tiles of Q windows).  For grouped input the same
 // threads -- one per read, coalesced -- check the caller's offsets: they must not step back and the runs must chain from
@@ -167,6 +177,47 @@ __global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const 
     const long long t_p = (r > 0) ? cov_off[r - 1] / Q : -1;
     for (long long k = t_p + 1; k <= t_r; ++k) tile_first[k] = (int32_t)r;
 }
+
+// tile_first_kernel's work riding in the geometry scan's second launch (device_scan.hpp Post), for a pass whose sizes the host
+// knows -- or assumes -- before anything has run (the caller's window count; what the context's last pass over a stream of this
+// shape found): every read as the scan writes its offsets -- its repeat counter cleared, the caller's offsets checked, the tiles
+// that begin inside it (read r owns the windows [off, off + nb): tile k begins at window k Q, and its first read is r + 1 when
+// off < k Q <= off + nb) -- and on the last workgroup the sizes the pass was built on against the ones the scan found (kErrHint:
+// every later kernel of the pass returns at once, raft_hip_finish runs it again with the host wait).
+struct PrepPost {
+    int32_t n_reads, Q;
+    long long n_tiles;
+    int32_t *tile_first, *rep_cnt, *err_flags;
+    long long *err_index;
+    GroupedOff grp;
+    int32_t n_runs;
+    long long n_rec;
+    long long want_bins, cap_rep, cap_cut;        // the sizes the host built the pass on: windows (exact), reserved repeat slots and markers (at most)
+    __device__ void operator()(long long r, const long long (&off)[3], const long long (&v)[3]) const
+    {
+        rep_cnt[r] = 0;
+        if (grp.off) {
+            bool bad = false;
+            for (int s = 0; s < n_runs; ++s) bad |= grp.at(s, r) > grp.at(s, r + 1);
+            if (r == 0) {
+                long long at = 0;
+                for (int s = 0; s < n_runs; ++s) { bad |= grp.at(s, 0) != at; at = grp.at(s, n_reads); }
+                bad |= at != n_rec;
+            }
+            if (bad) {
+                atomicOr(err_flags, kErrGroup);
+                atomicMin((unsigned long long *)err_index, (unsigned long long)r);
+            }
+        }
+        if (r == 0) tile_first[0] = 0;
+        const long long k0 = off[0] / Q + 1, k1 = r + 1 == n_reads ? n_tiles : min((off[0] + v[0]) / Q, n_tiles);
+        for (long long k = k0; k <= k1; ++k) tile_first[k] = (int32_t)(r + 1);
+    }
+    __device__ void closing(const long long (&tot)[3]) const
+    {
+        if (tot[0] != want_bins || tot[1] > cap_rep || tot[2] > cap_cut) atomicOr(err_flags, kErrHint);
+    }
+};
 
 // ---- grouped input of more runs than the pileup kernels take (kMaxSeg): merged into ONE run first ----------------------
 // (a PAF concatenated from many files; the intervals a rank of a pre-split job receives from its peers, two runs each).

@@ -40,9 +40,21 @@ __device__ __forceinline__ long long block_excl_scan64(long long v, long long *t
     return base + incl - v;
 }
 
-template <class Loader, int K>
-__global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(Loader ld, long long n, long long *partials)
+// Hooks (round 6: fewer launches at the head of a pass).  `Beside`: workgroups behind the scan's own run something else in the
+// same launch (the run guess, bucket.hpp GuessBeside).  `Post`: the apply kernel hands every element's exclusive offsets and values
+// to a functor as it writes them (the per-read work of tile_first_kernel, bucket.hpp PrepPost), and the grand totals to its
+// closing() on the last workgroup.
+struct NoBeside { __device__ void operator()(int) const {} };
+struct NoPost {
+    template <int K> __device__ void operator()(long long, const long long (&)[K], const long long (&)[K]) const {}
+    template <int K> __device__ void closing(const long long (&)[K]) const {}
+};
+
+template <class Loader, int K, class Beside = NoBeside>
+__global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(Loader ld, long long n, long long *partials, int n_scan_blocks = 0x7fffffff,
+                                                                     Beside beside = Beside())
 {
+    if ((int)blockIdx.x >= n_scan_blocks) { beside((int)blockIdx.x - n_scan_blocks); return; }
     __shared__ long long lds[kScanThreads / 64 + 1];
     long long acc[K];
 #pragma unroll
@@ -70,9 +82,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(Loader ld, 
 // FUSED: `partials` holds the workgroups' raw totals (scan_partials_kernel) and every workgroup adds up the ones before it by
 // itself -- a few KB from L2 per workgroup -- instead of waiting for a one-workgroup kernel to scan them (12 us per scan at
 // human scale, twice per pass); the last workgroup writes the grand totals.
-template <class Loader, int K, bool FUSED = true>
+template <class Loader, int K, bool FUSED = true, class Post = NoPost>
 __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, long long n, const long long *partials,
-                                                                  long long *totals, ScanOut<K> out)
+                                                                  long long *totals, ScanOut<K> out, Post post = Post())
 {
     __shared__ long long lds[kScanThreads / 64 + 1];
     __shared__ long long stage[kScanTile];      // blocked -> striped, so that the stores are coalesced
@@ -113,10 +125,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, lon
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] += v[j][k];
     }
+    long long first[K], grand[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         long long tot;
         long long run = (FUSED ? base[k] : partials[(long long)blockIdx.x * K + k]) + block_excl_scan64<kScanThreads>(acc[k], &tot, lds);
+        first[k] = run; grand[k] = FUSED ? base[k] + tot : 0;
         if (FUSED && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { totals[k] = base[k] + tot; out.p[k][n] = base[k] + tot; }
 #pragma unroll
         for (int j = 0; j < kScanItems; ++j) {
@@ -135,6 +149,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, lon
 #pragma unroll
         for (int k = 0; k < K; ++k) out.p[k][n] = totals[k];
     }
+    // the elements once more, for the hook: where each begins (all K sums) and what it holds
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        if (i0 + j < n) post(i0 + j, first, v[j]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) first[k] += v[j][k];
+    }
+    if (FUSED && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) post.closing(grand);
 }
 
 // Host driver.  partials must hold (scan_blocks(n) * K) + K int64; totals = partials + nblocks*K.

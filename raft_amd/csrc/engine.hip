@@ -406,6 +406,19 @@ __global__ void publish_sizes_kernel(const long long *scan_totals, const Ctrl *c
 }
 
 constexpr int kWaveCounters = 32;      // tile hand-out counters of the wave kernel, 256 bytes apart (pileup_wave.hpp next_range)
+// The pass's last kernel: one wave copies the control block -- everything raft_hip_finish reports -- into the context's page-locked
+// block, stamped with the pass's number (raft_hip_finish looks for it itself instead of sleeping in the runtime's wait, whose
+// wake-up is 20-30 us of a pass that may take 200), and then clears the block and the hand-out counters for the NEXT pass: the
+// one-wave launch that did that at the head of every pass (clear_ctrl_kernel) is only needed for a context's first pass now.
+__global__ __launch_bounds__(64) void publish_and_clear_kernel(TailPublish tp, long long *ctrl_words, int32_t *wave_ctr, int word_err_index, int word_insp_err_index)
+{
+    const int t = (int)threadIdx.x;
+    publish_stamped(tp.host_block, [&](int i) { return reinterpret_cast<const volatile long long *>(tp.ctrl_words)[i]; }, tp.n_ctrl_words, tp.pass_seq, t);
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // (every lane has its words: nothing below can overtake the reads)
+    __threadfence_system();
+    if (t < tp.n_ctrl_words) ctrl_words[t] = (t == word_err_index || t == word_insp_err_index) ? -1LL : 0LL;
+    if (t < kWaveCounters) wave_ctr[t * kCtrStride] = 0;
+}
 __global__ void clear_ctrl_kernel(Ctrl *ctrl, int32_t *wave_ctr)
 {
     constexpr int kWords = (int)(sizeof(Ctrl) / 8);
@@ -513,6 +526,20 @@ struct raft_hip_ctx {
     size_t h_stage_cap = 0;
     std::vector<DevBuf *> user_bufs;   // raft_hip_device_alloc
     bool emit_cuts = true;             // the pass writes the cut points (final_stars) itself; false: on demand (raft_hip_set_emit_cuts)
+    // what the context's last pass over plain columns found out on the way (run_pass: `speculate`): a pass over a stream of the same
+    // shape is built on it without the host wait and verifies it on the device
+    struct Shape {
+        bool valid = false;
+        int32_t n_reads = 0, reso = 0, minbins = 0, interval_length = 0, symmetric_mode = 0, variant = 0, tile_q = 0;
+        int64_t n_rec = 0;
+        const void *len = nullptr, *qid = nullptr;
+        long long B = 0, RU = 0, CU = 0;
+        int n_desc = 0;
+        long long desc[kMaxSeg] = {};
+    } shape;
+    bool speculated = false;           // the pass in flight was built on `shape`
+    hipStream_t clean_stream = nullptr;
+    bool ctrl_clean = false;           // the control block and the hand-out counters were cleared by the last pass's closing kernel, on clean_stream
 };
 
 namespace {
@@ -900,11 +927,21 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     // a grouped pass whose caller announced the window count needs nothing back from the device on the way
     const bool no_wait = grouped && in.hint_bins >= 0 && getenv("RAFT_NO_HINT") == nullptr;
     c->no_wait = no_wait;
+    // (RAFT_HOST_CLOCK=1: where the host is, us after entering, when it has issued what -- a speculative pass over an eighth of the
+    // bench set is issued in 26 us, 2-3 us a launch: profiles/r06_host_clock.txt)
+    static const bool host_clock = getenv("RAFT_HOST_CLOCK") != nullptr;
+    const auto hc_t0 = std::chrono::steady_clock::now();
+    auto hc_mark = [&](const char *what) { if (host_clock) fprintf(stderr, "[host] %-18s %7.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hc_t0).count()); };
     HIP_TRY(c, hipEventRecord(c->ev_pass0, st));
+    hc_mark("ev_pass0");
     HIP_TRY(c, c->ctrl.ensure(sizeof(Ctrl)));
     Ctrl *ctrl = c->ctrl.as<Ctrl>();
     HIP_TRY(c, c->wave_ctr.ensure((size_t)kWaveCounters * kCtrStride * 4));
-    hipLaunchKernelGGL(clear_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl, c->wave_ctr.as<int32_t>());      // (three fill commands before: ~5 us each on the device)
+    // (the last pass's closing kernel has cleared the block behind its hand-over -- unless this is the context's first pass, the
+    // last one did not get that far, or the stream is another)
+    if (!c->ctrl_clean || c->clean_stream != st || getenv("RAFT_ALWAYS_CLEAR") != nullptr)
+        hipLaunchKernelGGL(clear_ctrl_kernel, dim3(1), dim3(64), 0, st, ctrl, c->wave_ctr.as<int32_t>());      // (three fill commands before: ~5 us each on the device)
+    c->ctrl_clean = false;
     if (d_win && !lean && n_rec > 0)
         hipLaunchKernelGGL(unpack_windows_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>((n_rec + 255) / 256, 256 * 16))), dim3(256), 0, st,
                            (long long)n_rec, d_win, c->prm.reso, c->u_s.as<int32_t>(), c->u_e.as<int32_t>());
@@ -942,32 +979,53 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         for (int s2 = 0; s2 < kMaxSeg; ++s2) grp.adj[s2] = merge ? 0 : in.adj[s2];
     }
     long long *scan_totals = nullptr;
-    {
+    ReadPrepLoader prep_ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, recut ? pv.cap : INT32_MAX, pv.cap,
+                           &ctrl->err_flags, &ctrl->err_index, make_fast_div(c->prm.reso),
+                           make_fast_div(c->minbins < INT32_MAX ? c->minbins + 1 : 1), make_fast_div(c->prm.interval_length)};
+    ScanOut<3> prep_so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), c->cutcap_off.as<long long>()}};
+    // ---- A pass whose sizes the host knows before anything has run needs no wait on the way, and its head is THREE launches
+    // (round 6): [geometry scan, first half | run guess] -> [geometry scan, second half + the per-read work of tile_first_kernel +
+    // the check of what was assumed] -> tile_desc_kernel.  Two ways to know:
+    //  * the caller of a grouped pass announced its window count (no_wait, since round 3);
+    //  * SPECULATION: the context's last pass over plain columns went the sorted-run way, and this one has the same shape -- reads,
+    //    records, column addresses, parameters.  It is built on what that pass found (windows, reserved slots, where the runs end)
+    //    and every kernel that relies on it checks it: the scan's totals against the assumed ones, the sampled run ends against
+    //    the assumed ones (kErrHint: the later kernels return at once and raft_hip_finish runs the pass again the long way).
+    //    A streaming caller that hands over batch after batch through the same buffers gets the long way once.
+    const bool shape_fits = c->shape.valid && c->shape.n_reads == n_reads && c->shape.n_rec == n_rec && c->shape.len == (const void *)d_len &&
+                            c->shape.qid == (const void *)d_qid && c->shape.reso == c->prm.reso && c->shape.minbins == c->minbins &&
+                            c->shape.interval_length == c->prm.interval_length && c->shape.symmetric_mode == c->prm.symmetric_mode &&
+                            c->shape.variant == c->variant && c->shape.tile_q == c->tile_q;
+    const bool speculate = spec && wave && shape_fits && N > 0 && !c->is_lane && getenv("RAFT_NO_SPECULATE") == nullptr;
+    const bool known = wave && N > 0 && (speculate || (no_wait && getenv("RAFT_NO_FUSED_HEAD") == nullptr));
+    c->speculated = speculate;
+    if (speculate) c->sum.flags |= RAFT_HIP_SUM_SPECULATED;
+    if (!known) {
         hipStream_t gst = grouped ? st : c->side_stream;
         if (!grouped) {
             HIP_TRY(c, hipEventRecord(c->ev_ifork, st));                    // (the control block is clear)
             HIP_TRY(c, hipStreamWaitEvent(gst, c->ev_ifork, 0));
         }
-        ReadPrepLoader ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, recut ? pv.cap : INT32_MAX, pv.cap,
-                          &ctrl->err_flags, &ctrl->err_index, make_fast_div(c->prm.reso),
-                          make_fast_div(c->minbins < INT32_MAX ? c->minbins + 1 : 1), make_fast_div(c->prm.interval_length)};
-        ScanOut<3> so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), c->cutcap_off.as<long long>()}};
-        exclusive_scan<ReadPrepLoader, 3>(gst, ld, N, c->scan_tmp.as<long long>(), so, &scan_totals);
+        exclusive_scan<ReadPrepLoader, 3>(gst, prep_ld, N, c->scan_tmp.as<long long>(), prep_so, &scan_totals);
         if (!grouped) HIP_TRY(c, hipEventRecord(c->ev_gjoin, gst));
+        if (n_rec > 0 && !grouped) {
+            if (want_guess)
+                hipLaunchKernelGGL(guess_runs_kernel, dim3(kGuessBlocks), dim3(256), 0, st, (long long)n_rec, d_qid, &ctrl->guess,
+                                   c->samples.as<int32_t>());
+            if (!spec)
+                hipLaunchKernelGGL(inspect_kernel, dim3(igrid), dim3(256), 0, st, (long long)n_rec, n_reads,
+                                   c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
+        }
+        if (!grouped) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_gjoin, 0));
     }
-    if (n_rec > 0 && !grouped) {
-        if (want_guess)
-            hipLaunchKernelGGL(guess_runs_kernel, dim3(kGuessBlocks), dim3(256), 0, st, (long long)n_rec, d_qid, &ctrl->guess,
-                               c->samples.as<int32_t>());
-        if (!spec)
-            hipLaunchKernelGGL(inspect_kernel, dim3(igrid), dim3(256), 0, st, (long long)n_rec, n_reads,
-                               c->prm.symmetric_mode < 0 ? 1 : 0, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp);
-    }
-    if (!grouped) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_gjoin, 0));
     long long B, RU, CU;
-    if (no_wait) {
-        // (the caller's count is compared with the scan's by tile_first_kernel, the next kernel: kErrHint stops the pass there,
-        // and raft_hip_finish runs it again with the host wait)
+    if (speculate) {
+        B = c->shape.B; RU = c->shape.RU; CU = c->shape.CU;
+        hg->n_desc = c->shape.n_desc;
+        for (int i = 0; i < kMaxSeg; ++i) hg->desc_pos[i] = c->shape.desc[i];
+    } else if (no_wait) {
+        // (the caller's count is compared with the scan's on the device: kErrHint stops the pass there, and raft_hip_finish runs
+        // it again with the host wait)
         // sizes from the caller's window count: B as announced (checked on the device, kErrHint); bounds for the rest --
         // reserved raw-repeat slots sum_r ((w_r + 1) / (minbins + 1) + two per piece of a long read), markers sum_r (len_r / L + 2)
         B = in.hint_bins;
@@ -1072,9 +1130,25 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     HIP_TRY(c, c->tail_buf.ensure((size_t)7 * tail_blocks * 8));
     long long *const tail_part = c->tail_buf.as<long long>(), *const tail_prefix = tail_part + (size_t)4 * tail_blocks;
 
+    hc_mark("sized");
+    if (known) {
+        // the head in two launches (see above): the scan's first half with the run guess beside it, its second half with the per-read
+        // work of tile_first_kernel riding on it
+        const bool guess_too = !grouped && n_rec > 0 && want_guess;
+        long long *partials = c->scan_tmp.as<long long>();
+        scan_totals = partials + (long long)nb_scan * 3;
+        GuessBeside gb{(long long)n_rec, d_qid, &ctrl->guess, c->samples.as<int32_t>()};
+        hipLaunchKernelGGL((scan_partials_kernel<ReadPrepLoader, 3, GuessBeside>), dim3((unsigned)(nb_scan + (guess_too ? kGuessBlocks : 0))), dim3(kScanThreads), 0, st,
+                           prep_ld, N, partials, nb_scan, gb);
+        PrepPost pp{n_reads, Q, n_tiles, c->tile_first.as<int32_t>(), c->rep_cnt.as<int32_t>(), &ctrl->err_flags, &ctrl->err_index, grp, eff_runs,
+                    (long long)n_rec, B, RU, CU};
+        hipLaunchKernelGGL((scan_apply_kernel<ReadPrepLoader, 3, true, PrepPost>), dim3((unsigned)nb_scan), dim3(kScanThreads), 0, st, prep_ld, N, partials, scan_totals,
+                           prep_so, pp);
+    } else
     hipLaunchKernelGGL(tile_first_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, st, n_reads,
                        c->cov_off.as<long long>(), Q, n_tiles, c->tile_first.as<int32_t>(), &ctrl->err_flags, &ctrl->err_index, grp,
                        eff_runs, (long long)n_rec, c->rep_cnt.as<int32_t>(), scan_totals, no_wait ? in.hint_bins : -1LL);
+    hc_mark("head launched");
     if (expand)
         hipLaunchKernelGGL(expand_ids_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(((N + 63) / 64 * eff_runs + 3) / 4, 256 * 16))),
                            dim3(256), 0, st, n_reads, eff_runs, grp, c->exp_qid.as<int32_t>(), &ctrl->err_flags);
@@ -1148,6 +1222,16 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     }
 
     const bool fast = n_rec > 0 && symmetric && !c->force_bucket && n_desc + 1 <= kMaxSeg;
+    if (!grouped && spec && !speculate) {
+        // what this pass found out on the way, for the next one over a stream of the same shape (see `speculate`); a pass that turns
+        // out to have been built on a wrong guess takes it back (raft_hip_finish)
+        c->shape.valid = fast && table_ok && wave && N > 0;
+        c->shape.n_reads = n_reads; c->shape.n_rec = n_rec; c->shape.len = d_len; c->shape.qid = d_qid;
+        c->shape.reso = c->prm.reso; c->shape.minbins = c->minbins; c->shape.interval_length = c->prm.interval_length;
+        c->shape.symmetric_mode = c->prm.symmetric_mode; c->shape.variant = c->variant; c->shape.tile_q = c->tile_q;
+        c->shape.B = B; c->shape.RU = RU; c->shape.CU = CU; c->shape.n_desc = n_desc;
+        for (int i = 0; i < kMaxSeg; ++i) c->shape.desc[i] = i < n_desc ? desc[i] : 0;
+    } else if (!speculate && !grouped) c->shape.valid = false;
     bool bwin = false;                                // the general bucketing hands the pileup kernel window records (below)
     SegStarts sb{};
     const long long *seg_end_dev = nullptr;
@@ -1226,7 +1310,8 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
                        pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow,
                        (fast && table_ok) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
                        c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags,
-                       (recut && !wave) ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp, pv.cap);
+                       (recut && !wave) ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp, pv.cap,
+                       speculate ? &ctrl->guess : nullptr);
     pa.n_extra = recut ? &ctrl->n_extra : nullptr;
     pa.piece_w = pv.cap;
 
@@ -1243,7 +1328,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     const unsigned pgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * bpc));
     unsigned n_sum_blocks = pgrid;
     pa.tile_batch = n_tiles >= 64LL * pgrid ? 8 : (n_tiles >= 16LL * pgrid ? 2 : 1);
+    hc_mark("tile_desc launched");
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
+    hc_mark("ev_pile0");
     if (wave) {
         // ONE launch, no second stream: a persistent grid of single-wave workers, each drawing wave tiles from the list
         // tile_desc_kernel cut (its length is known on the device only: workers without a tile leave at once)
@@ -1363,7 +1450,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     } else {
         launch_general<6144, 5>(st, pgrid, pa);
     }
+    hc_mark("pileup launched");
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
+    hc_mark("ev_pile1");
     if (ow == kCovDelta4)      // the windows the tiles listed, gathered into the shared list (whose counter the control block carries)
         hipLaunchKernelGGL(compact_exceptions_kernel, dim3((unsigned)((d4_tiles + kCompactTiles - 1) / kCompactTiles)), dim3(256), 0, st, d4_tiles, kExcPerTile,
                            c->exc_tile_n.as<int32_t>(), c->exc_pidx.as<long long>(), c->exc_pval.as<int32_t>(), &ctrl->n_exc, c->exc_cap, c->exc_idx.as<long long>(), c->exc_val.as<int32_t>());
@@ -1400,13 +1489,17 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
             if (c->emit_cuts) hipLaunchKernelGGL(finalize_fill_kernel<true>, dim3(rgrid), dim3(256), 0, st, fa);
             else hipLaunchKernelGGL(finalize_fill_kernel<false>, dim3(rgrid), dim3(256), 0, st, fa);
         }
-        hipLaunchKernelGGL(publish_ctrl_kernel, dim3(1), dim3(64), 0, st, tp);
+        hipLaunchKernelGGL(publish_and_clear_kernel, dim3(1), dim3(64), 0, st, tp, reinterpret_cast<long long *>(ctrl), c->wave_ctr.as<int32_t>(),
+                           (int)(offsetof(Ctrl, err_index) / 8), (int)((offsetof(Ctrl, insp) + offsetof(InspectOut, err_index)) / 8));
         c->seq_armed = true;
+        c->ctrl_clean = true; c->clean_stream = st;
     }
     c->fa = fa; c->cuts_ready = c->emit_cuts;
     c->pass_width = ow; c->cov_valid = ow == 4;
+    hc_mark("tail launched");
     HIP_TRY(c, hipEventRecord(c->ev_pass1, st));
     HIP_TRY(c, hipGetLastError());
+    hc_mark("ev_pass1");
     c->ran = true;
     return RAFT_HIP_OK;
 }
@@ -1522,6 +1615,16 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
             c->spec = false;
             return RAFT_HIP_OK;
         };
+        if (c->speculated && c->pending_err == RAFT_HIP_OK) {
+            const Ctrl hc = ctrl_block();
+            if (hc.err_flags & kErrHint) {
+                // the stream is not what the context's last pass saw (other lengths, other run ends): the pass again, nothing remembered
+                c->shape.valid = false;
+                const int rc = run_pass(c, c->args, true);
+                if (rc != RAFT_HIP_OK) return rc;
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+            }
+        }
         if (c->grouped && c->pending_err == RAFT_HIP_OK) {
             const Ctrl hc = ctrl_block();
             if (hc.err_flags & kErrHint) {
@@ -1550,6 +1653,7 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
             const bool no_mirror = c->prm.symmetric_mode < 0 && hc.insp.sym_found == 0;   // assumed symmetric, found no mirror
             if (no_mirror) c->assume_sym = false;
             if ((hc.err_flags & (kErrOrder | kErrReadId)) || no_mirror) {   // run it again, this time after looking at every record
+                c->shape.valid = false;
                 const int rc = again(c->args);
                 if (rc != RAFT_HIP_OK) return rc;
             }

@@ -835,6 +835,12 @@ __global__ __launch_bounds__(THREADS, MINW) void pileup_kernel(PileupArgs a)
     }
 }
 
+// the sorted runs of the record stream as its samples show them (bucket.hpp guess_runs_kernel)
+struct GuessOut {
+    int32_t n_desc, pad;
+    long long desc_pos[kMaxSeg];
+};
+
 // What a pass that assumes a symmetric PAF (engine.hip run_pass, detecting contexts) still has to find: the mirror of
 // record 0 (chop.hpp:171-184).  It can only sit among the records of record 0's target read, and where those lie in each
 // sorted run is one more pair of the boundary searches tile_desc_kernel does anyway: the thread behind the closing
@@ -855,13 +861,25 @@ __global__ __launch_bounds__(256) void tile_desc_kernel(long long n_tiles, SegSt
                                                         int32_t *n_slow, const int32_t *samples, long long n_rec,
                                                         const long long *bucket_off, int32_t *err_flags, TileCut *extra,
                                                         int32_t *n_extra, int32_t extra_cap, int32_t piece_w, MirrorArgs mir,
-                                                        GroupedOff grp, int recut_cap)
+                                                        GroupedOff grp, int recut_cap, const GuessOut *verify_guess)
 {
     // fast_cap < 0: no tile is taken as it is -- every tile with reads is re-cut into entries of at most recut_cap windows and
     // fast_max_reads reads (pileup_wave.hpp: one wave per entry); otherwise recut_cap == fast_cap
     if (*(volatile int32_t *)err_flags & kErrStop) return;   // (sizes or offsets the device found wrong: nothing here is safe)
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    if (verify_guess && k == 0) {
+        // a pass built on the run ends the context's LAST pass over a stream of this shape sampled (engine.hip run_pass `speculate`):
+        // this pass's own samples must say the same, or the pass is not what it was built for
+        const int nd = verify_guess->n_desc;
+        bool same = nd == sb.n_seg - 1;
+        for (int i = 0; same && i < nd; ++i) {
+            bool found = false;
+            for (int j = 1; j < sb.n_seg; ++j) found |= verify_guess->desc_pos[i] == sb.start[j];
+            same = found;
+        }
+        if (!same) atomicOr(err_flags, kErrHint);
+    }
     const bool live = k < n_tiles;
     const bool edge = k <= n_tiles;                 // boundary n_tiles closes the last tile
     const bool mirror = mir.tid && k == n_tiles + 1;   // (see MirrorArgs)
