@@ -94,10 +94,13 @@ typedef struct raft_hip_summary {
     int32_t flags;              /* RAFT_HIP_SUM_*: bit 0 -- the general bucketing (interval_path == 1) sorted its sides as window-record items
                                    and the pileup kernel read those (4 bytes per interval) instead of coordinate columns;
                                    bit 1 -- the pass was built, without its host wait, on what the context's previous pass over a stream
-                                   of the same shape had found (sizes, sorted runs), and the device confirmed it (raft_hip_run_device) */
+                                   of the same shape had found (sizes, sorted runs), and the device confirmed it (raft_hip_run_device);
+                                   bits 2, 3 -- see RAFT_HIP_SUM_DEEP_TILES, RAFT_HIP_SUM_RERUN */
 } raft_hip_summary;
 #define RAFT_HIP_SUM_BUCKET_WINDOWS 1
 #define RAFT_HIP_SUM_SPECULATED 2
+#define RAFT_HIP_SUM_DEEP_TILES 4   /* tiles of 2^15 intervals or more took the 32-bit side kernel (pileup_deep.hpp) */
+#define RAFT_HIP_SUM_RERUN 8        /* raft_hip_finish ran the pass more than once (a refuted guess or assumption, a list that had to grow) */
 
 /* Device-resident outputs of the last run (valid until the next run/destroy).
  * Layout is CSR per read, FASTA-index order (= reference output order):

@@ -12,6 +12,7 @@
 #include "pileup_fast.hpp"
 #include "pileup_wave.hpp"
 #include "wave_launch.hpp"
+#include "pileup_deep.hpp"
 
 #ifndef RAFT_DEFAULT_VARIANT
 #define RAFT_DEFAULT_VARIANT 5
@@ -132,7 +133,7 @@ struct Ctrl {                         // device control block, cleared every pas
     long long out_totals[4];          // rep / cut / frag totals land here via the scan
     GuessOut guess;                   // sorted runs as seen from samples
     unsigned long long n_exc;         // windows at or above the limit of the encoding a pass wrote directly (PileupArgs::n_exc)
-    unsigned totals_done, pad_done;   // workgroups of totals_kernel that are through (the last one publishes this block)
+    int32_t n_deep, pad_deep;         // tiles pileup_wave_kernel listed for pileup_deep_kernel (may exceed the list: kErrDeep)
 };
 
 // Device buffers.  The large ones the pass streams through (coverage, repeats, cut points, fragments, the pipeline's staging
@@ -460,6 +461,8 @@ struct raft_hip_ctx {
     std::string last_error;
 
     // device buffers
+    DevBuf deep_list;                 // tiles too deep for 16-bit coverage (pileup_deep.hpp)
+    long long deep_cap = 1024;        // its entries; grows when a pass lists more (raft_hip_finish)
     DevBuf tail_buf;                  // the fused tail's sums (finalize.hpp FinalizeArgs::tail_part ...)
     DevBuf wave_ctr, ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_desc, tile_cuts, slow_list, block_sums;
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
@@ -669,7 +672,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
     c->lane_up_ev.clear(); c->lane_down_ev.clear();
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
-    DevBuf *all[] = {&c->tail_buf, &c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
+    DevBuf *all[] = {&c->deep_list, &c->tail_buf, &c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->gs_rid, &c->gs_s, &c->gs_e, &c->gs_off, &c->gs_err, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1, &c->gaps, &c->in_len,
@@ -1209,6 +1212,10 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     pa.raw_key = c->raw_key.as<int32_t>(); pa.raw_s = c->raw_s.as<int32_t>(); pa.raw_e = c->raw_e.as<int32_t>();
     pa.block_sums = c->block_sums.as<long long>(); pa.err_flags = &ctrl->err_flags; pa.err_index = &ctrl->err_index;
     pa.tile_counter = &ctrl->next_tile; pa.slow_counter = &ctrl->slow_next;
+    HIP_TRY(c, c->deep_list.ensure((size_t)c->deep_cap * sizeof(DeepTile)));
+    pa.deep_list = c->deep_list.p; pa.n_deep = &ctrl->n_deep; pa.deep_cap = (int32_t)std::min<long long>(c->deep_cap, INT32_MAX);
+    pa.deep_min = 32768; pa.deep_rep_total = &ctrl->totals[1];
+    if (const char *e = getenv("RAFT_DEEP_MIN")) pa.deep_min = std::max(1, atoi(e));     // (tests: ordinary tiles through pileup_deep_kernel)
     {   // n / reso as mulhi + shift, exact for 0 <= n < 2^31: with L = ceil(log2 reso) and
         // m = floor(2^(31+L) / reso) + 1 (< 2^32), n / reso == (n * m) >> (31 + L) == mulhi(n, m) >> (L - 1)
         const unsigned d = (unsigned)c->prm.reso;
@@ -1331,6 +1338,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     hc_mark("tile_desc launched");
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
     hc_mark("ev_pile0");
+    bool wave_launched = false;
     if (wave) {
         // ONE launch, no second stream: a persistent grid of single-wave workers, each drawing wave tiles from the list
         // tile_desc_kernel cut (its length is known on the device only: workers without a tile leave at once)
@@ -1348,6 +1356,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         pa.piece_w = (int32_t)std::min<long long>(extra_cap, INT32_MAX);    // (delta4: tile ids below this have slots of their own)
         launch_wave_variant(ow, lean || bwin, st, pa.n_seg, c->tile_cuts.p, &pa, n_waves);
         n_sum_blocks = (unsigned)n_waves;
+        wave_launched = true;
         // ---- where the coverage array lies, decided by measurement: OPT-IN (raft_hip_set_placement_trial / RAFT_PLACEMENT_TRIALS=<k>;
         // round 5 ran it by default, round 6 does not: the driver's own A/B showed 0.2 % between the policies, and a one-shot caller
         // paid 2 K - 1 extra launches and K - 1 coverage-sized allocations for nothing).  What this kernel gets from the part follows
@@ -1394,6 +1403,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
                     x.cov = cov_p;
                     HIP_TRY(c, hipMemsetAsync(c->rep_cnt.p, 0, (size_t)std::max(N, 1LL) * 4, st));
                     HIP_TRY(c, hipMemsetAsync(c->wave_ctr.p, 0, (size_t)kWaveCounters * kCtrStride * 4, st));
+                    HIP_TRY(c, hipMemsetAsync(&ctrl->n_deep, 0, 4, st));
                     if (e0) HIP_TRY(c, hipEventRecord(e0, st));
                     launch_wave_variant(ow, lean || bwin, st, x.n_seg, c->tile_cuts.p, &x, n_waves);
                     if (e1) HIP_TRY(c, hipEventRecord(e1, st));
@@ -1452,6 +1462,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     }
     hc_mark("pileup launched");
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
+    // the tiles the wave kernel listed instead of piling them up (2^15 intervals or more: pileup_deep.hpp); nearly always none
+    if (wave_launched)
+        hipLaunchKernelGGL(pileup_deep_kernel, dim3(64), dim3(kDeepThreads), 0, st, pa, c->deep_list.as<DeepTile>(), &ctrl->n_deep, pa.deep_cap, ow);
     hc_mark("ev_pile1");
     if (ow == kCovDelta4)      // the windows the tiles listed, gathered into the shared list (whose counter the control block carries)
         hipLaunchKernelGGL(compact_exceptions_kernel, dim3((unsigned)((d4_tiles + kCompactTiles - 1) / kCompactTiles)), dim3(256), 0, st, d4_tiles, kExcPerTile,
@@ -1608,7 +1621,9 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
             if (q != hipSuccess && q != hipErrorNotReady) return fail_hip(c, q, "hipStreamQuery after the pass");
         }
         auto ctrl_block = [&]() { return host_ctrl(c); };
+        int n_reruns = 0;
         auto again = [&](const raft_hip_ctx::PassArgs &a) -> int {       // the pass once more, this time nothing assumed
+            ++n_reruns;
             const int rc = run_pass(c, a, false);
             if (rc != RAFT_HIP_OK) return rc;
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1620,6 +1635,7 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
             if (hc.err_flags & kErrHint) {
                 // the stream is not what the context's last pass saw (other lengths, other run ends): the pass again, nothing remembered
                 c->shape.valid = false;
+                ++n_reruns;
                 const int rc = run_pass(c, c->args, true);
                 if (rc != RAFT_HIP_OK) return rc;
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1679,8 +1695,8 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
                 } else if ((hc.err_flags & kErrWide) && !c->no_bucket_win) {
                     c->no_bucket_win = true;            // a side's windows do not fit 16 bits: this context buckets coordinate pairs from now on
                     rerun = true;
-                } else if ((hc.err_flags & kErrDeep) && force_variant != 0) {
-                    force_variant = 0;
+                } else if ((hc.err_flags & kErrDeep) && (long long)hc.n_deep > c->deep_cap) {
+                    c->deep_cap = (long long)hc.n_deep + 64;     // more deep tiles than the list held: once more, with room
                     rerun = true;
                 } else if (c->pass_width != 4 && (long long)hc.n_exc > c->exc_cap && !(hc.err_flags & ~(kErrOrder | kErrExtra | kErrDeep | kErrWide))) {
                     c->exc_cap = (long long)hc.n_exc;
@@ -1706,11 +1722,13 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
             c->sum.total_coverage = (long long)hc.totals[0];
             c->sum.total_repeat_length = (long long)hc.totals[1];
             c->sum.total_read_length = (long long)hc.totals[2];
+            if (hc.n_deep > 0) c->sum.flags |= RAFT_HIP_SUM_DEEP_TILES;
             if (hc.err_flags) {
                 c->pending_err = code_from_flags(hc.err_flags);
                 c->pending_err_index = hc.err_index;
             }
         }
+        if (n_reruns > 0) c->sum.flags |= RAFT_HIP_SUM_RERUN;
         c->sum.error_index = c->pending_err ? c->pending_err_index : -1;
         c->finished = true;
     }

@@ -144,6 +144,11 @@ struct PileupArgs {
     const int32_t *n_extra;       // device count of extra tiles (nullptr: none, the general kernel takes those tiles)
     int32_t piece_w;
     int32_t *slow_counter;        // list mode of this kernel: the items of slow_list are handed out one by one
+    // tiles too deep for the wave kernel's 16-bit difference array (pileup_deep.hpp): listed by it, piled up by pileup_deep_kernel
+    void *deep_list;              // DeepTile[deep_cap]
+    int32_t *n_deep;              // device count (may exceed deep_cap: kErrDeep, the pass is run again with room)
+    int32_t deep_cap, deep_min;   // deep_min: intervals on a tile from which it goes that way (2^15; tests lower it)
+    unsigned long long *deep_rep_total;   // where pileup_deep_kernel adds its tiles' unclamped repeat bases (Ctrl::totals[1])
 };
 
 // Coarse index of the record stream (bucket.hpp guess_runs_kernel writes it, tile_desc_kernel reads it): the read id of
@@ -213,6 +218,14 @@ __device__ __forceinline__ void raise_error(const PileupArgs &a, int flag, long 
 {
     atomicOr(a.err_flags, flag);
     atomicMin((unsigned long long *)a.err_index, (unsigned long long)idx);
+}
+
+// A window at or above the limit of the one- or two-byte encoding (rare by the choice of the width), or a window the four-bit
+// encoding lists with its value.  (Inlined: a call from the row loop costs the kernel 46 registers and a stack.)
+__device__ __forceinline__ void note_exception(const PileupArgs &a, long long window, int v)
+{
+    const unsigned long long slot = atomicAdd(a.n_exc, 1ull);
+    if ((long long)slot < a.exc_cap) { a.exc_idx[slot] = window; a.exc_val[slot] = v; }
 }
 
 // read (in [r_a, r_b)) that owns global window g; reads with zero windows are skipped

@@ -158,14 +158,6 @@ __device__ __forceinline__ void emit_piece_run(const PileupArgs &a, const FastTa
     a.raw_e[idx] = start + (sT - sS) * a.reso;
 }
 
-// A window at or above the limit of the one- or two-byte encoding (rare by the choice of the width).  (Inlined: a call
-// from the row loop costs the kernel 46 registers and a stack.)
-__device__ __forceinline__ void note_exception(const PileupArgs &a, long long window, int v)
-{
-    const unsigned long long slot = atomicAdd(a.n_exc, 1ull);
-    if ((long long)slot < a.exc_cap) { a.exc_idx[slot] = window; a.exc_val[slot] = v; }
-}
-
 // EXTRA = false: the regular tiles (bounded by adjacent cuts).  EXTRA = true: the same kernel over the extra tiles that
 // tile_desc_kernel cut out of what does not fit (explicit cut pairs; intervals clipped to the tile; pieces of long reads):
 // an instantiation of its own, so that the regular tiles' code carries none of that.

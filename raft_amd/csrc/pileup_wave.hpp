@@ -31,7 +31,14 @@
 
 namespace raft {
 
-constexpr int kErrDeep = 1 << 9;     // a wave tile with 32768 or more intervals: 16-bit coverage is not safe for it
+constexpr int kErrDeep = 1 << 9;     // more tiles too deep for 16-bit coverage than the list for pileup_deep_kernel holds: the pass again, with room
+
+struct DeepTile {                    // what this kernel knows about a tile when it decides not to pile it up (pileup_deep.hpp does)
+    int32_t r_a, nr;                 // reads [r_a, r_a + nr)
+    int32_t piece, nwin;             // kCutPiece: ONE read longer than a tile, this is a piece of it; windows of the tile
+    long long g_lo;                  // first window of the tile in cov[]
+    int32_t lo[kMaxSeg], cnt[kMaxSeg];   // its records: [lo, lo + cnt) of every sorted run
+};
 
 // The empty difference array: the LOW half of every dword is biased by 0x8000, so that a -1 landing on an even slot never
 // borrows from the odd slot above it (the ds_add is a 32-bit add); one xor per dword takes the bias off again.
@@ -396,7 +403,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         const long long a0 = cur.g_lo & ~3LL;
         const int off0 = (int)(cur.g_lo - a0);
         const int t_end = off0 + cur.nwin;
-        const int rows = (t_end + 1 + 511) >> 9;
+        const int rows_all = (t_end + 1 + 511) >> 9;
         // ---- per-read table of this tile
         const int ro = rd.cv - (int)a0;                     // 32-bit wrap-around is exact
         if (lane <= nr) sm.rtab[lane] = ro;
@@ -543,7 +550,25 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             }
         }
         lane_cov += covsum;
-        if (cur.n_total >= 32768) { if (lane == 0) atomicOr(a.err_flags, kErrDeep); }
+        // ---- a tile with 2^15 intervals or more: every intermediate below is exact modulo 2^16 only.  Its records have been checked
+        // above like any other tile's; what they pile up to is left to pileup_deep_kernel (32-bit, a workgroup per tile), which
+        // finds the tile's description in a list.  The array is cleared of what the scatter left.
+        const bool deep = cur.n_total >= a.deep_min;
+        if (deep) {
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(a.n_deep, 1);
+            slot = uni(slot);
+            if (slot < a.deep_cap) {
+                if (lane == 0) {
+                    DeepTile dt;
+                    dt.r_a = cur.r_a; dt.nr = cur.nr; dt.piece = cur.piece; dt.nwin = cur.nwin; dt.g_lo = cur.g_lo;
+#pragma unroll
+                    for (int s = 0; s < kMaxSeg; ++s) { dt.lo[s] = s < NSEG ? cur.lo[s] : 0; dt.cnt[s] = s < NSEG ? cur.cnt[s] : 0; }
+                    reinterpret_cast<DeepTile *>(a.deep_list)[slot] = dt;
+                }
+            } else if (lane == 0) atomicOr(a.err_flags, kErrDeep);
+            for (int i = lane; i < SLOTS / 2; i += 64) sm.diff[i] = kZero;
+        }
         if (defer) plan_next();                  // (late: these loads are waited for right below, with nothing to hide behind)
 
         // ---- every load issued so far -- the NEXT tile's among them -- must have landed before this tile's first coverage
@@ -556,6 +581,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
         bool hp = false;                 // the slot before the next one is high
         int S = kNone;                   // start slot of the run currently open
         int nq = 0;
+        const int rows = deep ? 0 : rows_all;    // (a deep tile: no rows, no runs -- pileup_deep_kernel's)
         int32_t *const cov0 = OW == 4 ? a.cov + a0 : nullptr;
         char *const covp0 = OW == 4 ? nullptr : reinterpret_cast<char *>(a.covp) + (D4 ? a0 / 2 : a0 * OW);
         // (descriptor of this tile's piece of the coverage array: base = the tile's first aligned window, no stride, raw 32-bit data)
