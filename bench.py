@@ -77,8 +77,8 @@ DEFAULT_READS = {"hg002": 3_300_000, "ultralong": 400_000, "s50k": 50_000}
 def kernel_source_hash() -> str:
     """Identifies the kernels a counter profile belongs to (profiles/pmc_traffic.json goes stale with them)."""
     h = hashlib.sha1()
-    for f in ("pileup_wave.hpp", "wave_launch.hip", "wave_launch.hpp", "pileup_fast.hpp", "pileup.hpp", "engine.hip", "bucket.hpp", "finalize.hpp", "wave.hpp",
-              "device_scan.hpp", "pack.hpp"):
+    for f in ("pileup_wave.hpp", "wave_launch.hip", "wave_launch.hpp", "pileup_deep.hpp", "pileup.hpp", "engine.hip", "bucket.hpp", "finalize.hpp", "wave.hpp",
+              "device_scan.hpp", "pack.hpp", "sort_pairs.hpp"):
         with open(os.path.join(ROOT, "raft_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -163,7 +163,7 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
     host = [c.cpu().pin_memory().numpy() for c in (o.read_len, o.qid, o.qs, o.qe)]
     off = grouped_form(torch, hostio, o.n_reads, o.qid, pinned=True)
     eng = engine.Engine(pe, device=torch.cuda.current_device())
-    eng.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+    eng.set_tuning(args.tile_bins, args.force_bucket)
     width = 2 if p.est_cov >= 40 else 1                   # as the CLI chooses: deep sets pile up beyond a byte in repeats
     out = eng.host_output_buffers(host[0], pinned=True, width=width)   # sized by the bounds of include/raft_hip.h, from the read lengths
     out["frag_read"] = torch.empty(out["frag_begin"].size, dtype=torch.int32, pin_memory=True).numpy()
@@ -400,7 +400,6 @@ def main():
     ap.add_argument("--force-bucket", action="store_true")
     ap.add_argument("--plain-input-memory", action="store_true", help="leave the input columns where torch's allocator (hipMalloc) put them instead of moving them "
                     "into memory from raft_hip_device_alloc before the clock (see include/raft_hip.h: a pass's time depends on where its buffers lie)")
-    ap.add_argument("--variant", type=int, default=-1, help="pileup kernel variant (engine.hip kVariants), -1 = default")
     ap.add_argument("--no-placement-ab", action="store_true", help="skip the extra passes that time the pileup kernel with its buffers placed the other ways")
     args = ap.parse_args()
     # several GPUs: which form is the headline (default: configs[3] as written, pre-split)
@@ -503,7 +502,7 @@ def main():
     def make_engine(sh: Shard, width: int, routed: bool = False):
         # (routed: the records a rank of a host-routed job is handed ARE the query-side multiset of its reads, engine.hip run_routed)
         e = engine.Engine(p_sym if (sh.off is not None or args.handover or routed) else p, device=local)
-        e.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+        e.set_tuning(args.tile_bins, args.force_bucket)
         e.set_output_width(width)
         e.use_torch_stream()
         return e
@@ -590,7 +589,7 @@ def main():
         comm = None
         if presplit:
             e = engine.Engine(p_sym, device=local)
-            e.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+            e.set_tuning(args.tile_bins, args.force_bucket)
             e.use_torch_stream()
             if not shared:
                 # every rank has a GPU of its own: the native exchange (raft_hip_exchange -- RCCL all-gather of the piece sizes,
@@ -763,7 +762,7 @@ def main():
         for name, spread in (("spread8", 8), ("spread1", 1), ("hipMalloc", 0)):
             engine.set_placement(spread)
             ea = engine.Engine(p, device=local)
-            ea.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+            ea.set_tuning(args.tile_bins, args.force_bucket)
             ea.use_torch_stream()
             colsa = [ea.device_copy(c) for c in (o.read_len,) + tuple(o.columns())]
             kt, pt = [], []
@@ -800,7 +799,7 @@ def main():
                     return None
                 d_win = place(torch.as_tensor(win.view("int32")).to(dev))
             e3 = engine.Engine(p_sym, device=local)
-            e3.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+            e3.set_tuning(args.tile_bins, args.force_bucket)
             e3.set_output_width(8 if d4 else w)
             e3.use_torch_stream()
             kt, pt, wall = [], [], []
@@ -853,7 +852,7 @@ def main():
             e3.close()
             return res
         packed = encoded_pass("columns")
-        if not args.no_windows_leg and args.variant < 0 and p.reso <= 32767:
+        if not args.no_windows_leg and p.reso <= 32767:
             windows_leg = encoded_pass("windows")
             if windows_leg is not None:
                 windows_d4_leg = encoded_pass("windows_d4")
@@ -874,7 +873,7 @@ def main():
             else:
                 shg = None
                 e2 = engine.Engine(p_sym if form == "handover" else p, device=local)
-            e2.set_tuning(args.tile_bins, args.force_bucket, args.variant)
+            e2.set_tuning(args.tile_bins, args.force_bucket)
             e2.set_emit_cuts(cuts)
             e2.use_torch_stream()
             kt, pt, wall = [], [], []
@@ -921,7 +920,7 @@ def main():
 
     if rank == 0:
         per_step = elapsed / args.steps
-        # dominant kernel: pileup + prefix scan + coverage store + run scan (pileup_fast.hpp).
+        # dominant kernel: pileup + prefix scan + coverage store + run scan (pileup_wave.hpp).
         # algorithmic bytes per launch (this rank): 12 B per interval read once, 4 B per window written once,
         # 4 B per read (length) and 8 B per repeat emitted
         cov_bytes = s.n_bins // 2 + 4 * (s.n_bins // 1024) if args.cov_width == 8 else args.cov_width * s.n_bins
@@ -962,8 +961,7 @@ def main():
                                     + ("records pre-split, one all-to-all-v per step" if args.presplit else "host-routed, no data-path collective") if strong_line
                                     else f"reads x{n_gpus}, independent shards, no data-path collective") + (", ranks share GPUs (gloo check run)" if shared else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": ("pileup_wave_kernel" if args.variant in (-1, 5) else ("pileup_fast_kernel (regular + re-cut tiles)" if args.variant != 1 else "pileup_kernel"))
-                                   + ("" if args.variant < 0 else f" variant {args.variant}"),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "pileup_wave_kernel",
                          "kernel_ms": pile * 1e3, "bytes_algorithmic": bytes_alg, "bytes_kernel": bytes_kernel,
                          "bytes_kernel_note": ("the pileup kernel reads the sorted window records the bucketing left (4 B per interval + 8 B per read of offsets), not the "
                                                "12 B per interval the pass was handed: `frac` is priced on that, `pass_frac` on the pass's algorithmic bytes") if bucket_windows

@@ -501,14 +501,10 @@ int  raft_hip_reserve(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_le
  * context's stream around them. */
 int  raft_hip_last_timing(raft_hip_ctx *ctx, double *pileup_seconds, double *pass_seconds);
 
-/* Tuning knobs (optional): tile quantum in windows for the pileup kernel's read->workgroup map
- * (0 = the variant's default), force the counting-sort interval path, and the pileup kernel
- * variant (-1 = default; see kVariants in raft_amd/csrc/engine.hip). */
+/* Tuning knobs (optional): the quantum -- windows per range of reads a worker of the pileup kernel draws (0 = chosen from the
+ * set's size) --, force the general bucketing path, and `variant`: rounds 1-5 kept several pileup kernels and chose among them
+ * here; since ABI 11 there is one (raft_amd/csrc/pileup_wave.hpp), named by -1 or 5, and any other value is RAFT_HIP_ERR_PARAM. */
 int  raft_hip_set_tuning(raft_hip_ctx *ctx, int32_t tile_bins, int32_t force_bucket_path, int32_t variant);
-
-/* Diagnostic variant (3) only: copies the per-workgroup s_memtime stamps of the last pass
- * (16 uint64 per tile) to `host`; *n_tiles receives the number of tiles of that pass. */
-int  raft_hip_debug_stamps(raft_hip_ctx *ctx, unsigned long long *host, int64_t max_tiles, int64_t *n_tiles);
 
 /* On-device self test of the wavefront primitives (scan, ballots); 0 = pass. */
 int  raft_hip_selftest(int device_id);

@@ -9,14 +9,9 @@
 #include "finalize.hpp"
 #include "pack.hpp"
 #include "pileup.hpp"
-#include "pileup_fast.hpp"
 #include "pileup_wave.hpp"
 #include "wave_launch.hpp"
 #include "pileup_deep.hpp"
-
-#ifndef RAFT_DEFAULT_VARIANT
-#define RAFT_DEFAULT_VARIANT 5
-#endif
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -40,33 +35,9 @@ using namespace raft;
 
 namespace {
 
-// Pileup configurations.  `fast`: tiles of whole reads that fit one LDS window go to pileup_fast_kernel and the
-// general pileup_kernel only walks the remaining tiles; otherwise the general kernel handles every tile.
-// cap = windows staged in LDS, wg_per_cu = resident workgroups per CU (= waves per SIMD asked of the register
-// allocator), short_max: the tile quantum Q defaults to cap - short_max, so that a tile whose reads all have at most
-// short_max windows always fits one LDS window.
-struct PileVariant { int fast, cap, wg_per_cu, short_max; };
-constexpr PileVariant kVariants[] = {
-    {1, 7936, 4, 1664},   // 0: round 1-3's pileup: workgroup tiles, int32 LDS window (pileup_fast.hpp), 36.4 KB LDS, 4 workgroups/CU, Q = 6272;
-                          //    the pass a wave tile too deep for 16 bits falls back to (kErrDeep), and the A/B partner of variant 5
-    {0, 6144, 5, 2048},   // 1: general kernel only (the first design: the independent cross-check of tests/test_gpu_consistency.py)
-    {1, 7936, 4, 1664},   // 2: (retired: the 5-workgroup configuration; same as 0)
-    {1, 7936, 4, 1664},   // 3: variant 0 with s_memtime stamps in the fast kernel (diagnostic; raft_hip_debug_stamps)
-    {1, 7936, 4, 1664},   // 4: (retired: lane-serial rows; same as 0)
-    {2, kWaveSlots - 4, 4, 0},   // 5: one wave per tile, 16-bit difference array, workers cut their own tiles (pileup_wave.hpp): the default
-};
-constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
-constexpr int kDefaultVariant = RAFT_DEFAULT_VARIANT;
-constexpr int kDiagVariant = 3;
-// the variant a context starts with and raft_hip_set_tuning(variant = -1) returns to: RAFT_VARIANT=<n> (test sweeps, A/B) or the build's default
-int default_variant()
-{
-    static const int v = [] {
-        if (const char *e = getenv("RAFT_VARIANT")) { const int x = atoi(e); if (x >= 0 && x < kNumVariants) return x; }
-        return kDefaultVariant;
-    }();
-    return v;
-}
+// The windows of a wave tile (pileup_wave.hpp): its LDS array minus three alignment slots and the sentinel.  A read with more
+// windows is piled up in pieces of that many (joined by finalize_count_kernel).
+constexpr int kTileCap = kWaveSlots - 4;
 // coverage arrays a context's placement trial compares (run_pass): off unless asked for -- RAFT_PLACEMENT_TRIALS=<k>, k >= 2, or
 // raft_hip_set_placement_trial
 int default_trial_candidates()
@@ -74,60 +45,15 @@ int default_trial_candidates()
     static const int v = [] { const char *e = getenv("RAFT_PLACEMENT_TRIALS"); return e ? std::max(0, std::min(8, atoi(e))) : 0; }();
     return v;
 }
-constexpr int kFastSlots = 4;     // default number of prefetched intervals per lane and tile in the fast kernel
-
-template <int CAP, int MINW>
-void launch_general(hipStream_t st, unsigned grid, const PileupArgs &pa)
-{
-    hipLaunchKernelGGL((pileup_kernel<256, CAP, MINW, 3, false>), dim3(grid), dim3(256), 0, st, pa);
-}
-
-template <int CAP, int MINW, bool DIAG, int SLOTS = kFastSlots, int EXTRA = 0, int OW = 4>
-void launch_fast(hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
-{
-    constexpr int S4 = SLOTS % 4 == 0 ? SLOTS : 4;   // four sorted runs need a multiple of four slots
-    const size_t dyn = 0;
-    if (n_seg <= 1)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 1, SLOTS, MINW, DIAG, EXTRA, OW, false, 0>), dim3(grid), dim3(256), dyn, st, cuts, pa);
-    else if (n_seg == 2)
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 2, SLOTS, MINW, DIAG, EXTRA, OW, false, 0>), dim3(grid), dim3(256), dyn, st, cuts, pa);
-    else
-        hipLaunchKernelGGL((pileup_fast_kernel<CAP, 4, S4, MINW, DIAG, EXTRA, OW, false, 0>), dim3(grid), dim3(256), dyn, st, cuts, pa);
-}
 constexpr int kWinMaxRuns = 2;    // runs the window-record instantiations (pileup_wave.hpp IN = 1) take; more: unpacked to coordinate columns first
-
-// the workgroup-tile kernel's configurations by output width (pileup_fast.hpp OW; the diagnostic build writes int32 only).  Round 4
-// pruned its instantiations to what a fallback needs: coordinate columns in; int32, one or two bytes per window out (window
-// records are unpacked for it, the four-bit encoding is made from its int32 array afterwards); the lane-serial rows and the
-// 5-workgroup configuration are gone.
-template <int EXTRA>
-void launch_fast_variant(int variant, int ow, hipStream_t st, unsigned grid, int n_seg, const TileCut *cuts, const PileupArgs &pa)
-{
-    if (variant == kDiagVariant && EXTRA == 0) launch_fast<7936, 4, true, 6, 0, 4>(st, grid, n_seg, cuts, pa);
-    else if (ow == 1) launch_fast<7936, 4, false, 6, EXTRA, 1>(st, grid, n_seg, cuts, pa);
-    else if (ow == 2) launch_fast<7936, 4, false, 6, EXTRA, 2>(st, grid, n_seg, cuts, pa);
-    else launch_fast<7936, 4, false, 6, EXTRA, 4>(st, grid, n_seg, cuts, pa);
-}
-
-// RAFT_PRINT_OCCUPANCY=1: what the runtime thinks of the pileup kernels (registers, LDS, resident workgroups per CU)
-template <class K>
-void print_occupancy(const char *name, K kernel)
-{
-    hipFuncAttributes fa{};
-    int nb = -1;
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel));
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0);
-    fprintf(stderr, "occupancy %-28s regs %d lds %zu scratch %zu maxThreads %d -> blocks/CU (API) %d\n", name, fa.numRegs,
-            fa.sharedSizeBytes, fa.localSizeBytes, fa.maxThreadsPerBlock, nb);
-}
 
 struct Ctrl {                         // device control block, cleared every pass
     int32_t err_flags;
-    int32_t n_slow;                   // tiles left to the general pileup kernel (fast configurations)
+    int32_t pad_slow;
     long long err_index;              // (the first 16 bytes are what the pass's host wait reads back)
     int32_t next_tile;                // pileup_fast_kernel's tile hand-out counter
     int32_t slow_next;                // the general kernel's item hand-out counter (list mode)
-    int32_t n_extra, pad_extra;       // extra tiles tile_desc_kernel cut out of the tiles that do not fit the fast kernel
+    int32_t pad_extra[2];
     unsigned long long totals[4];     // coverage, repeat bp, read length
     InspectOut insp;
     long long out_totals[4];          // rep / cut / frag totals land here via the scan
@@ -394,7 +320,7 @@ template <int K> struct CountLoader {
 // few bytes cost ~25 us each on the device timeline (three of them ahead of the pass's host wait).  Stamped lines (finalize.hpp):
 // run_pass looks for them itself instead of sleeping in the runtime's wait (as raft_hip_finish does for the pass's end).
 constexpr int kInspWords = (int)(sizeof(InspectOut) / 8), kGuessWords = (int)(sizeof(GuessOut) / 8);
-constexpr int kSizesWords = 3 + 2 + kInspWords + kGuessWords;      // scan totals; err_flags | n_slow, err_index; InspectOut; GuessOut
+constexpr int kSizesWords = 3 + 2 + kInspWords + kGuessWords;      // scan totals; err_flags | pad, err_index; InspectOut; GuessOut
 static_assert(kSizesWords <= 48 && stamped_lines(kSizesWords) * 8 <= 96, "the sizes block outgrew its place");
 constexpr int kPackCountWord = 100;   // (raft_hip_pack's count of listed windows: a word of the block outside the stamped lines)
 __global__ void publish_sizes_kernel(const long long *scan_totals, const Ctrl *ctrl, long long *host, long long seq)
@@ -450,9 +376,7 @@ struct raft_hip_ctx {
     raft_hip_params prm{};
     int32_t high_cov = 0, div = 0, minbins = 1;
     int32_t tile_q = 0;               // 0 = variant default
-    int32_t variant = default_variant();
     int32_t force_bucket = 0;
-    bool no_recut = false;            // leave tiles that do not fit the fast kernel to the general kernel (fallback, A/B)
     bool no_bucket_win = false;       // general bucketing: a side's windows did not fit 16 bits once (kErrWide): coordinate pairs from then on
     size_t cov_trial_cap = 0;         // capacity of `cov` the placement trial has been run for (run_pass)
     double trial_ms[2] = {0.0, 0.0};  // that trial: the pileup kernel into `cov` as first placed / into the best of the other candidates (ms)
@@ -464,7 +388,7 @@ struct raft_hip_ctx {
     DevBuf deep_list;                 // tiles too deep for 16-bit coverage (pileup_deep.hpp)
     long long deep_cap = 1024;        // its entries; grows when a pass lists more (raft_hip_finish)
     DevBuf tail_buf;                  // the fused tail's sums (finalize.hpp FinalizeArgs::tail_part ...)
-    DevBuf wave_ctr, ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_desc, tile_cuts, slow_list, block_sums;
+    DevBuf wave_ctr, ctrl, scan_tmp, cov_off, rep_res_off, cutcap_off, tile_first, tile_cuts, block_sums;
     DevBuf cov, rep_cnt, raw_key, raw_s, raw_e, cut_cnt, frag_cnt, rep_off, cut_off, frag_off;
     DevBuf rep_s, rep_e, cuts, frag_read, frag_begin, frag_end;
     DevBuf b_cnt, b_off, b_rid, b_s, b_e;
@@ -473,14 +397,12 @@ struct raft_hip_ctx {
     DevBuf rs_k0, rs_k1, rs_v0, rs_v1, gaps;   // general streams, large inputs: (read id, start | end << 32) per side, before and after the radix sort; long runs of reads without intervals
     DevBuf samples;                   // up to kSamples + 2 read ids at evenly spaced records (guess_runs_kernel): coarse index
     DevBuf in_len, in_col[6];         // staging for raft_hip_run_host
-    DevBuf dbg;                       // diagnostic variant only
     DevBuf cov8, exc_idx, exc_val, exc_cnt;   // transfer encoding of cov[] (raft_hip_fetch_packed)
     int packed_width = 0;             // width (bytes per window) of the encoding the buffers hold, 0 = none
     long long n_exc = 0, exc_cap = 0;
     int out_width = 4;                // raft_hip_set_output_width: 1 / 2 = the pass writes the encoding, cov[] only on request
     int pass_width = 4;               // what the last pass wrote (4 where the general kernel had to take part)
     bool cov_valid = false;           // c->cov holds the int32 array of the last pass
-    long long dbg_tiles = 0;
     void *pinned = nullptr;           // small pinned scratch for readbacks
     long long *pinned_dev = nullptr;  // the same block as the device addresses it
     hipEvent_t ev_gjoin = nullptr;
@@ -672,11 +594,11 @@ void raft_hip_destroy(raft_hip_ctx *c)
     c->lane_up_ev.clear(); c->lane_down_ev.clear();
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
-    DevBuf *all[] = {&c->deep_list, &c->tail_buf, &c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_desc, &c->tile_cuts, &c->slow_list,
+    DevBuf *all[] = {&c->deep_list, &c->tail_buf, &c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->cutcap_off, &c->tile_first, &c->tile_cuts,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->gs_rid, &c->gs_s, &c->gs_e, &c->gs_off, &c->gs_err, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1, &c->gaps, &c->in_len,
-                     &c->dbg, &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->exc_idx2, &c->exc_val2, &c->sort_tmp, &c->exc_pidx, &c->exc_pval, &c->exc_tile_n, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
+                     &c->samples, &c->exp_qid, &c->in_off, &c->m_off, &c->u_s, &c->u_e, &c->cov_anchor, &c->abs_bits, &c->exc_idx2, &c->exc_val2, &c->sort_tmp, &c->exc_pidx, &c->exc_pval, &c->exc_tile_n, &c->x_qs, &c->x_qe, &c->x_off, &c->x_raw, &c->x_send_off, &c->x_cnt, &c->cov8, &c->exc_idx, &c->exc_val, &c->exc_cnt, &c->in_col[0], &c->in_col[1], &c->in_col[2], &c->in_col[3], &c->in_col[4], &c->in_col[5]};
     for (DevBuf *b : all) b->release();
     for (DevBuf *b : c->user_bufs) { b->release(); delete b; }
     c->user_bufs.clear();
@@ -768,10 +690,9 @@ void *raft_hip_get_stream(raft_hip_ctx *c) { return c ? (void *)c->stream : null
 int raft_hip_set_tuning(raft_hip_ctx *c, int32_t tile_bins, int32_t force_bucket_path, int32_t variant)
 {
     if (!c) return RAFT_HIP_ERR_PARAM;
-    if (variant < -1 || variant >= kNumVariants) return RAFT_HIP_ERR_PARAM;
-    const int v = variant < 0 ? default_variant() : variant;
-    if (tile_bins < 0 || tile_bins > (kVariants[v].fast == 2 ? (1 << 20) : kVariants[v].cap)) return RAFT_HIP_ERR_PARAM;   // (wave tiles: the quantum is the walkers' share, not a tile)
-    c->variant = v;
+    // (variant: rounds 1-5 kept several pileup kernels; -1 and 5 name the one there is -- pileup_wave.hpp -- and nothing else is accepted)
+    if (variant != -1 && variant != 5) return RAFT_HIP_ERR_PARAM;
+    if (tile_bins < 0 || tile_bins > (1 << 20)) return RAFT_HIP_ERR_PARAM;   // (the quantum is a worker's share of windows per draw, not a tile)
     c->tile_q = tile_bins;
     c->force_bucket = force_bucket_path ? 1 : 0;
     return RAFT_HIP_OK;
@@ -879,16 +800,10 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     hipStream_t st = c->stream;
     SyncScope scope(c->stream, c->side_stream);            // (a buffer that grows waits for this context's streams only)
     bool expand = false;
-    const PileVariant &pv = kVariants[c->variant];
-    // tiles that do not fit the fast kernel are re-cut for it (pileup.hpp tile_desc_kernel) unless told otherwise
-    // one wave per tile (pileup_wave.hpp): the workers cut their tiles themselves -- reads longer than a tile in pieces, which is
-    // what `recut` says to the geometry scan and to finalize -- from the boundaries of quantum tiles four times a tile's size
-    const bool wave = pv.fast == 2;
-    const bool recut = wave || (pv.fast && !c->no_recut && getenv("RAFT_NO_RECUT") == nullptr);
     // window records go to the fast kernel's own instantiation (pileup_fast.hpp IN = 1) where every tile is the fast kernel's
     // in its default configuration and the runs are few; anything else gets coordinate columns that fall into the same
     // windows (bucket.hpp unpack_windows_kernel) and takes the paths those have
-    const bool lean = d_win && n_rec > 0 && !merge && eff_runs <= kWinMaxRuns && wave && !c->force_bucket && getenv("RAFT_NO_WINDOW_KERNEL") == nullptr;
+    const bool lean = d_win && n_rec > 0 && !merge && eff_runs <= kWinMaxRuns && !c->force_bucket && getenv("RAFT_NO_WINDOW_KERNEL") == nullptr;
     if (d_win && !lean && n_rec > 0) {
         HIP_TRY(c, c->u_s.ensure((size_t)n_rec * 4));
         HIP_TRY(c, c->u_e.ensure((size_t)n_rec * 4));
@@ -922,11 +837,8 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     c->sum.n_reads = n_reads; c->sum.n_records = n_rec; c->sum.high_cov = c->high_cov; c->sum.error_index = -1;
     const long long N = n_reads;
 
-    // the encoding of cov[] is written directly when every tile goes through the fast kernel (pileup_fast.hpp OW); a pass
-    // the general kernel takes part in writes int32 and raft_hip_fetch_packed_w encodes it afterwards, as it always did
-    // (delta4: the default configuration's instantiations only; elsewhere the pass writes int32 and is encoded afterwards)
-    const bool d4_ok = wave;
-    const int ow = (c->out_width != 4 && recut && c->variant != kDiagVariant && (c->out_width != kCovDelta4 || d4_ok)) ? c->out_width : 4;
+    // the pileup kernel writes cov[] in the width the context asked for (int32, or its transfer encodings: pileup_wave.hpp OW)
+    const int ow = c->out_width;
     // a grouped pass whose caller announced the window count needs nothing back from the device on the way
     const bool no_wait = grouped && in.hint_bins >= 0 && getenv("RAFT_NO_HINT") == nullptr;
     c->no_wait = no_wait;
@@ -982,7 +894,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         for (int s2 = 0; s2 < kMaxSeg; ++s2) grp.adj[s2] = merge ? 0 : in.adj[s2];
     }
     long long *scan_totals = nullptr;
-    ReadPrepLoader prep_ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, recut ? pv.cap : INT32_MAX, pv.cap,
+    ReadPrepLoader prep_ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, kTileCap, kTileCap,
                            &ctrl->err_flags, &ctrl->err_index, make_fast_div(c->prm.reso),
                            make_fast_div(c->minbins < INT32_MAX ? c->minbins + 1 : 1), make_fast_div(c->prm.interval_length)};
     ScanOut<3> prep_so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), c->cutcap_off.as<long long>()}};
@@ -998,9 +910,9 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     const bool shape_fits = c->shape.valid && c->shape.n_reads == n_reads && c->shape.n_rec == n_rec && c->shape.len == (const void *)d_len &&
                             c->shape.qid == (const void *)d_qid && c->shape.reso == c->prm.reso && c->shape.minbins == c->minbins &&
                             c->shape.interval_length == c->prm.interval_length && c->shape.symmetric_mode == c->prm.symmetric_mode &&
-                            c->shape.variant == c->variant && c->shape.tile_q == c->tile_q;
-    const bool speculate = spec && wave && shape_fits && N > 0 && !c->is_lane && getenv("RAFT_NO_SPECULATE") == nullptr;
-    const bool known = wave && N > 0 && (speculate || (no_wait && getenv("RAFT_NO_FUSED_HEAD") == nullptr));
+                            c->shape.tile_q == c->tile_q;
+    const bool speculate = spec && shape_fits && N > 0 && !c->is_lane && getenv("RAFT_NO_SPECULATE") == nullptr;
+    const bool known = N > 0 && (speculate || (no_wait && getenv("RAFT_NO_FUSED_HEAD") == nullptr));
     c->speculated = speculate;
     if (speculate) c->sum.flags |= RAFT_HIP_SUM_SPECULATED;
     if (!known) {
@@ -1032,7 +944,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         // sizes from the caller's window count: B as announced (checked on the device, kErrHint); bounds for the rest --
         // reserved raw-repeat slots sum_r ((w_r + 1) / (minbins + 1) + two per piece of a long read), markers sum_r (len_r / L + 2)
         B = in.hint_bins;
-        RU = (B + N) / ((long long)c->minbins + 1) + 4 * (B / pv.cap) + 4;
+        RU = (B + N) / ((long long)c->minbins + 1) + 4 * (B / kTileCap) + 4;
         CU = B / std::max(1, c->prm.interval_length / c->prm.reso) + 2 * N + 2;
         if (c->prm.interval_length < c->prm.reso) CU = B * ((long long)c->prm.reso / c->prm.interval_length + 1) + 2 * N + 2;
     } else {
@@ -1062,26 +974,14 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     c->sum.n_bins = B; c->sum.total_windows = B;
     c->cap_rep = RU; c->cap_cut = CU;
     if (RU >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;   // reserved raw-repeat slots are indexed with 32 bits in LDS
-    // Tile quantum: a tile's windows are Q minus the overhang of the previous tile's last read plus that of its own, so
-    // the room left above Q has to follow the read lengths or most tiles of a long-read set overflow the LDS window
-    // (measured optima, mean windows per read -> room: 600 -> 1.7 k, 1200 -> 2.7 k, 3000 -> 3.9 k of a 7936-window tile).
-    int Q = c->tile_q ? std::min(c->tile_q, pv.cap) : pv.cap - pv.short_max;
-    // (wave tiles: the quantum only says which thread of tile_desc_kernel walks which reads -- three tiles' worth each)
-    if (wave) {
-        // three tiles' worth (four until round 5: the kernel likes short ranges -- 2.42 / 2.45 / 2.49 / 2.56 ms at two / three / four /
-        // eight tiles' worth in one context -- and tile_desc_kernel long ones; the pass is shortest at three, profiles/r05_quantum_sweep.txt),
-        // but never so few quantum tiles that workers stay without one (a 50 k-read set) or that the last draws
-        // of the kernel are a fifth of its duration (an eighth of the human-scale set: two tiles' worth)
-        const long long q3 = 3LL * (pv.cap / 128) * 128, q1 = (pv.cap / 128) * 128;
-        Q = c->tile_q ? std::max(256, c->tile_q) : (int)std::max(q1, std::min(q3, (B / (8LL * wave_grid_waves(true))) / 128 * 128));
-    }
-    if (!c->tile_q && pv.fast == 1 && N > 0) {
-        const double mean_w = (double)B / (double)N;
-        const int room = (int)std::min<double>(pv.cap / 2, std::max<double>(1408.0, 600.0 + 1.75 * mean_w));
-        Q = std::max(256, ((pv.cap - room) / 128) * 128);
-    }
+    // The quantum: boundaries at which a worker of the pileup kernel may begin (it cuts its tiles itself; tile_desc_kernel finds each
+    // boundary's first read, records and window).  Three tiles' worth (four until round 5: the kernel likes short ranges -- 2.42 / 2.45 /
+    // 2.49 / 2.56 ms at two / three / four / eight tiles' worth in one context -- and tile_desc_kernel long ones; the pass is shortest
+    // at three, profiles/r05_quantum_sweep.txt), but never so few ranges that workers stay without one (a 50 k-read set) or that the
+    // last draws of the kernel are a fifth of its duration (an eighth of the human-scale set: two tiles' worth)
+    const long long q3 = 3LL * (kTileCap / 128) * 128, q1 = (kTileCap / 128) * 128;
+    const int Q = c->tile_q ? std::max(256, c->tile_q) : (int)std::max(q1, std::min(q3, (B / (8LL * wave_grid_waves(true))) / 128 * 128));
     const long long n_tiles = B / Q + 1;
-    if (n_tiles * kDescDwords >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE; // descriptors are indexed with 32 bits
 
     if (ow == 4) HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));
     else {
@@ -1096,22 +996,14 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         c->exc_cap = cap;
     }
     HIP_TRY(c, c->tile_first.ensure((size_t)(n_tiles + 1) * 4));
-    HIP_TRY(c, c->tile_desc.ensure((size_t)n_tiles * sizeof(TileDesc)));
-    // extra tiles (tiles re-cut for the fast kernel: groups of whole reads, pieces of long reads) follow the regular cuts
-    long long extra_cap = 0;
+    // delta4: a tile lists windows in slots of its own, named by a tile id; the number bounds the ids that have slots (the tiles are
+    // cut by the workers -- a tile is closed by a full array, 63 reads, a long read or the end of a range; ids are drawn 32 at a time;
+    // a tile beyond them lists in the shared list)
     const bool ow_is_d4 = ow == kCovDelta4;
-    if (recut) {
-        extra_cap = n_tiles + B / pv.cap + N / 8 + 1024;
-        // (wave tiles are cut by the workers: no list; the number only bounds the tile ids under which a delta4 pass lists windows --
-        // a tile is closed by a full array, 63 reads, a long read or the end of a range; ids are drawn 32 at a time)
-        if (wave) extra_cap = ow_is_d4 ? 2 * n_tiles + 2 * (B / pv.cap) + N / 32 + 32LL * wave_grid_waves(true) + 1024 : 0;
-        if (const char *ec = getenv("RAFT_EXTRA_CAP")) extra_cap = std::max(0, atoi(ec));   // (tests: force the overflow fallback)
-        if ((n_tiles + 1 + 2 * extra_cap) * 8 >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;   // cut words are indexed with 32 bits
-    }
-    if (pv.fast) {
-        HIP_TRY(c, c->tile_cuts.ensure((size_t)(n_tiles + 1 + 2 * extra_cap) * sizeof(TileCut)));
-        HIP_TRY(c, c->slow_list.ensure((size_t)n_tiles * 4));
-    }
+    long long extra_cap = ow_is_d4 ? 2 * n_tiles + 2 * (B / kTileCap) + N / 32 + 32LL * wave_grid_waves(true) + 1024 : 0;
+    if (const char *ec = getenv("RAFT_EXTRA_CAP")) extra_cap = std::max(0, atoi(ec));   // (tests: tiles without slots of their own)
+    if ((n_tiles + 1) * 8 >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;   // boundary words are indexed with 32 bits
+    HIP_TRY(c, c->tile_cuts.ensure((size_t)(n_tiles + 1) * sizeof(TileCut)));
     HIP_TRY(c, c->block_sums.ensure((size_t)256 * 8 * 16 * 2 * 4));
     HIP_TRY(c, c->rep_cnt.ensure((size_t)std::max(N, 1LL) * 4));
     HIP_TRY(c, c->cut_cnt.ensure((size_t)std::max(N, 1LL) * 4));
@@ -1194,12 +1086,12 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
 
     PileupArgs pa{};
     pa.read_len = d_len; pa.cov_off = c->cov_off.as<long long>();
-    pa.td = c->tile_desc.as<TileDesc>(); pa.n_tiles = n_tiles; pa.n_reads = n_reads;
+    pa.n_tiles = n_tiles; pa.n_reads = n_reads;
     pa.reso = c->prm.reso; pa.high_cov = c->high_cov; pa.repeat_length = c->prm.repeat_length; pa.flank = c->prm.flanking_length;
     pa.cov = ow == 4 ? c->cov.as<int32_t>() : nullptr;
     pa.covp = ow == 4 ? nullptr : c->cov8.p; pa.n_exc = &ctrl->n_exc; pa.exc_cap = c->exc_cap;
     pa.cov_anchor = ow == kCovDelta4 ? c->cov_anchor.as<int32_t>() : nullptr; pa.d4_shift = c->d4_shift;
-    const long long d4_tiles = n_tiles + extra_cap;          // (regular tiles, then the extra ones)
+    const long long d4_tiles = n_tiles + extra_cap;          // (tile ids with slots of their own)
     if (ow == kCovDelta4) {
         HIP_TRY(c, c->exc_pidx.ensure((size_t)d4_tiles * kExcPerTile * 8));
         HIP_TRY(c, c->exc_pval.ensure((size_t)d4_tiles * kExcPerTile * 4));
@@ -1232,10 +1124,10 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     if (!grouped && spec && !speculate) {
         // what this pass found out on the way, for the next one over a stream of the same shape (see `speculate`); a pass that turns
         // out to have been built on a wrong guess takes it back (raft_hip_finish)
-        c->shape.valid = fast && table_ok && wave && N > 0;
+        c->shape.valid = fast && table_ok && N > 0;
         c->shape.n_reads = n_reads; c->shape.n_rec = n_rec; c->shape.len = d_len; c->shape.qid = d_qid;
         c->shape.reso = c->prm.reso; c->shape.minbins = c->minbins; c->shape.interval_length = c->prm.interval_length;
-        c->shape.symmetric_mode = c->prm.symmetric_mode; c->shape.variant = c->variant; c->shape.tile_q = c->tile_q;
+        c->shape.symmetric_mode = c->prm.symmetric_mode; c->shape.tile_q = c->tile_q;
         c->shape.B = B; c->shape.RU = RU; c->shape.CU = CU; c->shape.n_desc = n_desc;
         for (int i = 0; i < kMaxSeg; ++i) c->shape.desc[i] = i < n_desc ? desc[i] : 0;
     } else if (!speculate && !grouped) c->shape.valid = false;
@@ -1271,7 +1163,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
         const bool parted = cap_iv >= (1LL << 20) && (!symmetric || n_desc + 1 > kMaxSeg) && getenv("RAFT_NO_RADIX_SORT") == nullptr;
         // ... and as window records where the wave kernel runs and a window index fits 16 bits: 8 bytes per side through the sort,
         // the kernel's leanest input behind it
-        bwin = parted && wave && c->prm.reso <= 32767 && !c->no_bucket_win && getenv("RAFT_NO_BUCKET_WINDOWS") == nullptr;
+        bwin = parted && c->prm.reso <= 32767 && !c->no_bucket_win && getenv("RAFT_NO_BUCKET_WINDOWS") == nullptr;
         if (bwin) {
             const int prc = sort_sides_win(c, st, (long long)n_rec, n_reads, symmetric, d_qid, d_qs, d_qe, d_tid, d_ts, d_te, cap_iv,
                                            c->b_s.as<uint32_t>(), c->b_off.as<long long>(), &ctrl->err_flags, &ctrl->err_index);
@@ -1312,36 +1204,18 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     MirrorArgs mir{};
     if (spec && c->prm.symmetric_mode < 0 && fast) mir = {d_qs, d_qe, d_tid, d_ts, d_te, &ctrl->insp.sym_found};
     hipLaunchKernelGGL(tile_desc_kernel, dim3((unsigned)((n_tiles + 2 + 255) / 256)), dim3(256), 0, st, n_tiles, sb, seg_end_dev,
-                       pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_desc.as<TileDesc>(),
-                       pv.fast ? c->tile_cuts.as<TileCut>() : nullptr, wave ? INT32_MAX : pv.cap, wave ? INT32_MAX : kFastMaxReads,
-                       pv.fast ? c->slow_list.as<int32_t>() : nullptr, &ctrl->n_slow,
+                       pa.iv_rid, c->tile_first.as<int32_t>(), c->cov_off.as<long long>(), c->tile_cuts.as<TileCut>(),
                        (fast && table_ok) ? c->samples.as<int32_t>() : nullptr, (long long)n_rec,
-                       c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags,
-                       (recut && !wave) ? c->tile_cuts.as<TileCut>() + (n_tiles + 1) : nullptr, &ctrl->n_extra, (int32_t)extra_cap, pv.cap, mir, grp, pv.cap,
+                       c->sum.interval_path == 1 ? c->b_off.as<long long>() : nullptr, &ctrl->err_flags, mir, grp,
                        speculate ? &ctrl->guess : nullptr);
-    pa.n_extra = recut ? &ctrl->n_extra : nullptr;
-    pa.piece_w = pv.cap;
-
-    pa.dbg = nullptr;
-    if (c->variant == kDiagVariant) {
-        HIP_TRY(c, c->dbg.ensure((size_t)n_tiles * 16 * 8));
-        HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, (size_t)n_tiles * 16 * 8, st));
-        pa.dbg = c->dbg.as<unsigned long long>();
-        c->dbg_tiles = n_tiles;
-    }
-    // ---- the dominant kernel(s): persistent workgroups, wg_per_cu per CU
-    int bpc = pv.wg_per_cu;
-    if (const char *e = getenv("RAFT_PILEUP_WG_PER_CU")) bpc = std::max(1, std::min(atoi(e), pv.wg_per_cu)); // occupancy experiments
-    const unsigned pgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * bpc));
-    unsigned n_sum_blocks = pgrid;
-    pa.tile_batch = n_tiles >= 64LL * pgrid ? 8 : (n_tiles >= 16LL * pgrid ? 2 : 1);
+    // ---- the dominant kernel: ONE launch of a persistent grid of single-wave workers, each drawing ranges of reads from the
+    // boundaries tile_desc_kernel cut (workers without a range leave at once)
+    unsigned n_sum_blocks = 1;
     hc_mark("tile_desc launched");
     HIP_TRY(c, hipEventRecord(c->ev_pile0, st));
     hc_mark("ev_pile0");
     bool wave_launched = false;
-    if (wave) {
-        // ONE launch, no second stream: a persistent grid of single-wave workers, each drawing wave tiles from the list
-        // tile_desc_kernel cut (its length is known on the device only: workers without a tile leave at once)
+    {
         int n_waves = (int)std::max<long long>(1, std::min<long long>(wave_grid_waves(lean || bwin), n_tiles));
         pa.tile_batch = 1;
         int n_ctr = 8;
@@ -1352,7 +1226,6 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
 #endif
         pa.tile_batch |= (n_ctr - 1) << 24;
         pa.tile_counter = c->wave_ctr.as<int32_t>();
-        pa.n_extra = nullptr;
         pa.piece_w = (int32_t)std::min<long long>(extra_cap, INT32_MAX);    // (delta4: tile ids below this have slots of their own)
         launch_wave_variant(ow, lean || bwin, st, pa.n_seg, c->tile_cuts.p, &pa, n_waves);
         n_sum_blocks = (unsigned)n_waves;
@@ -1430,41 +1303,12 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
                 // (whichever array is kept holds this pass's coverage: every run wrote all of it)
             }
         }
-    } else if (pv.fast) {
-        const TileCut *cuts = c->tile_cuts.as<TileCut>();
-        // The tiles the fast kernel does not take (reads longer than the LDS window, very many reads) go to the general
-        // kernel on a second stream: the two kernels touch disjoint reads, and the general kernel's workgroups move in
-        // wherever a workgroup of the fast kernel's persistent grid has retired instead of waiting for the whole grid.
-        PileupArgs ps = pa;
-        ps.slow_list = c->slow_list.as<int32_t>(); ps.n_slow = &ctrl->n_slow;
-        ps.block_sums = pa.block_sums + 2 * (long long)pgrid;
-        ps.dbg = nullptr;
-        const unsigned sgrid = (unsigned)std::max<long long>(1, std::min<long long>(n_tiles, 256LL * 5));
-        // (Measured and dropped, round 3: regular tiles, then the re-cut ones, from ONE persistent grid -- pileup_fast.hpp
-        // EXTRA = 2, no second stream and no event hand-over at either end.  Slower on every workload: hg002 pass 2.92
-        // against 2.87 ms, ultralong 3.03 against 2.97, 50 k reads 0.200 against 0.192 -- the extra tiles are better off
-        // running BESIDE the regular ones from the start than behind them.)
-        {
-            HIP_TRY(c, hipEventRecord(c->ev_fork, st));
-            launch_fast_variant<0>(c->variant, ow, st, pgrid, pa.n_seg, cuts, pa);
-            HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-            if (recut) {
-                // the tiles that did not fit as they are, re-cut by tile_desc_kernel: the same kernel, its other instantiation
-                ps.slow_list = nullptr; ps.tile_counter = &ctrl->slow_next; ps.n_extra = &ctrl->n_extra; ps.tile_batch = 1;
-                launch_fast_variant<1>(c->variant, ow, c->side_stream, pgrid, pa.n_seg, cuts, ps);
-            } else launch_general<6144, 5>(c->side_stream, sgrid, ps);
-            HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
-            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
-            n_sum_blocks = pgrid + (recut ? pgrid : sgrid);
-        }
-    } else {
-        launch_general<6144, 5>(st, pgrid, pa);
     }
     hc_mark("pileup launched");
     HIP_TRY(c, hipEventRecord(c->ev_pile1, st));
     // the tiles the wave kernel listed instead of piling them up (2^15 intervals or more: pileup_deep.hpp); nearly always none
     if (wave_launched)
-        hipLaunchKernelGGL(pileup_deep_kernel, dim3(64), dim3(kDeepThreads), 0, st, pa, c->deep_list.as<DeepTile>(), &ctrl->n_deep, pa.deep_cap, ow);
+        hipLaunchKernelGGL(pileup_deep_kernel, dim3(1024), dim3(kDeepThreads), 0, st, pa, c->deep_list.as<DeepTile>(), &ctrl->n_deep, pa.deep_cap, ow);
     hc_mark("ev_pile1");
     if (ow == kCovDelta4)      // the windows the tiles listed, gathered into the shared list (whose counter the control block carries)
         hipLaunchKernelGGL(compact_exceptions_kernel, dim3((unsigned)((d4_tiles + kCompactTiles - 1) / kCompactTiles)), dim3(256), 0, st, d4_tiles, kExcPerTile,
@@ -1481,7 +1325,7 @@ static int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool veri
     fa.frag_read = c->frag_read.as<int32_t>(); fa.frag_begin = c->frag_begin.as<int32_t>(); fa.frag_end = c->frag_end.as<int32_t>();
     fa.err_flags = &ctrl->err_flags; fa.err_index = &ctrl->err_index;
     fa.by_L = make_fast_div(c->prm.interval_length); fa.by_div = make_fast_div(c->div); fa.by_reso = make_fast_div(c->prm.reso);
-    fa.long_windows = recut ? pv.cap : INT32_MAX; fa.reso = c->prm.reso; fa.repeat_length = c->prm.repeat_length;
+    fa.long_windows = kTileCap; fa.reso = c->prm.reso; fa.repeat_length = c->prm.repeat_length;
     fa.flank = c->prm.flanking_length; fa.rep_cnt_rw = c->rep_cnt.as<int32_t>(); fa.total_repeat = &ctrl->totals[1];
     fa.tail_part = tail_part; fa.tail_prefix = tail_prefix; fa.tail_blocks = tail_blocks;
     fa.rep_off_w = c->rep_off.as<long long>(); fa.cut_off_w = c->cut_off.as<long long>(); fa.frag_off_w = c->frag_off.as<long long>();
@@ -1674,44 +1518,27 @@ int raft_hip_finish(raft_hip_ctx *c, raft_hip_summary *summary)
                 if (rc != RAFT_HIP_OK) return rc;
             }
         }
-        // Three more reasons to run the pass again, each of which may turn up in the re-run of another: what one of them
-        // forces (the int32 kernels, no re-cut tiles, a longer list) stays in force for every later re-run of this call.
-        //  * kErrExtra: more extra tiles than room -> this pass with the general kernel for those tiles (the wave kernel has no
-        //    other tiles than the ones it cuts itself: int32 kernels);
-        //  * kErrDeep: a wave tile with 2^15 or more intervals (a pile-up that deep does not fit the 16-bit difference array
-        //    of pileup_wave.hpp) -> the int32 kernels;
+        // Three more reasons to run the pass again, each of which may turn up in the re-run of another:
+        //  * kErrWide: general bucketing, a side whose windows do not fit 16 bits -> coordinate pairs from now on;
+        //  * kErrDeep: more tiles of 2^15 intervals or more than the list for pileup_deep_kernel held -> once more, with room;
         //  * more windows at or above the encoding's limit than the list held -> once more with room for all of them.
-        {
-            int force_variant = -1;
-            bool force_no_recut = false;
-            for (int round = 0; round < 4 && c->pending_err == RAFT_HIP_OK; ++round) {
-                const Ctrl hc = ctrl_block();
-                if (hc.err_flags & kErrStop) break;
-                bool rerun = false;
-                if ((hc.err_flags & kErrExtra) && !force_no_recut) {
-                    force_no_recut = true;
-                    if (kVariants[c->variant].fast == 2) force_variant = 0;
-                    rerun = true;
-                } else if ((hc.err_flags & kErrWide) && !c->no_bucket_win) {
-                    c->no_bucket_win = true;            // a side's windows do not fit 16 bits: this context buckets coordinate pairs from now on
-                    rerun = true;
-                } else if ((hc.err_flags & kErrDeep) && (long long)hc.n_deep > c->deep_cap) {
-                    c->deep_cap = (long long)hc.n_deep + 64;     // more deep tiles than the list held: once more, with room
-                    rerun = true;
-                } else if (c->pass_width != 4 && (long long)hc.n_exc > c->exc_cap && !(hc.err_flags & ~(kErrOrder | kErrExtra | kErrDeep | kErrWide))) {
-                    c->exc_cap = (long long)hc.n_exc;
-                    rerun = true;
-                }
-                if (!rerun) break;
-                const int keep = c->variant;
-                const bool keep_recut = c->no_recut;
-                if (force_variant >= 0) c->variant = force_variant;
-                if (force_no_recut) c->no_recut = true;
-                const int rc = again(c->args);
-                c->variant = keep;
-                c->no_recut = keep_recut;
-                if (rc != RAFT_HIP_OK) return rc;
+        for (int round = 0; round < 4 && c->pending_err == RAFT_HIP_OK; ++round) {
+            const Ctrl hc = ctrl_block();
+            if (hc.err_flags & kErrStop) break;
+            bool rerun = false;
+            if ((hc.err_flags & kErrWide) && !c->no_bucket_win) {
+                c->no_bucket_win = true;            // a side's windows do not fit 16 bits: this context buckets coordinate pairs from now on
+                rerun = true;
+            } else if ((hc.err_flags & kErrDeep) && (long long)hc.n_deep > c->deep_cap) {
+                c->deep_cap = (long long)hc.n_deep + 64;     // more deep tiles than the list held: once more, with room
+                rerun = true;
+            } else if (c->pass_width != 4 && (long long)hc.n_exc > c->exc_cap && !(hc.err_flags & ~(kErrOrder | kErrDeep | kErrWide))) {
+                c->exc_cap = (long long)hc.n_exc;
+                rerun = true;
             }
+            if (!rerun) break;
+            const int rc = again(c->args);
+            if (rc != RAFT_HIP_OK) return rc;
         }
         if (c->pending_err == RAFT_HIP_OK) {
             Ctrl hc;
@@ -1807,8 +1634,8 @@ extern "C" int raft_hip_debug_swap(raft_hip_ctx *a, raft_hip_ctx *b, int which)
 {
     DevBuf raft_hip_ctx::*m[] = {&raft_hip_ctx::wave_ctr, &raft_hip_ctx::ctrl, &raft_hip_ctx::block_sums, &raft_hip_ctx::tile_cuts, &raft_hip_ctx::cov_off,
                                  &raft_hip_ctx::rep_res_off, &raft_hip_ctx::cutcap_off, &raft_hip_ctx::rep_cnt, &raft_hip_ctx::raw_key, &raft_hip_ctx::raw_s,
-                                 &raft_hip_ctx::raw_e, &raft_hip_ctx::cov, &raft_hip_ctx::tile_first, &raft_hip_ctx::tile_desc, &raft_hip_ctx::scan_tmp,
-                                 &raft_hip_ctx::samples, &raft_hip_ctx::slow_list, &raft_hip_ctx::cut_cnt, &raft_hip_ctx::frag_cnt, &raft_hip_ctx::rep_off,
+                                 &raft_hip_ctx::raw_e, &raft_hip_ctx::cov, &raft_hip_ctx::tile_first, &raft_hip_ctx::scan_tmp,
+                                 &raft_hip_ctx::samples, &raft_hip_ctx::cut_cnt, &raft_hip_ctx::frag_cnt, &raft_hip_ctx::rep_off,
                                  &raft_hip_ctx::cut_off, &raft_hip_ctx::frag_off, &raft_hip_ctx::rep_s, &raft_hip_ctx::rep_e, &raft_hip_ctx::cuts,
                                  &raft_hip_ctx::frag_read, &raft_hip_ctx::frag_begin, &raft_hip_ctx::frag_end};
     const int n = (int)(sizeof m / sizeof m[0]);
@@ -2227,7 +2054,7 @@ int prepare_lanes(raft_hip_ctx *c)
     }
     for (raft_hip_ctx *l : c->lanes) {
         apply_params(l, &c->prm);
-        l->tile_q = c->tile_q; l->variant = c->variant; l->force_bucket = 0;
+        l->tile_q = c->tile_q; l->force_bucket = 0;
         l->is_lane = true;
         l->emit_cuts = false;                         // (raft_hip_host_outputs holds no cut points)
     }
@@ -2358,7 +2185,7 @@ static int run_routed(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_reads,
             for (int e = 0; e < d; ++e) (void)raft_hip_set_params(ctxs[e], &keep[(size_t)e]);
             return rc0;
         }
-        ctxs[d]->tile_q = c->tile_q; ctxs[d]->variant = c->variant;
+        ctxs[d]->tile_q = c->tile_q;
     }
     // ---- chunk k runs on context k % n_job; a ticket chain publishes the sizes in chunk order
     std::mutex mu;
@@ -2737,7 +2564,7 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
             if (d > 0) {
                 const int rc0 = raft_hip_set_params(J.c, &c->prm);
                 if (rc0 != RAFT_HIP_OK) return rc0;
-                J.c->tile_q = c->tile_q; J.c->variant = c->variant;
+                J.c->tile_q = c->tile_q;
             }
             J.bins0 = bins; J.rep0 = rep_cap; J.frag0 = frag_cap;
             if (n_job > 1) {
@@ -3755,26 +3582,11 @@ int raft_hip_last_timing(raft_hip_ctx *c, double *pileup_seconds, double *pass_s
     return RAFT_HIP_OK;
 }
 
-int raft_hip_debug_stamps(raft_hip_ctx *c, unsigned long long *host, int64_t max_tiles, int64_t *n_tiles)
-{
-    if (!c || !n_tiles) return RAFT_HIP_ERR_PARAM;
-    if (!c->finished || c->variant != kDiagVariant) return RAFT_HIP_ERR_STATE;
-    *n_tiles = c->dbg_tiles;
-    const long long n = std::min<long long>(max_tiles, c->dbg_tiles);
-    if (host && n > 0) HIP_TRY(c, hipMemcpy(host, c->dbg.p, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
-    return RAFT_HIP_OK;
-}
-
 int raft_hip_selftest(int device_id)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return RAFT_HIP_ERR_DEVICE;
     if (hipSetDevice(device_id) != hipSuccess) return RAFT_HIP_ERR_DEVICE;
-    if (getenv("RAFT_PRINT_OCCUPANCY")) {
-        print_occupancy("fast<7936,2,6,4>", pileup_fast_kernel<7936, 2, 6, 4, false, 0>);
-        print_occupancy("fast<7936,1,6,4>", pileup_fast_kernel<7936, 1, 6, 4, false, 0>);
-        print_occupancy("general<256,6144,5,3>", pileup_kernel<256, 6144, 5, 3, false>);
-    }
     const int n = 256;
     int h_in[n], h_a[n], h_b[n];
     unsigned long long h_bal[n / 64];

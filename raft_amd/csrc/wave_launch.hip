@@ -3,7 +3,6 @@
 // The shared headers define (non-template) kernels; this translation unit sees them under a namespace of its own.
 #define raft raft_wave_tu
 #include "pack.hpp"
-#include "pileup_fast.hpp"     // note_exception
 #include "pileup_wave.hpp"
 #undef raft
 

@@ -23,7 +23,7 @@ EXPORTS = (
     "raft_hip_abi_version", "raft_hip_strerror", "raft_hip_last_error", "raft_hip_create", "raft_hip_destroy",
     "raft_hip_set_params", "raft_hip_set_stream", "raft_hip_use_own_stream", "raft_hip_get_stream", "raft_hip_run_device", "raft_hip_run_host",
     "raft_hip_finish", "raft_hip_outputs_device", "raft_hip_fetch", "raft_hip_last_timing", "raft_hip_set_tuning",
-    "raft_hip_selftest", "raft_hip_debug_stamps", "raft_hip_fetch_packed", "raft_hip_fetch_packed_w", "raft_hip_run_pipelined", "raft_hip_run_multi",
+    "raft_hip_selftest", "raft_hip_fetch_packed", "raft_hip_fetch_packed_w", "raft_hip_run_pipelined", "raft_hip_run_multi",
     "raft_hip_set_output_width", "raft_hip_packed_device", "raft_hip_run_device_grouped", "raft_hip_run_host_grouped",
     "raft_hip_run_multi_grouped", "raft_hip_host_register", "raft_hip_host_unregister", "raft_hip_comm_unique_id",
     "raft_hip_comm_create", "raft_hip_comm_destroy", "raft_hip_exchange", "raft_hip_exchange_local", "raft_hip_warm_up", "raft_hip_reserve",
@@ -186,7 +186,6 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.raft_hip_presplit_symmetric_local.argtypes = [C.POINTER(vp), i32, C.POINTER(_Records), C.POINTER(i32)]
     lib.raft_hip_packed_device.argtypes = [vp, C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
     lib.raft_hip_selftest.argtypes = [C.c_int]
-    lib.raft_hip_debug_stamps.argtypes = [vp, vp, i64, C.POINTER(i64)]
     if path is None:
         _lib = lib
     return lib
@@ -659,15 +658,6 @@ class Engine:
                                                     ptr["exc_value"], C.byref(n_exc), ptr["rep_offset"], ptr["rep_s"], ptr["rep_e"],
                                                     ptr["frag_offset"], ptr["frag_read"], ptr["frag_begin"], ptr["frag_end"]))
         return res
-
-    def debug_stamps(self, max_tiles: int = 1 << 20) -> np.ndarray:
-        """Diagnostic kernel variant 3: per-tile s_memtime stamps [n, 16] of the last pass."""
-        n = C.c_int64()
-        self._check(self._lib.raft_hip_debug_stamps(self._ctx, None, 0, C.byref(n)))
-        m = min(int(n.value), max_tiles)
-        out = np.zeros((m, 16), np.uint64)
-        self._check(self._lib.raft_hip_debug_stamps(self._ctx, C.c_void_p(out.ctypes.data), m, C.byref(n)))
-        return out
 
     def outputs_device(self) -> dict:
         """Zero-copy torch views of the device-resident outputs (valid until the next pass)."""

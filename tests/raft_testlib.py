@@ -368,3 +368,33 @@ def write_config1_inputs(tmp, cols, meta):
             shutil.copyfileobj(i, z)
         os.remove(os.path.join(tmp, f))
     return names
+
+
+# ---- the two pileup kernels ---------------------------------------------------------------------------------------------------
+# Rounds 1-5 kept several pileup kernels and the suites ran every case through each of them (raft_hip_set_tuning's `variant`).  Since
+# round 6 there is the wave kernel (16-bit difference array, one wave per tile: raft_amd/csrc/pileup_wave.hpp) and, for tiles of 2^15
+# intervals or more, the 32-bit side kernel (pileup_deep.hpp).  KERNELS names the two ways a case can be run: as it comes, and with
+# every tile sent the deep kernel's way (RAFT_DEEP_MIN=1, read by the engine at every pass) -- two independent implementations of
+# repeat.hpp:28-79 / 111-168 that must agree with the oracle and with each other.
+KERNELS = ("wave", "deep")
+
+
+class kernel_mode:
+    """with kernel_mode("deep"): every pass started inside sends all its tiles through pileup_deep_kernel."""
+    def __init__(self, mode):
+        assert mode in KERNELS or mode in (-1, 5, None), mode
+        self.deep = mode == "deep"
+
+    def __enter__(self):
+        self.old = os.environ.get("RAFT_DEEP_MIN")
+        if self.deep:
+            os.environ["RAFT_DEEP_MIN"] = "1"
+        return self
+
+    def __exit__(self, *exc):
+        if self.deep:
+            if self.old is None:
+                os.environ.pop("RAFT_DEEP_MIN", None)
+            else:
+                os.environ["RAFT_DEEP_MIN"] = self.old
+        return False

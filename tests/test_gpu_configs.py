@@ -22,13 +22,16 @@ def engine_result(eng, s, fetch_kw=None):
 
 
 def run_host(p, cols, **tuning):
+    """tuning: tile_bins, force_bucket, kernel ("wave" as it comes / "deep": every tile through pileup_deep_kernel)."""
     from raft_amd import engine
+    from raft_testlib import kernel_mode
     eng = engine.Engine(p, device=0)
     try:
         if tuning:
-            eng.set_tuning(tuning.get("tile_bins", 0), tuning.get("force_bucket", False), tuning.get("variant", -1))
-        eng.run_host(*cols)
-        s = eng.finish()
+            eng.set_tuning(tuning.get("tile_bins", 0), tuning.get("force_bucket", False), -1)
+        with kernel_mode(tuning.get("kernel", "wave")):
+            eng.run_host(*cols)
+            s = eng.finish()
         return engine_result(eng, s), s
     finally:
         eng.close()
@@ -36,10 +39,10 @@ def run_host(p, cols, **tuning):
 
 # ---- config 1 -----------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("mode", ["auto", "bucket", "general"])
+@pytest.mark.parametrize("mode", ["auto", "bucket", "deep"])
 def test_config1_standin_vs_reference_outputs(mode):
     p, cols, exp, meta = load_config1()
-    got, s = run_host(p, cols, force_bucket=(mode == "bucket"), variant=1 if mode == "general" else -1)
+    got, s = run_host(p, cols, force_bucket=(mode == "bucket"), kernel="deep" if mode == "deep" else "wave")
     assert s.symmetric == meta["symmetric"] and s.n_records == meta["n_rec"]
     for k in exp:
         assert np.array_equal(got[k], exp[k]), (mode, k)
@@ -54,11 +57,13 @@ def test_engine_vs_reference_binary_fuzz():
     from raft_amd import engine
     for i in range(ref_fuzz_count()):
         p, cols, exp = ref_fuzz_case(i)
+        from raft_testlib import kernel_mode
         eng = engine.Engine(p, device=0)
         try:
-            eng.set_tuning(0, i % 3 == 2, (-1, 1, 0)[i % 3] if i % 3 != 2 else -1)
-            eng.run_host(*cols)
-            s = eng.finish()
+            eng.set_tuning(0, i % 3 == 2, -1)            # (every third case: the general bucketing path; another third: the deep kernel)
+            with kernel_mode("deep" if i % 3 == 1 else "wave"):
+                eng.run_host(*cols)
+                s = eng.finish()
             assert_matches_ref_fuzz(engine_result(eng, s), exp, p, f"ref_fuzz case {i}")
         finally:
             eng.close()
@@ -173,9 +178,9 @@ def test_config5_parameter_sweep(ultralong_set, plen, cov_mul, reso):
     assert want["rep_s"].size > 0 or cov_mul == 2.0
     got, s = run_host(p, cols)
     assert_same_result(got, want, f"-p {plen} -m {cov_mul} -r {reso}")
-    if (plen, cov_mul) in ((5000, 1.3), (50000, 1.5)):     # the general kernel alone and the counting-sort path as well
-        got, s = run_host(p, cols, variant=1)
-        assert_same_result(got, want, f"-p {plen} -m {cov_mul} -r {reso} general kernel")
+    if (plen, cov_mul) in ((5000, 1.3), (50000, 1.5)):     # every tile through the deep kernel, and the counting-sort path as well
+        got, s = run_host(p, cols, kernel="deep")
+        assert_same_result(got, want, f"-p {plen} -m {cov_mul} -r {reso} deep kernel")
         got, s = run_host(p, cols, force_bucket=True)
         assert_same_result(got, want, f"-p {plen} -m {cov_mul} -r {reso} counting sort")
 
@@ -504,16 +509,14 @@ def _long_read_set(seed):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-@pytest.mark.parametrize("mode", ["default", "extra_cap_0", "no_recut", "variant2"])
+@pytest.mark.parametrize("mode", ["default", "deep"])
 def test_recut_tiles_and_pieces(seed, mode, monkeypatch):
-    """Tiles that do not fit the fast kernel are re-cut into groups and pieces (pileup.hpp tile_desc_kernel); with no room
-    for extra tiles the pass falls back to the general kernel (kErrExtra); RAFT_NO_RECUT keeps the round-1 split.  All
-    four must equal the oracle, incl. runs crossing piece boundaries and the repeat-length total."""
+    """Reads longer than a tile go in pieces, runs of tiny reads in groups of up to 63 (the workers of pileup_wave_kernel cut them
+    themselves; rounds 1-3: tile_desc_kernel re-cut them for the workgroup-tile kernel).  Through the wave kernel and through the deep
+    kernel: both must equal the oracle, incl. runs crossing piece boundaries and the repeat-length total."""
     from raft_amd import engine
-    if mode == "extra_cap_0":
-        monkeypatch.setenv("RAFT_EXTRA_CAP", "0")
-    if mode == "no_recut":
-        monkeypatch.setenv("RAFT_NO_RECUT", "1")
+    if mode == "deep":
+        monkeypatch.setenv("RAFT_DEEP_MIN", "1")
     rl, qid, a, b = _long_read_set(seed)
     for p in (RaftParams(est_cov=14, symmetric_mode=1), RaftParams(est_cov=9, reso=37, repeat_length=3000, interval_length=3000,
                                                                   read_length=9000, flanking_length=5000, symmetric_mode=1)):
@@ -522,7 +525,6 @@ def test_recut_tiles_and_pieces(seed, mode, monkeypatch):
         assert want["rep_s"].size > 20
         eng = engine.Engine(p, device=0)
         try:
-            eng.set_tuning(0, False, -1 if mode == "default" else 0)      # (the fallbacks belong to round 3's workgroup-tile kernel; "default": the wave kernel's own pieces)
             eng.run_host(rl, qid, a, b, None, None, None)
             s = eng.finish()
             assert_same_result(engine_result(eng, s), want, f"seed {seed} {mode} reso {p.reso}")
@@ -530,13 +532,13 @@ def test_recut_tiles_and_pieces(seed, mode, monkeypatch):
             eng.close()
 
 
-@pytest.mark.parametrize("mode", ["default", "no_recut", "general"])
+@pytest.mark.parametrize("mode", ["default", "deep"])
 def test_groups_of_reads_without_windows_are_still_checked(mode, monkeypatch):
     """A tile of nothing but zero-length reads: its (valid, empty) records pass, a record that needs a window is the
-    COORD error the oracle reports -- from the re-cut tiles of the fast kernel and from the general kernel alike."""
+    COORD error the oracle reports -- whichever kernel the tiles are left to."""
     from raft_amd import engine
-    if mode == "no_recut":
-        monkeypatch.setenv("RAFT_NO_RECUT", "1")
+    if mode == "deep":
+        monkeypatch.setenv("RAFT_DEEP_MIN", "1")
     from raft_testlib import OracleError
     rl = np.concatenate([np.full(300, 0, np.int32), np.array([5000, 0, 0, 7000], np.int32)])
     qid = np.sort(np.concatenate([np.arange(300), [300, 303, 303]])).astype(np.int32)
@@ -545,7 +547,6 @@ def test_groups_of_reads_without_windows_are_still_checked(mode, monkeypatch):
     p = RaftParams(est_cov=1, symmetric_mode=1)
     want = oracle_run(RaftParams(est_cov=1), rl, qid, s_, e_, qid, s_, e_); want["symmetric"] = 1
     eng = engine.Engine(p, device=0)
-    eng.set_tuning(0, False, 1 if mode == "general" else -1)
     eng.run_host(rl, qid, s_, e_, None, None, None)
     assert_same_result(engine_result(eng, eng.finish()), want, "zero-length reads")
     bad = e_.copy(); bad[7] = 3                          # an interval on a read that has no window

@@ -38,12 +38,16 @@ def test_pileup_configurations_agree(si, pi):
     o = make_overlaps(device="cuda:0", **SHAPES[si])
     cols = (o.read_len,) + o.columns()
     ref = None
-    for variant, bucket in ((1, False), (0, False), (5, False), (5, True), (0, True)):   # (5: the wave kernel, the default; 0: round 3's workgroup tiles; 1: the general kernel)
+    from raft_testlib import kernel_mode
+    # (the deep kernel: every tile through the 32-bit side kernel -- the independent implementation the wave kernel is checked against
+    # where the oracle does not finish; rounds 1-5: the workgroup-tile kernels of rounds 1-3)
+    for variant, bucket in (("deep", False), ("wave", False), ("wave", True), ("deep", True)):
         eng = engine.Engine(PARAMS[pi], device=0)
         try:
-            eng.set_tuning(0, bucket, variant)
-            eng.run_device(*cols)
-            s = eng.finish()
+            eng.set_tuning(0, bucket, -1)
+            with kernel_mode(variant):
+                eng.run_device(*cols)
+                s = eng.finish()
             out = {k: v.clone() for k, v in eng.outputs_device().items()}
             tot = (s.symmetric, s.n_bins, s.n_repeats, s.n_cuts, s.n_fragments, s.total_coverage, s.total_repeat_length,
                    s.total_read_length)

@@ -70,15 +70,16 @@ def all_forms(eng, run, want, what, direct=True):
 
 
 @pytest.mark.parametrize("name", sorted(MAN["synthetic"]))
-@pytest.mark.parametrize("variant", [-1, 0, 1])
-def test_golden_cases_delta4(name, variant):
+@pytest.mark.parametrize("variant", ["wave", "deep"])
+def test_golden_cases_delta4(name, variant, monkeypatch):
     from raft_amd import engine
+    if variant == "deep":
+        monkeypatch.setenv("RAFT_DEEP_MIN", "1")          # (every tile through pileup_deep_kernel: raft_testlib.KERNELS)
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     p = RaftParams(**MAN["synthetic"][name]["params"])
     cols = [z[k] for k in ("read_len", "qid", "qs", "qe", "tid", "ts", "te")]
     want = oracle_run(p, *cols)
     eng = engine.Engine(p, device=0)
-    eng.set_tuning(0, False, variant)
 
     def run():
         eng.run_host(*cols)
@@ -285,9 +286,9 @@ def test_pipelined_delta4_errors_and_shuffled_input():
     eng.close(); other.close()
 
 
-def test_delta4_when_the_general_kernel_has_to_take_part(monkeypatch):
-    """The re-cut list overflows (RAFT_EXTRA_CAP=1): the pass is run again with the general kernel, which writes int32 -- the
-    four-bit steps are then made from that array (pack_delta4_kernel) and are the same array."""
+def test_delta4_when_tiles_have_no_slots_of_their_own(monkeypatch):
+    """RAFT_EXTRA_CAP=1: one tile id has slots of its own for the windows it lists, every other tile lists in the shared list (rounds
+    3-5: the re-cut list overflowed and the general kernel took the pass) -- the same encoding."""
     from raft_amd import engine
     from raft_amd.synth import make_overlaps
     o = make_overlaps(n_reads=1200, seed=13, mean_len=90000, sigma=0.9, max_len=1_200_000, coverage=25)

@@ -54,11 +54,13 @@ def grouped_runs(eng, p, rl, qid, qs, qe, off, want, what, with_host=True):
 
 
 @pytest.mark.parametrize("name", sorted(n for n, m in MAN["synthetic"].items() if m["symmetric"] == 1))
-@pytest.mark.parametrize("variant", [-1, 0, 1])
-def test_golden_symmetric_cases_grouped(name, variant):
+@pytest.mark.parametrize("variant", ["wave", "deep"])
+def test_golden_symmetric_cases_grouped(name, variant, monkeypatch):
     """The symmetric golden cases of the reference binary through the grouped entry (when their record stream is a handful
     of sorted runs; a shuffled one has no grouped form and group_offsets says so)."""
     from raft_amd import engine, hostio
+    if variant == "deep":
+        monkeypatch.setenv("RAFT_DEEP_MIN", "1")          # (every tile through pileup_deep_kernel: raft_testlib.KERNELS)
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     p = RaftParams(**MAN["synthetic"][name]["params"])
     cols = [z[k] for k in ("read_len", "qid", "qs", "qe", "tid", "ts", "te")]
@@ -68,7 +70,6 @@ def test_golden_symmetric_cases_grouped(name, variant):
         pytest.skip(f"{name}: the record stream is not a handful of sorted runs")
     want = oracle_run(p, *cols)
     eng = engine.Engine(sym_params(p), device=0)
-    eng.set_tuning(0, False, variant)
     grouped_runs(eng, p, cols[0], cols[1], cols[2], cols[3], off, want, f"{name}/variant {variant}")
     got = result_of(eng, eng.summary)
     for k in exp:

@@ -21,15 +21,17 @@ def decode(codes, exc_index, exc_value):
     return cov
 
 
-def run_width(p, cols, width, variant=-1, force_bucket=False):
-    """Everything a caller can see of one pass in the given output width."""
+def run_width(p, cols, width, variant="wave", force_bucket=False):
+    """Everything a caller can see of one pass in the given output width (variant: raft_testlib.KERNELS)."""
     from raft_amd import engine
+    from raft_testlib import kernel_mode
     eng = engine.Engine(p, device=0)
     try:
-        eng.set_tuning(0, force_bucket, variant)
+        eng.set_tuning(0, force_bucket, -1)
         eng.set_output_width(width)
-        eng.run_host(*cols)
-        s = eng.finish()
+        with kernel_mode(variant):
+            eng.run_host(*cols)
+            s = eng.finish()
         pk = eng.packed_device()
         res = {"summary": s, "packed": None if pk is None else {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in pk.items()}}
         if pk is not None and pk["width"] == 2:
@@ -65,14 +67,13 @@ def check_against(res, want, width, what):
 
 
 @pytest.mark.parametrize("width", [1, 2])
-@pytest.mark.parametrize("mode", ["auto", "bucket", "variant2", "general"])
+@pytest.mark.parametrize("mode", ["auto", "bucket", "deep"])
 def test_config1_in_every_width(width, mode):
     p, cols, exp, meta = load_config1()
-    res = run_width(p, cols, width, variant={"variant2": 0, "general": 1}.get(mode, -1), force_bucket=(mode == "bucket"))
+    res = run_width(p, cols, width, variant="deep" if mode == "deep" else "wave", force_bucket=(mode == "bucket"))
     for k in exp:
         assert np.array_equal(res["fetch"][k], exp[k]), (mode, k)
-    # the general kernel writes int32: no encoding until somebody fetches one
-    assert (res["packed"] is None) == (mode == "general")
+    assert res["packed"] is not None                  # (both kernels write the encoding the context asked for)
     if res["packed"] is not None:
         assert np.array_equal(res["packed"]["cov8"], np.minimum(exp["cov"], 255 if width == 1 else 65535))
 

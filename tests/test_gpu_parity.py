@@ -20,18 +20,21 @@ def eng_mod():
     return engine
 
 
-def run_engine(engine, p, cols, tile_bins=0, force_bucket=False, device_resident=False, variant=-1):
+def run_engine(engine, p, cols, tile_bins=0, force_bucket=False, device_resident=False, variant="wave"):
+    """variant: "wave" (the pass as it comes) or "deep" (every tile through pileup_deep_kernel), raft_testlib.KERNELS."""
+    from raft_testlib import kernel_mode
     eng = engine.Engine(p, device=0)
     try:
-        eng.set_tuning(tile_bins, force_bucket, variant)
-        if device_resident:
-            import torch
-            dev = [torch.as_tensor(np.ascontiguousarray(c, dtype=np.int32)).to("cuda:0") for c in cols]
-            eng.use_torch_stream()
-            eng.run_device(*dev)
-        else:
-            eng.run_host(*cols)
-        s = eng.finish()
+        eng.set_tuning(tile_bins, force_bucket, -1)
+        with kernel_mode(variant):
+            if device_resident:
+                import torch
+                dev = [torch.as_tensor(np.ascontiguousarray(c, dtype=np.int32)).to("cuda:0") for c in cols]
+                eng.use_torch_stream()
+                eng.run_device(*dev)
+            else:
+                eng.run_host(*cols)
+            s = eng.finish()
         got = eng.fetch()
         got.update(symmetric=s.symmetric, high_cov=s.high_cov, total_coverage=s.total_coverage,
                    total_windows=s.total_windows, total_repeat_length=s.total_repeat_length,
@@ -112,12 +115,12 @@ def random_case(seed, n_lo=1, n_hi=60, len_hi=3000, m_hi=600):
 def test_random_small_vs_oracle(eng_mod, seed):
     p, cols = random_case(seed)
     want = oracle_run(p, *cols)
-    for tile, bucket, variant in ((0, False, -1), (32, False, (0, 1, 3, 5)[seed % 4]), (0, True, (0, 1, 3, 5)[(seed + 2) % 4]), (200, False, (0, 1, 3, 5)[(seed + 3) % 4])):
+    for tile, bucket, variant in ((0, False, "wave"), (32, False, ("wave", "deep")[seed % 2]), (0, True, ("wave", "deep")[(seed + 1) % 2]), (200, False, "deep")):
         got, s = run_engine(eng_mod, p, cols, tile_bins=tile, force_bucket=bucket, variant=variant)
         assert_same_result(got, want, f"seed {seed} tile {tile} bucket {bucket} variant {variant}")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 5])
+@pytest.mark.parametrize("variant", ["wave", "deep"])
 @pytest.mark.parametrize("name", ["s60_ultralong", "s200_smallparams", "s300_default", "edge_reads"])
 def test_golden_cases_all_kernel_variants(eng_mod, name, variant):
     p, cols, exp, meta = load_case(name)
@@ -211,7 +214,7 @@ def test_full_size_properties(eng_mod):
     eng.close()
 
 
-# ---- the paths of pileup_fast_kernel (variant 0/2/3) next to the general kernel (variant 1) ---------------------
+# ---- shapes that stress the tile paths (chosen for the workgroup-tile kernels of rounds 1-3; now through the wave and the deep kernel) ----
 
 def _sym_case(rl, qid, s, e, rng):
     """Symmetric record set from query-side intervals: record 1 mirrors record 0, targets are arbitrary other reads."""
@@ -277,7 +280,7 @@ def _fast_kernel_cases():
 FAST_CASES = _fast_kernel_cases()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 5])
+@pytest.mark.parametrize("variant", ["wave", "deep"])
 @pytest.mark.parametrize("name", sorted(FAST_CASES))
 def test_fast_kernel_paths(eng_mod, name, variant):
     p, cols = FAST_CASES[name]

@@ -1,11 +1,11 @@
 """GPU: the wave kernel (pileup_wave.hpp: one wave per tile, 16-bit difference array, workers that cut their own tiles) -- what is
 specific to it, beyond the parity, configuration and consistency suites that run with it as the default pileup:
 
-* against the int32 kernels (variants 0 and 1) on shapes that stress its tile cutting: very many short reads (63 per tile),
-  reads longer than a tile (pieces), dense stretches (tiles shrink to the reads whose records are in the slots; records
-  behind the slots are streamed), a stream of four runs (columns only), reads without records or windows;
-* the 16-bit bound: a tile with 2^15 or more intervals refutes the pass (kErrDeep) and the result comes from the int32
-  kernels -- same arrays as the oracle;
+* against the 32-bit side kernel (pileup_deep.hpp, every tile sent its way) on shapes that stress its tile cutting: very many short
+  reads (63 per tile), reads longer than a tile (pieces), dense stretches (tiles shrink to the reads whose records are in the
+  slots; records behind the slots are streamed), a stream of four runs (columns only), reads without records or windows;
+* the 16-bit bound: a tile with 2^15 or more intervals is left to pileup_deep_kernel in the same pass (tests/test_gpu_deep.py) --
+  same arrays as the oracle;
 * cut points written by the pass itself (raft_hip_set_emit_cuts) or by the first fetch: the same;
 * the host pipeline deriving offsets and window records from the plain columns chunk by chunk (raft_hip_run_multi,
   symmetric_mode = 1): the oracle's arrays, and every input the derivation gives up on (ids out of place, a negative
@@ -38,7 +38,7 @@ SHAPES = [
 
 @pytest.mark.parametrize("si", range(len(SHAPES)))
 @pytest.mark.parametrize("reso", [50, 7])
-def test_wave_kernel_equals_int32_kernels(si, reso):
+def test_wave_kernel_equals_deep_kernel(si, reso):
     import torch
     from raft_amd import engine
     from raft_amd.synth import make_overlaps
@@ -48,12 +48,14 @@ def test_wave_kernel_equals_int32_kernels(si, reso):
     p = RaftParams(est_cov=int(SHAPES[si]["coverage"]), reso=reso)
     cols = (o.read_len,) + o.columns()
     ref = None
-    for variant, bucket in ((0, False), (5, False), (5, True), (1, False)):
+    from raft_testlib import kernel_mode
+    for variant, bucket in (("deep", False), ("wave", False), ("wave", True)):
         eng = engine.Engine(p, device=0)
         try:
-            eng.set_tuning(0, bucket, variant)
-            eng.run_device(*cols)
-            s = eng.finish()
+            eng.set_tuning(0, bucket, -1)
+            with kernel_mode(variant):
+                eng.run_device(*cols)
+                s = eng.finish()
             out = {k: v.clone() for k, v in eng.outputs_device().items()}
             tot = (s.symmetric, s.n_bins, s.n_repeats, s.n_cuts, s.n_fragments, s.total_coverage, s.total_repeat_length, s.total_read_length)
         finally:
@@ -104,9 +106,9 @@ def test_wave_kernel_four_runs_and_window_records():
     eng.close()
 
 
-def test_a_tile_too_deep_for_sixteen_bits_falls_back_to_the_int32_kernels():
-    """40,000 intervals on one read: the wave kernel's tile refutes the pass (kErrDeep) and raft_hip_finish runs it again with
-    the int32 kernels -- coverage 40,000 in the middle of the read, as the oracle has it."""
+def test_a_tile_too_deep_for_sixteen_bits_goes_to_the_deep_kernel():
+    """40,000 intervals on one read: the wave kernel lists the tile and pileup_deep_kernel piles it up in the same pass -- coverage
+    40,000 in the middle of the read, as the oracle has it."""
     from raft_amd import engine
     rng = np.random.default_rng(9)
     rl = np.array([30000, 12000, 50000, 8000], np.int32)
@@ -121,17 +123,15 @@ def test_a_tile_too_deep_for_sixteen_bits_falls_back_to_the_int32_kernels():
     want["symmetric"] = 1
     assert want["cov"].max() >= 32768
     eng = engine.Engine(p, device=0)
-    eng.set_tuning(0, False, 5)
-    for _ in range(2):                                   # (the context is itself again after the fallback)
+    for _ in range(2):
         got, s = engine_result(eng, (rl, qid, qs, qe))
         assert_same_result(got, want, "deep tile")
     eng.close()
 
 
-def test_a_deep_tile_whose_int32_rerun_overflows_the_exception_list():
-    """kErrDeep sends the pass to the int32 kernels; with one byte per window that re-run lists more windows at
-    or above 255 than the default list holds (max(4096, B / 64)), and the re-run for THAT must stay with the int32 kernels --
-    it used to return to the wave kernel, meet the deep tile again and end in ERR_DEVICE."""
+def test_a_deep_tile_that_overflows_the_exception_list():
+    """A deep pile in one byte per window lists more windows at or above 255 than the default list holds (max(4096, B / 64)): the
+    pass is run again with room, deep tiles and all (ADVICE r04 was about this pair of re-runs on the int32 kernels)."""
     from test_gpu_packed_output import check_against, run_width
     rng = np.random.default_rng(11)
     rl = np.array([30000, 12000, 400000, 8000], np.int32)          # read 2: 8000 windows, most of them 40,000 deep
@@ -147,7 +147,7 @@ def test_a_deep_tile_whose_int32_rerun_overflows_the_exception_list():
     want["symmetric"] = 1
     assert want["cov"].max() >= 32768 and int((want["cov"] >= 255).sum()) > 4096
     for width in (1, 2):
-        res = run_width(p, cols, width, variant=5)
+        res = run_width(p, cols, width)
         check_against(res, want, width, f"deep tile, width {width}")
 
 

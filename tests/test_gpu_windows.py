@@ -57,11 +57,13 @@ def window_runs(eng, p, rl, off, win, want, what, widths=(4, 1, 2), with_host=Tr
 
 
 @pytest.mark.parametrize("name", sorted(n for n, m in MAN["synthetic"].items() if m["symmetric"] == 1))
-@pytest.mark.parametrize("variant", [-1, 0, 1])
-def test_golden_symmetric_cases_windows(name, variant):
-    """The symmetric golden cases of the reference binary as window records (variant -1: the kernel's own instantiation;
-    the others: unpacked on the device first)."""
+@pytest.mark.parametrize("variant", ["wave", "deep"])
+def test_golden_symmetric_cases_windows(name, variant, monkeypatch):
+    """The symmetric golden cases of the reference binary as window records, through the wave kernel's window-record instantiation
+    and with every tile through pileup_deep_kernel (which reads the same records: raft_testlib.KERNELS)."""
     from raft_amd import engine, hostio
+    if variant == "deep":
+        monkeypatch.setenv("RAFT_DEEP_MIN", "1")
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     p = RaftParams(**MAN["synthetic"][name]["params"])
     cols = [z[k] for k in ("read_len", "qid", "qs", "qe", "tid", "ts", "te")]
@@ -75,8 +77,7 @@ def test_golden_symmetric_cases_windows(name, variant):
         pytest.skip(f"{name}: window indices beyond 16 bits -- the coordinate columns are the caller's form")
     want = oracle_run(p, *cols)
     eng = engine.Engine(sym_params(p), device=0)
-    eng.set_tuning(0, False, variant)
-    window_runs(eng, p, cols[0], off, win, want, f"{name}/variant {variant}", widths=(4, 1) if variant == -1 else (4,))
+    window_runs(eng, p, cols[0], off, win, want, f"{name}/variant {variant}", widths=(4, 1))
     got = result_of(eng, eng.summary)
     for k in exp:
         assert np.array_equal(got[k], exp[k]), (name, k)
@@ -158,13 +159,13 @@ def test_errors_of_window_records():
     # (a) a record reaching past the last window of its read: same code and record index as from the coordinate entries
     be = cols[3].copy(); be[4321] = cols[0][cols[1][4321]] + 7000
     wbad = hostio.pack_windows(cols[2], be, p.reso)
-    for variant in (-1, 0, 1):
-        eng.set_tuning(0, False, variant)
-        for hint in (B, -1):
-            with pytest.raises(engine.RaftError) as e1:
-                eng.run_device_windows(d_rl, d_off, t(wbad.view(np.int32)), n_bins=hint); eng.finish()
-            assert e1.value.code == engine.ERR_COORD and e1.value.index == 4321, (variant, hint)
-    eng.set_tuning(0, False, -1)
+    from raft_testlib import kernel_mode
+    for variant in ("wave", "deep"):
+        with kernel_mode(variant):
+            for hint in (B, -1):
+                with pytest.raises(engine.RaftError) as e1:
+                    eng.run_device_windows(d_rl, d_off, t(wbad.view(np.int32)), n_bins=hint); eng.finish()
+                assert e1.value.code == engine.ERR_COORD and e1.value.index == 4321, (variant, hint)
     with pytest.raises(engine.RaftError) as e2:
         eng.run_host(cols[0], cols[1], cols[2], be, None, None, None); eng.finish()
     assert e2.value.code == engine.ERR_COORD and e2.value.index == 4321
@@ -211,9 +212,9 @@ def test_errors_of_window_records():
     eng.close()
 
 
-def test_more_extra_tiles_than_room_falls_back(monkeypatch):
-    """The re-cut list overflows (RAFT_EXTRA_CAP=1): the pass is run again with the general kernel, which takes coordinate
-    columns -- the window records are unpacked for it."""
+def test_window_records_when_tiles_have_no_slots_of_their_own(monkeypatch):
+    """RAFT_EXTRA_CAP=1 (rounds 3-5: the re-cut list overflowed and the general kernel took the pass; now: tile ids without slots of
+    their own in a four-bit pass) on a long-read set as window records: the oracle's arrays."""
     from raft_amd import engine, hostio
     from raft_amd.synth import make_overlaps
     o = make_overlaps(n_reads=1200, seed=13, mean_len=90000, sigma=0.9, max_len=1_200_000, coverage=25)

@@ -9,7 +9,7 @@ rocm-smi --showmemorypartition --showcomputepartition --showperflevel --showmaxp
 # 1. the headline line (default bench), rocprofv3 kernel stats of the same command, PMC traffic (FETCH_SIZE / WRITE_SIZE in passes of their own)
 tools/profile_round.sh $TAG > gpurun_out/$TAG/profile_round.log 2>&1
 # 2. SQ counters of the dominant kernel, per-dispatch timeline of a pass
-tools/pmc_probe.sh -1 3300000 > gpurun_out/$TAG/sq_counters.txt 2>&1
+tools/pmc_probe.sh 3300000 > gpurun_out/$TAG/sq_counters.txt 2>&1
 tools/pass_timeline.sh ${TAG}_tl > gpurun_out/$TAG/pass_timeline.txt 2>&1
 tools/pass_timeline.sh ${TAG}_tlg --input grouped > gpurun_out/$TAG/pass_timeline_grouped.txt 2>&1
 tools/pass_timeline.sh ${TAG}_tlw --input windows --cov-width 1 > gpurun_out/$TAG/pass_timeline_windows_w1.txt 2>&1
@@ -27,7 +27,6 @@ if [ -f raft_amd/lib/libraft_hip_diag.so ]; then
     echo "# six columns, a byte per window out"; PROBE_WIDTH=1 python tools/mode_probe.py RAFT_WAVE_MODE=0,1,2,4,8,14 3
     echo "# window records, a byte per window out"; PROBE_FORM=windows PROBE_WIDTH=1 python tools/mode_probe.py RAFT_WAVE_MODE=0,1,2,4,8,14 3
     echo "# workers (of 4096)"; python tools/mode_probe.py RAFT_WAVE_WAVES=4096,3072,2048,1024 2 ) 2>&1 | grep -E "RAFT_|^#" > gpurun_out/$TAG/mode_probe.txt
-  RAFT_VMM_SPREAD=1 python tools/placement_probe2.py 2>&1 | grep -v amdgpu > gpurun_out/$TAG/placement_probe2.txt
   unset RAFT_HIP_LIB
 fi
 # 4. other workloads and forms: configs[4] (ultralong), configs[1] (50 k reads), an eighth of configs[2] (one of eight GPUs in configs[3]),
@@ -44,7 +43,6 @@ tools/profile_round.sh ${TAG}_ul $B --workload ultralong > gpurun_out/$TAG/profi
 python bench.py $B --shuffle > gpurun_out/$TAG/bench_shuffle.json 2> gpurun_out/$TAG/bench_shuffle.err
 python bench.py $B --nonsym > gpurun_out/$TAG/bench_nonsym.json 2> gpurun_out/$TAG/bench_nonsym.err
 tools/pass_timeline.sh ${TAG}_tlsh --shuffle > gpurun_out/$TAG/pass_timeline_shuffle.txt 2>&1
-python bench.py $B --variant 0 > gpurun_out/$TAG/bench_variant0.json 2> gpurun_out/$TAG/bench_variant0.err
 # 5. host to host: the pipeline's stage clock with the engine deriving offsets and window records itself, and with prepared input
 python tools/pipe_trace.py 3300000 0 columns_d4 2> gpurun_out/$TAG/pipeline_trace_columns_d4.txt
 python tools/pipe_trace.py 3300000 0 windows_d4 2> gpurun_out/$TAG/pipeline_trace_windows_d4.txt
