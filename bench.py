@@ -78,7 +78,7 @@ def kernel_source_hash() -> str:
     """Identifies the kernels a counter profile belongs to (profiles/pmc_traffic.json goes stale with them)."""
     h = hashlib.sha1()
     for f in ("pileup_wave.hpp", "wave_launch.hip", "wave_launch.hpp", "pileup_deep.hpp", "pileup.hpp", "engine.hip", "bucket.hpp", "finalize.hpp", "wave.hpp",
-              "device_scan.hpp", "pack.hpp", "sort_pairs.hpp"):
+              "device_scan.hpp", "pack.hpp", "sort_pairs.hpp", "raft_types.hpp", "engine_ctx.hpp"):
         with open(os.path.join(ROOT, "raft_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

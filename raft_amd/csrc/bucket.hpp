@@ -23,15 +23,6 @@
 
 namespace raft {
 
-struct InspectOut {            // device words written by inspect_kernel
-    int32_t sym_found;         // a record i >= 1 mirrors record 0 (chop.hpp:175-184)
-    int32_t n_desc;            // positions i with qid[i] < qid[i-1]
-    int32_t err_flags;
-    int32_t pad;
-    long long err_index;
-    long long desc_pos[kMaxSeg]; // first kMaxSeg descent positions (unordered)
-};
-
 // One pass over qid (and over the other columns only where qid matches tid[0]): 16-byte loads, four records
 // per lane, so that the pass streams at HBM rate (it reads 4 B per record of the 12-24 B the pileup reads).
 // (Measured and dropped: writing a table "first record of every read in every run" from this pass, to turn the tile
@@ -223,7 +214,7 @@ struct PrepPost {
 // (a PAF concatenated from many files; the intervals a rank of a pre-split job receives from its peers, two runs each).
 // With the offsets at hand this needs no histogram and no atomics: read r's records of run j go behind its records of the
 // runs before, at sum_j' (off_j'[r] - off_j'[0]) + sum_{j' < j} count_j'(r).  24 bytes of traffic per record.
-constexpr int kMaxRuns = 16;
+// (kMaxRuns: raft_types.hpp)
 
 __global__ __launch_bounds__(256) void check_offsets_kernel(int32_t n_reads, int32_t n_runs, const long long *off, long long stride,
                                                             long long n_rec, int32_t *err_flags, long long *err_index)
@@ -513,7 +504,7 @@ __global__ __launch_bounds__(256) void fill_gaps_kernel(const GapList *__restric
 // (pileup_wave.hpp IN = 1: a word per record, the reads' offsets).  A side whose windows do not fit 16 bits raises kErrWide and the
 // pass is run again with the coordinate pairs above; a negative coordinate is reported here (the record's index), an interval past
 // its read's last window by the pileup kernel (the index into the bucketed array), as on the coordinate route.
-constexpr int kErrWide = 1 << 10;
+// (kErrWide: raft_types.hpp)
 __device__ __forceinline__ unsigned long long side_item(int rid, int s, int e, int reso, bool &neg, bool &wide)
 {
     neg = neg || (s | e) < 0;

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, lon
         long long tot;
         long long run = (FUSED ? base[k] : partials[(long long)blockIdx.x * K + k]) + block_excl_scan64<kScanThreads>(acc[k], &tot, lds);
         first[k] = run; grand[k] = FUSED ? base[k] + tot : 0;
-        if (FUSED && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { totals[k] = base[k] + tot; out.p[k][n] = base[k] + tot; }
+        if (FUSED && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { totals[k] = base[k] + tot; if (out.p[k]) out.p[k][n] = base[k] + tot; }
+        if (!out.p[k]) continue;                     // (a sum whose total is all anybody wants: no array written)
 #pragma unroll
         for (int j = 0; j < kScanItems; ++j) {
             stage[threadIdx.x * kScanItems + j] = run;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Loader ld, lon
     }
     if (!FUSED && blockIdx.x == 0 && threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) out.p[k][n] = totals[k];
+        for (int k = 0; k < K; ++k) if (out.p[k]) out.p[k][n] = totals[k];
     }
     // the elements once more, for the hook: where each begins (all K sums) and what it holds
 #pragma unroll

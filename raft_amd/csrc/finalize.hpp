@@ -10,61 +10,6 @@
 
 namespace raft {
 
-// n / d for 0 <= n < 2^31 and d >= 1 without a hardware divide (a 32-bit signed division is ~35 instructions; the sweeps
-// below do two per repeat and fragment, and the longest read's thread is what a long-read set waits for): with
-// L = ceil(log2 d) and m = floor(2^(31+L) / d) + 1 (< 2^32), n / d == mulhi(n, m) >> (L - 1)  (the identity pileup.hpp's
-// win_of uses for the windows)
-struct FastDiv {
-    uint32_t magic;
-    int32_t shift;                        // -1: d == 1
-};
-inline FastDiv make_fast_div(int d)
-{
-    FastDiv f{0u, -1};
-    if (d > 1) {
-        int L = 0;
-        while ((1ull << L) < (unsigned long long)d) ++L;
-        f.magic = (uint32_t)((1ull << (31 + L)) / (unsigned)d + 1ull);
-        f.shift = L - 1;
-    }
-    return f;
-}
-__device__ __forceinline__ int fdiv(const FastDiv &f, int n) { return f.shift < 0 ? n : (int)(__umulhi((unsigned)n, f.magic) >> f.shift); }
-
-struct FinalizeArgs {
-    int32_t n_reads;
-    const int32_t *read_len;
-    const long long *rep_res_off;
-    const int32_t *rep_cnt;
-    int32_t *raw_key, *raw_s, *raw_e;     // sorted in place by finalize_count_kernel
-    int32_t interval_length, div, overlap_length;
-    FastDiv by_L, by_div, by_reso;        // interval_length, div, reso as divisors
-    // reads with more than long_windows windows were piled up in pieces (pileup_fast.hpp emit_piece_run): their raw
-    // records are unflanked [start, end) runs per piece, to be joined, tested, flanked and clamped here
-    int32_t long_windows, reso, repeat_length, flank;
-    int32_t *rep_cnt_rw;                  // (rep_cnt, writable: the joined count replaces the pieces' count)
-    unsigned long long *total_repeat;     // repeat.hpp:127,152 for those reads
-    int32_t *cut_cnt, *frag_cnt;          // [n_reads]
-    const long long *rep_off, *cut_off, *frag_off; // [n_reads+1] (fill kernel)
-    int32_t *rep_s, *rep_e, *cuts, *frag_read, *frag_begin, *frag_end;
-    int32_t *err_flags;
-    long long *err_index;
-    // the tail's offsets without a scan of their own (round 6): finalize_count_kernel leaves every workgroup's sums of (repeats, cut
-    // points, fragments, read length) in tail_part[]; tail_prefix_kernel -- ONE workgroup -- turns them into where every workgroup's
-    // reads begin, and into the totals the host is handed; finalize_fill_kernel scans its 256 reads in the workgroup and writes
-    // rep_off / cut_off / frag_off itself; publish_ctrl_kernel hands the control block over.  count -> prefix -> fill -> publish:
-    // four launches, the middle one over N / 256 words, where there were five with two passes over the reads' counts and a third over
-    // their lengths (count, scan_partials, scan_apply, fill, totals).
-    // (Measured and dropped on the way, profiles/r06_tail_parts.txt: TWO launches, what crosses workgroups inside a kernel travelling in
-    // device-scope atomics -- per wave: non-returning adds into shared sums cost the count kernel 35 us of a pass over 3.3 M reads, a
-    // returning one per wave the fill kernel 55 us; per workgroup of 1024 reads: fill 206 us against 100, its sixteen waves waiting
-    // for each other at the barrier their common sums need.)
-    long long *tail_part;                 // [4][tail_blocks]
-    long long *tail_prefix;               // [3][tail_blocks]
-    int32_t tail_blocks;
-    long long *rep_off_w, *cut_off_w, *frag_off_w;   // (the offset arrays, writable)
-};
-
 __device__ __forceinline__ void swap3(int32_t *k, int32_t *s, int32_t *e, long long i, long long j)
 {
     int32_t t;
@@ -376,20 +321,6 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(FinalizeArgs a)
     if (threadIdx.x < 4) a.tail_part[(long long)threadIdx.x * a.tail_blocks + blockIdx.x] = scr[threadIdx.x][0] + scr[threadIdx.x][1] + scr[threadIdx.x][2] + scr[threadIdx.x][3];
 }
 
-// What the pass hands the host at its end: the sums of the pileup kernel's workers, the control block, the page-locked block the
-// host looks at.
-struct TailPublish {
-    long long n_tiles;                    // workers of the pileup kernel(s): two sums each in tile_sums
-    const long long *tile_sums;
-    unsigned long long *totals;           // Ctrl::totals: coverage, repeat bp, read length
-    const long long *bucket_off;          // general bucketing: its offsets (the true interval count at [n_reads]), else nullptr
-    long long *tails;                     // Ctrl::out_totals
-    const long long *ctrl_words;
-    int n_ctrl_words;
-    long long *host_block;
-    long long pass_seq;
-};
-
 // tail_part -> tail_prefix (exclusive) and the totals.  A workgroup per 1024 entries (N / 256 entries per array: 13 k for 3.3 M
 // reads): it adds up the entries before its own by itself -- a few KB from L2, all workgroups at once -- and scans its 1024.  The
 // last one also adds up what totals_kernel added up until round 5: the pileup workers' sums, the reads' lengths (the count kernel's
@@ -499,36 +430,6 @@ __device__ __forceinline__ void finalize_fill_one(const FinalizeArgs &a, int r, 
     a.frag_end[fo + nf - 1] = len;                // the last kept marker is the read's end
 }
 
-// What the host reads back without the runtime's wait travels in STAMPED LINES: 64 bytes of the context's page-locked block hold six
-// 8-byte data words and, in words 3 and 7, the number of the hand-over; one store instruction of the wave writes all lines, and a
-// line (at the least each 32-byte half of it) arrives whole.  The host takes a line when both stamps are the number it waits for.
-// (Round 4's form -- the words, a system-scope fence, then the number in a word of its own -- is NOT safe: stores to host memory
-// are posted writes that may pass each other.  tools/r05/s27.sh: the sizes hand-over read that way gave a stale window count in
-// 1 of 25 runs of the parity tests; none in 25 with the runtime's wait.)
-constexpr int kStampData = 6;
-__host__ __device__ constexpr int stamped_lines(int n_words) { return (n_words + kStampData - 1) / kStampData; }
-// lane t of one wave (0 .. 63) stores its word of the stamped form of src(0 .. n_words - 1); n_words <= 48
-template <class Src>
-__device__ __forceinline__ void publish_stamped(long long *host, Src src, int n_words, long long seq, int t)
-{
-    const int line = t >> 3, pos = t & 7;
-    long long v = seq;
-    if ((pos & 3) != 3) {
-        const int idx = line * kStampData + (pos < 3 ? pos : pos - 1);
-        v = idx < n_words ? src(idx) : 0;
-    }
-    if (line < stamped_lines(n_words)) host[t] = v;
-}
-inline bool stamped_seen(const volatile long long *h, int n_words, long long seq)
-{
-    for (int line = 0; line < stamped_lines(n_words); ++line)
-        if (h[line * 8 + 3] != seq || h[line * 8 + 7] != seq) return false;
-    return true;
-}
-inline void unstamp(const volatile long long *h, int n_words, long long *out)
-{
-    for (int i = 0; i < n_words; ++i) { const int pos = i % kStampData; out[i] = h[(i / kStampData) * 8 + (pos < 3 ? pos : pos + 1)]; }
-}
 // CUTS: the pass also writes the cut points themselves (chop.hpp:225-246 final_stars) -- the default of a
 // context (raft_hip_set_emit_cuts); the host pipelines, whose outputs hold no cut points, leave them to finalize_cuts_kernel.
 // Round 6: the kernel makes the three offset arrays itself (see FinalizeArgs::tail_part), adds up what totals_kernel added up and

@@ -11,6 +11,7 @@
 // to 1 or 2 (raft_hip_set_output_width) has the pileup kernel write it directly and never holds the int32 array at all
 // unless asked for it (unpack_cov_kernel).
 #pragma once
+#include "raft_types.hpp"
 #include "wave.hpp"
 
 namespace raft {
@@ -110,11 +111,10 @@ __global__ __launch_bounds__(256) void scatter_exceptions_kernel(const long long
 //     nib[w]  (byte w >> 1, low nibble = even w)   step + 8 for a step cov[w] - cov[w-1] in [-7, 7] (cov[-1] = 0), 0 = escape
 //     exceptions (w, cov[w])                        the ABSOLUTE value of every escaped window, ascending when handed out
 //     anchor[k] = cov[1024 k - 1]  (anchor[0] = 0)  where a decoder may start: blocks of 1024 windows decode independently
-// The pileup kernel writes it directly (pileup_fast.hpp OW = kCovDelta4): a step is the LDS difference array's own value,
+// The pileup kernel writes it directly (pileup_wave.hpp OW = kCovDelta4): a step is the LDS difference array's own value,
 // except at a tile's first window, whose predecessor another workgroup holds -- that window is always escaped.
 // Decoding (raft_host_unpack_coverage_d4 / unpack_delta4_kernel): v = anchor[k]; per window v = escape ? listed value : v + step.
-constexpr int kCovDelta4 = 8;     // width code of the encoding (raft_hip_set_output_width, raft_hip_host_outputs::cov_width)
-constexpr int kD4Block = 1024;
+// (kCovDelta4, kD4Block: raft_types.hpp)
 
 struct Delta4Out {
     uint8_t *nib;                 // ceil(B / 2) bytes (+ padding to a dword)

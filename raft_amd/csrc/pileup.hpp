@@ -15,125 +15,9 @@
 // Algorithmic bytes per launch: 12*I + 4*B + 4*N + 8*R.
 #pragma once
 #include "wave.hpp"
+#include "raft_types.hpp"
 
 namespace raft {
-
-constexpr int kMaxSeg = 4;   // sorted runs of the record stream the fast path accepts (hifiasm cis+trans = 2)
-
-enum : int {
-    kErrReadId = 1 << 0,
-    kErrCoord = 1 << 1,
-    kErrFragment = 1 << 2,
-    kErrInternal = 1 << 3,
-    kErrLen = 1 << 4,
-    kErrExtra = 1 << 6,         // (rounds 1-3: the list of re-cut tiles overflowed; no kernel raises it any more)
-    kErrOrder = 1 << 5,         // a pass that trusted a sampled guess of the sorted runs met a record that refutes it (not an
-                               // error of the input: the engine runs the pass again after looking at every record)
-    kErrHint = 1 << 7,          // the number of windows the caller announced (a pass without a host wait is sized by it) is not
-                               // what the read lengths give: every later kernel of the pass returns at once, the engine
-                               // runs the pass again with the host wait
-    kErrGroup = 1 << 8,         // grouped input (raft_hip_run_device_grouped): the per-read record offsets step back or do not
-                               // chain from 0 to n_rec
-    kErrStop = kErrHint | kErrGroup   // what a pass without a host wait cannot go on after: its later kernels return at once
-};
-
-// Grouped input (include/raft_hip.h raft_hip_run_device_grouped): the record stream is n_runs runs sorted by query id and
-// the caller says where each read's records begin in each run -- off[s * stride + r] (+ adj[s]: a chunk of the host
-// pipelines uploads slices of the caller's arrays and of its record columns) is the first record of read r in run s,
-// entry n_reads closes the run.  Tile cuts are then look-ups, not searches.
-struct GroupedOff {
-    const long long *off;      // nullptr: not grouped
-    long long stride;          // n_reads + 1
-    long long adj[kMaxSeg];
-    __device__ __forceinline__ long long at(int s, long long r) const { return off[s * stride + r] + adj[s]; }
-};
-
-constexpr int kExcPerTile = 16;   // delta4: listed windows a tile keeps in slots of its own (a HiFi tile lists ~12: its first window, large steps at read boundaries)
-
-struct SegStarts { long long start[kMaxSeg + 1]; int32_t n_seg; };
-
-// Boundaries of the quantum tiles (ranges of reads a worker of pileup_wave_kernel draws): boundary k says where range k begins --
-// its first read, that read's first record in every sorted run, its first window; entry n_tiles closes the last range.
-struct TileCut {
-    int32_t r_lo;              // first read of tile k
-    int32_t flags;             // (unused)
-    int32_t iv_lo[kMaxSeg];    // first interval of tile k in segment s (absolute index, < 2^31 checked by the host)
-    long long g_lo;            // first window of tile k in cov[]
-};
-static_assert(sizeof(TileCut) == 32, "a boundary is eight words, loaded by eight lanes");
-enum : int {
-    kCutPiece = 2,             // (a wave tile's own flag) the tile is a piece of ONE read longer than the LDS array
-};
-
-struct PileupArgs {
-    // intervals: sorted by read id inside each of n_seg segments
-    const int32_t *iv_rid, *iv_s, *iv_e;
-    // ... or "window records" (pileup_fast.hpp IN = 1): one word per record, first window | one past the last << 16, no read
-    // ids -- the reads' records are where the caller's offsets (grp) say
-    const uint32_t *iv_w;
-    GroupedOff grp;
-    int32_t n_seg;
-    // tiles and reads
-    long long n_tiles;            // ranges tile_desc_kernel cut (boundaries 0 .. n_tiles)
-    const int32_t *read_len;
-    const long long *cov_off;   // [n_reads+1]
-    int32_t n_reads;
-    // params
-    int32_t reso, high_cov, repeat_length, flank;
-    uint32_t div_magic;           // n / reso == mulhi(n, div_magic) >> div_shift for 0 <= n < 2^31 (reso > 1)
-    int32_t div_shift;            // -1: reso == 1
-    // outputs
-    int32_t *cov;
-    // pileup_fast_kernel instantiated with OW = 1 or 2 writes the transfer encoding of cov[] instead (pack.hpp: OW bytes per
-    // window, min(cov, 255 / 65535), plus the list of the windows at or above that limit) and leaves `cov` alone
-    void *covp;
-    int32_t *cov_anchor;          // OW = 8 (pack.hpp kCovDelta4, four bits per window): cov[1024 k - 1] per block of 1024 windows
-    int32_t d4_shift;             //     ... blocks counted from d4_shift windows before this pass's first (a chunk of a larger array: multiple of 4, < 1024)
-    long long *exc_pidx;          // ... and the windows it lists, kExcPerTile slots per tile (regular tiles, then the extra ones)
-    int32_t *exc_pval;
-    int32_t *exc_tile_n;          //     how many of its slots a tile used (zeroed before the pass)
-    unsigned long long *n_exc;    // windows at or above the limit (counted even when the list is full)
-    long long exc_cap;
-    long long *exc_idx;
-    int32_t *exc_val;
-    const long long *rep_res_off; // [n_reads+1] reserved slots for raw repeats
-    int32_t *rep_cnt;             // [n_reads], zeroed
-    int32_t *raw_key, *raw_s, *raw_e;
-    long long *block_sums;        // [2*gridDim.x]: sum of coverage, sum of unclamped repeat bp
-    int32_t *err_flags;           // device word, OR of kErr*
-    long long *err_index;         // first offending interval index (min)
-    int32_t *tile_counter;        // the ranges are handed out through these counters (pileup_wave.hpp next_range; zeroed before the pass)
-    int32_t tile_batch;           // bits 24..28: counters in use - 1; bits 20..23: diagnostic switches (-DRAFT_WAVE_DIAG builds)
-    int32_t piece_w;              // delta4: tile ids below this have slots of their own for the windows they list
-    int32_t *slow_counter;        // delta4: the counter those tile ids are drawn from
-    // tiles too deep for the wave kernel's 16-bit difference array (pileup_deep.hpp): listed by it, piled up by pileup_deep_kernel
-    void *deep_list;              // DeepTile[deep_cap]
-    int32_t *n_deep;              // device count (may exceed deep_cap: kErrDeep, the pass is run again with room)
-    int32_t deep_cap, deep_min;   // deep_min: intervals on a tile from which it goes that way (2^15; tests lower it)
-    unsigned long long *deep_rep_total;   // where pileup_deep_kernel adds its tiles' unclamped repeat bases (Ctrl::totals[1])
-};
-
-// Coarse index of the record stream (bucket.hpp guess_runs_kernel writes it, tile_desc_kernel reads it): the read id of
-// every 2^sh-th record and of the last one, with sh the smallest shift that leaves at most kSamples strides.
-constexpr int kGuessBlocks = 1024;                         // x 256 threads: one sample per thread (64 blocks, 16 k samples until round 5:
-                                                           // tile_desc_kernel's time is the lines its probes BEHIND the samples pull in)
-constexpr int kSamples = kGuessBlocks * 256;
-__host__ __device__ __forceinline__ int sample_shift(long long n)
-{
-    int sh = 0;
-    while (((n - 1) >> sh) >= kSamples) ++sh;
-    return sh;
-}
-// samples j = 0 .. n_samples - 1 sit at min(j << sh, n - 1)
-__host__ __device__ __forceinline__ long long n_samples(long long n, int sh) { return ((n - 1) >> sh) + 2; }
-__host__ __device__ __forceinline__ long long sample_pos(long long j, long long n, int sh)
-{
-    const long long p = j << sh;
-    return p < n - 1 ? p : n - 1;
-}
-
-constexpr int kRunQ = 16; // parked runs per wave and window before falling back to immediate emission
-constexpr int kNone = -1;
 
 // window index of base n (0 <= n < 2^31): n / reso without a hardware divide
 __device__ __forceinline__ unsigned win_of(const PileupArgs &a, unsigned n)
@@ -167,21 +51,6 @@ __device__ __forceinline__ long long lower_bound_rid(const int32_t *iv_rid, long
     }
     return lo;
 }
-
-// the sorted runs of the record stream as its samples show them (bucket.hpp guess_runs_kernel)
-struct GuessOut {
-    int32_t n_desc, pad;
-    long long desc_pos[kMaxSeg];
-};
-
-// What a pass that assumes a symmetric PAF (engine.hip run_pass, detecting contexts) still has to find: the mirror of
-// record 0 (chop.hpp:171-184).  It can only sit among the records of record 0's target read, and where those lie in each
-// sorted run is one more pair of the boundary searches tile_desc_kernel does anyway: the thread behind the closing
-// boundary searches for "tile" [tid[0], tid[0] + 1) and its wave then looks at those few records.
-struct MirrorArgs {
-    const int32_t *qs, *qe, *tid, *ts, *te;   // the record columns besides the id column the kernel searches (tid == nullptr: no search)
-    int32_t *found;                          // set to 1 when a record i > 0 mirrors record 0
-};
 
 // One thread per range boundary (the boundaries a worker of pileup_wave_kernel draws: TileCut): the boundary's first read, that
 // read's first window, and its first record in every sorted run -- looked up in the caller's offsets (grouped input) or in the

@@ -31,19 +31,10 @@
 
 namespace raft {
 
-constexpr int kErrDeep = 1 << 9;     // more tiles too deep for 16-bit coverage than the list for pileup_deep_kernel holds: the pass again, with room
-
-struct DeepTile {                    // what this kernel knows about a tile when it decides not to pile it up (pileup_deep.hpp does)
-    int32_t r_a, nr;                 // reads [r_a, r_a + nr)
-    int32_t piece, nwin;             // kCutPiece: ONE read longer than a tile, this is a piece of it; windows of the tile
-    long long g_lo;                  // first window of the tile in cov[]
-    int32_t lo[kMaxSeg], cnt[kMaxSeg];   // its records: [lo, lo + cnt) of every sorted run
-};
-
 // The empty difference array: the LOW half of every dword is biased by 0x8000, so that a -1 landing on an even slot never
 // borrows from the odd slot above it (the ds_add is a 32-bit add); one xor per dword takes the bias off again.
 constexpr uint32_t kZero = 0x00008000u;
-constexpr int kCtrStride = (4096 + 256) / 4;   // int32 words between two hand-out counters: another 4 KiB block AND another 256-byte slot of it
+// (kCtrStride: raft_types.hpp)
 constexpr int kWaveMaxReads = 63;    // reads per wave tile: lane j <-> read r_a + j, entry nr closes the table (nr + 1 <= 64)
 
 template <int SLOTS>
