@@ -505,44 +505,63 @@ __global__ __launch_bounds__(256) void fill_gaps_kernel(const GapList *__restric
 // pass is run again with the coordinate pairs above; a negative coordinate is reported here (the record's index), an interval past
 // its read's last window by the pileup kernel (the index into the bucketed array), as on the coordinate route.
 // (kErrWide: raft_types.hpp)
-__device__ __forceinline__ unsigned long long side_item(int rid, int s, int e, int reso, bool &neg, bool &wide)
+__device__ __forceinline__ unsigned long long side_item(int rid, int s, int e, const FastDiv &by_reso, bool &neg, bool &wide)
 {
     neg = neg || (s | e) < 0;
     unsigned first = 0, last1 = 0;
-    if (e > 0 && (s | e) >= 0) { first = (unsigned)s / (unsigned)reso; last1 = (unsigned)(e - 1) / (unsigned)reso + 1u; }
+    // (multiply-high divisions: two hardware divisions per side were most of what the first pass of the sort executed)
+    if (e > 0 && (s | e) >= 0) { first = (unsigned)fdiv(by_reso, s); last1 = (unsigned)fdiv(by_reso, e - 1) + 1u; }
     wide = wide || first > 65535u || last1 > 65535u;
     return (unsigned long long)(uint32_t)rid | ((unsigned long long)(first & 0xffffu) << 32) | ((unsigned long long)(last1 & 0xffffu) << 48);
 }
-__global__ __launch_bounds__(256) void expand_sides_win_kernel(long long n_rec, int32_t n_reads, int symmetric, int reso, const int32_t *qid, const int32_t *qs, const int32_t *qe,
-                                                               const int32_t *tid, const int32_t *ts, const int32_t *te, unsigned long long *item,
-                                                               int32_t *err_flags, long long *err_index)
-{
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (long long)gridDim.x * blockDim.x) {
-        const int q = qid[i];
-        const bool okq = q >= 0 && q < n_reads;
-        bool bad = !okq, neg = false, wide = false;
-        const unsigned long long xq = side_item(okq ? q : n_reads, qs[i], qe[i], reso, neg, wide);
-        item[i] = okq ? xq : (unsigned long long)(uint32_t)n_reads;
-        if (!okq) { neg = false; wide = false; }
-        if (!symmetric) {
-            const int t = tid[i];
-            const bool okt = t >= 0 && t < n_reads;
-            bad = bad || !okt;
-            const bool use = okt && t != q;
-            bool n2 = false, w2 = false;
-            const unsigned long long xt = side_item(use ? t : n_reads, ts[i], te[i], reso, n2, w2);
-            item[n_rec + i] = use ? xt : (unsigned long long)(uint32_t)n_reads;
-            if (use) { neg = neg || n2; wide = wide || w2; }
-        }
-        if (bad) {
-            atomicOr(err_flags, kErrReadId);
-            atomicMin((unsigned long long *)err_index, (unsigned long long)i);
-        } else if (neg) {
-            atomicOr(err_flags, kErrCoord);
-            atomicMin((unsigned long long *)err_index, (unsigned long long)i);
-        } else if (wide) atomicOr(err_flags, kErrWide);
+// The sides of the record columns as the item sort's first pass takes them (sort_pairs.hpp: Src): side j < n_rec is the query side of
+// record j, side n_rec + i the target side of record i (a non-symmetric PAF only; a side that does not exist -- a target on the query's
+// own read, an id out of range -- has the key n_reads and sorts behind every read).  Until round 6 expand_sides_win_kernel wrote
+// these items out and the first pass read them back; now the histogram reads the id columns and the scatter makes the items.
+// What the input can have wrong is reported by the scatter (item<true>), per side: an id outside [0, n_reads) (kErrReadId), a
+// negative coordinate (kErrCoord; neither for a side that does not exist), windows beyond 16 bits (kErrWide) -- the record's index.
+struct SideSource {
+    long long n_rec;
+    int32_t n_reads, symmetric;
+    FastDiv by_reso;
+    const int32_t *qid, *qs, *qe, *tid, *ts, *te;
+    int32_t *err_flags;
+    long long *err_index;
+    __device__ __forceinline__ uint32_t key(long long j) const
+    {
+        if (j < n_rec) { const int q = qid[j]; return q >= 0 && q < n_reads ? (uint32_t)q : (uint32_t)n_reads; }
+        const long long i = j - n_rec;
+        const int t = tid[i];
+        return t >= 0 && t < n_reads && t != qid[i] ? (uint32_t)t : (uint32_t)n_reads;
     }
-}
+    struct Raw { int r, s, e, q; };
+    __device__ __forceinline__ Raw load(long long j) const      // (plain loads, nothing dependent: a batch of them is in flight at once)
+    {
+        const bool query = j < n_rec;
+        const long long i = query ? j : j - n_rec;
+        const int32_t *ids = query ? qid : tid, *ss = query ? qs : ts, *ee = query ? qe : te;
+        return Raw{ids[i], ss[i], ee[i], qid[i]};
+    }
+    template <bool REPORT> __device__ __forceinline__ unsigned long long make(const Raw &v, long long j) const
+    {
+        const bool query = j < n_rec;
+        const long long i = query ? j : j - n_rec;
+        const bool ok = v.r >= 0 && v.r < n_reads;
+        const bool use = ok && (query || v.r != v.q);
+        bool neg = false, wide = false;
+        const unsigned long long x = side_item(use ? v.r : n_reads, v.s, v.e, by_reso, neg, wide);
+        if (REPORT) {
+            if (!ok) {
+                atomicOr(err_flags, kErrReadId);
+                atomicMin((unsigned long long *)err_index, (unsigned long long)i);
+            } else if (use && neg) {
+                atomicOr(err_flags, kErrCoord);
+                atomicMin((unsigned long long *)err_index, (unsigned long long)i);
+            } else if (use && wide) atomicOr(err_flags, kErrWide);
+        }
+        return use ? x : (unsigned long long)(uint32_t)n_reads;
+    }
+};
 
 __global__ __launch_bounds__(256) void unzip_items_kernel(long long n_ent, int32_t n_reads, const unsigned long long *__restrict__ item, uint32_t *__restrict__ b_win,
                                                           long long *__restrict__ off, GapList *gaps)

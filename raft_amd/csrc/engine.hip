@@ -317,14 +317,13 @@ static int sort_sides_win(raft_hip_ctx *c, hipStream_t st, long long n_rec, int3
     HIP_TRY(c, c->rs_v0.ensure((size_t)cap_iv * 8)); HIP_TRY(c, c->rs_v1.ensure((size_t)cap_iv * 8));
     HIP_TRY(c, c->gaps.ensure(sizeof(GapList)));
     HIP_TRY(c, hipMemsetAsync(c->gaps.p, 0, 8, st));
-    const unsigned g1 = (unsigned)std::max<long long>(1, std::min<long long>((n_rec + 255) / 256, 256 * 32));
-    hipLaunchKernelGGL(expand_sides_win_kernel, dim3(g1), dim3(256), 0, st, n_rec, n_reads, symmetric, c->prm.reso, d_qid, d_qs, d_qe, d_tid, d_ts, d_te,
-                       c->rs_v0.as<unsigned long long>(), err_flags, err_index);
     int bits = 1;
     while (bits < 32 && (1LL << bits) <= (long long)n_reads) ++bits;               // keys 0 .. n_reads (the sides that do not exist)
     HIP_TRY(c, c->sort_tmp.ensure(rs_items_tmp_bytes(cap_iv)));
     bool in_b = false;
-    HIP_TRY(c, radix_sort_items(st, c->rs_v0.as<unsigned long long>(), c->rs_v1.as<unsigned long long>(), cap_iv, bits, c->sort_tmp.p, &in_b));
+    // (the first pass makes its items from the columns: no expansion kernel, no 16 bytes per side written and read back)
+    const SideSource src{(long long)n_rec, n_reads, symmetric, make_fast_div(c->prm.reso), d_qid, d_qs, d_qe, d_tid, d_ts, d_te, err_flags, err_index};
+    HIP_TRY(c, radix_sort_items(st, src, c->rs_v0.as<unsigned long long>(), c->rs_v1.as<unsigned long long>(), cap_iv, bits, c->sort_tmp.p, &in_b));
     const unsigned long long *sorted = in_b ? c->rs_v1.as<unsigned long long>() : c->rs_v0.as<unsigned long long>();
     const unsigned g2 = (unsigned)std::max<long long>(1, std::min<long long>((cap_iv + 255) / 256, 256 * 32));
     hipLaunchKernelGGL(unzip_items_kernel, dim3(g2), dim3(256), 0, st, cap_iv, n_reads, sorted, o_win, off, c->gaps.as<GapList>());

@@ -281,8 +281,22 @@ inline hipError_t radix_sort_by_key(hipStream_t st, uint32_t *key_a, V *val_a, u
 // ---- the same sort over 64-bit ITEMS whose low 32 bits are the key (the general bucketing's window-record route: an interval is
 // (read id, first window | one past the last << 16) -- 8 bytes where the coordinate pair takes 12, one load and one store per pair and
 // pass instead of two, runs of twice the bytes)
-template <int IPT>
-__global__ __launch_bounds__(kRsThreads) void rs_hist_items_kernel(const unsigned long long *__restrict__ item, long long n, int shift, int n_tiles, int32_t *__restrict__ hist)
+// Where a pass of the item sort takes its items from: the array the pass before wrote -- or, for the FIRST pass, a functor that makes
+// them on the fly (bucket.hpp SideSource: the sides of the record columns; round 6 -- until then a kernel of its own wrote the items
+// out and the first pass read them back, 16 bytes of traffic per side for nothing).  key(i): the low 32 bits alone (the histogram
+// looks at nothing else); load(i) + make<REPORT>(raw, i): the whole item, REPORT: errors of the input are raised here, once.
+// (load / make: the scatter asks for a batch of raw values first and makes the items afterwards -- made one at a time, a tile's 32
+// rounds of loads were 32 round trips: 4.0 ms for the pass where the items' own array takes 1.3)
+struct ItemArray {
+    const unsigned long long *p;
+    typedef unsigned long long Raw;
+    __device__ __forceinline__ uint32_t key(long long i) const { return (uint32_t)p[i]; }
+    __device__ __forceinline__ Raw load(long long i) const { return p[i]; }
+    template <bool REPORT> __device__ __forceinline__ unsigned long long make(const Raw &r, long long) const { return r; }
+};
+
+template <int IPT, class Src>
+__global__ __launch_bounds__(kRsThreads) void rs_hist_items_kernel(Src src, long long n, int shift, int n_tiles, int32_t *__restrict__ hist)
 {
     __shared__ int32_t h[256];
     const int tile = rs_tile_of_block((int)blockIdx.x, n_tiles);
@@ -293,14 +307,14 @@ __global__ __launch_bounds__(kRsThreads) void rs_hist_items_kernel(const unsigne
 #pragma unroll 8
     for (int b = 0; b < IPT; ++b) {
         const long long i = t0 + (long long)b * kRsThreads + threadIdx.x;
-        if (i < n) atomicAdd(&h[((uint32_t)item[i] >> shift) & 255u], 1);
+        if (i < n) atomicAdd(&h[(src.key(i) >> shift) & 255u], 1);
     }
     __syncthreads();
     if (threadIdx.x < 256) hist[(long long)tile * 256 + threadIdx.x] = h[threadIdx.x];
 }
 
-template <int IPT>
-__global__ __launch_bounds__(kRsThreads) void rs_scatter_items_kernel(const unsigned long long *__restrict__ in, long long n, int shift, int n_tiles,
+template <int IPT, class Src, bool REPORT>
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_items_kernel(Src src, long long n, int shift, int n_tiles,
                                                                const int32_t *__restrict__ tile_off, unsigned long long *__restrict__ out)
 {
     constexpr int TILE = RsGeom<IPT>::kTile, SHARE = RsGeom<IPT>::kQuarter;
@@ -316,10 +330,21 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_items_kernel(const unsi
     for (int i = tid; i < kRsWaves * 256; i += kRsThreads) (&cnt[0][0])[i] = 0;
     __syncthreads();
     unsigned long long it[IPT];
+    constexpr int G = 8;                          // raw values asked for at once
+    static_assert(IPT % G == 0, "batches of G");
 #pragma unroll
-    for (int b = 0; b < IPT; ++b) {
-        const int j = w * SHARE + b * 64 + lane;
-        it[b] = j < n_valid ? in[t0 + j] : ~0ull;
+    for (int b0 = 0; b0 < IPT; b0 += G) {
+        typename Src::Raw raw[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int j = w * SHARE + (b0 + g) * 64 + lane;
+            raw[g] = src.load(t0 + min(j, max(n_valid - 1, 0)));
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int j = w * SHARE + (b0 + g) * 64 + lane;
+            it[b0 + g] = j < n_valid ? src.template make<REPORT>(raw[g], t0 + j) : ~0ull;
+        }
     }
 #pragma unroll
     for (int b = 0; b < IPT; ++b)
@@ -372,22 +397,27 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_items_kernel(const unsi
 
 constexpr int kRsItemsIpt = 32;      // 8192 items of 8 bytes: 64 KB of LDS per tile, runs of 256 bytes
 inline size_t rs_items_tmp_bytes(long long n) { return ((size_t)256 * (size_t)((n + RsGeom<kRsItemsIpt>::kTile - 1) / RsGeom<kRsItemsIpt>::kTile + 1) + (size_t)256 * kRsSegs) * 4; }
-inline hipError_t radix_sort_items(hipStream_t st, unsigned long long *a, unsigned long long *b, long long n, int bits, void *tmp, bool *in_b)
+// the first pass reads `first` (n items: any Src), every pass writes into a / b in turn beginning with a; *in_b: the sorted items are in b
+template <class First>
+inline hipError_t radix_sort_items(hipStream_t st, First first, unsigned long long *a, unsigned long long *b, long long n, int bits, void *tmp, bool *in_b)
 {
     constexpr int IPT = kRsItemsIpt;
-    *in_b = false;
-    if (n < 2) return hipSuccess;
-    const int n_tiles = (int)((n + RsGeom<IPT>::kTile - 1) / RsGeom<IPT>::kTile);
+    *in_b = true;                        // (nothing written yet: the roles swap before the first pass)
+    const int n_tiles = (int)std::max<long long>(1, (n + RsGeom<IPT>::kTile - 1) / RsGeom<IPT>::kTile);
     int32_t *hist = static_cast<int32_t *>(tmp), *seg = hist + (size_t)256 * n_tiles;
-    unsigned long long *xi = a, *xo = b;
-    for (int shift = 0; shift < bits; shift += 8) {
-        hipLaunchKernelGGL((rs_hist_items_kernel<IPT>), dim3(rs_grid(n_tiles)), dim3(kRsThreads), 0, st, xi, n, shift, n_tiles, hist);
+    unsigned long long *xi = b, *xo = a;
+    bool first_pass = true;
+    for (int shift = 0; shift < bits || first_pass; shift += 8) {
+        if (first_pass) hipLaunchKernelGGL((rs_hist_items_kernel<IPT, First>), dim3(rs_grid(n_tiles)), dim3(kRsThreads), 0, st, first, n, shift, n_tiles, hist);
+        else hipLaunchKernelGGL((rs_hist_items_kernel<IPT, ItemArray>), dim3(rs_grid(n_tiles)), dim3(kRsThreads), 0, st, ItemArray{xi}, n, shift, n_tiles, hist);
         hipLaunchKernelGGL(rs_segsum_kernel, dim3(kRsSegs), dim3(256), 0, st, n_tiles, hist, seg);
         hipLaunchKernelGGL(rs_segscan_kernel, dim3(1), dim3(256), 0, st, seg);
         hipLaunchKernelGGL(rs_tilescan_kernel, dim3(kRsSegs), dim3(256), 0, st, n_tiles, hist, seg);
-        hipLaunchKernelGGL((rs_scatter_items_kernel<IPT>), dim3(rs_grid(n_tiles)), dim3(kRsThreads), 0, st, xi, n, shift, n_tiles, hist, xo);
+        if (first_pass) hipLaunchKernelGGL((rs_scatter_items_kernel<IPT, First, true>), dim3(rs_grid(n_tiles)), dim3(kRsThreads), 0, st, first, n, shift, n_tiles, hist, xo);
+        else hipLaunchKernelGGL((rs_scatter_items_kernel<IPT, ItemArray, false>), dim3(rs_grid(n_tiles)), dim3(kRsThreads), 0, st, ItemArray{xi}, n, shift, n_tiles, hist, xo);
         std::swap(xi, xo);
         *in_b = !*in_b;
+        first_pass = false;
     }
     return hipGetLastError();
 }
