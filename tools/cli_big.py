@@ -58,11 +58,15 @@ try:
         t0 = time.perf_counter()
         p = subprocess.run([exe, "-e", str(est_cov), "-o", "x", fa, paf], cwd=out, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
         wall = time.perf_counter() - t0
+        t_end = time.time()
         print(f"\n== {tag}: exit {p.returncode}, wall {wall:.2f} s")
         for ln in p.stderr.decode().splitlines():
             if ln.startswith("PIPE"):
                 print("   " + ln)
-            if ln.startswith("TIMING"):
+            if ln.startswith("TIMING leaving-at"):
+                # what lies behind main(): the kernel tearing the process down (mappings, page-locked ranges, the GPU context)
+                print(f"   TIMING {'teardown':16s} {t_end - float(ln.split()[2]):8.3f} s   (from main() leaving to the parent seeing the exit)")
+            elif ln.startswith("TIMING"):
                 print("   " + ln)
                 if ln.startswith("TIMING engine+fetch"):
                     sec = float(ln.split()[2])

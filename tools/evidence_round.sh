@@ -20,7 +20,7 @@ tools/pass_timeline.sh ${TAG}_tlw --input windows --cov-width 1 > gpurun_out/$TA
 tools/membench 7.4 10 32 > gpurun_out/$TAG/membench.txt 2>&1
 for m in 0 2 10; do echo "== mode $m"; tools/membench 7.4 $m 32 8 2>&1 | grep buffer; done > gpurun_out/$TAG/membench_placement.txt 2>&1
 tools/variance_probe.sh 6 > gpurun_out/$TAG/variance_probe.txt 2>&1
-# (the run-time switches exist in a diagnostic build only: make -C raft_amd/csrc LIB=libraft_hip_diag.so BUILD=../../build/csrc_diag DEFS="-DRAFT_WAVE_DIAG -DRAFT_DEBUG_SWAP")
+# (the run-time switches exist in a diagnostic build only: make -C raft_amd/csrc LIB=libraft_hip_diag.so BUILD=../../build/csrc_diag DEFS="-DRAFT_WAVE_DIAG")
 if [ -f raft_amd/lib/libraft_hip_diag.so ]; then
   export RAFT_HIP_LIB=$PWD/raft_amd/lib/libraft_hip_diag.so
   ( echo "# six columns, int32 out; mode bits: 1 no reuse of the per-read tables, 2 no run scan, 4 no scatter, 8 no coverage stores"; python tools/mode_probe.py RAFT_WAVE_MODE=0,1,2,4,8,14 3
