@@ -138,7 +138,7 @@ struct GuessBeside {
 // It also clears the reads' repeat counters (a fill command of its own before) and, in a pass that was sized by the caller's
 // window count, compares that count with the scan's (kErrHint; a fill command and a one-wave kernel of their own cost
 // ~15 us of a 0.5 ms pass on an eighth of the human-scale set).
-__global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const long long *cov_off, int Q,
+__global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const long long *cov_off, Quantum qz,
                                                          long long n_tiles, int32_t *tile_first, int32_t *err_flags,
                                                          long long *err_index, GroupedOff grp, int32_t n_runs, long long n_rec,
                                                          int32_t *rep_cnt, const long long *scan_totals, long long hint_bins)
@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const 
             atomicMin((unsigned long long *)err_index, (unsigned long long)r);
         }
     }
-    const long long t_r = (r < n_reads) ? cov_off[r] / Q : n_tiles;
-    const long long t_p = (r > 0) ? cov_off[r - 1] / Q : -1;
+    const long long t_r = (r < n_reads) ? min(qz.idx(cov_off[r]), n_tiles) : n_tiles;
+    const long long t_p = (r > 0) ? min(qz.idx(cov_off[r - 1]), n_tiles) : -1;
     for (long long k = t_p + 1; k <= t_r; ++k) tile_first[k] = (int32_t)r;
 }
 
@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void tile_first_kernel(int32_t n_reads, const 
 // off < k Q <= off + nb) -- and on the last workgroup the sizes the pass was built on against the ones the scan found (kErrHint:
 // every later kernel of the pass returns at once, raft_hip_finish runs it again with the host wait).
 struct PrepPost {
-    int32_t n_reads, Q;
+    int32_t n_reads;
+    Quantum qz;
     long long n_tiles;
     int32_t *tile_first, *rep_cnt, *err_flags;
     long long *err_index;
@@ -201,7 +202,7 @@ struct PrepPost {
             }
         }
         if (r == 0) tile_first[0] = 0;
-        const long long k0 = off[0] / Q + 1, k1 = r + 1 == n_reads ? n_tiles : min((off[0] + v[0]) / Q, n_tiles);
+        const long long k0 = qz.idx(off[0]) + 1, k1 = r + 1 == n_reads ? n_tiles : min(qz.idx(off[0] + v[0]), n_tiles);
         for (long long k = k0; k <= k1; ++k) tile_first[k] = (int32_t)(r + 1);
     }
     __device__ void closing(const long long (&tot)[3]) const

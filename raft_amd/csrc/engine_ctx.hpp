@@ -371,8 +371,10 @@ struct raft_hip_ctx {
         long long B = 0, RU = 0, CU = 0;
         int n_desc = 0;
         long long desc[kMaxSeg] = {};
+        bool had_deep = true;          // its tiles of 2^15 intervals or more (raft_hip_finish): none -> a speculative pass does not launch pileup_deep_kernel
     } shape;
     bool speculated = false;           // the pass in flight was built on `shape`
+    bool deep_skipped = false;         // ... and without a launch of pileup_deep_kernel (a deep tile then refutes it: kErrDeep)
     hipStream_t clean_stream = nullptr;
     bool ctrl_clean = false;           // the control block and the hand-out counters were cleared by the last pass's closing kernel, on clean_stream
 };

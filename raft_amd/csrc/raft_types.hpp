@@ -189,6 +189,47 @@ inline FastDiv make_fast_div(int d)
 }
 __device__ __forceinline__ int fdiv(const FastDiv &f, int n) { return f.shift < 0 ? n : (int)(__umulhi((unsigned)n, f.magic) >> f.shift); }
 
+// Where the ranges of reads a worker of pileup_wave_kernel draws may begin: boundary k lies at a window position at(k), and
+// tile_first[k] is the first read that begins at or behind it (bucket.hpp PrepPost / tile_first_kernel), its records and first
+// window what tile_desc_kernel looks up.  Uniform: at(k) = k q.  Graded (round 6, sets with many tiles per worker): the set is
+// eight shares of `share` windows -- what one of the kernel's eight hand-out counters deals out, in order -- and a share's boundaries
+// lie q_long apart for its first n_long ranges and q_short apart behind them: few boundaries where a draw's length does not matter,
+// short ranges where the kernel's end would otherwise wait for the last long draw (two / three / four / eight tiles' worth per
+// draw, uniform: 2.42 / 2.45 / 2.49 / 2.56 ms) -- and tile_desc_kernel's searches, one per boundary and run, are the fixed part's
+// largest item.  A share may close with a range shorter than q_short, and boundaries behind the set's last window own nothing.
+struct Quantum {
+    int32_t q;                            // uniform: boundaries q windows apart (share == 0)
+    long long share;                      // graded: windows per share (a multiple of 128), boundaries per share, ...
+    int32_t per_share, n_long, q_long, q_short;
+    // the largest k with at(k) <= w, for 0 <= w
+    __host__ __device__ long long idx(long long w) const
+    {
+        if (share == 0) return w < (1LL << 31) ? (long long)((unsigned)w / (unsigned)q) : w / q;
+        int s = 0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += w >= (long long)i * share ? 1 : 0;
+        if (w >= 8 * share) return 8LL * per_share;                       // (behind every share: the closing boundary)
+        const unsigned x = (unsigned)(w - (long long)s * share);          // (share < 2^31: checked where the quantum is made)
+        const unsigned in_long = (unsigned)n_long * (unsigned)q_long;
+        const unsigned j = x < in_long ? x / (unsigned)q_long : (unsigned)n_long + (x - in_long) / (unsigned)q_short;
+        return (long long)s * per_share + (long long)(j < (unsigned)per_share ? j : (unsigned)per_share - 1u);
+    }
+    __host__ __device__ long long n_ranges(long long n_windows) const { return share == 0 ? n_windows / q + 1 : 8LL * per_share; }
+};
+inline Quantum uniform_quantum(int q) { Quantum z{}; z.q = q; return z; }
+// eight shares of ceil(B / 8) windows (rounded up to 128): `frac_long` of a share in ranges of q_long, the rest in ranges of q_short
+inline Quantum graded_quantum(long long n_windows, int q_long, int q_short, double frac_long)
+{
+    Quantum z{};
+    z.share = ((n_windows + 7) / 8 + 127) / 128 * 128;
+    z.q_long = q_long; z.q_short = q_short;
+    z.n_long = (int32_t)((double)z.share * frac_long / q_long);
+    const long long rest = z.share - (long long)z.n_long * q_long;
+    z.per_share = z.n_long + (int32_t)((rest + q_short - 1) / q_short);
+    z.q = q_short;
+    return z;
+}
+
 struct FinalizeArgs {
     int32_t n_reads;
     const int32_t *read_len;

@@ -138,3 +138,36 @@ def test_detecting_context_speculates_too_and_keeps_detecting():
     eng.run_device(*dev); s = eng.finish()
     assert_same_result(_result(eng, s), want2, "mirror gone")
     eng.close()
+
+
+def test_a_deep_pile_appears_in_a_stream_that_had_none():
+    """A speculative pass over a stream whose last pass listed no deep tile does not launch the 32-bit side kernel.  Same counts, same
+    run, same window count -- but now 40,000 records sit on one read: the wave kernel finds no room for the tile, the pass is run
+    again the long way (RERUN), and the result is the oracle's; the passes after that launch the side kernel and need no re-run."""
+    import torch
+    from raft_amd import engine
+    p = RaftParams(est_cov=8, symmetric_mode=1)
+    rng = np.random.default_rng(21)
+    n_reads, n = 1200, 48000
+    rl = rng.integers(30000, 60000, n_reads).astype(np.int32)
+    qid = np.repeat(np.arange(n_reads, dtype=np.int32), n // n_reads)               # 40 records per read, one sorted run
+    a = (rng.random(n) * rl[qid] * 0.5).astype(np.int32); b = (a + 1 + (rng.random(n) * rl[qid] * 0.4).astype(np.int32)).astype(np.int32)
+    dev = [torch.from_numpy(x).to("cuda:0") for x in (rl, qid, a, b)]
+    eng = engine.Engine(p, device=0)
+    for _ in range(3):
+        eng.run_device(*dev); s = eng.finish()
+    assert s.flags & SPECULATED and not (s.flags & 4)
+    qid2 = np.sort(np.concatenate([qid[::6][:n - 40000], np.full(40000, 700, np.int32)])).astype(np.int32)      # 8,000 records spread over the reads + the pile
+    a2 = (rng.random(n) * rl[qid2] * 0.5).astype(np.int32); b2 = (a2 + 1 + (rng.random(n) * rl[qid2] * 0.4).astype(np.int32)).astype(np.int32)
+    want = oracle_run(p, rl, qid2, a2, b2, qid2, a2, b2); want["symmetric"] = 1
+    assert want["cov"].max() >= 10000
+    for t, x in zip(dev[1:], (qid2, a2, b2)):
+        t.copy_(torch.from_numpy(x))
+    flags = []
+    for it in range(3):
+        eng.run_device(*dev); s = eng.finish()
+        flags.append(s.flags)
+        assert_same_result(_result(eng, s), want, f"deep pile, pass {it}")
+    assert flags[0] & 8 and flags[0] & 4 and not (flags[0] & SPECULATED), flags         # re-run, deep tiles taken
+    assert all(f & 4 and not (f & 8) for f in flags[1:]), flags
+    eng.close()
