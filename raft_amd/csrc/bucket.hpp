@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void expand_ids_kernel(int32_t n_reads, int32_
     }
 }
 
-// Window records (pileup_fast.hpp IN = 1) for the passes that need coordinate columns -- the general pileup kernel, the merge
+// Window records (pileup_wave.hpp IN = 1) for the passes that need coordinate columns -- more runs than its instantiations take, the merge
 // of more than kMaxSeg runs: coordinates that fall into the same windows (first * reso, last1 * reso; an empty record
 // becomes (0, 0)).  reso <= 32767 keeps 65535 * reso inside int32 (checked by the engine).
 __global__ __launch_bounds__(256) void unpack_windows_kernel(long long n, const uint32_t *__restrict__ w, int32_t reso, int32_t *__restrict__ qs,

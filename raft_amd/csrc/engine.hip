@@ -355,9 +355,8 @@ int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool verify_in_k
     hipStream_t st = c->stream;
     SyncScope scope(c->stream, c->side_stream);            // (a buffer that grows waits for this context's streams only)
     bool expand = false;
-    // window records go to the fast kernel's own instantiation (pileup_fast.hpp IN = 1) where every tile is the fast kernel's
-    // in its default configuration and the runs are few; anything else gets coordinate columns that fall into the same
-    // windows (bucket.hpp unpack_windows_kernel) and takes the paths those have
+    // window records go to the pileup kernel's own instantiation (pileup_wave.hpp IN = 1) where the runs are few; anything else gets
+    // coordinate columns that fall into the same windows (bucket.hpp unpack_windows_kernel) and takes the paths those have
     const bool lean = d_win && n_rec > 0 && !merge && eff_runs <= kWinMaxRuns && !c->force_bucket && getenv("RAFT_NO_WINDOW_KERNEL") == nullptr;
     if (d_win && !lean && n_rec > 0) {
         HIP_TRY(c, c->u_s.ensure((size_t)n_rec * 4));
@@ -992,7 +991,7 @@ int raft_hip_run_host(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len,
                                six ? c->in_col[4].as<int32_t>() : nullptr, six ? c->in_col[5].as<int32_t>() : nullptr);
 }
 
-// the control block as the pass's last workgroup handed it over (totals_kernel: stamped lines, 1024 bytes into the page-locked block)
+// the control block as the pass's last workgroup handed it over (publish_and_clear_kernel: stamped lines, 1024 bytes into the page-locked block)
 Ctrl host_ctrl(const raft_hip_ctx *c)
 {
     static_assert(sizeof(Ctrl) % 8 == 0 && sizeof(Ctrl) / 8 <= 48, "the control block travels in one wave's stamped lines");

@@ -43,8 +43,8 @@ struct Ctrl {                         // device control block, cleared every pas
     int32_t err_flags;
     int32_t pad_slow;
     long long err_index;              // (the first 16 bytes are what the pass's host wait reads back)
-    int32_t next_tile;                // pileup_fast_kernel's tile hand-out counter
-    int32_t slow_next;                // the general kernel's item hand-out counter (list mode)
+    int32_t next_tile;                // (unused since round 6: the wave kernel's hand-out counters are raft_hip_ctx::wave_ctr)
+    int32_t slow_next;                // delta4: the counter tile ids are drawn from (PileupArgs::slow_counter)
     int32_t pad_extra[2];
     unsigned long long totals[4];     // coverage, repeat bp, read length
     InspectOut insp;
@@ -311,7 +311,7 @@ struct raft_hip_ctx {
     int packed_width = 0;             // width (bytes per window) of the encoding the buffers hold, 0 = none
     long long n_exc = 0, exc_cap = 0;
     int out_width = 4;                // raft_hip_set_output_width: 1 / 2 = the pass writes the encoding, cov[] only on request
-    int pass_width = 4;               // what the last pass wrote (4 where the general kernel had to take part)
+    int pass_width = 4;               // what the last pass wrote
     bool cov_valid = false;           // c->cov holds the int32 array of the last pass
     void *pinned = nullptr;           // small pinned scratch for readbacks
     long long *pinned_dev = nullptr;  // the same block as the device addresses it
@@ -343,7 +343,7 @@ struct raft_hip_ctx {
     DevBuf exc_pidx, exc_pval, exc_tile_n; // delta4: the windows each tile lists, kExcPerTile slots per tile (compact_exceptions_kernel)
     bool exc_sorted = false;
     long long sizes_seq = 0;           // number of the last sizes hand-over of run_pass (publish_sizes_kernel)
-    long long pass_seq = 0;            // number of the pass whose totals_kernel is queued (written behind the control block when it is through)
+    long long pass_seq = 0;            // number of the pass whose closing kernel is queued (written behind the control block when it is through)
     bool seq_armed = false;
     int d4_shift = 0;                  // delta4 on a chunk of a larger array (the host pipelines' lanes): windows of the block its first window lies in that precede it
     DevBuf x_qs, x_qe, x_off, x_raw, x_send_off, x_cnt;   // pre-split exchange (raft_hip_exchange*): what this rank received / staged

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void pack_cov_kernel(const int32_t *__restrict
 }
 
 // The other direction, for a caller that asks for cov[] as int32 after a pass that wrote the encoding directly
-// (pileup_fast.hpp OW = 1 / 2): codes widened, then the listed windows overwritten with their values.
+// (pileup_wave.hpp OW = 1 / 2): codes widened, then the listed windows overwritten with their values.
 template <class T>
 __global__ __launch_bounds__(256) void unpack_cov_kernel(const T *__restrict__ codes, long long n_bins, int32_t *__restrict__ cov)
 {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void compact_exceptions_kernel(long long n_til
     }
 }
 
-// int32 cov[] -> delta4 (after a pass that wrote int32: the general kernel took part, or the caller asked late)
+// int32 cov[] -> delta4 (after a pass that wrote int32: the caller asked late)
 __global__ __launch_bounds__(256) void pack_delta4_kernel(const int32_t *__restrict__ cov, long long n_bins, Delta4Out o, int shift)
 {
     const long long n4 = (n_bins + 3) >> 2;

@@ -1,6 +1,6 @@
 // pileup_wave.hpp -- the pileup kernel of round 4: one WAVE per tile, a 16-bit difference array, eight windows per lane.
 //
-// What pileup_fast.hpp's counters and stamps said: its time does not follow its bytes -- 53 % of
+// What the counters and stamps of round 3's workgroup-tile kernel said (docs/history.md §5): its time does not follow its bytes -- 53 % of
 // the wave cycles are waits, the vector pipe is a quarter busy, and what a tile costs is its dependent chains (LDS read ->
 // adds -> six DPP steps -> carry; three workgroup barriers; a pass over the array just to hand every wave its start value)
 // executed by four waves per SIMD.  This kernel removes the chains' causes instead of shortening them:
@@ -23,9 +23,9 @@
 //     would wait for the stores); the stores are raw buffer stores of whole 16-byte lanes (the compiler merged plain ones
 //     with the tile edges' element stores into 12 + 4 bytes).
 //   * bound: every intermediate is exact modulo 2^16 and every coverage value must be below 32768.  A tile holds fewer
-//     intervals than that or it refutes the pass (kErrDeep: raft_hip_finish runs the pass again with the int32 kernels).
+//     intervals than that, or it is left to pileup_deep_kernel (pileup_deep.hpp: 32-bit, a workgroup per tile, in the same pass).
 // Reference semantics: repeat.hpp:28-79 (profileCoverage), repeat.hpp:111-168 (run scan) -- see pileup.hpp; the run scan
-// of a half-row is pileup_fast.hpp's per-lane scan (one wave shift + one max-scan).
+// of a half-row is a per-lane scan of four slots (one wave shift + one max-scan), as in round 3's kernel.
 #pragma once
 #include "pileup.hpp"
 
@@ -113,7 +113,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
     static_assert(IN == 0 || NSEG <= 2, "window records: one or two runs");
     constexpr bool D4 = OW == 8;
     const int lane = (int)(threadIdx.x & 63u);
-    // (every worker owns two words of the sums totals_kernel adds up: also the ones that leave without a tile)
+    // (every worker owns two words of the sums tail_prefix_kernel adds up: also the ones that leave without a tile)
     auto leave_empty = [&]() { if (lane == 0) { a.block_sums[2 * (long long)wave_id] = 0; a.block_sums[2 * (long long)wave_id + 1] = 0; } };
     if (uni(*(volatile int32_t *)a.err_flags) & (kErrExtra | kErrStop)) { leave_empty(); return; }
     const int n_seg_tiles = (int)a.n_tiles;      // segments (quantum tiles) tile_desc_kernel cut: boundaries cuts[0 .. n_seg_tiles]
@@ -825,7 +825,7 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             const unsigned xh = (mx + kthr) & 0x80008000u;
             if (kMode & 2) continue;             // (diagnostic, RAFT_WAVE_MODE: no run scan)
             if (__ballot(xh != 0u) == 0ull && !hp) continue;
-            // per half-row: pileup_fast.hpp's per-lane scan of four slots
+            // per half-row: a per-lane scan of four slots
 #pragma unroll 1
             for (int h = 0; h < 2; ++h) {
                 const int hb = base + h * 256;                         // first slot of the half-row

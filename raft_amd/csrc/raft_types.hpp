@@ -58,7 +58,7 @@ enum : int {
 struct PileupArgs {
     // intervals: sorted by read id inside each of n_seg segments
     const int32_t *iv_rid, *iv_s, *iv_e;
-    // ... or "window records" (pileup_fast.hpp IN = 1): one word per record, first window | one past the last << 16, no read
+    // ... or "window records" (pileup_wave.hpp IN = 1): one word per record, first window | one past the last << 16, no read
     // ids -- the reads' records are where the caller's offsets (grp) say
     const uint32_t *iv_w;
     GroupedOff grp;
@@ -74,7 +74,7 @@ struct PileupArgs {
     int32_t div_shift;            // -1: reso == 1
     // outputs
     int32_t *cov;
-    // pileup_fast_kernel instantiated with OW = 1 or 2 writes the transfer encoding of cov[] instead (pack.hpp: OW bytes per
+    // pileup_wave_kernel instantiated with OW = 1 or 2 writes the transfer encoding of cov[] instead (pack.hpp: OW bytes per
     // window, min(cov, 255 / 65535), plus the list of the windows at or above that limit) and leaves `cov` alone
     void *covp;
     int32_t *cov_anchor;          // OW = 8 (pack.hpp kCovDelta4, four bits per window): cov[1024 k - 1] per block of 1024 windows
@@ -238,7 +238,7 @@ struct FinalizeArgs {
     int32_t *raw_key, *raw_s, *raw_e;     // sorted in place by finalize_count_kernel
     int32_t interval_length, div, overlap_length;
     FastDiv by_L, by_div, by_reso;        // interval_length, div, reso as divisors
-    // reads with more than long_windows windows were piled up in pieces (pileup_fast.hpp emit_piece_run): their raw
+    // reads with more than long_windows windows were piled up in pieces (pileup_wave.hpp: a tile with kCutPiece): their raw
     // records are unflanked [start, end) runs per piece, to be joined, tested, flanked and clamped here
     int32_t long_windows, reso, repeat_length, flank;
     int32_t *rep_cnt_rw;                  // (rep_cnt, writable: the joined count replaces the pieces' count)

@@ -17,7 +17,7 @@ namespace raft {
 constexpr int kWaveSlots = RAFT_WAVE_SLOTS;
 // waves of the full persistent grid: every SIMD of the chip holds RAFT_WAVE_WPS of them (n_waves of a launch: at most that, a multiple of RAFT_WAVE_WPB)
 int wave_grid_waves(bool win);
-// ow: bytes per window written (4, 1, 2, or 8 = four-bit steps); win: window records (pileup_fast.hpp IN = 1)
+// ow: bytes per window written (4, 1, 2, or 8 = four-bit steps); win: window records (pileup_wave.hpp IN = 1)
 // (cuts: const TileCut *, pa: const PileupArgs * -- untyped here because wave_launch.hip includes the shared kernel headers under
 // a namespace of its own, so that the kernels those headers define do not exist twice in the library)
 void launch_wave_variant(int ow, bool win, hipStream_t st, int n_seg, const void *cuts, const void *pa, int n_waves);

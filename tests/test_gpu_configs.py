@@ -488,7 +488,7 @@ def test_detecting_context_alternating_inputs():
         eng.close()
 
 
-# ---- tiles re-cut for the fast kernel (groups of reads, pieces of long reads) ----------------------------------------------
+# ---- reads longer than a tile (pieces), runs of tiny reads (groups of up to 63) --------------------------------------------------
 
 def _long_read_set(seed):
     """Short reads with a few reads far longer than the LDS window between them (default reso: > 397 kb), coverage thin in

@@ -1,9 +1,10 @@
-"""GPU: the pileup configurations against each other at sizes the CPU oracle does not reach.
+"""GPU: the two pileup kernels against each other at sizes the CPU oracle does not reach.
 
-pileup_fast_kernel (+ the general kernel for the tiles it leaves), the general kernel alone, and the smaller fast
-configuration are three code paths over the same reference semantics; on any input all outputs must be identical.
-The oracle-based tests pin the semantics on small inputs; this one catches scale-dependent faults (tile seams,
-dynamic tile hand-out, chunked long reads, overflow of the prefetch slots) on a few hundred thousand reads.
+pileup_wave_kernel (one wave per tile, packed 16-bit arithmetic) and pileup_deep_kernel (a workgroup per tile, plain 32-bit:
+every tile sent its way, raft_testlib.kernel_mode) are two code paths over the same reference semantics, through the sorted-run path
+and through the general bucketing; on any input all outputs must be identical.  The oracle-based tests pin the semantics on small
+inputs; this one catches scale-dependent faults (tile seams, dynamic hand-out of ranges, long reads in pieces, records behind the
+prefetch slots) on a few hundred thousand reads.  (Rounds 1-5: the workgroup-tile kernels of rounds 1-3 were the partners.)
 """
 import numpy as np
 import pytest

@@ -1,4 +1,4 @@
-"""GPU: passes that write the transfer encoding of cov[] directly (raft_hip_set_output_width, pileup_fast.hpp OW = 1 / 2).
+"""GPU: passes that write the transfer encoding of cov[] directly (raft_hip_set_output_width, pileup_wave.hpp OW = 1 / 2).
 
 The encoding is a lossless restatement of what repeat.hpp:102-108 hands its formatter, so every check is exact: the
 decoded array equals the oracle's cov, every other output is untouched by the width, and the widths agree with each other.

@@ -239,7 +239,7 @@ def _intervals(rl, ids, rng, frac=1.0):
 def _fast_kernel_cases():
     rng = np.random.default_rng(77)
     cases = {}
-    # (a) very many tiny reads per tile (more than the fast kernel's table holds) between ordinary reads
+    # (a) very many tiny reads per tile (more than a tile's per-read table holds: 63) between ordinary reads
     rl = np.concatenate([rng.integers(2000, 30000, 40), rng.integers(60, 400, 1500), rng.integers(2000, 30000, 40)]).astype(np.int32)
     qid = np.sort(rng.integers(0, len(rl), 30000)).astype(np.int32)
     s, e = _intervals(rl, qid, rng)

@@ -3,7 +3,7 @@ oracle, the golden outputs of the reference binary and the coordinate-column ent
 
 A window record is what profileCoverage uses of an interval (repeat.hpp:69-72: the windows qs / reso .. (qe - 1) / reso),
 cut from the coordinates where they are tokenised (raft_host_pack_windows): one 32-bit word per record and no read id -- the
-read is where the caller's offsets say.  The default configuration takes them in the pileup kernel itself (pileup_fast.hpp
+read is where the caller's offsets say.  The default configuration takes them in the pileup kernel itself (pileup_wave.hpp
 IN = 1: the reads of a wave's records come from the tile's slice of the offsets); every other configuration, more than two
 runs and the pass's fallbacks unpack them to coordinate columns first.  Bar: bit-exact.
 """

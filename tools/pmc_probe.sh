@@ -30,9 +30,7 @@ for name in ("sq1","sq2","tcc1","tcc2"):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
             if "pileup" in kn:
-                # pileup_fast_kernel<CAP, NSEG, U, MINW, DIAG, EXTRA, OW>: the sixth template argument tells the instantiations apart
-                targs = kn.split("<", 1)[1].split(">", 1)[0].split(",") if "<" in kn else []
-                tag = "wave" if "pileup_wave" in kn else ("general" if "pileup_fast" not in kn else ("extra" if len(targs) > 5 and targs[5].strip() in ("true", "1") else "regular"))
+                tag = "wave" if "pileup_wave" in kn else "deep"
                 agg[(tag, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for k, v in sorted(agg.items()):
         print(f"{name:5s} {k[0]:8s} {k[1]:24s} n={len(v)} mean={sum(v)/len(v):.4g}")

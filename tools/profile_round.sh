@@ -12,12 +12,12 @@ python3 - <<PY
 import csv, glob, json, collections
 tag = "$TAG"
 def pileup_mean(d, counter):
-    # per pass: pileup_fast_kernel + the general pileup_kernel that walks the remaining tiles (means per launch, summed)
+    # per pass: pileup_wave_kernel (+ pileup_deep_kernel, which finds its list empty on the bench sets): means per launch, summed
     v = collections.defaultdict(list)
     for f in glob.glob(f"gpurun_out/{tag}/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if "pileup" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                v[r["Kernel_Name"]].append(float(r["Counter_Value"]))     # (regular tiles, extra tiles, general kernel: one launch each per pass)
+                v[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return sum(sum(x) / len(x) for x in v.values()) if v else None
 fetch, write = pileup_mean("pmc_fetch", "FETCH_SIZE"), pileup_mean("pmc_write", "WRITE_SIZE")
 print("FETCH_SIZE", fetch, "WRITE_SIZE", write)
@@ -27,7 +27,7 @@ if fetch is not None and write is not None:
     traffic = (2 * fetch + write) * 1024
     json.dump({"hbm_bytes_per_launch": traffic, "fetch_size_kib": fetch, "write_size_kib": write,
                "records_per_gpu": b["config"]["records_per_gpu"], "kernel_source_hash": b["roofline"]["kernel_source_hash"],
-               "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), every pileup kernel of a pass (regular tiles, extra tiles), means per launch summed; "
+               "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), the pileup kernels of a pass (pileup_wave_kernel + the empty pileup_deep_kernel), means per launch summed; "
                          f"bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section; session {tag} (gpurun_out/{tag}/pmc_traffic.json, kept as profiles/{tag}_pmc_traffic.json)",
                "session": tag},
               open(f"gpurun_out/{tag}/pmc_traffic.json", "w"), indent=1)
