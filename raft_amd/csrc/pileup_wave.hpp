@@ -96,6 +96,9 @@ __device__ __forceinline__ int wave_shl1(int v, int last)      // lane l takes l
 // stores gave 2.05-2.22, the pass 1.5 % shorter.  Write-through (`sc1`: the line is dropped from the L2 at once) fetched 8 % less
 // and took 12 % longer; the packed encodings (a quarter / an eighth of the bytes) gain nothing from `nt` and stay plain.
 template <int OW> struct CovAux { static constexpr int v = OW == 4 ? 2 : 0; };
+// (the record slots' loads stay plain: marked non-temporal like the coverage stores, the column form ran 2-8 % slower in one process --
+// 2.175 / 2.197 against 2.136 / 2.031 ms, three contexts each, tools/lib_ab.py -- and the window-record form the same, 1.571 / 1.567)
+constexpr int kRecAux = 0;
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
@@ -198,16 +201,16 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
             if (IN == 1) {
                 const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_w + p0), 0, bytes, 0x00020000);
 #pragma unroll
-                for (int it = 0; it < ITER; ++it) g.st[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, 0);
+                for (int it = 0; it < ITER; ++it) g.st[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(rw, lane4 + it * 256, 0, kRecAux);
             } else {
                 const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_rid + p0), 0, bytes, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_s + p0), 0, bytes, 0x00020000);
                 const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_e + p0), 0, bytes, 0x00020000);
 #pragma unroll
                 for (int it = 0; it < ITER; ++it) {
-                    g.rid[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(rr, lane4 + it * 256, 0, 0);
-                    g.st[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + it * 256, 0, 0);
-                    g.en[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(re, lane4 + it * 256, 0, 0);
+                    g.rid[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(rr, lane4 + it * 256, 0, kRecAux);
+                    g.st[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + it * 256, 0, kRecAux);
+                    g.en[it * NSEG + s] = __builtin_amdgcn_raw_buffer_load_b32(re, lane4 + it * 256, 0, kRecAux);
                 }
             }
         }
