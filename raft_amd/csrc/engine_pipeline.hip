@@ -999,7 +999,24 @@ static int run_multi_impl(raft_hip_ctx *const *ctxs, int32_t n_ctx, int32_t n_re
                     LANE_TRY(hipStreamWaitEvent(jc->down_stream, jc->lane_down_ev[(size_t)li], 0));
                     stamp(k, "d2h wait set");
                     for (auto &j : job)
-                        if (j.dst && j.bytes) { LANE_TRY(hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, jc->down_stream)); if (trace) stamp(k, "d2h copy"); }
+                        if (j.dst && j.bytes) {
+                            // (trace: a copy call that holds its caller.  In a process's first passes one or two of them take ~7 ms of
+                            // the caller's CPU time each, whatever their size: the runtime picks another SDMA engine when the stream's
+                            // last one is busy, and an engine's first use sets its queue up -- hsa_amd_memory_async_copy_on_engine ->
+                            // a KFD SVM ioctl, profiles/r06_sdma_first_use.txt.  A long-lived context stops seeing them.)
+                            timespec c0{}, c1{};
+                            const auto w0 = std::chrono::steady_clock::now();
+                            if (trace) clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
+                            LANE_TRY(hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, jc->down_stream));
+                            if (trace) {
+                                clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c1);
+                                const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                                if (wall > 0.5)
+                                    fprintf(stderr, "PIPE chunk %2d d2h copy %d of %zu bytes held its caller %.3f ms (thread cpu %.3f ms)\n", k, (int)(&j - job), j.bytes, wall,
+                                            (c1.tv_sec - c0.tv_sec) * 1e3 + (c1.tv_nsec - c0.tv_nsec) * 1e-6);
+                                stamp(k, "d2h copy");
+                            }
+                        }
                     LANE_TRY(hipEventRecord(jc->lane_down_ev[(size_t)li], jc->down_stream));
                 }
                 stamp(k, "d2h queued");

@@ -440,26 +440,42 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 if (left > 0) one(g.rid[u], g.st[u], g.en[u], lane < left);
             }
             if (cur.more) {
-                // records behind the slots: streamed until an id at or beyond the tile's last read (or the range's end) says stop,
-                // the next 64 in flight while these are piled up
+                // records behind the slots: streamed until an id at or beyond the tile's last read (or the range's end) says stop, in
+                // groups of kStream batches of 64 whose loads go out together (the slots' registers are free by now): one latency per
+                // group.  One batch ahead of the one piled up, as until round 6, left a tile of ultralong reads -- ~830 records where
+                // the slots hold 512 -- waiting out a load's latency six times over.  (Loads carried across the loop's back edge
+                // -- a ring of batches -- are waited for as if they were the youngest: the compiler's wait counts do not survive
+                // the merge.)  Raw buffer loads: the range's end is the descriptor's.
+                constexpr int kStream = NSEG <= 2 ? 4 : 2;
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) {
                     if (!open_run[s]) continue;
-                    const long long base = (long long)cur.lo[s];
                     const int limit = avail_s[s];
+                    const unsigned bytes = (unsigned)max(limit, 0) * 4u;
+                    const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_rid + cur.lo[s]), 0, bytes, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t qs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_s + cur.lo[s]), 0, bytes, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t qe = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_e + cur.lo[s]), 0, bytes, 0x00020000);
                     int i0 = ITER * 64, total = cur.cnt[s];
-                    int rA = 0x7fffffff, sA = 0, eA = 0;
-                    if (i0 + lane < limit) { rA = (a.iv_rid + base)[i0 + lane]; sA = (a.iv_s + base)[i0 + lane]; eA = (a.iv_e + base)[i0 + lane]; }
-                    while (i0 < limit) {
-                        const int i1 = i0 + 64;
-                        int rB = 0x7fffffff, sB = 0, eB = 0;
-                        if (i1 + lane < limit) { rB = (a.iv_rid + base)[i1 + lane]; sB = (a.iv_s + base)[i1 + lane]; eB = (a.iv_e + base)[i1 + lane]; }
-                        const bool mine = i0 + lane < limit && rA < r_b;           // (sorted: a prefix of the lanes)
-                        const int n = (int)__popcll(__ballot(mine));
-                        one(rA, sA, eA, mine);
-                        total += n;
-                        if (n < 64) break;
-                        rA = rB; sA = sB; eA = eB; i0 = i1;
+                    bool go = i0 < limit;
+                    while (go) {
+                        int rq[kStream], sq[kStream], eq[kStream];
+#pragma unroll
+                        for (int d = 0; d < kStream; ++d) {
+                            const int vo = (i0 + d * 64 + lane) * 4;
+                            rq[d] = __builtin_amdgcn_raw_buffer_load_b32(qr, vo, 0, kRecAux);
+                            sq[d] = __builtin_amdgcn_raw_buffer_load_b32(qs, vo, 0, kRecAux);
+                            eq[d] = __builtin_amdgcn_raw_buffer_load_b32(qe, vo, 0, kRecAux);
+                        }
+#pragma unroll
+                        for (int d = 0; d < kStream; ++d) {
+                            if (!go) continue;
+                            const bool mine = i0 + lane < limit && rq[d] < r_b;        // (sorted: a prefix of the lanes)
+                            const int n = (int)__popcll(__ballot(mine));
+                            one(rq[d], sq[d], eq[d], mine);
+                            total += n;
+                            i0 += 64;
+                            if (n < 64 || i0 >= limit) go = false;
+                        }
                     }
                     cur.cnt[s] = total;
                 }
@@ -513,17 +529,18 @@ __device__ __forceinline__ void wave_tile_loop(WaveSmem<SLOTS> &sm, const TileCu
                 // (the lanes behind the tile's count hold the next tile's records: an empty word piles nothing up)
                 if (cur.cnt[s] > i0) one_w(read_of(s, i0, i0 + lane), i0 + lane < cur.cnt[s] ? (unsigned)g.st[u] : 0u);
             }
-            if (cur.more) {                      // records beyond the slots: streamed, the next 64 in flight while these are piled up
+            if (cur.more) {                      // records beyond the slots: streamed, in groups of kStream batches of 64 whose loads go out together
+                constexpr int kStream = 4;
 #pragma unroll
                 for (int s = 0; s < NSEG; ++s) {
-                    const long long base = (long long)cur.lo[s];
-                    int i0 = ITER * 64;
-                    unsigned wA = i0 + lane < cur.cnt[s] ? (a.iv_w + base)[i0 + lane] : 0u;
-                    while (i0 < cur.cnt[s]) {
-                        const int i1 = i0 + 64;
-                        const unsigned wB = i1 + lane < cur.cnt[s] ? (a.iv_w + base)[i1 + lane] : 0u;
-                        one_w(read_of(s, i0, i0 + lane), wA);
-                        wA = wB; i0 = i1;
+                    const __amdgpu_buffer_rsrc_t qw = __builtin_amdgcn_make_buffer_rsrc((void *)(a.iv_w + cur.lo[s]), 0, (unsigned)max(cur.cnt[s], 0) * 4u, 0x00020000);
+                    for (int i0 = ITER * 64; i0 < cur.cnt[s]; i0 += kStream * 64) {
+                        unsigned wq[kStream];
+#pragma unroll
+                        for (int d = 0; d < kStream; ++d) wq[d] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(qw, (i0 + d * 64 + lane) * 4, 0, kRecAux);
+#pragma unroll
+                        for (int d = 0; d < kStream; ++d)      // (a lane behind the count: 0 from the descriptor's range check -- an empty word)
+                            if (i0 + d * 64 < cur.cnt[s]) one_w(read_of(s, i0 + d * 64, i0 + d * 64 + lane), wq[d]);
                     }
                 }
             }

@@ -13,6 +13,7 @@
 //     only and is skipped when it has fewer than 10 fields; numeric fields go through strtol.
 #include "../../include/raft_host.h"
 
+#include <emmintrin.h>
 #include <zlib.h>
 
 #include <fcntl.h>
@@ -273,16 +274,32 @@ bool inflate_bgzf_parallel(const char *path, std::unique_ptr<char[]> &out, size_
 }
 
 // ---- name table: open addressing over (offset, length) into one arena ---------------------------
+// Read names -> ids.  Open addressing over 16-byte slots that hold what a lookup needs next to each other: 32 bits of the
+// hash, the id, and where the name lies in the arena.  A PAF line looks its target name up in a table of 10^5..10^7 names -- a miss
+// in every cache level that matters -- so the dependent loads are the cost: slot, then the name's bytes (compared in full: the
+// hash only decides where to look).  (Until round 6: slot -> length -> offset -> bytes, four misses and a bytewise hash,
+// 160 of the tokeniser's 230 ns per record.)
 class NameTable {
 public:
-    int32_t find(const char *s, size_t n) const
+    int32_t find(const char *s, size_t n) const { return find_hashed(hash(s, n), s, n); }
+    // a lookup in three steps, so that a caller with several names in hand can have their cache misses overlap:
+    // hash() + prefetch_slot(), then prefetch_name(), then find_hashed()
+    void prefetch_slot(unsigned long long hv) const { if (!slots_.empty()) __builtin_prefetch(&slots_[(size_t)hv & (slots_.size() - 1)]); }
+    void prefetch_name(unsigned long long hv) const
+    {
+        if (slots_.empty()) return;
+        const Slot &e = slots_[(size_t)hv & (slots_.size() - 1)];
+        if (e.id >= 0) __builtin_prefetch(arena_.data() + e.off);
+    }
+    int32_t find_hashed(unsigned long long hv, const char *s, size_t n) const
     {
         if (slots_.empty()) return -1;
-        size_t h = hash(s, n) & (slots_.size() - 1);
+        const uint32_t tag = (uint32_t)(hv >> 32);
+        size_t h = (size_t)hv & (slots_.size() - 1);
         for (;;) {
-            const int32_t id = slots_[h];
-            if (id < 0) return -1;
-            if (len_[id] == n && memcmp(arena_.data() + off_[id], s, n) == 0) return id;
+            const Slot &e = slots_[h];
+            if (e.id < 0) return -1;
+            if (e.tag == tag && e.len == n && memcmp(arena_.data() + e.off, s, n) == 0) return e.id;
             h = (h + 1) & (slots_.size() - 1);
         }
     }
@@ -302,28 +319,47 @@ public:
     size_t name_len(int32_t id) const { return len_[id]; }
     size_t size() const { return off_.size(); }
 
-private:
-    static size_t hash(const char *s, size_t n)
+    // eight bytes at a time (multiply, fold), the tail zero-extended: any 64-bit mixing does, equal strings hash equal
+    static unsigned long long hash(const char *s, size_t n)
     {
-        unsigned long long h = 1469598103934665603ull;
-        for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)s[i]; h *= 1099511628211ull; }
-        return (size_t)(h ^ (h >> 29));
+        unsigned long long h = 0x9e3779b97f4a7c15ull ^ (unsigned long long)n;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            unsigned long long w;
+            memcpy(&w, s + i, 8);
+            h = (h ^ w) * 0xff51afd7ed558ccdull;
+            h ^= h >> 32;
+        }
+        if (i < n) {
+            unsigned long long w = 0;
+            memcpy(&w, s + i, n - i);
+            h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
+            h ^= h >> 32;
+        }
+        h *= 0xff51afd7ed558ccdull;
+        return h ^ (h >> 29);
     }
+private:
+    struct Slot { uint32_t tag; int32_t id; uint64_t off : 40, len : 24; };
+    static_assert(sizeof(Slot) == 16, "one slot, one aligned 16 bytes");
     void place(int32_t id)
     {
-        size_t h = hash(arena_.data() + off_[id], len_[id]) & (slots_.size() - 1);
-        while (slots_[h] >= 0) h = (h + 1) & (slots_.size() - 1);
-        slots_[h] = id;
+        const unsigned long long hv = hash(arena_.data() + off_[id], len_[id]);
+        size_t h = (size_t)hv & (slots_.size() - 1);
+        while (slots_[h].id >= 0) h = (h + 1) & (slots_.size() - 1);
+        slots_[h].tag = (uint32_t)(hv >> 32); slots_[h].id = id; slots_[h].off = off_[id]; slots_[h].len = len_[id];
     }
     void grow()
     {
         const size_t n = slots_.empty() ? 1024 : slots_.size() * 2;
-        slots_.assign(n, -1);
+        Slot empty{};
+        empty.id = -1;
+        slots_.assign(n, empty);
         for (int32_t id = 0; id < (int32_t)off_.size(); ++id) place(id);
     }
     std::string arena_;
     std::vector<size_t> off_, len_;
-    std::vector<int32_t> slots_;
+    std::vector<Slot> slots_;
 };
 
 // chop.hpp:101: ^read=[0-9]+,[a-z]+,position=[0-9]+-[0-9]+,length=[0-9]+,(.*)  (whole-name match)
@@ -451,7 +487,6 @@ struct raft_host_text {                  // a file's bytes in memory (inflated i
 };
 
 struct raft_host_paf {
-    std::vector<std::vector<int32_t>> scratch;   // the tokeniser's per-worker columns, kept so that nobody pays for unmapping them in between
     std::unique_ptr<int32_t[]> col[6];   // allocated untouched: the workers' copies are the first writes
     size_t n = 0;
     int symmetric = 0;                   // chop.hpp:175-184: some record after the first mirrors the first
@@ -845,7 +880,7 @@ int raft_host_paf_parse(raft_host_text *text, const raft_host_reads *reads, raft
     char *const data = text->buf.get();     // (tokenised in place: the text is consumed)
     // Lines are independent: the buffer is cut at newlines into one chunk per thread, each chunk is tokenised into
     // its own columns (paf.hpp:50-87 rules), and the chunks are concatenated in file order.
-    struct Chunk { std::vector<int32_t> col[6]; size_t err_pos = (size_t)-1; std::string err_name; bool mirror = false; };
+    struct Chunk { size_t lines = 0, n = 0; size_t err_pos = (size_t)-1; std::string err_name; bool mirror = false; };
     const size_t total = data_n;
     auto num = [](const char *s) -> int32_t {
         // paf.hpp:64-75 -> chop.hpp:157-160: strtol, then uint32, then int.  Plain runs of up to 18 digits (every
@@ -898,8 +933,27 @@ int raft_host_paf_parse(raft_host_text *text, const raft_host_reads *reads, raft
         cut[t] = nl ? (size_t)(nl - data) + 1 : total;
     }
     std::vector<Chunk> chunks((size_t)T);
+    // The columns are allocated once, for as many records as there are lines, and every worker writes its records where they
+    // belong: a pass that only counts newlines tells where that is.  (Until round 6 every worker filled vectors of its own, which
+    // were then copied together: twice the pages touched, 24 more bytes moved per record.)  Lines that are not records -- fewer
+    // than ten fields, paf.hpp:84-85 -- leave gaps, closed afterwards; a PAF has none.
+    parallel_for(T, [&](int t) {
+        size_t c = 0, i = cut[t];
+        const size_t end = cut[t + 1];
+        const __m128i vn = _mm_set1_epi8('\n');
+        for (; i + 16 <= end; i += 16)
+            c += (size_t)__builtin_popcount((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(data + i)), vn)));
+        for (; i < end; ++i) c += data[i] == '\n';
+        chunks[(size_t)t].lines = c;
+    });
+    std::vector<size_t> off((size_t)T + 1, 0);
+    for (int t = 0; t < T; ++t) off[(size_t)t + 1] = off[(size_t)t] + chunks[(size_t)t].lines;
+    std::unique_ptr<raft_host_paf> P(new raft_host_paf());
+    for (int k = 0; k < 6; ++k) P->col[k].reset(new int32_t[off[(size_t)T] ? off[(size_t)T] : 1]);
     parallel_for(T, [&](int t) {
         Chunk &C = chunks[(size_t)t];
+        int32_t *const out_col[6] = {P->col[0].get() + off[(size_t)t], P->col[1].get() + off[(size_t)t], P->col[2].get() + off[(size_t)t],
+                                     P->col[3].get() + off[(size_t)t], P->col[4].get() + off[(size_t)t], P->col[5].get() + off[(size_t)t]};
         const char *lastq = nullptr, *lastt = nullptr;
         size_t lastq_n = 0, lastt_n = 0;
         int32_t lastq_id = -1, lastt_id = -1;
@@ -909,42 +963,99 @@ int raft_host_paf_parse(raft_host_text *text, const raft_host_reads *reads, raft
             if (id >= 0) { cs = s; cn = n; cid = id; }
             return id;
         };
-        size_t pos = cut[t];
+        const size_t pos0 = cut[t];
         const size_t end = cut[t + 1];
-        for (auto &v : C.col) v.reserve((end - pos) / 48 + 16);     // a PAF line rarely has fewer than 48 bytes
-        while (pos < end) {
-            char *line = data + pos;
-            char *nl = (char *)memchr(line, '\n', end - pos);
-            if (!nl) break;
-            size_t len = (size_t)(nl - line);
-            const bool is_last_sentinel = (size_t)(nl - data) == total - 1;
-            const size_t line_pos = pos;
-            pos += len + 1;
-            if (is_last_sentinel && len == 0) break;     // the newline we appended after a file that ended in '\n'
-            if (len > 1 && line[len - 1] == '\r') --len;
-            // split on TAB only (paf.hpp:56-58)
-            char *fld[11];
-            size_t fl[11];
-            int nf = 0;
-            char *q = line;
-            for (size_t i = 0; i <= len; ++i) {
-                if (i < len && line[i] != '\t') continue;
-                if (nf < 11) { fld[nf] = q; fl[nf] = (size_t)(line + i - q); }
-                line[i] = '\0';
-                ++nf;
-                q = line + i + 1;
+        // One pass over the bytes finds tabs and newlines sixteen at a time (SSE2: every x86-64 has it); a line is handed on when
+        // its newline turns up, as the positions of its first ten tabs.  Split on TAB only (paf.hpp:56-58); nothing is written
+        // into the text.  (Until round 6: memchr for the newline, then a byte loop for the tabs -- 80 of the tokeniser's 230 ns
+        // per record.)
+        auto field_num = [&](size_t b, size_t e) -> int32_t {
+            // one to eight digits and nothing else -- every coordinate of a real PAF: eight bytes at once, the bytes before the
+            // field replaced by '0'
+            const size_t L = e - b;
+            if (L - 1 < 8 && e >= 8) {
+                unsigned long long w;
+                memcpy(&w, data + e - 8, 8);
+                const unsigned long long low = L == 8 ? 0ull : ((1ull << ((8 - L) * 8)) - 1ull);
+                w = (w & ~low) | (0x3030303030303030ull & low);
+                const unsigned long long d = w - 0x3030303030303030ull;
+                if (((d | (d + 0x7676767676767676ull) | w) & 0x8080808080808080ull) == 0ull) {
+                    unsigned long long x = (d * 2561ull) >> 8;
+                    x = ((x & 0x00ff00ff00ff00ffull) * 6553601ull) >> 16;
+                    return (int32_t)(uint32_t)(((x & 0x0000ffff0000ffffull) * 42949672960001ull) >> 32);
+                }
             }
-            if (nf < 10) continue;                        // paf.hpp:84-85: silently skipped
-            const int32_t a = resolve(fld[0], fl[0], lastq, lastq_n, lastq_id);
-            const int32_t b = resolve(fld[5], fl[5], lastt, lastt_n, lastt_id);
-            if (a < 0 || b < 0) { C.err_pos = line_pos; C.err_name = a < 0 ? fld[0] : fld[5]; break; }
-            const int32_t v_qs = num(fld[2]), v_qe = num(fld[3]), v_ts = num(fld[7]), v_te = num(fld[8]);
-            C.col[0].push_back(a); C.col[1].push_back(v_qs); C.col[2].push_back(v_qe);
-            C.col[3].push_back(b); C.col[4].push_back(v_ts); C.col[5].push_back(v_te);
-            if (have0 && a == r0[3] && b == r0[0] && v_ts == r0[1] && v_te == r0[2] && v_qs == r0[4] && v_qe == r0[5] &&
-                line_pos != rec0_pos)
-                C.mirror = true;
+            unsigned long long v = 0;
+            size_t i = b;
+            while (i < e && i - b < 19 && data[i] >= '0' && data[i] <= '9') { v = v * 10 + (unsigned)(data[i] - '0'); ++i; }
+            if (i == b || i - b == 19) return num(std::string(data + b, e - b).c_str());       // blanks, signs, overflow: strtol's rules
+            return (int32_t)(uint32_t)v;       // trailing garbage ends the number, as in strtol
+        };
+        size_t line_start = pos0, tab[10];
+        int nt = 0;
+        bool stop = false;
+        // Lines wait in groups of eight for their target names: the hashes first (each fetching its slot of the name table), then the
+        // slots (each fetching its name's bytes), then the lines in file order -- two cache misses per group where there were two per
+        // line.  The query name is the line before's nearly always (a PAF grouped by query).
+        struct Pending { size_t ls, tab[9]; unsigned long long hv; };
+        constexpr int kGroup = 8;
+        Pending pend[kGroup];
+        int np = 0;
+        auto flush = [&]() {
+            for (int k = 0; k < np; ++k) {
+                Pending &L = pend[k];
+                L.hv = NameTable::hash(data + L.tab[4] + 1, L.tab[5] - L.tab[4] - 1);
+                reads->names.prefetch_slot(L.hv);
+            }
+            for (int k = 0; k < np; ++k) reads->names.prefetch_name(pend[k].hv);
+            for (int k = 0; k < np && !stop; ++k) {
+                const Pending &L = pend[k];
+                char *const q = data + L.ls, *const tn = data + L.tab[4] + 1;
+                const size_t qn = L.tab[0] - L.ls, tnn = L.tab[5] - L.tab[4] - 1;
+                const int32_t a = resolve(q, qn, lastq, lastq_n, lastq_id);
+                int32_t b = lastt_id;
+                if (!(lastt && lastt_n == tnn && memcmp(lastt, tn, tnn) == 0)) {
+                    b = reads->names.find_hashed(L.hv, tn, tnn);
+                    if (b >= 0) { lastt = tn; lastt_n = tnn; lastt_id = b; }
+                }
+                if (a < 0 || b < 0) { C.err_pos = L.ls; C.err_name = a < 0 ? std::string(q, qn) : std::string(tn, tnn); stop = true; break; }
+                const int32_t v_qs = field_num(L.tab[1] + 1, L.tab[2]), v_qe = field_num(L.tab[2] + 1, L.tab[3]);
+                const int32_t v_ts = field_num(L.tab[6] + 1, L.tab[7]), v_te = field_num(L.tab[7] + 1, L.tab[8]);
+                const size_t at = C.n++;
+                out_col[0][at] = a; out_col[1][at] = v_qs; out_col[2][at] = v_qe;
+                out_col[3][at] = b; out_col[4][at] = v_ts; out_col[5][at] = v_te;
+                if (have0 && a == r0[3] && b == r0[0] && v_ts == r0[1] && v_te == r0[2] && v_qs == r0[4] && v_qe == r0[5] && L.ls != rec0_pos)
+                    C.mirror = true;
+            }
+            np = 0;
+        };
+        auto line_done = [&](size_t nl) {
+            const size_t ls = line_start;
+            const int ntabs = nt;
+            line_start = nl + 1; nt = 0;
+            if (ntabs + 1 < 10) return;                   // paf.hpp:84-85: silently skipped
+            Pending &L = pend[np++];
+            L.ls = ls;
+            for (int k = 0; k < 9; ++k) L.tab[k] = tab[k];
+            if (np == kGroup) flush();
+        };
+        auto delim = [&](size_t p) {
+            if (data[p] == '\t') { if (nt < 10) tab[nt] = p; ++nt; }
+            else line_done(p);
+        };
+        size_t i = pos0;
+        const __m128i vt = _mm_set1_epi8('\t'), vn = _mm_set1_epi8('\n');
+        for (; i + 16 <= end && !stop; i += 16) {
+            const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(data + i));
+            unsigned m = (unsigned)_mm_movemask_epi8(_mm_or_si128(_mm_cmpeq_epi8(v, vt), _mm_cmpeq_epi8(v, vn)));
+            while (m && !stop) {
+                delim(i + (size_t)__builtin_ctz(m));
+                m &= m - 1;
+            }
         }
+        for (; i < end && !stop; ++i)
+            if (data[i] == '\t' || data[i] == '\n') delim(i);
+        if (!stop) flush();
     });
     int rc = RAFT_HOST_OK;
     for (const Chunk &C : chunks)                         // the first offending line in file order wins
@@ -954,24 +1065,16 @@ int raft_host_paf_parse(raft_host_text *text, const raft_host_reads *reads, raft
             break;
         }
     if (rc != RAFT_HOST_OK) return rc;
-    raft_host_paf *P = new raft_host_paf();
-    std::vector<size_t> off((size_t)T + 1, 0);
-    for (int t = 0; t < T; ++t) off[(size_t)t + 1] = off[(size_t)t] + chunks[(size_t)t].col[0].size();
-    P->n = off[(size_t)T];
     for (const Chunk &C : chunks) if (C.mirror) P->symmetric = 1;
-    for (int k = 0; k < 6; ++k) P->col[k].reset(new int32_t[P->n ? P->n : 1]);
-    parallel_for(T, [&](int t) {
-        for (int k = 0; k < 6; ++k)
-            if (!chunks[(size_t)t].col[k].empty())
-                memcpy(P->col[k].get() + off[(size_t)t], chunks[(size_t)t].col[k].data(), chunks[(size_t)t].col[k].size() * sizeof(int32_t));
-    });
-    // (the workers' columns -- a GB of touched pages at human scale -- stay with the object until raft_host_paf_free: unmapping them
-    // here took as long as tokenising them, and unmapping them on a thread of their own held the address space's lock against the
-    // page-locking and the engine's pipeline that run next: 0.4 s either way on the 10 GB set.  The CLI never frees: it exits)
-    if (P->n > (1u << 22))
-        for (Chunk &C : chunks)
-            for (auto &v : C.col) if (v.capacity()) P->scratch.push_back(std::move(v));
-    *out = P;
+    size_t n_rec = 0;
+    for (int t = 0; t < T; ++t) {                         // (gaps: lines that were no records)
+        const Chunk &C = chunks[(size_t)t];
+        if (n_rec != off[(size_t)t] && C.n)
+            for (int k = 0; k < 6; ++k) memmove(P->col[k].get() + n_rec, P->col[k].get() + off[(size_t)t], C.n * sizeof(int32_t));
+        n_rec += C.n;
+    }
+    P->n = n_rec;
+    *out = P.release();
     return RAFT_HOST_OK;
 }
 

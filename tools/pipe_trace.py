@@ -22,7 +22,7 @@ out = eng.host_output_buffers(host[0], pinned=True, width=8 if mode.endswith("_d
 if not mode.startswith("columns"):
     off = hostio.group_offsets(reads, host[1], out=torch.empty(4 * (reads + 1), dtype=torch.int64, pin_memory=True).numpy())
     win = hostio.pack_windows(host[2], host[3], 50, out=torch.empty(o.n_rec, dtype=torch.int32, pin_memory=True).numpy().view(np.uint32))
-for it in range(3):
+for it in range(int(os.environ.get("RAFT_TRACE_PASSES", "3"))):
     sys.stderr.write(f"---- pass {it}\n")
     t = time.perf_counter()
     if mode.startswith("columns"):
