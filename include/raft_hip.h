@@ -492,7 +492,8 @@ int  raft_hip_host_unregister(void *ptr);
 int  raft_hip_warm_up(raft_hip_ctx *ctx);
 /* Optional: allocates the device buffers of a coming host-to-host job from what its caller knows early -- the reads' lengths
  * and an estimate of the record count (the CLI: from the size of the overlaps file) -- for a job shared by n_ctx contexts
- * in coverage width cov_width.  Buffers only grow: a short estimate costs what no estimate would have cost. */
+ * in coverage width cov_width, and the page-locked staging a job over plain columns derives its chunks into (three chunks' worth
+ * of window records).  Buffers only grow: a short estimate costs what no estimate would have cost. */
 int  raft_hip_reserve(raft_hip_ctx *ctx, int32_t n_reads, const int32_t *read_len, int64_t n_rec_estimate, int32_t n_ctx,
                       int32_t cov_width);
 

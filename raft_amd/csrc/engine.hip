@@ -538,8 +538,16 @@ int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool verify_in_k
     // eight tiles' worth, its last tenth in ranges of two -- half the boundaries tile_desc_kernel has to look up, and the kernel's end
     // waits for a short draw.  (RAFT_GRADED_QUANTUM=0: uniform, as until round 6.)
     static const bool graded_off = [] { const char *e = getenv("RAFT_GRADED_QUANTUM"); return e && atoi(e) == 0; }();
-    const bool graded = !c->tile_q && !graded_off && B / kTileCap >= 64LL * wave_grid_waves(true) && (B + 7) / 8 + 128 < (1LL << 31);
-    const Quantum qz = graded ? graded_quantum(B, 8 * (int)q1, 2 * (int)q1, 0.9) : uniform_quantum(Q);
+    bool graded = !c->tile_q && !graded_off && B / kTileCap >= 64LL * wave_grid_waves(true) && (B + 7) / 8 + 128 < (1LL << 31);
+    Quantum qz = graded ? graded_quantum(B, 8 * (int)q1, 2 * (int)q1, 0.9) : uniform_quantum(Q);
+    if (const char *e = getenv("RAFT_GRADED")) {        // (experiment: "long,short,frac,min tiles per worker", long / short in halves of a tile's worth)
+        int ql = 4, qs = 2, mt = 8;
+        double fr = 0.75;
+        if (sscanf(e, "%d,%d,%lf,%d", &ql, &qs, &fr, &mt) >= 3 && !c->tile_q && B / kTileCap >= (long long)mt * wave_grid_waves(true) && (B + 7) / 8 + 128 < (1LL << 31)) {
+            graded = true;
+            qz = graded_quantum(B, std::max(128, ql * (int)q1 / 2 / 128 * 128), std::max(128, qs * (int)q1 / 2 / 128 * 128), fr);
+        }
+    }
     const long long n_tiles = qz.n_ranges(B);
 
     if (ow == 4) HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));

@@ -1189,6 +1189,20 @@ int raft_hip_reserve(raft_hip_ctx *c, int32_t n_reads, const int32_t *read_len, 
         const long long per_ctx = (chunks + n_ctx - 1) / n_ctx;
         for (int li = 0; li < std::min<long long>(kLanes, per_ctx); ++li) who.push_back(c->lanes[(size_t)li]);
     } else who.push_back(c);
+    if (chunked) {
+        // ... and the page-locked ring the lanes derive plain columns into (run_multi_impl, DeriveRing): 300 MB for a 4.4e7-record
+        // job, whose page-locking was 50 of the 64 ms that job's engine call took (profiles/r06_s18_cli_s500k.txt: its two chunks
+        // were through after 8 ms)
+        const size_t off_b = ((size_t)kWinMaxRuns * ((size_t)nr + 1) * 8 + 255) & ~(size_t)255;
+        const size_t need = ((off_b + (size_t)nrec * 4 + 255) & ~(size_t)255) * DeriveRing::R;
+        if (need > c->h_stage_cap && !getenv("RAFT_NO_DERIVE")) {
+            HIP_TRY(c, hipSetDevice(c->device));
+            if (c->h_stage) (void)hipHostFree(c->h_stage);
+            c->h_stage = nullptr; c->h_stage_cap = 0;
+            HIP_TRY(c, hipHostMalloc(&c->h_stage, need, hipHostMallocDefault));
+            c->h_stage_cap = need;
+        }
+    }
     std::vector<int64_t> zeros((size_t)nr + 1, 0);
     for (raft_hip_ctx *l : who) {
         HIP_TRY(l, hipSetDevice(l->device));
