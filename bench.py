@@ -240,6 +240,18 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
             # (its chunks are cut elsewhere, so the encoding differs from the prepared-input one where chunks begin: compared decoded)
             same_s = (ss.n_bins, ss.n_repeats, ss.n_fragments, ss.total_coverage, ss.total_repeat_length) == psum and \
                 all(np.array_equal(pcopy[k], sres[k]) for k in pcopy if k != "cov8") and d4_equals_bytes(sres, ss.n_bins)
+            # ... and what a caller that prepares pays for its first job (the CLI's way: raft_hip_warm_up + raft_hip_reserve beside the
+            # tokenising, outside this clock): a fresh context's first call
+            e_res = engine.Engine(pe, device=torch.cuda.current_device())
+            e_res.set_tuning(args.tile_bins, args.force_bucket)
+            e_res.warm_up()
+            e_res.reserve(host[0], o.n_rec, 1, 8)
+            t0 = time.perf_counter()
+            rres, rs = e_res.run_pipelined(host[0], host[1], host[2], host[3], out=out4)
+            first_reserved = time.perf_counter() - t0
+            same_r = (rs.n_bins, rs.n_repeats, rs.n_fragments, rs.total_coverage, rs.total_repeat_length) == psum
+            del rres
+            e_res.close()
             # ... and the same boundary with the two derivations as calls of the host library in front of the engine (round 4's first form)
             off_buf = torch.empty(4 * (o.n_reads + 1), dtype=torch.int64, pin_memory=True).numpy()
             xt = []
@@ -254,6 +266,7 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
                 xt.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
             xm = min(xt)
             wrec["from_soa"] = {"records_per_s": o.n_rec / ssec, "fragments_per_s": ss.n_fragments / ssec, "seconds": ssec, "first_pass_s": stimes[0],
+                                "first_pass_after_reserve_s": first_reserved, "first_pass_after_reserve_equals": bool(same_r),
                                 "equals_prepared_input": bool(same_s), "h2d_bytes": host[0].nbytes + 8 * 2 * (o.n_reads + 1) + 4 * o.n_rec,
                                 "explicit_host_calls": {"seconds": xm[0], "group_offsets_s": xm[1], "pack_windows_s": xm[2], "engine_s": xm[3]},
                                 "boundary": "page-locked int32 columns (read_len, qid, qs, qe) + the tokeniser's symmetric flag in; repeats, fragments and "
@@ -320,6 +333,8 @@ def e2e_leg(args, torch, engine, hostio, o, p, n_iter=3):
             top = dict(top, **{k: wrec["from_soa"][k] for k in ("records_per_s", "fragments_per_s", "seconds")})
             top["mode"] = "SoA boundary: " + wrec["from_soa"]["boundary"]
         res["byte_per_window_d2h_bytes"] = res["d2h_bytes"]
+        if "first_pass_after_reserve_s" in wrec.get("from_soa", {}):
+            res["first_pass_after_reserve_s"] = wrec["from_soa"]["first_pass_after_reserve_s"]
         res.update(records_per_s=top["records_per_s"], fragments_per_s=top["fragments_per_s"], seconds=top["seconds"], mode=top["mode"],
                    h2d_bytes=wrec["h2d_bytes"], d2h_bytes=top.get("d2h_bytes", res["d2h_bytes"]), window_records=wrec)
     return res

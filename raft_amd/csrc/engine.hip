@@ -528,26 +528,21 @@ int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool verify_in_k
     c->cap_rep = RU; c->cap_cut = CU;
     if (RU >= (1LL << 31)) return RAFT_HIP_ERR_TOO_LARGE;   // reserved raw-repeat slots are indexed with 32 bits in LDS
     // The quantum: boundaries at which a worker of the pileup kernel may begin (it cuts its tiles itself; tile_desc_kernel finds each
-    // boundary's first read, records and window).  Three tiles' worth (four until round 5: the kernel likes short ranges -- 2.42 / 2.45 /
-    // 2.49 / 2.56 ms at two / three / four / eight tiles' worth in one context -- and tile_desc_kernel long ones; the pass is shortest
-    // at three, profiles/r05_quantum_sweep.txt), but never so few ranges that workers stay without one (a 50 k-read set) or that the
-    // last draws of the kernel are a fifth of its duration (an eighth of the human-scale set: two tiles' worth)
+    // boundary's first read, records and window).  Three tiles' worth (four until round 5: on the human-scale set the kernel likes
+    // short ranges -- 2.42 / 2.45 / 2.49 / 2.56 ms at two / three / four / eight tiles' worth in one context -- and tile_desc_kernel
+    // long ones; the pass is shortest at three, profiles/r05_quantum_sweep.txt).  Smaller sets keep the three tiles' worth down to
+    // two ranges per worker, and two tiles' worth below that: a draw is an atomic and two boundary records a worker waits for, and
+    // with five to fifteen tiles per worker those waits cost more than the kernel's last draws do (profiles/r06_quantum_small_sets.txt:
+    // an eighth of the human-scale set 0.424 -> 0.410 ms per step, 200 k reads 0.289 -> 0.276, 50 k reads 0.186 -> 0.178; until
+    // round 6 such sets were cut into eight ranges per worker or single tiles' worth).
     const long long q3 = 3LL * (kTileCap / 128) * 128, q1 = (kTileCap / 128) * 128;
-    const int Q = c->tile_q ? std::max(256, c->tile_q) : (int)std::max(q1, std::min(q3, (B / (8LL * wave_grid_waves(true))) / 128 * 128));
+    const int Q = c->tile_q ? std::max(256, c->tile_q) : (int)std::max(2 * q1, std::min(q3, (B / (2LL * wave_grid_waves(true))) / 128 * 128));
     // A set with many tiles per worker gets a GRADED quantum (raft_types.hpp Quantum): most of each eighth of the set in ranges of
     // eight tiles' worth, its last tenth in ranges of two -- half the boundaries tile_desc_kernel has to look up, and the kernel's end
     // waits for a short draw.  (RAFT_GRADED_QUANTUM=0: uniform, as until round 6.)
     static const bool graded_off = [] { const char *e = getenv("RAFT_GRADED_QUANTUM"); return e && atoi(e) == 0; }();
-    bool graded = !c->tile_q && !graded_off && B / kTileCap >= 64LL * wave_grid_waves(true) && (B + 7) / 8 + 128 < (1LL << 31);
-    Quantum qz = graded ? graded_quantum(B, 8 * (int)q1, 2 * (int)q1, 0.9) : uniform_quantum(Q);
-    if (const char *e = getenv("RAFT_GRADED")) {        // (experiment: "long,short,frac,min tiles per worker", long / short in halves of a tile's worth)
-        int ql = 4, qs = 2, mt = 8;
-        double fr = 0.75;
-        if (sscanf(e, "%d,%d,%lf,%d", &ql, &qs, &fr, &mt) >= 3 && !c->tile_q && B / kTileCap >= (long long)mt * wave_grid_waves(true) && (B + 7) / 8 + 128 < (1LL << 31)) {
-            graded = true;
-            qz = graded_quantum(B, std::max(128, ql * (int)q1 / 2 / 128 * 128), std::max(128, qs * (int)q1 / 2 / 128 * 128), fr);
-        }
-    }
+    const bool graded = !c->tile_q && !graded_off && B / kTileCap >= 64LL * wave_grid_waves(true) && (B + 7) / 8 + 128 < (1LL << 31);
+    const Quantum qz = graded ? graded_quantum(B, 8 * (int)q1, 2 * (int)q1, 0.9) : uniform_quantum(Q);
     const long long n_tiles = qz.n_ranges(B);
 
     if (ow == 4) HIP_TRY(c, c->cov.ensure((size_t)std::max(B, 1LL) * 4));

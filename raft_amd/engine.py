@@ -248,6 +248,17 @@ class Engine:
         """Opt in to the coverage array's placement trial at the context's first large pass: 2..8 candidate arrays, 0 = off (the default)."""
         self._check(self._lib.raft_hip_set_placement_trial(self._ctx, candidates))
 
+    def warm_up(self):
+        """raft_hip_warm_up: the engine's code on the device, the pipeline's lanes -- what a context's first host-to-host job would
+        otherwise pay inside its own clock."""
+        self._check(self._lib.raft_hip_warm_up(self._ctx))
+
+    def reserve(self, read_len, n_rec_estimate: int, n_ctx: int = 1, cov_width: int = 1):
+        """raft_hip_reserve: device buffers and page-locked staging of a coming host-to-host job, from the reads' lengths and an
+        estimate of the record count (cov_width: 1, 2 or 8 = four-bit steps)."""
+        rl = np.ascontiguousarray(np.asarray(read_len), dtype=np.int32)
+        self._check(self._lib.raft_hip_reserve(self._ctx, rl.size, C.c_void_p(rl.ctypes.data if rl.size else 0), int(n_rec_estimate), int(n_ctx), int(cov_width)))
+
     def placement_trial(self):
         """(first_ms, best_other_ms, kept) of the coverage array's placement trial -- kept: 0 the first placement, 1 a plain block, 2 another
         chunk mapping -- or None when none has run (raft_hip_placement_trial)."""
