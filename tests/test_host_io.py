@@ -543,3 +543,72 @@ def test_delta4_decoder_and_writer(tmp_path, threads):
             hostio.unpack_coverage_d4(3000, nib, anchor, np.array([5], np.int64), np.array([1], np.int32))
     finally:
         hostio.set_threads(0)
+
+
+# ---- the tokeniser's fast paths (round 6: sixteen bytes at a time, eight digits at a time, names in groups of eight, columns written in
+# place) against a plain restatement of paf.hpp:50-87 + chop.hpp:157-160, on a text large enough for several workers ----------------
+
+def _strtol_as_int32(field: str) -> int:
+    """strtol(field, NULL, 10) -> uint32 -> int, as the reference converts a coordinate (chop.hpp:157-160)."""
+    m = re.match(r"[ \t\n\v\f\r]*([+-]?)(\d*)", field)
+    if not m or not m.group(2):
+        return 0
+    v = int(m.group(2))
+    v = min(v, 2 ** 63 - 1 if m.group(1) != "-" else 2 ** 63)          # strtol saturates
+    if m.group(1) == "-":
+        v = -v
+    v &= 0xffffffff
+    return v - (1 << 32) if v >= (1 << 31) else v
+
+
+@pytest.mark.parametrize("threads", [1, 2, 7])
+def test_paf_tokeniser_fast_paths_against_the_rules(tmp_path, threads):
+    rng = np.random.default_rng(20241008 + threads)
+    n = 300
+    names = [f"m64011_{i}/{int(rng.integers(1, 10 ** 6))}/ccs" if i % 3 else f"r{i}" for i in range(n)]
+    with open(tmp_path / "r.fa", "w") as f:
+        for nm in names:
+            f.write(f">{nm}\nACGT\n")
+    odd_numbers = ["", " 7", "+12", "-5", "12x", "x12", "00000000000000000042", "99999999999999999999", "4294967295", "2147483648", "123456789", "0"]
+    lines, want = [], [[] for _ in range(6)]
+    for k in range(60000):
+        q, t = int(rng.integers(0, n)), int(rng.integers(0, n))
+        if k % 5:                                     # (a PAF grouped by query: the line before's name, mostly)
+            q = prev_q
+        prev_q = q
+        f4 = [str(int(rng.integers(0, 10 ** int(rng.integers(1, 9))))) for _ in range(4)]
+        if k % 97 == 0:
+            f4[int(rng.integers(0, 4))] = odd_numbers[int(rng.integers(0, len(odd_numbers)))]
+        fields = [names[q], "100", f4[0], f4[1], "+", names[t], "100", f4[2], f4[3], "5", "6", "60"]
+        kind = k % 211
+        if kind == 0:
+            fields = fields[:int(rng.integers(1, 10))]             # fewer than ten fields: no record (paf.hpp:84-85)
+        elif kind == 1:
+            fields = fields[:10]                                    # exactly ten
+        elif kind == 2:
+            fields += ["tp:A:P", "cm:i:9"]                          # more than eleven
+        eol = "\r\n" if k % 389 == 0 else "\n"
+        lines.append("\t".join(fields) + eol)
+        if len(fields) >= 10:
+            for c, v in zip(range(6), (q, _strtol_as_int32(f4[0]), _strtol_as_int32(f4[1]), t, _strtol_as_int32(f4[2]), _strtol_as_int32(f4[3]))):
+                want[c].append(v)
+    if threads == 2:
+        lines[-1] = lines[-1].rstrip("\r\n")                        # a last line without its newline
+    text = "".join(lines)
+    assert len(text) > (1 << 21)                                    # (several workers: the loader uses one below 1 MB)
+    (tmp_path / "o.paf").write_text(text)
+    try:
+        hostio.set_threads(threads)
+        reads = hostio.Reads(str(tmp_path / "r.fa"))
+        got = hostio.load_paf(str(tmp_path / "o.paf"), reads)
+        for c in range(6):
+            assert np.array_equal(got[c], np.asarray(want[c], np.int64).astype(np.int32)), c
+        # an unknown name in the middle of the text: reported, whichever worker and group of lines meets it
+        bad = lines[:40000] + ["nobody\t1\t2\t3\t+\t" + names[0] + "\t1\t2\t3\t4\t5\t6\n"] + lines[40000:]
+        (tmp_path / "bad.paf").write_text("".join(bad))
+        with pytest.raises(hostio.HostError) as e:
+            hostio.load_paf(str(tmp_path / "bad.paf"), reads)
+        assert e.value.code == hostio.ERR_UNKNOWN_NAME and e.value.what == "nobody"
+        reads.close()
+    finally:
+        hostio.set_threads(0)
