@@ -106,6 +106,49 @@ def test_wave_kernel_four_runs_and_window_records():
     eng.close()
 
 
+@pytest.mark.parametrize("two_runs", [False, True])
+def test_records_behind_the_slots_stream_in_groups(two_runs):
+    """A tile holds 256 records of a run in its prefetch slots (320 as window records); what lies behind them streams in groups of
+    four batches of 64 (pileup_wave.hpp `cur.more`).  One read per tile, with record counts on every side of the slots' end, of a
+    batch's and of a group's: columns and window records, one run and two, against the oracle."""
+    from raft_amd import engine, hostio
+    rng = np.random.default_rng(606 + two_runs)
+    edges = [0, 1, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 258, 300, 319, 320, 321, 383, 384, 385, 511, 512, 513, 575, 576, 577,
+             639, 640, 641, 767, 768, 769, 831, 832, 833, 1023, 1024, 1025, 1100, 1279, 1280, 1281, 1500]
+    counts = edges + [int(x) for x in rng.integers(0, 1400, 40)]
+    n = len(counts)
+    read_len = rng.integers(150_000, 200_000, n).astype(np.int32)        # 3000 .. 4000 windows: one read per tile
+    runs = []
+    for r in range(2 if two_runs else 1):
+        k = counts if r == 0 else list(reversed(counts))
+        qid = np.repeat(np.arange(n, dtype=np.int32), k)
+        L = read_len[qid].astype(np.int64)
+        a, b = (rng.random(qid.size) * L).astype(np.int64), (rng.random(qid.size) * L).astype(np.int64)
+        runs.append((qid, np.minimum(a, b).astype(np.int32), np.minimum(np.maximum(a, b) + 1, L).astype(np.int32)))
+    qid, qs, qe = (np.concatenate([r[k] for r in runs]) for k in range(3))
+    cols = [read_len, qid, qs, qe, qid.copy(), qs.copy(), qe.copy()]     # (target = query: nothing beside the query sides to pile up)
+    p = RaftParams(est_cov=30, symmetric_mode=1)
+    want = oracle_run(RaftParams(est_cov=30), *cols)
+    eng = engine.Engine(p, device=0)
+    try:
+        got, s = engine_result(eng, cols[:4] + [None, None, None])
+        got["symmetric"] = want["symmetric"]
+        assert s.interval_path == 0 and s.n_segments == (2 if two_runs else 1)
+        assert_same_result(got, want, "columns")
+        off = hostio.group_offsets(n, qid)
+        win = hostio.pack_windows(qs, qe, 50)
+        for width in (4, 1, 8):
+            eng.set_output_width(width)
+            eng.run_host_windows(read_len, off, win)
+            s = eng.finish()
+            g = eng.fetch()
+            g.update(symmetric=want["symmetric"], high_cov=s.high_cov, total_coverage=s.total_coverage, total_windows=s.total_windows,
+                     total_repeat_length=s.total_repeat_length, total_read_length=s.total_read_length)
+            assert_same_result(g, want, f"window records, width {width}")
+    finally:
+        eng.close()
+
+
 def test_a_tile_too_deep_for_sixteen_bits_goes_to_the_deep_kernel():
     """40,000 intervals on one read: the wave kernel lists the tile and pileup_deep_kernel piles it up in the same pass -- coverage
     40,000 in the middle of the read, as the oracle has it."""
