@@ -137,7 +137,7 @@ def test_records_behind_the_slots_stream_in_groups(two_runs):
         assert_same_result(got, want, "columns")
         off = hostio.group_offsets(n, qid)
         win = hostio.pack_windows(qs, qe, 50)
-        for width in (4, 1, 8):
+        for width in (4, 1, 2, 8):                   # (2: the two-byte encoding's 8-byte stores with a scalar offset, on every tile's edge rows)
             eng.set_output_width(width)
             eng.run_host_windows(read_len, off, win)
             s = eng.finish()
