@@ -132,6 +132,24 @@ struct GuessBeside {
     __device__ void operator()(int block) const { guess_runs_body(block, n_rec, qid, out, samples); }
 };
 
+// A speculative pass over reads whose geometry the context still holds (engine_ctx.hpp geom_id): the lengths against the copy the scan
+// that made it kept; any difference refutes the pass (kErrHint: raft_hip_finish runs it again the long way, which scans).  The repeat
+// counters are cleared on the way; `Beside`: as in scan_partials_kernel.
+constexpr int kVerifyReads = 1024;
+template <class Beside>
+__global__ __launch_bounds__(256) void verify_lengths_kernel(int32_t n_reads, const int32_t *len, const int32_t *seen, int32_t *rep_cnt, int32_t *err_flags,
+                                                             int n_blocks, Beside beside)
+{
+    if ((int)blockIdx.x >= n_blocks) { beside((int)blockIdx.x - n_blocks); return; }
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < kVerifyReads / 256; ++j) {
+        const long long i = (long long)blockIdx.x * kVerifyReads + j * 256 + threadIdx.x;
+        if (i < n_reads) { bad |= len[i] != seen[i]; rep_cnt[i] = 0; }
+    }
+    if (bad) atomicOr(err_flags, kErrHint);
+}
+
 // tile_first[k] = first read whose first window lies in tile k or later (tiles of Q windows).  For grouped input the same
 // threads -- one per read, coalesced -- check the caller's offsets: they must not step back and the runs must chain from
 // record 0 to record n_rec (kErrGroup; every later kernel of the pass then returns at once).

@@ -23,9 +23,11 @@ struct ReadPrepLoader {               // per read: windows, reserved repeat slot
     long long *err_index;
     FastDiv by_reso, by_mb1, by_L;    // reso, minbins + 1, L as divisors (three hardware divisions per read, one of them 64 bits wide,
                                       // twice per pass, were most of what the two scan kernels executed)
+    int32_t *seen;                    // the lengths as this scan saw them (engine_ctx.hpp len_seen)
     __device__ void operator()(long long i, long long (&v)[3]) const
     {
         int l = len[i];
+        seen[i] = l;
         if (l < 0) {
             atomicOr(err_flags, kErrLen);
             atomicMin((unsigned long long *)err_index, (unsigned long long)i);
@@ -189,7 +191,7 @@ void raft_hip_destroy(raft_hip_ctx *c)
     c->lane_up_ev.clear(); c->lane_down_ev.clear();
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
-    DevBuf *all[] = {&c->deep_list, &c->tail_buf, &c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->tile_first, &c->tile_cuts,
+    DevBuf *all[] = {&c->len_seen, &c->deep_list, &c->tail_buf, &c->wave_ctr, &c->ctrl, &c->scan_tmp, &c->cov_off, &c->rep_res_off, &c->tile_first, &c->tile_cuts,
                      &c->block_sums, &c->cov, &c->rep_cnt, &c->raw_key, &c->raw_s, &c->raw_e, &c->cut_cnt, &c->frag_cnt,
                      &c->rep_off, &c->cut_off, &c->frag_off, &c->rep_s, &c->rep_e, &c->cuts, &c->frag_read,
                      &c->frag_begin, &c->frag_end, &c->b_cnt, &c->b_off, &c->b_rid, &c->b_s, &c->b_e, &c->gs_rid, &c->gs_s, &c->gs_e, &c->gs_off, &c->gs_err, &c->rs_k0, &c->rs_k1, &c->rs_v0, &c->rs_v1, &c->gaps, &c->in_len,
@@ -449,7 +451,9 @@ int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool verify_in_k
     long long *scan_totals = nullptr;
     ReadPrepLoader prep_ld{d_len, c->prm.reso, c->minbins, c->prm.interval_length, kTileCap, kTileCap,
                            &ctrl->err_flags, &ctrl->err_index, make_fast_div(c->prm.reso),
-                           make_fast_div(c->minbins < INT32_MAX ? c->minbins + 1 : 1), make_fast_div(c->prm.interval_length)};
+                           make_fast_div(c->minbins < INT32_MAX ? c->minbins + 1 : 1), make_fast_div(c->prm.interval_length), nullptr};
+    HIP_TRY(c, c->len_seen.ensure((size_t)std::max(N, 1LL) * 4));
+    prep_ld.seen = c->len_seen.as<int32_t>();
     ScanOut<3> prep_so{{c->cov_off.as<long long>(), c->rep_res_off.as<long long>(), nullptr}};   // (marker capacities: only their sum is used, to size the cut points' array)
     // ---- A pass whose sizes the host knows before anything has run needs no wait on the way, and its head is THREE launches
     // (round 6): [geometry scan, first half | run guess] -> [geometry scan, second half + the per-read work of tile_first_kernel +
@@ -468,6 +472,9 @@ int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool verify_in_k
     const bool known = N > 0 && (speculate || (no_wait && getenv("RAFT_NO_FUSED_HEAD") == nullptr));
     c->speculated = speculate;
     if (speculate) c->sum.flags |= RAFT_HIP_SUM_SPECULATED;
+    // (the geometry of the remembered pass, if nobody has written it since: engine_ctx.hpp geom_id.  RAFT_NO_KEEP_GEOMETRY=1: scanned again)
+    const bool keep_geom = speculate && !grouped && c->geom_id != 0 && c->shape.geom_id == c->geom_id && getenv("RAFT_NO_KEEP_GEOMETRY") == nullptr;
+    if (!keep_geom) ++c->geom_id;
     if (!known) {
         hipStream_t gst = grouped ? st : c->side_stream;
         if (!grouped) {
@@ -595,12 +602,19 @@ int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool verify_in_k
         long long *partials = c->scan_tmp.as<long long>();
         scan_totals = partials + (long long)nb_scan * 3;
         GuessBeside gb{(long long)n_rec, d_qid, &ctrl->guess, c->samples.as<int32_t>()};
+        if (keep_geom) {
+            // ONE launch: the lengths against the ones the geometry was made from (kErrHint), the repeat counters cleared; the run guess beside it
+            const int vb = (int)((N + kVerifyReads - 1) / kVerifyReads);
+            hipLaunchKernelGGL((verify_lengths_kernel<GuessBeside>), dim3((unsigned)(vb + (guess_too ? kGuessBlocks : 0))), dim3(256), 0, st, n_reads, d_len,
+                               c->len_seen.as<int32_t>(), c->rep_cnt.as<int32_t>(), &ctrl->err_flags, vb, gb);
+        } else {
         hipLaunchKernelGGL((scan_partials_kernel<ReadPrepLoader, 3, GuessBeside>), dim3((unsigned)(nb_scan + (guess_too ? kGuessBlocks : 0))), dim3(kScanThreads), 0, st,
                            prep_ld, N, partials, nb_scan, gb);
         PrepPost pp{n_reads, qz, n_tiles, c->tile_first.as<int32_t>(), c->rep_cnt.as<int32_t>(), &ctrl->err_flags, &ctrl->err_index, grp, eff_runs,
                     (long long)n_rec, B, RU, CU};
         hipLaunchKernelGGL((scan_apply_kernel<ReadPrepLoader, 3, true, PrepPost>), dim3((unsigned)nb_scan), dim3(kScanThreads), 0, st, prep_ld, N, partials, scan_totals,
                            prep_so, pp);
+        }
     } else
     hipLaunchKernelGGL(tile_first_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, st, n_reads,
                        c->cov_off.as<long long>(), qz, n_tiles, c->tile_first.as<int32_t>(), &ctrl->err_flags, &ctrl->err_index, grp,
@@ -693,7 +707,7 @@ int run_pass(raft_hip_ctx *c, const raft_hip_ctx::PassArgs &in, bool verify_in_k
         c->shape.n_reads = n_reads; c->shape.n_rec = n_rec; c->shape.len = d_len; c->shape.qid = d_qid;
         c->shape.reso = c->prm.reso; c->shape.minbins = c->minbins; c->shape.interval_length = c->prm.interval_length;
         c->shape.symmetric_mode = c->prm.symmetric_mode; c->shape.tile_q = c->tile_q;
-        c->shape.B = B; c->shape.RU = RU; c->shape.CU = CU; c->shape.n_desc = n_desc;
+        c->shape.B = B; c->shape.RU = RU; c->shape.CU = CU; c->shape.n_desc = n_desc; c->shape.geom_id = c->geom_id;
         for (int i = 0; i < kMaxSeg; ++i) c->shape.desc[i] = i < n_desc ? desc[i] : 0;
     } else if (!speculate && !grouped) c->shape.valid = false;
     bool bwin = false;                                // the general bucketing hands the pileup kernel window records (below)

@@ -372,7 +372,13 @@ struct raft_hip_ctx {
         int n_desc = 0;
         long long desc[kMaxSeg] = {};
         bool had_deep = true;          // its tiles of 2^15 intervals or more (raft_hip_finish): none -> a speculative pass does not launch pileup_deep_kernel
+        unsigned long long geom_id = 0;   // which writing of the per-read geometry (cov_off, rep_res_off, tile_first, len_seen) that pass ran on
     } shape;
+    // The per-read geometry of a pass depends on the read lengths and the parameters alone.  A speculative pass over the same reads
+    // keeps what the context holds (geom_id says that nobody has written the arrays since) and only compares the lengths with the copy
+    // the scan left (len_seen): one kernel over 8 bytes per read where the scan's two halves ran over the reads twice.
+    DevBuf len_seen;
+    unsigned long long geom_id = 0;
     bool speculated = false;           // the pass in flight was built on `shape`
     bool deep_skipped = false;         // ... and without a launch of pileup_deep_kernel (a deep tile then refutes it: kErrDeep)
     hipStream_t clean_stream = nullptr;

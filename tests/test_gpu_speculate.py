@@ -60,7 +60,7 @@ def test_second_pass_over_the_same_buffers_speculates_and_equals_the_oracle():
     eng.close()
 
 
-@pytest.mark.parametrize("what", ["lengths", "run_ends", "unsorted", "bad_id"])
+@pytest.mark.parametrize("what", ["lengths", "same_windows", "run_ends", "unsorted", "bad_id"])
 def test_a_stream_that_is_not_what_was_assumed_is_run_the_long_way(what):
     """Same counts, same addresses, other contents: the device refutes the assumption (other window count; other run ends; no
     sorted runs at all; an id out of range) and the result -- or the error -- is what a fresh context gives."""
@@ -77,6 +77,11 @@ def test_a_stream_that_is_not_what_was_assumed_is_run_the_long_way(what):
     rl2, qid2, a2, b2 = rl.copy(), qid.copy(), a.copy(), b.copy()
     if what == "lengths":
         rl2 = rl + 50 * rng.integers(1, 4, rl.size).astype(np.int32)          # more windows per read, the records still fit
+    elif what == "same_windows":
+        # every read one base longer where that leaves its window count alone: the geometry the context holds would still be right for the
+        # pileup, the fragments' would not (chop.hpp:209-223) -- the lengths themselves are compared, not what was derived from them
+        rl2 = rl + ((rl % 50 > 0) & (rl % 50 < 49)).astype(np.int32)
+        assert (rl2 != rl).any() and np.array_equal((rl2 + 49) // 50, (rl + 49) // 50)
     elif what == "run_ends":
         h = qid.size // 2                                                     # the second run begins 1000 records later
         q = np.concatenate([np.sort(qid[:h + 1000]), np.sort(qid[h + 1000:])]).astype(np.int32)
@@ -170,4 +175,31 @@ def test_a_deep_pile_appears_in_a_stream_that_had_none():
         assert_same_result(_result(eng, s), want, f"deep pile, pass {it}")
     assert flags[0] & 8 and flags[0] & 4 and not (flags[0] & SPECULATED), flags         # re-run, deep tiles taken
     assert all(f & 4 and not (f & 8) for f in flags[1:]), flags
+    eng.close()
+
+
+def test_another_set_of_reads_in_between_does_not_leave_its_geometry_behind():
+    """A speculative pass keeps the per-read geometry the context holds when nobody has written it since the pass it is built on.  A
+    grouped pass over OTHER reads writes it: the next pass over the first set -- same buffers, same shape, speculative -- must not run
+    on the other set's window offsets."""
+    import torch
+    from raft_amd import engine, hostio
+    p = RaftParams(est_cov=8, symmetric_mode=1)
+    rl, (qid, a, b) = _set(11)
+    want = oracle_run(p, rl, qid, a, b, qid, a, b); want["symmetric"] = 1
+    dev = [torch.from_numpy(x).to("cuda:0") for x in (rl, qid, a, b)]
+    rl_o, (qid_o, a_o, b_o) = _set(12, n_reads=3000, n=40000, two_runs=False)      # as many reads, other lengths
+    want_o = oracle_run(p, rl_o, qid_o, a_o, b_o, qid_o, a_o, b_o); want_o["symmetric"] = 1
+    off_o = hostio.group_offsets(rl_o.size, qid_o)
+    eng = engine.Engine(p, device=0)
+    for it in range(3):
+        eng.run_device(*dev); s = eng.finish()
+    assert s.flags & SPECULATED
+    assert_same_result(_result(eng, s), want, "first set")
+    eng.run_host_grouped(rl_o, off_o, a_o, b_o); s = eng.finish()
+    assert_same_result(_result(eng, s), want_o, "the other set, grouped")
+    for it in range(2):
+        eng.run_device(*dev); s = eng.finish()
+        assert_same_result(_result(eng, s), want, f"first set again, pass {it}")
+    assert s.flags & SPECULATED
     eng.close()
