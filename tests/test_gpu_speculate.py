@@ -103,7 +103,9 @@ def test_a_stream_that_is_not_what_was_assumed_is_run_the_long_way(what):
         want = oracle_run(p, rl2, qid2, a2, b2, qid2, a2, b2); want["symmetric"] = 1
         eng.run_device(*dev)
         s = eng.finish()
-        assert not (s.flags & SPECULATED)
+        # (lengths that leave every window count alone refute the pass only where it kept the geometry it held: with
+        # RAFT_NO_KEEP_GEOMETRY=1 the scan runs over the new lengths and the pass stands)
+        assert what == "same_windows" or not (s.flags & SPECULATED)
         assert_same_result(_result(eng, s), want, what)
         # ... and the context is itself again afterwards
         eng.run_device(*dev); s = eng.finish()
