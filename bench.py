@@ -407,7 +407,10 @@ def main():
                     help="several GPUs: ONE set cut into --gpus contiguous read ranges, every rank handed the records of its reads (configs[3] without the exchange) as the headline")
     ap.add_argument("--weak", action="store_true", help="several GPUs: every rank an independent set of the workload's size as the headline (rounds 1-5's default)")
     ap.add_argument("--no-extra-legs", "--no-strong-leg", dest="no_extra_legs", action="store_true", help="several GPUs: only the headline form, no legs for the other two")
-    ap.add_argument("--presplit-windows", action="store_true", help="pre-split form: the slices travel as window records (4 bytes per record) instead of coordinate columns (8)")
+    ap.add_argument("--presplit-windows", action="store_true", help="(the default since round 6, kept for old command lines)")
+    ap.add_argument("--presplit-columns", action="store_true",
+                    help="pre-split form: the slices travel as the two coordinate columns (8 bytes per record) instead of window records (4): what reads "
+                         "of 65,535 windows or more get in any case")
     ap.add_argument("--watchdog-seconds", type=float, default=1500.0, help="several GPUs: a rank that has not finished by then exits non-zero (0 = off)")
     ap.add_argument("--shuffle", action="store_true", help="the records in random order (create_pileup's bucketing in full: the counting-sort path); never the headline")
     ap.add_argument("--nonsym", action="store_true", help="a non-symmetric PAF (one record per pair: target sides are piled up too, chop.hpp:165-169), shuffled; never the headline")
@@ -597,6 +600,8 @@ def main():
         e.close()
         return [s.n_fragments, s.n_repeats, s.total_coverage, s.total_repeat_length, s.n_bins]
 
+    nonlocal_form = ["coordinate columns (8 bytes per record)"]      # what the native exchange of the last pre-split run sent
+
     def strong_run(full, presplit, warmup, steps):
         """Times the strong-scaling step on this rank's share of `full`; returns (summary, elapsed, kernel s, pass s, records
         of the whole set, totals-equal-single-GPU or None)."""
@@ -616,12 +621,14 @@ def main():
                 off_sl = grouped_form(torch, hostio, full.n_reads, cols[0])                # (the tokeniser's by-product, like the columns)
                 my_bins = windows_of(my_len, p.reso)
                 bnp = bounds.numpy()
-                if args.presplit_windows:
-                    # the slices as window records (raft_host_pack_windows, the tokeniser's: one word per record): half the bytes over
-                    # xGMI; what arrives goes to raft_hip_run_device_windows (more than two runs arriving: unpacked on the device first)
+                # the slices as window records (raft_host_pack_windows, the tokeniser's: one word per record): half the bytes over xGMI
+                # -- at two ranks a step moves half the set over ONE link -- ; what arrives goes to raft_hip_run_device_windows (more than
+                # two runs arriving: unpacked on the device first).  Every rank decides the same way: the longest read of the whole set.
+                wv = None
+                if not args.presplit_columns and int(full.read_len.max()) < 65535 * p.reso:
                     wv = hostio.pack_windows(cols[1].cpu().numpy(), cols[2].cpu().numpy(), p.reso)
-                    if wv is None:
-                        raise SystemExit("bench.py: --presplit-windows needs reads below 65,535 windows")
+                nonlocal_form[0] = "window records (4 bytes per record)" if wv is not None else "coordinate columns (8 bytes per record)"
+                if wv is not None:
                     d_win = torch.as_tensor(wv.view("int32")).to(dev)
                     sl = engine.Slice(off_sl, d_win, None, device_offsets=True)
                 else:
@@ -974,7 +981,8 @@ def main():
                        "cut_points_total_rank0": s.n_cuts,
                        "sharding": (f"the ONE set of {o.n_reads} reads in {n_gpus} contiguous read ranges, "
                                     + ("records pre-split, one all-to-all-v per step" if args.presplit else "host-routed, no data-path collective") if strong_line
-                                    else f"reads x{n_gpus}, independent shards, no data-path collective") + (", ranks share GPUs (gloo check run)" if shared else "")},
+                                    else f"reads x{n_gpus}, independent shards, no data-path collective") + (", ranks share GPUs (gloo check run)" if shared else ""),
+                       **({"exchange_form": nonlocal_form[0]} if (strong_line and args.presplit and world > 1 and not shared) else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "pileup_wave_kernel",
                          "kernel_ms": pile * 1e3, "bytes_algorithmic": bytes_alg, "bytes_kernel": bytes_kernel,
